@@ -1,0 +1,202 @@
+"""Generate golden vectors by IMPORTING the reference's pure-PyTorch pieces.
+
+Run only in the build container (needs /root/reference, which never travels to the
+GPU box).  The outputs (*.npz next to this file) are committed; tests read only
+those.  Annotation-only third-party packages the reference imports but this image
+lacks (torchtyping, jaxtyping, nerfacc, wandb, tensorboard) are replaced IN
+PROCESS by empty stand-ins -- they carry type annotations / logging only and take
+no part in the arithmetic captured here.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Sub(torch.Tensor):
+        def __class_getitem__(cls, item):
+            return cls
+
+    class _CT:
+        AABB = 0
+        UN_BOUNDED_SPHERE = 1
+        UN_BOUNDED_TANH = 2
+
+    stub("torchtyping", TensorType=_Sub, patch_typeguard=lambda *a, **k: None)
+    stub("jaxtyping", Float=_Sub, Int=_Sub, Shaped=_Sub, Bool=_Sub)
+    stub("nerfacc", ContractionType=_CT)
+    stub("wandb")
+    stub("torch.utils.tensorboard", SummaryWriter=object)
+
+
+def gen_mlp(out):
+    """a8: gfnerf/mlp.py MLPNetwork fwd + grads for base_network and mlp_head shapes
+    (nerfacto_field.py:174-179, 217-227 with hidden_dim=128 from config.py:124-125)."""
+    from gfnerf.mlp import MLPNetwork
+
+    for tag, n_in, n_out, n_hidden, out_act, seed in (
+        ("base", 32, 16, 1, "None", 4),
+        ("head", 63, 3, 2, "Sigmoid", 5),
+    ):
+        torch.manual_seed(seed)
+        net = MLPNetwork(n_in, n_out, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": out_act,
+                                       "n_neurons": 128, "n_hidden_layers": n_hidden})
+        x = (torch.rand(257, n_in) * 2 - 1).requires_grad_(True)
+        y = net(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        out[f"mlp_{tag}_x"] = x.detach().numpy()
+        out[f"mlp_{tag}_y"] = y.detach().numpy()
+        out[f"mlp_{tag}_gy"] = gy.numpy()
+        out[f"mlp_{tag}_gx"] = x.grad.numpy()
+        for i, layer in enumerate(net.layers):
+            out[f"mlp_{tag}_W{i}"] = layer.weight.detach().numpy()
+            out[f"mlp_{tag}_b{i}"] = layer.bias.detach().numpy()
+            out[f"mlp_{tag}_gW{i}"] = layer.weight.grad.numpy()
+            out[f"mlp_{tag}_gb{i}"] = layer.bias.grad.numpy()
+
+
+def gen_composite(out):
+    """a12-a13: RaySamples.get_weights_f2nerf (rays.py:178-200) + RGB / Accumulation /
+    Depth('expected') renderers (renderers.py) on a dense [R,S] batch whose tails are
+    zero-padded exactly like PersSampler's dense output (PersSampler_cuda.cu:437-444)."""
+    from nerfstudio.cameras.rays import Frustums, RaySamples
+    from nerfstudio.model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+    torch.manual_seed(11)
+    R, S = 37, 24
+    counts = torch.randint(0, S + 1, (R,))
+    counts[0] = 0
+    counts[1] = S
+    valid = (torch.arange(S)[None, :] < counts[:, None]).float()[..., None]
+    sigma = torch.exp(torch.randn(R, S, 1) * 2.0) * valid
+    sigma[2, 3, 0] = float("inf")  # alpha = 1 there
+    sigma[3, 1, 0] = 1e30
+    delta = (torch.rand(R, S, 1) * 0.05 + 1e-3) * valid  # zero padding -> alpha 0
+    t = (torch.cumsum(torch.rand(R, S, 1) * 0.1 + 0.01, dim=1) + 0.3) * valid
+    rgb = torch.rand(R, S, 3)
+    rgb[4, 0, 1] = float("nan")  # hits nan_to_num only in eval mode
+    sigma.requires_grad_(True)
+    rgb_g = rgb.clone().requires_grad_(True)
+
+    fr = Frustums(origins=torch.zeros(R, S, 3), directions=torch.ones(R, S, 3), starts=t, ends=t,
+                  pixel_area=torch.ones(R, S, 1))
+    rs = RaySamples(frustums=fr, deltas=delta)
+    w, a, T = rs.get_weights_f2nerf(sigma)
+    ren = RGBRenderer(background_color="black")
+    ren.train()
+    rgb_train = ren(rgb=rgb_g, weights=w)
+    acc = AccumulationRenderer()(weights=w)
+    depth = DepthRenderer(method="expected")(weights=w, ray_samples=rs)
+    # gradient of a scalar through rgb (train mode) and accumulation; rows with NaN rgb are excluded
+    g_rgb = torch.randn(R, 3)
+    g_rgb[4] = 0.0
+    g_acc = torch.randn(R, 1)
+    (rgb_train * g_rgb).nansum().add((acc * g_acc).sum()).backward()
+    ren.eval()
+    with torch.no_grad():
+        rgb_eval = ren(rgb=rgb.clone(), weights=w.detach())
+
+    out["cmp_counts"] = counts.numpy()
+    out["cmp_sigma"] = sigma.detach().numpy()
+    out["cmp_delta"] = delta.numpy()
+    out["cmp_t"] = t.numpy()
+    out["cmp_rgb"] = rgb.numpy()
+    out["cmp_weights"] = w.detach().numpy()
+    out["cmp_alphas"] = a.detach().numpy()
+    out["cmp_trans"] = T.detach().numpy()
+    out["cmp_rgb_train"] = rgb_train.detach().numpy()
+    out["cmp_rgb_eval"] = rgb_eval.numpy()
+    out["cmp_acc"] = acc.detach().numpy()
+    out["cmp_depth"] = depth.detach().numpy()
+    out["cmp_g_rgb"] = g_rgb.numpy()
+    out["cmp_g_acc"] = g_acc.numpy()
+    out["cmp_d_sigma"] = sigma.grad.numpy()
+    out["cmp_d_rgb"] = rgb_g.grad.numpy()
+
+
+def gen_activations(out):
+    """a11: trunc_exp fwd/bwd (activations.py:24-42) incl. the +-15 clamp."""
+    from nerfstudio.field_components.activations import trunc_exp
+
+    x = torch.tensor([-20.0, -15.0, -3.0, 0.0, 1.0, 2.5, 15.0, 20.0, 30.0], requires_grad=True)
+    y = trunc_exp(x)
+    y.backward(torch.ones_like(y))
+    out["texp_x"] = x.detach().numpy()
+    out["texp_y"] = y.detach().numpy()
+    out["texp_gx"] = x.grad.numpy()
+
+
+def gen_sh(out):
+    """SH degree 4, nerfstudio convention (utils/math.py:27-87).  tcnn's own kernel is
+    third-party and absent; it differs from this by the sign of the odd-m terms."""
+    from nerfstudio.utils.math import components_from_spherical_harmonics
+
+    torch.manual_seed(3)
+    d = torch.randn(200, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    out["sh_dirs"] = d.numpy()
+    out["sh_ns"] = components_from_spherical_harmonics(levels=4, directions=d).numpy()
+
+
+def gen_losses(out):
+    """Charbonnier (losses.py:73-84) as called by GFNeRFModel.get_loss_dict (nerfacto.py:636)."""
+    from nerfstudio.model_components.losses import CharbonnierLoss
+
+    torch.manual_seed(6)
+    pred = torch.rand(64, 3, requires_grad=True)
+    gt = torch.rand(64, 3)
+    loss = CharbonnierLoss()(gt, pred)
+    loss.backward()
+    out["charb_pred"] = pred.detach().numpy()
+    out["charb_gt"] = gt.numpy()
+    out["charb_loss"] = np.array(loss.item(), np.float64)
+    out["charb_gpred"] = pred.grad.numpy()
+
+
+def gen_adam(out):
+    """torch.optim.Adam(lr=1e-2, eps=1e-15) -- the optimiser config.py:130 hands the table to."""
+    torch.manual_seed(8)
+    p = torch.randn(300, requires_grad=True)
+    opt = torch.optim.Adam([p], lr=1e-2, eps=1e-15)
+    out["adam_p0"] = p.detach().numpy().copy()
+    gs = []
+    for _ in range(3):
+        g = torch.randn(300) * torch.tensor(10.0).pow(torch.randint(-6, 1, (300,)).float())
+        gs.append(g.numpy())
+        p.grad = g.clone()
+        opt.step()
+    out["adam_g"] = np.stack(gs)
+    out["adam_p3"] = p.detach().numpy()
+
+
+def main():
+    assert os.path.isdir(REF), "reference tree not mounted; fixtures can only be regenerated in the build container"
+    _install_stubs()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(1)
+    out = {}
+    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam):
+        fn(out)
+    path = os.path.join(HERE, "reference_vectors.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""Pins the CPU oracle against vectors captured from the reference's importable
+PyTorch code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+
+def _dense_to_packed(counts, *arrays):
+    S = arrays[0].shape[1]
+    mask = np.arange(S)[None, :] < counts[:, None]
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return offsets, mask, [a[mask] for a in arrays]
+
+
+def test_f16_conversion_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2**32, size=200000, dtype=np.uint64).astype(np.uint32)
+    vals = bits.view(np.float32)
+    vals = np.concatenate([vals, np.float32([0, -0.0, 65504, 65519.99, 65520, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8,
+                                              6.1e-5, 6.0975552e-5, np.inf, -np.inf])])
+    vals = vals[~np.isnan(vals)]
+    lib = oracle.lib()
+    want = vals.astype(np.float16)
+    got = np.array([lib.gfn_o_f32_to_f16(float(v)) for v in vals[:20000]], np.uint16)
+    assert np.array_equal(got, want.view(np.uint16)[:20000])
+    tail = np.array([lib.gfn_o_f32_to_f16(float(v)) for v in vals[-13:]], np.uint16)
+    assert np.array_equal(tail, want.view(np.uint16)[-13:])
+    halfs = np.arange(0, 65536, dtype=np.uint16)
+    back = np.array([lib.gfn_o_f16_to_f32(int(h)) for h in halfs], np.float32)
+    ref = halfs.view(np.float16).astype(np.float32)
+    ok = np.isnan(ref) | (back == ref)
+    assert ok.all()
+
+
+def test_mlp_matches_reference(oracle, golden):
+    """a8 MLPNetwork (gfnerf/mlp.py:35-57): forward and all gradients."""
+    for tag, acts in (("base", ["relu", "none"]), ("head", ["relu", "relu", "sigmoid"])):
+        x = golden[f"mlp_{tag}_x"]
+        hs = [x]
+        for i, act in enumerate(acts):
+            hs.append(oracle.linear_fwd(hs[-1], golden[f"mlp_{tag}_W{i}"], golden[f"mlp_{tag}_b{i}"], act))
+        np.testing.assert_allclose(hs[-1], golden[f"mlp_{tag}_y"], rtol=1e-5, atol=1e-6)
+        g = golden[f"mlp_{tag}_gy"]
+        for i in reversed(range(len(acts))):
+            g, dW, db = oracle.linear_bwd(hs[i], golden[f"mlp_{tag}_W{i}"], hs[i + 1], g, acts[i])
+            np.testing.assert_allclose(dW, golden[f"mlp_{tag}_gW{i}"], rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(db, golden[f"mlp_{tag}_gb{i}"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(g, golden[f"mlp_{tag}_gx"], rtol=1e-4, atol=1e-6)
+
+
+def test_composite_matches_reference(oracle, golden):
+    """a12-a13 get_weights_f2nerf + renderers, dense zero-padded -> packed."""
+    counts = golden["cmp_counts"]
+    offsets, mask, (sigma, delta, t, rgb) = _dense_to_packed(
+        counts, golden["cmp_sigma"][..., 0], golden["cmp_delta"][..., 0], golden["cmp_t"][..., 0], golden["cmp_rgb"])
+    out = oracle.composite_fwd(offsets, sigma, delta, t, rgb)
+    np.testing.assert_allclose(out["weights"], golden["cmp_weights"][..., 0][mask], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["alphas"], golden["cmp_alphas"][..., 0][mask], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["trans"], golden["cmp_trans"][..., 0][mask], rtol=1e-5, atol=1e-7)
+    # padded samples of the dense reference carry zero weight, so packed == dense
+    assert np.all(golden["cmp_weights"][..., 0][~mask] == 0)
+    ref_rgb = golden["cmp_rgb_train"]
+    nanrow = np.isnan(ref_rgb).any(axis=1)
+    assert nanrow.sum() == 1  # the planted NaN colour propagates in train mode
+    np.testing.assert_allclose(out["rgb"][~nanrow], ref_rgb[~nanrow], rtol=1e-5, atol=1e-6)
+    assert np.isnan(out["rgb"][nanrow]).any()
+    np.testing.assert_allclose(out["acc"], golden["cmp_acc"][:, 0], rtol=1e-5, atol=1e-6)
+    depth = oracle.depth_finalize(out["depth_raw"], offsets, t, 1.0)
+    np.testing.assert_allclose(depth, golden["cmp_depth"][:, 0], rtol=1e-5, atol=1e-6)
+    # eval mode: nan_to_num(rgb) then clamp to [0,1]  (renderers.py:131-137)
+    out_e = oracle.composite_fwd(offsets, sigma, delta, t, np.nan_to_num(rgb))
+    np.testing.assert_allclose(np.clip(out_e["rgb"], 0, 1), golden["cmp_rgb_eval"], rtol=1e-5, atol=1e-6)
+
+
+def test_composite_backward_matches_reference(oracle, golden):
+    counts = golden["cmp_counts"]
+    offsets, mask, (sigma, delta, t, rgb) = _dense_to_packed(
+        counts, golden["cmp_sigma"][..., 0], golden["cmp_delta"][..., 0], golden["cmp_t"][..., 0], golden["cmp_rgb"])
+    d_sigma, d_rgb = oracle.composite_bwd(offsets, sigma, delta, np.nan_to_num(rgb), golden["cmp_g_rgb"],
+                                          golden["cmp_g_acc"][:, 0])
+    ref_ds = golden["cmp_d_sigma"][..., 0][mask]
+    ref_dr = golden["cmp_d_rgb"][mask]
+    finite = np.isfinite(ref_ds) & np.isfinite(sigma) & (sigma < 1e20)
+    # rays holding an inf / 1e30 density produce NaN/inf-tainted gradients in torch; compare the rest
+    ray_of = np.repeat(np.arange(len(counts)), counts)
+    bad_rays = np.unique(ray_of[~finite])
+    keep = ~np.isin(ray_of, bad_rays)
+    assert keep.sum() > 200
+    np.testing.assert_allclose(d_sigma[keep], ref_ds[keep], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(d_rgb[keep], ref_dr[keep], rtol=1e-5, atol=1e-7)
+
+
+def test_trunc_exp_matches_reference(oracle, golden):
+    """a11: sigma = trunc_exp(h0 + 1): feed h0 = x - 1."""
+    x = golden["texp_x"]
+    h = (x - 1.0).astype(np.float32)[:, None]
+    # x-1+1 is exact for these values
+    np.testing.assert_allclose(oracle.density_fwd(h), golden["texp_y"], rtol=2e-6)
+    np.testing.assert_allclose(oracle.density_bwd(h, np.ones(len(x), np.float32)), golden["texp_gx"], rtol=2e-6)
+
+
+def test_sh4_magnitudes_match_nerfstudio(oracle, golden):
+    d = golden["sh_dirs"]
+    ns = oracle.sh4(d, convention=1, round_f16=False)
+    np.testing.assert_allclose(ns, golden["sh_ns"], rtol=1e-5, atol=1e-6)
+    # tcnn convention (unpinned): same polynomials on 2*d01-1 with odd-m terms negated
+    tc = oracle.sh4((d + 1.0) / 2.0, convention=0, round_f16=False)
+    sign = np.ones(16, np.float32)
+    sign[[1, 3, 5, 7, 9, 11, 13, 15]] = -1
+    np.testing.assert_allclose(tc, golden["sh_ns"] * sign, rtol=1e-4, atol=2e-6)
+
+
+def test_charbonnier_and_adam(oracle, golden):
+    loss, g = oracle.charbonnier(golden["charb_pred"], golden["charb_gt"])
+    np.testing.assert_allclose(loss, golden["charb_loss"], rtol=1e-6)
+    np.testing.assert_allclose(g, golden["charb_gpred"], rtol=1e-4, atol=1e-7)
+    p = golden["adam_p0"].copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for s in range(3):
+        oracle.adam_step(p, golden["adam_g"][s], m, v, s + 1)
+    np.testing.assert_allclose(p, golden["adam_p3"], rtol=1e-6, atol=1e-7)
+
+
+def test_search_order_closed_form(oracle):
+    """PersSampler.cpp:138-151 LUT == bitrev3(k) ^ (~st & 7)."""
+    so = oracle.search_order()
+    br = [0, 4, 2, 6, 1, 5, 3, 7]
+    for st in range(8):
+        for k in range(8):
+            assert so[st, k] == br[k] ^ (~st & 7)
+        assert sorted(so[st]) == list(range(8))
