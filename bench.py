@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/s of the GF-NeRF hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--stage focal|global]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full training pass of the hot path over one batch of 4096 synthetic rays:
+PersSampler trace+march -> Hash3DAnchored (global + active focal table) -> base MLP -> density /
+SH / appearance head input -> head MLP -> compositing -> Charbonnier loss -> full backward ->
+Adam.  Workload (BASELINE.json configs[2]): "GF-NeRF global+focal, 4 sub-encoder blocks on 1 GPU,
+Rubble-scale synthetic cameras, 4096 rays x 192 samples".  With N > 1 (configs[3]) every rank
+owns one focal block and its own rays (weak scaling); the reference freezes the global table
+and the decoder in this stage, so there is no data-path collective; `--stage
+global` exercises the ray-data-parallel global stage with an RCCL all-reduce of the gradients.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_RAYS = 4096
+TARGET_SAMPLES = {"focal": 192, "global": 128}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--stage", choices=["focal", "global"], default="focal")
+    ap.add_argument("--n-side", type=int, default=20, help="cameras per side of the synthetic capture grid")
+    ap.add_argument("--log2-T", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
+    ap.add_argument("--cpu-rays", type=int, default=96, help="rays in the bounded cpu_baseline sample")
+    return ap.parse_args()
+
+
+def pick_fineness(hp, o, d, target, scene, torch):
+    """Bisect the ray-march fineness so the mean valid samples per ray hits the config's budget."""
+    lo, hi = 0.5, 64.0
+    R = o.shape[0]
+    best = None
+    for _ in range(14):
+        mid = (lo * hi) ** 0.5
+        noise = torch.from_numpy(scene.make_noise(R, True, mid, seed=1)).cuda()
+        s = hp.sample(o, d, noise)
+        mean = s["pts_offsets"][-1].item() / R
+        best = (mid, mean)
+        if abs(mean - target) / target < 0.005:
+            break
+        if mean > target:
+            lo = mid
+        else:
+            hi = mid
+    return best
+
+
+def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
+    """The oracle (a CPU port of the same path) on a bounded slice of the same batch, all host threads
+    for the OpenMP-parallel pieces.  fwd + bwd, no optimiser step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pipeline as opipe  # oracle: test infrastructure, used here only as the reported CPU baseline
+
+    o, d, cam, gt = (a[:n_rays] for a in batch)
+    noise = scene.make_noise(n_rays, True, fineness, seed=1)
+    t0 = time.perf_counter()
+    loss, grads, aux = opipe.loss_and_grads(P, o, d, cam, gt, noise, log2_T, block=block)
+    dt = time.perf_counter() - t0
+    n_samples = int(aux["samples"]["pts_offsets"][-1])
+    return dict(value=n_rays / dt, unit="rays/s", cores=os.cpu_count(), kind="port",
+                sample=f"{n_rays} rays ({n_samples} samples) of the same batch, oracle fwd+bwd (no Adam), {dt:.1f} s; "
+                       "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import gfnerf_amd
+    from gfnerf_amd import _lib, hotpath, scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    _lib.require_device()  # the HIP extension + a gfx950 device, or fail loudly
+
+    # ---- synthetic scene (untimed): cameras + octree from the host C++ builder, cached per box
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene")
+    t_build = time.perf_counter()
+    if rank == 0:
+        sc = scene.build_scene(n_side=args.n_side, max_depth=16, seed=1234, cache_dir=cache)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        sc = scene.build_scene(n_side=args.n_side, max_depth=16, seed=1234, cache_dir=cache)
+    t_build = time.perf_counter() - t_build
+    n_cams = sc["c2w"].shape[0]
+    n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
+    cfg = hotpath.HotPathConfig(log2_T=args.log2_T)
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks)
+    for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
+        g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
+        b.uniform_(-1e-3, 1e-3, generator=g)
+
+    # ---- batches resident in HBM before the timed region (4 rotated batches per rank)
+    batches_np, batches = [], []
+    for k in range(4):
+        o, d, cam = scene.make_rays(sc["c2w"], N_RAYS, seed=1000 * rank + k)
+        gt = np.random.default_rng(7 + k).random((N_RAYS, 3)).astype(np.float32)
+        batches_np.append((o, d, cam, gt))
+        batches.append(tuple(torch.from_numpy(a).cuda() for a in (o, d, cam, gt)))
+    target = TARGET_SAMPLES[args.stage]
+    fineness, mean_samples = pick_fineness(hp, batches[0][0], batches[0][1], target, scene, torch)
+    noises = [torch.from_numpy(scene.make_noise(N_RAYS, True, fineness, seed=k + 1)).cuda() for k in range(4)]
+
+    allreduce = None
+    if world > 1 and args.stage == "global":
+        def allreduce(grads):  # ray data parallelism: sum of per-rank mean losses -> average
+            for g in grads:
+                dist.all_reduce(g)
+                g.mul_(1.0 / world)
+
+    def step(i):
+        o, d, cam, gt = batches[i % 4]
+        block = (i % n_blocks) if args.stage == "focal" else None
+        return hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce)
+
+    for i in range(args.warmup):
+        step(i)
+    # dominant kernel: timed live with events on the launch stream (torch's current stream)
+    hp.timed_ops = {"*"} if args.stage_times else {"hash_bwd"}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, aux = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    n_live = aux["samples"]["pts_offsets"][-1].item()
+
+    if rank == 0 and args.stage_times:
+        tot = 0.0
+        for name, ev in hp.timings.items():
+            t = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+            tot += t
+            print(f"[stage] {name:16s} {t:8.3f} ms/step ({len(ev) // args.steps} launches)", file=sys.stderr)
+        print(f"[stage] {'sum':16s} {tot:8.3f} ms/step", file=sys.stderr)
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = N_RAYS * world * args.steps / elapsed
+        # roofline of the dominant kernel (hash table gradient scatter): algorithmic bytes =
+        # 16 levels x 8 corners x 2 ch x 4 B f32 atomic adds = 1024 B + 128 B grad + 16 B point/anchor per sample
+        ev = hp.timings.get("hash_bwd", [])
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+        alg_bytes = n_live * (16 * 8 * 2 * 4 + 128 + 16)
+        roofline = dict(bound="hbm", kernel="hash_bwd_kernel", achieved=(alg_bytes / (kern_ms * 1e-3) / 1e9) if kern_ms else None,
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms else None,
+                        traffic=None, avg_kernel_ms=kern_ms, alg_bytes_per_launch=alg_bytes)
+        out = dict(metric="train_rays_per_sec", value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   samples_per_sec=value * n_live / N_RAYS,
+                   config=dict(workload=("GF-NeRF global+focal train step, 4 focal blocks resident (1 active/step), "
+                                         if args.stage == "focal" and world == 1 else
+                                         "GF-NeRF focal stage, 1 block per GPU, " if args.stage == "focal" else
+                                         "GF-NeRF global stage train step (ray data parallel), ") +
+                                        f"4096 rays x {target} samples, Rubble-scale synthetic cameras",
+                               rays_per_batch=N_RAYS, mean_samples_per_ray=n_live / N_RAYS, log2_table_size=args.log2_T,
+                               n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
+                               fineness=fineness, stage=args.stage, early_T=cfg.early_T, mlp="f32 MFMA 32x32x2",
+                               parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
+                                            else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
+                               scene_build_s=round(t_build, 1), loss=float(loss.item())),
+                   roofline=roofline)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
+                                               0 if args.stage == "focal" else None, scene)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""ctypes binding of include/gfnerf_amd.h.  No fallback: if the shared library cannot be
+loaded (or built), every op raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgfnerf_amd.so")
+
+_vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
+SIGNATURES = {
+    "gfn_last_error": (C.c_char_p, []),
+    "gfn_version": (_i32, []),
+    "gfn_device_count": (_i32, []),
+    "gfn_hash_level_scales_host": (None, [_vp]),
+    "gfn_hash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
+    "gfn_trace": (_i32, [_vp, _vp, _i64, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gfn_march": (_i32, [_vp, _vp, _vp, _i64, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _i64, _vp, _vp]),
+    "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
+    "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_linear_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "gfn_linear_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
+                              _vp]),
+    "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),
+    "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gfn_composite_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_depth_finalize": (_i32, [_vp, _i64, _vp, _f32, _vp]),
+    "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp]),
+    "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
+    "gfn_octree_build_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _u64, _i32, C.POINTER(_vp),
+                                     C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),
+    "gfn_free_host": (None, [_vp]),
+}
+
+_lib = None
+
+
+class GfnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (building first if the .so is absent and hipcc exists) and return the CDLL."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own ROCm runtime; it must be the HIP runtime of this process (loading the
+    # system libamdhip64 first leaves torch with "No HIP GPUs are available"), so load torch first.
+    import torch  # noqa: F401
+
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build  # raises if hipcc is missing
+
+        _build.build_extension()
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:  # no fallback
+        raise GfnError(f"cannot load the HIP extension {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().gfn_last_error().decode("utf-8", "replace")
+        raise GfnError(f"{what} failed (status {rc}): {msg}")
+
+
+def require_device():
+    n = lib().gfn_device_count()
+    if n <= 0:
+        raise GfnError("no gfx950 (MI355X) device visible: the HIP path has no CPU fallback")
+    return n

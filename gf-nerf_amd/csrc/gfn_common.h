@@ -1,0 +1,56 @@
+// gfn_common.h -- shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gfnerf_amd.h"
+
+static_assert(sizeof(gfn_tree_node) == GFN_TREE_NODE_BYTES, "TreeNode ABI (PersSampler.h:39-48)");
+static_assert(sizeof(gfn_trans_info) == GFN_TRANS_INFO_BYTES, "TransInfo ABI (PersSampler.h:31-37)");
+static_assert(offsetof(gfn_tree_node, trans_idx) == 96, "TreeNode.trans_idx");
+static_assert(offsetof(gfn_trans_info, weight) == 384, "TransInfo.weight");
+static_assert(offsetof(gfn_trans_info, dis_summary) == 544, "TransInfo.dis_summary");
+
+// error plumbing (defined in runtime.hip)
+void gfn_set_error(const char* fmt, ...);
+#define GFN_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      gfn_set_error(__VA_ARGS__);     \
+      return GFN_ERR_ARG;             \
+    }                                 \
+  } while (0)
+#define GFN_CHECK_HIP(expr)                                                          \
+  do {                                                                               \
+    hipError_t e__ = (expr);                                                         \
+    if (e__ != hipSuccess) {                                                         \
+      gfn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return GFN_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+#define GFN_CHECK_LAUNCH() GFN_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// live element count: device value if given, else the host capacity.
+__device__ __forceinline__ int64_t gfn_live_n(int64_t n_max, const int32_t* n_dev) {
+  if (n_dev) {
+    int64_t n = (int64_t)(*n_dev);
+    return n < n_max ? n : n_max;
+  }
+  return n_max;
+}
+
+// f32 -> f16 -> f32 round trip, RNE (v_cvt_f16_f32 / v_cvt_f32_f16).  The empty asm pins x as
+// an f32 VGPR first: without it hipcc folds `(half)(a*b)` into v_fma_mixlo_f16, which rounds the
+// exact product ONCE, whereas the reference (mul.f32 then cvt.rn.f16.f32) rounds twice.
+__device__ __forceinline__ float gfn_round_f16(float x) {
+  asm volatile("" : "+v"(x));
+  return (float)(_Float16)x;
+}
+
+// Eigen 3.4 fixed-size reduction order (redux_novec_unroller halves the range);
+// see oracle/gfn_oracle.c.  Compiled with -ffp-contract=off.
+__device__ __forceinline__ float gfn_sum3(float a, float b, float c) { return a + (b + c); }
+__device__ __forceinline__ float gfn_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }

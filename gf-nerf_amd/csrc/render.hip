@@ -1,0 +1,410 @@
+// render.hip -- everything between the MLPs and the pixel: SH(4) view encoding,
+// head-input assembly + density activation, front-to-back compositing with early
+// termination (forward and backward), the Charbonnier loss and Adam.
+//
+// Replaces (reference file:line):
+//   tcnn SphericalHarmonics(4) call      gfnerf/nerfacto_field.py:152-158,519-521
+//   trunc_exp / concat glue              gfnerf/nerfacto_field.py:491-503,540-547
+//   RaySamples.get_weights_f2nerf        nerfstudio/cameras/rays.py:178-200
+//   RGB/Accumulation/Depth renderers     nerfstudio/model_components/renderers.py:97-98,216,279-281
+//   CharbonnierLoss                      nerfstudio/model_components/losses.py:73-84
+//   torch.optim.Adam (config.py:130)     one fused elementwise kernel
+#include <math.h>
+
+#include "gfn_common.h"
+
+namespace {
+
+// ---- SH degree 4, tiny-cuda-nn convention ---------------------------------
+__global__ void sh4_kernel(const float* __restrict__ dirs, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // get_normalized_directions (nerfacto_field.py:64-70) then tcnn maps [0,1] -> [-1,1]
+  float x = (dirs[3 * i] + 1.0f) * 0.5f, y = (dirs[3 * i + 1] + 1.0f) * 0.5f, z = (dirs[3 * i + 2] + 1.0f) * 0.5f;
+  x = x * 2.f - 1.f; y = y * 2.f - 1.f; z = z * 2.f - 1.f;
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  float o[16];
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.4886025119029199f * y;
+  o[2] = 0.4886025119029199f * z;
+  o[3] = -0.4886025119029199f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.9461746957575601f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.5462742152960396f * x2 - 0.5462742152960396f * y2;
+  o[9] = -0.5900435899266435f * y * (3.f * x2 - y2);
+  o[10] = 2.890611442640554f * xy * z;
+  o[11] = -0.4570457994644658f * y * (5.f * z2 - 1.f);
+  o[12] = 0.3731763325901154f * z * (5.f * z2 - 3.f);
+  o[13] = -0.4570457994644658f * x * (5.f * z2 - 1.f);
+  o[14] = 1.445305721320277f * z * (x2 - y2);
+  o[15] = -0.5900435899266435f * x * (x2 - 3.f * y2);
+#pragma unroll
+  for (int k = 0; k < 16; k++) out[16 * i + k] = gfn_round_f16(o[k]);  // tcnn emits __half
+}
+
+// ---- head input assembly: one wave per sample row (64 columns) -------------
+__global__ __launch_bounds__(256) void head_pack_kernel(
+    int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ h,
+    const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
+    const int* __restrict__ ray_id, float* __restrict__ sigma, float* __restrict__ xh) {
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  const int col = threadIdx.x & 63;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n; s += (int64_t)gridDim.x * 4) {
+    const int ray = ray_id[s];
+    float v;
+    if (col < 16) v = sh[(int64_t)ray * 16 + col];
+    else if (col < 31) v = h[s * 16 + (col - 15)];
+    else if (col < 63) v = emb ? emb[(int64_t)cam_idx[ray] * 32 + (col - 31)] : 0.f;
+    else v = 0.f;
+    xh[s * 64 + col] = v;
+    if (col == 0) sigma[s] = expf(h[s * 16] + 1.0f);  // trunc_exp(h0 + 1), nerfacto_field.py:499
+  }
+}
+
+// backward of head_pack, sample-parallel part: 16 lanes per sample write dh[s, 0:16]
+__global__ __launch_bounds__(256) void head_unpack_bwd_kernel(
+    int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ h,
+    const float* __restrict__ dsigma, const float* __restrict__ dxh, float* __restrict__ dh) {
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  const int c = threadIdx.x & 15;
+  for (int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); s < n; s += (int64_t)gridDim.x * 16) {
+    float v;
+    if (c == 0) {
+      float xx = h[s * 16] + 1.0f;
+      xx = fminf(fmaxf(xx, -15.f), 15.f);  // activations.py:41
+      v = dsigma[s] * expf(xx);
+    } else {
+      v = dxh[s * 64 + 15 + c];
+    }
+    dh[s * 16 + c] = v;
+  }
+}
+
+// embedding gradient: the 32 appearance channels are per-RAY constants, so reduce over the
+// ray's samples first (one wave per ray, half-waves take alternate samples) and issue one
+// 128-B atomic row per ray instead of one per sample.
+__global__ __launch_bounds__(256) void emb_grad_kernel(const int* __restrict__ pts_offsets, int n_rays,
+                                                       const float* __restrict__ dxh,
+                                                       const int* __restrict__ cam_idx,
+                                                       float* __restrict__ demb) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  const int c = lane & 31, hh = lane >> 5;
+  float acc = 0.f;
+  for (int i = s + hh; i < e; i += 2) acc += dxh[(int64_t)i * 64 + 31 + c];
+  acc += __shfl_xor(acc, 32, 64);
+  if (hh == 0 && e > s) atomicAdd(demb + (int64_t)cam_idx[ray] * 32 + c, acc);
+}
+
+// ---- compositing -------------------------------------------------------------
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (isnan(v)) return 0.f;
+  if (isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void tminmax_init_kernel(float* t_minmax) {
+  t_minmax[0] = INFINITY;
+  t_minmax[1] = 0.f;  // t >= 0 always (global_near = 0.01)
+}
+
+// one wave per ray; lanes sweep the ray's samples 64 at a time (front to back)
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const int* __restrict__ pts_offsets, int n_rays, const float* __restrict__ sigma,
+    const float* __restrict__ dt, const float* __restrict__ t, const float* __restrict__ rgb,
+    float early_T, float* __restrict__ weights, float* __restrict__ alphas,
+    float* __restrict__ out_rgb, float* __restrict__ out_acc, float* __restrict__ out_depth,
+    float* __restrict__ t_minmax) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  float carry = 0.f;  // sum of dt*sigma of all earlier chunks
+  float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
+  float tmin = INFINITY, tmax = 0.f;
+  bool dead = false;  // wave-uniform: transmittance already below early_T
+  for (int base = s; base < e; base += 64) {
+    const int i = base + lane;
+    const bool v = i < e;
+    const float ti = v ? t[i] : 0.f;
+    if (v) { tmin = fminf(tmin, ti); tmax = fmaxf(tmax, ti); }
+    if (dead) {
+      if (v) { if (weights) weights[i] = 0.f; if (alphas) alphas[i] = 1.f - expf(-(dt[i] * sigma[i])); }
+      continue;
+    }
+    const float ds = v ? dt[i] * sigma[i] : 0.f;
+    const float incl = wave_incl_scan(ds, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.f;
+    const float T = expf(-(carry + excl));
+    const float alpha = 1.f - expf(-ds);
+    float w = nan_to_num(alpha * T);
+    if (early_T > 0.f && T < early_T) w = 0.f;
+    if (v) {
+      if (weights) weights[i] = w;
+      if (alphas) alphas[i] = alpha;
+      cr += w * rgb[3 * i]; cg += w * rgb[3 * i + 1]; cb += w * rgb[3 * i + 2];
+      ca += w;
+      cd += w * ti;
+    }
+    carry += __shfl(incl, 63, 64);
+    if (early_T > 0.f && expf(-carry) < early_T) dead = true;
+  }
+  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); ca = wave_sum(ca); cd = wave_sum(cd);
+  if (t_minmax) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      tmin = fminf(tmin, __shfl_xor(tmin, off, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+    }
+    if (lane == 0) {
+      if (e - s < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
+      // non-negative floats order like their bit patterns
+      atomicMin(reinterpret_cast<unsigned*>(t_minmax), __float_as_uint(tmin));
+      atomicMax(reinterpret_cast<unsigned*>(t_minmax + 1), __float_as_uint(tmax));
+    }
+  }
+  if (lane == 0) {
+    out_rgb[3 * ray] = cr; out_rgb[3 * ray + 1] = cg; out_rgb[3 * ray + 2] = cb;
+    if (out_acc) out_acc[ray] = ca;
+    if (out_depth) out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
+  }
+}
+
+__global__ void depth_finalize_kernel(float* depth, int64_t n, const float* __restrict__ t_minmax, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float d = depth[i];
+  d = fminf(fmaxf(d, t_minmax[0]), t_minmax[1]);  // renderers.py:281 (batch-global clip)
+  depth[i] = d * (1.0f / scale);                  // nerfacto.py:546: tensor / python scalar = a * (1/b) on device
+}
+
+// d(rgb,acc)/d(sigma,rgb): w_i = alpha_i T_i;  dw_i/dsigma_i = dt_i T_{i+1};
+// dw_k/dsigma_i = -dt_i w_k (k>i).  One wave per ray, chunks walked BACK to front so
+// the suffix sum  sum_{k>i} G_k w_k  is built from later terms only (no cancellation).
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const int* __restrict__ pts_offsets, int n_rays, const float* __restrict__ sigma,
+    const float* __restrict__ dt, const float* __restrict__ rgb, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_acc, float early_T, float* __restrict__ d_sigma,
+    float* __restrict__ d_rgb) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  const int n_chunks = (e - s + 63) / 64;  // <= 16
+  // pass 1: carry-in of dt*sigma for every chunk (lane c keeps chunk c's carry)
+  float my_carry = 0.f;
+  {
+    float carry = 0.f;
+    for (int c = 0; c < n_chunks; c++) {
+      const int i = s + c * 64 + lane;
+      const float ds = (i < e) ? dt[i] * sigma[i] : 0.f;
+      if (lane == c) my_carry = carry;
+      carry += wave_sum(ds);
+    }
+  }
+  const float gr = g_rgb[3 * ray], gg = g_rgb[3 * ray + 1], gb = g_rgb[3 * ray + 2];
+  const float ga = g_acc ? g_acc[ray] : 0.f;
+  float suffix = 0.f;  // sum over later chunks of G_k w_k
+  for (int c = n_chunks - 1; c >= 0; c--) {
+    const int i = s + c * 64 + lane;
+    const bool v = i < e;
+    const float carry = __shfl(my_carry, c, 64);
+    const float ds = v ? dt[i] * sigma[i] : 0.f;
+    const float incl = wave_incl_scan(ds, lane);
+    const float T = expf(-(carry + (incl - ds)));
+    const float Tn = expf(-(carry + incl));
+    float w = (1.f - expf(-ds)) * T;
+    const bool cut = early_T > 0.f && T < early_T;
+    if (cut || !v) w = 0.f;
+    float G = 0.f;
+    if (v) G = gr * rgb[3 * i] + gg * rgb[3 * i + 1] + gb * rgb[3 * i + 2] + ga;
+    const float gw = G * w;
+    // reverse inclusive scan within the chunk: rs = sum_{k>=lane} gw_k
+    float rs = gw;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      float u = __shfl_down(rs, off, 64);
+      if (lane + off < 64) rs += u;
+    }
+    const float later = suffix + (rs - gw);
+    if (v) {
+      d_sigma[i] = cut ? 0.f : dt[i] * (G * Tn - later);
+      if (d_rgb) { d_rgb[3 * i] = w * gr; d_rgb[3 * i + 1] = w * gg; d_rgb[3 * i + 2] = w * gb; }
+    }
+    suffix += __shfl(rs, 0, 64);
+  }
+}
+
+// ---- loss -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ gt, int64_t n_elems,
+                                                          float inv_rows, float eps, float* loss,
+                                                          float* __restrict__ g_pred) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = pred[i] - gt[i];
+    const float q = sqrtf(d * d + eps * eps);
+    acc += q;
+    if (g_pred) g_pred[i] = d / q * inv_rows;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_rows);
+}
+
+// ---- Adam ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float one_m_b1, float beta2, float one_m_b2, float step_size,
+                                                   float bc2_sqrt, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * one_m_b1;
+    const float vi = v[i] * beta2 + (one_m_b2 * gi) * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfn_sh4(const float* dirs, int64_t n_rays, float* out, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(dirs && out && n_rays > 0, "gfn_sh4: bad arguments");
+  sh4_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, gfn_stream(stream)>>>(dirs, n_rays, out);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+static unsigned rows_grid(int64_t n_max, int rows_per_block) {
+  int64_t b = (n_max + rows_per_block - 1) / rows_per_block;
+  if (b > 256 * 64) b = 256 * 64;
+  return (unsigned)(b > 0 ? b : 1);
+}
+
+int gfn_head_pack(const float* h, const float* sh, const float* emb, const int32_t* cam_idx,
+                  const int32_t* ray_id, int64_t n_max, const int32_t* n_dev, float* sigma,
+                  float* xh, void* stream) {
+  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(h && sh && ray_id && sigma && xh, "gfn_head_pack: null pointer");
+  GFN_CHECK_ARG(!emb || cam_idx, "gfn_head_pack: emb given without cam_idx");
+  GFN_CHECK_ARG(n_max >= 0 && n_max < (1ll << 31) / 64, "gfn_head_pack: n_max=%lld", (long long)n_max);
+  if (n_max == 0) return GFN_OK;
+  head_pack_kernel<<<rows_grid(n_max, 4), 256, 0, gfn_stream(stream)>>>(n_max, n_dev, h, sh, emb, cam_idx, ray_id, sigma, xh);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_head_unpack_bwd(const float* h, const float* dsigma, const float* dxh,
+                        const int32_t* cam_idx, const int32_t* pts_offsets, int64_t n_rays,
+                        int64_t n_max, const int32_t* n_dev, float* dh, float* demb, void* stream) {
+  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(h && dsigma && dxh && dh, "gfn_head_unpack_bwd: null pointer");
+  GFN_CHECK_ARG(!demb || (cam_idx && pts_offsets), "gfn_head_unpack_bwd: demb given without cam_idx/pts_offsets");
+  GFN_CHECK_ARG(n_max >= 0 && n_max < (1ll << 31) / 64 && n_rays >= 0, "gfn_head_unpack_bwd: n_max=%lld", (long long)n_max);
+  if (n_max == 0) return GFN_OK;
+  hipStream_t st = gfn_stream(stream);
+  head_unpack_bwd_kernel<<<rows_grid(n_max, 16), 256, 0, st>>>(n_max, n_dev, h, dsigma, dxh, dh);
+  GFN_CHECK_LAUNCH();
+  if (demb && n_rays > 0) {
+    emb_grad_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, dxh, cam_idx, demb);
+    GFN_CHECK_LAUNCH();
+  }
+  return GFN_OK;
+}
+
+int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* sigma,
+                      const float* dt, const float* t, const float* rgb, float early_T,
+                      float* weights, float* alphas, float* out_rgb, float* out_acc,
+                      float* out_depth, float* t_minmax, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && out_rgb, "gfn_composite_fwd: null pointer");  // sample arrays may be null when every ray is empty
+  GFN_CHECK_ARG(n_rays >= 0 && n_rays < (1ll << 30), "gfn_composite_fwd: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return GFN_OK;
+  hipStream_t st = gfn_stream(stream);
+  if (t_minmax) {
+    tminmax_init_kernel<<<1, 1, 0, st>>>(t_minmax);
+    GFN_CHECK_LAUNCH();
+  }
+  composite_fwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, sigma, dt, t, rgb, early_T,
+                                                                    weights, alphas, out_rgb, out_acc, out_depth, t_minmax);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_depth_finalize(float* depth, int64_t n_rays, const float* t_minmax, float scale_factor, void* stream) {
+  GFN_CHECK_ARG(depth && t_minmax && n_rays >= 0 && scale_factor != 0.f, "gfn_depth_finalize: bad arguments");
+  if (n_rays == 0) return GFN_OK;
+  depth_finalize_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, gfn_stream(stream)>>>(depth, n_rays, t_minmax, scale_factor);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_composite_bwd(const int32_t* pts_offsets, int64_t n_rays, const float* sigma,
+                      const float* dt, const float* rgb, const float* g_rgb, const float* g_acc,
+                      float early_T, float* d_sigma, float* d_rgb, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && g_rgb, "gfn_composite_bwd: null pointer");
+  GFN_CHECK_ARG(n_rays >= 0 && n_rays < (1ll << 30), "gfn_composite_bwd: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return GFN_OK;
+  composite_bwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, gfn_stream(stream)>>>(pts_offsets, (int)n_rays, sigma, dt, rgb,
+                                                                                    g_rgb, g_acc, early_T, d_sigma, d_rgb);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps, float* loss_dev,
+                    float* g_pred, void* stream) {
+  if (rows == 0) return GFN_OK;
+  GFN_CHECK_ARG(pred && gt && rows > 0, "gfn_charbonnier: bad arguments");
+  const int64_t n = rows * 3;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  charbonnier_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(pred, gt, n, 1.0f / (float)rows, eps, loss_dev, g_pred);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                  float beta1, float beta2, float eps, void* stream) {
+  GFN_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "gfn_adam_step: bad arguments");
+  if (n == 0) return GFN_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  adam_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
+                                                               (float)(lr / bc1), (float)sqrt(bc2), eps);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_fill_zero(void* p, int64_t bytes, void* stream) {
+  GFN_CHECK_ARG(p && bytes >= 0, "gfn_fill_zero: bad arguments");
+  if (bytes == 0) return GFN_OK;
+  GFN_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)bytes, gfn_stream(stream)));
+  return GFN_OK;
+}
+
+}  // extern "C"

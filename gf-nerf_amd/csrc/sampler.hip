@@ -1,0 +1,557 @@
+// sampler.hip -- PersSampler on gfx950: octree traversal (K3), perspective-warp
+// ray march (K4), dense export, node statistics (K5/K6).
+//
+// Replaces gfnerf/bindings/PtsSampler/PersSampler_cuda.cu:21-318 (K3/K4),
+// :321-477 (GetSamples host logic: here count -> device scan -> fill with NO
+// host synchronisation and PACKED outputs) and :518-665 (UpdateOctNodes).
+//
+// Arithmetic order is kept identical to oracle/gfn_oracle.c (itself a
+// restatement of the .cu, Eigen reductions spelled as halving trees) and the
+// file is compiled with -ffp-contract=off, so leaf lists, sample counts and
+// every f32 produced here are bit-exact against the oracle.
+#include "gfn_common.h"
+
+namespace {
+
+constexpr int kRayBlock = 64;   // one wave per workgroup: 4096 rays -> 64 WGs spread over CUs
+constexpr int kMaxDepth = 24;   // MAX_STACK_SIZE 48 int64 = 24 (node, child_ptr) pairs (:7,:70)
+
+struct NodeView {
+  const uint8_t* base;
+  __device__ __forceinline__ float4 box(int u) const {  // center xyz + side_len (@0..15)
+    return *reinterpret_cast<const float4*>(base + (size_t)u * GFN_TREE_NODE_BYTES);
+  }
+  __device__ __forceinline__ int child(int u, int k) const {  // low word of int64 childs[k] (@24)
+    return *reinterpret_cast<const int*>(base + (size_t)u * GFN_TREE_NODE_BYTES + 24 + 8 * k);
+  }
+  __device__ __forceinline__ int trans_idx(int u) const {
+    return *reinterpret_cast<const int*>(base + (size_t)u * GFN_TREE_NODE_BYTES + 96);
+  }
+  __device__ __forceinline__ int block_idx(int u) const {
+    return *reinterpret_cast<const int*>(base + (size_t)u * GFN_TREE_NODE_BYTES + 104);
+  }
+};
+
+// PersSampler_cuda.cu:21-51
+__device__ __forceinline__ void get_intersection(const float o[3], const float d[3], float4 box,
+                                                 float& near, float& far) {
+  const float c[3] = {box.x, box.y, box.z};
+  const float hf = box.w * .5f;
+  float t0[3], t1[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (d[i] < 1e-6f && d[i] > -1e-6f) {
+      if (o[i] > c[i] - hf && o[i] < c[i] + hf) {
+        t0[i] = -1e6f; t1[i] = 1e6f;
+      } else {
+        t0[i] = 1e6f; t1[i] = -1e6f;
+      }
+    } else if (d[i] > 0) {
+      t0[i] = ((c[i] - hf) - o[i]) / d[i];
+      t1[i] = ((c[i] + hf) - o[i]) / d[i];
+    } else {
+      t0[i] = ((c[i] + hf) - o[i]) / d[i];
+      t1[i] = ((c[i] - hf) - o[i]) / d[i];
+    }
+  }
+  near = fmaxf(near, fmaxf(t0[0], fmaxf(t0[1], t0[2])));
+  far = fminf(far, fminf(t1[0], fminf(t1[1], t1[2])));
+}
+
+// child visit order: PersSampler.cpp:138-151 sorts 0..7 by a total order whose
+// closed form is bitrev3(k) ^ (~st & 7) (checked against the sort in tests).
+__device__ __forceinline__ int search_child(int ray_st, int k) {
+  const int br = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);
+  return br ^ (~ray_st & 7);
+}
+
+// K3: PersSampler_cuda.cu:53-152.  FILL=false counts, FILL=true writes.
+template <bool FILL>
+__global__ __launch_bounds__(kRayBlock) void trace_kernel(
+    int n_rays, NodeView nodes, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    float near_bound, float far_bound, int max_hits, int* __restrict__ counts,
+    const int* __restrict__ offsets, int* __restrict__ hit_idx, float2* __restrict__ hit_nf,
+    int64_t hit_cap, int* __restrict__ overflow) {
+  __shared__ int s_node[kMaxDepth][kRayBlock];
+  __shared__ signed char s_child[kMaxDepth][kRayBlock];
+  const int lane = threadIdx.x;
+  const int ray = blockIdx.x * kRayBlock + lane;
+  if (ray >= n_rays) return;
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  int max_cnt = max_hits;
+  int64_t out_base = 0;
+  if (FILL) {
+    out_base = offsets[ray];
+    int64_t end = offsets[ray + 1];
+    if (end > hit_cap) { end = hit_cap; if (overflow) atomicOr(overflow, 1); }
+    max_cnt = (int)(end > out_base ? end - out_base : 0);  // :76
+  }
+  const int ray_st = ((d[0] > 0.f) << 2) | ((d[1] > 0.f) << 1) | (d[2] > 0.f);  // :87
+  int sp = 0, cnt = 0;
+  s_node[0][lane] = 0;
+  s_child[0][lane] = -1;
+  while (sp >= 0 && cnt < max_cnt) {
+    const int u = s_node[sp][lane];
+    int child_ptr = s_child[sp][lane];
+    bool descend = true;
+    if (child_ptr == -1) {
+      float cur_near = near_bound, cur_far = far_bound;
+      get_intersection(o, d, nodes.box(u), cur_near, cur_far);
+      if (cur_near < cur_far) {
+        child_ptr = 0;
+        while (child_ptr < 8 && nodes.child(u, search_child(ray_st, child_ptr)) < 0) child_ptr++;
+        if (child_ptr >= 8) {  // leaf
+          if (nodes.trans_idx(u) >= 0) {  // :110
+            if (FILL) {
+              hit_idx[out_base + cnt] = u;
+              hit_nf[out_base + cnt] = make_float2(cur_near, cur_far);
+            }
+            cnt++;
+          }
+          descend = false;
+        }
+      } else {
+        descend = false;
+      }
+    } else {
+      child_ptr = child_ptr + 1;
+      while (child_ptr < 8 && nodes.child(u, search_child(ray_st, child_ptr)) < 0) child_ptr++;
+      if (child_ptr >= 8) descend = false;
+    }
+    if (descend) {
+      s_child[sp][lane] = (signed char)child_ptr;
+      if (sp + 1 < kMaxDepth) {
+        sp++;
+        s_node[sp][lane] = nodes.child(u, search_child(ray_st, child_ptr));
+        s_child[sp][lane] = -1;
+      } else if (overflow) {
+        atomicOr(overflow, 2);  // deeper than the reference's own 24-entry stack
+      }
+    } else {
+      sp--;
+    }
+  }
+  if (!FILL) counts[ray] = cnt;
+}
+
+// Exclusive scan of counts[n] -> offsets[n+1] in one workgroup (n is a ray count).
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int n,
+                                                    int* __restrict__ offsets) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int beg = tid * chunk;
+  const int end = min(beg + chunk, n);
+  int sum = 0;
+  for (int i = beg; i < end; i++) sum += counts[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    int v = (tid >= off) ? s_part[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;  // exclusive prefix of this chunk
+  for (int i = beg; i < end; i++) {
+    int c = counts[i];
+    offsets[i] = run;
+    run += c;
+  }
+  if (tid == 1023) offsets[n] = s_part[1023];
+}
+
+struct TransView {
+  const float* p;  // 144 floats: w2xz[12][2][4] @0, weight[3][12] @96, center @132, side @135, dis @136
+  __device__ __forceinline__ float w2xz(int i, int r, int c) const { return p[i * 8 + r * 4 + c]; }
+  __device__ __forceinline__ float weight(int r, int i) const { return p[96 + r * 12 + i]; }
+};
+
+__device__ __forceinline__ float sum12(const float* q) {
+  return (gfn_sum3(q[0], q[1], q[2]) + gfn_sum3(q[3], q[4], q[5])) +
+         (gfn_sum3(q[6], q[7], q[8]) + gfn_sum3(q[9], q[10], q[11]));
+}
+
+// PersSampler_cuda.cu:172-188 followed by `jac * rays_d` and its norm (:268-271)
+__device__ __forceinline__ float warp_jac_dir_norm(TransView tr, const float xyz[3], const float d[3]) {
+  float tj[GFN_N_PROS][3];
+#pragma unroll
+  for (int i = 0; i < GFN_N_PROS; i++) {
+    const float4 m0 = *reinterpret_cast<const float4*>(tr.p + i * 8);
+    const float4 m1 = *reinterpret_cast<const float4*>(tr.p + i * 8 + 4);
+    const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
+    const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
+    const float dv0 = 1.f / x1;
+    const float dv1 = -x0 / (x1 * x1);
+    tj[i][0] = dv0 * m0.x + dv1 * m1.x;
+    tj[i][1] = dv0 * m0.y + dv1 * m1.y;
+    tj[i][2] = dv0 * m0.z + dv1 * m1.z;
+  }
+  float pj[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float jr[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float q[GFN_N_PROS];
+#pragma unroll
+      for (int i = 0; i < GFN_N_PROS; i++) q[i] = tr.weight(r, i) * tj[i][c];
+      jr[c] = sum12(q);
+    }
+    pj[r] = gfn_sum3(jr[0] * d[0], jr[1] * d[1], jr[2] * d[2]);
+  }
+  return sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
+}
+
+// PersSampler_cuda.cu:155-170
+__device__ __forceinline__ void warp_point(TransView tr, const float xyz[3], float out[3]) {
+  float v[GFN_N_PROS];
+#pragma unroll
+  for (int i = 0; i < GFN_N_PROS; i++) {
+    const float4 m0 = *reinterpret_cast<const float4*>(tr.p + i * 8);
+    const float4 m1 = *reinterpret_cast<const float4*>(tr.p + i * 8 + 4);
+    const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
+    const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
+    v[i] = x0 / x1;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float q[GFN_N_PROS];
+#pragma unroll
+    for (int i = 0; i < GFN_N_PROS; i++) q[i] = tr.weight(r, i) * v[i];
+    out[r] = sum12(q);
+  }
+}
+
+// K4: PersSampler_cuda.cu:190-318.
+template <bool FILL>
+__global__ __launch_bounds__(kRayBlock) void march_kernel(
+    int n_rays, float sample_l, int scale_by_dis, int table_space, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ noise_all,
+    const int* __restrict__ oct_offsets, const int* __restrict__ hit_idx,
+    const float2* __restrict__ hit_nf, NodeView nodes, const float* __restrict__ transes,
+    int* __restrict__ counts, const int* __restrict__ pts_offsets, float* __restrict__ world_pts,
+    float* __restrict__ warped_pts, float* __restrict__ dirs, float* __restrict__ dists,
+    float* __restrict__ ts, int* __restrict__ anchors, int* __restrict__ ray_id,
+    float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow) {
+  const int ray = blockIdx.x * kRayBlock + threadIdx.x;
+  if (ray >= n_rays) return;
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  const float* noise = noise_all + ray;  // :204 sliding window over one shared array
+  const int oct_s = oct_offsets[ray];
+  const int n_oct = oct_offsets[ray + 1] - oct_s;
+  hit_idx += oct_s;
+  hit_nf += oct_s;
+  int max_n = GFN_MAX_SAMPLE_PER_RAY;
+  int64_t base = 0;
+  if (FILL) {
+    base = pts_offsets[ray];
+    int64_t end = pts_offsets[ray + 1];
+    if (end > pts_cap) { end = pts_cap; if (overflow) atomicOr(overflow, 4); }
+    max_n = (int)(end > base ? end - base : 0);
+    if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;  // :237
+    if (first_oct_dis) first_oct_dis[ray] = n_oct > 0 ? hit_nf[0].x : 1e9f;  // :229-234
+  }
+  int pts_ptr = 0;
+  if (max_n > 0 && n_oct > 0) {
+    int oct_ptr = 0;
+    int cur_oct_idx = hit_idx[0];
+    float cur_march_step = 0.f, exp_march_step = 0.f;
+    float2 nf = hit_nf[0];
+    float cur_t = nf.x;
+    float cur_far = nf.y;
+    float cur_near = nf.x;
+    float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
+    bool first = true;
+    while (pts_ptr < max_n && oct_ptr < n_oct) {
+      const int trans_idx = nodes.trans_idx(cur_oct_idx);
+      TransView tr{transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4)};
+      const float dx = o[0] - tr.p[132], dy = o[1] - tr.p[133], dz = o[2] - tr.p[134];
+      const float cur_radius = sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tr.p[136];  // :266
+      const float cur_radius_clip = fmaxf(cur_radius, 1.f);
+      const float pnorm = warp_jac_dir_norm(tr, xyz, d);
+      const float warp_step = sample_l * noise[pts_ptr];  // :270
+      exp_march_step = warp_step / (pnorm + 1e-6f);
+      if (scale_by_dis) exp_march_step *= cur_radius_clip;
+      cur_march_step = exp_march_step;
+      if (FILL && !first) {  // :278-290
+        const int64_t p = base + pts_ptr;
+        float w[3];
+        warp_point(tr, xyz, w);
+        if (table_space) {
+          // (sampled_pts + 1.5) / 3.0 (nerfacto_field.py:431).  On the device the reference runs on,
+          // torch divides a tensor by a Python scalar as a * (1/b) in f32
+          // (ATen/native/cuda/BinaryDivTrueKernel.cu, is_cpu_scalar branch) -- restated as such.
+          const float inv3 = 1.0f / 3.0f;
+          w[0] = (w[0] + 1.5f) * inv3; w[1] = (w[1] + 1.5f) * inv3; w[2] = (w[2] + 1.5f) * inv3;
+        }
+        if (world_pts) { world_pts[3 * p] = xyz[0]; world_pts[3 * p + 1] = xyz[1]; world_pts[3 * p + 2] = xyz[2]; }
+        if (dirs) { dirs[3 * p] = d[0]; dirs[3 * p + 1] = d[1]; dirs[3 * p + 2] = d[2]; }
+        warped_pts[3 * p] = w[0]; warped_pts[3 * p + 1] = w[1]; warped_pts[3 * p + 2] = w[2];
+        ts[p] = cur_t;
+        dists[p] = exp_march_step * (pnorm + 1e-6f);
+        anchors[3 * p] = trans_idx;
+        anchors[3 * p + 1] = cur_oct_idx;
+        anchors[3 * p + 2] = nodes.block_idx(cur_oct_idx);
+        if (ray_id) ray_id[p] = ray;
+      }
+      if (!first) pts_ptr += 1;
+      while (cur_t + cur_march_step > cur_far) {  // :295-305
+        oct_ptr++;
+        if (oct_ptr >= n_oct) break;
+        cur_oct_idx = hit_idx[oct_ptr];
+        nf = hit_nf[oct_ptr];
+        cur_near = nf.x;
+        cur_far = nf.y;
+        const int64_t ex = (int64_t)ceilf(fmaxf((cur_near - cur_t) / exp_march_step, 1.f));
+        cur_march_step = exp_march_step * (float)ex;
+      }
+      cur_t += cur_march_step;
+      xyz[0] = o[0] + d[0] * cur_t; xyz[1] = o[1] + d[1] * cur_t; xyz[2] = o[2] + d[2] * cur_t;
+      first = false;
+    }
+  }
+  if (!FILL) counts[ray] = pts_ptr;
+}
+
+__global__ void normalize_dirs_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+  const float nrm = sqrtf((x * x + y * y) + z * z);
+  out[3 * i] = x / nrm; out[3 * i + 1] = y / nrm; out[3 * i + 2] = z / nrm;
+}
+
+// packed -> dense [R,1024,.] zero-padded (PersSampler_cuda.cu:437-476).  One
+// workgroup per ray; every dense element is written (no separate zero fill).
+__global__ __launch_bounds__(256) void to_dense_kernel(
+    const int* __restrict__ pts_offsets, const float* __restrict__ world_pts,
+    const float* __restrict__ warped_pts, const float* __restrict__ dirs,
+    const float* __restrict__ dists, const float* __restrict__ ts, const int* __restrict__ anchors,
+    float* __restrict__ d_world, float* __restrict__ d_warped, float* __restrict__ d_dirs,
+    float* __restrict__ d_dists, float* __restrict__ d_ts, int64_t* __restrict__ d_anchors,
+    int64_t* __restrict__ d_se) {
+  const int ray = blockIdx.x;
+  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  const int n = min(e - s, GFN_MAX_SAMPLE_PER_RAY);
+  const int64_t dbase = (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY;
+  if (threadIdx.x == 0 && d_se) { d_se[2 * ray] = s; d_se[2 * ray + 1] = e; }  // :216-217,:312
+  for (int i = threadIdx.x; i < GFN_MAX_SAMPLE_PER_RAY * 3; i += blockDim.x) {
+    const bool v = (i / 3) < n;
+    const int64_t src = (int64_t)s * 3 + i;
+    if (d_world) d_world[dbase * 3 + i] = (v && world_pts) ? world_pts[src] : 0.f;
+    if (d_warped) d_warped[dbase * 3 + i] = v ? warped_pts[src] : 0.f;
+    if (d_dirs) d_dirs[dbase * 3 + i] = (v && dirs) ? dirs[src] : 0.f;
+    if (d_anchors) d_anchors[dbase * 3 + i] = v ? (int64_t)anchors[src] : 0;
+  }
+  for (int i = threadIdx.x; i < GFN_MAX_SAMPLE_PER_RAY; i += blockDim.x) {
+    const bool v = i < n;
+    if (d_dists) d_dists[dbase + i] = v ? dists[s + i] : 0.f;
+    if (d_ts) d_ts[dbase + i] = v ? ts[s + i] : 0.f;
+  }
+}
+
+// ---- UpdateOctNodes --------------------------------------------------------
+#define OCC_WEIGHT_BASE 512
+#define ABS_WEIGHT_THRES 0.01
+#define REL_WEIGHT_THRES 0.1
+#define OCC_ALPHA_BASE 32
+#define ABS_ALPHA_THRES 0.02
+#define REL_ALPHA_THRES 0.1
+
+__global__ void fill_i64_kernel(long long* p, long long v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// K5 MarkVistNodeKernel (:518-574) on packed samples.
+__global__ __launch_bounds__(kRayBlock) void mark_visit_kernel(
+    int n_rays, const int* __restrict__ pts_offsets, const int* __restrict__ anchors,
+    const float* __restrict__ weights, const float* __restrict__ alphas, long long* w_adder,
+    long long* a_adder, long long* mark, long long* visit_cnt) {
+  const int ray = blockIdx.x * kRayBlock + threadIdx.x;
+  if (ray >= n_rays) return;
+  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  if (s >= e) return;
+  float max_w = 0.f, max_a = 0.f;
+  for (int i = s; i < e; i++) { max_w = fmaxf(max_w, weights[i]); max_a = fmaxf(max_a, alphas[i]); }
+  const float w_thres = fminf((float)(max_w * REL_WEIGHT_THRES), (float)ABS_WEIGHT_THRES);  // :544 (double math)
+  const float a_thres = fminf((float)(max_a * REL_ALPHA_THRES), (float)ABS_ALPHA_THRES);
+  float cw = 0.f, ca = 0.f;
+  int cur = -1;
+  long long cnt = 0;
+  for (int i = s; i <= e; i++) {
+    const int oi = (i < e) ? anchors[3 * i + 1] : -2;
+    if (cur != oi) {
+      if (cur >= 0) {
+        atomicMax(w_adder + cur, (long long)(cw > w_thres ? OCC_WEIGHT_BASE : -1));
+        atomicMax(a_adder + cur, (long long)(ca > a_thres ? OCC_ALPHA_BASE : -1));
+        atomicMax(visit_cnt + cur, cnt);
+        mark[cur] = 1;
+      }
+      cur = oi; cw = 0.f; ca = 0.f; cnt = 0;
+    }
+    if (i < e) {
+      cw = fmaxf(cw, weights[i]);
+      ca = fmaxf(ca, alphas[i]);
+      cnt += 1;
+    }
+  }
+}
+
+// host-side torch ops of :641-655 + K6 MarkInvalidNodes (:576-582)
+__global__ void node_stats_kernel(int64_t n_nodes, const long long* __restrict__ w_adder,
+                                  const long long* __restrict__ a_adder,
+                                  const long long* __restrict__ mark, long long* weight_stats,
+                                  long long* alpha_stats, uint8_t* nodes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  auto upd = [](long long s, long long adder, long long mk) {
+    const long long occ = adder > 0;
+    const long long m = occ * adder;
+    s = s > m ? s : m;
+    s += mk * (1 - occ) * adder;
+    return s < -100 ? -100 : (s > (1 << 20) ? (long long)(1 << 20) : s);
+  };
+  const long long ws = upd(weight_stats[i], w_adder[i], mark[i]);
+  const long long as = upd(alpha_stats[i], a_adder[i], mark[i]);
+  weight_stats[i] = ws;
+  alpha_stats[i] = as;
+  if (ws < 0 || as < 0) *reinterpret_cast<long long*>(nodes + i * GFN_TREE_NODE_BYTES + 96) = -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfn_normalize_dirs(const float* rays_d_raw, float* rays_d, int64_t n_rays, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(rays_d_raw && rays_d && n_rays > 0, "gfn_normalize_dirs: bad arguments");
+  normalize_dirs_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, gfn_stream(stream)>>>(rays_d_raw, rays_d, n_rays);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_trace(const float* rays_o, const float* rays_d, int64_t n_rays, const void* nodes,
+              int64_t n_nodes, float near_bound, float far_bound, int max_hits,
+              int32_t* oct_offsets, int32_t* hit_idx, float* hit_near_far, int64_t hit_cap,
+              int32_t* overflow_dev, void* stream) {
+  GFN_CHECK_ARG(oct_offsets, "gfn_trace: null oct_offsets");
+  if (n_rays == 0) {
+    GFN_CHECK_HIP(hipMemsetAsync(oct_offsets, 0, sizeof(int32_t), gfn_stream(stream)));
+    return GFN_OK;
+  }
+  GFN_CHECK_ARG(rays_o && rays_d && nodes && hit_idx && hit_near_far, "gfn_trace: null pointer");
+  GFN_CHECK_ARG(n_rays >= 0 && n_rays < (1ll << 30) && n_nodes > 0 && n_nodes < (1ll << 31),
+                "gfn_trace: n_rays=%lld n_nodes=%lld out of range", (long long)n_rays, (long long)n_nodes);
+  GFN_CHECK_ARG(max_hits > 0 && max_hits <= GFN_MAX_OCT_PER_RAY, "gfn_trace: max_hits=%d not in (0,1024]", max_hits);
+  GFN_CHECK_ARG(hit_cap > 0 && hit_cap < (1ll << 31), "gfn_trace: hit_cap=%lld", (long long)hit_cap);
+  hipStream_t st = gfn_stream(stream);
+  if (n_rays == 0) {
+    GFN_CHECK_HIP(hipMemsetAsync(oct_offsets, 0, sizeof(int32_t), st));
+    return GFN_OK;
+  }
+  const unsigned grid = (unsigned)((n_rays + kRayBlock - 1) / kRayBlock);
+  NodeView nv{reinterpret_cast<const uint8_t*>(nodes)};
+  // per-ray counts are staged in hit_idx (unused until the fill pass); the scan consumes them first
+  GFN_CHECK_ARG(hit_cap >= n_rays, "gfn_trace: hit_cap (%lld) must be >= n_rays (%lld) (used as count scratch)",
+                (long long)hit_cap, (long long)n_rays);
+  int* counts = hit_idx;
+  trace_kernel<false><<<grid, kRayBlock, 0, st>>>((int)n_rays, nv, rays_o, rays_d, near_bound, far_bound, max_hits,
+                                                  counts, nullptr, nullptr, nullptr, hit_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(counts, (int)n_rays, oct_offsets);
+  GFN_CHECK_LAUNCH();
+  trace_kernel<true><<<grid, kRayBlock, 0, st>>>((int)n_rays, nv, rays_o, rays_d, near_bound, far_bound, max_hits,
+                                                 nullptr, oct_offsets, hit_idx,
+                                                 reinterpret_cast<float2*>(hit_near_far), hit_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+              float sample_l, int scale_by_dis, int table_space, const int32_t* oct_offsets,
+              const int32_t* hit_idx, const float* hit_near_far, const void* nodes, const void* transes,
+              int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+              float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+              int32_t* overflow_dev, void* stream) {
+  GFN_CHECK_ARG(pts_offsets, "gfn_march: null pts_offsets");
+  if (n_rays == 0) {
+    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), gfn_stream(stream)));
+    return GFN_OK;
+  }
+  GFN_CHECK_ARG(rays_o && rays_d && noise && oct_offsets && hit_idx && hit_near_far && nodes && transes,
+                "gfn_march: null input pointer");
+  GFN_CHECK_ARG(pts_offsets && warped_pts && dists && ts && anchors, "gfn_march: null output pointer");
+  GFN_CHECK_ARG(n_rays >= 0 && n_rays < (1ll << 30), "gfn_march: n_rays=%lld", (long long)n_rays);
+  GFN_CHECK_ARG(pts_cap >= n_rays && pts_cap * 3 < (1ll << 31), "gfn_march: pts_cap=%lld must be in [n_rays, 2^31/3)",
+                (long long)pts_cap);
+  hipStream_t st = gfn_stream(stream);
+  if (n_rays == 0) {
+    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
+    return GFN_OK;
+  }
+  const unsigned grid = (unsigned)((n_rays + kRayBlock - 1) / kRayBlock);
+  NodeView nv{reinterpret_cast<const uint8_t*>(nodes)};
+  int* counts = anchors;  // scratch until the fill pass (pts_cap >= n_rays checked above)
+  march_kernel<false><<<grid, kRayBlock, 0, st>>>(
+      (int)n_rays, sample_l, scale_by_dis, table_space, rays_o, rays_d, noise, oct_offsets, hit_idx,
+      reinterpret_cast<const float2*>(hit_near_far), nv, reinterpret_cast<const float*>(transes), counts, nullptr,
+      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(counts, (int)n_rays, pts_offsets);
+  GFN_CHECK_LAUNCH();
+  march_kernel<true><<<grid, kRayBlock, 0, st>>>(
+      (int)n_rays, sample_l, scale_by_dis, table_space, rays_o, rays_d, noise, oct_offsets, hit_idx,
+      reinterpret_cast<const float2*>(hit_near_far), nv, reinterpret_cast<const float*>(transes), nullptr,
+      pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float* world_pts,
+                         const float* warped_pts, const float* dirs, const float* dists,
+                         const float* ts, const int32_t* anchors, float* d_world, float* d_warped,
+                         float* d_dirs, float* d_dists, float* d_ts, int64_t* d_anchors,
+                         int64_t* d_pts_idx_start_end, void* stream) {
+  GFN_CHECK_ARG(pts_offsets && n_rays >= 0, "gfn_samples_to_dense: bad arguments");
+  GFN_CHECK_ARG((!d_warped || warped_pts) && (!d_dists || dists) && (!d_ts || ts) && (!d_anchors || anchors),
+                "gfn_samples_to_dense: dense output requested without its packed source");
+  if (n_rays == 0) return GFN_OK;
+  to_dense_kernel<<<(unsigned)n_rays, 256, 0, gfn_stream(stream)>>>(pts_offsets, world_pts, warped_pts, dirs, dists, ts,
+                                                                   anchors, d_world, d_warped, d_dirs, d_dists, d_ts,
+                                                                   d_anchors, d_pts_idx_start_end);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
+                     const float* weights, const float* alphas, int64_t n_nodes,
+                     int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
+                     int64_t* scratch, void* stream) {
+  GFN_CHECK_ARG(pts_offsets && anchors && weights && alphas && weight_stats && alpha_stats && visit_cnt && nodes && scratch,
+                "gfn_update_nodes: null pointer");
+  GFN_CHECK_ARG(n_rays >= 0 && n_nodes > 0, "gfn_update_nodes: bad sizes");
+  hipStream_t st = gfn_stream(stream);
+  long long* w_adder = reinterpret_cast<long long*>(scratch);
+  long long* a_adder = w_adder + n_nodes;
+  long long* mark = a_adder + n_nodes;
+  const unsigned gn = (unsigned)((n_nodes + 255) / 256);
+  fill_i64_kernel<<<(unsigned)((2 * n_nodes + 255) / 256), 256, 0, st>>>(w_adder, -1, 2 * n_nodes);  // :617-618
+  GFN_CHECK_LAUNCH();
+  GFN_CHECK_HIP(hipMemsetAsync(mark, 0, sizeof(long long) * n_nodes, st));
+  if (n_rays > 0) {
+    mark_visit_kernel<<<(unsigned)((n_rays + kRayBlock - 1) / kRayBlock), kRayBlock, 0, st>>>(
+        (int)n_rays, pts_offsets, anchors, weights, alphas, w_adder, a_adder, mark,
+        reinterpret_cast<long long*>(visit_cnt));
+    GFN_CHECK_LAUNCH();
+  }
+  node_stats_kernel<<<gn, 256, 0, st>>>(n_nodes, w_adder, a_adder, mark, reinterpret_cast<long long*>(weight_stats),
+                                        reinterpret_cast<long long*>(alpha_stats), reinterpret_cast<uint8_t*>(nodes));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+"""The per-ray hot path, end to end, on one MI355X.
+
+Mirrors the call order of GFNeRFModel.get_outputs (gfnerf/nerfacto.py:522-619):
+  PersSampler (trace + march)  ->  Hash3DAnchored (+ residual block table in the focal
+  stage, nerfacto_field.py:477-489)  ->  base_network  ->  trunc_exp density + SH/appearance
+  head input  ->  mlp_head  ->  get_weights_f2nerf + renderers,
+and for training the matching backward, the Charbonnier loss and Adam.  Every stage is a
+call through the C ABI into hand-written HIP kernels (ops.py); samples stay PACKED and the
+live sample count stays on the device (no host synchronisation inside a step).
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops, scene
+
+STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
+STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
+
+
+@dataclass
+class HotPathConfig:
+    log2_T: int = 21                 # config.py:119
+    hidden: int = 128                # config.py:124-125
+    sample_l: float = 1.0 / 256      # perssampler.py:64
+    scale_by_dis: bool = True        # perssampler.py:62
+    global_near: float = 0.01        # perssampler.py:61
+    max_oct_per_ray: int = 1024      # perssampler.py:60
+    max_samples_per_ray: int = 1024  # PersSampler_cuda.cu:9 (capacity of the packed buffers per ray)
+    early_T: float = 1e-4            # early-termination transmittance (0 = reference: none)
+    scale_factor: float = 10.0       # config.py:49
+    lr: float = 1e-2                 # config.py:130
+    lr_block: float = 5e-3           # nerfacto.py:448-488 (block tables)
+    adam_eps: float = 1e-15
+    use_appearance_embedding: bool = True  # config.py:50
+
+
+class HotPath:
+    def __init__(self, nodes, transes, n_cams, cfg=None, device="cuda:0", seed=0, n_blocks=0):
+        self.cfg = cfg or HotPathConfig()
+        self.dev = torch.device(device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
+        self.nodes = t(np.asarray(nodes).view(np.uint8).reshape(-1))
+        self.transes = t(np.asarray(transes).view(np.uint8).reshape(-1))
+        self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
+        self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
+        T = self.cfg.log2_T
+        self.prim = t(scene.make_primes(self.n_volumes, seed=seed + 2))
+        self.bias = torch.zeros((16 * self.n_volumes, 3), dtype=torch.float32, device=self.dev)
+        self.table = t(scene.make_feat_pool(T, seed=seed + 2))  # base_encoding_init (Reset: U(-1e-2,1e-2))
+        # residual block tables start at zero in the reference (nerfacto_field.py:345); tiny noise here
+        # would hide nothing in training but zeros would hide kernel bugs in tests -> caller may overwrite
+        self.blocks = [torch.zeros((16 * (1 << T), 2), dtype=torch.float32, device=self.dev) for _ in range(n_blocks)]
+        base, head = scene.make_mlps(seed=seed + 4, hidden=self.cfg.hidden)
+        shapes = [w.shape for w, _ in base + head]
+        sizes = [w.size + b.size for w, b in base + head]
+        self.mlp_flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.dev)
+        self.mlp_grad = torch.zeros_like(self.mlp_flat)
+        self.layers, self.layer_grads = [], []
+        off = 0
+        for (w, b), shp in zip(base + head, shapes):
+            W = self.mlp_flat[off:off + w.size].view(shp); gW = self.mlp_grad[off:off + w.size].view(shp)
+            off += w.size
+            B = self.mlp_flat[off:off + b.size]; gB = self.mlp_grad[off:off + b.size]
+            off += b.size
+            W.copy_(t(w)); B.copy_(t(b))
+            self.layers.append((W, B)); self.layer_grads.append((gW, gB))
+        rng = np.random.default_rng(seed + 5)
+        self.emb = t(rng.standard_normal((n_cams, 32)).astype(np.float32))  # nn.Embedding init N(0,1)
+        self.emb_grad = torch.zeros_like(self.emb)
+        self.table_grad = None
+        self._adam = {}
+        self.step = 0
+        self.weight_stats = torch.full((self.n_nodes,), 1000, dtype=torch.int64, device=self.dev)  # INIT_NODE_STAT
+        self.alpha_stats = torch.full((self.n_nodes,), 1000, dtype=torch.int64, device=self.dev)
+        self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)
+        self.timed_ops = set()  # stage names to bracket with events on the launch stream (bench.py)
+        self.timings = {}
+
+    def _timed(self, name, fn, *a, **k):
+        if name not in self.timed_ops and "*" not in self.timed_ops:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        self.timings.setdefault(name, []).append((e0, e1))
+        return r
+
+    def export_params(self):
+        """Host copies of every parameter / state blob (for checkpoints and for the test oracle)."""
+        c = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
+        return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[c(b) for b in self.blocks],
+                    prim=c(self.prim), bias=c(self.bias), layers=[(c(W), c(B)) for W, B in self.layers], emb=c(self.emb))
+
+    # ------------------------------------------------------------------ sampling
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False):
+        """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points."""
+        c = self.cfg
+        d = ops.normalize_dirs(rays_d_raw)
+        R = rays_o.shape[0]
+        off, hi, nf, ovf = self._timed("trace", ops.trace, rays_o, d, self.nodes, near=c.global_near, far=1e8,
+                                       max_hits=c.max_oct_per_ray)
+        s = self._timed("march", ops.march, rays_o, d, noise, c.sample_l, c.scale_by_dis, off, hi, nf, self.nodes,
+                        self.transes, pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world,
+                        want_dirs=need_world, table_space=True)
+        s["dirs_unit"] = d
+        s["n_dev"] = s["pts_offsets"][R:R + 1]
+        s["oct_offsets"] = off
+        return s
+
+    # -------------------------------------------------------------------- field
+    def _field_forward(self, s, cam_idx, block=None):
+        """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples."""
+        n_dev = s["n_dev"]
+        T, V = self.cfg.log2_T, self.n_volumes
+        feat = self._timed("hash_fwd", ops.hash_fwd, self.table, self.prim, self.bias, s["warped_pts"], s["anchors"], V, T,
+                           n_dev=n_dev)
+        if block is not None:  # hash_feats += residual_hash_feats (nerfacto_field.py:485-486)
+            self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.prim, self.bias, s["warped_pts"],
+                        s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
+        (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
+        a1 = self._timed("base_fwd", ops.linear_fwd, feat, bW0, bb0, "relu", n_dev=n_dev)
+        h = self._timed("base_fwd", ops.linear_fwd, a1, bW1, bb1, "none", n_dev=n_dev)
+        sh = ops.sh4(s["dirs_unit"])
+        emb = self.emb if self.cfg.use_appearance_embedding else None
+        sigma, xh = self._timed("head_pack", ops.head_pack, h, sh, emb, cam_idx, s["ray_id"], n_dev=n_dev)
+        c1 = self._timed("head_fwd", ops.linear_fwd, xh, hW0, hb0, "relu", n_dev=n_dev, in_dim=63)
+        c2 = self._timed("head_fwd", ops.linear_fwd, c1, hW1, hb1, "relu", n_dev=n_dev)
+        rgb = self._timed("head_fwd", ops.linear_fwd, c2, hW2, hb2, "sigmoid", n_dev=n_dev)
+        return dict(feat=feat, a1=a1, h=h, xh=xh, c1=c1, c2=c2, rgb=rgb, sigma=sigma)
+
+    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None):
+        """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566)."""
+        c = self.cfg
+        early = c.early_T if early_T is None else early_T
+        s = self.sample(rays_o, rays_d_raw, noise)
+        f = self._field_forward(s, cam_idx, block)
+        comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)
+        depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
+        rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)  # eval branch of RGBRenderer (renderers.py:131-137)
+        return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
+                    oct_depth=s["first_oct_dis"][:, None] / c.scale_factor, samples=s, field=f, weights=comp["weights"],
+                    alphas=comp["alphas"])
+
+    # ----------------------------------------------------------------- training
+    def _adam_state(self, name, p):
+        if name not in self._adam:
+            self._adam[name] = (torch.zeros_like(p), torch.zeros_like(p))
+        return self._adam[name]
+
+    def zero_grads(self, stage, block=None):
+        if self.table_grad is None:
+            self.table_grad = torch.zeros_like(self.table)
+        ops.fill_zero(self.table_grad)
+        if stage == STAGE_GLOBAL:
+            ops.fill_zero(self.mlp_grad)
+            ops.fill_zero(self.emb_grad)
+
+    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None):
+        """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux)."""
+        c = self.cfg
+        train_mlp = stage == STAGE_GLOBAL
+        self._timed("zero_grads", self.zero_grads, stage, block)
+        s = self.sample(rays_o, rays_d_raw, noise)
+        n_dev = s["n_dev"]
+        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None)
+        comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
+                           early_T=c.early_T)
+        loss, g_rgb = ops.charbonnier(comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        d_sigma, d_rgb = self._timed("composite_bwd", ops.composite_bwd, s["pts_offsets"], f["sigma"], s["dists"], f["rgb"],
+                                     g_rgb, None, early_T=c.early_T)
+        (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = self.layers
+        g = self.layer_grads
+        gw = lambda i: (g[i][0], g[i][1]) if train_mlp else (None, None)  # noqa: E731
+        dc2, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c2"], hW2, f["rgb"], d_rgb, "sigmoid", dW=gw(4)[0], db=gw(4)[1], need_dw=train_mlp, n_dev=n_dev)
+        dc1, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c1"], hW1, f["c2"], dc2, "relu", dW=gw(3)[0], db=gw(3)[1], need_dw=train_mlp, n_dev=n_dev)
+        dxh, _, _ = self._timed("head_bwd", ops.linear_bwd, f["xh"], hW0, f["c1"], dc1, "relu", dW=gw(2)[0], db=gw(2)[1], need_dw=train_mlp, n_dev=n_dev, in_dim=63)
+        demb = self.emb_grad if (train_mlp and c.use_appearance_embedding) else None
+        dh = ops.head_unpack_bwd(f["h"], d_sigma, dxh, cam_idx, s["pts_offsets"], demb=demb, n_dev=n_dev)
+        da1, _, _ = self._timed("base_bwd", ops.linear_bwd, f["a1"], bW1, f["h"], dh, "none", dW=gw(1)[0], db=gw(1)[1], need_dw=train_mlp, n_dev=n_dev)
+        dfeat, _, _ = self._timed("base_bwd", ops.linear_bwd, f["feat"], bW0, f["a1"], da1, "relu", dW=gw(0)[0], db=gw(0)[1], need_dw=train_mlp, n_dev=n_dev)
+        # both tables see the same d(feat) (sum of two lookups); only the trainable one is scattered
+        self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
+                    c.log2_T, grad_pool=self.table_grad, n_dev=n_dev)
+        return loss, dict(samples=s, field=f, comp=comp)
+
+    def optimizer_step(self, stage=STAGE_GLOBAL, block=None):
+        c = self.cfg
+        self.step += 1
+        if stage == STAGE_GLOBAL:
+            for name, p, gr in (("table", self.table, self.table_grad), ("mlp", self.mlp_flat, self.mlp_grad),
+                                ("emb", self.emb, self.emb_grad)):
+                if name == "emb" and not c.use_appearance_embedding:
+                    continue
+                m, v = self._adam_state(name, p)
+                self._timed("adam", ops.adam_step, p, gr, m, v, self.step, lr=c.lr, eps=c.adam_eps)
+        else:
+            p = self.blocks[block]
+            m, v = self._adam_state(f"block{block}", p)
+            self._timed("adam", ops.adam_step, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps)
+
+    def grads(self, stage=STAGE_GLOBAL):
+        """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
+        if stage == STAGE_GLOBAL:
+            out = [self.table_grad, self.mlp_grad]
+            if self.cfg.use_appearance_embedding:
+                out.append(self.emb_grad)
+            return out
+        return [self.table_grad]
+
+    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None):
+        """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
+        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block)
+        if allreduce is not None:
+            allreduce(self.grads(stage))
+        self.optimizer_step(stage, block)
+        return loss, aux
+
+    def update_oct_nodes(self, aux):
+        """persampler.update_oct_nodes (nerfacto.py:606-613) on the packed samples of the last step."""
+        s, comp = aux["samples"], aux["comp"]
+        ops.update_nodes(s["pts_offsets"], s["anchors"], comp["weights"], comp["alphas"], self.weight_stats,
+                         self.alpha_stats, self.visit_cnt, self.nodes)
+
+
+def fineness_at(step, init=16.0, decay_end=10000):
+    """PersSampler::UpdateRayMarch (PersSampler.cpp:958-967)."""
+    if step >= decay_end:
+        return 1.0
+    p = float(step) / float(decay_end)
+    return math.exp(math.log(1.0) * p + math.log(init) * (1.0 - p))

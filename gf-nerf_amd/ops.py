@@ -1,0 +1,364 @@
+"""Torch-tensor front-end of the C ABI (include/gfnerf_amd.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+function below validates its tensors, then passes raw device pointers, sizes and the
+stream handle to the hand-written HIP kernels.  There is no eager/PyTorch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_SAMPLE_PER_RAY = 1024
+MAX_OCT_PER_RAY = 1024
+TREE_NODE_BYTES = 128
+TRANS_INFO_BYTES = 576
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name, shape_last=None):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.GfnError(f"{name}: expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise _lib.GfnError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.GfnError(f"{name}: tensor must be contiguous")
+    if shape_last is not None and (t.dim() == 0 or t.shape[-1] != shape_last):
+        raise _lib.GfnError(f"{name}: last dimension must be {shape_last}, got {tuple(t.shape)}")
+
+
+def level_scales():
+    out = np.zeros(16, np.float32)
+    _lib.lib().gfn_hash_level_scales_host(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+# --------------------------------------------------------------------------- hash
+def _anchor_stride(anchors, n):
+    if anchors.dim() == 2 and anchors.shape == (n, 3):
+        return 3  # packed sampler anchors: column 0 is trans_idx
+    if anchors.numel() != n:
+        raise _lib.GfnError("anchors and pts disagree on n")
+    return 1
+
+
+def hash_fwd(feat_pool, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, out=None, n_dev=None, accumulate=False):
+    """Hash3DAnchored forward: pts [n,3] f32, anchors [n] i32|i64 (or packed [n,3] i32) -> [n,32] f32."""
+    _chk(feat_pool, torch.float32, "feat_pool"); _chk(prim_pool, torch.int32, "prim_pool")
+    _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
+    if anchors.dtype not in (torch.int32, torch.int64):
+        raise _lib.GfnError("anchors: expected int32 or int64")
+    _chk(anchors, anchors.dtype, "anchors")
+    n = pts.shape[0]
+    if feat_pool.numel() != 16 * (1 << log2_T) * 2:
+        raise _lib.GfnError(f"feat_pool has {feat_pool.numel()} elements, expected {16 * (1 << log2_T) * 2}")
+    if prim_pool.numel() != 16 * n_volumes * 3 or bias_pool.numel() != 16 * n_volumes * 3:
+        raise _lib.GfnError("prim_pool / bias_pool do not match n_volumes")
+    stride = _anchor_stride(anchors, n)
+    if out is None:
+        if accumulate:
+            raise _lib.GfnError("accumulate=True needs an existing out tensor")
+        out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
+    _chk(out, torch.float32, "out", 32)
+    rc = _lib.lib().gfn_hash_fwd(_ptr(feat_pool), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
+                                 int(anchors.dtype == torch.int64), stride, n, _ptr(n_dev), n_volumes, log2_T,
+                                 int(bool(accumulate)), _ptr(out), _stream())
+    _lib.check(rc, "gfn_hash_fwd")
+    return out
+
+
+def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, grad_pool=None, n_dev=None):
+    """Scatter grad_out [n,32] into grad_pool [16*T,2] (accumulating; allocated zeroed if None)."""
+    _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool")
+    _chk(pts, torch.float32, "pts", 3); _chk(grad_out, torch.float32, "grad_out", 32)
+    _chk(anchors, anchors.dtype, "anchors")
+    n = pts.shape[0]
+    if grad_out.shape[0] != n:
+        raise _lib.GfnError("grad_out / pts disagree on n")
+    stride = _anchor_stride(anchors, n)
+    if grad_pool is None:
+        grad_pool = torch.zeros((16 * (1 << log2_T), 2), dtype=torch.float32, device=pts.device)
+    _chk(grad_pool, torch.float32, "grad_pool")
+    if grad_pool.numel() != 16 * (1 << log2_T) * 2:
+        raise _lib.GfnError("grad_pool has the wrong size")
+    rc = _lib.lib().gfn_hash_bwd(_ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
+                                 int(anchors.dtype == torch.int64), stride, _ptr(grad_out), n, _ptr(n_dev), n_volumes,
+                                 log2_T, _ptr(grad_pool), _stream())
+    _lib.check(rc, "gfn_hash_bwd")
+    return grad_pool
+
+
+# ------------------------------------------------------------------------ sampler
+def normalize_dirs(rays_d):
+    _chk(rays_d, torch.float32, "rays_d", 3)
+    out = torch.empty_like(rays_d)
+    _lib.check(_lib.lib().gfn_normalize_dirs(_ptr(rays_d), _ptr(out), rays_d.shape[0], _stream()), "gfn_normalize_dirs")
+    return out
+
+
+def trace(rays_o, rays_d, nodes, near=0.01, far=1e8, max_hits=MAX_OCT_PER_RAY, hit_cap=None):
+    """K3.  nodes: uint8 blob [n_nodes*128].  -> (oct_offsets i32[R+1], hit_idx i32[cap], hit_nf f32[cap,2], overflow i32[1])"""
+    _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3)
+    _chk(nodes, torch.uint8, "nodes")
+    if nodes.numel() % TREE_NODE_BYTES:
+        raise _lib.GfnError("nodes blob is not a multiple of 128 bytes")
+    R = rays_o.shape[0]
+    if hit_cap is None:
+        hit_cap = max(R * max_hits, 1)
+    dev = rays_o.device
+    oct_offsets = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    hit_idx = torch.empty(hit_cap, dtype=torch.int32, device=dev)
+    hit_nf = torch.empty((hit_cap, 2), dtype=torch.float32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().gfn_trace(_ptr(rays_o), _ptr(rays_d), R, _ptr(nodes), nodes.numel() // TREE_NODE_BYTES, near, far,
+                              max_hits, _ptr(oct_offsets), _ptr(hit_idx), _ptr(hit_nf), hit_cap, _ptr(overflow),
+                              _stream())
+    _lib.check(rc, "gfn_trace")
+    return oct_offsets, hit_idx, hit_nf, overflow
+
+
+def march(rays_o, rays_d, noise, sample_l, scale_by_dis, oct_offsets, hit_idx, hit_nf, nodes, transes, pts_cap=None,
+          want_world=True, want_dirs=True, table_space=False):
+    """K4 -> dict of PACKED tensors (capacity pts_cap; live count = pts_offsets[-1] on device)."""
+    _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3)
+    _chk(noise, torch.float32, "noise"); _chk(oct_offsets, torch.int32, "oct_offsets")
+    _chk(hit_idx, torch.int32, "hit_idx"); _chk(hit_nf, torch.float32, "hit_nf", 2)
+    _chk(nodes, torch.uint8, "nodes"); _chk(transes, torch.uint8, "transes")
+    R = rays_o.shape[0]
+    if noise.numel() < MAX_SAMPLE_PER_RAY + R:
+        raise _lib.GfnError(f"noise needs at least {MAX_SAMPLE_PER_RAY + R} entries")
+    if transes.numel() % TRANS_INFO_BYTES:
+        raise _lib.GfnError("transes blob is not a multiple of 576 bytes")
+    if pts_cap is None:
+        pts_cap = max(R * MAX_SAMPLE_PER_RAY, 1)
+    dev = rays_o.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(
+        pts_offsets=torch.empty(R + 1, dtype=torch.int32, device=dev),
+        world_pts=f(pts_cap, 3) if want_world else None,
+        warped_pts=f(pts_cap, 3),
+        dirs=f(pts_cap, 3) if want_dirs else None,
+        dists=f(pts_cap), ts=f(pts_cap),
+        anchors=torch.empty((pts_cap, 3), dtype=torch.int32, device=dev),
+        ray_id=torch.empty(pts_cap, dtype=torch.int32, device=dev),
+        first_oct_dis=f(R),
+        overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+    )
+    rc = _lib.lib().gfn_march(_ptr(rays_o), _ptr(rays_d), _ptr(noise), R, float(sample_l), int(bool(scale_by_dis)),
+                              int(bool(table_space)), _ptr(oct_offsets), _ptr(hit_idx), _ptr(hit_nf), _ptr(nodes), _ptr(transes),
+                              _ptr(out["pts_offsets"]), _ptr(out["world_pts"]), _ptr(out["warped_pts"]),
+                              _ptr(out["dirs"]), _ptr(out["dists"]), _ptr(out["ts"]), _ptr(out["anchors"]),
+                              _ptr(out["ray_id"]), _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]),
+                              _stream())
+    _lib.check(rc, "gfn_march")
+    return out
+
+
+def samples_to_dense(s, n_rays):
+    """Packed sampler output -> the reference's dense GetSamples() list (PersSampler_cuda.cu:467-476)."""
+    dev = s["pts_offsets"].device
+    M = MAX_SAMPLE_PER_RAY
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+    d_world, d_warped, d_dirs = f(n_rays, M, 3), f(n_rays, M, 3), f(n_rays, M, 3)
+    d_dists, d_ts = f(n_rays, M), f(n_rays, M)
+    d_anchors = torch.empty((n_rays, M, 3), dtype=torch.int64, device=dev)
+    d_se = torch.empty((n_rays, 2), dtype=torch.int64, device=dev)
+    rc = _lib.lib().gfn_samples_to_dense(_ptr(s["pts_offsets"]), n_rays, _ptr(s["world_pts"]), _ptr(s["warped_pts"]),
+                                         _ptr(s["dirs"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(s["anchors"]),
+                                         _ptr(d_world), _ptr(d_warped), _ptr(d_dirs), _ptr(d_dists), _ptr(d_ts),
+                                         _ptr(d_anchors), _ptr(d_se), _stream())
+    _lib.check(rc, "gfn_samples_to_dense")
+    return [d_world, d_warped, d_dirs, d_dists, d_ts, d_anchors, d_se, s["first_oct_dis"].view(n_rays, 1)]
+
+
+def update_nodes(pts_offsets, anchors, weights, alphas, weight_stats, alpha_stats, visit_cnt, nodes):
+    _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(anchors, torch.int32, "anchors", 3)
+    _chk(weights, torch.float32, "weights"); _chk(alphas, torch.float32, "alphas")
+    for t, nm in ((weight_stats, "weight_stats"), (alpha_stats, "alpha_stats"), (visit_cnt, "visit_cnt")):
+        _chk(t, torch.int64, nm)
+    _chk(nodes, torch.uint8, "nodes")
+    n_nodes = nodes.numel() // TREE_NODE_BYTES
+    if weight_stats.numel() != n_nodes or alpha_stats.numel() != n_nodes or visit_cnt.numel() != n_nodes:
+        raise _lib.GfnError("stat tensors must have n_nodes entries")
+    scratch = torch.empty(3 * n_nodes, dtype=torch.int64, device=nodes.device)
+    rc = _lib.lib().gfn_update_nodes(_ptr(pts_offsets), pts_offsets.numel() - 1, _ptr(anchors), _ptr(weights),
+                                     _ptr(alphas), n_nodes, _ptr(weight_stats), _ptr(alpha_stats), _ptr(visit_cnt),
+                                     _ptr(nodes), _ptr(scratch), _stream())
+    _lib.check(rc, "gfn_update_nodes")
+
+
+# ---------------------------------------------------------------------------- MLP
+ACT = {"none": 0, "relu": 1, "sigmoid": 2}
+
+
+def linear_fwd(x, W, b, act="none", out=None, n_dev=None, in_dim=None):
+    """y = act(x[:, :in_dim] W^T + b).  x [n, ldx] f32, W [out,in] f32."""
+    _chk(x, torch.float32, "x"); _chk(W, torch.float32, "W"); _chk(b, torch.float32, "b")
+    n, ldx = x.shape
+    out_dim, w_in = W.shape
+    in_dim = w_in if in_dim is None else in_dim
+    if in_dim != w_in or in_dim > ldx:
+        raise _lib.GfnError(f"linear_fwd: W is {tuple(W.shape)} but x has {ldx} columns")
+    if out is None:
+        out = torch.empty((n, out_dim), dtype=torch.float32, device=x.device)
+    _chk(out, torch.float32, "out")
+    rc = _lib.lib().gfn_linear_fwd(_ptr(x), ldx, _ptr(W), _ptr(b), n, _ptr(n_dev), in_dim, out_dim, ACT[act], _ptr(out),
+                                   out.shape[1], _stream())
+    _lib.check(rc, "gfn_linear_fwd")
+    return out
+
+
+def linear_bwd(x, W, y, dy, act="none", need_dx=True, dW=None, db=None, dx=None, n_dev=None, need_dw=True, in_dim=None):
+    """-> (dx or None, dW, db); dW/db accumulate into the given tensors (allocated zeroed if None);
+    need_dw=False skips the weight/bias gradient (frozen MLPs of the focal stage)."""
+    for t, nm in ((x, "x"), (W, "W"), (y, "y"), (dy, "dy")):
+        _chk(t, torch.float32, nm)
+    n, ldx = x.shape
+    out_dim, w_in = W.shape
+    in_dim = w_in if in_dim is None else in_dim
+    if in_dim != w_in or in_dim > ldx:
+        raise _lib.GfnError(f"linear_bwd: W is {tuple(W.shape)} but x has {ldx} columns")
+    if need_dw and dW is None:
+        dW = torch.zeros_like(W)
+    if need_dw and db is None:
+        db = torch.zeros(out_dim, dtype=torch.float32, device=x.device)
+    if not need_dw:
+        dW = db = None
+    _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db")
+    if need_dx and dx is None:
+        dx = torch.empty((n, ldx), dtype=torch.float32, device=x.device)
+        if ldx > in_dim:
+            dx[:, in_dim:].zero_()
+    rc = _lib.lib().gfn_linear_bwd(_ptr(x), ldx, _ptr(W), _ptr(y), y.shape[1], _ptr(dy), dy.shape[1], n, _ptr(n_dev),
+                                   in_dim, out_dim, ACT[act], _ptr(dx) if need_dx else None,
+                                   dx.shape[1] if need_dx else 0, _ptr(dW), _ptr(db), _stream())
+    _lib.check(rc, "gfn_linear_bwd")
+    return (dx if need_dx else None), dW, db
+
+
+def sh4(dirs):
+    _chk(dirs, torch.float32, "dirs", 3)
+    out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)
+    _lib.check(_lib.lib().gfn_sh4(_ptr(dirs), dirs.shape[0], _ptr(out), _stream()), "gfn_sh4")
+    return out
+
+
+def head_pack(h, sh, emb, cam_idx, ray_id, n_dev=None):
+    _chk(h, torch.float32, "h", 16); _chk(sh, torch.float32, "sh", 16); _chk(emb, torch.float32, "emb", 32)
+    _chk(cam_idx, torch.int32, "cam_idx"); _chk(ray_id, torch.int32, "ray_id")
+    n = h.shape[0]
+    sigma = torch.empty(n, dtype=torch.float32, device=h.device)
+    xh = torch.empty((n, 64), dtype=torch.float32, device=h.device)
+    rc = _lib.lib().gfn_head_pack(_ptr(h), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(ray_id), n, _ptr(n_dev), _ptr(sigma),
+                                  _ptr(xh), _stream())
+    _lib.check(rc, "gfn_head_pack")
+    return sigma, xh
+
+
+def head_unpack_bwd(h, dsigma, dxh, cam_idx, pts_offsets, demb=None, n_dev=None):
+    _chk(h, torch.float32, "h", 16); _chk(dsigma, torch.float32, "dsigma"); _chk(dxh, torch.float32, "dxh", 64)
+    _chk(cam_idx, torch.int32, "cam_idx"); _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(demb, torch.float32, "demb", 32)
+    n = h.shape[0]
+    dh = torch.empty((n, 16), dtype=torch.float32, device=h.device)
+    rc = _lib.lib().gfn_head_unpack_bwd(_ptr(h), _ptr(dsigma), _ptr(dxh), _ptr(cam_idx), _ptr(pts_offsets),
+                                        pts_offsets.numel() - 1, n, _ptr(n_dev), _ptr(dh), _ptr(demb), _stream())
+    _lib.check(rc, "gfn_head_unpack_bwd")
+    return dh
+
+
+# --------------------------------------------------------------------- compositing
+def composite_fwd(pts_offsets, sigma, dt, t, rgb, early_T=0.0, want_weights=True):
+    _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(sigma, torch.float32, "sigma"); _chk(dt, torch.float32, "dt")
+    _chk(t, torch.float32, "t"); _chk(rgb, torch.float32, "rgb", 3)
+    R = pts_offsets.numel() - 1
+    dev = sigma.device
+    n = sigma.shape[0]
+    weights = torch.empty(n, dtype=torch.float32, device=dev) if want_weights else None
+    alphas = torch.empty(n, dtype=torch.float32, device=dev) if want_weights else None
+    out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    out_acc = torch.empty(R, dtype=torch.float32, device=dev)
+    out_depth = torch.empty(R, dtype=torch.float32, device=dev)
+    t_minmax = torch.empty(2, dtype=torch.float32, device=dev)
+    rc = _lib.lib().gfn_composite_fwd(_ptr(pts_offsets), R, _ptr(sigma), _ptr(dt), _ptr(t), _ptr(rgb), float(early_T),
+                                      _ptr(weights), _ptr(alphas), _ptr(out_rgb), _ptr(out_acc), _ptr(out_depth),
+                                      _ptr(t_minmax), _stream())
+    _lib.check(rc, "gfn_composite_fwd")
+    return dict(weights=weights, alphas=alphas, rgb=out_rgb, acc=out_acc, depth_raw=out_depth, t_minmax=t_minmax)
+
+
+def depth_finalize(depth_raw, t_minmax, scale_factor):
+    d = depth_raw.clone()
+    _lib.check(_lib.lib().gfn_depth_finalize(_ptr(d), d.numel(), _ptr(t_minmax), float(scale_factor), _stream()),
+               "gfn_depth_finalize")
+    return d
+
+
+def composite_bwd(pts_offsets, sigma, dt, rgb, g_rgb, g_acc=None, early_T=0.0):
+    _chk(g_rgb, torch.float32, "g_rgb", 3); _chk(g_acc, torch.float32, "g_acc")
+    R = pts_offsets.numel() - 1
+    n = sigma.shape[0]
+    d_sigma = torch.empty(n, dtype=torch.float32, device=sigma.device)
+    d_rgb = torch.empty((n, 3), dtype=torch.float32, device=sigma.device)
+    rc = _lib.lib().gfn_composite_bwd(_ptr(pts_offsets), R, _ptr(sigma), _ptr(dt), _ptr(rgb), _ptr(g_rgb), _ptr(g_acc),
+                                      float(early_T), _ptr(d_sigma), _ptr(d_rgb), _stream())
+    _lib.check(rc, "gfn_composite_bwd")
+    return d_sigma, d_rgb
+
+
+# ------------------------------------------------------------------ loss / optimiser
+def charbonnier(pred, gt, eps=1e-6):
+    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3)
+    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    g = torch.empty_like(pred)
+    _lib.check(_lib.lib().gfn_charbonnier(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(loss), _ptr(g), _stream()),
+               "gfn_charbonnier")
+    return loss, g
+
+
+def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, torch.float32, nm)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise _lib.GfnError("adam_step: size mismatch")
+    _lib.check(_lib.lib().gfn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), float(lr), float(beta1),
+                                        float(beta2), float(eps), _stream()), "gfn_adam_step")
+
+
+def fill_zero(t):
+    _lib.check(_lib.lib().gfn_fill_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "gfn_fill_zero")
+
+
+# ---------------------------------------------------------------- octree (host side)
+def octree_build(c2w, intri, bounds, max_depth=16, bbox_side_len=512.0, split_dist_thres=1.5, seed=1234, threads=0):
+    """Host C++ builder -> (nodes uint8 [n_nodes*128], transes uint8 [n_trans*576]) numpy blobs."""
+    c2w = np.ascontiguousarray(c2w, np.float32)
+    intri = np.ascontiguousarray(intri, np.float32)
+    bounds = np.ascontiguousarray(bounds, np.float32)
+    n = c2w.shape[0]
+    assert c2w.shape == (n, 3, 4) and intri.shape == (n, 3, 3) and bounds.shape == (n, 2)
+    np_, tp_ = C.c_void_p(), C.c_void_p()
+    nn, nt = C.c_int64(), C.c_int64()
+    L = _lib.lib()
+    rc = L.gfn_octree_build_host(c2w.ctypes.data_as(C.c_void_p), intri.ctypes.data_as(C.c_void_p),
+                                 bounds.ctypes.data_as(C.c_void_p), n, max_depth, bbox_side_len, split_dist_thres, seed,
+                                 threads, C.byref(np_), C.byref(nn), C.byref(tp_), C.byref(nt))
+    _lib.check(rc, "gfn_octree_build_host")
+    try:
+        nodes = np.ctypeslib.as_array(C.cast(np_, C.POINTER(C.c_uint8)), shape=(nn.value * TREE_NODE_BYTES,)).copy()
+        nt_b = max(nt.value, 1) * TRANS_INFO_BYTES
+        transes = np.ctypeslib.as_array(C.cast(tp_, C.POINTER(C.c_uint8)), shape=(nt_b,)).copy()
+    finally:
+        L.gfn_free_host(np_)
+        L.gfn_free_host(tp_)
+    return nodes, transes[: nt.value * TRANS_INFO_BYTES] if nt.value else transes[:0]

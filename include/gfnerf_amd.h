@@ -1,0 +1,230 @@
+/*
+ * gfnerf_amd.h -- C ABI of the MI355X-native GF-NeRF per-ray hot path.
+ *
+ * This is the drop-in boundary for the reference's native operator interface,
+ * the TorchScript custom classes registered in
+ *   gfnerf/bindings/hashanchored/bindings.cpp:343-399  (my_classes.Hash3DAnchored,
+ *   my_classes.PersSampler)
+ * plus the PyTorch ops the reference runs between them on the hot path
+ * (gfnerf/mlp.py, nerfstudio/cameras/rays.py:178-200, model_components/renderers.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the callee never allocates outputs, never synchronises and never throws:
+ *     it enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     0, or a negative gfn_status with the text in gfn_last_error();
+ *   - sample arrays are PACKED (CSR): ray r owns samples
+ *     [pts_offsets[r], pts_offsets[r+1]); the total N lives on the device in
+ *     pts_offsets[n_rays].  Kernels that consume packed samples take `n_max`
+ *     (host-known capacity, used for grid sizing) and `n_dev` (device pointer to
+ *     the live count, may be NULL when n_max is exact);
+ *   - dense [R,1024,.] views of the reference (PersSampler_cuda.cu:437-444) are
+ *     produced on request by gfn_samples_to_dense.
+ */
+#ifndef GFNERF_AMD_H
+#define GFNERF_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFN_N_LEVELS 16          /* Hash3DAnchored.h:18 */
+#define GFN_N_CHANNELS 2         /* Hash3DAnchored.h:17 */
+#define GFN_N_PROS 12            /* PersSampler.h:15 */
+#define GFN_MAX_SAMPLE_PER_RAY 1024   /* PersSampler_cuda.cu:9 */
+#define GFN_MAX_OCT_PER_RAY 1024      /* PersSampler_cuda.cu:8 */
+#define GFN_TREE_NODE_BYTES 128  /* sizeof(TreeNode),  PersSampler.h:39-48 */
+#define GFN_TRANS_INFO_BYTES 576 /* sizeof(TransInfo), PersSampler.h:31-37 */
+
+typedef enum {
+  GFN_OK = 0,
+  GFN_ERR_ARG = -1,      /* bad argument (null pointer, size, range) */
+  GFN_ERR_HIP = -2,      /* a HIP runtime call failed */
+  GFN_ERR_NO_DEVICE = -3 /* no gfx950 device visible */
+} gfn_status;
+
+const char* gfn_last_error(void);
+int gfn_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only host). */
+int gfn_device_count(void);
+
+/* ---------------------------------------------------------------------- *
+ * Checkpoint ABI structs (byte layouts of the blobs PersSampler::States()
+ * returns, PersSampler.cpp:969-979).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float center[3];
+  float side_len;
+  int64_t parent;
+  int64_t childs[8];
+  uint8_t is_leaf_node;
+  uint8_t pad0[7];
+  int64_t trans_idx;
+  int64_t block_idx;
+  uint8_t pad1[16];
+} gfn_tree_node; /* 128 B */
+
+typedef struct {
+  float w2xz[GFN_N_PROS][2][4];
+  float weight[3][GFN_N_PROS];
+  float center[3];
+  float side_len;
+  float dis_summary;
+  uint8_t pad[28];
+} gfn_trans_info; /* 576 B */
+
+/* ====================================================================== *
+ * Hash3DAnchored  (replaces my_classes.Hash3DAnchored.AnchoredQuery and its
+ * autograd backward: bindings.cpp:317-321; Hash3DAnchored_cuda.cu:160-239)
+ * ====================================================================== */
+/* scales[l] = 2^(7 l/15 + 3) (Hash3DAnchored_cuda.cu:28), host helper. */
+void gfn_hash_level_scales_host(float out_host[GFN_N_LEVELS]);
+
+/* feat_pool f32 [16*T*2] master table (States()[0]); prim_pool i32 [16,V,3];
+ * bias_pool f32 [16*V,3]; pts f32 [n,3] already in table space
+ * ((warped+1.5)/3, nerfacto_field.py:431); anchors i32 or i64, element i at
+ * anchors[i*anchor_stride] (stride 1 = the reference's [n] tensor, 3 = column 0 of
+ * the packed sampler's [n,3] anchors).  out f32 [n,32].  anchors_i64 != 0 selects
+ * the reference's int64 anchors.  accumulate != 0: out += features (the focal
+ * stage's residual table, nerfacto_field.py:485-486). */
+int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* bias_pool,
+                 const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
+                 int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
+                 int accumulate, float* out, void* stream);
+
+/* grad_out f32 [n,32] -> grad_pool f32 [16*T*2], ACCUMULATED (caller zeroes or
+ * calls gfn_fill_zero).  Quantisation of every contribution follows
+ * Hash3DAnchored_cuda.cu:147-151,219 (x128 -> f16, product -> f16); the sum is
+ * kept in f32 instead of f16 and the /128 (:238) is applied per contribution. */
+int gfn_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const float* pts,
+                 const void* anchors, int anchors_i64, int anchor_stride, const float* grad_out,
+                 int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
+                 float* grad_pool, void* stream);
+
+/* ====================================================================== *
+ * PersSampler  (replaces my_classes.PersSampler.GetSamples / UpdateOctNodes:
+ * bindings.cpp:37-63; PersSampler_cuda.cu:321-477, 584-665)
+ * ====================================================================== */
+/* rays_d_raw f32 [R,3] -> unit directions (PersSampler_cuda.cu:323). */
+int gfn_normalize_dirs(const float* rays_d_raw, float* rays_d, int64_t n_rays, void* stream);
+
+/* K3 (PersSampler_cuda.cu:53-152), both passes + device-side scan, no host sync.
+ * nodes: blob of gfn_tree_node[n_nodes].  oct_offsets i32 [R+1] (exclusive scan,
+ * ray order -> deterministic, unlike the reference's atomicAdd packing);
+ * hit_idx i32 [hit_cap], hit_near_far f32 [hit_cap,2].  hit_cap >= R*max_hits
+ * can never overflow; a smaller cap truncates and sets *overflow_dev != 0. */
+int gfn_trace(const float* rays_o, const float* rays_d, int64_t n_rays, const void* nodes,
+              int64_t n_nodes, float near_bound, float far_bound, int max_hits,
+              int32_t* oct_offsets, int32_t* hit_idx, float* hit_near_far, int64_t hit_cap,
+              int32_t* overflow_dev, void* stream);
+
+/* K4 (PersSampler_cuda.cu:190-318), count + scan + fill.  noise f32 [1024+R+10]
+ * (rays_noise, :380-389, already multiplied by the fineness).  Packed outputs of
+ * capacity pts_cap: world_pts/warped_pts/dirs f32 [.,3] (world_pts, dirs may be
+ * NULL), dists, ts f32 [.], anchors i32 [.,3] (trans_idx, oct_idx, block_idx),
+ * ray_id i32 [.] (may be NULL); pts_offsets i32 [R+1]; first_oct_dis f32 [R].
+ * table_space != 0 stores (warped + 1.5) / 3 (nerfacto_field.py:431) in warped_pts. */
+int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+              float sample_l, int scale_by_dis, int table_space, const int32_t* oct_offsets, const int32_t* hit_idx,
+              const float* hit_near_far, const void* nodes, const void* transes,
+              int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+              float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+              int32_t* overflow_dev, void* stream);
+
+/* Packed -> the reference's dense, zero-padded GetSamples() tensors
+ * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
+ * anchors i64 [R,1024,3], pts_idx_start_end i64 [R,2].  Any output may be NULL. */
+int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float* world_pts,
+                         const float* warped_pts, const float* dirs, const float* dists,
+                         const float* ts, const int32_t* anchors, float* d_world, float* d_warped,
+                         float* d_dirs, float* d_dists, float* d_ts, int64_t* d_anchors,
+                         int64_t* d_pts_idx_start_end, void* stream);
+
+/* K5 + stat update + K6 (PersSampler_cuda.cu:518-665) on packed samples.
+ * weight_stats/alpha_stats/visit_cnt i64 [n_nodes] and the node blob are updated
+ * in place; scratch i64 [3*n_nodes]. */
+int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
+                     const float* weights, const float* alphas, int64_t n_nodes,
+                     int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
+                     int64_t* scratch, void* stream);
+
+/* ====================================================================== *
+ * Field pieces (replace gfnerf/mlp.py MLPNetwork, the tcnn SH(4) encoding and
+ * the glue of GFNeRFField.get_density/get_outputs, nerfacto_field.py:412-591)
+ * ====================================================================== */
+/* y[n,out_dim] = act(x[n,in_dim(ld ldx)] W[out_dim,in_dim]^T + b); act 0 none,
+ * 1 ReLU, 2 Sigmoid.  f32 in / f32 accumulate on v_mfma_f32_32x32x2_f32. */
+int gfn_linear_fwd(const float* x, int ldx, const float* W, const float* b, int64_t n_max,
+                   const int32_t* n_dev, int in_dim, int out_dim, int act, float* y, int ldy,
+                   void* stream);
+/* dz = dy * act'(y);  dx[n,in_dim] = dz W (NULL to skip);  dW += dz^T x, db += sum dz
+ * (ACCUMULATED, f32 atomics across workgroups; caller zeroes). */
+int gfn_linear_bwd(const float* x, int ldx, const float* W, const float* y, int ldy,
+                   const float* dy, int lddy, int64_t n_max, const int32_t* n_dev, int in_dim,
+                   int out_dim, int act, float* dx, int lddx, float* dW, float* db, void* stream);
+
+/* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
+ * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
+ * default output.  dirs f32 [R,3] -> out f32 [R,16]. */
+int gfn_sh4(const float* dirs, int64_t n_rays, float* out, void* stream);
+
+/* Head input assembly + density activation (nerfacto_field.py:491-503,540-547):
+ *   sigma[i] = exp(h[i,0] + 1);  xh[i, 0:16] = sh[ray_id[i]];  xh[i,16:31] = h[i,1:16];
+ *   xh[i,31:63] = emb[cam_idx[ray_id[i]]] (zeros if emb == NULL);  xh[i,63] = 0.
+ * h f32 [n,16], xh f32 [n,64]. */
+int gfn_head_pack(const float* h, const float* sh, const float* emb, const int32_t* cam_idx,
+                  const int32_t* ray_id, int64_t n_max, const int32_t* n_dev, float* sigma,
+                  float* xh, void* stream);
+/* backward of gfn_head_pack: dh[i,0] = dsigma[i]*exp(clamp(h0+1,-15,15)) (trunc_exp,
+ * activations.py:24-42); dh[i,1:16] = dxh[i,16:31]; demb[cam[ray]] += sum over the ray's
+ * samples of dxh[i,31:63] (ACCUMULATED; demb may be NULL). */
+int gfn_head_unpack_bwd(const float* h, const float* dsigma, const float* dxh,
+                        const int32_t* cam_idx, const int32_t* pts_offsets, int64_t n_rays,
+                        int64_t n_max, const int32_t* n_dev, float* dh, float* demb, void* stream);
+
+/* ====================================================================== *
+ * Compositing  (replaces RaySamples.get_weights_f2nerf, rays.py:178-200, and
+ * RGB / Accumulation / Depth("expected") renderers, renderers.py:69-138,195-283)
+ * ====================================================================== */
+/* early_T > 0 stops a ray once its transmittance drops below early_T.
+ * weights/alphas f32 [n] may be NULL.  out_depth is the un-clipped expectation;
+ * t_minmax f32 [2] (may be NULL) receives the batch-global {min,max} of t incl.
+ * the reference's zero padding, for gfn_depth_finalize. */
+int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* sigma,
+                      const float* dt, const float* t, const float* rgb, float early_T,
+                      float* weights, float* alphas, float* out_rgb, float* out_acc,
+                      float* out_depth, float* t_minmax, void* stream);
+int gfn_depth_finalize(float* depth, int64_t n_rays, const float* t_minmax, float scale_factor,
+                       void* stream);
+int gfn_composite_bwd(const int32_t* pts_offsets, int64_t n_rays, const float* sigma,
+                      const float* dt, const float* rgb, const float* g_rgb, const float* g_acc,
+                      float early_T, float* d_sigma, float* d_rgb, void* stream);
+
+/* ====================================================================== *
+ * Loss + optimiser (nerfstudio losses.py:73-84,
+ * torch.optim.Adam as configured in gfnerf/config.py:130)
+ * ====================================================================== */
+/* loss_dev[0] += sum(sqrt((pred-gt)^2+eps^2))/rows; g_pred = d loss / d pred. */
+int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps, float* loss_dev,
+                    float* g_pred, void* stream);
+int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                  float beta1, float beta2, float eps, void* stream);
+int gfn_fill_zero(void* p, int64_t bytes, void* stream);
+
+/* ====================================================================== *
+ * Host-side octree construction (replaces PersOctree::PersOctree,
+ * PersSampler.cpp:92-152,516-831).  Pure host C++; returns malloc'd blobs the
+ * caller frees with gfn_free_host.
+ * ====================================================================== */
+int gfn_octree_build_host(const float* c2w_host /*[n_cams,3,4]*/, const float* intri_host /*[n_cams,3,3]*/,
+                          const float* bounds_host /*[n_cams,2]*/, int64_t n_cams, int max_depth,
+                          float bbox_side_len, float split_dist_thres, uint64_t seed, int threads,
+                          void** nodes_out_host, int64_t* n_nodes_out, void** trans_out_host,
+                          int64_t* n_trans_out);
+void gfn_free_host(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFNERF_AMD_H */

@@ -637,7 +637,9 @@ void gfn_o_depth_finalize(float* depth, const int64_t* offsets, int64_t n_rays, 
   for (int64_t r = 0; r < n_rays; r++) {
     float d = depth[r];
     d = d < tmin ? tmin : (d > tmax ? tmax : d); /* renderers.py:281 */
-    depth[r] = d / scale_factor;                 /* nerfacto.py:546 */
+    /* nerfacto.py:546 `depth / self.scale_factor`: on the device the reference runs on torch
+     * evaluates tensor / python-scalar as a * (1/b) in f32 (ATen BinaryDivTrueKernel.cu) */
+    depth[r] = d * (1.0f / scale_factor);
   }
 }
 
