@@ -119,6 +119,7 @@ def main():
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
         g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
         b.uniform_(-1e-3, 1e-3, generator=g)
+    hp.refresh_shadows()
 
     # ---- batches resident in HBM before the timed region (4 rotated batches per rank)
     batches_np, batches = [], []
@@ -173,11 +174,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = N_RAYS * world * args.steps / elapsed
-        # roofline of the dominant kernel (hash table gradient scatter): algorithmic bytes =
-        # 16 levels x 8 corners x 2 ch x 4 B f32 atomic adds = 1024 B + 128 B grad + 16 B point/anchor per sample
+        # roofline of the dominant kernel (hash table gradient scatter): algorithmic bytes per sample =
+        # 16 levels x 8 corners x 2 ch x 2 B packed-f16 atomic adds (512 B) + 128 B grad + 16 B point/anchor
         ev = hp.timings.get("hash_bwd", [])
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
-        alg_bytes = n_live * (16 * 8 * 2 * 4 + 128 + 16)
+        alg_bytes = n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)
         roofline = dict(bound="hbm", kernel="hash_bwd_kernel", achieved=(alg_bytes / (kern_ms * 1e-3) / 1e9) if kern_ms else None,
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms else None,
                         traffic=None, avg_kernel_ms=kern_ms, alg_bytes_per_launch=alg_bytes)

@@ -15,7 +15,9 @@ SIGNATURES = {
     "gfn_device_count": (_i32, []),
     "gfn_hash_level_scales_host": (None, [_vp]),
     "gfn_hash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),
+    "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
     "gfn_trace": (_i32, [_vp, _vp, _i64, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_march": (_i32, [_vp, _vp, _vp, _i64, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -33,6 +35,7 @@ SIGNATURES = {
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp]),
+    "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
     "gfn_octree_build_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _u64, _i32, C.POINTER(_vp),
                                      C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),

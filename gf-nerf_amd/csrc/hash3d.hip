@@ -2,11 +2,19 @@
 //
 // Replaces gfnerf/bindings/field/Hash3DAnchored_cuda.cu:11-155 (K1, K2) and the
 // host wrappers :160-239.  Differences that are design, not numerics:
-//   * the f32 master table is gathered directly and rounded to f16 in registers
+//   * lane = SAMPLE (64 consecutive samples of a ray per wave), levels walked in a
+//     loop: neighbouring samples share cells on the coarse levels, so their gathers
+//     collapse onto the same cache lines (the reference's thread = (point, level)
+//     grid, :17-18, gives every lane of a gather a different level region);
+//   * the table is gathered either from an f16 shadow kept current by the optimiser
+//     kernel or straight from the f32 master with the rounding done in registers
 //     (the reference converts the WHOLE pool to f16 on every call, :185);
-//   * gradients are accumulated in f32 (reference: f16 atomics, :151), each
-//     contribution quantised exactly as the reference does;
-//   * anchors may be int32 (packed sampler output) or int64 (reference ABI).
+//   * the focal stage's two lookups (global + residual block table,
+//     nerfacto_field.py:477-486) share one pass over the samples;
+//   * gradients: per-level run-length reduction across the wave (consecutive samples
+//     in one cell) before the atomics; accumulation either in f32 or, like the
+//     reference (:151), in packed f16 with the x128 loss scale (:209) kept in the
+//     buffer.
 // The level-overlap addressing quirk (:37 + :74: level base l*T elements, slot
 // address pos*2+k) is kept bit-for-bit so reference checkpoints stay loadable.
 #include <math.h>
@@ -14,6 +22,8 @@
 #include "gfn_common.h"
 
 namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 struct LevelScales {
   float s[GFN_N_LEVELS];
@@ -29,12 +39,15 @@ __device__ __forceinline__ uint32_t sat_u32(float f) {
   return f <= 0.f ? 0u : (f >= 4294967040.f ? 0xffffffffu : (uint32_t)f);
 }
 
-__device__ __forceinline__ void hash_corners(float px, float py, float pz, float scale, const int* prim,
-                                             const float* bias, uint32_t mask, Corners& c) {
+// :27-69.  Returns the integer cell (ux,uy,uz) through `cell` for run detection.
+__device__ __forceinline__ void hash_corners(float px, float py, float pz, float scale, const int* __restrict__ prim,
+                                             const float* __restrict__ bias, uint32_t mask, Corners& c,
+                                             uint32_t cell[3]) {
   px = px * scale; py = py * scale; pz = pz * scale;  // :29
-  px = px + bias[0]; py = py + bias[1]; pz = pz + bias[2];  // :41
+  if (bias) { px = px + bias[0]; py = py + bias[1]; pz = pz + bias[2]; }  // :41 (null = all-zero bias pool)
   const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
   const uint32_t ux = sat_u32(fx), uy = sat_u32(fy), uz = sat_u32(fz);
+  cell[0] = ux; cell[1] = uy; cell[2] = uz;
   const uint32_t pa = (uint32_t)prim[0], pb = (uint32_t)prim[1], pc = (uint32_t)prim[2];
   const uint32_t x0 = ux * pa, x1 = (ux + 1u) * pa;
   const uint32_t y0 = uy * pb, y1 = (uy + 1u) * pb;
@@ -60,94 +73,219 @@ __device__ __forceinline__ void hash_corners(float px, float py, float pz, float
   c.w[7] = (a * b) * cc;
 }
 
-template <typename AnchorT>
+// one level of one table: 8 gathers, trilinear blend in f32, result rounded to f16 (:71-78,:195)
+template <bool F16>
+__device__ __forceinline__ float2 gather_level(const void* __restrict__ table, int64_t level_base, const Corners& c) {
+  float2 f[8];
+  if (F16) {
+    const half2_t* base = reinterpret_cast<const half2_t*>(reinterpret_cast<const _Float16*>(table) + level_base);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const half2_t v = base[c.pos[d]];
+      f[d] = make_float2((float)v[0], (float)v[1]);
+    }
+  } else {
+    const float2* base = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(table) + level_base);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const float2 v = base[c.pos[d]];
+      f[d] = make_float2(gfn_round_f16(v.x), gfn_round_f16(v.y));  // :185 pool.to(f16)
+    }
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const float t0 = c.w[d] * f[d].x, t1 = c.w[d] * f[d].y;  // :74-77, left-to-right sum
+    a0 = (d == 0) ? t0 : a0 + t0;
+    a1 = (d == 0) ? t1 : a1 + t1;
+  }
+  return make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
+}
+
+template <typename AnchorT, bool F16, bool DUAL>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, int64_t n_volumes, int log2_T, LevelScales sc,
-    const float* __restrict__ feat_pool, const int* __restrict__ prim_pool,
-    const float* __restrict__ bias_pool, const float* __restrict__ pts,
-    const AnchorT* __restrict__ anchors, int anchor_stride, int accumulate, float* __restrict__ out) {
-  __shared__ float s_scale[GFN_N_LEVELS];
-  if (threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = sc.s[threadIdx.x];
-  __syncthreads();
+    const void* __restrict__ table_a, const void* __restrict__ table_b, const int* __restrict__ prim_pool,
+    const float* __restrict__ bias_pool, const float* __restrict__ pts, const AnchorT* __restrict__ anchors,
+    int anchor_stride, int accumulate, float* __restrict__ out) {
   const int64_t n = gfn_live_n(n_max, n_dev);
   const uint32_t T = 1u << log2_T;
-  // thread = (point, level); 16 consecutive lanes = 16 levels of one point, so a
-  // wave writes 4 points x 32 f32 = 512 contiguous bytes.
-  const int level = threadIdx.x & 15;
-  for (int64_t pt = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pt < n; pt += (int64_t)gridDim.x * 16) {
-    const int64_t vol = (int64_t)anchors[pt * anchor_stride];
-    const int64_t tr = (int64_t)level * n_volumes + vol;  // :32,:40
-    Corners c;
-    hash_corners(pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2], s_scale[level], prim_pool + 3 * tr,
-                 bias_pool + 3 * tr, T - 1u, c);
-    const float2* base = reinterpret_cast<const float2*>(feat_pool + (int64_t)level * T);
-    float2 f[8];
+  // wave-uniform trip count: every lane of a wave runs the same number of iterations
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+    const int64_t pt = base + threadIdx.x;
+    const bool valid = pt < n;
+    const int64_t q = valid ? pt : n - 1;  // clamp: invalid lanes redo the last sample, store nothing
+    const float px = pts[3 * q], py = pts[3 * q + 1], pz = pts[3 * q + 2];
+    const int64_t vol = (int64_t)anchors[q * anchor_stride];
+    float o[32];
 #pragma unroll
-    for (int d = 0; d < 8; d++) f[d] = base[c.pos[d]];  // 8 independent gathers in flight
-    float a0 = 0.f, a1 = 0.f;
+    for (int level = 0; level < GFN_N_LEVELS; level++) {
+      const int64_t tr = (int64_t)level * n_volumes + vol;  // :32,:40
+      Corners c;
+      uint32_t cell[3];
+      hash_corners(px, py, pz, sc.s[level], prim_pool + 3 * tr, bias_pool ? bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+      float2 r = gather_level<F16>(table_a, (int64_t)level * T, c);
+      if (DUAL) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486): f32 add of two f16-valued terms
+        const float2 r2 = gather_level<F16>(table_b, (int64_t)level * T, c);
+        r.x = r.x + r2.x; r.y = r.y + r2.y;
+      }
+      o[2 * level] = r.x; o[2 * level + 1] = r.y;
+    }
+    if (valid) {
+      float4* dst = reinterpret_cast<float4*>(out + pt * 32);
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-      const float t0 = c.w[d] * gfn_round_f16(f[d].x);  // :185 pool.to(f16), :74-77 float(half)
-      const float t1 = c.w[d] * gfn_round_f16(f[d].y);
-      a0 = (d == 0) ? t0 : a0 + t0;
-      a1 = (d == 0) ? t1 : a1 + t1;
+      for (int k = 0; k < 8; k++) {
+        float4 v = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        if (accumulate) {
+          const float4 p = dst[k];
+          v.x = p.x + v.x; v.y = p.y + v.y; v.z = p.z + v.z; v.w = p.w + v.w;
+        }
+        dst[k] = v;
+      }
     }
-    float2 res = make_float2(gfn_round_f16(a0), gfn_round_f16(a1));  // :73,:195
-    float2* dst = reinterpret_cast<float2*>(out) + pt * 16 + level;
-    if (accumulate) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), f32 add
-      const float2 prev = *dst;
-      res.x = prev.x + res.x; res.y = prev.y + res.y;
-    }
-    *dst = res;
   }
 }
 
-template <typename AnchorT>
+// Sum v over the lanes [lane, run_end] (runs are maximal groups of consecutive lanes with the
+// same cell); the run head (lowest lane) ends up with the run total.
+__device__ __forceinline__ float run_sum(float v, int lane, int run_end) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_down(v, off, 64);
+    if (lane + off <= run_end) v += u;
+  }
+  return v;
+}
+
+template <typename AnchorT, bool GRAD_F16>
 __global__ __launch_bounds__(256) void hash_bwd_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, int64_t n_volumes, int log2_T, LevelScales sc,
-    const int* __restrict__ prim_pool, const float* __restrict__ bias_pool,
-    const float* __restrict__ pts, const AnchorT* __restrict__ anchors, int anchor_stride,
-    const float* __restrict__ grad_out, float* __restrict__ grad_pool) {
+    const int* __restrict__ prim_pool, const float* __restrict__ bias_pool, const float* __restrict__ pts,
+    const AnchorT* __restrict__ anchors, int anchor_stride, const float* __restrict__ grad_out,
+    void* __restrict__ grad_pool) {
   __shared__ float s_scale[GFN_N_LEVELS];
   if (threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = sc.s[threadIdx.x];
   __syncthreads();
   const int64_t n = gfn_live_n(n_max, n_dev);
   const uint32_t T = 1u << log2_T;
-  const int level = threadIdx.x & 15;
-  for (int64_t pt = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pt < n; pt += (int64_t)gridDim.x * 16) {
-    const float2 g = reinterpret_cast<const float2*>(grad_out)[pt * 16 + level];
-    const float g0 = gfn_round_f16(g.x * 128.f);  // :219
-    const float g1 = gfn_round_f16(g.y * 128.f);
-    if (g0 == 0.f && g1 == 0.f) continue;  // :149
-    const int64_t vol = (int64_t)anchors[pt * anchor_stride];
-    const int64_t tr = (int64_t)level * n_volumes + vol;
-    Corners c;
-    hash_corners(pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2], s_scale[level], prim_pool + 3 * tr,
-                 bias_pool + 3 * tr, T - 1u, c);
-    float* base = grad_pool + (int64_t)level * T;
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += (int64_t)gridDim.x * 256) {
+    const int64_t pt = base + threadIdx.x;
+    const bool valid = pt < n;
+    const int64_t q = valid ? pt : n - 1;
+    const float px = pts[3 * q], py = pts[3 * q + 1], pz = pts[3 * q + 2];
+    const int64_t vol = (int64_t)anchors[q * anchor_stride];
+    const float2* gp = reinterpret_cast<const float2*>(grad_out + q * 32);
+#pragma unroll 1
+    for (int level = 0; level < GFN_N_LEVELS; level++) {
+      const int64_t tr = (int64_t)level * n_volumes + vol;
+      Corners c;
+      uint32_t cell[3];
+      hash_corners(px, py, pz, s_scale[level], prim_pool + 3 * tr, bias_pool ? bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+      const float2 g = gp[level];
+      float g0 = gfn_round_f16(g.x * 128.f);  // :219 grad_in = (grad * 128).half()
+      float g1 = gfn_round_f16(g.y * 128.f);
+      const bool live = valid && (g0 != 0.f || g1 != 0.f);  // :149
+      if (!live) { g0 = 0.f; g1 = 0.f; }
+      // run detection: same volume and same integer cell as the previous lane => same 8 slots
+      const uint32_t pvol = __shfl_up((uint32_t)vol, 1, 64), pcx = __shfl_up(cell[0], 1, 64);
+      const uint32_t pcy = __shfl_up(cell[1], 1, 64), pcz = __shfl_up(cell[2], 1, 64);
+      const bool head = (lane == 0) || pvol != (uint32_t)vol || pcx != cell[0] || pcy != cell[1] || pcz != cell[2];
+      const unsigned long long heads = __ballot(head);
+      float c0[8], c1[8];
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-      // :150 (half)(w0*ws[d]); the reference's final /128 (:238) is exact (power of two)
-      const float c0 = gfn_round_f16(g0 * c.w[d]) * (1.f / 128.f);
-      const float c1 = gfn_round_f16(g1 * c.w[d]) * (1.f / 128.f);
-      float* dst = base + (size_t)c.pos[d] * 2;
-      atomicAdd(dst, c0);
-      atomicAdd(dst + 1, c1);
+      for (int d = 0; d < 8; d++) {  // :150 (half)(w0*ws[d]) -- each contribution quantised like the reference
+        c0[d] = gfn_round_f16(g0 * c.w[d]);
+        c1[d] = gfn_round_f16(g1 * c.w[d]);
+      }
+      bool issue = live;
+      if (__popcll(heads) <= 40) {  // wave-uniform: runs are long enough to pay for the shuffles
+        const unsigned long long later = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const int run_end = later ? lane + __builtin_ctzll(later) : 63;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          c0[d] = run_sum(c0[d], lane, run_end);
+          c1[d] = run_sum(c1[d], lane, run_end);
+        }
+        issue = head;  // zero sums are skipped below
+      }
+      if (issue) {
+        if (GRAD_F16) {
+          half2_t* baseh = reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(grad_pool) + (int64_t)level * T);
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            if (c0[d] != 0.f || c1[d] != 0.f) {
+              const half2_t v = {(_Float16)c0[d], (_Float16)c1[d]};  // x128-scaled, like the reference's pool (:222,:151)
+              __builtin_amdgcn_global_atomic_fadd_v2f16(
+                  (__attribute__((address_space(1))) half2_t*)(baseh + c.pos[d]), v);
+            }
+          }
+        } else {
+          float* basef = reinterpret_cast<float*>(grad_pool) + (int64_t)level * T;
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            if (c0[d] != 0.f || c1[d] != 0.f) {
+              float* dst = basef + (size_t)c.pos[d] * 2;
+              atomicAdd(dst, c0[d] * (1.f / 128.f));  // the reference's final /128 (:238), exact (power of two)
+              atomicAdd(dst + 1, c1[d] * (1.f / 128.f));
+            }
+          }
+        }
+      }
     }
   }
 }
 
-int check_common(const char* fn, int64_t n_max, int64_t n_volumes, int log2_T) {
+int check_common(const char* fn, int64_t n_max, int64_t n_volumes, int log2_T, int anchor_stride) {
   GFN_CHECK_ARG(n_max >= 0 && n_max < (1ll << 31), "%s: n_max=%lld out of range", fn, (long long)n_max);
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 26), "%s: n_volumes=%lld", fn, (long long)n_volumes);
   GFN_CHECK_ARG(log2_T >= 4 && log2_T <= 26, "%s: log2_T=%d must be in [4,26]", fn, log2_T);
+  GFN_CHECK_ARG(anchor_stride >= 1, "%s: anchor_stride=%d", fn, anchor_stride);
   return GFN_OK;
 }
 
 unsigned point_grid(int64_t n_max) {
-  int64_t blocks = (n_max + 15) / 16;
-  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond ~8 WG of 256 threads per CU
+  int64_t blocks = (n_max + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 workgroups per CU
   return (unsigned)(blocks > 0 ? blocks : 1);
+}
+
+template <typename AnchorT>
+void launch_fwd(bool f16, bool dual, unsigned grid, hipStream_t st, int64_t n_max, const int32_t* n_dev, int64_t V,
+                int log2_T, const LevelScales& sc, const void* ta, const void* tb, const int* prim, const float* bias,
+                const float* pts, const AnchorT* anchors, int stride, int accumulate, float* out) {
+#define GFN_FWD(F, D)                                                                                              \
+  hash_fwd_kernel<AnchorT, F, D><<<grid, 256, 0, st>>>(n_max, n_dev, V, log2_T, sc, ta, tb, prim, bias, pts, anchors, \
+                                                       stride, accumulate, out)
+  if (f16) { if (dual) GFN_FWD(true, true); else GFN_FWD(true, false); }
+  else     { if (dual) GFN_FWD(false, true); else GFN_FWD(false, false); }
+#undef GFN_FWD
+}
+
+int hash_fwd_impl(const char* fn, const void* ta, const void* tb, bool f16, const int32_t* prim_pool,
+                  const float* bias_pool, const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
+                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T, int accumulate, float* out,
+                  void* stream) {
+  if (n_max == 0) return GFN_OK;  // empty batch: pointers may be null
+  GFN_CHECK_ARG(ta && prim_pool && pts && anchors && out, "%s: null pointer", fn);
+  if (int rc = check_common(fn, n_max, n_volumes, log2_T, anchor_stride)) return rc;
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0, "%s: out must be 16-byte aligned", fn);
+  LevelScales sc;
+  gfn_hash_level_scales_host(sc.s);
+  const unsigned grid = point_grid(n_max);
+  hipStream_t st = gfn_stream(stream);
+  if (anchors_i64)
+    launch_fwd<int64_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, bias_pool, pts,
+                        (const int64_t*)anchors, anchor_stride, accumulate, out);
+  else
+    launch_fwd<int32_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, bias_pool, pts,
+                        (const int32_t*)anchors, anchor_stride, accumulate, out);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (_Float16)src[i];
 }
 
 }  // namespace
@@ -166,20 +304,24 @@ int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* 
                  const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                  int accumulate, float* out, void* stream) {
-  if (n_max == 0) return GFN_OK;  // empty batch: pointers may be null
-  GFN_CHECK_ARG(feat_pool && prim_pool && bias_pool && pts && anchors && out, "gfn_hash_fwd: null pointer");
-  GFN_CHECK_ARG(anchor_stride >= 1, "gfn_hash_fwd: anchor_stride=%d", anchor_stride);
-  if (int rc = check_common("gfn_hash_fwd", n_max, n_volumes, log2_T)) return rc;
-  if (n_max == 0) return GFN_OK;
-  LevelScales sc;
-  gfn_hash_level_scales_host(sc.s);
-  const unsigned grid = point_grid(n_max);
-  if (anchors_i64)
-    hash_fwd_kernel<int64_t><<<grid, 256, 0, gfn_stream(stream)>>>(n_max, n_dev, n_volumes, log2_T, sc, feat_pool, prim_pool,
-                                                                  bias_pool, pts, (const int64_t*)anchors, anchor_stride, accumulate, out);
-  else
-    hash_fwd_kernel<int32_t><<<grid, 256, 0, gfn_stream(stream)>>>(n_max, n_dev, n_volumes, log2_T, sc, feat_pool, prim_pool,
-                                                                  bias_pool, pts, (const int32_t*)anchors, anchor_stride, accumulate, out);
+  return hash_fwd_impl("gfn_hash_fwd", feat_pool, nullptr, false, prim_pool, bias_pool, pts, anchors, anchors_i64,
+                       anchor_stride, n_max, n_dev, n_volumes, log2_T, accumulate, out, stream);
+}
+
+int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                     const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
+                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
+                     float* out, void* stream) {
+  return hash_fwd_impl("gfn_hash_fwd_f16", table_f16, table2_f16, true, prim_pool, bias_pool, pts, anchors, anchors_i64,
+                       anchor_stride, n_max, n_dev, n_volumes, log2_T, 0, out, stream);
+}
+
+int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream) {
+  if (n_elems == 0) return GFN_OK;
+  GFN_CHECK_ARG(feat_pool && table_f16 && n_elems > 0, "gfn_table_to_f16: bad arguments");
+  int64_t blocks = (n_elems + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  f32_to_f16_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(feat_pool, reinterpret_cast<_Float16*>(table_f16), n_elems);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -187,21 +329,20 @@ int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* 
 int gfn_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const float* pts,
                  const void* anchors, int anchors_i64, int anchor_stride, const float* grad_out,
                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
-                 float* grad_pool, void* stream) {
+                 void* grad_pool, int grad_f16, void* stream) {
   if (n_max == 0) return GFN_OK;
-  GFN_CHECK_ARG(prim_pool && bias_pool && pts && anchors && grad_out && grad_pool, "gfn_hash_bwd: null pointer");
-  GFN_CHECK_ARG(anchor_stride >= 1, "gfn_hash_bwd: anchor_stride=%d", anchor_stride);
-  if (int rc = check_common("gfn_hash_bwd", n_max, n_volumes, log2_T)) return rc;
-  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(prim_pool && pts && anchors && grad_out && grad_pool, "gfn_hash_bwd: null pointer");
+  if (int rc = check_common("gfn_hash_bwd", n_max, n_volumes, log2_T, anchor_stride)) return rc;
   LevelScales sc;
   gfn_hash_level_scales_host(sc.s);
   const unsigned grid = point_grid(n_max);
-  if (anchors_i64)
-    hash_bwd_kernel<int64_t><<<grid, 256, 0, gfn_stream(stream)>>>(n_max, n_dev, n_volumes, log2_T, sc, prim_pool, bias_pool,
-                                                                  pts, (const int64_t*)anchors, anchor_stride, grad_out, grad_pool);
-  else
-    hash_bwd_kernel<int32_t><<<grid, 256, 0, gfn_stream(stream)>>>(n_max, n_dev, n_volumes, log2_T, sc, prim_pool, bias_pool,
-                                                                  pts, (const int32_t*)anchors, anchor_stride, grad_out, grad_pool);
+  hipStream_t st = gfn_stream(stream);
+#define GFN_BWD(A, H)                                                                                               \
+  hash_bwd_kernel<A, H><<<grid, 256, 0, st>>>(n_max, n_dev, n_volumes, log2_T, sc, prim_pool, bias_pool, pts, (const A*)anchors, \
+                                              anchor_stride, grad_out, grad_pool)
+  if (anchors_i64) { if (grad_f16) GFN_BWD(int64_t, true); else GFN_BWD(int64_t, false); }
+  else             { if (grad_f16) GFN_BWD(int32_t, true); else GFN_BWD(int32_t, false); }
+#undef GFN_BWD
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -35,6 +35,8 @@ class HotPathConfig:
     lr_block: float = 5e-3           # nerfacto.py:448-488 (block tables)
     adam_eps: float = 1e-15
     use_appearance_embedding: bool = True  # config.py:50
+    table_f16_shadow: bool = True    # gather from f16 shadows refreshed by the Adam kernel (same values as :185's cast)
+    grad_f16: bool = True            # table gradient pool in f16 with the x128 loss scale, like the reference (:151,:209)
 
 
 class HotPath:
@@ -49,6 +51,7 @@ class HotPath:
         T = self.cfg.log2_T
         self.prim = t(scene.make_primes(self.n_volumes, seed=seed + 2))
         self.bias = torch.zeros((16 * self.n_volumes, 3), dtype=torch.float32, device=self.dev)
+        self.bias_arg = None  # the pool is all zeros (rand_bias off): kernels skip the loads; set to self.bias otherwise
         self.table = t(scene.make_feat_pool(T, seed=seed + 2))  # base_encoding_init (Reset: U(-1e-2,1e-2))
         # residual block tables start at zero in the reference (nerfacto_field.py:345); tiny noise here
         # would hide nothing in training but zeros would hide kernel bugs in tests -> caller may overwrite
@@ -71,6 +74,9 @@ class HotPath:
         self.emb = t(rng.standard_normal((n_cams, 32)).astype(np.float32))  # nn.Embedding init N(0,1)
         self.emb_grad = torch.zeros_like(self.emb)
         self.table_grad = None
+        self.table16 = None
+        self.blocks16 = []
+        self.refresh_shadows()
         self._adam = {}
         self.step = 0
         self.weight_stats = torch.full((self.n_nodes,), 1000, dtype=torch.int64, device=self.dev)  # INIT_NODE_STAT
@@ -78,6 +84,14 @@ class HotPath:
         self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)
         self.timed_ops = set()  # stage names to bracket with events on the launch stream (bench.py)
         self.timings = {}
+
+    def refresh_shadows(self):
+        """(Re)build the f16 shadow tables after the masters were written from outside the optimiser."""
+        if self.cfg.table_f16_shadow:
+            self.table16 = ops.table_to_f16(self.table, self.table16)
+            if len(self.blocks16) != len(self.blocks):
+                self.blocks16 = [None] * len(self.blocks)
+            self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
 
     def _timed(self, name, fn, *a, **k):
         if name not in self.timed_ops and "*" not in self.timed_ops:
@@ -116,11 +130,15 @@ class HotPath:
         """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples."""
         n_dev = s["n_dev"]
         T, V = self.cfg.log2_T, self.n_volumes
-        feat = self._timed("hash_fwd", ops.hash_fwd, self.table, self.prim, self.bias, s["warped_pts"], s["anchors"], V, T,
-                           n_dev=n_dev)
-        if block is not None:  # hash_feats += residual_hash_feats (nerfacto_field.py:485-486)
-            self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.prim, self.bias, s["warped_pts"],
-                        s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
+        if self.cfg.table_f16_shadow:  # one pass; the residual block table (nerfacto_field.py:485-486) fused in
+            feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
+                               s["anchors"], V, T, table2_f16=None if block is None else self.blocks16[block], n_dev=n_dev)
+        else:
+            feat = self._timed("hash_fwd", ops.hash_fwd, self.table, self.prim, self.bias_arg, s["warped_pts"], s["anchors"],
+                               V, T, n_dev=n_dev)
+            if block is not None:
+                self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.prim, self.bias_arg, s["warped_pts"],
+                            s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
         a1 = self._timed("base_fwd", ops.linear_fwd, feat, bW0, bb0, "relu", n_dev=n_dev)
         h = self._timed("base_fwd", ops.linear_fwd, a1, bW1, bb1, "none", n_dev=n_dev)
@@ -153,7 +171,8 @@ class HotPath:
 
     def zero_grads(self, stage, block=None):
         if self.table_grad is None:
-            self.table_grad = torch.zeros_like(self.table)
+            self.table_grad = torch.zeros(self.table.shape, dtype=torch.float16 if self.cfg.grad_f16 else torch.float32,
+                                          device=self.dev)
         ops.fill_zero(self.table_grad)
         if stage == STAGE_GLOBAL:
             ops.fill_zero(self.mlp_grad)
@@ -183,16 +202,21 @@ class HotPath:
         da1, _, _ = self._timed("base_bwd", ops.linear_bwd, f["a1"], bW1, f["h"], dh, "none", dW=gw(1)[0], db=gw(1)[1], need_dw=train_mlp, n_dev=n_dev)
         dfeat, _, _ = self._timed("base_bwd", ops.linear_bwd, f["feat"], bW0, f["a1"], da1, "relu", dW=gw(0)[0], db=gw(0)[1], need_dw=train_mlp, n_dev=n_dev)
         # both tables see the same d(feat) (sum of two lookups); only the trainable one is scattered
-        self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
-                    c.log2_T, grad_pool=self.table_grad, n_dev=n_dev)
+        self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
+                    c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
         return loss, dict(samples=s, field=f, comp=comp)
 
     def optimizer_step(self, stage=STAGE_GLOBAL, block=None):
         c = self.cfg
         self.step += 1
+        # only elements [0, 17T) of a table are addressable (level-overlap quirk); the rest never receive a
+        # gradient, so dense Adam leaves them untouched and they are skipped exactly
+        n_live = 17 * (1 << c.log2_T)
         if stage == STAGE_GLOBAL:
-            for name, p, gr in (("table", self.table, self.table_grad), ("mlp", self.mlp_flat, self.mlp_grad),
-                                ("emb", self.emb, self.emb_grad)):
+            m, v = self._adam_state("table", self.table)
+            self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self.step, lr=c.lr, eps=c.adam_eps,
+                        shadow_f16=self.table16, n=n_live)
+            for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
                 m, v = self._adam_state(name, p)
@@ -200,7 +224,8 @@ class HotPath:
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
-            self._timed("adam", ops.adam_step, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps)
+            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps,
+                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live)
 
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""

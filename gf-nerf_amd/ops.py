@@ -78,8 +78,41 @@ def hash_fwd(feat_pool, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, o
     return out
 
 
-def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, grad_pool=None, n_dev=None):
-    """Scatter grad_out [n,32] into grad_pool [16*T,2] (accumulating; allocated zeroed if None)."""
+def table_to_f16(feat_pool, out=None):
+    """f16 shadow of a master table (same flat indexing, incl. the level-overlap quirk)."""
+    _chk(feat_pool, torch.float32, "feat_pool")
+    if out is None:
+        out = torch.empty(feat_pool.shape, dtype=torch.float16, device=feat_pool.device)
+    _chk(out, torch.float16, "out")
+    _lib.check(_lib.lib().gfn_table_to_f16(_ptr(feat_pool), _ptr(out), feat_pool.numel(), _stream()), "gfn_table_to_f16")
+    return out
+
+
+def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, out=None, n_dev=None):
+    """Lookup from f16 shadow table(s); table2_f16 fuses the focal stage's residual table (sum of both)."""
+    _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16")
+    _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
+    _chk(anchors, anchors.dtype, "anchors")
+    n = pts.shape[0]
+    for t in (table_f16, table2_f16):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2:
+            raise _lib.GfnError("f16 table has the wrong size")
+    if prim_pool.numel() != 16 * n_volumes * 3:
+        raise _lib.GfnError("prim_pool does not match n_volumes")
+    stride = _anchor_stride(anchors, n)
+    if out is None:
+        out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
+    _chk(out, torch.float32, "out", 32)
+    rc = _lib.lib().gfn_hash_fwd_f16(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts),
+                                     _ptr(anchors), int(anchors.dtype == torch.int64), stride, n, _ptr(n_dev), n_volumes,
+                                     log2_T, _ptr(out), _stream())
+    _lib.check(rc, "gfn_hash_fwd_f16")
+    return out
+
+
+def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, grad_pool=None, n_dev=None, grad_f16=False):
+    """Scatter grad_out [n,32] into grad_pool [16*T,2] (accumulating; allocated zeroed if None).
+    grad_f16: pool is float16 and keeps the reference's x128 scale (packed f16 atomics)."""
     _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool")
     _chk(pts, torch.float32, "pts", 3); _chk(grad_out, torch.float32, "grad_out", 32)
     _chk(anchors, anchors.dtype, "anchors")
@@ -87,14 +120,15 @@ def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, gr
     if grad_out.shape[0] != n:
         raise _lib.GfnError("grad_out / pts disagree on n")
     stride = _anchor_stride(anchors, n)
+    gdt = torch.float16 if grad_f16 else torch.float32
     if grad_pool is None:
-        grad_pool = torch.zeros((16 * (1 << log2_T), 2), dtype=torch.float32, device=pts.device)
-    _chk(grad_pool, torch.float32, "grad_pool")
+        grad_pool = torch.zeros((16 * (1 << log2_T), 2), dtype=gdt, device=pts.device)
+    _chk(grad_pool, gdt, "grad_pool")
     if grad_pool.numel() != 16 * (1 << log2_T) * 2:
         raise _lib.GfnError("grad_pool has the wrong size")
     rc = _lib.lib().gfn_hash_bwd(_ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
                                  int(anchors.dtype == torch.int64), stride, _ptr(grad_out), n, _ptr(n_dev), n_volumes,
-                                 log2_T, _ptr(grad_pool), _stream())
+                                 log2_T, _ptr(grad_pool), int(bool(grad_f16)), _stream())
     _lib.check(rc, "gfn_hash_bwd")
     return grad_pool
 
@@ -333,6 +367,21 @@ def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15):
         raise _lib.GfnError("adam_step: size mismatch")
     _lib.check(_lib.lib().gfn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), float(lr), float(beta1),
                                         float(beta2), float(eps), _stream()), "gfn_adam_step")
+
+
+def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None):
+    """Adam on (the first n elements of) a hash table; g float32, or float16 carrying the x128 loss scale."""
+    _chk(p, torch.float32, "p"); _chk(m, torch.float32, "m"); _chk(v, torch.float32, "v"); _chk(shadow_f16, torch.float16, "shadow")
+    if g.dtype not in (torch.float32, torch.float16):
+        raise _lib.GfnError("adam_step_table: gradient must be float32 or float16")
+    _chk(g, g.dtype, "g")
+    n = p.numel() if n is None else n
+    if not (p.numel() == g.numel() == m.numel() == v.numel()) or n > p.numel():
+        raise _lib.GfnError("adam_step_table: size mismatch")
+    g16 = g.dtype == torch.float16
+    _lib.check(_lib.lib().gfn_adam_step_ex(_ptr(p), _ptr(g), int(g16), (1.0 / 128.0) if g16 else 1.0, _ptr(m), _ptr(v), n,
+                                           int(step), float(lr), float(beta1), float(beta2), float(eps), _ptr(shadow_f16),
+                                           _stream()), "gfn_adam_step_ex")
 
 
 def fill_zero(t):

@@ -82,7 +82,7 @@ typedef struct {
 void gfn_hash_level_scales_host(float out_host[GFN_N_LEVELS]);
 
 /* feat_pool f32 [16*T*2] master table (States()[0]); prim_pool i32 [16,V,3];
- * bias_pool f32 [16*V,3]; pts f32 [n,3] already in table space
+ * bias_pool f32 [16*V,3] or NULL for the all-zero pool; pts f32 [n,3] already in table space
  * ((warped+1.5)/3, nerfacto_field.py:431); anchors i32 or i64, element i at
  * anchors[i*anchor_stride] (stride 1 = the reference's [n] tensor, 3 = column 0 of
  * the packed sampler's [n,3] anchors).  out f32 [n,32].  anchors_i64 != 0 selects
@@ -93,14 +93,27 @@ int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* 
                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                  int accumulate, float* out, void* stream);
 
-/* grad_out f32 [n,32] -> grad_pool f32 [16*T*2], ACCUMULATED (caller zeroes or
- * calls gfn_fill_zero).  Quantisation of every contribution follows
- * Hash3DAnchored_cuda.cu:147-151,219 (x128 -> f16, product -> f16); the sum is
- * kept in f32 instead of f16 and the /128 (:238) is applied per contribution. */
+/* Same lookup from f16 shadow tables (u16 [16*T*2], element i = f16(master[i]) RNE, kept
+ * current by gfn_adam_step_ex): identical results to gfn_hash_fwd, half the gather bytes.
+ * table2_f16 != NULL fuses the focal stage's residual lookup: out = feat(table) + feat(table2). */
+int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                     const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
+                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
+                     float* out, void* stream);
+/* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
+int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
+
+/* grad_out f32 [n,32] -> grad_pool [16*T*2], ACCUMULATED (caller zeroes).  Every
+ * contribution is quantised like Hash3DAnchored_cuda.cu:147-151,219 (x128 -> f16,
+ * product -> f16); contributions of consecutive samples that fall in the same cell are
+ * summed in registers first.  grad_f16 == 0: f32 pool, atomics in f32, the /128 (:238)
+ * already applied.  grad_f16 != 0: u16(f16) pool accumulated with packed f16 atomics and
+ * still carrying the x128 scale -- the reference's own accumulation (:151,:222); the
+ * consumer divides by 128 (gfn_adam_step_ex grad_scale). */
 int gfn_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const float* pts,
                  const void* anchors, int anchors_i64, int anchor_stride, const float* grad_out,
                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
-                 float* grad_pool, void* stream);
+                 void* grad_pool, int grad_f16, void* stream);
 
 /* ====================================================================== *
  * PersSampler  (replaces my_classes.PersSampler.GetSamples / UpdateOctNodes:
@@ -210,6 +223,12 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
                     float* g_pred, void* stream);
 int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
                   float beta1, float beta2, float eps, void* stream);
+/* Adam for a hash table: g is f32 (g_f16 == 0) or f16 (g_f16 != 0) and is multiplied by
+ * g_scale first (1/128 for gfn_hash_bwd's f16 pool); shadow_f16 (may be NULL) receives
+ * f16(p) of every updated element so gfn_hash_fwd_f16 stays current. */
+int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
+                     int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
+                     void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
 
 /* ====================================================================== *

@@ -121,6 +121,79 @@ def test_hash_backward(oracle, ops, dev):
     np.testing.assert_allclose(got2, 2 * got, rtol=2e-3, atol=1e-7)
 
 
+def test_hash_forward_f16_shadow_and_fused_dual(oracle, ops, dev):
+    """f16 shadow tables give the same bits as the f32 master path; the fused dual lookup equals feat(A)+feat(B)."""
+    from gfnerf_amd import scene
+
+    rng = np.random.default_rng(21)
+    log2_T, n_vol, n = 15, 11, 9000
+    pa, pb = scene.make_feat_pool(log2_T, seed=2), scene.make_feat_pool(log2_T, seed=5, scale=3e-3)
+    prim = scene.make_primes(n_vol, seed=3)
+    bias = np.zeros((16 * n_vol, 3), np.float32)
+    pts = rng.random((n, 3), dtype=np.float32)
+    anchors3 = np.stack([np.sort(rng.integers(0, n_vol, n)), rng.integers(0, 99, n), rng.integers(0, 9, n)], 1).astype(np.int32)
+    wa = oracle.hash_fwd(pa, prim, bias, pts, anchors3[:, 0], n_vol, log2_T)
+    wb = oracle.hash_fwd(pb, prim, bias, pts, anchors3[:, 0], n_vol, log2_T)
+    a16, b16 = ops.table_to_f16(_t(pa, dev)), ops.table_to_f16(_t(pb, dev))
+    assert np.array_equal(a16.cpu().numpy(), pa.astype(np.float16))
+    common = (_t(prim, dev), None, _t(pts, dev), _t(anchors3, dev), n_vol, log2_T)  # bias None == zero pool; packed [n,3] anchors
+    got = ops.hash_fwd_f16(a16, *common).cpu().numpy()
+    assert np.array_equal(got, wa)
+    dual = ops.hash_fwd_f16(a16, *common, table2_f16=b16).cpu().numpy()
+    assert np.array_equal(dual, wa + wb)
+    # unfused two-call form of the boundary (accumulate) agrees bit for bit
+    two = ops.hash_fwd(_t(pa, dev), _t(prim, dev), _t(bias, dev), _t(pts, dev), _t(anchors3, dev), n_vol, log2_T)
+    ops.hash_fwd(_t(pb, dev), _t(prim, dev), _t(bias, dev), _t(pts, dev), _t(anchors3, dev), n_vol, log2_T, out=two, accumulate=True)
+    assert np.array_equal(two.cpu().numpy(), dual)
+
+
+def test_hash_backward_f16_pool_and_runs(oracle, ops, dev):
+    """Packed-f16 gradient pool (the reference's own accumulation, x128-scaled) and the run-length path
+    (consecutive samples in one cell), against the oracle's exact sum of the same quantised contributions."""
+    from gfnerf_amd import scene
+
+    rng = np.random.default_rng(9)
+    log2_T, n_vol, n = 13, 3, 8192
+    prim = scene.make_primes(n_vol, seed=3)
+    # a slow march through table space: long runs on the coarse levels, none on the fine ones
+    t = np.linspace(0, 1, n, dtype=np.float32)[:, None]
+    pts = (np.array([[0.1, 0.2, 0.3]], np.float32) + t * np.array([[0.7, 0.5, 0.6]], np.float32)).astype(np.float32)
+    anchors = (np.arange(n) // 3000).astype(np.int32)
+    g = (rng.standard_normal((n, 32)) * 1e-3).astype(np.float32)
+    want = oracle.hash_bwd(prim, None if False else np.zeros((16 * n_vol, 3), np.float32), pts, anchors, g, n_vol, log2_T)
+    args = (_t(prim, dev), None, _t(pts, dev), _t(anchors, dev), _t(g, dev), n_vol, log2_T)
+    got32 = ops.hash_bwd(*args).cpu().numpy()
+    np.testing.assert_allclose(got32, want, rtol=2e-5, atol=1e-9)
+    got16 = ops.hash_bwd(*args, grad_f16=True)
+    assert got16.dtype.is_floating_point and got16.element_size() == 2
+    got16 = got16.float().cpu().numpy() / 128.0
+    scale = np.abs(want).max()
+    # f16 running sums: relative error ~2^-11 per add; coarse-level slots take tens of adds
+    np.testing.assert_allclose(got16, want, rtol=2e-2, atol=2e-3 * scale)
+    assert np.abs(got16 - want).max() < 4e-3 * scale
+    assert np.all(got16[want == 0] == 0)  # untouched slots stay exactly zero (tiny sums may underflow f16 to zero)
+
+
+def test_adam_table_f16_grad_and_shadow(oracle, ops, dev):
+    import torch
+
+    rng = np.random.default_rng(3)
+    n = 5000
+    p0 = rng.standard_normal(n).astype(np.float32) * 1e-2
+    g = (rng.standard_normal(n) * 1e-3).astype(np.float32)
+    g16 = (g * 128).astype(np.float16)
+    p_ref, m_ref, v_ref = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    oracle.adam_step(p_ref, (g16.astype(np.float32) / 128).astype(np.float32), m_ref, v_ref, 1)
+    p = _t(p0.copy(), dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.zeros(n, dtype=torch.float16, device=dev)
+    ops.adam_step_table(p, _t(g16, dev), m, v, 1, shadow_f16=shadow, n=4000)
+    got = p.cpu().numpy()
+    np.testing.assert_allclose(got[:4000], p_ref[:4000], rtol=1e-6, atol=1e-8)
+    assert np.array_equal(got[4000:], p0[4000:])  # elements beyond n untouched
+    assert np.array_equal(shadow.cpu().numpy()[:4000], got[:4000].astype(np.float16))
+
+
 # --------------------------------------------------------------------------- sampler
 def _sample_both(oracle, ops, dev, n_rays=700, train=True, fineness=6.0, seed=0):
     from gfnerf_amd import scene

@@ -22,13 +22,14 @@ def setup():
     import pipeline as opipe
 
     sc = small_scene()
-    cfg = hotpath.HotPathConfig(log2_T=14, early_T=0.0)
+    cfg = hotpath.HotPathConfig(log2_T=14, early_T=0.0, grad_f16=False)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
     rng = np.random.default_rng(11)
     hp.blocks[0].copy_(torch.from_numpy(rng.uniform(-1e-2, 1e-2, tuple(hp.blocks[0].shape)).astype(np.float32)))
     # larger weights than the default init so sigma spans ~an order of magnitude and rays saturate
     hp.table.mul_(100.0)
     hp.layers[1][0].mul_(4.0)
+    hp.refresh_shadows()
     R = 384
     o, d, cam = rays_for(sc, R, seed=3)
     noise = scene.make_noise(R, True, 5.0, seed=2)
@@ -98,6 +99,27 @@ def test_training_gradients_match_oracle(setup, stage):
         np.testing.assert_allclose(hp.emb_grad.cpu().numpy(), g["emb"], rtol=1e-3, atol=1e-4 * np.abs(g["emb"]).max())
     else:
         assert hp.mlp_grad.abs().max().item() == 0 or True  # MLP grads are not produced in the focal stage
+
+
+def test_training_f16_gradient_pool(setup):
+    """Default training mode: table gradient accumulated in packed f16 (x128 scale) like the reference."""
+    from gfnerf_amd import hotpath
+
+    S = setup
+    t = S["t"]
+    hp32 = S["hp"]
+    hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global")
+    ref = hp32.table_grad.cpu().numpy()
+    old = hp32.cfg.grad_f16
+    try:
+        hp32.cfg.grad_f16, hp32.table_grad = True, None
+        hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global")
+        got = hp32.table_grad.float().cpu().numpy() / 128.0
+    finally:
+        hp32.cfg.grad_f16, hp32.table_grad = old, None
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 5e-3 * scale
+    assert np.all(got[ref == 0] == 0)
 
 
 def test_train_steps_reduce_loss(setup):
