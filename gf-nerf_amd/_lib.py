@@ -22,6 +22,9 @@ SIGNATURES = {
     "gfn_trace": (_i32, [_vp, _vp, _i64, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_march": (_i32, [_vp, _vp, _vp, _i64, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _vp, _i64, _vp, _vp]),
+    "gfn_tree_compact": (_i32, [_vp, _i64, _vp, _vp]),
+    "gfn_sample_rays": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_linear_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -316,6 +316,243 @@ __global__ __launch_bounds__(kRayBlock) void march_kernel(
   if (!FILL) counts[ray] = pts_ptr;
 }
 
+// ============================================================================
+// Fast path used by the training / render loop (gfn_sample_rays): same arithmetic,
+// same outputs, laid out for the machine.
+//   * nodes are repacked to ONE 64-byte line each (box, 8 child ids, trans/block idx),
+//     so a DFS visit is a single cache-line fetch instead of up to ten dependent loads
+//     from the 128-byte checkpoint struct;
+//   * the traversal runs once, writing each ray's leaves to its own dense slot
+//     (R x max_hits is small) -- no count pass, no scan, no host sync;
+//   * the march gives every ray a 16-lane row of a wave: lanes 0..11 own one of the
+//     12 perspective projections, the 3x12 contractions are 4-step shuffle trees in
+//     exactly the association of sum12(), and the leaf's TransInfo stays in registers
+//     until the ray crosses into the next leaf.  4096 rays = 1024 waves instead of 64.
+// ============================================================================
+struct __attribute__((aligned(64))) CompactNode {
+  float cx, cy, cz, side;
+  int child[8];
+  int trans_idx, block_idx, pad0, pad1;
+};
+static_assert(sizeof(CompactNode) == 64, "one cache line per node");
+
+__global__ void compact_nodes_kernel(NodeView nodes, int64_t n_nodes, CompactNode* __restrict__ out) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_nodes) return;
+  CompactNode c;
+  const float4 b = nodes.box((int)u);
+  c.cx = b.x; c.cy = b.y; c.cz = b.z; c.side = b.w;
+#pragma unroll
+  for (int k = 0; k < 8; k++) c.child[k] = nodes.child((int)u, k);
+  c.trans_idx = nodes.trans_idx((int)u);
+  c.block_idx = nodes.block_idx((int)u);
+  c.pad0 = 0; c.pad1 = 0;
+  out[u] = c;
+}
+
+// K3, one pass, dense output slots [ray*max_hits, ...); counts[ray] = number of leaves.
+__global__ __launch_bounds__(kRayBlock) void trace_dense_kernel(
+    int n_rays, const CompactNode* __restrict__ nodes, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, float near_bound, float far_bound, int max_hits,
+    int* __restrict__ counts, int* __restrict__ hit_idx, float2* __restrict__ hit_nf, int* __restrict__ overflow) {
+  __shared__ int s_node[kMaxDepth][kRayBlock];
+  __shared__ signed char s_child[kMaxDepth][kRayBlock];
+  const int lane = threadIdx.x;
+  const int ray = blockIdx.x * kRayBlock + lane;
+  if (ray >= n_rays) return;
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  const int64_t out_base = (int64_t)ray * max_hits;
+  const int ray_st = ((d[0] > 0.f) << 2) | ((d[1] > 0.f) << 1) | (d[2] > 0.f);
+  int sp = 0, cnt = 0;
+  s_node[0][lane] = 0;
+  s_child[0][lane] = -1;
+  while (sp >= 0 && cnt < max_hits) {
+    const int u = s_node[sp][lane];
+    int child_ptr = s_child[sp][lane];
+    // the whole node in one 64-byte fetch
+    const int4* np = reinterpret_cast<const int4*>(nodes + u);
+    const int4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    const int ch[8] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    bool descend = true;
+    if (child_ptr == -1) {
+      float cur_near = near_bound, cur_far = far_bound;
+      get_intersection(o, d, make_float4(__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z), __int_as_float(w0.w)),
+                       cur_near, cur_far);
+      if (cur_near < cur_far) {
+        child_ptr = 0;
+        while (child_ptr < 8 && ch[search_child(ray_st, child_ptr)] < 0) child_ptr++;
+        if (child_ptr >= 8) {
+          if (w3.x >= 0) {  // trans_idx
+            hit_idx[out_base + cnt] = u;
+            hit_nf[out_base + cnt] = make_float2(cur_near, cur_far);
+            cnt++;
+          }
+          descend = false;
+        }
+      } else {
+        descend = false;
+      }
+    } else {
+      child_ptr = child_ptr + 1;
+      while (child_ptr < 8 && ch[search_child(ray_st, child_ptr)] < 0) child_ptr++;
+      if (child_ptr >= 8) descend = false;
+    }
+    if (descend) {
+      s_child[sp][lane] = (signed char)child_ptr;
+      if (sp + 1 < kMaxDepth) {
+        sp++;
+        s_node[sp][lane] = ch[search_child(ray_st, child_ptr)];
+        s_child[sp][lane] = -1;
+      } else if (overflow) {
+        atomicOr(overflow, 2);
+      }
+    } else {
+      sp--;
+    }
+  }
+  counts[ray] = cnt;
+}
+
+// tree sum of one value per lane over lanes 0..11 of each 16-lane row, association of sum12():
+// ((q0+(q1+q2)) + (q3+(q4+q5))) + ((q6+(q7+q8)) + (q9+(q10+q11))); the result is valid on lane 0 of the row.
+// lane i of a 16-lane row reads lane i+N of the same row (0 beyond the row): DPP row_shl, no LDS traffic
+template <int N>
+__device__ __forceinline__ float row_down(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum12(float q) {
+  const float a = q + row_down<1>(q);   // lanes 3k+1: q[3k+1] + q[3k+2]
+  const float b = q + row_down<1>(a);   // lanes 3k  : q[3k] + (q[3k+1] + q[3k+2])
+  const float c = b + row_down<3>(b);   // lanes 0, 6: s0 + s1, s2 + s3
+  return c + row_down<6>(c);            // lane 0
+}
+
+constexpr int kGroup = 16;                 // lanes per ray
+constexpr int kRaysPerBlock = 256 / kGroup;  // 16 rays per 256-thread workgroup
+
+// K4 with a 16-lane row per ray.  Hits come from the dense slots of trace_dense_kernel.
+template <bool FILL>
+__global__ __launch_bounds__(256) void march_group_kernel(
+    int n_rays, float sample_l, int scale_by_dis, int table_space, int max_hits,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ noise_all,
+    const int* __restrict__ hit_counts, const int* __restrict__ hit_idx, const float2* __restrict__ hit_nf,
+    const CompactNode* __restrict__ nodes, const float* __restrict__ transes, int* __restrict__ counts,
+    const int* __restrict__ pts_offsets, float* __restrict__ world_pts, float* __restrict__ warped_pts,
+    float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
+    int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow) {
+  const int g = threadIdx.x & (kGroup - 1);          // projection index owned by this lane (0..11 live)
+  const int ray = blockIdx.x * kRaysPerBlock + (threadIdx.x / kGroup);
+  const bool in_range = ray < n_rays;
+  const int r = in_range ? ray : 0;
+  const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+  const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+  const float* noise = noise_all + r;
+  const int n_oct = in_range ? hit_counts[r] : 0;
+  hit_idx += (int64_t)r * max_hits;
+  hit_nf += (int64_t)r * max_hits;
+  int max_n = GFN_MAX_SAMPLE_PER_RAY;
+  int64_t base = 0;
+  if (FILL) {
+    base = pts_offsets[r];
+    int64_t end = pts_offsets[r + 1];
+    if (end > pts_cap) { end = pts_cap; if (overflow && g == 0) atomicOr(overflow, 4); }
+    max_n = (int)(end > base ? end - base : 0);
+    if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;
+    if (in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
+  }
+  bool active = in_range && max_n > 0 && n_oct > 0;
+  int pts_ptr = 0, oct_ptr = 0;
+  int cur_oct_idx = active ? hit_idx[0] : 0;
+  float2 nf = active ? hit_nf[0] : make_float2(0.f, 0.f);
+  float cur_t = nf.x, cur_far = nf.y, cur_near = nf.x;
+  float cur_march_step = 0.f, exp_march_step = 0.f;
+  float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
+  bool first = true;
+  // this lane's slice of the current leaf's TransInfo
+  int loaded_oct = -1, trans_idx = 0, block_idx = 0;
+  float4 m0 = make_float4(0, 0, 0, 0), m1 = make_float4(0, 0, 0, 1);
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, tcx = 0.f, tcy = 0.f, tcz = 0.f, tdis = 1.f;
+  const int gi = g < GFN_N_PROS ? g : 0;
+  while (__any(active)) {
+    if (active && loaded_oct != cur_oct_idx) {  // row-uniform: reload on leaf change only
+      const CompactNode* nd = nodes + cur_oct_idx;
+      trans_idx = nd->trans_idx;
+      block_idx = nd->block_idx;
+      const float* tp = transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4);
+      m0 = *reinterpret_cast<const float4*>(tp + gi * 8);
+      m1 = *reinterpret_cast<const float4*>(tp + gi * 8 + 4);
+      w0 = tp[96 + gi]; w1 = tp[96 + 12 + gi]; w2 = tp[96 + 24 + gi];
+      tcx = tp[132]; tcy = tp[133]; tcz = tp[134]; tdis = tp[136];
+      loaded_oct = cur_oct_idx;
+    }
+    // per-lane projection i = g  (PersSampler_cuda.cu:155-188)
+    const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
+    const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
+    const float dv0 = 1.f / x1;
+    const float dv1 = -x0 / (x1 * x1);
+    const bool lv = g < GFN_N_PROS;
+    const float tj0 = lv ? dv0 * m0.x + dv1 * m1.x : 0.f;
+    const float tj1 = lv ? dv0 * m0.y + dv1 * m1.y : 0.f;
+    const float tj2 = lv ? dv0 * m0.z + dv1 * m1.z : 0.f;
+    float jac[9];
+    jac[0] = row_sum12(w0 * tj0); jac[1] = row_sum12(w0 * tj1); jac[2] = row_sum12(w0 * tj2);
+    jac[3] = row_sum12(w1 * tj0); jac[4] = row_sum12(w1 * tj1); jac[5] = row_sum12(w1 * tj2);
+    jac[6] = row_sum12(w2 * tj0); jac[7] = row_sum12(w2 * tj1); jac[8] = row_sum12(w2 * tj2);
+    float pj[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) pj[rr] = gfn_sum3(jac[rr * 3] * d[0], jac[rr * 3 + 1] * d[1], jac[rr * 3 + 2] * d[2]);
+    float pnorm = sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
+    pnorm = __shfl(pnorm, 0, 16);  // lane 0 of the row holds the true reductions
+    float wp[3] = {0.f, 0.f, 0.f};
+    if (FILL) {  // warped point (:155-170): v_i = x0/x1, out_r = sum12(weight[r][i] * v_i)
+      const float v = lv ? x0 / x1 : 0.f;
+      wp[0] = row_sum12(w0 * v); wp[1] = row_sum12(w1 * v); wp[2] = row_sum12(w2 * v);
+    }
+    if (active) {
+      const float dx = o[0] - tcx, dy = o[1] - tcy, dz = o[2] - tcz;
+      const float cur_radius = sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tdis;
+      const float cur_radius_clip = fmaxf(cur_radius, 1.f);
+      const float warp_step = sample_l * noise[pts_ptr];
+      exp_march_step = warp_step / (pnorm + 1e-6f);
+      if (scale_by_dis) exp_march_step *= cur_radius_clip;
+      cur_march_step = exp_march_step;
+      if (FILL && !first && g == 0) {
+        const int64_t p = base + pts_ptr;
+        if (table_space) {
+          const float inv3 = 1.0f / 3.0f;
+          wp[0] = (wp[0] + 1.5f) * inv3; wp[1] = (wp[1] + 1.5f) * inv3; wp[2] = (wp[2] + 1.5f) * inv3;
+        }
+        if (world_pts) { world_pts[3 * p] = xyz[0]; world_pts[3 * p + 1] = xyz[1]; world_pts[3 * p + 2] = xyz[2]; }
+        if (dirs) { dirs[3 * p] = d[0]; dirs[3 * p + 1] = d[1]; dirs[3 * p + 2] = d[2]; }
+        warped_pts[3 * p] = wp[0]; warped_pts[3 * p + 1] = wp[1]; warped_pts[3 * p + 2] = wp[2];
+        ts[p] = cur_t;
+        dists[p] = exp_march_step * (pnorm + 1e-6f);
+        anchors[3 * p] = trans_idx;
+        anchors[3 * p + 1] = cur_oct_idx;
+        anchors[3 * p + 2] = block_idx;
+        if (ray_id) ray_id[p] = ray;
+      }
+      if (!first) pts_ptr += 1;
+      while (cur_t + cur_march_step > cur_far) {
+        oct_ptr++;
+        if (oct_ptr >= n_oct) break;
+        cur_oct_idx = hit_idx[oct_ptr];
+        nf = hit_nf[oct_ptr];
+        cur_near = nf.x;
+        cur_far = nf.y;
+        const int64_t ex = (int64_t)ceilf(fmaxf((cur_near - cur_t) / exp_march_step, 1.f));
+        cur_march_step = exp_march_step * (float)ex;
+      }
+      cur_t += cur_march_step;
+      xyz[0] = o[0] + d[0] * cur_t; xyz[1] = o[1] + d[1] * cur_t; xyz[2] = o[2] + d[2] * cur_t;
+      first = false;
+      active = pts_ptr < max_n && oct_ptr < n_oct;
+    }
+  }
+  if (!FILL && in_range && g == 0) counts[ray] = pts_ptr;
+}
+
 __global__ void normalize_dirs_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -507,6 +744,60 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
       (int)n_rays, sample_l, scale_by_dis, table_space, rays_o, rays_d, noise, oct_offsets, hit_idx,
       reinterpret_cast<const float2*>(hit_near_far), nv, reinterpret_cast<const float*>(transes), nullptr,
       pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void* stream) {
+  if (n_nodes == 0) return GFN_OK;
+  GFN_CHECK_ARG(nodes && compact_out && n_nodes > 0 && n_nodes < (1ll << 31), "gfn_tree_compact: bad arguments");
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(compact_out) & 63) == 0, "gfn_tree_compact: output must be 64-byte aligned");
+  NodeView nv{reinterpret_cast<const uint8_t*>(nodes)};
+  compact_nodes_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, gfn_stream(stream)>>>(nv, n_nodes,
+                                                                                        reinterpret_cast<CompactNode*>(compact_out));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                    const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                    int max_hits, float sample_l, int scale_by_dis, int table_space,
+                    int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
+                    int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+                    float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+                    int32_t* overflow_dev, void* stream) {
+  GFN_CHECK_ARG(pts_offsets, "gfn_sample_rays: null pts_offsets");
+  hipStream_t st = gfn_stream(stream);
+  if (n_rays == 0) {
+    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
+    return GFN_OK;
+  }
+  GFN_CHECK_ARG(rays_o && rays_d && noise && compact_nodes && transes && hit_counts && hit_idx && hit_near_far,
+                "gfn_sample_rays: null input / workspace pointer");
+  GFN_CHECK_ARG(warped_pts && dists && ts && anchors, "gfn_sample_rays: null output pointer");
+  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_sample_rays: n_rays=%lld", (long long)n_rays);
+  GFN_CHECK_ARG(max_hits > 0 && max_hits <= GFN_MAX_OCT_PER_RAY && n_rays * max_hits < (1ll << 31),
+                "gfn_sample_rays: max_hits=%d", max_hits);
+  GFN_CHECK_ARG(pts_cap >= n_rays && pts_cap * 3 < (1ll << 31), "gfn_sample_rays: pts_cap=%lld must be in [n_rays, 2^31/3)",
+                (long long)pts_cap);
+  const CompactNode* cn = reinterpret_cast<const CompactNode*>(compact_nodes);
+  trace_dense_kernel<<<(unsigned)((n_rays + kRayBlock - 1) / kRayBlock), kRayBlock, 0, st>>>(
+      (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
+      reinterpret_cast<float2*>(hit_near_far), overflow_dev);
+  GFN_CHECK_LAUNCH();
+  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  int* counts = anchors;  // scratch until the fill pass
+  march_group_kernel<false><<<grid, 256, 0, st>>>(
+      (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
+      reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts, nullptr, nullptr,
+      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev);
+  GFN_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(counts, (int)n_rays, pts_offsets);
+  GFN_CHECK_LAUNCH();
+  march_group_kernel<true><<<grid, 256, 0, st>>>(
+      (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
+      reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), nullptr, pts_offsets,
+      world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

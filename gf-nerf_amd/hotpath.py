@@ -47,6 +47,8 @@ class HotPath:
         self.nodes = t(np.asarray(nodes).view(np.uint8).reshape(-1))
         self.transes = t(np.asarray(transes).view(np.uint8).reshape(-1))
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
+        self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
+        self._sampler_ws = None
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
         self.prim = t(scene.make_primes(self.n_volumes, seed=seed + 2))
@@ -115,14 +117,13 @@ class HotPath:
         c = self.cfg
         d = ops.normalize_dirs(rays_d_raw)
         R = rays_o.shape[0]
-        off, hi, nf, ovf = self._timed("trace", ops.trace, rays_o, d, self.nodes, near=c.global_near, far=1e8,
-                                       max_hits=c.max_oct_per_ray)
-        s = self._timed("march", ops.march, rays_o, d, noise, c.sample_l, c.scale_by_dis, off, hi, nf, self.nodes,
-                        self.transes, pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world,
-                        want_dirs=need_world, table_space=True)
+        s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
+                        c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
+                        pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world, want_dirs=need_world,
+                        table_space=True, workspace=self._sampler_ws)
+        self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
-        s["oct_offsets"] = off
         return s
 
     # -------------------------------------------------------------------- field
@@ -249,6 +250,7 @@ class HotPath:
         s, comp = aux["samples"], aux["comp"]
         ops.update_nodes(s["pts_offsets"], s["anchors"], comp["weights"], comp["alphas"], self.weight_stats,
                          self.alpha_stats, self.visit_cnt, self.nodes)
+        ops.tree_compact(self.nodes, self.nodes_compact)  # K6 may have invalidated leaves
 
 
 def fineness_at(step, init=16.0, decay_end=10000):

@@ -199,6 +199,49 @@ def march(rays_o, rays_d, noise, sample_l, scale_by_dis, oct_offsets, hit_idx, h
     return out
 
 
+def tree_compact(nodes, out=None):
+    """Checkpoint node blob -> one 64-byte line per node for the fast sampler."""
+    _chk(nodes, torch.uint8, "nodes")
+    n_nodes = nodes.numel() // TREE_NODE_BYTES
+    if out is None:
+        out = torch.empty(max(n_nodes, 1) * 64, dtype=torch.uint8, device=nodes.device)
+    _lib.check(_lib.lib().gfn_tree_compact(_ptr(nodes), n_nodes, _ptr(out), _stream()), "gfn_tree_compact")
+    return out
+
+
+def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8,
+                max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None):
+    """Fast GetSamples: single-pass dense trace + 16-lane-per-ray march.  Same dict as march()."""
+    _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
+    _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
+    R = rays_o.shape[0]
+    if noise.numel() < MAX_SAMPLE_PER_RAY + R:
+        raise _lib.GfnError(f"noise needs at least {MAX_SAMPLE_PER_RAY + R} entries")
+    if pts_cap is None:
+        pts_cap = max(R * MAX_SAMPLE_PER_RAY, 1)
+    dev = rays_o.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    if workspace is None or workspace["hit_idx"].numel() < R * max_hits:
+        workspace = dict(hit_counts=torch.empty(max(R, 1), dtype=torch.int32, device=dev),
+                         hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
+                         hit_nf=f(max(R * max_hits, 1), 2))
+    out = dict(
+        pts_offsets=torch.empty(R + 1, dtype=torch.int32, device=dev),
+        world_pts=f(pts_cap, 3) if want_world else None, warped_pts=f(pts_cap, 3), dirs=f(pts_cap, 3) if want_dirs else None,
+        dists=f(pts_cap), ts=f(pts_cap), anchors=torch.empty((pts_cap, 3), dtype=torch.int32, device=dev),
+        ray_id=torch.empty(pts_cap, dtype=torch.int32, device=dev), first_oct_dis=f(R),
+        overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace,
+    )
+    rc = _lib.lib().gfn_sample_rays(_ptr(rays_o), _ptr(rays_d), _ptr(noise), R, _ptr(compact_nodes), _ptr(transes), near, far,
+                                    max_hits, float(sample_l), int(bool(scale_by_dis)), int(bool(table_space)),
+                                    _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]), _ptr(workspace["hit_nf"]),
+                                    _ptr(out["pts_offsets"]), _ptr(out["world_pts"]), _ptr(out["warped_pts"]), _ptr(out["dirs"]),
+                                    _ptr(out["dists"]), _ptr(out["ts"]), _ptr(out["anchors"]), _ptr(out["ray_id"]),
+                                    _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _stream())
+    _lib.check(rc, "gfn_sample_rays")
+    return out
+
+
 def samples_to_dense(s, n_rays):
     """Packed sampler output -> the reference's dense GetSamples() list (PersSampler_cuda.cu:467-476)."""
     dev = s["pts_offsets"].device

@@ -145,6 +145,20 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
               float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
               int32_t* overflow_dev, void* stream);
 
+/* Fast path of GetSamples() for the training / render loop: K3 once into per-ray dense
+ * slots + K4 with a 16-lane wave row per ray; bit-identical samples to gfn_trace + gfn_march.
+ * compact_nodes: output of gfn_tree_compact (64 B per node, 64-byte aligned), to be refreshed
+ * whenever the node blob changes (gfn_update_nodes).  Workspace: hit_counts i32 [R],
+ * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2]. */
+int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void* stream);
+int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                    const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                    int max_hits, float sample_l, int scale_by_dis, int table_space,
+                    int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
+                    int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+                    float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+                    int32_t* overflow_dev, void* stream);
+
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
  * anchors i64 [R,1024,3], pts_idx_start_end i64 [R,2].  Any output may be NULL. */

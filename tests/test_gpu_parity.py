@@ -264,6 +264,54 @@ def test_march_bit_exact(oracle, ops, dev, train, fineness):
     assert int(g["overflow"].item()) == 0
 
 
+@pytest.mark.parametrize("train,fineness,n_rays", [(True, 6.0, 333), (False, 0.5, 70), (False, 16.0, 4)])
+def test_fast_sampler_bit_exact(oracle, ops, dev, train, fineness, n_rays):
+    """gfn_sample_rays (compact nodes, one-pass dense trace, 16-lane row per ray, DPP reductions) produces the
+    same bits as the oracle -- and therefore as the gfn_trace + gfn_march boundary functions."""
+    from gfnerf_amd import scene
+
+    sc, ref, gpu = _sample_both(oracle, ops, dev, n_rays=n_rays, train=train, fineness=fineness)
+    m = ref["m"]
+    noise = scene.make_noise(n_rays, train, fineness, seed=1)
+    cn = ops.tree_compact(_t(sc["nodes"], dev))
+    for table_space in (False, True):
+        g = ops.sample_rays(_t(ref["o"], dev), _t(ref["d"], dev), _t(noise, dev), cn, _t(sc["transes"], dev), 1.0 / 256, True,
+                            want_world=True, want_dirs=True, table_space=table_space)
+        po = g["pts_offsets"].cpu().numpy()
+        assert np.array_equal(po.astype(np.int64), m["pts_offsets"])
+        N = int(po[-1])
+        assert np.array_equal(g["workspace"]["hit_counts"].cpu().numpy()[:n_rays].astype(np.int64), np.diff(ref["off"]))
+        assert np.array_equal(g["anchors"].cpu().numpy()[:N].astype(np.int64), m["anchors"])
+        want_w = m["warped_pts"] if not table_space else ((m["warped_pts"] + np.float32(1.5)) * (np.float32(1) / np.float32(3))).astype(np.float32)
+        for k, want in (("ts", m["ts"]), ("dists", m["dists"]), ("warped_pts", want_w), ("world_pts", m["world_pts"]), ("dirs", m["dirs"])):
+            a = g[k].cpu().numpy()[:N]
+            assert np.array_equal(a, want), f"{k} (table_space={table_space}): max abs diff {np.abs(a - want).max()}"
+        assert np.array_equal(g["first_oct_dis"].cpu().numpy(), m["first_oct_dis"])
+        assert np.array_equal(g["ray_id"].cpu().numpy()[:N], np.repeat(np.arange(n_rays), np.diff(po)))
+        assert int(g["overflow"].item()) == 0
+
+
+def test_fast_sampler_missing_and_empty(oracle, ops, dev):
+    import torch
+
+    from gfnerf_amd import scene
+
+    sc = small_scene()
+    cn = ops.tree_compact(_t(sc["nodes"], dev))
+    o = np.array([[1000.0, 1000.0, 1000.0], [0.0, 0.0, 12.0], [900.0, 0, 0]], np.float32)
+    d = oracle.normalize_dirs(np.array([[1.0, 1.0, 1.0], [0.1, 0.2, -1.0], [1.0, 0, 0]], np.float32))
+    noise = scene.make_noise(3, False, 8.0)
+    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE)
+    off, hi, nf = oracle.trace(o, d, nodes)
+    m = oracle.march(o, d, noise, 1 / 256, True, off, hi, nf, nodes, sc["transes"].view(oracle.TRANS_INFO_DTYPE))
+    g = ops.sample_rays(_t(o, dev), _t(d, dev), _t(noise, dev), cn, _t(sc["transes"], dev), 1 / 256, True, table_space=False)
+    assert np.array_equal(g["pts_offsets"].cpu().numpy().astype(np.int64), m["pts_offsets"])
+    assert np.array_equal(g["first_oct_dis"].cpu().numpy(), m["first_oct_dis"])
+    e = torch.empty((0, 3), device=dev)
+    g0 = ops.sample_rays(e, e, _t(noise, dev), cn, _t(sc["transes"], dev), 1 / 256, True)
+    assert g0["pts_offsets"].cpu().tolist() == [0]
+
+
 def test_dense_export_matches_reference_layout(oracle, ops, dev):
     """GetSamples() return list (PersSampler_cuda.cu:437-476): dense [R,1024,.], zero padded, int64 anchors."""
     sc, ref, gpu = _sample_both(oracle, ops, dev, n_rays=64, train=False, fineness=8.0)
