@@ -323,7 +323,8 @@ __global__ __launch_bounds__(kRayBlock) void march_kernel(
 //     so a DFS visit is a single cache-line fetch instead of up to ten dependent loads
 //     from the 128-byte checkpoint struct;
 //   * the traversal runs once, writing each ray's leaves to its own dense slot
-//     (R x max_hits is small) -- no count pass, no scan, no host sync;
+//     (R x max_hits is small) -- no count pass, no scan, no host sync -- with an 8-lane
+//     group per ray that tests all children of a node in one step;
 //   * the march gives every ray a 16-lane row of a wave: lanes 0..11 own one of the
 //     12 perspective projections, the 3x12 contractions are 4-step shuffle trees in
 //     exactly the association of sum12(), and the leaf's TransInfo stays in registers
@@ -350,68 +351,92 @@ __global__ void compact_nodes_kernel(NodeView nodes, int64_t n_nodes, CompactNod
   out[u] = c;
 }
 
-// K3, one pass, dense output slots [ray*max_hits, ...); counts[ray] = number of leaves.
-__global__ __launch_bounds__(kRayBlock) void trace_dense_kernel(
+// K3 with an 8-lane group per ray: popping an internal node tests its 8 children at once (lane k
+// takes the k-th child in the ray's visiting order, each child is one 64-byte line), the survivors
+// are pushed in reverse so the DFS order -- and with it the emitted leaf list, near/far bits and the
+// max_hits cut -- is exactly that of the reference's one-child-at-a-time loop (:89-140).
+constexpr int kTG = 8;                      // lanes per ray
+constexpr int kTraceRays = 256 / kTG;       // 32 rays per workgroup
+constexpr int kTraceStack = 7 * kMaxDepth + 2;  // every expansion nets at most +7 entries per level
+
+__global__ __launch_bounds__(256) void trace_group_kernel(
     int n_rays, const CompactNode* __restrict__ nodes, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float near_bound, float far_bound, int max_hits,
     int* __restrict__ counts, int* __restrict__ hit_idx, float2* __restrict__ hit_nf, int* __restrict__ overflow) {
-  __shared__ int s_node[kMaxDepth][kRayBlock];
-  __shared__ signed char s_child[kMaxDepth][kRayBlock];
-  const int lane = threadIdx.x;
-  const int ray = blockIdx.x * kRayBlock + lane;
-  if (ray >= n_rays) return;
-  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
-  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
-  const int64_t out_base = (int64_t)ray * max_hits;
+  __shared__ int s_id[kTraceRays][kTraceStack];       // >= 0: internal node to expand; < 0: ~leaf id to emit
+  __shared__ float2 s_nf[kTraceRays][kTraceStack];
+  const int k = threadIdx.x & (kTG - 1);
+  const int slot = threadIdx.x / kTG;
+  const int ray = blockIdx.x * kTraceRays + slot;
+  const bool in_range = ray < n_rays;
+  const int r = in_range ? ray : 0;
+  const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+  const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+  const int64_t out_base = (int64_t)r * max_hits;
   const int ray_st = ((d[0] > 0.f) << 2) | ((d[1] > 0.f) << 1) | (d[2] > 0.f);
+  const int my_child_slot = search_child(ray_st, k);
+  const int gshift = (threadIdx.x & 63) & ~(kTG - 1);  // bit position of this group inside the wave ballot
   int sp = 0, cnt = 0;
-  s_node[0][lane] = 0;
-  s_child[0][lane] = -1;
-  while (sp >= 0 && cnt < max_hits) {
-    const int u = s_node[sp][lane];
-    int child_ptr = s_child[sp][lane];
-    // the whole node in one 64-byte fetch
-    const int4* np = reinterpret_cast<const int4*>(nodes + u);
+  if (in_range) {  // root (:84-86)
+    const int4* np = reinterpret_cast<const int4*>(nodes);
     const int4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-    const int ch[8] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    bool descend = true;
-    if (child_ptr == -1) {
-      float cur_near = near_bound, cur_far = far_bound;
-      get_intersection(o, d, make_float4(__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z), __int_as_float(w0.w)),
-                       cur_near, cur_far);
-      if (cur_near < cur_far) {
-        child_ptr = 0;
-        while (child_ptr < 8 && ch[search_child(ray_st, child_ptr)] < 0) child_ptr++;
-        if (child_ptr >= 8) {
-          if (w3.x >= 0) {  // trans_idx
-            hit_idx[out_base + cnt] = u;
-            hit_nf[out_base + cnt] = make_float2(cur_near, cur_far);
-            cnt++;
-          }
-          descend = false;
-        }
-      } else {
-        descend = false;
+    float nr = near_bound, fr = far_bound;
+    get_intersection(o, d, make_float4(__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z), __int_as_float(w0.w)), nr, fr);
+    if (nr < fr) {
+      const bool leaf = w1.x < 0 && w1.y < 0 && w1.z < 0 && w1.w < 0 && w2.x < 0 && w2.y < 0 && w2.z < 0 && w2.w < 0;
+      if (!leaf) {
+        if (k == 0) { s_id[slot][0] = 0; s_nf[slot][0] = make_float2(nr, fr); }
+        sp = 1;
+      } else if (w3.x >= 0) {
+        if (k == 0) { s_id[slot][0] = ~0; s_nf[slot][0] = make_float2(nr, fr); }
+        sp = 1;
       }
-    } else {
-      child_ptr = child_ptr + 1;
-      while (child_ptr < 8 && ch[search_child(ray_st, child_ptr)] < 0) child_ptr++;
-      if (child_ptr >= 8) descend = false;
-    }
-    if (descend) {
-      s_child[sp][lane] = (signed char)child_ptr;
-      if (sp + 1 < kMaxDepth) {
-        sp++;
-        s_node[sp][lane] = ch[search_child(ray_st, child_ptr)];
-        s_child[sp][lane] = -1;
-      } else if (overflow) {
-        atomicOr(overflow, 2);
-      }
-    } else {
-      sp--;
     }
   }
-  counts[ray] = cnt;
+  bool active = in_range && sp > 0 && cnt < max_hits;
+  while (__any(active)) {
+    bool keep = false, leaf_child = false;
+    int ck = -1;
+    float cn = 0.f, cf = 0.f;
+    if (active) {
+      const int e = s_id[slot][sp - 1];
+      const float2 enf = s_nf[slot][sp - 1];
+      sp--;
+      if (e < 0) {  // leaf with a valid transform: emit (:110-117)
+        if (k == 0) {
+          hit_idx[out_base + cnt] = ~e;
+          hit_nf[out_base + cnt] = enf;
+        }
+        cnt++;
+      } else {
+        ck = nodes[e].child[my_child_slot];
+        if (ck >= 0) {
+          const int4* np = reinterpret_cast<const int4*>(nodes + ck);
+          const int4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+          cn = near_bound; cf = far_bound;
+          get_intersection(o, d, make_float4(__int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z), __int_as_float(w0.w)), cn, cf);
+          leaf_child = w1.x < 0 && w1.y < 0 && w1.z < 0 && w1.w < 0 && w2.x < 0 && w2.y < 0 && w2.z < 0 && w2.w < 0;
+          keep = (cn < cf) && (!leaf_child || w3.x >= 0);
+        }
+      }
+    }
+    const unsigned mask = (unsigned)((__ballot(keep) >> gshift) & 0xFFull);  // wave-uniform call
+    if (active && mask) {
+      const int n_push = __popc(mask);
+      if (sp + n_push <= kTraceStack) {
+        if (keep) {
+          const int pos = sp + __popc(mask >> (k + 1));  // reverse order: first child ends on top
+          s_id[slot][pos] = leaf_child ? ~ck : ck;
+          s_nf[slot][pos] = make_float2(cn, cf);
+        }
+        sp += n_push;
+      } else if (overflow && k == 0) {
+        atomicOr(overflow, 2);
+      }
+    }
+    active = in_range && sp > 0 && cnt < max_hits;
+  }
+  if (in_range && k == 0) counts[ray] = cnt;
 }
 
 // tree sum of one value per lane over lanes 0..11 of each 16-lane row, association of sum12():
@@ -781,7 +806,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
   GFN_CHECK_ARG(pts_cap >= n_rays && pts_cap * 3 < (1ll << 31), "gfn_sample_rays: pts_cap=%lld must be in [n_rays, 2^31/3)",
                 (long long)pts_cap);
   const CompactNode* cn = reinterpret_cast<const CompactNode*>(compact_nodes);
-  trace_dense_kernel<<<(unsigned)((n_rays + kRayBlock - 1) / kRayBlock), kRayBlock, 0, st>>>(
+  trace_group_kernel<<<(unsigned)((n_rays + kTraceRays - 1) / kTraceRays), 256, 0, st>>>(
       (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
       reinterpret_cast<float2*>(hit_near_far), overflow_dev);
   GFN_CHECK_LAUNCH();

@@ -119,7 +119,11 @@ def test_training_f16_gradient_pool(setup):
         hp32.cfg.grad_f16, hp32.table_grad = old, None
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() < 5e-3 * scale
-    assert np.all(got[ref == 0] == 0)
+    # slots nobody touched stay exactly zero; a slot whose f32 sum cancels exactly may keep an f16 ulp
+    untouched = np.ones(ref.size, bool)
+    untouched[: 17 * (1 << S["cfg"].log2_T)] = False
+    assert np.all(got.reshape(-1)[untouched] == 0)
+    assert np.abs(got[ref == 0]).max() <= 1e-4 * scale
 
 
 def test_train_steps_reduce_loss(setup):
