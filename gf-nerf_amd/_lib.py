@@ -16,6 +16,8 @@ SIGNATURES = {
     "gfn_hash_level_scales_host": (None, [_vp]),
     "gfn_hash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_table_pair_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "gfn_hash_fwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
@@ -30,6 +32,8 @@ SIGNATURES = {
     "gfn_linear_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "gfn_linear_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                               _vp]),
+    "gfn_field_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_field_bwd_dx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -38,7 +42,7 @@ SIGNATURES = {
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp]),
-    "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
     "gfn_octree_build_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _u64, _i32, C.POINTER(_vp),
                                      C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),

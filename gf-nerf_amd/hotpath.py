@@ -37,6 +37,7 @@ class HotPathConfig:
     use_appearance_embedding: bool = True  # config.py:50
     table_f16_shadow: bool = True    # gather from f16 shadows refreshed by the Adam kernel (same values as :185's cast)
     grad_f16: bool = True            # table gradient pool in f16 with the x128 loss scale, like the reference (:151,:209)
+    fused_field: bool = True         # decoder as one kernel per direction (needs hidden == 128)
 
 
 class HotPath:
@@ -78,6 +79,7 @@ class HotPath:
         self.table_grad = None
         self.table16 = None
         self.blocks16 = []
+        self._pairs_stale = False
         self.refresh_shadows()
         self._adam = {}
         self.step = 0
@@ -93,7 +95,9 @@ class HotPath:
             self.table16 = ops.table_to_f16(self.table, self.table16)
             if len(self.blocks16) != len(self.blocks):
                 self.blocks16 = [None] * len(self.blocks)
-            self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+            # focal stage: global + block interleaved per slot (one 8-byte gather per corner)
+            self.blocks16 = [ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+        self._pairs_stale = False
 
     def _timed(self, name, fn, *a, **k):
         if name not in self.timed_ops and "*" not in self.timed_ops:
@@ -127,24 +131,37 @@ class HotPath:
         return s
 
     # -------------------------------------------------------------------- field
-    def _field_forward(self, s, cam_idx, block=None):
-        """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples."""
+    def _field_forward(self, s, cam_idx, block=None, fused=None, save=False):
+        """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples.
+        fused: one decoder kernel (sigma, rgb [+ ReLU masks when save]); else the per-layer kernels,
+        which keep every activation (needed for the weight gradients of the global stage)."""
         n_dev = s["n_dev"]
         T, V = self.cfg.log2_T, self.n_volumes
-        if self.cfg.table_f16_shadow:  # one pass; the residual block table (nerfacto_field.py:485-486) fused in
+        fused = (self.cfg.fused_field and self.cfg.hidden == 128) if fused is None else fused
+        if block is not None and self._pairs_stale:  # the global table moved since the interleaved images were built
+            self.refresh_shadows()
+        if self.cfg.table_f16_shadow and block is not None:  # residual block table (nerfacto_field.py:485-486) fused in
+            feat = self._timed("hash_fwd", ops.hash_fwd_pair, self.blocks16[block], self.prim, self.bias_arg, s["warped_pts"],
+                               s["anchors"], V, T, n_dev=n_dev)
+        elif self.cfg.table_f16_shadow:
             feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
-                               s["anchors"], V, T, table2_f16=None if block is None else self.blocks16[block], n_dev=n_dev)
+                               s["anchors"], V, T, n_dev=n_dev)
         else:
             feat = self._timed("hash_fwd", ops.hash_fwd, self.table, self.prim, self.bias_arg, s["warped_pts"], s["anchors"],
                                V, T, n_dev=n_dev)
             if block is not None:
                 self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.prim, self.bias_arg, s["warped_pts"],
                             s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
+        emb = self.emb if self.cfg.use_appearance_embedding else None
+        if fused:
+            sh = ops.sh4(s["dirs_unit"])
+            out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save)
+            out["feat"] = feat
+            return out
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
         a1 = self._timed("base_fwd", ops.linear_fwd, feat, bW0, bb0, "relu", n_dev=n_dev)
         h = self._timed("base_fwd", ops.linear_fwd, a1, bW1, bb1, "none", n_dev=n_dev)
         sh = ops.sh4(s["dirs_unit"])
-        emb = self.emb if self.cfg.use_appearance_embedding else None
         sigma, xh = self._timed("head_pack", ops.head_pack, h, sh, emb, cam_idx, s["ray_id"], n_dev=n_dev)
         c1 = self._timed("head_fwd", ops.linear_fwd, xh, hW0, hb0, "relu", n_dev=n_dev, in_dim=63)
         c2 = self._timed("head_fwd", ops.linear_fwd, c1, hW1, hb1, "relu", n_dev=n_dev)
@@ -186,12 +203,18 @@ class HotPath:
         self._timed("zero_grads", self.zero_grads, stage, block)
         s = self.sample(rays_o, rays_d_raw, noise)
         n_dev = s["n_dev"]
-        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None)
+        fused = (not train_mlp) and c.fused_field and c.hidden == 128  # frozen decoder: masks are all the backward needs
+        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None, fused=fused, save=fused)
         comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
                            early_T=c.early_T)
         loss, g_rgb = ops.charbonnier(comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
         d_sigma, d_rgb = self._timed("composite_bwd", ops.composite_bwd, s["pts_offsets"], f["sigma"], s["dists"], f["rgb"],
                                      g_rgb, None, early_T=c.early_T)
+        if fused:
+            dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev)
+            self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
+                        c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
+            return loss, dict(samples=s, field=f, comp=comp)
         (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = self.layers
         g = self.layer_grads
         gw = lambda i: (g[i][0], g[i][1]) if train_mlp else (None, None)  # noqa: E731
@@ -217,6 +240,7 @@ class HotPath:
             m, v = self._adam_state("table", self.table)
             self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self.step, lr=c.lr, eps=c.adam_eps,
                         shadow_f16=self.table16, n=n_live)
+            self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
             for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
@@ -226,7 +250,7 @@ class HotPath:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
             self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps,
-                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live)
+                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live, shadow_pair=True)
 
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""

@@ -110,6 +110,36 @@ def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_
     return out
 
 
+def table_pair_f16(global_pool, block_pool, out=None):
+    """Interleaved f16 image {global.ch0, global.ch1, block.ch0, block.ch1} per slot for hash_fwd_pair."""
+    _chk(global_pool, torch.float32, "global_pool"); _chk(block_pool, torch.float32, "block_pool")
+    if global_pool.numel() != block_pool.numel():
+        raise _lib.GfnError("tables differ in size")
+    if out is None:
+        out = torch.empty(global_pool.numel() * 2, dtype=torch.float16, device=global_pool.device)
+    _chk(out, torch.float16, "out")
+    _lib.check(_lib.lib().gfn_table_pair_f16(_ptr(global_pool), _ptr(block_pool), _ptr(out), global_pool.numel(), _stream()),
+               "gfn_table_pair_f16")
+    return out
+
+
+def hash_fwd_pair(pair_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, out=None, n_dev=None):
+    _chk(pair_f16, torch.float16, "pair_f16"); _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool")
+    _chk(pts, torch.float32, "pts", 3); _chk(anchors, anchors.dtype, "anchors")
+    n = pts.shape[0]
+    if pair_f16.numel() != 16 * (1 << log2_T) * 4:
+        raise _lib.GfnError("pair table has the wrong size")
+    stride = _anchor_stride(anchors, n)
+    if out is None:
+        out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
+    _chk(out, torch.float32, "out", 32)
+    rc = _lib.lib().gfn_hash_fwd_pair(_ptr(pair_f16), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
+                                      int(anchors.dtype == torch.int64), stride, n, _ptr(n_dev), n_volumes, log2_T, _ptr(out),
+                                      _stream())
+    _lib.check(rc, "gfn_hash_fwd_pair")
+    return out
+
+
 def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, grad_pool=None, n_dev=None, grad_f16=False):
     """Scatter grad_out [n,32] into grad_pool [16*T,2] (accumulating; allocated zeroed if None).
     grad_f16: pool is float16 and keeps the reference's x128 scale (packed f16 atomics)."""
@@ -324,6 +354,50 @@ def linear_bwd(x, W, y, dy, act="none", need_dx=True, dW=None, db=None, dx=None,
     return (dx if need_dx else None), dW, db
 
 
+def _weight_ptrs(layers):
+    """10 device pointers {W,b} x {base0, base1, head0, head1, head2} as a C array (kept alive by the caller)."""
+    shapes = [(128, 32), (16, 128), (128, 63), (128, 128), (3, 128)]
+    if len(layers) != 5:
+        raise _lib.GfnError("expected 5 (W, b) layers")
+    ptrs = []
+    for (W, b), shp in zip(layers, shapes):
+        _chk(W, torch.float32, "W"); _chk(b, torch.float32, "b")
+        if tuple(W.shape) != shp or b.numel() != shp[0]:
+            raise _lib.GfnError(f"fused field kernels need hidden_dim 128 layers, got {tuple(W.shape)} (expected {shp})")
+        ptrs += [W.data_ptr(), b.data_ptr()]
+    return (C.c_void_p * 10)(*ptrs)
+
+
+def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False):
+    """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None)."""
+    _chk(feat, torch.float32, "feat", 32); _chk(ray_id, torch.int32, "ray_id"); _chk(sh, torch.float32, "sh", 16)
+    _chk(emb, torch.float32, "emb", 32); _chk(cam_idx, torch.int32, "cam_idx")
+    n = feat.shape[0]
+    dev = feat.device
+    sigma = torch.empty(n, dtype=torch.float32, device=dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    h0 = torch.empty(n, dtype=torch.float32, device=dev) if save else None
+    masks = torch.empty((n, 6), dtype=torch.int64, device=dev) if save else None
+    wp = _weight_ptrs(layers)
+    rc = _lib.lib().gfn_field_fwd(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), wp, n, _ptr(n_dev), _ptr(sigma),
+                                  _ptr(rgb), _ptr(h0), _ptr(masks), _stream())
+    _lib.check(rc, "gfn_field_fwd")
+    return dict(sigma=sigma, rgb=rgb, h0=h0, masks=masks)
+
+
+def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None):
+    """Fused decoder backward w.r.t. the hash features (decoder frozen) -> dfeat [n,32]."""
+    _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
+    _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6)
+    n = d_sigma.shape[0]
+    dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
+    wp = _weight_ptrs(layers)
+    rc = _lib.lib().gfn_field_bwd_dx(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), wp, n, _ptr(n_dev), _ptr(dfeat),
+                                     _stream())
+    _lib.check(rc, "gfn_field_bwd_dx")
+    return dfeat
+
+
 def sh4(dirs):
     _chk(dirs, torch.float32, "dirs", 3)
     out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)
@@ -412,7 +486,7 @@ def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15):
                                         float(beta2), float(eps), _stream()), "gfn_adam_step")
 
 
-def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None):
+def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None, shadow_pair=False):
     """Adam on (the first n elements of) a hash table; g float32, or float16 carrying the x128 loss scale."""
     _chk(p, torch.float32, "p"); _chk(m, torch.float32, "m"); _chk(v, torch.float32, "v"); _chk(shadow_f16, torch.float16, "shadow")
     if g.dtype not in (torch.float32, torch.float16):
@@ -424,7 +498,7 @@ def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15
     g16 = g.dtype == torch.float16
     _lib.check(_lib.lib().gfn_adam_step_ex(_ptr(p), _ptr(g), int(g16), (1.0 / 128.0) if g16 else 1.0, _ptr(m), _ptr(v), n,
                                            int(step), float(lr), float(beta1), float(beta2), float(eps), _ptr(shadow_f16),
-                                           _stream()), "gfn_adam_step_ex")
+                                           int(bool(shadow_pair)), _stream()), "gfn_adam_step_ex")
 
 
 def fill_zero(t):

@@ -100,6 +100,15 @@ int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, cons
                      const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
                      int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                      float* out, void* stream);
+/* Focal stage with the two tables INTERLEAVED per slot (u16 [16*T*4]: {global.ch0, global.ch1,
+ * block.ch0, block.ch1} as f16): one 8-byte gather per corner instead of two 4-byte gathers;
+ * out = feat(global) + feat(block), bit-identical to the two-table forms.  Built by
+ * gfn_table_pair_f16; the block half is kept current by gfn_adam_step_ex (shadow_pair = 1). */
+int gfn_table_pair_f16(const float* global_pool, const float* block_pool, uint16_t* pair_f16, int64_t n_elems,
+                       void* stream);
+int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const float* bias_pool, const float* pts,
+                      const void* anchors, int anchors_i64, int anchor_stride, int64_t n_max, const int32_t* n_dev,
+                      int64_t n_volumes, int log2_T, float* out, void* stream);
 /* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
 int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
 
@@ -191,6 +200,21 @@ int gfn_linear_bwd(const float* x, int ldx, const float* W, const float* y, int 
                    const float* dy, int lddy, int64_t n_max, const int32_t* n_dev, int in_dim,
                    int out_dim, int act, float* dx, int lddx, float* dW, float* db, void* stream);
 
+/* The whole decoder in one launch (nerfacto_field.py:455-555): feat f32 [n,32] (hash features)
+ * -> base_network -> sigma = trunc_exp(h0+1); [SH | geo | appearance] -> mlp_head -> rgb.
+ * weights: 10 device pointers {bW0[128,32], bb0, bW1[16,128], bb1, hW0[128,63], hb0,
+ * hW1[128,128], hb1, hW2[3,128], hb2} (hidden_dim 128, config.py:124-125).  sh f32 [R,16]
+ * (gfn_sh4), emb f32 [n_cams,32] or NULL (zeros), cam_idx i32 [R], ray_id i32 [n].
+ * h0 f32 [n] and masks u64 [n,3,2] (ReLU bit masks of the three 128-wide layers) are written
+ * when non-NULL and are all the backward needs. */
+int gfn_field_fwd(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
+                  const int32_t* cam_idx, const float* const* weights, int64_t n_max,
+                  const int32_t* n_dev, float* sigma, float* rgb, float* h0, uint64_t* masks, void* stream);
+/* (d_sigma [n], d_rgb [n,3]) -> dfeat f32 [n,32] with the decoder frozen (focal stage). */
+int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
+                     const uint64_t* masks, const float* const* weights, int64_t n_max,
+                     const int32_t* n_dev, float* dfeat, void* stream);
+
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
  * default output.  dirs f32 [R,3] -> out f32 [R,16]. */
@@ -239,10 +263,11 @@ int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
                   float beta1, float beta2, float eps, void* stream);
 /* Adam for a hash table: g is f32 (g_f16 == 0) or f16 (g_f16 != 0) and is multiplied by
  * g_scale first (1/128 for gfn_hash_bwd's f16 pool); shadow_f16 (may be NULL) receives
- * f16(p) of every updated element so gfn_hash_fwd_f16 stays current. */
+ * f16(p) of every updated element so gfn_hash_fwd_f16 stays current (shadow_pair != 0: the
+ * shadow is the block half of a gfn_table_pair_f16 image). */
 int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
-                     void* stream);
+                     int shadow_pair, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
 
 /* ====================================================================== *

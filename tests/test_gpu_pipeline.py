@@ -66,6 +66,58 @@ def test_render_matches_oracle(setup, block):
     assert out["oct_depth"].min() > 0  # nerfacto.py:556
 
 
+def test_fused_decoder_matches_per_layer_kernels(setup):
+    """gfn_field_fwd / gfn_field_bwd_dx (one kernel per direction) against the per-layer kernels and the oracle."""
+    import torch
+
+    from gfnerf_amd import ops
+
+    S = setup
+    hp, t = S["hp"], S["t"]
+    s = hp.sample(t(S["o"]), t(S["d"]), t(S["noise"]))
+    cam = t(S["cam"])
+    N = int(s["pts_offsets"][-1].item())
+    fu = hp._field_forward(s, cam, block=0, fused=True, save=True)
+    un = hp._field_forward(s, cam, block=0, fused=False)
+    np.testing.assert_allclose(fu["sigma"].cpu().numpy()[:N], un["sigma"].cpu().numpy()[:N], rtol=2e-5)
+    np.testing.assert_allclose(fu["rgb"].cpu().numpy()[:N], un["rgb"].cpu().numpy()[:N], atol=2e-6)
+    np.testing.assert_allclose(fu["h0"].cpu().numpy()[:N], un["h"].cpu().numpy()[:N, 0], rtol=2e-5, atol=2e-6)
+    # ReLU masks reproduce the sign pattern of the stored activations (bit r + 16 t of word (layer, h))
+    masks = fu["masks"].cpu().numpy()[:N].view(np.uint64).reshape(N, 3, 2)
+    for li, key in enumerate(("a1", "c1", "c2")):
+        act = un[key].cpu().numpy()[:N]
+        bits = np.zeros((N, 128), bool)
+        for h in range(2):
+            for tt in range(4):
+                for r in range(16):
+                    bits[:, 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h] = (masks[:, li, h] >> np.uint64(tt * 16 + r)) & np.uint64(1)
+        agree = (bits == (act > 0)).mean()
+        assert agree > 0.9999, (key, agree)  # an activation within an ulp of zero may flip
+    # backward: random upstream gradients, some rows exactly zero (dead samples)
+    rng = np.random.default_rng(1)
+    cap = s["ts"].shape[0]
+    d_sigma = np.zeros(cap, np.float32); d_rgb = np.zeros((cap, 3), np.float32)
+    d_sigma[:N] = rng.standard_normal(N) * 1e-2
+    d_rgb[:N] = rng.standard_normal((N, 3)) * 1e-1
+    dead = rng.random(N) < 0.3
+    dead[: 64] = True
+    d_sigma[:N][dead] = 0; d_rgb[:N][dead] = 0
+    dfeat = ops.field_bwd_dx(t(d_sigma), t(d_rgb), fu["rgb"], fu["h0"], fu["masks"], hp.layers, n_dev=s["n_dev"]).cpu().numpy()[:N]
+    (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = hp.layers
+    n_dev = s["n_dev"]
+    dc2, _, _ = ops.linear_bwd(un["c2"], hW2, un["rgb"], t(d_rgb), "sigmoid", need_dw=False, n_dev=n_dev)
+    dc1, _, _ = ops.linear_bwd(un["c1"], hW1, un["c2"], dc2, "relu", need_dw=False, n_dev=n_dev)
+    dxh, _, _ = ops.linear_bwd(un["xh"], hW0, un["c1"], dc1, "relu", need_dw=False, n_dev=n_dev, in_dim=63)
+    dh = ops.head_unpack_bwd(un["h"], t(d_sigma), dxh, cam, s["pts_offsets"], n_dev=n_dev)
+    da1, _, _ = ops.linear_bwd(un["a1"], bW1, un["h"], dh, "none", need_dw=False, n_dev=n_dev)
+    want, _, _ = ops.linear_bwd(un["feat"], bW0, un["a1"], da1, "relu", need_dw=False, n_dev=n_dev)
+    want = want.cpu().numpy()[:N]
+    assert np.all(dfeat[dead] == 0)
+    # an activation within rounding of zero can sit on opposite sides of the ReLU in the two paths: allow a few flips
+    bad = ~np.isclose(dfeat, want, rtol=1e-3, atol=1e-5 * np.abs(want).max())
+    assert bad.mean() < 1e-4, bad.mean()
+
+
 def test_early_termination_within_tolerance(setup):
     S = setup
     hp, t = S["hp"], S["t"]
