@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
     ap.add_argument("--cpu-rays", type=int, default=96, help="rays in the bounded cpu_baseline sample")
+    ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
+    ap.add_argument("--share-block-primes", action="store_true",
+                    help="block tables reuse the global table's primes (enables the interleaved one-gather-per-corner image); "
+                         "default: own primes per table like the reference")
     return ap.parse_args()
 
 
@@ -114,7 +118,7 @@ def main():
     t_build = time.perf_counter() - t_build
     n_cams = sc["c2w"].shape[0]
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
-    cfg = hotpath.HotPathConfig(log2_T=args.log2_T)
+    cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks)
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
         g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
@@ -147,7 +151,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     # dominant kernel: timed live with events on the launch stream (torch's current stream)
-    hp.timed_ops = {"*"} if args.stage_times else {"hash_bwd"}
+    hp.timed_ops = {"*"} if args.stage_times else {"hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,14 +178,27 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = N_RAYS * world * args.steps / elapsed
-        # roofline of the dominant kernel (hash table gradient scatter): algorithmic bytes per sample =
-        # 16 levels x 8 corners x 2 ch x 2 B packed-f16 atomic adds (512 B) + 128 B grad + 16 B point/anchor
-        ev = hp.timings.get("hash_bwd", [])
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
-        alg_bytes = n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)
-        roofline = dict(bound="hbm", kernel="hash_bwd_kernel", achieved=(alg_bytes / (kern_ms * 1e-3) / 1e9) if kern_ms else None,
-                        peak=HBM_PEAK_GBS, unit="GB/s", frac=(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms else None,
-                        traffic=None, avg_kernel_ms=kern_ms, alg_bytes_per_launch=alg_bytes)
+        # per-kernel event timings over the timed region; the dominant one carries the roofline.
+        # Algorithmic bytes per sample (DESIGN.md "Kernels"): hash lookup = 16 levels x 8 corners x 4 B f16x2 per
+        # table (512 B/table) + 16 B point/anchor + 128 B features written; hash scatter = 16 x 8 x 4 B
+        # packed-f16 atomic adds + 128 B gradient read + 16 B point/anchor.
+        n_tables = 2 if args.stage == "focal" else 1
+        alg = {"hash_fwd": n_live * (512 * n_tables + 16 + 128), "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)}
+        kern = {}
+        for name, ev in hp.timings.items():
+            kern[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
+        kern_ms = kern[dom]
+        alg_bytes = alg[dom]
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
+        traffic = None
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get(f"{dom}:{args.stage}")
+        roofline = dict(bound="hbm", kernel=dom + "_kernel", achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
+                        alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()})
+        w = aux["comp"]["weights"][:n_live]
+        alive_frac = float((w > 0).float().mean().item()) if w is not None else None
         out = dict(metric="train_rays_per_sec", value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    samples_per_sec=value * n_live / N_RAYS,
@@ -192,7 +209,9 @@ def main():
                                         f"4096 rays x {target} samples, Rubble-scale synthetic cameras",
                                rays_per_batch=N_RAYS, mean_samples_per_ray=n_live / N_RAYS, log2_table_size=args.log2_T,
                                n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
-                               fineness=fineness, stage=args.stage, early_T=cfg.early_T, mlp="f32 MFMA 32x32x2",
+                               fineness=fineness, stage=args.stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
+                               block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
+                               mlp="f32 MFMA 32x32x2",
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
                                scene_build_s=round(t_build, 1), loss=float(loss.item())),

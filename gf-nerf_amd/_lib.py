@@ -15,7 +15,7 @@ SIGNATURES = {
     "gfn_device_count": (_i32, []),
     "gfn_hash_level_scales_host": (None, [_vp]),
     "gfn_hash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_pair_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "gfn_hash_fwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),

@@ -126,8 +126,8 @@ template <typename AnchorT, bool F16, bool DUAL, bool PAIR = false>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, int64_t n_volumes, int log2_T, LevelScales sc,
     const void* __restrict__ table_a, const void* __restrict__ table_b, const int* __restrict__ prim_pool,
-    const float* __restrict__ bias_pool, const float* __restrict__ pts, const AnchorT* __restrict__ anchors,
-    int anchor_stride, int accumulate, float* __restrict__ out) {
+    const int* __restrict__ prim_pool_b, const float* __restrict__ bias_pool, const float* __restrict__ pts,
+    const AnchorT* __restrict__ anchors, int anchor_stride, int accumulate, float* __restrict__ out) {
   const int64_t n = gfn_live_n(n_max, n_dev);
   const uint32_t T = 1u << log2_T;
   // wave-uniform trip count: every lane of a wave runs the same number of iterations
@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(
       if (PAIR) r = gather_level_pair(table_a, (int64_t)level * T, c);
       else r = gather_level<F16>(table_a, (int64_t)level * T, c);
       if (DUAL && !PAIR) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486): f32 add of two f16-valued terms
+        // every Hash3DAnchored draws its own primes (Hash3DAnchored.cpp:43-50): same cell and weights, other slots
+        if (prim_pool_b) hash_corners(px, py, pz, sc.s[level], prim_pool_b + 3 * tr, bias_pool ? bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
         const float2 r2 = gather_level<F16>(table_b, (int64_t)level * T, c);
         r.x = r.x + r2.x; r.y = r.y + r2.y;
       }
@@ -274,10 +276,10 @@ unsigned point_grid(int64_t n_max) {
 
 template <typename AnchorT>
 void launch_fwd(bool f16, bool dual, unsigned grid, hipStream_t st, int64_t n_max, const int32_t* n_dev, int64_t V,
-                int log2_T, const LevelScales& sc, const void* ta, const void* tb, const int* prim, const float* bias,
-                const float* pts, const AnchorT* anchors, int stride, int accumulate, float* out) {
+                int log2_T, const LevelScales& sc, const void* ta, const void* tb, const int* prim, const int* prim_b,
+                const float* bias, const float* pts, const AnchorT* anchors, int stride, int accumulate, float* out) {
 #define GFN_FWD(F, D)                                                                                              \
-  hash_fwd_kernel<AnchorT, F, D><<<grid, 256, 0, st>>>(n_max, n_dev, V, log2_T, sc, ta, tb, prim, bias, pts, anchors, \
+  hash_fwd_kernel<AnchorT, F, D><<<grid, 256, 0, st>>>(n_max, n_dev, V, log2_T, sc, ta, tb, prim, prim_b, bias, pts, anchors, \
                                                        stride, accumulate, out)
   if (f16) { if (dual) GFN_FWD(true, true); else GFN_FWD(true, false); }
   else     { if (dual) GFN_FWD(false, true); else GFN_FWD(false, false); }
@@ -285,7 +287,7 @@ void launch_fwd(bool f16, bool dual, unsigned grid, hipStream_t st, int64_t n_ma
 }
 
 int hash_fwd_impl(const char* fn, const void* ta, const void* tb, bool f16, const int32_t* prim_pool,
-                  const float* bias_pool, const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
+                  const int32_t* prim_pool_b, const float* bias_pool, const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
                   int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T, int accumulate, float* out,
                   void* stream) {
   if (n_max == 0) return GFN_OK;  // empty batch: pointers may be null
@@ -297,10 +299,10 @@ int hash_fwd_impl(const char* fn, const void* ta, const void* tb, bool f16, cons
   const unsigned grid = point_grid(n_max);
   hipStream_t st = gfn_stream(stream);
   if (anchors_i64)
-    launch_fwd<int64_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, bias_pool, pts,
+    launch_fwd<int64_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, prim_pool_b, bias_pool, pts,
                         (const int64_t*)anchors, anchor_stride, accumulate, out);
   else
-    launch_fwd<int32_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, bias_pool, pts,
+    launch_fwd<int32_t>(f16, tb != nullptr, grid, st, n_max, n_dev, n_volumes, log2_T, sc, ta, tb, prim_pool, prim_pool_b, bias_pool, pts,
                         (const int32_t*)anchors, anchor_stride, accumulate, out);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
@@ -349,10 +351,10 @@ int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const 
   hipStream_t st = gfn_stream(stream);
   if (anchors_i64)
     hash_fwd_kernel<int64_t, true, true, true><<<grid, 256, 0, st>>>(n_max, n_dev, n_volumes, log2_T, sc, pair_f16, nullptr, prim_pool,
-                                                                    bias_pool, pts, (const int64_t*)anchors, anchor_stride, 0, out);
+                                                                    nullptr, bias_pool, pts, (const int64_t*)anchors, anchor_stride, 0, out);
   else
     hash_fwd_kernel<int32_t, true, true, true><<<grid, 256, 0, st>>>(n_max, n_dev, n_volumes, log2_T, sc, pair_f16, nullptr, prim_pool,
-                                                                    bias_pool, pts, (const int32_t*)anchors, anchor_stride, 0, out);
+                                                                    nullptr, bias_pool, pts, (const int32_t*)anchors, anchor_stride, 0, out);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -369,15 +371,15 @@ int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* 
                  const float* pts, const void* anchors, int anchors_i64, int anchor_stride,
                  int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                  int accumulate, float* out, void* stream) {
-  return hash_fwd_impl("gfn_hash_fwd", feat_pool, nullptr, false, prim_pool, bias_pool, pts, anchors, anchors_i64,
+  return hash_fwd_impl("gfn_hash_fwd", feat_pool, nullptr, false, prim_pool, nullptr, bias_pool, pts, anchors, anchors_i64,
                        anchor_stride, n_max, n_dev, n_volumes, log2_T, accumulate, out, stream);
 }
 
 int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                     const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
+                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
                      int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                      float* out, void* stream) {
-  return hash_fwd_impl("gfn_hash_fwd_f16", table_f16, table2_f16, true, prim_pool, bias_pool, pts, anchors, anchors_i64,
+  return hash_fwd_impl("gfn_hash_fwd_f16", table_f16, table2_f16, true, prim_pool, table2_f16 ? prim_pool2 : nullptr, bias_pool, pts, anchors, anchors_i64,
                        anchor_stride, n_max, n_dev, n_volumes, log2_T, 0, out, stream);
 }
 

@@ -1,0 +1,303 @@
+"""PersSampler (gfnerf/perssampler.py:48-135,350-530) on the HIP kernels.
+
+`_NativePersSampler` mirrors the TorchScript class my_classes.PersSampler (bindings.cpp:18-299,359-398): InitSampler
+with the reference's 18 positional arguments, GetSamples -> the 8 dense tensors of PersSampler_cuda.cu:467-476,
+UpdateOctNodes / UpdateRayMarch / UpdateMode / UpdateBlockIdxs, States / LoadStates with the reference's blobs, and
+the get_*_ accessors.  Internally samples stay packed; the dense tensors are an export for callers that want the
+reference's layout.  Not implemented yet: ProcOctree (compaction / subdivision at milestones, PersSampler.cpp:
+154-417) -- UpdateOctNodes performs K5/K6 and the statistics update only."""
+import math
+from typing import Any, List, Mapping
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .rays import RayBundle, RaySamples, WarpedSamples
+
+TRAIN, VALIDATE = 0, 1
+INIT_NODE_STAT = 1000
+_NODE_DT = np.dtype({"names": ["center", "side_len", "parent", "childs", "is_leaf_node", "trans_idx", "block_idx"],
+                     "formats": [("<f4", 3), "<f4", "<i8", ("<i8", 8), "u1", "<i8", "<i8"],
+                     "offsets": [0, 12, 16, 24, 88, 96, 104], "itemsize": 128})
+_TRANS_DT = np.dtype({"names": ["w2xz", "weight", "center", "side_len", "dis_summary"],
+                      "formats": [("<f4", (12, 2, 4)), ("<f4", (3, 12)), ("<f4", 3), "<f4", "<f4"],
+                      "offsets": [0, 384, 528, 540, 544], "itemsize": 576})
+
+
+class _NativePersSampler:
+    def __init__(self):
+        self.initialised = False
+
+    def InitSampler(self, split_dist_thres, sub_div_milestones, compact_freq, max_oct_intersect_per_ray, global_near,
+                    scale_by_dis, bbox_levels, sample_l, max_level, c2w, w2c, intri, bounds, mode, sampled_oct_per_ray,
+                    ray_march_fineness, ray_march_init_fineness, ray_march_fineness_decay_end_iter, seed=1234):
+        """PersSampler::PersSampler (PersSampler.cpp:899-952).  w2c is accepted for signature parity and recomputed
+        inside the builder."""
+        dev = c2w.device
+        self.device = dev
+        self.sub_div_milestones_ = list(reversed([int(v) for v in sub_div_milestones]))  # :915
+        self.compact_freq_ = int(compact_freq)
+        self.max_oct_intersect_per_ray_ = int(max_oct_intersect_per_ray)
+        self.global_near_ = float(np.float32(global_near))
+        self.scale_by_dis_ = bool(scale_by_dis)
+        self.sample_l_ = float(np.float32(sample_l))
+        self.mode_ = int(mode)
+        self.sampled_oct_per_ray_ = float(sampled_oct_per_ray)
+        self.ray_march_fineness_ = float(ray_march_fineness)
+        self.ray_march_init_fineness_ = float(ray_march_init_fineness)
+        self.ray_march_fineness_decay_end_iter_ = int(ray_march_fineness_decay_end_iter)
+        bbox_side_len = float(1 << (int(bbox_levels) - 1))  # :921
+        nodes, transes = ops.octree_build(c2w.detach().cpu().numpy(), intri.detach().cpu().numpy(),
+                                          bounds.detach().cpu().numpy(), max_depth=int(max_level), bbox_side_len=bbox_side_len,
+                                          split_dist_thres=float(split_dist_thres), seed=seed)
+        self._set_tree(torch.from_numpy(nodes).to(dev), torch.from_numpy(transes).to(dev))
+        self.n_volumes_ = self.pers_trans_gpu_.numel() // ops.TRANS_INFO_BYTES  # :936
+        self.tree_visit_cnt_ = torch.zeros(self.n_nodes, dtype=torch.int64, device=dev)
+        self.generator = torch.Generator(device=dev)
+        self.generator.manual_seed(seed)
+        self.last_packed = None
+        self.initialised = True
+
+    def _set_tree(self, nodes, transes):
+        self.tree_nodes_gpu_ = nodes.contiguous()
+        self.pers_trans_gpu_ = transes.contiguous()
+        self.n_nodes = self.tree_nodes_gpu_.numel() // ops.TREE_NODE_BYTES
+        self.nodes_compact_ = ops.tree_compact(self.tree_nodes_gpu_)
+        dev = nodes.device
+        self.tree_weight_stats_ = torch.full((self.n_nodes,), INIT_NODE_STAT, dtype=torch.int64, device=dev)
+        self.tree_alpha_stats_ = torch.full((self.n_nodes,), INIT_NODE_STAT, dtype=torch.int64, device=dev)
+        self._ws = None
+
+    # ---------------------------------------------------------------- sampling
+    def make_noise(self, n_rays):
+        """rays_noise (PersSampler_cuda.cu:380-389)."""
+        n = ops.MAX_SAMPLE_PER_RAY + n_rays + 10
+        if self.mode_ == VALIDATE:
+            noise = torch.ones(n, dtype=torch.float32, device=self.device)
+        else:
+            noise = (torch.rand(n, dtype=torch.float32, device=self.device, generator=self.generator) - 0.5) + 1.0
+        return noise.mul_(self.ray_march_fineness_)
+
+    def sample_packed(self, rays_o, rays_d, noise=None, table_space=False, want_world=True):
+        d = ops.normalize_dirs(rays_d.contiguous().float())
+        if noise is None:
+            noise = self.make_noise(rays_o.shape[0])
+        s = ops.sample_rays(rays_o.contiguous().float(), d, noise, self.nodes_compact_, self.pers_trans_gpu_, self.sample_l_,
+                            self.scale_by_dis_, near=self.global_near_, far=1e8, max_hits=self.max_oct_intersect_per_ray_,
+                            want_world=want_world, want_dirs=want_world, table_space=table_space, workspace=self._ws)
+        self._ws = s["workspace"]
+        s["dirs_unit"] = d
+        R = rays_o.shape[0]
+        s["n_dev"] = s["pts_offsets"][R:R + 1]
+        if self.mode_ != VALIDATE and R > 0:  # :386-387 running mean of leaves per ray (kept on the device: no sync)
+            per_ray = s["workspace"]["hit_counts"][:R].float().mean()
+            self.sampled_oct_per_ray_ = self.sampled_oct_per_ray_ * 0.9 + per_ray * 0.1
+        self.last_packed = s
+        return s
+
+    def GetSamples(self, rays_o, rays_d, bounds) -> List[torch.Tensor]:
+        """-> [world_pts, warped_pts, dirs, dists, t, anchors(i64), pts_idx_start_end, first_oct_dis], dense [R,1024,.]
+        (bounds is ignored by the reference too, PersSampler_cuda.cu:326-327)."""
+        s = self.sample_packed(rays_o, rays_d, table_space=False, want_world=True)
+        return ops.samples_to_dense(s, rays_o.shape[0])
+
+    # ------------------------------------------------------------- tree updates
+    def UpdateOctNodes(self, sampled_anchors, pts_idx_bounds, sampled_weights, sampled_alpha, iter_step):
+        """K5 + statistics + K6 (PersSampler_cuda.cu:584-665).  Accepts the reference's dense [R,1024,.] tensors
+        (gathered to the packed order of the last GetSamples) or already-packed [N] weights / alphas."""
+        s = self.last_packed
+        assert s is not None, "UpdateOctNodes needs the samples of the preceding GetSamples call"
+        cap = s["ts"].shape[0]
+        if sampled_weights.dim() >= 2 and sampled_weights.shape[1] == ops.MAX_SAMPLE_PER_RAY:
+            R = sampled_weights.shape[0]
+            counts = (s["pts_offsets"][1:] - s["pts_offsets"][:-1]).long()
+            mask = torch.arange(ops.MAX_SAMPLE_PER_RAY, device=self.device)[None, :] < counts[:, None]
+            w = torch.zeros(cap, dtype=torch.float32, device=self.device)
+            a = torch.zeros(cap, dtype=torch.float32, device=self.device)
+            wv = sampled_weights.reshape(R, -1)[mask]
+            w[: wv.numel()] = wv
+            a[: wv.numel()] = sampled_alpha.reshape(R, -1)[mask]
+        else:
+            w, a = sampled_weights.contiguous().float(), sampled_alpha.contiguous().float()
+        ops.update_nodes(s["pts_offsets"], s["anchors"], w, a, self.tree_weight_stats_, self.tree_alpha_stats_,
+                         self.tree_visit_cnt_, self.tree_nodes_gpu_)
+        ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)
+        # ProcOctree at milestones / every compact_freq iterations (:667-676) is not built yet
+
+    def UpdateRayMarch(self, cur_step):
+        if cur_step >= self.ray_march_fineness_decay_end_iter_:  # PersSampler.cpp:958-967
+            self.ray_march_fineness_ = 1.0
+        else:
+            p = float(cur_step) / float(self.ray_march_fineness_decay_end_iter_)
+            self.ray_march_fineness_ = math.exp(math.log(1.0) * p + math.log(self.ray_march_init_fineness_) * (1.0 - p))
+
+    def UpdateMode(self, mode):
+        self.mode_ = int(mode)
+
+    def UpdateBlockIdxs(self, centers):
+        """SetBlockIdxsNearestKernel (PersSampler_cuda.cu:746-766): nearest block centre per node.  One-shot at the
+        stage switch; done with tensor ops on views of the blob."""
+        nodes = self.tree_nodes_gpu_.view(self.n_nodes, ops.TREE_NODE_BYTES)
+        c = nodes[:, :12].contiguous().view(torch.float32).view(self.n_nodes, 3)
+        dist = (c[:, None, :].double() - centers[None].double().to(c.device)).norm(dim=-1)
+        idx = dist.argmin(dim=1)
+        nodes[:, 104:112] = idx.view(-1, 1).contiguous().view(torch.uint8).view(self.n_nodes, 8)
+        ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)
+
+    # ------------------------------------------------------------------ state
+    def States(self) -> List[torch.Tensor]:
+        ms = torch.tensor(self.sub_div_milestones_, dtype=torch.int64, device=self.device)
+        return [self.tree_nodes_gpu_, self.pers_trans_gpu_, self.tree_visit_cnt_, ms]  # PersSampler.cpp:969-979
+
+    def LoadStates(self, states: List[torch.Tensor], idx: int) -> int:
+        dev = self.device
+        nodes = states[idx].clone().to(dev); idx += 1
+        trans = states[idx].clone().to(dev); idx += 1
+        self._set_tree(nodes, trans)
+        self.tree_visit_cnt_ = states[idx].clone().to(dev).contiguous(); idx += 1
+        self.sub_div_milestones_ = [int(v) for v in states[idx].cpu().tolist()]; idx += 1
+        return idx
+
+    # --------------------------------------------------------------- accessors
+    def _nodes_np(self):
+        return self.tree_nodes_gpu_.cpu().numpy().view(_NODE_DT)
+
+    def get_tree_nodes_center_(self):
+        return self._nodes_np()["center"].astype(np.float64).tolist()
+
+    def get_tree_nodes_block_idx_(self):
+        return self._nodes_np()["block_idx"].tolist()
+
+    def get_tree_nodes_side_len_(self):
+        return self._nodes_np()["side_len"].astype(np.float64).tolist()
+
+    def get_tree_nodes_trans_idx_(self):
+        return self._nodes_np()["trans_idx"].tolist()
+
+    def get_tree_nodes_is_leaf_node_(self):
+        return [bool(v) for v in self._nodes_np()["is_leaf_node"]]
+
+    def get_pers_trans_info(self):
+        t = self.pers_trans_gpu_.cpu().numpy().view(_TRANS_DT)
+        return (t["w2xz"].astype(np.float64).tolist(), t["weight"].astype(np.float64).tolist(),
+                t["center"].astype(np.float64).tolist(), t["side_len"].astype(np.float64).tolist(),
+                t["dis_summary"].astype(np.float64).tolist())
+
+    def get_sub_div_milestones_(self): return list(self.sub_div_milestones_)
+    def get_compact_freq_(self): return self.compact_freq_
+    def get_max_oct_intersect_per_ray_(self): return self.max_oct_intersect_per_ray_
+    def get_global_near_(self): return self.global_near_
+    def get_sample_l_(self): return self.sample_l_
+    def get_scale_by_dis_(self): return float(self.scale_by_dis_)
+    def get_mode_(self): return self.mode_
+    def get_n_volumes_(self): return self.n_volumes_
+    def get_sampled_oct_per_ray_(self): return float(self.sampled_oct_per_ray_)
+    def get_ray_march_fineness_(self): return self.ray_march_fineness_
+
+
+class _Cameras:
+    """What PersSampler needs from nerfstudio's Cameras: camera_to_worlds [n,3,4] + intrinsics matrices [n,3,3]."""
+
+    def __init__(self, camera_to_worlds, intrinsics):
+        self.camera_to_worlds = camera_to_worlds
+        self._K = intrinsics
+
+    def get_intrinsics_matrices(self):
+        return self._K
+
+    def __len__(self):
+        return self.camera_to_worlds.shape[0]
+
+
+class PersSampler(nn.Module):
+    def __init__(self, cameras, n_split_dataset, steps_per_split_dataset, steps_perssampler_init, bounds,
+                 split_dist_thres: float = 1.5, sub_div_milestones=(2000, 4000, 6000, 8000, 10000), compact_freq: int = 1000,
+                 max_oct_intersect_per_ray: int = 1024, global_near: float = 0.01, scale_by_dis: bool = True,
+                 bbox_levels: int = 8, sample_l: float = 1.0 / 256, max_level: int = 16, mode: int = 0,
+                 sampled_oct_per_ray: int = 512, ray_march_fineness: float = 1.0, ray_march_init_fineness=16.0,
+                 ray_march_fineness_decay_end_iter=10000, device=None, seed=1234) -> None:
+        super().__init__()
+        self.device = torch.device(device or "cuda:0")
+        self.cameras = cameras
+        c2w = cameras.camera_to_worlds.to(self.device).float()
+        n = c2w.shape[0]
+        w2c = torch.eye(4, device=self.device).unsqueeze(0).repeat(n, 1, 1).contiguous()
+        w2c[:, 0:3, :] = c2w
+        w2c = torch.linalg.inv(w2c)[:, 0:3, :].contiguous()
+        intri = cameras.get_intrinsics_matrices().to(self.device).float()
+        self.bounds = bounds.to(self.device).float()
+        self.max_pts_per_ray = 1024
+        scale = max(steps_perssampler_init // 30000, 1)  # perssampler.py:99-100
+        ray_march_fineness_decay_end_iter = int(ray_march_fineness_decay_end_iter * scale)
+        sub_div_milestones = [int(x * scale) for x in sub_div_milestones]
+        self.sampler = _NativePersSampler()
+        self.sampler.InitSampler(split_dist_thres, sub_div_milestones, compact_freq, max_oct_intersect_per_ray, global_near,
+                                 scale_by_dis, bbox_levels, sample_l, max_level, c2w, w2c, intri, self.bounds, mode,
+                                 sampled_oct_per_ray, ray_march_fineness, ray_march_init_fineness,
+                                 ray_march_fineness_decay_end_iter, seed=seed)
+        self._register_state_dict_hook(self.state_dict_hook)
+        for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts", "cameras_labels"):
+            self.register_buffer(k, None)
+        self.register_buffer("c2w", c2w)
+        self.n_split_dataset = n_split_dataset
+        self.steps_per_split_dataset = steps_per_split_dataset
+        self.steps_perssampler_init = steps_perssampler_init
+
+    def forward(self, ray_bundle: RayBundle) -> RaySamples:
+        return self.generate_ray_samples(ray_bundle)
+
+    def generate_ray_samples(self, ray_bundle: RayBundle, dense: bool = True) -> RaySamples:
+        """perssampler.py:350-447.  The step arrives as a Python int / 0-d tensor; no .item() round trips beyond that."""
+        cur_step, cur_split_idx = -1, -1
+        if ray_bundle.steps is not None:
+            cur_step = int(ray_bundle.steps.reshape(-1)[0]) if isinstance(ray_bundle.steps, torch.Tensor) else int(ray_bundle.steps)
+            if cur_step >= self.steps_perssampler_init:
+                cur_split_idx = ((cur_step - self.steps_perssampler_init) // self.steps_per_split_dataset) % self.n_split_dataset
+        packed = self.sampler.sample_packed(ray_bundle.origins, ray_bundle.directions, table_space=False, want_world=dense)
+        f2 = None
+        if dense:
+            R = len(ray_bundle)
+            (world, warped, dirs, dists, t, anchors, se, fod) = ops.samples_to_dense(packed, R)
+            f2 = WarpedSamples(sampled_world_pts=world, sampled_pts=warped, sampled_dirs=dirs, sampled_dists=dists.unsqueeze(-1),
+                               sampled_t=t.unsqueeze(-1), sampled_anchors=anchors,
+                               pts_idx_start_end=se.unsqueeze(1).expand(-1, self.max_pts_per_ray, -1),
+                               first_oct_dis=fod.unsqueeze(1).expand(-1, self.max_pts_per_ray, -1))
+        return RaySamples(f2samples=f2, camera_indices=ray_bundle.camera_indices, rel_camera_indices=ray_bundle.rel_camera_indices,
+                          deltas=None if f2 is None else f2.sampled_dists, cur_step=cur_step,
+                          cur_split_dataset_idx=cur_split_idx, packed=packed)
+
+    def update_oct_nodes(self, sampled_anchors, pts_idx_bounds, sampled_weights, sampled_alpha, iter_step: int):
+        self.sampler.UpdateOctNodes(sampled_anchors, pts_idx_bounds, sampled_weights, sampled_alpha, iter_step)
+
+    def update_ray_march(self, cur_step: int):
+        self.sampler.UpdateRayMarch(cur_step)
+
+    def update_mode(self, mode: int):
+        self.sampler.UpdateMode(mode)
+
+    def update_block_idx(self, block_centers):
+        self.sampler.UpdateBlockIdxs(block_centers)
+
+    def states(self):
+        return self.sampler.States()
+
+    def load_states(self, states, idx):
+        return self.sampler.LoadStates(states, idx)
+
+    def state_dict_hook(self, *args):
+        destination, prefix = args[1], args[2]
+        tree_nodes_gpu_, pers_trans_gpu_, tree_visit_cnt_, milestones_ts_ = self.states()
+        destination[prefix + "tree_nodes_gpu"] = tree_nodes_gpu_
+        destination[prefix + "pers_trans_gpu"] = pers_trans_gpu_
+        destination[prefix + "tree_visit_cnt"] = tree_visit_cnt_
+        destination[prefix + "milestones_ts"] = milestones_ts_
+        return destination
+
+    def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
+        keys = ["persampler." + k for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts")]
+        states = [state_dict[k] for k in keys]
+        for k in keys:
+            del state_dict[k]
+        self.load_states(states, idx=0)

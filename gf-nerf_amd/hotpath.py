@@ -38,6 +38,8 @@ class HotPathConfig:
     table_f16_shadow: bool = True    # gather from f16 shadows refreshed by the Adam kernel (same values as :185's cast)
     grad_f16: bool = True            # table gradient pool in f16 with the x128 loss scale, like the reference (:151,:209)
     fused_field: bool = True         # decoder as one kernel per direction (needs hidden == 128)
+    share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
+                                      # one-gather-per-corner image; False: own primes per table, like the reference
 
 
 class HotPath:
@@ -45,8 +47,14 @@ class HotPath:
         self.cfg = cfg or HotPathConfig()
         self.dev = torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
-        self.nodes = t(np.asarray(nodes).view(np.uint8).reshape(-1))
-        self.transes = t(np.asarray(transes).view(np.uint8).reshape(-1))
+
+        def blob(a):  # numpy blob or a device uint8 tensor (shared with a PersSampler)
+            if isinstance(a, torch.Tensor):
+                return a.to(self.dev).contiguous().view(torch.uint8).reshape(-1)
+            return t(np.asarray(a).view(np.uint8).reshape(-1))
+
+        self.nodes = blob(nodes)
+        self.transes = blob(transes)
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
@@ -59,6 +67,9 @@ class HotPath:
         # residual block tables start at zero in the reference (nerfacto_field.py:345); tiny noise here
         # would hide nothing in training but zeros would hide kernel bugs in tests -> caller may overwrite
         self.blocks = [torch.zeros((16 * (1 << T), 2), dtype=torch.float32, device=self.dev) for _ in range(n_blocks)]
+        # every Hash3DAnchored draws its own primes (Hash3DAnchored.cpp:43-50; add_table, nerfacto_field.py:341-347)
+        self.block_prims = [self.prim if self.cfg.share_block_primes else t(scene.make_primes(self.n_volumes, seed=seed + 100 + i))
+                            for i in range(n_blocks)]
         base, head = scene.make_mlps(seed=seed + 4, hidden=self.cfg.hidden)
         shapes = [w.shape for w, _ in base + head]
         sizes = [w.size + b.size for w, b in base + head]
@@ -95,8 +106,10 @@ class HotPath:
             self.table16 = ops.table_to_f16(self.table, self.table16)
             if len(self.blocks16) != len(self.blocks):
                 self.blocks16 = [None] * len(self.blocks)
-            # focal stage: global + block interleaved per slot (one 8-byte gather per corner)
-            self.blocks16 = [ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+            if self.cfg.share_block_primes:  # global + block interleaved per slot (one 8-byte gather per corner)
+                self.blocks16 = [ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+            else:
+                self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
         self._pairs_stale = False
 
     def _timed(self, name, fn, *a, **k):
@@ -113,6 +126,7 @@ class HotPath:
         """Host copies of every parameter / state blob (for checkpoints and for the test oracle)."""
         c = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
         return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[c(b) for b in self.blocks],
+                    block_prims=[c(p) for p in self.block_prims],
                     prim=c(self.prim), bias=c(self.bias), layers=[(c(W), c(B)) for W, B in self.layers], emb=c(self.emb))
 
     # ------------------------------------------------------------------ sampling
@@ -140,9 +154,12 @@ class HotPath:
         fused = (self.cfg.fused_field and self.cfg.hidden == 128) if fused is None else fused
         if block is not None and self._pairs_stale:  # the global table moved since the interleaved images were built
             self.refresh_shadows()
-        if self.cfg.table_f16_shadow and block is not None:  # residual block table (nerfacto_field.py:485-486) fused in
+        if self.cfg.table_f16_shadow and block is not None and self.cfg.share_block_primes:
             feat = self._timed("hash_fwd", ops.hash_fwd_pair, self.blocks16[block], self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, n_dev=n_dev)
+        elif self.cfg.table_f16_shadow and block is not None:  # residual block table (nerfacto_field.py:485-486) fused in
+            feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
+                               s["anchors"], V, T, table2_f16=self.blocks16[block], prim_pool2=self.block_prims[block], n_dev=n_dev)
         elif self.cfg.table_f16_shadow:
             feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, n_dev=n_dev)
@@ -150,8 +167,8 @@ class HotPath:
             feat = self._timed("hash_fwd", ops.hash_fwd, self.table, self.prim, self.bias_arg, s["warped_pts"], s["anchors"],
                                V, T, n_dev=n_dev)
             if block is not None:
-                self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.prim, self.bias_arg, s["warped_pts"],
-                            s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
+                self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.block_prims[block], self.bias_arg,
+                            s["warped_pts"], s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
         emb = self.emb if self.cfg.use_appearance_embedding else None
         if fused:
             sh = ops.sh4(s["dirs_unit"])
@@ -196,39 +213,53 @@ class HotPath:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
 
-    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None):
-        """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux)."""
+    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None):
+        """Training forward of get_outputs.  Returns (comp, ctx): comp holds rgb [R,3], acc, depth_raw, weights,
+        alphas; ctx is what backward() needs (the reference keeps the whole autograd graph alive instead)."""
         c = self.cfg
         train_mlp = stage == STAGE_GLOBAL
         self._timed("zero_grads", self.zero_grads, stage, block)
         s = self.sample(rays_o, rays_d_raw, noise)
-        n_dev = s["n_dev"]
         fused = (not train_mlp) and c.fused_field and c.hidden == 128  # frozen decoder: masks are all the backward needs
         f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None, fused=fused, save=fused)
         comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
                            early_T=c.early_T)
-        loss, g_rgb = ops.charbonnier(comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)
+        self._last_train_ctx = ctx
+        return comp, ctx
+
+    def backward(self, ctx, g_rgb, g_acc=None):
+        """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R])."""
+        c = self.cfg
+        s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
+        train_mlp = ctx["stage"] == STAGE_GLOBAL
+        n_dev = s["n_dev"]
         d_sigma, d_rgb = self._timed("composite_bwd", ops.composite_bwd, s["pts_offsets"], f["sigma"], s["dists"], f["rgb"],
-                                     g_rgb, None, early_T=c.early_T)
-        if fused:
+                                     g_rgb, g_acc, early_T=c.early_T)
+        if ctx["fused"]:
             dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev)
-            self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
-                        c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
-            return loss, dict(samples=s, field=f, comp=comp)
-        (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = self.layers
-        g = self.layer_grads
-        gw = lambda i: (g[i][0], g[i][1]) if train_mlp else (None, None)  # noqa: E731
-        dc2, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c2"], hW2, f["rgb"], d_rgb, "sigmoid", dW=gw(4)[0], db=gw(4)[1], need_dw=train_mlp, n_dev=n_dev)
-        dc1, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c1"], hW1, f["c2"], dc2, "relu", dW=gw(3)[0], db=gw(3)[1], need_dw=train_mlp, n_dev=n_dev)
-        dxh, _, _ = self._timed("head_bwd", ops.linear_bwd, f["xh"], hW0, f["c1"], dc1, "relu", dW=gw(2)[0], db=gw(2)[1], need_dw=train_mlp, n_dev=n_dev, in_dim=63)
-        demb = self.emb_grad if (train_mlp and c.use_appearance_embedding) else None
-        dh = ops.head_unpack_bwd(f["h"], d_sigma, dxh, cam_idx, s["pts_offsets"], demb=demb, n_dev=n_dev)
-        da1, _, _ = self._timed("base_bwd", ops.linear_bwd, f["a1"], bW1, f["h"], dh, "none", dW=gw(1)[0], db=gw(1)[1], need_dw=train_mlp, n_dev=n_dev)
-        dfeat, _, _ = self._timed("base_bwd", ops.linear_bwd, f["feat"], bW0, f["a1"], da1, "relu", dW=gw(0)[0], db=gw(0)[1], need_dw=train_mlp, n_dev=n_dev)
-        # both tables see the same d(feat) (sum of two lookups); only the trainable one is scattered
-        self._timed("hash_bwd", ops.hash_bwd, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
+        else:
+            (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = self.layers
+            g = self.layer_grads
+            gw = lambda i: (g[i][0], g[i][1]) if train_mlp else (None, None)  # noqa: E731
+            dc2, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c2"], hW2, f["rgb"], d_rgb, "sigmoid", dW=gw(4)[0], db=gw(4)[1], need_dw=train_mlp, n_dev=n_dev)
+            dc1, _, _ = self._timed("head_bwd", ops.linear_bwd, f["c1"], hW1, f["c2"], dc2, "relu", dW=gw(3)[0], db=gw(3)[1], need_dw=train_mlp, n_dev=n_dev)
+            dxh, _, _ = self._timed("head_bwd", ops.linear_bwd, f["xh"], hW0, f["c1"], dc1, "relu", dW=gw(2)[0], db=gw(2)[1], need_dw=train_mlp, n_dev=n_dev, in_dim=63)
+            demb = self.emb_grad if (train_mlp and c.use_appearance_embedding) else None
+            dh = ops.head_unpack_bwd(f["h"], d_sigma, dxh, cam_idx, s["pts_offsets"], demb=demb, n_dev=n_dev)
+            da1, _, _ = self._timed("base_bwd", ops.linear_bwd, f["a1"], bW1, f["h"], dh, "none", dW=gw(1)[0], db=gw(1)[1], need_dw=train_mlp, n_dev=n_dev)
+            dfeat, _, _ = self._timed("base_bwd", ops.linear_bwd, f["feat"], bW0, f["a1"], da1, "relu", dW=gw(0)[0], db=gw(0)[1], need_dw=train_mlp, n_dev=n_dev)
+        # both tables see the same d(feat) (sum of two lookups); only the trainable one is scattered, through ITS primes
+        prim = self.prim if train_mlp else self.block_prims[ctx["block"]]
+        self._timed("hash_bwd", ops.hash_bwd, prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
-        return loss, dict(samples=s, field=f, comp=comp)
+
+    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None):
+        """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux)."""
+        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block)
+        loss, g_rgb = ops.charbonnier(comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        self.backward(ctx, g_rgb)
+        return loss, ctx
 
     def optimizer_step(self, stage=STAGE_GLOBAL, block=None):
         c = self.cfg
@@ -250,7 +281,8 @@ class HotPath:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
             self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps,
-                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live, shadow_pair=True)
+                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live,
+                        shadow_pair=c.share_block_primes)
 
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""

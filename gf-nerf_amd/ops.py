@@ -88,8 +88,11 @@ def table_to_f16(feat_pool, out=None):
     return out
 
 
-def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, out=None, n_dev=None):
-    """Lookup from f16 shadow table(s); table2_f16 fuses the focal stage's residual table (sum of both)."""
+def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None,
+                 n_dev=None):
+    """Lookup from f16 shadow table(s); table2_f16 fuses the focal stage's residual table (sum of both), hashed with
+    prim_pool2 (its own primes) or, when None, with prim_pool."""
+    _chk(prim_pool2, torch.int32, "prim_pool2")
     _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16")
     _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
     _chk(anchors, anchors.dtype, "anchors")
@@ -103,7 +106,7 @@ def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_
     if out is None:
         out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
     _chk(out, torch.float32, "out", 32)
-    rc = _lib.lib().gfn_hash_fwd_f16(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts),
+    rc = _lib.lib().gfn_hash_fwd_f16(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), _ptr(pts),
                                      _ptr(anchors), int(anchors.dtype == torch.int64), stride, n, _ptr(n_dev), n_volumes,
                                      log2_T, _ptr(out), _stream())
     _lib.check(rc, "gfn_hash_fwd_f16")

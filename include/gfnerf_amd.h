@@ -95,14 +95,18 @@ int gfn_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const float* 
 
 /* Same lookup from f16 shadow tables (u16 [16*T*2], element i = f16(master[i]) RNE, kept
  * current by gfn_adam_step_ex): identical results to gfn_hash_fwd, half the gather bytes.
- * table2_f16 != NULL fuses the focal stage's residual lookup: out = feat(table) + feat(table2). */
+ * table2_f16 != NULL fuses the focal stage's residual lookup: out = feat(table) + feat(table2);
+ * prim_pool2 = the second table's own primes (every Hash3DAnchored draws its own,
+ * Hash3DAnchored.cpp:43-50), or NULL when it shares prim_pool. */
 int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                     const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
+                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
                      int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                      float* out, void* stream);
 /* Focal stage with the two tables INTERLEAVED per slot (u16 [16*T*4]: {global.ch0, global.ch1,
  * block.ch0, block.ch1} as f16): one 8-byte gather per corner instead of two 4-byte gathers;
- * out = feat(global) + feat(block), bit-identical to the two-table forms.  Built by
+ * out = feat(global) + feat(block), bit-identical to the two-table forms.  ONLY valid when the
+ * block table was created with the global table's primes (an option of this framework; tables
+ * from a reference checkpoint carry their own primes and need gfn_hash_fwd_f16).  Built by
  * gfn_table_pair_f16; the block half is kept current by gfn_adam_step_ex (shadow_pair = 1). */
 int gfn_table_pair_f16(const float* global_pool, const float* block_pool, uint16_t* pair_f16, int64_t n_elems,
                        void* stream);

@@ -36,7 +36,8 @@ def field_forward(P, m, cam_idx, log2_T, block=None, threads=0, use_emb=True):
     anchors = np.ascontiguousarray(m["anchors"][:, 0])
     feat = O.hash_fwd(P["table"], P["prim"], P["bias"], m["x"], anchors, V, log2_T, threads=threads)
     if block is not None:
-        feat = feat + O.hash_fwd(P["blocks"][block], P["prim"], P["bias"], m["x"], anchors, V, log2_T, threads=threads)
+        bprim = P["block_prims"][block] if "block_prims" in P else P["prim"]  # each table hashes with its own primes
+        feat = feat + O.hash_fwd(P["blocks"][block], bprim, P["bias"], m["x"], anchors, V, log2_T, threads=threads)
     (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = P["layers"]
     a1 = O.linear_fwd(feat, bW0, bb0, "relu", threads=threads)
     h = O.linear_fwd(a1, bW1, bb1, "none", threads=threads)
@@ -86,5 +87,7 @@ def loss_and_grads(P, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, log2_T, block=
     da1, grads["bW1"], grads["bb1"] = O.linear_bwd(f["a1"], bW1, f["h"], dh, "none")
     dfeat, grads["bW0"], grads["bb0"] = O.linear_bwd(f["feat"], bW0, f["a1"], da1, "relu")
     V = P["prim"].shape[1]
-    grads["table"] = O.hash_bwd(P["prim"], P["bias"], m["x"], np.ascontiguousarray(m["anchors"][:, 0]), dfeat, V, log2_T)
+    # focal stage (block given): the gradient belongs to the block table and scatters through ITS primes
+    gprim = P["prim"] if block is None else P.get("block_prims", [P["prim"]] * (block + 1))[block]
+    grads["table"] = O.hash_bwd(gprim, P["bias"], m["x"], np.ascontiguousarray(m["anchors"][:, 0]), dfeat, V, log2_T)
     return loss, grads, dict(samples=m, field=f, comp=comp, dfeat=dfeat)

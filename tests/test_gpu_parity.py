@@ -141,6 +141,11 @@ def test_hash_forward_f16_shadow_and_fused_dual(oracle, ops, dev):
     assert np.array_equal(got, wa)
     dual = ops.hash_fwd_f16(a16, *common, table2_f16=b16).cpu().numpy()
     assert np.array_equal(dual, wa + wb)
+    # the residual table hashed with its OWN primes (what add_table does in the reference)
+    prim2 = scene.make_primes(n_vol, seed=77)
+    wb2 = oracle.hash_fwd(pb, prim2, bias, pts, anchors3[:, 0], n_vol, log2_T)
+    dual2 = ops.hash_fwd_f16(a16, *common, table2_f16=b16, prim_pool2=_t(prim2, dev)).cpu().numpy()
+    assert np.array_equal(dual2, wa + wb2) and not np.array_equal(dual2, dual)
     pair = ops.table_pair_f16(_t(pa, dev), _t(pb, dev))
     assert np.array_equal(ops.hash_fwd_pair(pair, *common).cpu().numpy(), dual)  # interleaved 8-byte gathers
     # unfused two-call form of the boundary (accumulate) agrees bit for bit
