@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
     ap.add_argument("--cpu-rays", type=int, default=96, help="rays in the bounded cpu_baseline sample")
     ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
+    ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
+                    help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     ap.add_argument("--share-block-primes", action="store_true",
                     help="block tables reuse the global table's primes (enables the interleaved one-gather-per-corner image); "
                          "default: own primes per table like the reference")
@@ -118,7 +120,8 @@ def main():
     t_build = time.perf_counter() - t_build
     n_cams = sc["c2w"].shape[0]
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
-    cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes)
+    cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
+                                mlp_precision=args.mlp_precision)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks)
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
         g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
@@ -211,7 +214,8 @@ def main():
                                n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
                                fineness=fineness, stage=args.stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
                                block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
-                               mlp="f32 MFMA 32x32x2",
+                               mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" and args.stage == "focal"
+                                    else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
                                scene_build_s=round(t_build, 1), loss=float(loss.item())),

@@ -1,0 +1,501 @@
+// field_x3.hip -- the fused decoder of field.hip on the f16 matrix pipe at f32 accuracy.
+//
+// v_mfma_f32_32x32x2_f32 runs at the vector rate (64 FLOP/clk/SIMD); v_mfma_f32_32x32x16_f16 is 16x
+// that.  Every f32 operand x is split into two f16 numbers, x ~= hi + lo' * 2^-11 with
+// hi = rtz_f16(x), lo' = rtz_f16((x - hi) * 2^11)  (the 2^11 keeps lo' out of the f16 subnormals),
+// and a product sum becomes three MFMAs into two f32 accumulators,
+//     main += A_hi B_hi            corr += A_hi B_lo' + A_lo' B_hi        result = main + corr * 2^-11,
+// dropping only the lo*lo term (2^-22 relative): ~1e-6 of sum|a b|, 5.3x fewer matrix-pipe
+// cycles than the exact f32 form.  The reference runs these layers in f32 (nn.Linear,
+// gfnerf/mlp.py:35-57); parity bar 1e-3 abs (BASELINE.json), tests hold 1e-5.
+//
+// Structure is field.hip's: a wave owns 32 samples (MFMA column = lane&31), the weights are the A
+// operand, and every layer's 32x32 accumulator tile IS the next layer's B operand -- registers
+// 8s..8s+7 of a tile, split and packed, are the 8-element fragment of k-step s, whose k order is
+// row = 16s + 8(i>>2) + 4h + (i&3) (h = lane>>5); the weight images are laid out in that order, one
+// contiguous 1 KiB chunk (64 lanes x 16 B, a conflict-free ds_read_b128) per (k-step, out tile).
+// The images are built once per weight update by field_pack_x3_kernel and copied into LDS by
+// every workgroup (146 KiB forward, 112 KiB backward; 512 threads = two waves per SIMD so one
+// wave's split/ReLU VALU work overlaps the other's MFMAs).
+#include "gfn_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+constexpr int FWD_CHUNKS = 72, BWD_CHUNKS = 56, FWD_BIAS = 448;
+static_assert(GFN_FIELD_X3_FWD_BYTES == FWD_CHUNKS * 2048 + FWD_BIAS * 4, "forward image size");
+static_assert(GFN_FIELD_X3_BWD_BYTES == BWD_CHUNKS * 2048, "backward image size");
+static_assert(GFN_FIELD_X3_FWD_BYTES <= 160 * 1024, "forward LDS image must fit one CU");
+
+// forward chunk bases
+constexpr int C_B0 = 0;    // base L1: [u 2][ot 4]
+constexpr int C_B1 = 8;    // base L2: [u 8]
+constexpr int C_H0 = 16;   // head L1: [u 4][ot 4]   u0 = geo rows of the base tile, u1 = SH, u2,u3 = appearance
+constexpr int C_H1 = 32;   // head L2: [u 8][ot 4]
+constexpr int C_H2 = 64;   // head L3: [u 8]
+// backward chunk bases (A = W^T: rows = layer inputs, k = layer outputs)
+constexpr int D_G3 = 0;    // d c2 = hW2^T dz3 : [it 4]
+constexpr int D_G2 = 4;    // d c1 = hW1^T dz2 : [u 8][it 4]
+constexpr int D_G1 = 36;   // d h[1:16] = hW0[:,16:31]^T dz1 : [u 8]
+constexpr int D_GB1 = 44;  // d a1 = bW1^T dh : [it 4]
+constexpr int D_GB0 = 48;  // d feat = bW0^T dz : [u 8]
+
+__device__ __forceinline__ int acc_row(int t, int s, int h, int i) { return 32 * t + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
+
+struct FieldWeights {
+  const float* bW0; const float* bb0; const float* bW1; const float* bb1; const float* hW0; const float* hb0;
+  const float* hW1; const float* hb1; const float* hW2; const float* hb2;
+};
+
+__device__ float fwd_weight(const FieldWeights& w, int c, int h, int r, int i) {
+  if (c < C_B1) { const int u = c >> 2, ot = c & 3; return w.bW0[(32 * ot + r) * 32 + 16 * u + 8 * h + i]; }
+  if (c < C_H0) { const int u = c - C_B1; return r < 16 ? w.bW1[r * 128 + acc_row(u >> 1, u & 1, h, i)] : 0.f; }
+  if (c < C_H1) {
+    const int cc = c - C_H0, u = cc >> 2, o = 32 * (cc & 3) + r;
+    if (u == 0) { const int row = acc_row(0, 0, h, i); return row == 0 ? 0.f : w.hW0[o * 63 + 15 + row]; }  // row 0 = density channel
+    if (u == 1) return w.hW0[o * 63 + 8 * h + i];
+    return w.hW0[o * 63 + 31 + 16 * (u - 2) + 8 * h + i];
+  }
+  if (c < C_H2) { const int cc = c - C_H1, u = cc >> 2, ot = cc & 3; return w.hW1[(32 * ot + r) * 128 + acc_row(u >> 1, u & 1, h, i)]; }
+  const int u = c - C_H2;
+  return r < 3 ? w.hW2[r * 128 + acc_row(u >> 1, u & 1, h, i)] : 0.f;
+}
+
+__device__ float bwd_weight(const FieldWeights& w, int c, int h, int r, int i) {
+  if (c < D_G2) { const int it = c; return (h == 0 && i < 3) ? w.hW2[i * 128 + 32 * it + r] : 0.f; }
+  if (c < D_G1) { const int cc = c - D_G2, u = cc >> 2, it = cc & 3; return w.hW1[acc_row(u >> 1, u & 1, h, i) * 128 + 32 * it + r]; }
+  if (c < D_GB1) { const int u = c - D_G1; return (r >= 1 && r <= 15) ? w.hW0[acc_row(u >> 1, u & 1, h, i) * 63 + 15 + r] : 0.f; }
+  if (c < D_GB0) { const int it = c - D_GB1; return w.bW1[acc_row(0, 0, h, i) * 128 + 32 * it + r]; }
+  const int u = c - D_GB0;
+  return w.bW0[acc_row(u >> 1, u & 1, h, i) * 32 + r];
+}
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // round toward zero: saturates at 65504, never rounds to inf
+  const float r0 = (x0 - (float)hv[0]) * 2048.f, r1 = (x1 - (float)hv[1]) * 2048.f;  // exact
+  hi = __builtin_bit_cast(uint32_t, hv);
+  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+
+// one thread per (chunk, lane): 8 weights -> 16 B of the hi image and 16 B of the lo image
+__global__ void field_pack_x3_kernel(FieldWeights w, u32x4* __restrict__ fwd, u32x4* __restrict__ bwd) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = gid >> 6, lane = gid & 63, h = lane >> 5, r = lane & 31;
+  if (c < FWD_CHUNKS) {
+    if (!fwd) return;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      uint32_t a, b;
+      split2(fwd_weight(w, c, h, r, 2 * p), fwd_weight(w, c, h, r, 2 * p + 1), a, b);
+      hi[p] = a; lo[p] = b;
+    }
+    fwd[gid] = hi;
+    fwd[FWD_CHUNKS * 64 + gid] = lo;
+    if (c == 0) {  // biases behind the two images: bb0[128] bb1[32] hb0[128] hb1[128] hb2[32]
+      float* bp = reinterpret_cast<float*>(fwd + 2 * FWD_CHUNKS * 64);
+      for (int e = lane; e < FWD_BIAS; e += 64) {
+        float v;
+        if (e < 128) v = w.bb0[e];
+        else if (e < 160) v = e - 128 < 16 ? w.bb1[e - 128] : 0.f;
+        else if (e < 288) v = w.hb0[e - 160];
+        else if (e < 416) v = w.hb1[e - 288];
+        else v = e - 416 < 3 ? w.hb2[e - 416] : 0.f;
+        bp[e] = v;
+      }
+    }
+  } else if (c < FWD_CHUNKS + BWD_CHUNKS) {
+    if (!bwd) return;
+    const int cb = c - FWD_CHUNKS;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      uint32_t a, b;
+      split2(bwd_weight(w, cb, h, r, 2 * p), bwd_weight(w, cb, h, r, 2 * p + 1), a, b);
+      hi[p] = a; lo[p] = b;
+    }
+    bwd[cb * 64 + lane] = hi;
+    bwd[BWD_CHUNKS * 64 + cb * 64 + lane] = lo;
+  }
+}
+
+struct Acc2 {
+  f32x16 m, c;
+};
+
+__device__ __forceinline__ void mma3(Acc2& a, const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, int chunk, int lane,
+                                     const u32x4& bhi, const u32x4& blo) {
+  const h8 ah = __builtin_bit_cast(h8, Ihi[chunk * 64 + lane]);
+  const h8 al = __builtin_bit_cast(h8, Ilo[chunk * 64 + lane]);
+  const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
+  a.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a.m, 0, 0, 0);
+  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a.c, 0, 0, 0);
+  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a.c, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting every later operand read (register blow-up)
+}
+
+__device__ __forceinline__ void acc_init_bias(Acc2& a, const float* __restrict__ bias, int ot, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {  // registers 4g..4g+3 = rows 32ot + 8g + 4h + 0..3
+    const float4 b = *reinterpret_cast<const float4*>(bias + 32 * ot + 8 * g + 4 * h);
+    a.m[4 * g] = b.x; a.m[4 * g + 1] = b.y; a.m[4 * g + 2] = b.z; a.m[4 * g + 3] = b.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) a.c[r] = 0.f;
+}
+__device__ __forceinline__ void acc_init_zero(Acc2& a) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) { a.m[r] = 0.f; a.c[r] = 0.f; }
+}
+__device__ __forceinline__ float acc_get(const Acc2& a, int r) { return __builtin_fmaf(a.c[r], 0x1p-11f, a.m[r]); }
+
+// a finished tile -> (ReLU, mask bits,) the two k-step fragments of the next layer
+struct Frag {
+  u32x4 hi[2], lo[2];
+};
+template <bool RELU>
+__device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    v[r] = acc_get(a, r);
+    if (RELU) {
+      const bool on = v[r] > 0.f;
+      v[r] = on ? v[r] : 0.f;
+      mask |= (unsigned long long)on << (t * 16 + r);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      uint32_t a_, b_;
+      split2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1], a_, b_);
+      f.hi[s][p] = a_; f.lo[s][p] = b_;
+    }
+}
+__device__ __forceinline__ void split8(const float* x, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    uint32_t a_, b_;
+    split2(x[2 * p], x[2 * p + 1], a_, b_);
+    hi[p] = a_; lo[p] = b_;
+  }
+}
+__device__ __forceinline__ void load8(const float* p, float* x) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512) void field_fwd_x3_kernel(
+    int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
+    const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
+    const u32x4* __restrict__ image, float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ h0_out,
+    unsigned long long* __restrict__ masks /* [n][3][2] */) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 L[];
+  for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
+  __syncthreads();
+  const u32x4* Ihi = L;
+  const u32x4* Ilo = L + FWD_CHUNKS * 64;
+  const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
+  const float* Bb0 = bias; const float* Bb1 = bias + 128; const float* Bh0 = bias + 160; const float* Bh1 = bias + 288; const float* Bh2 = bias + 416;
+
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int64_t n_tiles = (n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    const int64_t s = tile * 32 + j;
+    const bool valid = s < n;
+    const int64_t q = valid ? s : n - 1;
+    // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
+    u32x4 xh[2], xl[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float x[8];
+      load8(feat + q * 32 + 16 * u + 8 * h, x);
+      split8(x, xh[u], xl[u]);
+    }
+    Frag a1[4];
+    unsigned long long m_a1 = 0;
+#pragma unroll
+    for (int ot = 0; ot < 4; ot++) {
+      Acc2 a;
+      acc_init_bias(a, Bb0, ot, h);
+#pragma unroll
+      for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
+      tile_to_frag<true>(a, a1[ot], m_a1, ot);
+    }
+    // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
+    Acc2 hh;
+    acc_init_bias(hh, Bb1, 0, h);
+#pragma unroll
+    for (int u = 0; u < 8; u++) mma3(hh, Ihi, Ilo, C_B1 + u, lane, a1[u >> 1].hi[u & 1], a1[u >> 1].lo[u & 1]);
+    const float h0v = acc_get(hh, 0);  // row 0 = density channel: register 0 of the h=0 lanes
+    if (valid && h == 0) {
+      sigma[s] = expf(h0v + 1.0f);  // trunc_exp(h0 + 1), nerfacto_field.py:499
+      if (SAVE) h0_out[s] = h0v;
+    }
+    u32x4 gh, gl;  // rows 0..15 of the tile = k-step 0 (row 0 meets zero weights)
+    {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
+      split8(v, gh, gl);
+    }
+    // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
+    const int ray = ray_id[q];
+    u32x4 sh_h, sh_l, e_h[2], e_l[2];
+    {
+      float x[8];
+      load8(sh + (int64_t)ray * 16 + 8 * h, x);
+      split8(x, sh_h, sh_l);
+      if (emb) {
+        const float* ep = emb + (int64_t)cam_idx[ray] * 32;
+#pragma unroll
+        for (int u = 0; u < 2; u++) { load8(ep + 16 * u + 8 * h, x); split8(x, e_h[u], e_l[u]); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
+      }
+    }
+    Frag c1[4];
+    unsigned long long m_c1 = 0;
+#pragma unroll
+    for (int ot = 0; ot < 4; ot++) {
+      Acc2 a;
+      acc_init_bias(a, Bh0, ot, h);
+      mma3(a, Ihi, Ilo, C_H0 + 0 * 4 + ot, lane, gh, gl);
+      mma3(a, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, sh_h, sh_l);
+      mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
+      mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
+      tile_to_frag<true>(a, c1[ot], m_c1, ot);
+    }
+    // ---- head layer 2: 128 -> 128, ReLU
+    Frag c2[4];
+    unsigned long long m_c2 = 0;
+#pragma unroll
+    for (int ot = 0; ot < 4; ot++) {
+      Acc2 a;
+      acc_init_bias(a, Bh1, ot, h);
+#pragma unroll
+      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
+      tile_to_frag<true>(a, c2[ot], m_c2, ot);
+    }
+    // ---- head layer 3: 128 -> 3 (padded), sigmoid
+    Acc2 o3;
+    acc_init_bias(o3, Bh2, 0, h);
+#pragma unroll
+    for (int u = 0; u < 8; u++) mma3(o3, Ihi, Ilo, C_H2 + u, lane, c2[u >> 1].hi[u & 1], c2[u >> 1].lo[u & 1]);
+    if (valid) {
+      if (h == 0) {  // rows 0..2 = registers 0..2 of the h=0 lanes
+        rgb[3 * s] = 1.f / (1.f + expf(-acc_get(o3, 0)));
+        rgb[3 * s + 1] = 1.f / (1.f + expf(-acc_get(o3, 1)));
+        rgb[3 * s + 2] = 1.f / (1.f + expf(-acc_get(o3, 2)));
+      }
+      if (SAVE) {
+        unsigned long long* mp = masks + s * 6 + h;
+        mp[0] = m_a1; mp[2] = m_c1; mp[4] = m_c2;
+      }
+    }
+  }
+}
+
+template <bool RELU_MASK>
+__device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    v[r] = acc_get(a, r);
+    if (RELU_MASK) v[r] = ((mask >> (t * 16 + r)) & 1ull) ? v[r] : 0.f;  // ReLU'
+  }
+#pragma unroll
+  for (int s = 0; s < 2; s++) split8(v + 8 * s, f.hi[s], f.lo[s]);
+}
+
+__global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
+    int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
+    const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
+    const u32x4* __restrict__ image, float* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 L[];
+  for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
+  __syncthreads();
+  const u32x4* Ihi = L;
+  const u32x4* Ilo = L + BWD_CHUNKS * 64;
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int64_t n_tiles = (n + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    const int64_t s = tile * 32 + j;
+    const bool valid = s < n;
+    const int64_t q = valid ? s : n - 1;
+    const float ds = valid ? d_sigma[q] : 0.f;
+    float dz3[3];
+    bool any_grad = ds != 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float y = rgb[3 * q + c];
+      const float g = valid ? d_rgb[3 * q + c] : 0.f;
+      dz3[c] = g * y * (1.f - y);  // sigmoid'
+      any_grad = any_grad || g != 0.f;
+    }
+    float4* dst = reinterpret_cast<float4*>(dfeat + s * 32);
+    if (!__any(any_grad)) {  // wave-uniform: the whole tile lies behind its rays' termination points
+      if (valid) {
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) dst[2 * qd + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
+    // d h0 = d sigma * exp(clamp(h0+1, -15, 15))  (trunc_exp backward, activations.py:41)
+    float xx = h0[q] + 1.0f;
+    xx = fminf(fmaxf(xx, -15.f), 15.f);
+    const float dh0 = ds * expf(xx);
+    // per-sample power-of-two scale: gradients are ~1e-5 and below, under the f16 normal range.
+    // Every quantity of this sample's column is linear in (dz3, dh0), so the scale is undone exactly at the end.
+    const float mx = fmaxf(fmaxf(fabsf(dz3[0]), fabsf(dz3[1])), fmaxf(fabsf(dz3[2]), fabsf(dh0)));
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    e = e < 27 ? 27 : (e > 227 ? 227 : e);
+    const float sc = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^(127-e): mx*sc in [1,2)
+    const float inv = __uint_as_float((uint32_t)e << 23);          // 2^(e-127)
+    const unsigned long long* mp = masks + q * 6 + h;
+    const unsigned long long m_a1 = mp[0], m_c1 = mp[2], m_c2 = mp[4];
+    // ---- d c2 = hW2^T dz3 : one k-step whose fragment is (dz3[0..2], 0...) on the h=0 lanes
+    u32x4 zh, zl;
+    {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (h == 0) { v[0] = dz3[0] * sc; v[1] = dz3[1] * sc; v[2] = dz3[2] * sc; }
+      split8(v, zh, zl);
+    }
+    Frag g2[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      Acc2 a;
+      acc_init_zero(a);
+      mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
+      grad_tile_to_frag<true>(a, g2[it], m_c2, it);
+    }
+    // ---- d c1 = hW1^T dz2
+    Frag g1[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      Acc2 a;
+      acc_init_zero(a);
+#pragma unroll
+      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
+      grad_tile_to_frag<true>(a, g1[it], m_c1, it);
+    }
+    // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
+    u32x4 dh_h, dh_l;
+    {
+      Acc2 a;
+      acc_init_zero(a);
+#pragma unroll
+      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G1 + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
+      if (h == 0) v[0] = dh0 * sc;
+      split8(v, dh_h, dh_l);
+    }
+    // ---- d a1 = bW1^T dh
+    Frag ga[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      Acc2 a;
+      acc_init_zero(a);
+      mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
+      grad_tile_to_frag<true>(a, ga[it], m_a1, it);
+    }
+    // ---- d feat = bW0^T dz
+    Acc2 gf;
+    acc_init_zero(gf);
+#pragma unroll
+    for (int u = 0; u < 8; u++) mma3(gf, Ihi, Ilo, D_GB0 + u, lane, ga[u >> 1].hi[u & 1], ga[u >> 1].lo[u & 1]);
+    if (valid) {
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++)  // rows 8qd+4h .. +3
+        dst[2 * qd + h] = make_float4(acc_get(gf, 4 * qd) * inv, acc_get(gf, 4 * qd + 1) * inv, acc_get(gf, 4 * qd + 2) * inv,
+                                      acc_get(gf, 4 * qd + 3) * inv);
+    }
+  }
+}
+
+unsigned persistent_grid8(int64_t n_max) {
+  int64_t tiles = (n_max + 31) / 32;
+  int64_t blocks = (tiles + 7) / 8;
+  if (blocks > 256) blocks = 256;  // one 512-thread workgroup per CU: the LDS image is copied once per workgroup
+  return (unsigned)(blocks > 0 ? blocks : 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_image, void* stream) {
+  GFN_CHECK_ARG(weights, "gfn_field_pack_x3: null weights");
+  for (int i = 0; i < 10; i++) GFN_CHECK_ARG(weights[i], "gfn_field_pack_x3: null weight pointer %d", i);
+  GFN_CHECK_ARG(fwd_image || bwd_image, "gfn_field_pack_x3: no output image");
+  FieldWeights w{weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6], weights[7], weights[8], weights[9]};
+  const int threads = (FWD_CHUNKS + BWD_CHUNKS) * 64;
+  field_pack_x3_kernel<<<threads / 256, 256, 0, gfn_stream(stream)>>>(w, reinterpret_cast<u32x4*>(fwd_image), reinterpret_cast<u32x4*>(bwd_image));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
+                     const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
+                     uint64_t* masks, void* stream) {
+  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
+  GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
+  GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
+  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_fwd_x3: n_max=%lld", (long long)n_max);
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(fwd_image) & 15) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(sh) & 15) == 0 && (reinterpret_cast<uintptr_t>(emb) & 15) == 0,
+                "gfn_field_fwd_x3: image, feat, sh and emb must be 16-byte aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    attr_set = true;
+  }
+  const unsigned grid = persistent_grid8(n_max);
+  const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
+  if (masks)
+    field_fwd_x3_kernel<true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, gfn_stream(stream)>>>(
+        n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, reinterpret_cast<unsigned long long*>(masks));
+  else
+    field_fwd_x3_kernel<false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img,
+                                                                                         sigma, rgb, nullptr, nullptr);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
+                        const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, void* stream) {
+  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && dfeat, "gfn_field_bwd_dx_x3: null pointer");
+  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_bwd_dx_x3: n_max=%lld", (long long)n_max);
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(bwd_image) & 15) == 0 && (reinterpret_cast<uintptr_t>(dfeat) & 15) == 0,
+                "gfn_field_bwd_dx_x3: image and dfeat must be 16-byte aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
+    attr_set = true;
+  }
+  field_bwd_dx_x3_kernel<<<persistent_grid8(n_max), 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(
+      n_max, n_dev, d_sigma, d_rgb, rgb, h0, reinterpret_cast<const unsigned long long*>(masks),
+      reinterpret_cast<const u32x4*>(bwd_image), dfeat);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+}  // extern "C"

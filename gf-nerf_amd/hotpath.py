@@ -38,6 +38,7 @@ class HotPathConfig:
     table_f16_shadow: bool = True    # gather from f16 shadows refreshed by the Adam kernel (same values as :185's cast)
     grad_f16: bool = True            # table gradient pool in f16 with the x128 loss scale, like the reference (:151,:209)
     fused_field: bool = True         # decoder as one kernel per direction (needs hidden == 128)
+    mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
 
@@ -91,6 +92,8 @@ class HotPath:
         self.table16 = None
         self.blocks16 = []
         self._pairs_stale = False
+        self._x3_images = [None, None]   # split-f16 weight images of the fused decoder (forward, backward)
+        self._x3_stale = True
         self.refresh_shadows()
         self._adam = {}
         self.step = 0
@@ -111,6 +114,14 @@ class HotPath:
             else:
                 self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
         self._pairs_stale = False
+        self._x3_stale = True  # callers use this hook after writing parameters from outside the optimiser
+
+    def _x3(self):
+        """Current split-f16 weight images of the fused decoder (rebuilt after every weight update)."""
+        if self._x3_stale or self._x3_images[0] is None:
+            self._x3_images = list(ops.field_pack_x3(self.layers, self._x3_images[0], self._x3_images[1]))
+            self._x3_stale = False
+        return self._x3_images
 
     def _timed(self, name, fn, *a, **k):
         if name not in self.timed_ops and "*" not in self.timed_ops:
@@ -172,7 +183,9 @@ class HotPath:
         emb = self.emb if self.cfg.use_appearance_embedding else None
         if fused:
             sh = ops.sh4(s["dirs_unit"])
-            out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save)
+            prec = self.cfg.mlp_precision
+            out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save,
+                              precision=prec, image=self._x3()[0] if prec == "x3" else None)
             out["feat"] = feat
             return out
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
@@ -237,7 +250,9 @@ class HotPath:
         d_sigma, d_rgb = self._timed("composite_bwd", ops.composite_bwd, s["pts_offsets"], f["sigma"], s["dists"], f["rgb"],
                                      g_rgb, g_acc, early_T=c.early_T)
         if ctx["fused"]:
-            dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev)
+            prec = c.mlp_precision
+            dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev,
+                                precision=prec, image=self._x3()[1] if prec == "x3" else None)
         else:
             (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = self.layers
             g = self.layer_grads
@@ -272,6 +287,7 @@ class HotPath:
             self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self.step, lr=c.lr, eps=c.adam_eps,
                         shadow_f16=self.table16, n=n_live)
             self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
+            self._x3_stale = True
             for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue

@@ -371,8 +371,26 @@ def _weight_ptrs(layers):
     return (C.c_void_p * 10)(*ptrs)
 
 
-def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False):
-    """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None)."""
+FIELD_X3_FWD_BYTES, FIELD_X3_BWD_BYTES = 149248, 114688
+
+
+def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bwd=True):
+    """Build the split-f16 weight images of the x3 decoder kernels (to be redone whenever the weights change)."""
+    dev = layers[0][0].device
+    if want_fwd and fwd_image is None:
+        fwd_image = torch.empty(FIELD_X3_FWD_BYTES, dtype=torch.uint8, device=dev)
+    if want_bwd and bwd_image is None:
+        bwd_image = torch.empty(FIELD_X3_BWD_BYTES, dtype=torch.uint8, device=dev)
+    wp = _weight_ptrs(layers)
+    rc = _lib.lib().gfn_field_pack_x3(wp, _ptr(fwd_image) if want_fwd else None, _ptr(bwd_image) if want_bwd else None, _stream())
+    _lib.check(rc, "gfn_field_pack_x3")
+    return fwd_image, bwd_image
+
+
+def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None):
+    """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None).
+    precision "x3": split-f16 MFMA (f32 accuracy, ~5x the f32 matrix rate; `image` = a current forward image from
+    field_pack_x3, built here when absent); "f32": exact f32 MFMA."""
     _chk(feat, torch.float32, "feat", 32); _chk(ray_id, torch.int32, "ray_id"); _chk(sh, torch.float32, "sh", 16)
     _chk(emb, torch.float32, "emb", 32); _chk(cam_idx, torch.int32, "cam_idx")
     n = feat.shape[0]
@@ -381,23 +399,41 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False):
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     h0 = torch.empty(n, dtype=torch.float32, device=dev) if save else None
     masks = torch.empty((n, 6), dtype=torch.int64, device=dev) if save else None
-    wp = _weight_ptrs(layers)
-    rc = _lib.lib().gfn_field_fwd(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), wp, n, _ptr(n_dev), _ptr(sigma),
-                                  _ptr(rgb), _ptr(h0), _ptr(masks), _stream())
-    _lib.check(rc, "gfn_field_fwd")
+    if precision == "x3":
+        if image is None:
+            image, _ = field_pack_x3(layers, want_bwd=False)
+        rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
+                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _stream())
+        _lib.check(rc, "gfn_field_fwd_x3")
+    elif precision == "f32":
+        wp = _weight_ptrs(layers)
+        rc = _lib.lib().gfn_field_fwd(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), wp, n, _ptr(n_dev), _ptr(sigma),
+                                      _ptr(rgb), _ptr(h0), _ptr(masks), _stream())
+        _lib.check(rc, "gfn_field_fwd")
+    else:
+        raise _lib.GfnError(f"unknown decoder precision {precision!r}")
     return dict(sigma=sigma, rgb=rgb, h0=h0, masks=masks)
 
 
-def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None):
+def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None, precision="x3", image=None):
     """Fused decoder backward w.r.t. the hash features (decoder frozen) -> dfeat [n,32]."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
     _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6)
     n = d_sigma.shape[0]
     dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
-    wp = _weight_ptrs(layers)
-    rc = _lib.lib().gfn_field_bwd_dx(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), wp, n, _ptr(n_dev), _ptr(dfeat),
-                                     _stream())
-    _lib.check(rc, "gfn_field_bwd_dx")
+    if precision == "x3":
+        if image is None:
+            _, image = field_pack_x3(layers, want_fwd=False)
+        rc = _lib.lib().gfn_field_bwd_dx_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
+                                            _ptr(dfeat), _stream())
+        _lib.check(rc, "gfn_field_bwd_dx_x3")
+    elif precision == "f32":
+        wp = _weight_ptrs(layers)
+        rc = _lib.lib().gfn_field_bwd_dx(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), wp, n, _ptr(n_dev), _ptr(dfeat),
+                                         _stream())
+        _lib.check(rc, "gfn_field_bwd_dx")
+    else:
+        raise _lib.GfnError(f"unknown decoder precision {precision!r}")
     return dfeat
 
 

@@ -219,6 +219,20 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
                      const uint64_t* masks, const float* const* weights, int64_t n_max,
                      const int32_t* n_dev, float* dfeat, void* stream);
 
+/* The same two kernels on the f16 matrix pipe at f32 accuracy (every operand split into two f16
+ * halves, three MFMAs per product sum, ~1e-6 relative; see csrc/field_x3.hip).  The weight images
+ * are built by gfn_field_pack_x3 whenever the weights change (either image may be NULL) and are
+ * read-only to the kernels; buffers of GFN_FIELD_X3_{FWD,BWD}_BYTES, 16-byte aligned. */
+#define GFN_FIELD_X3_FWD_BYTES 149248
+#define GFN_FIELD_X3_BWD_BYTES 114688
+int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_image, void* stream);
+int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
+                     const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
+                     float* sigma, float* rgb, float* h0, uint64_t* masks, void* stream);
+int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
+                        const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
+                        float* dfeat, void* stream);
+
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
  * default output.  dirs f32 [R,3] -> out f32 [R,16]. */

@@ -66,14 +66,17 @@ def test_render_matches_oracle(setup, block):
     assert out["oct_depth"].min() > 0  # nerfacto.py:556
 
 
-def test_fused_decoder_matches_per_layer_kernels(setup):
-    """gfn_field_fwd / gfn_field_bwd_dx (one kernel per direction) against the per-layer kernels and the oracle."""
+@pytest.mark.parametrize("precision", ["x3", "f32"])
+def test_fused_decoder_matches_per_layer_kernels(setup, precision):
+    """gfn_field_fwd[_x3] / gfn_field_bwd_dx[_x3] (one kernel per direction; split-f16 and exact-f32 MFMA forms) against
+    the per-layer f32 kernels."""
     import torch
 
     from gfnerf_amd import ops
 
     S = setup
     hp, t = S["hp"], S["t"]
+    hp.cfg.mlp_precision = precision
     s = hp.sample(t(S["o"]), t(S["d"]), t(S["noise"]))
     cam = t(S["cam"])
     N = int(s["pts_offsets"][-1].item())
@@ -102,7 +105,9 @@ def test_fused_decoder_matches_per_layer_kernels(setup):
     dead = rng.random(N) < 0.3
     dead[: 64] = True
     d_sigma[:N][dead] = 0; d_rgb[:N][dead] = 0
-    dfeat = ops.field_bwd_dx(t(d_sigma), t(d_rgb), fu["rgb"], fu["h0"], fu["masks"], hp.layers, n_dev=s["n_dev"]).cpu().numpy()[:N]
+    dfeat = ops.field_bwd_dx(t(d_sigma), t(d_rgb), fu["rgb"], fu["h0"], fu["masks"], hp.layers, n_dev=s["n_dev"],
+                             precision=precision).cpu().numpy()[:N]
+    hp.cfg.mlp_precision = "x3"
     (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = hp.layers
     n_dev = s["n_dev"]
     dc2, _, _ = ops.linear_bwd(un["c2"], hW2, un["rgb"], t(d_rgb), "sigmoid", need_dw=False, n_dev=n_dev)
