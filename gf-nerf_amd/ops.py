@@ -437,6 +437,29 @@ def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None, precision="
     return dfeat
 
 
+def split_f16(x):
+    """x f32 -> (hi, lo') f16 planes with x ~= hi + lo' * 2^-11 (the operand format of the x3 kernels)."""
+    hi = x.to(torch.float16)
+    lo = ((x - hi.float()) * 2048.0).to(torch.float16)
+    return hi, lo
+
+
+def wgrad_x3(dz, a, dW, db=None, n_dev=None, scale=None, m_valid=None, k_valid=None, col_map=None):
+    """dW[m, col(k)] += sum_s dz[s, m] a[s, k] / scale from split-f16 planes dz = (hi, lo'), a = (hi, lo')."""
+    (dz_hi, dz_lo), (a_hi, a_lo) = dz, a
+    for t in (dz_hi, dz_lo, a_hi, a_lo):
+        _chk(t, torch.float16, "plane")
+    _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db"); _chk(scale, torch.float32, "scale"); _chk(col_map, torch.int32, "col_map")
+    n = dz_hi.shape[0]
+    m_valid = dz_hi.shape[1] if m_valid is None else m_valid
+    k_valid = a_hi.shape[1] if k_valid is None else k_valid
+    rc = _lib.lib().gfn_wgrad_x3(_ptr(dz_hi), _ptr(dz_lo), dz_hi.stride(0), dz_hi.shape[1], _ptr(a_hi), _ptr(a_lo), a_hi.stride(0),
+                                 a_hi.shape[1], n, _ptr(n_dev), _ptr(scale), m_valid, k_valid, _ptr(col_map), _ptr(dW), dW.stride(0),
+                                 _ptr(db), _stream())
+    _lib.check(rc, "gfn_wgrad_x3")
+    return dW
+
+
 def sh4(dirs):
     _chk(dirs, torch.float32, "dirs", 3)
     out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)

@@ -233,6 +233,19 @@ int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* r
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                         float* dfeat, void* stream);
 
+/* Weight gradient of one decoder layer from split-f16 planes (global stage):
+ *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]
+ * for m < m_valid, k < k_valid; col(k) = col_map[k] (skipped when negative) or k.  A plane is two
+ * u16(f16) arrays [n][ld]: hi and lo' with x ~= hi + lo' * 2^-11; feat_* = stored columns (multiple
+ * of 8, <= 128; tile shapes 128x128, 32x128, 128x64, 128x32 after rounding up to 32).  scale_dev
+ * (device f32, may be NULL = 1) is the power-of-two factor the producer multiplied dz by.
+ * ACCUMULATES with f32 atomics (caller zeroes).  Replaces autograd's dW = dz^T a of the nn.Linear
+ * layers in gfnerf/mlp.py:35-57. */
+int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int feat_dz, const uint16_t* a_hi,
+                 const uint16_t* a_lo, int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev,
+                 const float* scale_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
+                 float* db, void* stream);
+
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
  * default output.  dirs f32 [R,3] -> out f32 [R,16]. */

@@ -554,3 +554,42 @@ def test_charbonnier_and_adam(oracle, ops, dev, golden):
     for s in range(3):
         ops.adam_step(p, _t(golden["adam_g"][s], dev), m, v, s + 1)
     np.testing.assert_allclose(p.cpu().numpy(), golden["adam_p3"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("m_feat,k_feat,m_valid,k_valid", [(128, 128, 128, 128), (8, 128, 3, 128), (128, 64, 128, 63),
+                                                           (16, 128, 16, 128), (128, 32, 128, 32)])
+def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid):
+    """gfn_wgrad_x3 (split-f16 planes, transposed LDS reads) against a float64 dz^T a, ragged n, device count, scale, col_map."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n_cap, n = 5000, 4321  # not a multiple of the 64-sample slab
+    dz = (rng.standard_normal((n_cap, m_feat)) * np.exp(rng.uniform(-6, 0, (n_cap, 1)))).astype(np.float32)
+    a = np.maximum(rng.standard_normal((n_cap, k_feat)), 0).astype(np.float32) * 3.0
+    dz[:, m_valid:] = 0
+    scale = 64.0
+    t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    dzp = ops.split_f16(t(dz * scale)); ap = ops.split_f16(t(a))
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    col_map = None
+    ldw = k_valid
+    if k_valid == 63:  # permuted / dropped columns, like the head's first layer
+        perm = rng.permutation(63).astype(np.int32)
+        perm[5] = -1
+        col_map = t(np.concatenate([perm, [-1]]).astype(np.int32))
+    dW = torch.zeros((m_valid, ldw), dtype=torch.float32, device=dev)
+    db = torch.zeros(m_valid, dtype=torch.float32, device=dev)
+    ops.wgrad_x3(dzp, ap, dW, db=db, n_dev=n_dev, scale=torch.tensor([scale], device=dev), m_valid=m_valid, k_valid=k_valid,
+                 col_map=col_map)
+    want = dz[:n, :m_valid].astype(np.float64).T @ a[:n, :k_valid].astype(np.float64)
+    if col_map is not None:
+        w2 = np.zeros((m_valid, ldw))
+        cm = col_map.cpu().numpy()
+        for k in range(k_valid):
+            if cm[k] >= 0:
+                w2[:, cm[k]] = want[:, k]
+        want = w2
+    got = dW.cpu().numpy()
+    mag = (np.abs(dz[:n, :m_valid]).astype(np.float64).T @ np.abs(a[:n, :k_valid]).astype(np.float64)).max()
+    assert np.abs(got - want).max() < 2e-6 * mag, (np.abs(got - want).max(), mag)
+    np.testing.assert_allclose(db.cpu().numpy(), dz[:n, :m_valid].astype(np.float64).sum(0), rtol=1e-4, atol=2e-6 * np.abs(dz[:n]).sum(0).max())

@@ -1,0 +1,72 @@
+// Scratch micro-benchmark: random 4-/8-byte gathers from a table (what bounds Hash3DAnchored's lookup?).
+// hipcc --offload-arch=gfx950 -O3 tools/gather_bench.hip -o /tmp/gather_bench && /tmp/gather_bench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+// KIND 0: global_load_dword (64-bit vaddr), 1: buffer_load_dword (32-bit voffset), 2: buffer dwordx2
+template <int KIND, int K>
+__global__ __launch_bounds__(256) void gather(const uint32_t* __restrict__ table, uint32_t mask, int iters, uint32_t* __restrict__ out) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, 0x7fffffff, 0x00020000);
+  uint32_t acc = 0;
+  for (int it = 0; it < iters; it++) {
+    uint32_t idx[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) idx[k] = mix(tid * 977u + it * 131071u + k * 7919u) & mask;
+    uint32_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (KIND == 0) v[k] = table[idx[k]];
+      else if (KIND == 1) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, idx[k] * 4u, 0, 0);
+      else { auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, (idx[k] & ~1u) * 4u, 0, 0); v[k] = t[0] ^ t[1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) acc += v[k];
+  }
+  out[tid] = acc;
+}
+
+template <int KIND, int K>
+int run(const char* name, const uint32_t* table, uint32_t mask, int blocks, int iters, uint32_t* out) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  gather<KIND, K><<<blocks, 256>>>(table, mask, iters, out);
+  CK(hipDeviceSynchronize());
+  float best = 1e9;
+  for (int r = 0; r < 3; r++) {
+    CK(hipEventRecord(e0));
+    gather<KIND, K><<<blocks, 256>>>(table, mask, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  const double n = (double)blocks * 256 * iters * K;
+  printf("%-34s table %4u MB blocks %5d K %2d: %7.3f ms  %7.1f G gathers/s\n", name, (mask + 1) / 262144, blocks, K, best, n / best / 1e6);
+  return 0;
+}
+
+int main() {
+  uint32_t* table; uint32_t* out;
+  const size_t tbytes = 512u << 20;
+  CK(hipMalloc(&table, tbytes)); CK(hipMemset(table, 1, tbytes));
+  CK(hipMalloc(&out, 64u << 20));
+  for (uint32_t mb : {4u, 64u, 128u, 512u}) {
+    const uint32_t mask = mb * 262144u - 1u;
+    for (int blocks : {2048, 4096}) {
+      const int iters = 2048 * 24 / blocks;
+      run<0, 8>("global dword", table, mask, blocks, iters, out);
+      run<1, 8>("buffer dword", table, mask, blocks, iters, out);
+      run<1, 16>("buffer dword", table, mask, blocks, iters / 2, out);
+      run<1, 32>("buffer dword", table, mask, blocks, iters / 4, out);
+      run<2, 8>("buffer dwordx2", table, mask, blocks, iters, out);
+      run<2, 16>("buffer dwordx2", table, mask, blocks, iters / 2, out);
+    }
+  }
+  return 0;
+}
