@@ -214,8 +214,7 @@ def main():
                                n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
                                fineness=fineness, stage=args.stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
                                block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
-                               mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" and args.stage == "focal"
-                                    else "f32 MFMA 32x32x2"),
+                               mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
                                scene_build_s=round(t_build, 1), loss=float(loss.item())),

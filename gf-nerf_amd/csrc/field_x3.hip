@@ -25,7 +25,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
-constexpr int FWD_CHUNKS = 72, BWD_CHUNKS = 56, FWD_BIAS = 448;
+constexpr int FWD_CHUNKS = 72, BWD_CHUNKS = 64, FWD_BIAS = 448;
 static_assert(GFN_FIELD_X3_FWD_BYTES == FWD_CHUNKS * 2048 + FWD_BIAS * 4, "forward image size");
 static_assert(GFN_FIELD_X3_BWD_BYTES == BWD_CHUNKS * 2048, "backward image size");
 static_assert(GFN_FIELD_X3_FWD_BYTES <= 160 * 1024, "forward LDS image must fit one CU");
@@ -42,6 +42,13 @@ constexpr int D_G2 = 4;    // d c1 = hW1^T dz2 : [u 8][it 4]
 constexpr int D_G1 = 36;   // d h[1:16] = hW0[:,16:31]^T dz1 : [u 8]
 constexpr int D_GB1 = 44;  // d a1 = bW1^T dh : [it 4]
 constexpr int D_GB0 = 48;  // d feat = bW0^T dz : [u 8]
+constexpr int D_GE = 56;   // d appearance = hW0[:,31:63]^T dz1 : [u 8]   (global stage only)
+// split-f16 planes kept for the weight gradients (global stage): one hi and one lo' array, row layouts (columns, f16)
+constexpr int FP_LD = GFN_FIELD_X3_FWD_PLANE_LD;   // feat 0..31 | a1 32..159 | xp 160..223 | c1 224..351 | c2 352..479
+constexpr int FP_FEAT = 0, FP_A1 = 32, FP_XP = 160, FP_C1 = 224, FP_C2 = 352;
+constexpr int BP_LD = GFN_FIELD_X3_BWD_PLANE_LD;   // dz3 0..7 | dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407
+constexpr int BP_DZ3 = 0, BP_DH = 8, BP_DZ2 = 24, BP_DZ1 = 152, BP_DZA1 = 280;
+static_assert(FP_LD == 480 && BP_LD == 408, "plane row widths");
 
 __device__ __forceinline__ int acc_row(int t, int s, int h, int i) { return 32 * t + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
 
@@ -69,8 +76,9 @@ __device__ float bwd_weight(const FieldWeights& w, int c, int h, int r, int i) {
   if (c < D_G1) { const int cc = c - D_G2, u = cc >> 2, it = cc & 3; return w.hW1[acc_row(u >> 1, u & 1, h, i) * 128 + 32 * it + r]; }
   if (c < D_GB1) { const int u = c - D_G1; return (r >= 1 && r <= 15) ? w.hW0[acc_row(u >> 1, u & 1, h, i) * 63 + 15 + r] : 0.f; }
   if (c < D_GB0) { const int it = c - D_GB1; return w.bW1[acc_row(0, 0, h, i) * 128 + 32 * it + r]; }
-  const int u = c - D_GB0;
-  return w.bW0[acc_row(u >> 1, u & 1, h, i) * 32 + r];
+  if (c < D_GE) { const int u = c - D_GB0; return w.bW0[acc_row(u >> 1, u & 1, h, i) * 32 + r]; }
+  const int u = c - D_GE;
+  return w.hW0[acc_row(u >> 1, u & 1, h, i) * 63 + 31 + r];
 }
 
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
@@ -190,12 +198,38 @@ __device__ __forceinline__ void load8(const float* p, float* x) {
   x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
 }
 
-template <bool SAVE>
+// a tile's two fragments -> columns col0 .. col0+31 of this sample's plane rows (registers 8s+4g..+3 = rows 16s+8g+4h..+3)
+__device__ __forceinline__ void store_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const Frag& f, int h) {
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      *reinterpret_cast<uint2*>(row_hi + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.hi[s][2 * g], f.hi[s][2 * g + 1]);
+      *reinterpret_cast<uint2*>(row_lo + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.lo[s][2 * g], f.lo[s][2 * g + 1]);
+    }
+}
+// the first k-step of a tile (rows 0..15) -> 16 columns
+__device__ __forceinline__ void store_half_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
+                                                const u32x4& fl, int h) {
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    *reinterpret_cast<uint2*>(row_hi + col0 + 8 * g + 4 * h) = make_uint2(fh[2 * g], fh[2 * g + 1]);
+    *reinterpret_cast<uint2*>(row_lo + col0 + 8 * g + 4 * h) = make_uint2(fl[2 * g], fl[2 * g + 1]);
+  }
+}
+// a natural-order fragment (k = 8h + i) -> 16 columns
+__device__ __forceinline__ void store_nat(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
+                                          const u32x4& fl, int h) {
+  *reinterpret_cast<u32x4*>(row_hi + col0 + 8 * h) = fh;
+  *reinterpret_cast<u32x4*>(row_lo + col0 + 8 * h) = fl;
+}
+
+template <bool SAVE, bool PLANES>
 __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
     const u32x4* __restrict__ image, float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ h0_out,
-    unsigned long long* __restrict__ masks /* [n][3][2] */) {
+    unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
@@ -212,6 +246,8 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const int64_t s = tile * 32 + j;
     const bool valid = s < n;
     const int64_t q = valid ? s : n - 1;
+    uint16_t* const row_hi = PLANES ? planes_hi + q * FP_LD : nullptr;  // invalid lanes rewrite the last live row with the same values
+    uint16_t* const row_lo = PLANES ? planes_lo + q * FP_LD : nullptr;
     // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
     u32x4 xh[2], xl[2];
 #pragma unroll
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
       float x[8];
       load8(feat + q * 32 + 16 * u + 8 * h, x);
       split8(x, xh[u], xl[u]);
+      if (PLANES) store_nat(row_hi, row_lo, FP_FEAT + 16 * u, xh[u], xl[u], h);
     }
     Frag a1[4];
     unsigned long long m_a1 = 0;
@@ -229,6 +266,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
       tile_to_frag<true>(a, a1[ot], m_a1, ot);
+      if (PLANES) store_tile(row_hi, row_lo, FP_A1 + 32 * ot, a1[ot], h);
     }
     // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
     Acc2 hh;
@@ -246,6 +284,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
       split8(v, gh, gl);
+      if (PLANES) store_half_tile(row_hi, row_lo, FP_XP, gh, gl, h);
     }
     // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
     const int ray = ray_id[q];
@@ -264,6 +303,11 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
           for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
       }
+      if (PLANES) {
+        store_nat(row_hi, row_lo, FP_XP + 16, sh_h, sh_l, h);
+        store_nat(row_hi, row_lo, FP_XP + 32, e_h[0], e_l[0], h);
+        store_nat(row_hi, row_lo, FP_XP + 48, e_h[1], e_l[1], h);
+      }
     }
     Frag c1[4];
     unsigned long long m_c1 = 0;
@@ -276,6 +320,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
       mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
       mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
       tile_to_frag<true>(a, c1[ot], m_c1, ot);
+      if (PLANES) store_tile(row_hi, row_lo, FP_C1 + 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU
     Frag c2[4];
@@ -287,6 +332,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       tile_to_frag<true>(a, c2[ot], m_c2, ot);
+      if (PLANES) store_tile(row_hi, row_lo, FP_C2 + 32 * ot, c2[ot], h);
     }
     // ---- head layer 3: 128 -> 3 (padded), sigmoid
     Acc2 o3;
@@ -319,10 +365,27 @@ __device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsign
   for (int s = 0; s < 2; s++) split8(v + 8 * s, f.hi[s], f.lo[s]);
 }
 
+// Sum v over the lanes [lane, run_end] of this 32-lane half (runs = consecutive samples of one ray).
+__device__ __forceinline__ float half_run_sum(float v, int j, int run_end) {
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const float u = __shfl_down(v, off, 32);
+    if (j + off <= run_end) v += u;
+  }
+  return v;
+}
+
+// PLANES = false: the focal stage (decoder frozen): d feat only, per-sample gradient scale.
+// PLANES = true : the global stage: also writes dz of every layer as split-f16 planes (for gfn_wgrad_x3) under ONE
+//                 power-of-two scale for the whole batch (gfn_grad_scale_of(*gmax)), and reduces the appearance-embedding
+//                 gradient over each ray's samples into demb.
+template <bool PLANES>
 __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
-    const u32x4* __restrict__ image, float* __restrict__ dfeat) {
+    const u32x4* __restrict__ image, float* __restrict__ dfeat, const float* __restrict__ gmax_dev,
+    uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, const int* __restrict__ ray_id,
+    const int* __restrict__ cam_idx, float* __restrict__ demb) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
@@ -332,6 +395,8 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t n_tiles = (n + 31) / 32;
+  float g_sc = 1.f, g_inv = 1.f;
+  if (PLANES) { g_sc = gfn_grad_scale_of(gmax_dev[0]); g_inv = 1.0f / g_sc; }
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
     const int64_t s = tile * 32 + j;
     const bool valid = s < n;
@@ -347,10 +412,18 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       any_grad = any_grad || g != 0.f;
     }
     float4* dst = reinterpret_cast<float4*>(dfeat + s * 32);
+    uint16_t* const row_hi = PLANES ? planes_hi + s * BP_LD : nullptr;
+    uint16_t* const row_lo = PLANES ? planes_lo + s * BP_LD : nullptr;
     if (!__any(any_grad)) {  // wave-uniform: the whole tile lies behind its rays' termination points
       if (valid) {
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) dst[2 * qd + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PLANES) {  // this lane's half of the row (BP_LD/2 = 204 columns = 408 bytes, 8-byte aligned)
+          uint2* zh = reinterpret_cast<uint2*>(row_hi + h * (BP_LD / 2));
+          uint2* zl = reinterpret_cast<uint2*>(row_lo + h * (BP_LD / 2));
+#pragma unroll 1
+          for (int e = 0; e < BP_LD / 8; e++) { zh[e] = make_uint2(0u, 0u); zl[e] = make_uint2(0u, 0u); }
+        }
       }
       continue;
     }
@@ -358,13 +431,18 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
     float xx = h0[q] + 1.0f;
     xx = fminf(fmaxf(xx, -15.f), 15.f);
     const float dh0 = ds * expf(xx);
-    // per-sample power-of-two scale: gradients are ~1e-5 and below, under the f16 normal range.
-    // Every quantity of this sample's column is linear in (dz3, dh0), so the scale is undone exactly at the end.
-    const float mx = fmaxf(fmaxf(fabsf(dz3[0]), fabsf(dz3[1])), fmaxf(fabsf(dz3[2]), fabsf(dh0)));
-    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-    e = e < 27 ? 27 : (e > 227 ? 227 : e);
-    const float sc = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^(127-e): mx*sc in [1,2)
-    const float inv = __uint_as_float((uint32_t)e << 23);          // 2^(e-127)
+    float sc, inv;
+    if (PLANES) {
+      sc = g_sc; inv = g_inv;
+    } else {
+      // per-sample power-of-two scale: gradients are ~1e-5 and below, under the f16 normal range.
+      // Every quantity of this sample's column is linear in (dz3, dh0), so the scale is undone exactly at the end.
+      const float mx = fmaxf(fmaxf(fabsf(dz3[0]), fabsf(dz3[1])), fmaxf(fabsf(dz3[2]), fabsf(dh0)));
+      int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+      e = e < 27 ? 27 : (e > 227 ? 227 : e);
+      sc = __uint_as_float((uint32_t)(254 - e) << 23);   // 2^(127-e): mx*sc in [1,2)
+      inv = __uint_as_float((uint32_t)e << 23);          // 2^(e-127)
+    }
     const unsigned long long* mp = masks + q * 6 + h;
     const unsigned long long m_a1 = mp[0], m_c1 = mp[2], m_c2 = mp[4];
     // ---- d c2 = hW2^T dz3 : one k-step whose fragment is (dz3[0..2], 0...) on the h=0 lanes
@@ -373,6 +451,10 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (h == 0) { v[0] = dz3[0] * sc; v[1] = dz3[1] * sc; v[2] = dz3[2] * sc; }
       split8(v, zh, zl);
+      if (PLANES && valid && h == 0) {
+        *reinterpret_cast<u32x4*>(row_hi + BP_DZ3) = zh;
+        *reinterpret_cast<u32x4*>(row_lo + BP_DZ3) = zl;
+      }
     }
     Frag g2[4];
 #pragma unroll
@@ -381,6 +463,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
       grad_tile_to_frag<true>(a, g2[it], m_c2, it);
+      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZ2 + 32 * it, g2[it], h);
     }
     // ---- d c1 = hW1^T dz2
     Frag g1[4];
@@ -391,6 +474,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
       grad_tile_to_frag<true>(a, g1[it], m_c1, it);
+      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZ1 + 32 * it, g1[it], h);
     }
     // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
     u32x4 dh_h, dh_l;
@@ -404,6 +488,27 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
       if (h == 0) v[0] = dh0 * sc;
       split8(v, dh_h, dh_l);
+      if (PLANES && valid) store_half_tile(row_hi, row_lo, BP_DH, dh_h, dh_l, h);
+    }
+    if (PLANES && demb) {
+      // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
+      Acc2 a;
+      acc_init_zero(a);
+#pragma unroll
+      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_GE + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
+      const int ray = valid ? ray_id[q] : -1;
+      const int prev = __shfl_up(ray, 1, 32);
+      const bool head = (j == 0) || prev != ray;
+      const unsigned long long heads64 = __ballot(head);
+      const uint32_t heads = (uint32_t)(heads64 >> (32 * h));
+      const uint32_t later = (j == 31) ? 0u : (heads >> (j + 1));
+      const int run_end = later ? j + __builtin_ctz(later) : 31;
+      float* erow = (head && valid) ? demb + (int64_t)cam_idx[ray] * 32 : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = half_run_sum(valid ? acc_get(a, r) : 0.f, j, run_end);
+        if (erow && v != 0.f) atomicAdd(erow + (r & 3) + 8 * (r >> 2) + 4 * h, v * inv);
+      }
     }
     // ---- d a1 = bW1^T dh
     Frag ga[4];
@@ -413,6 +518,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
       grad_tile_to_frag<true>(a, ga[it], m_a1, it);
+      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZA1 + 32 * it, ga[it], h);
     }
     // ---- d feat = bW0^T dz
     Acc2 gf;
@@ -426,6 +532,26 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
                                       acc_get(gf, 4 * qd + 3) * inv);
     }
   }
+}
+
+// largest |gradient| entering the decoder: max over samples of |d rgb| and |d sigma * exp(clamp(h0+1))|, as f32 bits
+// (non-negative floats order like unsigned integers) -- the batch-wide scale of the global-stage backward
+__global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma,
+                                                       const float* __restrict__ d_rgb, const float* __restrict__ h0,
+                                                       uint32_t* __restrict__ gmax) {
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float xx = h0[i] + 1.0f;
+    xx = fminf(fmaxf(xx, -15.f), 15.f);
+    const float a = fabsf(d_sigma[i] * expf(xx));
+    const float b = fmaxf(fmaxf(fabsf(d_rgb[3 * i]), fabsf(d_rgb[3 * i + 1])), fabsf(d_rgb[3 * i + 2]));
+    const float c = fmaxf(a, b);
+    m = (c <= 3.0e38f) ? fmaxf(m, c) : m;  // ignore inf / nan
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(gmax, __float_as_uint(m));
 }
 
 unsigned persistent_grid8(int64_t n_max) {
@@ -452,50 +578,97 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
                      const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
-                     uint64_t* masks, void* stream) {
+                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
+  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || masks),
+                "gfn_field_fwd_x3: planes need both halves and the masks");
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_fwd_x3: n_max=%lld", (long long)n_max);
-  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(fwd_image) & 15) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(sh) & 15) == 0 && (reinterpret_cast<uintptr_t>(emb) & 15) == 0,
-                "gfn_field_fwd_x3: image, feat, sh and emb must be 16-byte aligned");
+  GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(sh) |
+                  reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
+                "gfn_field_fwd_x3: image, feat, sh, emb and planes must be 16-byte aligned");
   static bool attr_set = false;
   if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
     attr_set = true;
   }
   const unsigned grid = persistent_grid8(n_max);
   const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
-  if (masks)
-    field_fwd_x3_kernel<true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, gfn_stream(stream)>>>(
-        n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, reinterpret_cast<unsigned long long*>(masks));
+  hipStream_t st = gfn_stream(stream);
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
+  if (planes_hi)
+    field_fwd_x3_kernel<true, true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
+                                                                              planes_hi, planes_lo);
+  else if (masks)
+    field_fwd_x3_kernel<true, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
+                                                                               nullptr, nullptr);
   else
-    field_fwd_x3_kernel<false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img,
-                                                                                         sigma, rgb, nullptr, nullptr);
+    field_fwd_x3_kernel<false, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb,
+                                                                                nullptr, nullptr, nullptr, nullptr);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
+                             const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat,
+                             const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, const int32_t* ray_id,
+                             const int32_t* cam_idx, float* demb, void* stream) {
+  if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && dfeat, "%s: null pointer", fn);
+  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "%s: n_max=%lld", fn, (long long)n_max);
+  GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(dfeat) | reinterpret_cast<uintptr_t>(planes_hi) |
+                  reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
+    attr_set = true;
+  }
+  const unsigned grid = persistent_grid8(n_max);
+  const u32x4* img = reinterpret_cast<const u32x4*>(bwd_image);
+  const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(masks);
+  if (planes_hi)
+    field_bwd_dx_x3_kernel<true><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev,
+                                                                                           planes_hi, planes_lo, ray_id, cam_idx, demb);
+  else
+    field_bwd_dx_x3_kernel<false><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, nullptr,
+                                                                                            nullptr, nullptr, nullptr, nullptr, nullptr);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
 
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
                         const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, void* stream) {
+  return field_bwd_x3_impl("gfn_field_bwd_dx_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, stream);
+}
+
+int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
+                     const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, const float* gmax_dev,
+                     uint16_t* planes_hi, uint16_t* planes_lo, const int32_t* ray_id, const int32_t* cam_idx, float* demb,
+                     void* stream) {
+  GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi && planes_lo), "gfn_field_bwd_x3: gmax and both plane halves are required");
+  GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_x3: demb needs ray_id and cam_idx");
+  return field_bwd_x3_impl("gfn_field_bwd_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, gmax_dev, planes_hi, planes_lo,
+                           ray_id, cam_idx, demb, stream);
+}
+
+int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max, const int32_t* n_dev, float* gmax_dev,
+                 void* stream) {
   if (n_max == 0) return GFN_OK;
-  GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && dfeat, "gfn_field_bwd_dx_x3: null pointer");
-  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_bwd_dx_x3: n_max=%lld", (long long)n_max);
-  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(bwd_image) & 15) == 0 && (reinterpret_cast<uintptr_t>(dfeat) & 15) == 0,
-                "gfn_field_bwd_dx_x3: image and dfeat must be 16-byte aligned");
-  static bool attr_set = false;
-  if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
-    attr_set = true;
-  }
-  field_bwd_dx_x3_kernel<<<persistent_grid8(n_max), 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(
-      n_max, n_dev, d_sigma, d_rgb, rgb, h0, reinterpret_cast<const unsigned long long*>(masks),
-      reinterpret_cast<const u32x4*>(bwd_image), dfeat);
+  GFN_CHECK_ARG(d_sigma && d_rgb && h0 && gmax_dev, "gfn_grad_max: null pointer");
+  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31), "gfn_grad_max: n_max=%lld", (long long)n_max);
+  int64_t blocks = (n_max + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  grad_max_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, h0, reinterpret_cast<uint32_t*>(gmax_dev));
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
+
+float gfn_grad_scale_host(float gmax) { return gfn_grad_scale_of(gmax); }
 
 }  // extern "C"

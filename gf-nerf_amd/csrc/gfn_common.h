@@ -42,6 +42,18 @@ __device__ __forceinline__ int64_t gfn_live_n(int64_t n_max, const int32_t* n_de
   return n_max;
 }
 
+// Power-of-two gradient scale of the global-stage decoder backward: gmax * scale lies in [8, 16), which leaves the
+// f16 halves three orders of magnitude of headroom for growth through the transposed layers and ~1e-12 of gmax
+// as absolute resolution (hi + lo' * 2^-11, f16 subnormals included).
+__host__ __device__ __forceinline__ float gfn_grad_scale_of(float gmax) {
+  union { float f; uint32_t u; } v;
+  v.f = gmax;
+  int e = (int)((v.u >> 23) & 0xffu);
+  e = e < 27 ? 27 : (e > 227 ? 227 : e);
+  v.u = (uint32_t)(257 - e) << 23;  // 2^(130 - e)
+  return v.f;
+}
+
 // f32 -> f16 -> f32 round trip, RNE (v_cvt_f16_f32 / v_cvt_f32_f16).  The empty asm pins x as
 // an f32 VGPR first: without it hipcc folds `(half)(a*b)` into v_fma_mixlo_f16, which rounds the
 // exact product ONCE, whereas the reference (mul.f32 then cvt.rn.f16.f32) rounds twice.

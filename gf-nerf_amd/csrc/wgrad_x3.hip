@@ -53,7 +53,7 @@ __device__ __forceinline__ void stage_plane(_Float16* dst /*[tiles][S][32]*/, co
 // and loops over the NI in tiles.
 template <int MO, int NI>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int32_t* __restrict__ n_dev, Plane dz, Plane a,
-                                                       const float* __restrict__ scale_dev, float* __restrict__ dW, int ldw,
+                                                       const float* __restrict__ gmax_dev, float* __restrict__ dW, int ldw,
                                                        int m_valid, int k_valid, const int* __restrict__ col_map,
                                                        float* __restrict__ db) {
   constexpr bool WAVE_IS_NI = (NI == 4);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
     }
     __syncthreads();
   }
-  const float inv = scale_dev ? 1.0f / scale_dev[0] : 1.0f;  // the producers' power-of-two gradient scale
+  const float inv = gmax_dev ? 1.0f / gfn_grad_scale_of(gmax_dev[0]) : 1.0f;  // the producer's power-of-two gradient scale
   if (db) {
     const int m = threadIdx.x & 127;
     if (m < m_valid && m < 32 * MO && bsum != 0.f) atomicAdd(db + m, bsum * inv);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
 }
 
 template <int MO, int NI>
-int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* scale_dev, float* dW, int ldw,
+int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
            int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
   const size_t lds = (size_t)2 * (MO + NI) * S * 32 * sizeof(_Float16);
   static bool attr_set = false;
@@ -150,7 +150,7 @@ int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a,
   }
   int64_t blocks = (n_max + S - 1) / S;
   if (blocks > 512) blocks = 512;
-  wgrad_x3_kernel<MO, NI><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, scale_dev, dW, ldw, m_valid, k_valid, col_map, db);
+  wgrad_x3_kernel<MO, NI><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -160,7 +160,7 @@ int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a,
 extern "C" {
 
 int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int feat_dz, const uint16_t* a_hi, const uint16_t* a_lo,
-                 int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev, const float* scale_dev, int m_valid, int k_valid,
+                 int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev, const float* gmax_dev, int m_valid, int k_valid,
                  const int32_t* col_map, float* dW, int ldw, float* db, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(dz_hi && dz_lo && a_hi && a_lo && dW, "gfn_wgrad_x3: null pointer");
@@ -174,7 +174,7 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
   const Plane dz{dz_hi, dz_lo, ld_dz, feat_dz}, a{a_hi, a_lo, ld_a, feat_a};
   const int MO = (feat_dz + 31) / 32, NI = (feat_a + 31) / 32;
   hipStream_t st = gfn_stream(stream);
-#define GFN_WG(M, N) return launch<M, N>(n_max, n_dev, dz, a, scale_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
+#define GFN_WG(M, N) return launch<M, N>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
   if (MO == 4 && NI == 4) GFN_WG(4, 4);
   if (MO == 1 && NI == 4) GFN_WG(1, 4);
   if (MO == 4 && NI == 2) GFN_WG(4, 2);

@@ -92,6 +92,7 @@ class HotPath:
         self.table16 = None
         self.blocks16 = []
         self._pairs_stale = False
+        self._plane_bufs = None
         self._x3_images = [None, None]   # split-f16 weight images of the fused decoder (forward, backward)
         self._x3_stale = True
         self.refresh_shadows()
@@ -115,6 +116,19 @@ class HotPath:
                 self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
         self._pairs_stale = False
         self._x3_stale = True  # callers use this hook after writing parameters from outside the optimiser
+
+    def _planes(self, cap):
+        """Split-f16 activation / gradient planes of the global stage (480 + 408 f16 columns, hi and lo' each), sized like
+        the packed sample buffers and kept across steps."""
+        if self._plane_bufs is None or self._plane_bufs[0][0].shape[0] < cap:
+            mk = lambda ld: (torch.empty((cap, ld), dtype=torch.float16, device=self.dev),  # noqa: E731
+                             torch.empty((cap, ld), dtype=torch.float16, device=self.dev))
+            self._plane_bufs = (mk(ops.FIELD_X3_FWD_PLANE_LD), mk(ops.FIELD_X3_BWD_PLANE_LD))
+            # xp plane column -> hW0 column: base rows 1..15 = geo (16..30), row 0 = density channel (none), SH, appearance
+            cm = np.concatenate([[-1], 15 + np.arange(1, 16), np.arange(16), 31 + np.arange(32)]).astype(np.int32)
+            self._xp_col_map = torch.from_numpy(cm).to(self.dev)
+            self._gmax = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        return self._plane_bufs
 
     def _x3(self):
         """Current split-f16 weight images of the fused decoder (rebuilt after every weight update)."""
@@ -156,7 +170,7 @@ class HotPath:
         return s
 
     # -------------------------------------------------------------------- field
-    def _field_forward(self, s, cam_idx, block=None, fused=None, save=False):
+    def _field_forward(self, s, cam_idx, block=None, fused=None, save=False, planes=None):
         """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples.
         fused: one decoder kernel (sigma, rgb [+ ReLU masks when save]); else the per-layer kernels,
         which keep every activation (needed for the weight gradients of the global stage)."""
@@ -185,7 +199,7 @@ class HotPath:
             sh = ops.sh4(s["dirs_unit"])
             prec = self.cfg.mlp_precision
             out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save,
-                              precision=prec, image=self._x3()[0] if prec == "x3" else None)
+                              precision=prec, image=self._x3()[0] if prec == "x3" else None, planes=planes)
             out["feat"] = feat
             return out
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
@@ -233,8 +247,11 @@ class HotPath:
         train_mlp = stage == STAGE_GLOBAL
         self._timed("zero_grads", self.zero_grads, stage, block)
         s = self.sample(rays_o, rays_d_raw, noise)
-        fused = (not train_mlp) and c.fused_field and c.hidden == 128  # frozen decoder: masks are all the backward needs
-        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None, fused=fused, save=fused)
+        # focal stage (frozen decoder): the ReLU masks are all the backward needs; global stage: the x3 kernels also keep
+        # every layer input as split-f16 planes for the weight gradients (the exact-f32 fused kernels have no such form)
+        fused = c.fused_field and c.hidden == 128 and (not train_mlp or c.mlp_precision == "x3")
+        planes = self._planes(s["ts"].shape[0])[0] if (fused and train_mlp) else None
+        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None, fused=fused, save=fused, planes=planes)
         comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
                            early_T=c.early_T)
         ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)
@@ -249,7 +266,21 @@ class HotPath:
         n_dev = s["n_dev"]
         d_sigma, d_rgb = self._timed("composite_bwd", ops.composite_bwd, s["pts_offsets"], f["sigma"], s["dists"], f["rgb"],
                                      g_rgb, g_acc, early_T=c.early_T)
-        if ctx["fused"]:
+        if ctx["fused"] and train_mlp:
+            fp, bp = self._planes(s["ts"].shape[0])
+            ops.fill_zero(self._gmax)
+            self._timed("field_bwd", ops.grad_max, d_sigma, d_rgb, f["h0"], self._gmax, n_dev=n_dev)
+            demb = self.emb_grad if c.use_appearance_embedding else None
+            dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
+                                bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+            g = self.layer_grads
+            F, B = ops.FWD_PLANE, ops.BWD_PLANE
+            n_cap = s["ts"].shape[0]
+            for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
+                                          (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None)):
+                self._timed("wgrad", ops.wgrad_x3, (bp[0], bp[1]) + B[dzk], (fp[0], fp[1]) + F[ak], g[li][0], db=g[li][1], n_dev=n_dev,
+                            gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
+        elif ctx["fused"]:
             prec = c.mlp_precision
             dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev,
                                 precision=prec, image=self._x3()[1] if prec == "x3" else None)

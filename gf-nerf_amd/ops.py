@@ -371,7 +371,11 @@ def _weight_ptrs(layers):
     return (C.c_void_p * 10)(*ptrs)
 
 
-FIELD_X3_FWD_BYTES, FIELD_X3_BWD_BYTES = 149248, 114688
+FIELD_X3_FWD_BYTES, FIELD_X3_BWD_BYTES = 149248, 131072
+FIELD_X3_FWD_PLANE_LD, FIELD_X3_BWD_PLANE_LD = 480, 408
+# column ranges of the planes (include/gfnerf_amd.h)
+FWD_PLANE = dict(feat=(0, 32), a1=(32, 128), xp=(160, 64), c1=(224, 128), c2=(352, 128))
+BWD_PLANE = dict(dz3=(0, 8), dh=(8, 16), dz2=(24, 128), dz1=(152, 128), dza1=(280, 128))
 
 
 def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bwd=True):
@@ -387,7 +391,7 @@ def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bw
     return fwd_image, bwd_image
 
 
-def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None):
+def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None, planes=None):
     """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None).
     precision "x3": split-f16 MFMA (f32 accuracy, ~5x the f32 matrix rate; `image` = a current forward image from
     field_pack_x3, built here when absent); "f32": exact f32 MFMA."""
@@ -402,8 +406,13 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
     if precision == "x3":
         if image is None:
             image, _ = field_pack_x3(layers, want_bwd=False)
+        ph, pl = planes if planes is not None else (None, None)
+        for t in (ph, pl):  # split-f16 activation planes for the weight gradients (global stage)
+            _chk(t, torch.float16, "planes", FIELD_X3_FWD_PLANE_LD)
+            if t is not None and t.shape[0] < n:
+                raise _lib.GfnError("activation planes are shorter than the sample buffers")
         rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
-                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _stream())
+                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), _stream())
         _lib.check(rc, "gfn_field_fwd_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)
@@ -444,20 +453,61 @@ def split_f16(x):
     return hi, lo
 
 
-def wgrad_x3(dz, a, dW, db=None, n_dev=None, scale=None, m_valid=None, k_valid=None, col_map=None):
-    """dW[m, col(k)] += sum_s dz[s, m] a[s, k] / scale from split-f16 planes dz = (hi, lo'), a = (hi, lo')."""
-    (dz_hi, dz_lo), (a_hi, a_lo) = dz, a
-    for t in (dz_hi, dz_lo, a_hi, a_lo):
-        _chk(t, torch.float16, "plane")
-    _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db"); _chk(scale, torch.float32, "scale"); _chk(col_map, torch.int32, "col_map")
-    n = dz_hi.shape[0]
-    m_valid = dz_hi.shape[1] if m_valid is None else m_valid
-    k_valid = a_hi.shape[1] if k_valid is None else k_valid
-    rc = _lib.lib().gfn_wgrad_x3(_ptr(dz_hi), _ptr(dz_lo), dz_hi.stride(0), dz_hi.shape[1], _ptr(a_hi), _ptr(a_lo), a_hi.stride(0),
-                                 a_hi.shape[1], n, _ptr(n_dev), _ptr(scale), m_valid, k_valid, _ptr(col_map), _ptr(dW), dW.stride(0),
-                                 _ptr(db), _stream())
+def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=None, col_map=None, n=None):
+    """dW[m, col(k)] += sum_s dz[s, m] a[s, k] / gfn_grad_scale(gmax) from split-f16 planes.  dz and a are
+    (hi, lo') pairs of [n, width] tensors, or (hi, lo', col0, width) to address a column range of wider planes."""
+    def unpack(p):
+        hi, lo = p[0], p[1]
+        _chk(hi, torch.float16, "plane"); _chk(lo, torch.float16, "plane")
+        col0, width = (p[2], p[3]) if len(p) == 4 else (0, hi.shape[1])
+        if hi.shape != lo.shape or col0 + width > hi.shape[1]:
+            raise _lib.GfnError("plane halves differ or the column range is out of bounds")
+        eb = hi.element_size()
+        return hi.data_ptr() + col0 * eb, lo.data_ptr() + col0 * eb, hi.stride(0), width, hi.shape[0]
+    dzh, dzl, ld_dz, w_dz, n_dz = unpack(dz)
+    ah, al, ld_a, w_a, n_a = unpack(a)
+    _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db"); _chk(gmax, torch.float32, "gmax"); _chk(col_map, torch.int32, "col_map")
+    n = min(n_dz, n_a) if n is None else n
+    m_valid = w_dz if m_valid is None else m_valid
+    k_valid = w_a if k_valid is None else k_valid
+    if dW.shape[0] < m_valid or (col_map is None and dW.shape[1] < k_valid) or (col_map is not None and col_map.numel() < k_valid):
+        raise _lib.GfnError("dW / col_map too small for the requested rows and columns")
+    rc = _lib.lib().gfn_wgrad_x3(dzh, dzl, ld_dz, w_dz, ah, al, ld_a, w_a, n, _ptr(n_dev), _ptr(gmax), m_valid, k_valid, _ptr(col_map),
+                                 _ptr(dW), dW.stride(0), _ptr(db), _stream())
     _lib.check(rc, "gfn_wgrad_x3")
     return dW
+
+
+def grad_scale(gmax: float) -> float:
+    """The power-of-two scale the global-stage decoder backward derives from the largest incoming gradient."""
+    return float(_lib.lib().gfn_grad_scale_host(float(gmax)))
+
+
+def grad_max(d_sigma, d_rgb, h0, gmax, n_dev=None):
+    """gmax[0] = max(gmax[0], max |d rgb|, max |d sigma * exp(clamp(h0 + 1))|) (gmax zeroed by the caller)."""
+    _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(h0, torch.float32, "h0")
+    _chk(gmax, torch.float32, "gmax")
+    rc = _lib.lib().gfn_grad_max(_ptr(d_sigma), _ptr(d_rgb), _ptr(h0), d_sigma.shape[0], _ptr(n_dev), _ptr(gmax), _stream())
+    _lib.check(rc, "gfn_grad_max")
+    return gmax
+
+
+def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=None, cam_idx=None, demb=None, n_dev=None):
+    """Fused decoder backward of the global stage: dfeat [n,32] + dz planes (for wgrad_x3) + appearance-embedding gradient."""
+    _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
+    _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6); _chk(gmax, torch.float32, "gmax")
+    _chk(ray_id, torch.int32, "ray_id"); _chk(cam_idx, torch.int32, "cam_idx"); _chk(demb, torch.float32, "demb", 32)
+    ph, pl = planes
+    n = d_sigma.shape[0]
+    for t in (ph, pl):
+        _chk(t, torch.float16, "planes", FIELD_X3_BWD_PLANE_LD)
+        if t.shape[0] < n:
+            raise _lib.GfnError("gradient planes are shorter than the sample buffers")
+    dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
+    rc = _lib.lib().gfn_field_bwd_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
+                                     _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _stream())
+    _lib.check(rc, "gfn_field_bwd_x3")
+    return dfeat
 
 
 def sh4(dirs):

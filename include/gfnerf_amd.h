@@ -220,30 +220,50 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
                      const int32_t* n_dev, float* dfeat, void* stream);
 
 /* The same two kernels on the f16 matrix pipe at f32 accuracy (every operand split into two f16
- * halves, three MFMAs per product sum, ~1e-6 relative; see csrc/field_x3.hip).  The weight images
- * are built by gfn_field_pack_x3 whenever the weights change (either image may be NULL) and are
- * read-only to the kernels; buffers of GFN_FIELD_X3_{FWD,BWD}_BYTES, 16-byte aligned. */
+ * halves x ~= hi + lo' * 2^-11, three MFMAs per product sum, ~1e-6 relative; see csrc/field_x3.hip).
+ * The weight images are built by gfn_field_pack_x3 whenever the weights change (either image may be
+ * NULL) and are read-only to the kernels; buffers of GFN_FIELD_X3_{FWD,BWD}_BYTES, 16-byte aligned.
+ *
+ * Global stage (decoder trains): gfn_field_fwd_x3 with planes_{hi,lo} != NULL also keeps every layer
+ * input as split-f16 planes u16 [n][GFN_FIELD_X3_FWD_PLANE_LD]: columns feat 0..31 | a1 32..159 |
+ * xp 160..223 (base output rows 0..15, SH 16, appearance 32) | c1 224..351 | c2 352..479;
+ * gfn_field_bwd_x3 writes dz of every layer as planes u16 [n][GFN_FIELD_X3_BWD_PLANE_LD]: dz3 0..7 |
+ * dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407, all multiplied by the power-of-two scale
+ * gfn_grad_scale_host(*gmax_dev) (gmax_dev: device f32 = largest |gradient| entering the decoder,
+ * from gfn_grad_max into a zeroed word), and accumulates the appearance-embedding gradient into
+ * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients. */
 #define GFN_FIELD_X3_FWD_BYTES 149248
-#define GFN_FIELD_X3_BWD_BYTES 114688
+#define GFN_FIELD_X3_BWD_BYTES 131072
+#define GFN_FIELD_X3_FWD_PLANE_LD 480
+#define GFN_FIELD_X3_BWD_PLANE_LD 408
 int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_image, void* stream);
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
-                     float* sigma, float* rgb, float* h0, uint64_t* masks, void* stream);
+                     float* sigma, float* rgb, float* h0, uint64_t* masks, uint16_t* planes_hi,
+                     uint16_t* planes_lo, void* stream);
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                         float* dfeat, void* stream);
+int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
+                     const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
+                     float* dfeat, const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo,
+                     const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* stream);
+int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
+                 const int32_t* n_dev, float* gmax_dev, void* stream);
+float gfn_grad_scale_host(float gmax);
 
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]
  * for m < m_valid, k < k_valid; col(k) = col_map[k] (skipped when negative) or k.  A plane is two
  * u16(f16) arrays [n][ld]: hi and lo' with x ~= hi + lo' * 2^-11; feat_* = stored columns (multiple
- * of 8, <= 128; tile shapes 128x128, 32x128, 128x64, 128x32 after rounding up to 32).  scale_dev
- * (device f32, may be NULL = 1) is the power-of-two factor the producer multiplied dz by.
+ * of 8, <= 128; tile shapes 128x128, 32x128, 128x64, 128x32 after rounding up to 32).  gmax_dev
+ * (device f32, may be NULL = no scale) is the word gfn_field_bwd_x3 took its scale from: the dz plane
+ * carries the factor gfn_grad_scale_host(*gmax_dev), divided out here.
  * ACCUMULATES with f32 atomics (caller zeroes).  Replaces autograd's dW = dz^T a of the nn.Linear
  * layers in gfnerf/mlp.py:35-57. */
 int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int feat_dz, const uint16_t* a_hi,
                  const uint16_t* a_lo, int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev,
-                 const float* scale_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
+                 const float* gmax_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
                  float* db, void* stream);
 
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on

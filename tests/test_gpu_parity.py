@@ -579,7 +579,8 @@ def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid):
         col_map = t(np.concatenate([perm, [-1]]).astype(np.int32))
     dW = torch.zeros((m_valid, ldw), dtype=torch.float32, device=dev)
     db = torch.zeros(m_valid, dtype=torch.float32, device=dev)
-    ops.wgrad_x3(dzp, ap, dW, db=db, n_dev=n_dev, scale=torch.tensor([scale], device=dev), m_valid=m_valid, k_valid=k_valid,
+    assert ops.grad_scale(0.2) == scale  # gmax in [1/8, 1/4) -> scale 64
+    ops.wgrad_x3(dzp, ap, dW, db=db, n_dev=n_dev, gmax=torch.tensor([0.2], device=dev), m_valid=m_valid, k_valid=k_valid,
                  col_map=col_map)
     want = dz[:n, :m_valid].astype(np.float64).T @ a[:n, :k_valid].astype(np.float64)
     if col_map is not None:
