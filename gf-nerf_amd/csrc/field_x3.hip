@@ -43,7 +43,9 @@ constexpr int D_G1 = 36;   // d h[1:16] = hW0[:,16:31]^T dz1 : [u 8]
 constexpr int D_GB1 = 44;  // d a1 = bW1^T dh : [it 4]
 constexpr int D_GB0 = 48;  // d feat = bW0^T dz : [u 8]
 constexpr int D_GE = 56;   // d appearance = hW0[:,31:63]^T dz1 : [u 8]   (global stage only)
-// split-f16 planes kept for the weight gradients (global stage): one hi and one lo' array, row layouts (columns, f16)
+// split-f16 planes kept for the weight gradients (global stage): one hi and one lo' buffer of cap * LD f16 each,
+// PLANE-MAJOR: the plane with first column C and width W is the contiguous array [cap][W] at element offset cap * C
+// (so gfn_wgrad_x3 streams whole 128-byte lines).  Columns:
 constexpr int FP_LD = GFN_FIELD_X3_FWD_PLANE_LD;   // feat 0..31 | a1 32..159 | xp 160..223 | c1 224..351 | c2 352..479
 constexpr int FP_FEAT = 0, FP_A1 = 32, FP_XP = 160, FP_C1 = 224, FP_C2 = 352;
 constexpr int BP_LD = GFN_FIELD_X3_BWD_PLANE_LD;   // dz3 0..7 | dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
     const u32x4* __restrict__ image, float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ h0_out,
-    unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo) {
+    unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo,
+    int64_t cap) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
@@ -246,8 +249,9 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const int64_t s = tile * 32 + j;
     const bool valid = s < n;
     const int64_t q = valid ? s : n - 1;
-    uint16_t* const row_hi = PLANES ? planes_hi + q * FP_LD : nullptr;  // invalid lanes rewrite the last live row with the same values
-    uint16_t* const row_lo = PLANES ? planes_lo + q * FP_LD : nullptr;
+    // plane-major buffers: plane P (width W, first column C) is the contiguous array [cap][W] at element offset cap * C;
+    // invalid lanes rewrite the last live row with the same values
+#define FPL(half, C, W) (planes_##half + cap * (C) + q * (W))
     // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
     u32x4 xh[2], xl[2];
 #pragma unroll
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
       float x[8];
       load8(feat + q * 32 + 16 * u + 8 * h, x);
       split8(x, xh[u], xl[u]);
-      if (PLANES) store_nat(row_hi, row_lo, FP_FEAT + 16 * u, xh[u], xl[u], h);
+      if (PLANES) store_nat(FPL(hi, FP_FEAT, 32), FPL(lo, FP_FEAT, 32), 16 * u, xh[u], xl[u], h);
     }
     Frag a1[4];
     unsigned long long m_a1 = 0;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
       tile_to_frag<true>(a, a1[ot], m_a1, ot);
-      if (PLANES) store_tile(row_hi, row_lo, FP_A1 + 32 * ot, a1[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_A1, 128), FPL(lo, FP_A1, 128), 32 * ot, a1[ot], h);
     }
     // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
     Acc2 hh;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
       split8(v, gh, gl);
-      if (PLANES) store_half_tile(row_hi, row_lo, FP_XP, gh, gl, h);
+      if (PLANES) store_half_tile(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 0, gh, gl, h);
     }
     // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
     const int ray = ray_id[q];
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
           for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
       }
       if (PLANES) {
-        store_nat(row_hi, row_lo, FP_XP + 16, sh_h, sh_l, h);
-        store_nat(row_hi, row_lo, FP_XP + 32, e_h[0], e_l[0], h);
-        store_nat(row_hi, row_lo, FP_XP + 48, e_h[1], e_l[1], h);
+        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 16, sh_h, sh_l, h);
+        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 32, e_h[0], e_l[0], h);
+        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 48, e_h[1], e_l[1], h);
       }
     }
     Frag c1[4];
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
       mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
       mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
       tile_to_frag<true>(a, c1[ot], m_c1, ot);
-      if (PLANES) store_tile(row_hi, row_lo, FP_C1 + 32 * ot, c1[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_C1, 128), FPL(lo, FP_C1, 128), 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU
     Frag c2[4];
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       tile_to_frag<true>(a, c2[ot], m_c2, ot);
-      if (PLANES) store_tile(row_hi, row_lo, FP_C2 + 32 * ot, c2[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_C2, 128), FPL(lo, FP_C2, 128), 32 * ot, c2[ot], h);
     }
     // ---- head layer 3: 128 -> 3 (padded), sigmoid
     Acc2 o3;
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
       }
     }
   }
+#undef FPL
 }
 
 template <bool RELU_MASK>
@@ -384,8 +389,9 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
     const u32x4* __restrict__ image, float* __restrict__ dfeat, const float* __restrict__ gmax_dev,
-    uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, const int* __restrict__ ray_id,
+    uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, int64_t cap, const int* __restrict__ ray_id,
     const int* __restrict__ cam_idx, float* __restrict__ demb) {
+#define BPL(half, C, W) (planes_##half + cap * (C) + s * (W))
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
@@ -412,17 +418,20 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       any_grad = any_grad || g != 0.f;
     }
     float4* dst = reinterpret_cast<float4*>(dfeat + s * 32);
-    uint16_t* const row_hi = PLANES ? planes_hi + s * BP_LD : nullptr;
-    uint16_t* const row_lo = PLANES ? planes_lo + s * BP_LD : nullptr;
     if (!__any(any_grad)) {  // wave-uniform: the whole tile lies behind its rays' termination points
       if (valid) {
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) dst[2 * qd + h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PLANES) {  // this lane's half of the row (BP_LD/2 = 204 columns = 408 bytes, 8-byte aligned)
-          uint2* zh = reinterpret_cast<uint2*>(row_hi + h * (BP_LD / 2));
-          uint2* zl = reinterpret_cast<uint2*>(row_lo + h * (BP_LD / 2));
-#pragma unroll 1
-          for (int e = 0; e < BP_LD / 8; e++) { zh[e] = make_uint2(0u, 0u); zl[e] = make_uint2(0u, 0u); }
+        if (PLANES) {  // zero this sample's rows of the five gradient planes (lane half h: its half of each row)
+          const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 8; e++) {  // 128-wide rows = 256 B = 16 pieces, 8 per half
+            reinterpret_cast<u32x4*>(BPL(hi, BP_DZ2, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZ2, 128))[8 * h + e] = z;
+            reinterpret_cast<u32x4*>(BPL(hi, BP_DZ1, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZ1, 128))[8 * h + e] = z;
+            reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZA1, 128))[8 * h + e] = z;
+          }
+          reinterpret_cast<u32x4*>(BPL(hi, BP_DH, 16))[h] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DH, 16))[h] = z;
+          if (h == 0) { *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3, 8)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3, 8)) = z; }
         }
       }
       continue;
@@ -452,8 +461,8 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       if (h == 0) { v[0] = dz3[0] * sc; v[1] = dz3[1] * sc; v[2] = dz3[2] * sc; }
       split8(v, zh, zl);
       if (PLANES && valid && h == 0) {
-        *reinterpret_cast<u32x4*>(row_hi + BP_DZ3) = zh;
-        *reinterpret_cast<u32x4*>(row_lo + BP_DZ3) = zl;
+        *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3, 8)) = zh;
+        *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3, 8)) = zl;
       }
     }
     Frag g2[4];
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
       grad_tile_to_frag<true>(a, g2[it], m_c2, it);
-      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZ2 + 32 * it, g2[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZ2, 128), BPL(lo, BP_DZ2, 128), 32 * it, g2[it], h);
     }
     // ---- d c1 = hW1^T dz2
     Frag g1[4];
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
       grad_tile_to_frag<true>(a, g1[it], m_c1, it);
-      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZ1 + 32 * it, g1[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZ1, 128), BPL(lo, BP_DZ1, 128), 32 * it, g1[it], h);
     }
     // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
     u32x4 dh_h, dh_l;
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
       if (h == 0) v[0] = dh0 * sc;
       split8(v, dh_h, dh_l);
-      if (PLANES && valid) store_half_tile(row_hi, row_lo, BP_DH, dh_h, dh_l, h);
+      if (PLANES && valid) store_half_tile(BPL(hi, BP_DH, 16), BPL(lo, BP_DH, 16), 0, dh_h, dh_l, h);
     }
     if (PLANES && demb) {
       // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
       grad_tile_to_frag<true>(a, ga[it], m_a1, it);
-      if (PLANES && valid) store_tile(row_hi, row_lo, BP_DZA1 + 32 * it, ga[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZA1, 128), BPL(lo, BP_DZA1, 128), 32 * it, ga[it], h);
     }
     // ---- d feat = bW0^T dz
     Acc2 gf;
@@ -533,6 +542,8 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
     }
   }
 }
+
+#undef BPL
 
 // largest |gradient| entering the decoder: max over samples of |d rgb| and |d sigma * exp(clamp(h0+1))|, as f32 bits
 // (non-negative floats order like unsigned integers) -- the batch-wide scale of the global-stage backward
@@ -578,9 +589,10 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
                      const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
-                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, void* stream) {
+                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
+  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 8", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
   GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || masks),
@@ -602,24 +614,25 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
   if (planes_hi)
     field_fwd_x3_kernel<true, true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                              planes_hi, planes_lo);
+                                                                              planes_hi, planes_lo, plane_cap);
   else if (masks)
     field_fwd_x3_kernel<true, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                               nullptr, nullptr);
+                                                                               nullptr, nullptr, 0);
   else
     field_fwd_x3_kernel<false, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb,
-                                                                                nullptr, nullptr, nullptr, nullptr);
+                                                                                nullptr, nullptr, nullptr, nullptr, 0);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
 
 static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                              const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat,
-                             const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, const int32_t* ray_id,
+                             const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
                              const int32_t* cam_idx, float* demb, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && dfeat, "%s: null pointer", fn);
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "%s: n_max=%lld", fn, (long long)n_max);
+  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "%s: plane_cap=%lld must be >= n_max and a multiple of 8", fn, (long long)plane_cap);
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(dfeat) | reinterpret_cast<uintptr_t>(planes_hi) |
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   static bool attr_set = false;
@@ -633,28 +646,28 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(masks);
   if (planes_hi)
     field_bwd_dx_x3_kernel<true><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev,
-                                                                                           planes_hi, planes_lo, ray_id, cam_idx, demb);
+                                                                                           planes_hi, planes_lo, plane_cap, ray_id, cam_idx, demb);
   else
     field_bwd_dx_x3_kernel<false><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, nullptr,
-                                                                                            nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                                                            nullptr, nullptr, 0, nullptr, nullptr, nullptr);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
 
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
                         const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, void* stream) {
-  return field_bwd_x3_impl("gfn_field_bwd_dx_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, nullptr, nullptr, nullptr,
+  return field_bwd_x3_impl("gfn_field_bwd_dx_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, nullptr, nullptr, nullptr, 0,
                            nullptr, nullptr, nullptr, stream);
 }
 
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
                      const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, const float* gmax_dev,
-                     uint16_t* planes_hi, uint16_t* planes_lo, const int32_t* ray_id, const int32_t* cam_idx, float* demb,
-                     void* stream) {
+                     uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx,
+                     float* demb, void* stream) {
   GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi && planes_lo), "gfn_field_bwd_x3: gmax and both plane halves are required");
   GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_x3: demb needs ray_id and cam_idx");
   return field_bwd_x3_impl("gfn_field_bwd_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, gmax_dev, planes_hi, planes_lo,
-                           ray_id, cam_idx, demb, stream);
+                           plane_cap, ray_id, cam_idx, demb, stream);
 }
 
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max, const int32_t* n_dev, float* gmax_dev,

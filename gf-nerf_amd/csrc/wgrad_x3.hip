@@ -38,24 +38,48 @@ __device__ __forceinline__ h8 tr_frag(const _Float16* tile /*[S][32]*/, int ks, 
   return __builtin_bit_cast(h8, r);
 }
 
-__device__ __forceinline__ void stage_plane(_Float16* dst /*[tiles][S][32]*/, const uint16_t* __restrict__ src, int ld, int feat,
-                                            int64_t s0, int64_t n) {
-  const int pieces = feat >> 3;  // 16-byte pieces per sample row
-  for (int e = threadIdx.x; e < S * pieces; e += blockDim.x) {
-    const int s = e / pieces, f = (e - s * pieces) << 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (s0 + s < n) v = *reinterpret_cast<const u32x4*>(src + (s0 + s) * ld + f);
-    *reinterpret_cast<u32x4*>(dst + ((f >> 5) * S + s) * 32 + (f & 31)) = v;
+// One slab = 64 samples x (FD + FA) features x {hi, lo'}.  Each thread owns a fixed set of 16-byte pieces; the next
+// slab's pieces are fetched into registers while the matrix pipe works on the current one.
+template <int FEAT>
+struct Stager {
+  static constexpr int PIECES = FEAT / 8;                 // 16-byte pieces per sample row
+  static constexpr int TOTAL = S * PIECES;                // pieces per slab
+  static constexpr int PER_THREAD = (TOTAL + 255) / 256;
+  u32x4 hi[PER_THREAD], lo[PER_THREAD];
+
+  __device__ __forceinline__ void fetch(const Plane& p, int64_t s0, int64_t n) {
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; it++) {
+      const int e = it * 256 + (int)threadIdx.x;
+      const int s = e / PIECES, f = (e % PIECES) * 8;
+      hi[it] = u32x4{0u, 0u, 0u, 0u}; lo[it] = u32x4{0u, 0u, 0u, 0u};
+      if (e < TOTAL && s0 + s < n) {
+        hi[it] = *reinterpret_cast<const u32x4*>(p.hi + (s0 + s) * p.ld + f);
+        lo[it] = *reinterpret_cast<const u32x4*>(p.lo + (s0 + s) * p.ld + f);
+      }
+    }
   }
-}
+  __device__ __forceinline__ void commit(_Float16* dst_hi, _Float16* dst_lo) const {  // -> [tile][S][32]
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; it++) {
+      const int e = it * 256 + (int)threadIdx.x;
+      const int s = e / PIECES, f = (e % PIECES) * 8;
+      if (e < TOTAL) {
+        *reinterpret_cast<u32x4*>(dst_hi + ((f >> 5) * S + s) * 32 + (f & 31)) = hi[it];
+        *reinterpret_cast<u32x4*>(dst_lo + ((f >> 5) * S + s) * 32 + (f & 31)) = lo[it];
+      }
+    }
+  }
+};
 
 // WAVE_IS_NI: wave w owns in-tile w and loops over the MO out tiles (NI == 4); else wave w owns out tile w (MO == 4)
 // and loops over the NI in tiles.
-template <int MO, int NI>
+template <int FD, int FA>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int32_t* __restrict__ n_dev, Plane dz, Plane a,
                                                        const float* __restrict__ gmax_dev, float* __restrict__ dW, int ldw,
                                                        int m_valid, int k_valid, const int* __restrict__ col_map,
                                                        float* __restrict__ db) {
+  constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   constexpr bool WAVE_IS_NI = (NI == 4);
   static_assert(WAVE_IS_NI || MO == 4, "one of the tile counts must be 4 (one per wave)");
   constexpr int PPW = WAVE_IS_NI ? MO : NI;  // pairs per wave
@@ -66,7 +90,6 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
   _Float16* Blo = Bhi + NI * S * 32;
   // features beyond the stored ones stay zero for the whole kernel
   for (int e = threadIdx.x; e < 2 * (MO + NI) * S * 32 / 8; e += blockDim.x) reinterpret_cast<u32x4*>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
-  __syncthreads();
   const int64_t n = gfn_live_n(n_max, n_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x16 accm[PPW], accc[PPW];
@@ -76,13 +99,16 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
     for (int r = 0; r < 16; r++) { accm[t][r] = 0.f; accc[t][r] = 0.f; }
   float bsum = 0.f;
   const int64_t n_slabs = (n + S - 1) / S;
+  Stager<FD> sd;
+  Stager<FA> sa;
+  if ((int64_t)blockIdx.x < n_slabs) { sd.fetch(dz, (int64_t)blockIdx.x * S, n); sa.fetch(a, (int64_t)blockIdx.x * S, n); }
+  __syncthreads();
   for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
-    const int64_t s0 = slab * S;
-    stage_plane(Ahi, dz.hi, dz.ld, dz.feat, s0, n);
-    stage_plane(Alo, dz.lo, dz.ld, dz.feat, s0, n);
-    stage_plane(Bhi, a.hi, a.ld, a.feat, s0, n);
-    stage_plane(Blo, a.lo, a.ld, a.feat, s0, n);
+    sd.commit(Ahi, Alo);
+    sa.commit(Bhi, Blo);
     __syncthreads();
+    const int64_t next = slab + gridDim.x;
+    if (next < n_slabs) { sd.fetch(dz, next * S, n); sa.fetch(a, next * S, n); }  // in flight under the MFMAs below
     if (db) {  // bias gradient: column sums of dz (threads 0..127: hi plane, 128..255: lo' plane)
       const int m = threadIdx.x & 127, part = threadIdx.x >> 7;
       if (m < 32 * MO) {
@@ -139,18 +165,19 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
   }
 }
 
-template <int MO, int NI>
+template <int FD, int FA>
 int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
            int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
+  constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   const size_t lds = (size_t)2 * (MO + NI) * S * 32 * sizeof(_Float16);
   static bool attr_set = false;
   if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<MO, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   int64_t blocks = (n_max + S - 1) / S;
   if (blocks > 512) blocks = 512;
-  wgrad_x3_kernel<MO, NI><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
+  wgrad_x3_kernel<FD, FA><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -172,15 +199,15 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(dz_hi) | reinterpret_cast<uintptr_t>(dz_lo) | reinterpret_cast<uintptr_t>(a_hi) |
                   reinterpret_cast<uintptr_t>(a_lo)) & 15) == 0, "gfn_wgrad_x3: planes must be 16-byte aligned");
   const Plane dz{dz_hi, dz_lo, ld_dz, feat_dz}, a{a_hi, a_lo, ld_a, feat_a};
-  const int MO = (feat_dz + 31) / 32, NI = (feat_a + 31) / 32;
   hipStream_t st = gfn_stream(stream);
-#define GFN_WG(M, N) return launch<M, N>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
-  if (MO == 4 && NI == 4) GFN_WG(4, 4);
-  if (MO == 1 && NI == 4) GFN_WG(1, 4);
-  if (MO == 4 && NI == 2) GFN_WG(4, 2);
-  if (MO == 4 && NI == 1) GFN_WG(4, 1);
+#define GFN_WG(D, A) if (feat_dz == D && feat_a == A) return launch<D, A>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
+  GFN_WG(128, 128);  // head layer 2
+  GFN_WG(8, 128);    // head layer 3 (3 outputs)
+  GFN_WG(128, 64);   // head layer 1 (63 inputs)
+  GFN_WG(16, 128);   // base layer 2
+  GFN_WG(128, 32);   // base layer 1
 #undef GFN_WG
-  gfn_set_error("gfn_wgrad_x3: unsupported tile shape %d x %d (supported: 4x4, 1x4, 4x2, 4x1)", MO, NI);
+  gfn_set_error("gfn_wgrad_x3: unsupported plane widths %d x %d (supported: 128x128, 8x128, 128x64, 16x128, 128x32)", feat_dz, feat_a);
   return GFN_ERR_ARG;
 }
 

@@ -120,9 +120,10 @@ class HotPath:
     def _planes(self, cap):
         """Split-f16 activation / gradient planes of the global stage (480 + 408 f16 columns, hi and lo' each), sized like
         the packed sample buffers and kept across steps."""
-        if self._plane_bufs is None or self._plane_bufs[0][0].shape[0] < cap:
-            mk = lambda ld: (torch.empty((cap, ld), dtype=torch.float16, device=self.dev),  # noqa: E731
-                             torch.empty((cap, ld), dtype=torch.float16, device=self.dev))
+        if self._plane_bufs is None or self._plane_bufs[0][0].numel() < cap * ops.FIELD_X3_FWD_PLANE_LD:
+            cap = (cap + 7) // 8 * 8
+            mk = lambda ld: (torch.empty(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
+                             torch.empty(cap * ld, dtype=torch.float16, device=self.dev))
             self._plane_bufs = (mk(ops.FIELD_X3_FWD_PLANE_LD), mk(ops.FIELD_X3_BWD_PLANE_LD))
             # xp plane column -> hW0 column: base rows 1..15 = geo (16..30), row 0 = density channel (none), SH, appearance
             cm = np.concatenate([[-1], 15 + np.arange(1, 16), np.arange(16), 31 + np.arange(32)]).astype(np.int32)
@@ -274,11 +275,14 @@ class HotPath:
             dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
                                 bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
             g = self.layer_grads
-            F, B = ops.FWD_PLANE, ops.BWD_PLANE
+            fv = lambda k: (ops.plane_view(fp[0], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE),  # noqa: E731
+                            ops.plane_view(fp[1], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE))
+            bv = lambda k: (ops.plane_view(bp[0], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE),  # noqa: E731
+                            ops.plane_view(bp[1], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE))
             n_cap = s["ts"].shape[0]
             for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
                                           (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None)):
-                self._timed("wgrad", ops.wgrad_x3, (bp[0], bp[1]) + B[dzk], (fp[0], fp[1]) + F[ak], g[li][0], db=g[li][1], n_dev=n_dev,
+                self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
                             gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
         elif ctx["fused"]:
             prec = c.mlp_precision

@@ -378,6 +378,27 @@ FWD_PLANE = dict(feat=(0, 32), a1=(32, 128), xp=(160, 64), c1=(224, 128), c2=(35
 BWD_PLANE = dict(dz3=(0, 8), dh=(8, 16), dz2=(24, 128), dz1=(152, 128), dza1=(280, 128))
 
 
+def _plane_cap(ph, pl, ld, n):
+    """Plane buffers are flat f16 tensors of cap * ld elements, plane-major (see include/gfnerf_amd.h)."""
+    if ph is None and pl is None:
+        return 0
+    for t in (ph, pl):
+        _chk(t, torch.float16, "planes")
+    if ph.numel() != pl.numel() or ph.numel() % ld:
+        raise _lib.GfnError("plane halves differ in size or are not a multiple of the row width")
+    cap = ph.numel() // ld
+    if cap < n or cap % 8:
+        raise _lib.GfnError("plane capacity must cover the sample buffers and be a multiple of 8")
+    return cap
+
+
+def plane_view(buf, ld, name, table):
+    """The [cap, width] view of plane `name` inside a plane-major buffer."""
+    cap = buf.numel() // ld
+    c0, w = table[name]
+    return buf.view(-1)[cap * c0: cap * (c0 + w)].view(cap, w)
+
+
 def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bwd=True):
     """Build the split-f16 weight images of the x3 decoder kernels (to be redone whenever the weights change)."""
     dev = layers[0][0].device
@@ -407,12 +428,9 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
         if image is None:
             image, _ = field_pack_x3(layers, want_bwd=False)
         ph, pl = planes if planes is not None else (None, None)
-        for t in (ph, pl):  # split-f16 activation planes for the weight gradients (global stage)
-            _chk(t, torch.float16, "planes", FIELD_X3_FWD_PLANE_LD)
-            if t is not None and t.shape[0] < n:
-                raise _lib.GfnError("activation planes are shorter than the sample buffers")
+        cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)  # split-f16 activation planes for the weight gradients (global stage)
         rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
-                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), _stream())
+                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, _stream())
         _lib.check(rc, "gfn_field_fwd_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)
@@ -499,13 +517,10 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
     _chk(ray_id, torch.int32, "ray_id"); _chk(cam_idx, torch.int32, "cam_idx"); _chk(demb, torch.float32, "demb", 32)
     ph, pl = planes
     n = d_sigma.shape[0]
-    for t in (ph, pl):
-        _chk(t, torch.float16, "planes", FIELD_X3_BWD_PLANE_LD)
-        if t.shape[0] < n:
-            raise _lib.GfnError("gradient planes are shorter than the sample buffers")
+    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
     dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
     rc = _lib.lib().gfn_field_bwd_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
-                                     _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _stream())
+                                     _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _stream())
     _lib.check(rc, "gfn_field_bwd_x3")
     return dfeat
 

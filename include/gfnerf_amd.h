@@ -225,10 +225,12 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * NULL) and are read-only to the kernels; buffers of GFN_FIELD_X3_{FWD,BWD}_BYTES, 16-byte aligned.
  *
  * Global stage (decoder trains): gfn_field_fwd_x3 with planes_{hi,lo} != NULL also keeps every layer
- * input as split-f16 planes u16 [n][GFN_FIELD_X3_FWD_PLANE_LD]: columns feat 0..31 | a1 32..159 |
- * xp 160..223 (base output rows 0..15, SH 16, appearance 32) | c1 224..351 | c2 352..479;
- * gfn_field_bwd_x3 writes dz of every layer as planes u16 [n][GFN_FIELD_X3_BWD_PLANE_LD]: dz3 0..7 |
- * dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407, all multiplied by the power-of-two scale
+ * input as split-f16 planes.  A plane buffer holds plane_cap * LD u16 (plane_cap >= n_max, multiple of
+ * 8) and is PLANE-MAJOR: the plane with first column C and width W is the contiguous array
+ * [plane_cap][W] at element offset plane_cap * C.  Forward (LD = GFN_FIELD_X3_FWD_PLANE_LD): feat
+ * C=0 W=32 | a1 C=32 W=128 | xp C=160 W=64 (base output rows 0..15, SH 16, appearance 32) | c1 C=224
+ * W=128 | c2 C=352 W=128.  gfn_field_bwd_x3 writes dz of every layer (LD = GFN_FIELD_X3_BWD_PLANE_LD):
+ * dz3 C=0 W=8 | dh C=8 W=16 | dz2 C=24 W=128 | dz1 C=152 W=128 | dza1 C=280 W=128, all multiplied by the power-of-two scale
  * gfn_grad_scale_host(*gmax_dev) (gmax_dev: device f32 = largest |gradient| entering the decoder,
  * from gfn_grad_max into a zeroed word), and accumulates the appearance-embedding gradient into
  * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients. */
@@ -240,14 +242,15 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
                      float* sigma, float* rgb, float* h0, uint64_t* masks, uint16_t* planes_hi,
-                     uint16_t* planes_lo, void* stream);
+                     uint16_t* planes_lo, int64_t plane_cap, void* stream);
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                         float* dfeat, void* stream);
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                      const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                      float* dfeat, const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo,
-                     const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* stream);
+                     int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx, float* demb,
+                     void* stream);
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);
