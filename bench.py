@@ -194,12 +194,18 @@ def main():
         kern_ms = kern[dom]
         alg_bytes = alg[dom]
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
-        traffic = None
+        traffic, req = None, None
         if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get(f"{dom}:{args.stage}")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get(f"{dom}:{args.stage}")
+            n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests")
+            if n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
+                req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
+                           frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
+                           source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
         roofline = dict(bound="hbm", kernel=dom + "_kernel", achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
-                        alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()})
+                        alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()}, request_rate=req)
         w = aux["comp"]["weights"][:n_live]
         alive_frac = float((w > 0).float().mean().item()) if w is not None else None
         out = dict(metric="train_rays_per_sec", value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
