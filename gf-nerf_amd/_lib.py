@@ -29,6 +29,9 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_mark_invisible_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "gfn_octree_proc_host": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
+                                    C.POINTER(_vp)]),
     "gfn_linear_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "gfn_linear_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                               _vp]),
@@ -39,6 +42,7 @@ SIGNATURES = {
     "gfn_field_bwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_grad_max": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_grad_scale_host": (_f32, [_f32]),
+    "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),

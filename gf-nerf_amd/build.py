@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libgfnerf_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIP_SOURCES = ["runtime.hip", "hash3d.hip", "sampler.hip", "mlp.hip", "field.hip", "field_x3.hip", "wgrad_x3.hip", "render.hip"]
-CXX_SOURCES = ["octree_build.cpp"]
+CXX_SOURCES = ["octree_build.cpp", "octree_proc.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
                "-Wno-unused-function", "-I", INCLUDE]
 CXX_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-Wall", "-I", INCLUDE]

@@ -565,10 +565,13 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(gmax, __float_as_uint(m));
 }
 
+int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
+
 unsigned persistent_grid8(int64_t n_max) {
   int64_t tiles = (n_max + 31) / 32;
   int64_t blocks = (tiles + 7) / 8;
-  if (blocks > 256) blocks = 256;  // one 512-thread workgroup per CU: the LDS image is copied once per workgroup
+  const int cap = (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256;
+  if (blocks > cap) blocks = cap;  // one 512-thread workgroup per CU: the LDS image is copied once per workgroup
   return (unsigned)(blocks > 0 ? blocks : 1);
 }
 
@@ -683,5 +686,11 @@ int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int6
 }
 
 float gfn_grad_scale_host(float gmax) { return gfn_grad_scale_of(gmax); }
+
+int gfn_set_decoder_cus(int n_cus) {
+  const int old = g_decoder_cus;
+  g_decoder_cus = n_cus < 0 ? 0 : n_cus;
+  return old;
+}
 
 }  // extern "C"

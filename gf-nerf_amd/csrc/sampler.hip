@@ -684,6 +684,42 @@ __global__ void node_stats_kernel(int64_t n_nodes, const long long* __restrict__
   if (ws < 0 || as < 0) *reinterpret_cast<long long*>(nodes + i * GFN_TREE_NODE_BYTES + 96) = -1;
 }
 
+// K7 MarkInvisibleNodes (PersSampler_cuda.cu:680-742): a node no training camera can see loses its warp
+// (trans_idx = -1).  One wave per node, lanes stride over the cameras, the wave stops at the first camera that sees the
+// node (the reference loops one thread per node over all cameras).  Arithmetic in the reference's order: Eigen forms
+// w2c * c.homogeneous() as leftCols(3) * c + col(3) with the 3-term sum a + (b + c); radius = side_len * 0.707 in double.
+__device__ __forceinline__ bool camera_sees(const float* __restrict__ K, const float* __restrict__ W, const float* __restrict__ bd,
+                                            float cx_, float cy_, float cz_, float radius) {
+  float p[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) p[r] = (W[4 * r] * cx_ + (W[4 * r + 1] * cy_ + W[4 * r + 2] * cz_)) + W[4 * r + 3];
+  if (-p[2] < bd[0] - radius || -p[2] > bd[1] + radius) return false;
+  const float nrm = sqrtf(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
+  if (nrm < radius) return true;
+  const float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+  const float bias_x = radius / -p[2] * fx, bias_y = radius / -p[2] * fy;
+  const float img_x = p[0] / -p[2] * fx, img_y = p[1] / -p[2] * fy;
+  return !(img_x + bias_x < -cx || img_x > cx + bias_x || img_y + bias_y < -cy || img_y > cy + bias_y);
+}
+
+__global__ __launch_bounds__(256) void mark_invisible_kernel(int64_t n_nodes, int64_t n_cams, uint8_t* __restrict__ nodes,
+                                                            const float* __restrict__ intri, const float* __restrict__ w2c,
+                                                            const float* __restrict__ bounds) {
+  const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_nodes) return;  // wave-uniform
+  const int lane = threadIdx.x & 63;
+  gfn_tree_node* nd = reinterpret_cast<gfn_tree_node*>(nodes + node * GFN_TREE_NODE_BYTES);
+  const float cx = nd->center[0], cy = nd->center[1], cz = nd->center[2];
+  const float radius = (float)((double)nd->side_len * 0.707);
+  bool seen = false;
+  for (int64_t c0 = 0; c0 < n_cams && !seen; c0 += 64) {
+    const int64_t cam = c0 + lane;
+    const bool v = cam < n_cams && camera_sees(intri + 9 * cam, w2c + 12 * cam, bounds + 2 * cam, cx, cy, cz, radius);
+    seen = __any(v);
+  }
+  if (!seen && lane == 0) nd->trans_idx = -1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -866,6 +902,16 @@ int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* 
   }
   node_stats_kernel<<<gn, 256, 0, st>>>(n_nodes, w_adder, a_adder, mark, reinterpret_cast<long long*>(weight_stats),
                                         reinterpret_cast<long long*>(alpha_stats), reinterpret_cast<uint8_t*>(nodes));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_mark_invisible_nodes(void* nodes, int64_t n_nodes, const float* intri, const float* w2c, const float* bounds,
+                             int64_t n_cams, void* stream) {
+  GFN_CHECK_ARG(nodes && intri && w2c && bounds, "gfn_mark_invisible_nodes: null pointer");
+  GFN_CHECK_ARG(n_nodes > 0 && n_cams > 0 && n_nodes < (1ll << 31), "gfn_mark_invisible_nodes: bad sizes");
+  mark_invisible_kernel<<<(unsigned)((n_nodes + 3) / 4), 256, 0, gfn_stream(stream)>>>(n_nodes, n_cams, reinterpret_cast<uint8_t*>(nodes),
+                                                                                      intri, w2c, bounds);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -52,6 +52,10 @@ class _NativePersSampler:
         nodes, transes = ops.octree_build(c2w.detach().cpu().numpy(), intri.detach().cpu().numpy(),
                                           bounds.detach().cpu().numpy(), max_depth=int(max_level), bbox_side_len=bbox_side_len,
                                           split_dist_thres=float(split_dist_thres), seed=seed)
+        # kept for MarkInvisibleNodes (PersOctree keeps intri_, w2c_, bound_ on the device, PersSampler.cpp:100-107)
+        self.intri_ = intri.detach().to(dev).float().contiguous()
+        self.w2c_ = w2c.detach().to(dev).float().contiguous()
+        self.bound_ = bounds.detach().to(dev).float().contiguous()
         self._set_tree(torch.from_numpy(nodes).to(dev), torch.from_numpy(transes).to(dev))
         self.n_volumes_ = self.pers_trans_gpu_.numel() // ops.TRANS_INFO_BYTES  # :936
         self.tree_visit_cnt_ = torch.zeros(self.n_nodes, dtype=torch.int64, device=dev)
@@ -123,8 +127,40 @@ class _NativePersSampler:
             w, a = sampled_weights.contiguous().float(), sampled_alpha.contiguous().float()
         ops.update_nodes(s["pts_offsets"], s["anchors"], w, a, self.tree_weight_stats_, self.tree_alpha_stats_,
                          self.tree_visit_cnt_, self.tree_nodes_gpu_)
+        # subdivision milestones and the periodic compaction (:667-676)
+        changed = False
+        while self.sub_div_milestones_ and self.sub_div_milestones_[-1] <= iter_step:
+            self.ProcOctree(True, True, self.sub_div_milestones_[-1] <= 0)
+            self.MarkInvisibleNodes()
+            self.ProcOctree(True, False, False)
+            self.sub_div_milestones_.pop()
+            changed = True
+        if iter_step % self.compact_freq_ == 0:
+            self.ProcOctree(True, False, False)
+            changed = True
+        if not changed:
+            ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)  # K6 may have invalidated leaves
+
+    def ProcOctree(self, compact: bool, subdivide: bool, brute_force: bool):
+        """PersOctree::ProcOctree (PersSampler.cpp:154-417): blob and statistics to the host, gfn_octree_proc_host, back
+        (the reference makes the same round trip); visit counts restart at zero (:415)."""
+        dev = self.device
+        nodes, w, a = ops.octree_proc_host(self.tree_nodes_gpu_.cpu().numpy(), self.tree_weight_stats_.cpu().numpy(),
+                                           self.tree_alpha_stats_.cpu().numpy(), self.tree_visit_cnt_.cpu().numpy(),
+                                           compact=compact, subdivide=subdivide, brute_force=brute_force)
+        self.tree_nodes_gpu_ = torch.from_numpy(nodes).to(dev)
+        self.n_nodes = nodes.size // ops.TREE_NODE_BYTES
+        self.tree_weight_stats_ = torch.from_numpy(w).to(dev)
+        self.tree_alpha_stats_ = torch.from_numpy(a).to(dev)
+        self.tree_visit_cnt_ = torch.zeros(self.n_nodes, dtype=torch.int64, device=dev)
+        self.nodes_compact_ = ops.tree_compact(self.tree_nodes_gpu_)
+        self._ws = None
+        self.last_packed = None  # node indices of the previous samples are stale now
+
+    def MarkInvisibleNodes(self):
+        """K7 (PersSampler_cuda.cu:709-742)."""
+        ops.mark_invisible_nodes(self.tree_nodes_gpu_, self.intri_, self.w2c_, self.bound_)
         ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)
-        # ProcOctree at milestones / every compact_freq iterations (:667-676) is not built yet
 
     def UpdateRayMarch(self, cur_step):
         if cur_step >= self.ray_march_fineness_decay_end_iter_:  # PersSampler.cpp:958-967

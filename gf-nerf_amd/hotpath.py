@@ -360,6 +360,25 @@ class HotPath:
         ops.tree_compact(self.nodes, self.nodes_compact)  # K6 may have invalidated leaves
 
 
+    def proc_octree(self, compact=True, subdivide=False, brute_force=False):
+        """PersOctree::ProcOctree (PersSampler.cpp:154-417) on this path's tree: host round trip like the reference,
+        then the 64-byte sampler image is rebuilt.  Node indices change; hash volumes (trans_idx) do not."""
+        nodes, w, a = ops.octree_proc_host(self.nodes.cpu().numpy(), self.weight_stats.cpu().numpy(), self.alpha_stats.cpu().numpy(),
+                                           self.visit_cnt.cpu().numpy(), compact=compact, subdivide=subdivide, brute_force=brute_force)
+        self.nodes = torch.from_numpy(nodes).to(self.dev)
+        self.n_nodes = nodes.size // ops.TREE_NODE_BYTES
+        self.weight_stats = torch.from_numpy(w).to(self.dev)
+        self.alpha_stats = torch.from_numpy(a).to(self.dev)
+        self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)
+        self.nodes_compact = ops.tree_compact(self.nodes)
+        self._sampler_ws = None
+
+    def mark_invisible_nodes(self, intri, w2c, bounds):
+        """K7 MarkInvisibleNodes (PersSampler_cuda.cu:709-742)."""
+        ops.mark_invisible_nodes(self.nodes, intri, w2c, bounds)
+        ops.tree_compact(self.nodes, self.nodes_compact)
+
+
 def fineness_at(step, init=16.0, decay_end=10000):
     """PersSampler::UpdateRayMarch (PersSampler.cpp:958-967)."""
     if step >= decay_end:

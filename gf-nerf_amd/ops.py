@@ -308,6 +308,42 @@ def update_nodes(pts_offsets, anchors, weights, alphas, weight_stats, alpha_stat
     _lib.check(rc, "gfn_update_nodes")
 
 
+def mark_invisible_nodes(nodes, intri, w2c, bounds):
+    """K7: trans_idx = -1 for nodes no camera sees (in place on the device blob)."""
+    _chk(nodes, torch.uint8, "nodes"); _chk(intri, torch.float32, "intri", 3); _chk(w2c, torch.float32, "w2c", 4)
+    _chk(bounds, torch.float32, "bounds", 2)
+    n_cams = intri.shape[0]
+    if tuple(intri.shape) != (n_cams, 3, 3) or tuple(w2c.shape) != (n_cams, 3, 4) or tuple(bounds.shape) != (n_cams, 2):
+        raise _lib.GfnError("expected intri [n,3,3], w2c [n,3,4], bounds [n,2]")
+    rc = _lib.lib().gfn_mark_invisible_nodes(_ptr(nodes), nodes.numel() // TREE_NODE_BYTES, _ptr(intri), _ptr(w2c), _ptr(bounds), n_cams,
+                                             _stream())
+    _lib.check(rc, "gfn_mark_invisible_nodes")
+
+
+def octree_proc_host(nodes, weight_stats, alpha_stats, visit_cnt, compact=True, subdivide=False, brute_force=False):
+    """PersOctree::ProcOctree on host numpy arrays -> (nodes uint8 blob, weight_stats i64, alpha_stats i64) of the new tree."""
+    nodes = np.ascontiguousarray(np.asarray(nodes).view(np.uint8).reshape(-1))
+    n = nodes.size // TREE_NODE_BYTES
+    w, a, v = (np.ascontiguousarray(x, np.int64) for x in (weight_stats, alpha_stats, visit_cnt))
+    if not (w.size == n and a.size == n and v.size == n):
+        raise _lib.GfnError("stat arrays must have n_nodes entries")
+    out_n, out_w, out_a, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    L = _lib.lib()
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = L.gfn_octree_proc_host(vp(nodes), n, vp(w), vp(a), vp(v), int(compact), int(subdivide), int(brute_force), C.byref(out_n),
+                                C.byref(m), C.byref(out_w), C.byref(out_a))
+    _lib.check(rc, "gfn_octree_proc_host")
+    try:
+        k = m.value
+        new_nodes = np.ctypeslib.as_array(C.cast(out_n, C.POINTER(C.c_uint8)), shape=(k * TREE_NODE_BYTES,)).copy()
+        new_w = np.ctypeslib.as_array(C.cast(out_w, C.POINTER(C.c_int64)), shape=(k,)).copy()
+        new_a = np.ctypeslib.as_array(C.cast(out_a, C.POINTER(C.c_int64)), shape=(k,)).copy()
+    finally:
+        for ptr in (out_n, out_w, out_a):
+            L.gfn_free_host(ptr)
+    return new_nodes, new_w, new_a
+
+
 # ---------------------------------------------------------------------------- MLP
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 

@@ -189,6 +189,22 @@ int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* 
                      int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
                      int64_t* scratch, void* stream);
 
+/* K7 MarkInvisibleNodes (PersSampler_cuda.cu:680-742): trans_idx = -1 for every node that no camera
+ * sees.  intri f32 [n_cams,3,3], w2c f32 [n_cams,3,4], bounds f32 [n_cams,2], row-major (the tensors
+ * InitSampler receives, bindings.cpp:24-35). */
+int gfn_mark_invisible_nodes(void* nodes, int64_t n_nodes, const float* intri, const float* w2c,
+                             const float* bounds, int64_t n_cams, void* stream);
+
+/* PersOctree::ProcOctree (PersSampler.cpp:154-417), host side like the reference: compact != 0 prunes
+ * subtrees without a valid leaf, splices single-child chains and renumbers; subdivide != 0 splits every
+ * leaf with visit_cnt > 4 (every leaf when brute_force) into 8 octants that inherit its warp and
+ * statistics.  compact must be non-zero (every call site of the reference passes true).  Inputs are HOST arrays (nodes blob, i64 stats [n_nodes]); outputs are malloc'd host
+ * arrays (gfn_free_host).  The caller uploads them and zeroes visit_cnt (:415). */
+int gfn_octree_proc_host(const void* nodes_host, int64_t n_nodes, const int64_t* weight_stats_host,
+                         const int64_t* alpha_stats_host, const int64_t* visit_cnt_host, int compact,
+                         int subdivide, int brute_force, void** nodes_out_host, int64_t* n_nodes_out,
+                         int64_t** weight_stats_out_host, int64_t** alpha_stats_out_host);
+
 /* ====================================================================== *
  * Field pieces (replace gfnerf/mlp.py MLPNetwork, the tcnn SH(4) encoding and
  * the glue of GFNeRFField.get_density/get_outputs, nerfacto_field.py:412-591)
@@ -254,6 +270,11 @@ int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb,
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);
+/* The fused x3 decoder kernels are persistent, one 512-thread workgroup per CU with the whole LDS and
+ * register file.  n_cus > 0 caps their grid so that they leave the other CUs to the fabric-bound
+ * gather / scatter kernels of another chunk running on a second stream (0 = every CU).  Returns the
+ * previous value.  Process-wide. */
+int gfn_set_decoder_cus(int n_cus);
 
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]

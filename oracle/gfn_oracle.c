@@ -778,3 +778,187 @@ void gfn_o_adam_step(float* p, const float* g, float* m, float* v, int64_t n, in
     p[i] = p[i] - step_size * (m[i] / denom);
   }
 }
+
+
+/* ======================================================================== *
+ * a15: PersOctree::ProcOctree (PersSampler.cpp:154-417), statement by statement.
+ * ======================================================================== */
+#define GFN_O_INIT_NODE_STAT 1000 /* PersSampler.h INIT_NODE_STAT */
+
+typedef struct {
+  gfn_o_tree_node* nodes;
+  int64_t* w;
+  int64_t* a;
+  int64_t n, cap;
+} o_vec;
+
+static void o_vec_push(o_vec* v, const gfn_o_tree_node* nd, int64_t w, int64_t a) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 64;
+    v->nodes = (gfn_o_tree_node*)realloc(v->nodes, (size_t)v->cap * sizeof(gfn_o_tree_node));
+    v->w = (int64_t*)realloc(v->w, (size_t)v->cap * sizeof(int64_t));
+    v->a = (int64_t*)realloc(v->a, (size_t)v->cap * sizeof(int64_t));
+  }
+  if (nd) v->nodes[v->n] = *nd; else memset(&v->nodes[v->n], 0, sizeof(gfn_o_tree_node));
+  v->w[v->n] = w;
+  v->a[v->n] = a;
+  v->n++;
+}
+
+static int o_single_child(const gfn_o_tree_node* t, int64_t u) { /* :234-252 */
+  int64_t cnt = 0, ret = -1;
+  for (int64_t i = 0; i < 8; i++)
+    if (t[u].childs[i] >= 0) { ret = i; cnt++; }
+  return cnt == 1 ? (int)ret : -1;
+}
+
+typedef struct {
+  const gfn_o_tree_node* wp; const int64_t* w_wp; const int64_t* a_wp;
+  const int64_t* visit_cnt; const int64_t* inv_idx; int brute_force; o_vec* out;
+} o_subdiv_ctx;
+
+static int64_t o_subdiv(o_subdiv_ctx* c, int64_t u, int64_t pa) { /* :336-395 */
+  o_vec* nn = c->out;
+  const int64_t new_u = nn->n;
+  o_vec_push(nn, &c->wp[u], c->w_wp[u], c->a_wp[u]);
+  nn->nodes[new_u].parent = pa;
+  if (c->wp[u].is_leaf_node) {
+    if (!c->brute_force && c->visit_cnt[c->inv_idx[u]] <= 4) return new_u;
+    for (int64_t st = 0; st < 8; st++) {
+      const float off[3] = {(float)((st >> 2) & 1) - .5f, (float)((st >> 1) & 1) - .5f, (float)(st & 1) - .5f};
+      float sub_center[3];
+      for (int k = 0; k < 3; k++) /* center + side_len * .5f * offset, left to right (:353) */
+        sub_center[k] = nn->nodes[new_u].center[k] + (nn->nodes[new_u].side_len * .5f) * off[k];
+      const int64_t v = nn->n;
+      o_vec_push(nn, NULL, nn->w[new_u], nn->a[new_u]);  /* emplace_back(): value-initialised node */
+      nn->nodes[new_u].childs[st] = v;
+      for (int k = 0; k < 3; k++) nn->nodes[v].center[k] = sub_center[k];
+      nn->nodes[v].side_len = nn->nodes[new_u].side_len * .5f;
+      nn->nodes[v].parent = new_u;
+      for (int k = 0; k < 8; k++) nn->nodes[v].childs[k] = -1;
+      nn->nodes[v].is_leaf_node = 1;
+      nn->nodes[v].trans_idx = nn->nodes[new_u].trans_idx;
+      /* block_idx left at its value-initialised 0 (:366 is commented out in the reference) */
+    }
+    nn->nodes[new_u].is_leaf_node = 0;
+    nn->nodes[new_u].trans_idx = -1;
+    nn->w[new_u] = GFN_O_INIT_NODE_STAT;
+    nn->a[new_u] = GFN_O_INIT_NODE_STAT;
+  } else {
+    for (int64_t st = 0; st < 8; st++) {
+      if (nn->nodes[new_u].childs[st] >= 0) {
+        const int64_t v = o_subdiv(c, nn->nodes[new_u].childs[st], new_u);
+        nn->nodes[new_u].childs[st] = v;
+      }
+    }
+  }
+  return new_u;
+}
+
+void gfn_o_proc_octree(const gfn_o_tree_node* nodes, int64_t n_nodes, const int64_t* weight_stats,
+                       const int64_t* alpha_stats, const int64_t* visit_cnt, int compact, int subdivide,
+                       int brute_force, gfn_o_tree_node** nodes_out, int64_t* n_out, int64_t** weight_out,
+                       int64_t** alpha_out) {
+  gfn_o_tree_node* t = (gfn_o_tree_node*)malloc((size_t)n_nodes * sizeof(gfn_o_tree_node));
+  memcpy(t, nodes, (size_t)n_nodes * sizeof(gfn_o_tree_node));
+  /* First, compact tree nodes (:175-223) */
+  while (compact) {
+    for (int64_t u = 0; u < n_nodes; u++) {
+      if (!t[u].is_leaf_node) continue;
+      if (t[u].trans_idx < 0 && t[u].parent >= 0) {
+        const int64_t v = t[u].parent;
+        for (int64_t st = 0; st < 8; st++)
+          if (t[v].childs[st] == u) t[v].childs[st] = -1;
+      }
+    }
+    int update_flag = 0;
+    for (int64_t u = 1; u < n_nodes; u++) { /* root can not be leaf node */
+      int has_valid_childs = 0;
+      for (int64_t st = 0; st < 8; st++)
+        if (t[u].childs[st] >= 0) { has_valid_childs = 1; break; }
+      if (!has_valid_childs) {
+        if (!t[u].is_leaf_node) update_flag = 1;
+        t[u].is_leaf_node = 1;
+      }
+    }
+    if (!update_flag) break;
+  }
+  /* Compress path (:226-276) */
+  if (compact) {
+    for (int64_t u = 0; u < n_nodes; u++) {
+      if (t[u].is_leaf_node && t[u].trans_idx < 0) continue;
+      int64_t v = t[u].parent;
+      int st = -1;
+      while (v >= 0 && t[v].parent >= 0 && (st = o_single_child(t, v)) >= 0) {
+        const int64_t vv = t[v].parent;
+        for (int64_t i = 0; i < 8; i++)
+          if (t[vv].childs[i] == v) t[vv].childs[i] = u;
+        t[u].parent = vv;
+        t[v].trans_idx = -1;
+        t[v].is_leaf_node = 1; /* The flag to remove it */
+        v = vv;
+      }
+      (void)st;
+    }
+  }
+  /* renumber (:278-321) */
+  int64_t* new_idx = (int64_t*)malloc((size_t)n_nodes * sizeof(int64_t));
+  int64_t* inv_idx = (int64_t*)malloc((size_t)n_nodes * sizeof(int64_t));
+  int64_t n_compacted = 0;
+  for (int64_t u = 0; u < n_nodes; u++) {
+    new_idx[u] = -1;
+    if (!t[u].is_leaf_node || t[u].trans_idx >= 0) {
+      inv_idx[n_compacted] = u;
+      new_idx[u] = n_compacted++;
+    }
+  }
+  o_vec nv = {0};
+  for (int64_t u = 0; u < n_nodes; u++) {
+    if (new_idx[u] < 0) continue;
+    gfn_o_tree_node node = t[u];
+    if (node.parent >= 0) node.parent = new_idx[node.parent];
+    for (int64_t st = 0; st < 8; st++)
+      if (node.childs[st] >= 0) node.childs[st] = new_idx[node.childs[st]];
+    o_vec_push(&nv, &node, weight_stats[u], alpha_stats[u]);
+  }
+  /* Sub-divide (:326-398) */
+  if (subdivide) {
+    o_vec out = {0};
+    o_subdiv_ctx c = {nv.nodes, nv.w, nv.a, visit_cnt, inv_idx, brute_force, &out};
+    o_subdiv(&c, 0, -1);
+    free(nv.nodes); free(nv.w); free(nv.a);
+    nv = out;
+  }
+  free(t); free(new_idx); free(inv_idx);
+  *nodes_out = nv.nodes; *n_out = nv.n; *weight_out = nv.w; *alpha_out = nv.a;
+}
+
+void gfn_o_free(void* p) { free(p); }
+
+/* CheckVisible (PersSampler_cuda.cu:680-707).  Eigen 3.4 evaluates Matrix<3,4> * v.homogeneous() WITHOUT forming the
+ * 4-vector (Geometry/Homogeneous.h, homogeneous_left_product_impl): dst = lhs.leftCols(3) * v; dst += lhs.col(3),
+ * the 3x3 . 3x1 part coefficient-based with the 3-term redux a + (b + c).  (QueryFrameTransform, by contrast,
+ * materialises the Wec4f first, :156-157, and gets the 4-term halving tree.)  norm() = sqrt(x*x + (y*y + z*z)). */
+static int64_t o_check_visible(const float c[3], float side_len, const float* K, const float* W, const float* bd) {
+  float p[3];
+  for (int r = 0; r < 3; r++) p[r] = (W[4 * r] * c[0] + (W[4 * r + 1] * c[1] + W[4 * r + 2] * c[2])) + W[4 * r + 3];
+  const float radius = (float)((double)side_len * 0.707);  /* float * double literal, rounded back on assignment */
+  if (-p[2] < bd[0] - radius || -p[2] > bd[1] + radius) return 0;
+  const float nrm = sqrtf(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
+  if (nrm < radius) return 1;
+  const float cx = K[2], cy = K[5], fx = K[0], fy = K[4];
+  const float bias_x = radius / -p[2] * fx, bias_y = radius / -p[2] * fy;
+  const float img_x = p[0] / -p[2] * fx, img_y = p[1] / -p[2] * fy;
+  if (img_x + bias_x < -cx || img_x > cx + bias_x || img_y + bias_y < -cy || img_y > cy + bias_y) return 0;
+  return 1;
+}
+
+void gfn_o_mark_invisible(gfn_o_tree_node* nodes, int64_t n_nodes, const float* intri, const float* w2c,
+                          const float* bounds, int64_t n_cams) {
+  for (int64_t u = 0; u < n_nodes; u++) {
+    int64_t n_vis = 0;
+    for (int64_t cam = 0; cam < n_cams; cam++)
+      n_vis += o_check_visible(nodes[u].center, nodes[u].side_len, intri + 9 * cam, w2c + 12 * cam, bounds + 2 * cam);
+    if (n_vis < 1) nodes[u].trans_idx = -1;
+  }
+}

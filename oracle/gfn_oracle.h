@@ -150,6 +150,20 @@ void gfn_o_update_nodes(const int64_t* pts_offsets, int64_t n_rays, const int64_
                         int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt,
                         gfn_o_tree_node* nodes);
 
+/* ---- a15: ProcOctree (PersSampler.cpp:154-417) -------------------------- */
+/* compact (prune invalid leaves to a fixpoint, compress single-child paths, renumber) and / or
+ * subdivide (leaves with visit_cnt > 4, every leaf when brute_force).  Inputs are untouched; the new
+ * tree is malloc'd: *nodes_out [*n_out], *weight_out / *alpha_out [*n_out] (free with gfn_o_free).
+ * The reference zeroes visit_cnt afterwards (:415). */
+void gfn_o_proc_octree(const gfn_o_tree_node* nodes, int64_t n_nodes, const int64_t* weight_stats,
+                       const int64_t* alpha_stats, const int64_t* visit_cnt, int compact, int subdivide,
+                       int brute_force, gfn_o_tree_node** nodes_out, int64_t* n_out, int64_t** weight_out,
+                       int64_t** alpha_out);
+void gfn_o_free(void* p);
+/* K7 MarkInvisibleNodes (PersSampler_cuda.cu:680-742): trans_idx = -1 for nodes no camera sees.
+ * intri f32 [n_cams,3,3], w2c f32 [n_cams,3,4], bounds f32 [n_cams,2], all row-major. */
+void gfn_o_mark_invisible(gfn_o_tree_node* nodes, int64_t n_nodes, const float* intri, const float* w2c,
+                          const float* bounds, int64_t n_cams);
 /* ---- losses / optimiser (the rows SURVEY 8(f) marks next) ---------------- */
 /* losses.py:73-84 CharbonnierLoss: mean(sqrt((p-g)^2 + eps^2)) */
 double gfn_o_charbonnier(const float* pred, const float* gt, int64_t n, float eps, float* d_pred);

@@ -52,6 +52,7 @@ def lib():
         _lib.gfn_o_f32_to_f16.restype = C.c_uint16
         _lib.gfn_o_f32_to_f16.argtypes = [C.c_float]
         _lib.gfn_o_charbonnier.restype = C.c_double
+        _lib.gfn_o_free.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -263,6 +264,33 @@ def update_nodes(pts_offsets, oct_idx, weights, alphas, weight_stats, alpha_stat
     lib().gfn_o_update_nodes(_p(pts_offsets), C.c_int64(pts_offsets.shape[0] - 1), _p(oct_idx), _p(weights),
                              _p(alphas), C.c_int64(n_nodes), _p(weight_stats), _p(alpha_stats), _p(visit_cnt),
                              _p(nodes))
+
+
+def proc_octree(nodes, weight_stats, alpha_stats, visit_cnt, compact=True, subdivide=False, brute_force=False):
+    """PersOctree::ProcOctree -> (nodes, weight_stats, alpha_stats) of the new tree (inputs untouched)."""
+    nodes = np.ascontiguousarray(nodes.view(TREE_NODE_DTYPE).reshape(-1))
+    weight_stats, alpha_stats, visit_cnt = _i64(weight_stats), _i64(alpha_stats), _i64(visit_cnt)
+    n = nodes.shape[0]
+    assert weight_stats.shape[0] == n and alpha_stats.shape[0] == n and visit_cnt.shape[0] == n
+    out_nodes, out_w, out_a, n_out = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    lib().gfn_o_proc_octree(_p(nodes), C.c_int64(n), _p(weight_stats), _p(alpha_stats), _p(visit_cnt), C.c_int(int(compact)),
+                            C.c_int(int(subdivide)), C.c_int(int(brute_force)), C.byref(out_nodes), C.byref(n_out),
+                            C.byref(out_w), C.byref(out_a))
+    m = n_out.value
+    # copy as raw bytes: a structured copy would drop the padding bytes, which are part of the checkpoint blob
+    res_nodes = np.frombuffer(C.string_at(out_nodes.value, m * 128), dtype=np.uint8).copy().view(TREE_NODE_DTYPE)
+    res_w = np.frombuffer(C.string_at(out_w.value, m * 8), dtype=np.int64).copy()
+    res_a = np.frombuffer(C.string_at(out_a.value, m * 8), dtype=np.int64).copy()
+    for ptr in (out_nodes, out_w, out_a):
+        lib().gfn_o_free(ptr)
+    return res_nodes, res_w, res_a
+
+
+def mark_invisible(nodes, intri, w2c, bounds):
+    """K7 MarkInvisibleNodes, in place on nodes."""
+    intri, w2c, bounds = _f32(intri), _f32(w2c), _f32(bounds)
+    assert nodes.dtype == TREE_NODE_DTYPE and nodes.flags["C_CONTIGUOUS"]
+    lib().gfn_o_mark_invisible(_p(nodes), C.c_int64(nodes.shape[0]), _p(intri), _p(w2c), _p(bounds), C.c_int64(intri.shape[0]))
 
 
 def charbonnier(pred, gt, eps=1e-6):

@@ -256,3 +256,89 @@ def test_model_get_outputs_and_training_loop(oracle, dev):
     assert hist[5] < hist[0] and hist[9] < hist[6], hist
     assert not torch.equal(model.feat_pool.detach(), table0) and not torch.equal(model.block_pools[0].detach(), block0)
     assert float(model.get_metrics_dict(outputs, batch)["psnr"]) > 0
+
+
+def _w2c_of(c2w):
+    n = c2w.shape[0]
+    m = np.concatenate([c2w.astype(np.float64), np.tile(np.array([[[0, 0, 0, 1.0]]]), (n, 1, 1))], axis=1)
+    return np.linalg.inv(m)[:, :3, :].astype(np.float32)
+
+
+def test_mark_invisible_nodes_matches_oracle(oracle, dev):
+    """K7 (PersSampler_cuda.cu:680-742) on the built tree plus nodes pushed outside every frustum."""
+    from gfnerf_amd import ops
+
+    sc = small_scene()
+    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE).copy()
+    rng = np.random.default_rng(2)
+    far = rng.choice(np.nonzero(nodes["trans_idx"] >= 0)[0], 40, replace=False)
+    nodes["center"][far[:20], 2] += 900.0          # far above the cameras, behind them
+    nodes["center"][far[20:], :2] += 3000.0        # far off to the side
+    w2c = _w2c_of(sc["c2w"])
+    want = nodes.copy()
+    oracle.mark_invisible(want, sc["intri"], w2c, sc["bounds"])
+    blob = _t(nodes.view(np.uint8).reshape(-1), dev)
+    ops.mark_invisible_nodes(blob, _t(sc["intri"], dev), _t(w2c, dev), _t(sc["bounds"], dev))
+    got = blob.cpu().numpy().view(oracle.TREE_NODE_DTYPE)
+    assert np.array_equal(got["trans_idx"], want["trans_idx"])
+    changed = (want["trans_idx"] != nodes["trans_idx"]).sum()
+    assert 20 <= changed < nodes.shape[0] // 2, changed
+    for f in ("center", "side_len", "parent", "childs", "is_leaf_node", "block_idx"):
+        assert np.array_equal(got[f], nodes[f])
+
+
+def test_update_oct_nodes_milestone_runs_proc_octree(oracle, dev):
+    """UpdateOctNodes at a subdivision milestone (PersSampler_cuda.cu:667-676): K5/K6, ProcOctree(subdivide),
+    MarkInvisibleNodes, ProcOctree(compact) -- tree and statistics equal the oracle's sequence byte for byte, and the
+    sampler keeps producing the oracle's samples on the new tree."""
+    import torch
+
+    from gfnerf_amd.gfnerf.perssampler import PersSampler, _Cameras
+
+    sc = small_scene()
+    cams = _Cameras(torch.from_numpy(sc["c2w"]), torch.from_numpy(sc["intri"]))
+    ps = PersSampler(cams, n_split_dataset=2, steps_per_split_dataset=100, steps_perssampler_init=300,
+                     bounds=torch.from_numpy(sc["bounds"]), bbox_levels=10, max_level=9, device=dev, seed=7)
+    nat = ps.sampler
+    nat.sub_div_milestones_ = [50, 20]  # reversed list: 20 fires first
+    nat.compact_freq_ = 1000
+    R = 256
+    o, d, _ = rays_for(sc, R, seed=9)
+    ps.update_mode(1)
+    nat.ray_march_fineness_ = 6.0
+    s = nat.sample_packed(_t(o, dev), _t(d, dev))
+    N = int(s["pts_offsets"][-1].item())
+    rng = np.random.default_rng(4)
+    w = (rng.random(s["ts"].shape[0]) * 0.02).astype(np.float32)
+    a = (rng.random(s["ts"].shape[0]) * 0.05).astype(np.float32)
+    w[rng.random(w.size) < 0.5] = 0
+    # oracle sequence on host copies
+    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE).copy()
+    ws = np.full(nodes.shape[0], 1000, np.int64); as_ = ws.copy(); vc = np.zeros(nodes.shape[0], np.int64)
+    po = s["pts_offsets"].cpu().numpy().astype(np.int64)
+    anchors = s["anchors"].cpu().numpy()[:N].astype(np.int64)
+    for _ in range(3):  # a few updates so that some statistics go negative and K6 invalidates leaves
+        oracle.update_nodes(po, anchors[:, 1].copy(), w[:N], a[:N], ws, as_, vc, nodes)
+        nat.last_packed = s
+        nat.UpdateOctNodes(None, None, _t(w, dev), _t(a, dev), 7)
+    assert np.array_equal(nat.tree_weight_stats_.cpu().numpy(), ws) and np.array_equal(nat.tree_visit_cnt_.cpu().numpy(), vc)
+    oracle.update_nodes(po, anchors[:, 1].copy(), w[:N], a[:N], ws, as_, vc, nodes)
+    n1, w1, a1 = oracle.proc_octree(nodes, ws, as_, vc, compact=True, subdivide=True, brute_force=False)
+    oracle.mark_invisible(n1, sc["intri"], _w2c_of(sc["c2w"]), sc["bounds"])
+    n2, w2, a2 = oracle.proc_octree(n1, w1, a1, np.zeros(n1.shape[0], np.int64), compact=True, subdivide=False, brute_force=False)
+    nat.last_packed = s
+    nat.UpdateOctNodes(None, None, _t(w, dev), _t(a, dev), 20)  # milestone 20 fires
+    assert nat.get_sub_div_milestones_() == [50]
+    assert nat.n_nodes == n2.shape[0] and nat.n_nodes != sc["n_nodes"]
+    assert nat.tree_nodes_gpu_.cpu().numpy().tobytes() == n2.tobytes()
+    assert np.array_equal(nat.tree_weight_stats_.cpu().numpy(), w2) and np.array_equal(nat.tree_alpha_stats_.cpu().numpy(), a2)
+    assert int(nat.tree_visit_cnt_.abs().sum().item()) == 0
+    # sampling on the new tree: same leaves and samples as the oracle
+    s2 = nat.sample_packed(_t(o, dev), _t(d, dev))
+    dn = oracle.normalize_dirs(d)
+    off, hi, nf = oracle.trace(o, dn, n2)
+    m = oracle.march(o, dn, np.full(1024 + R + 10, 6.0, np.float32), 1 / 256, True, off, hi, nf, n2, sc["transes"].view(oracle.TRANS_INFO_DTYPE))
+    N2 = int(m["pts_offsets"][-1])
+    assert np.array_equal(s2["pts_offsets"].cpu().numpy().astype(np.int64), m["pts_offsets"])
+    assert np.array_equal(s2["anchors"].cpu().numpy()[:N2].astype(np.int64), m["anchors"])
+    assert np.array_equal(s2["ts"].cpu().numpy()[:N2], m["ts"])
