@@ -6,7 +6,7 @@
 
 One "step" = one full training pass of the hot path over one batch of 4096 synthetic rays:
 PersSampler trace+march -> Hash3DAnchored (global + active focal table) -> base MLP -> density /
-SH / appearance head input -> head MLP -> compositing -> Charbonnier loss -> full backward ->
+SH / appearance head input -> head MLP -> compositing -> Charbonnier + S3IM loss -> full backward ->
 Adam.  Workload (BASELINE.json configs[2]): "GF-NeRF global+focal, 4 sub-encoder blocks on 1 GPU,
 Rubble-scale synthetic cameras, 4096 rays x 192 samples".  With N > 1 (configs[3]) every rank
 owns one focal block and its own rays (weak scaling); the reference freezes the global table
@@ -138,6 +138,9 @@ def main():
     target = TARGET_SAMPLES[args.stage]
     fineness, mean_samples = pick_fineness(hp, batches[0][0], batches[0][1], target, scene, torch)
     noises = [torch.from_numpy(scene.make_noise(N_RAYS, True, fineness, seed=k + 1)).cuda() for k in range(4)]
+    # S3IM's arange + 9 randperm index vectors (losses.py:780-789), like the noise: drawn before the timed region
+    from gfnerf_amd import ops as _ops
+    s3im_idx = [_ops.s3im_index(N_RAYS, cfg.s3im_repeat_time, device="cuda") for _ in range(4)]
 
     allreduce = None
     if world > 1 and args.stage == "global":
@@ -149,7 +152,7 @@ def main():
     def step(i):
         o, d, cam, gt = batches[i % 4]
         block = (i % n_blocks) if args.stage == "focal" else None
-        return hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce)
+        return hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3im_idx[i % 4])
 
     for i in range(args.warmup):
         step(i)

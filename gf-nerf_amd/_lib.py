@@ -48,10 +48,12 @@ SIGNATURES = {
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gfn_generate_rays": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_composite_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_depth_finalize": (_i32, [_vp, _i64, _vp, _f32, _vp]),
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "gfn_s3im": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),

@@ -307,6 +307,114 @@ __global__ __launch_bounds__(256) void adam_ex_kernel(float* __restrict__ p, con
   }
 }
 
+// Cameras.generate_rays for perspective cameras without distortion (nerfstudio/cameras/cameras.py:560-734, GF's
+// lookat_directions :704): pixel -> (origin, unit direction, pixel area, |d|).  Either explicit (camera, (y, x)) pairs
+// (what the pixel samplers hand to RayGenerator) or a raster run of one camera's image (render.py:109), pixel p ->
+// (y, x) = (p / width + 0.5, p % width + 0.5) (get_image_coords, pixel_offset 0.5).
+__device__ __forceinline__ float cam_dir(const float* __restrict__ M, float cxn, float cyn, float out[3]) {
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) v[i] = (cxn * M[4 * i] + cyn * M[4 * i + 1]) + (-1.0f) * M[4 * i + 2];  // sum(dir * rotation, -1), :697-699
+  float nrm = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  nrm = fmaxf(nrm, 8.8817841970012523e-16f);  // normalize_with_norm, camera_utils.py:28,251
+#pragma unroll
+  for (int i = 0; i < 3; i++) out[i] = v[i] / nrm;
+  return nrm;
+}
+
+__global__ __launch_bounds__(256) void generate_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ intr,
+                                                           const int* __restrict__ cam_idx, int cam0, const float* __restrict__ coords,
+                                                           int64_t first_pixel, int width, int64_t n, float* __restrict__ origins,
+                                                           float* __restrict__ directions, float* __restrict__ lookat,
+                                                           float* __restrict__ pixel_area, float* __restrict__ dir_norm) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int cam = cam_idx ? cam_idx[i] : cam0;
+  const float* M = c2w + 12 * (int64_t)cam;
+  const float fx = intr[4 * cam], fy = intr[4 * cam + 1], cx = intr[4 * cam + 2], cy = intr[4 * cam + 3];
+  float y, x;
+  if (coords) { y = coords[2 * i]; x = coords[2 * i + 1]; }
+  else { const int64_t p = first_pixel + i; y = (float)(p / width) + 0.5f; x = (float)(p % width) + 0.5f; }
+  const float c0x = (x - cx) / fx, c0y = -(y - cy) / fy;                        // :606
+  const float c1x = (x - cx + 1.0f) / fx, c2y = -(y - cy + 1.0f) / fy;          // :607-608 (offsets for dx, dy)
+  float d0[3], d1[3], d2[3];
+  const float nrm = cam_dir(M, c0x, c0y, d0);
+  cam_dir(M, c1x, c0y, d1);
+  cam_dir(M, c0x, c2y, d2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (origins) origins[3 * i + k] = M[4 * k + 3];
+    if (lookat) lookat[3 * i + k] = M[4 * k + 2];
+    directions[3 * i + k] = d0[k];
+  }
+  if (dir_norm) dir_norm[i] = nrm;
+  if (pixel_area) {  // :712-716
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float a = d0[k] - d1[k], b = d0[k] - d2[k]; sx += a * a; sy += b * b; }
+    pixel_area[i] = sqrtf(sx) * sqrtf(sy);
+  }
+}
+
+// S3IM (nerfstudio/model_components/losses.py:713-794; gfnerf/config.py:96-100: kernel 4, stride 4, 10 repeats,
+// virtual patch height 32): the batch's rays, repeated under random permutations, are laid out as a [3, H, W] image and
+// compared with a strided SSIM.  Stride == kernel size, so every virtual pixel belongs to at most one window: one thread
+// per (channel, window) evaluates the window and scatters d loss / d pred to its 16 rays.
+struct S3imWin { float w[4][4]; };
+__global__ __launch_bounds__(256) void s3im_kernel(const float* __restrict__ gt, const float* __restrict__ pred, const int* __restrict__ index,
+                                                  int64_t H, int64_t W, int64_t OH, int64_t OW, S3imWin win, float mult,
+                                                  float* __restrict__ loss_dev, float* __restrict__ g_pred) {
+  const int64_t cells = 3 * OH * OW;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float ssim = 0.f;
+  if (id < cells) {
+    const int c = (int)(id / (OH * OW));
+    const int64_t rem = id - (int64_t)c * OH * OW, oy = rem / OW, ox = rem - oy * OW;
+    float x1[16], x2[16], ww[16];
+    int ray[16];
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t y = oy * 4 - 1 + i, x = ox * 4 - 1 + j;  // padding (4-1)//2 = 1 (:741)
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const int r = in ? index[y * W + x] : -1;
+        ray[4 * i + j] = r;
+        const float a = in ? gt[3 * (int64_t)r + c] : 0.f, b = in ? pred[3 * (int64_t)r + c] : 0.f, wt = win.w[i][j];
+        x1[4 * i + j] = a; x2[4 * i + j] = b; ww[4 * i + j] = wt;
+        mu1 += wt * a; mu2 += wt * b; e11 += wt * a * a; e22 += wt * b * b; e12 += wt * a * b;
+      }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+    const float inv = 1.f / (B1 * B2);
+    ssim = A1 * A2 * inv;
+    if (g_pred) {
+      const float k = -mult / (float)cells;  // loss = mult * (1 - mean(ssim_map))
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        if (ray[p] < 0) continue;
+        const float dA1 = 2.f * mu1 * ww[p], dA2 = 2.f * ww[p] * (x1[p] - mu1), dB1 = 2.f * mu2 * ww[p], dB2 = 2.f * ww[p] * (x2[p] - mu2);
+        const float ds = (dA1 * A2 + A1 * dA2) * inv - ssim * (dB1 * B2 + B1 * dB2) * inv;
+        atomicAdd(g_pred + 3 * (int64_t)ray[p] + c, k * ds);
+      }
+    }
+  }
+  // block sum of ssim -> one atomic per workgroup
+  __shared__ float part[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ssim += __shfl_xor(ssim, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ssim;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    float contrib = -mult * tot / (float)cells;
+    if (blockIdx.x == 0) contrib += mult;  // the "1 -" term, once
+    atomicAdd(loss_dev, contrib);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -446,6 +554,40 @@ int gfn_fill_zero(void* p, int64_t bytes, void* stream) {
   GFN_CHECK_ARG(p && bytes >= 0, "gfn_fill_zero: bad arguments");
   if (bytes == 0) return GFN_OK;
   GFN_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)bytes, gfn_stream(stream)));
+  return GFN_OK;
+}
+
+int gfn_generate_rays(const float* c2w, const float* intr, const int32_t* cam_idx, int32_t cam0, const float* coords,
+                      int64_t first_pixel, int32_t width, int64_t n, float* origins, float* directions, float* lookat,
+                      float* pixel_area, float* dir_norm, void* stream) {
+  if (n == 0) return GFN_OK;
+  GFN_CHECK_ARG(c2w && intr && directions, "gfn_generate_rays: null pointer");
+  GFN_CHECK_ARG(n > 0 && n < (1ll << 40), "gfn_generate_rays: n=%lld", (long long)n);
+  GFN_CHECK_ARG(coords || (width > 0 && first_pixel >= 0), "gfn_generate_rays: raster mode needs width > 0 and first_pixel >= 0");
+  GFN_CHECK_ARG(cam_idx || cam0 >= 0, "gfn_generate_rays: cam0=%d", (int)cam0);
+  generate_rays_kernel<<<(unsigned)((n + 255) / 256), 256, 0, gfn_stream(stream)>>>(c2w, intr, cam_idx, cam0, coords, first_pixel, width, n,
+                                                                                   origins, directions, lookat, pixel_area, dir_norm);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_s3im(const float* gt, const float* pred, const int32_t* index, int64_t n_idx, int patch_h, float mult, float* loss_dev,
+             float* g_pred, void* stream) {
+  GFN_CHECK_ARG(gt && pred && index && loss_dev, "gfn_s3im: null pointer");
+  GFN_CHECK_ARG(patch_h >= 4 && n_idx >= 4 * (int64_t)patch_h && n_idx % patch_h == 0, "gfn_s3im: n_idx=%lld must be a multiple of patch_h=%d (>= 4 columns)",
+                (long long)n_idx, patch_h);
+  const int64_t H = patch_h, W = n_idx / patch_h;
+  const int64_t OH = (H + 2 - 4) / 4 + 1, OW = (W + 2 - 4) / 4 + 1;
+  S3imWin win;
+  {  // gaussian(4, 1.5) as torch builds it: f32 tensor of exp values divided by its f32 sum, outer product (:726-733)
+    float g[4], sum = 0.f;
+    for (int x = 0; x < 4; x++) { g[x] = (float)exp(-(double)((x - 2) * (x - 2)) / (2.0 * 1.5 * 1.5)); sum += g[x]; }
+    for (int x = 0; x < 4; x++) g[x] = g[x] / sum;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) win.w[i][j] = g[i] * g[j];
+  }
+  const int64_t cells = 3 * OH * OW;
+  s3im_kernel<<<(unsigned)((cells + 255) / 256), 256, 0, gfn_stream(stream)>>>(gt, pred, index, H, W, OH, OW, win, mult, loss_dev, g_pred);
+  GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
 

@@ -38,6 +38,9 @@ class HotPathConfig:
     table_f16_shadow: bool = True    # gather from f16 shadows refreshed by the Adam kernel (same values as :185's cast)
     grad_f16: bool = True            # table gradient pool in f16 with the x128 loss scale, like the reference (:151,:209)
     fused_field: bool = True         # decoder as one kernel per direction (needs hidden == 128)
+    s3im_loss_mult: float = 1.0      # gfnerf/config.py:96 (0 disables the S3IM term of get_loss_dict, nerfacto.py:687-688)
+    s3im_patch_height: int = 32      # config.py:100
+    s3im_repeat_time: int = 10       # config.py:99
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
@@ -304,10 +307,18 @@ class HotPath:
         self._timed("hash_bwd", ops.hash_bwd, prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
-    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None):
-        """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux)."""
+    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None):
+        """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
+        s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent."""
+        c = self.cfg
         comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block)
-        loss, g_rgb = ops.charbonnier(comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        R = rays_o.shape[0]
+        if c.s3im_loss_mult > 0 and (R * c.s3im_repeat_time) % c.s3im_patch_height == 0 and R * c.s3im_repeat_time >= 4 * c.s3im_patch_height:
+            if s3im_index is None:
+                s3im_index = ops.s3im_index(R, c.s3im_repeat_time, device=self.dev)
+            self._timed("loss", ops.s3im, gt_rgb, comp["rgb"], s3im_index, patch_h=c.s3im_patch_height, mult=c.s3im_loss_mult,
+                        loss=loss, g_pred=g_rgb)
         self.backward(ctx, g_rgb)
         return loss, ctx
 
@@ -344,9 +355,9 @@ class HotPath:
             return out
         return [self.table_grad]
 
-    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None):
+    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None, s3im_index=None):
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
-        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block)
+        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index)
         if allreduce is not None:
             allreduce(self.grads(stage))
         self.optimizer_step(stage, block)

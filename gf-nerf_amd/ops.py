@@ -344,6 +344,38 @@ def octree_proc_host(nodes, weight_stats, alpha_stats, visit_cnt, compact=True, 
     return new_nodes, new_w, new_a
 
 
+def generate_rays(c2w, intr, cam_idx=None, coords=None, cam0=0, first_pixel=0, width=0, n=None, out=None, want_extras=True):
+    """Cameras.generate_rays (perspective, no distortion).  Explicit (cam_idx i32 [n], coords f32 [n,2] = (y, x)) pairs, or the
+    raster run [first_pixel, first_pixel + n) of camera cam0's image of the given width.
+    -> dict(origins, directions, lookat [n,3], pixel_area, dir_norm [n]); `out` may pre-allocate origins / directions."""
+    _chk(c2w, torch.float32, "c2w", 4); _chk(intr, torch.float32, "intr", 4); _chk(cam_idx, torch.int32, "cam_idx")
+    _chk(coords, torch.float32, "coords", 2)
+    if coords is not None:
+        n = coords.shape[0]
+        if cam_idx is None or cam_idx.numel() != n:
+            raise _lib.GfnError("explicit coords need one camera index per ray")
+    elif n is None or width <= 0:
+        raise _lib.GfnError("raster mode needs n and width")
+    n_cams = c2w.shape[0]
+    if tuple(c2w.shape) != (n_cams, 3, 4) or tuple(intr.shape) != (n_cams, 4) or not (0 <= cam0 < n_cams):
+        raise _lib.GfnError("expected c2w [n_cams,3,4], intr [n_cams,4] and a valid cam0")
+    dev = c2w.device
+    o = out or {}
+    res = dict(origins=o.get("origins", None), directions=o.get("directions", None))
+    for k in ("origins", "directions"):
+        if res[k] is None:
+            res[k] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        _chk(res[k], torch.float32, k, 3)
+    res["lookat"] = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_extras else None
+    res["pixel_area"] = torch.empty(n, dtype=torch.float32, device=dev) if want_extras else None
+    res["dir_norm"] = torch.empty(n, dtype=torch.float32, device=dev) if want_extras else None
+    rc = _lib.lib().gfn_generate_rays(_ptr(c2w), _ptr(intr), _ptr(cam_idx), int(cam0), _ptr(coords), int(first_pixel), int(width), n,
+                                      _ptr(res["origins"]), _ptr(res["directions"]), _ptr(res["lookat"]), _ptr(res["pixel_area"]),
+                                      _ptr(res["dir_norm"]), _stream())
+    _lib.check(rc, "gfn_generate_rays")
+    return res
+
+
 # ---------------------------------------------------------------------------- MLP
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 
@@ -638,6 +670,28 @@ def charbonnier(pred, gt, eps=1e-6):
     _lib.check(_lib.lib().gfn_charbonnier(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(loss), _ptr(g), _stream()),
                "gfn_charbonnier")
     return loss, g
+
+
+def s3im_index(n_rays, repeat_time=10, generator=None, device=None):
+    """The index vector S3IM.forward builds (losses.py:780-789): arange followed by repeat_time - 1 random permutations."""
+    parts = [torch.arange(n_rays, device=device, dtype=torch.int64)]
+    parts += [torch.randperm(n_rays, device=device, generator=generator) for _ in range(repeat_time - 1)]
+    return torch.cat(parts).to(torch.int32)
+
+
+def s3im(gt, pred, index, patch_h=32, mult=1.0, loss=None, g_pred=None, want_grad=True):
+    """loss[0] += mult * S3IM(gt, pred); g_pred += mult * d/d pred.  -> (loss [1], g_pred [R,3])."""
+    _chk(gt, torch.float32, "gt", 3); _chk(pred, torch.float32, "pred", 3); _chk(index, torch.int32, "index")
+    if gt.shape != pred.shape:
+        raise _lib.GfnError("s3im: gt and pred differ in shape")
+    if loss is None:
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    if g_pred is None and want_grad:
+        g_pred = torch.zeros_like(pred)
+    _chk(loss, torch.float32, "loss"); _chk(g_pred, torch.float32, "g_pred", 3)
+    rc = _lib.lib().gfn_s3im(_ptr(gt), _ptr(pred), _ptr(index), index.numel(), int(patch_h), float(mult), _ptr(loss), _ptr(g_pred), _stream())
+    _lib.check(rc, "gfn_s3im")
+    return loss, g_pred
 
 
 def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15):

@@ -310,6 +310,20 @@ int gfn_head_unpack_bwd(const float* h, const float* dsigma, const float* dxh,
                         int64_t n_max, const int32_t* n_dev, float* dh, float* demb, void* stream);
 
 /* ====================================================================== *
+ * Ray generation (Cameras.generate_rays, nerfstudio/cameras/cameras.py:560-734,
+ * perspective cameras without distortion; GF's lookat_directions :704)
+ * ====================================================================== */
+/* c2w f32 [n_cams,3,4]; intr f32 [n_cams,4] = (fx, fy, cx, cy).  Rays are either explicit pairs
+ * (cam_idx i32 [n], coords f32 [n,2] = (y, x) with the 0.5 pixel offset already added) or, with
+ * coords == NULL, the raster run of pixels first_pixel .. first_pixel+n-1 of an image `width`
+ * pixels wide seen by camera cam0 (cam_idx == NULL) -- what render.py renders tile by tile.
+ * Outputs (origins, lookat, pixel_area, dir_norm may be NULL): origins / directions (unit) /
+ * lookat f32 [n,3], pixel_area / dir_norm f32 [n]. */
+int gfn_generate_rays(const float* c2w, const float* intr, const int32_t* cam_idx, int32_t cam0,
+                      const float* coords, int64_t first_pixel, int32_t width, int64_t n, float* origins,
+                      float* directions, float* lookat, float* pixel_area, float* dir_norm, void* stream);
+
+/* ====================================================================== *
  * Compositing  (replaces RaySamples.get_weights_f2nerf, rays.py:178-200, and
  * RGB / Accumulation / Depth("expected") renderers, renderers.py:69-138,195-283)
  * ====================================================================== */
@@ -334,6 +348,12 @@ int gfn_composite_bwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
 /* loss_dev[0] += sum(sqrt((pred-gt)^2+eps^2))/rows; g_pred = d loss / d pred. */
 int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps, float* loss_dev,
                     float* g_pred, void* stream);
+/* S3IM (losses.py:713-794 as configured by gfnerf/config.py:96-100: 4x4 gaussian window, stride 4, zero
+ * padding 1): loss_dev[0] += mult * (1 - mean SSIM) over the virtual image [3, patch_h, n_idx/patch_h]
+ * whose pixel k is ray index[k] (arange + randperms, :780-789); g_pred [R,3] += mult * d/d pred (may be
+ * NULL).  gt, pred f32 [R,3]. */
+int gfn_s3im(const float* gt, const float* pred, const int32_t* index, int64_t n_idx, int patch_h, float mult,
+             float* loss_dev, float* g_pred, void* stream);
 int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
                   float beta1, float beta2, float eps, void* stream);
 /* Adam for a hash table: g is f32 (g_f16 == 0) or f16 (g_f16 != 0) and is multiplied by

@@ -962,3 +962,92 @@ void gfn_o_mark_invisible(gfn_o_tree_node* nodes, int64_t n_nodes, const float* 
     if (n_vis < 1) nodes[u].trans_idx = -1;
   }
 }
+
+
+/* ======================================================================== *
+ * Cameras.generate_rays (cameras.py:560-734), perspective, distortion-free.
+ * ======================================================================== */
+static void o_cam_dir(const float* R /* c2w row-major 3x4 */, float cxn, float cyn, float out[3], float* norm_out) {
+  /* directions_stack = [x, y, -1]; rotated = sum(dir[None, :] * rotation, -1) (:697-699): row i = sum_j d[j] R[i][j];
+   * normalize_with_norm: x / max(||x||, eps) (camera_utils.py:240-252) */
+  const float d[3] = {cxn, cyn, -1.0f};
+  float v[3];
+  for (int i = 0; i < 3; i++) v[i] = (d[0] * R[4 * i] + d[1] * R[4 * i + 1]) + d[2] * R[4 * i + 2];
+  float nrm = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  const float eps = (float)(2.220446049250313e-16 * 4.0); /* _EPS = np.finfo(float).eps * 4.0 (camera_utils.py:28), .to(x) */
+  if (nrm < eps) nrm = eps;
+  for (int i = 0; i < 3; i++) out[i] = v[i] / nrm;
+  if (norm_out) *norm_out = nrm;
+}
+
+void gfn_o_generate_rays(const float* c2w, const float* intr, const int32_t* cam_idx, const float* coords, int64_t n,
+                         float* origins, float* directions, float* lookat, float* pixel_area, float* dir_norm) {
+  for (int64_t i = 0; i < n; i++) {
+    const float* M = c2w + 12 * (int64_t)cam_idx[i];
+    const float fx = intr[4 * cam_idx[i]], fy = intr[4 * cam_idx[i] + 1], cx = intr[4 * cam_idx[i] + 2], cy = intr[4 * cam_idx[i] + 3];
+    const float y = coords[2 * i], x = coords[2 * i + 1];
+    /* :606-608 */
+    const float c0x = (x - cx) / fx, c0y = -(y - cy) / fy;
+    const float cxx = (x - cx + 1.0f) / fx, cyy = -(y - cy + 1.0f) / fy;
+    float d0[3], d1[3], d2[3], nrm;
+    o_cam_dir(M, c0x, c0y, d0, &nrm);
+    o_cam_dir(M, cxx, c0y, d1, NULL);
+    o_cam_dir(M, c0x, cyy, d2, NULL);
+    if (origins) for (int k = 0; k < 3; k++) origins[3 * i + k] = M[4 * k + 3];
+    if (lookat) for (int k = 0; k < 3; k++) lookat[3 * i + k] = M[4 * k + 2];
+    if (directions) for (int k = 0; k < 3; k++) directions[3 * i + k] = d0[k];
+    if (dir_norm) dir_norm[i] = nrm;
+    if (pixel_area) { /* :712-716 */
+      float sx = 0.f, sy = 0.f;
+      for (int k = 0; k < 3; k++) { const float a = d0[k] - d1[k], b = d0[k] - d2[k]; sx += a * a; sy += b * b; }
+      pixel_area[i] = sqrtf(sx) * sqrtf(sy);
+    }
+  }
+}
+
+
+/* ======================================================================== *
+ * S3IM (nerfstudio/model_components/losses.py:713-794), kernel 4, stride 4.
+ * ======================================================================== */
+double gfn_o_s3im(const float* a, const float* b, const int32_t* index, int64_t n_idx, int patch_h, float* d_b, int64_t n_rays) {
+  const int K = 4, stride = 4, pad = (K - 1) / 2; /* :741 padding = (kernel_size-1)//2 */
+  const int64_t H = patch_h, W = n_idx / patch_h; /* reshape(1, 3, patch_h, -1), :790-791 */
+  const int64_t OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+  double g[4], gs = 0; /* gaussian(4, 1.5), :726-728 */
+  for (int x = 0; x < K; x++) { g[x] = exp(-(double)((x - K / 2) * (x - K / 2)) / (2.0 * 1.5 * 1.5)); gs += g[x]; }
+  float w[4][4];
+  { float g32[4]; for (int x = 0; x < K; x++) g32[x] = (float)g[x] / (float)gs; /* torch.Tensor (f32) / sum */
+    for (int i = 0; i < K; i++) for (int j = 0; j < K; j++) w[i][j] = g32[i] * g32[j]; }
+  const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+  const double count = (double)(3 * OH * OW);
+  if (d_b) memset(d_b, 0, (size_t)n_rays * 3 * sizeof(float));
+  double total = 0;
+  for (int c = 0; c < 3; c++)
+    for (int64_t oy = 0; oy < OH; oy++)
+      for (int64_t ox = 0; ox < OW; ox++) {
+        double mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+        for (int i = 0; i < K; i++)
+          for (int j = 0; j < K; j++) {
+            const int64_t y = oy * stride - pad + i, x = ox * stride - pad + j;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue; /* zero padding */
+            const int64_t r = index[y * W + x];
+            const double x1 = a[3 * r + c], x2 = b[3 * r + c], ww = w[i][j];
+            mu1 += ww * x1; mu2 += ww * x2; e11 += ww * x1 * x1; e22 += ww * x2 * x2; e12 += ww * x1 * x2;
+          }
+        const double s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const double A1 = 2 * mu1 * mu2 + C1, A2 = 2 * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+        total += (A1 * A2) / (B1 * B2);
+        if (!d_b) continue;
+        for (int i = 0; i < K; i++)
+          for (int j = 0; j < K; j++) {
+            const int64_t y = oy * stride - pad + i, x = ox * stride - pad + j;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;
+            const int64_t r = index[y * W + x];
+            const double x1 = a[3 * r + c], x2 = b[3 * r + c], ww = w[i][j];
+            const double dA1 = 2 * mu1 * ww, dA2 = 2 * ww * (x1 - mu1), dB1 = 2 * mu2 * ww, dB2 = 2 * ww * (x2 - mu2);
+            const double ds = (dA1 * A2 + A1 * dA2) / (B1 * B2) - (A1 * A2) * (dB1 * B2 + B1 * dB2) / ((B1 * B2) * (B1 * B2));
+            d_b[3 * r + c] += (float)(-ds / count); /* loss = 1 - mean(ssim_map) */
+          }
+      }
+  return 1.0 - total / count;
+}

@@ -164,9 +164,19 @@ void gfn_o_free(void* p);
  * intri f32 [n_cams,3,3], w2c f32 [n_cams,3,4], bounds f32 [n_cams,2], all row-major. */
 void gfn_o_mark_invisible(gfn_o_tree_node* nodes, int64_t n_nodes, const float* intri, const float* w2c,
                           const float* bounds, int64_t n_cams);
+/* ---- Cameras.generate_rays, perspective cameras without distortion
+ * (nerfstudio/cameras/cameras.py:560-734; GF's lookat_directions :704).  c2w f32 [n_cams,3,4], intr f32
+ * [n_cams,4] = (fx, fy, cx, cy), cam_idx i32 [n], coords f32 [n,2] = (y, x) incl. the 0.5 pixel offset.
+ * Outputs [n,3] x3, [n] x2 (any may be NULL): origins, unit directions, c2w[:, :, 2], pixel area, |d|. */
+void gfn_o_generate_rays(const float* c2w, const float* intr, const int32_t* cam_idx, const float* coords, int64_t n,
+                         float* origins, float* directions, float* lookat, float* pixel_area, float* dir_norm);
 /* ---- losses / optimiser (the rows SURVEY 8(f) marks next) ---------------- */
 /* losses.py:73-84 CharbonnierLoss: mean(sqrt((p-g)^2 + eps^2)) */
 double gfn_o_charbonnier(const float* pred, const float* gt, int64_t n, float eps, float* d_pred);
+/* losses.py:713-794 S3IM: 1 - mean SSIM (4x4 gaussian window sigma 1.5, stride 4, zero padding 1, C1 = .01^2,
+ * C2 = .03^2) of the virtual patches [3, patch_h, n_idx/patch_h] built from img[index[k]]; a, b f32 [R,3], index i32
+ * [n_idx] (the concatenated arange + 9 randperms, :780-789).  d_b (may be NULL) = d loss / d b. */
+double gfn_o_s3im(const float* a, const float* b, const int32_t* index, int64_t n_idx, int patch_h, float* d_b, int64_t n_rays);
 /* torch.optim.Adam single step (no amsgrad, no weight decay) */
 void gfn_o_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
                      float beta1, float beta2, float eps);

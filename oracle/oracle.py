@@ -293,6 +293,52 @@ def mark_invisible(nodes, intri, w2c, bounds):
     lib().gfn_o_mark_invisible(_p(nodes), C.c_int64(nodes.shape[0]), _p(intri), _p(w2c), _p(bounds), C.c_int64(intri.shape[0]))
 
 
+def generate_rays(c2w, intr, cam_idx, coords):
+    """Cameras.generate_rays (perspective, no distortion) -> dict(origins, directions, lookat, pixel_area, dir_norm)."""
+    c2w, intr, coords = _f32(c2w), _f32(intr), _f32(coords)
+    cam_idx = np.ascontiguousarray(cam_idx, np.int32)
+    n = cam_idx.shape[0]
+    o = {k: np.zeros((n, 3), np.float32) for k in ("origins", "directions", "lookat")}
+    o["pixel_area"] = np.zeros(n, np.float32); o["dir_norm"] = np.zeros(n, np.float32)
+    lib().gfn_o_generate_rays(_p(c2w), _p(intr), _p(cam_idx), _p(coords), C.c_int64(n), _p(o["origins"]), _p(o["directions"]),
+                              _p(o["lookat"]), _p(o["pixel_area"]), _p(o["dir_norm"]))
+    return o
+
+
+def gf_lr_multiplier(step, lr_init, lr_final=None, max_steps=100000, warmup_steps=0, lr_pre_warmup=1e-8, ramp="cosine",
+                     n_split_dataset=1, steps_per_split_dataset=1000, steps_perssampler_init=10000):
+    """GFNerfExponentialDecayScheduler.get_scheduler's lambda (engine/schedulers.py:145-182), statement by statement."""
+    if lr_final is None:
+        lr_final = lr_init
+    if step < warmup_steps:
+        if ramp == "cosine":
+            lr = lr_pre_warmup + (1 - lr_pre_warmup) * np.sin(0.5 * np.pi * np.clip(step / warmup_steps, 0, 1))
+        else:
+            lr = lr_pre_warmup + (lr_init - lr_pre_warmup) * step / warmup_steps
+    else:
+        init_stage = steps_perssampler_init > 0 and step < steps_perssampler_init
+        if init_stage:
+            relative_step = step
+        else:
+            cur_split = ((step - steps_perssampler_init) // steps_per_split_dataset) % n_split_dataset
+            cur_circles = (step - steps_perssampler_init) // (steps_per_split_dataset * n_split_dataset)
+            relative_step = (step - steps_perssampler_init - cur_circles * steps_per_split_dataset * n_split_dataset
+                             - cur_split * steps_per_split_dataset + cur_circles * steps_per_split_dataset)
+        t = np.clip((relative_step - warmup_steps) / (max_steps - warmup_steps), 0, 1)
+        lr = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+    return lr / lr_init
+
+
+def s3im(a, b, index, patch_h=32):
+    """S3IM loss (kernel 4, stride 4) -> (loss, d loss / d b)."""
+    a, b = _f32(a), _f32(b)
+    index = np.ascontiguousarray(index, np.int32)
+    d = np.zeros_like(b)
+    lib().gfn_o_s3im.restype = C.c_double
+    loss = lib().gfn_o_s3im(_p(a), _p(b), _p(index), C.c_int64(index.size), C.c_int(patch_h), _p(d), C.c_int64(a.shape[0]))
+    return float(loss), d
+
+
 def charbonnier(pred, gt, eps=1e-6):
     pred, gt = _f32(pred), _f32(gt)
     d = np.zeros_like(pred)

@@ -64,13 +64,17 @@ def render(P, rays_o, rays_d_raw, cam_idx, noise, log2_T, block=None, early_T=0.
 
 
 def loss_and_grads(P, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, log2_T, block=None, train_mlp=True, use_emb=True,
-                   **sampler_kw):
+                   s3im_index=None, s3im_mult=1.0, **sampler_kw):
     """Charbonnier loss (nerfacto.py:636) and every parameter gradient, by hand-written backward
     of the same pieces (reference: autograd + Hash3DAnchoredFunction::backward)."""
     m = sample(P, rays_o, rays_d_raw, noise, **sampler_kw)
     f = field_forward(P, m, cam_idx, log2_T, block, use_emb=use_emb)
     comp = O.composite_fwd(m["pts_offsets"], f["sigma"], m["dists"], m["ts"], f["rgb"])
     loss, g_rgb = O.charbonnier(comp["rgb"], gt_rgb)
+    if s3im_index is not None:  # + s3im_loss_mult * S3IM(image, rgb) (nerfacto.py:687-688, config.py:96)
+        l2, g2 = O.s3im(gt_rgb, comp["rgb"], s3im_index, patch_h=32)
+        loss = loss + s3im_mult * l2
+        g_rgb = (g_rgb + np.float32(s3im_mult) * g2).astype(np.float32)
     d_sigma, d_rgb = O.composite_bwd(m["pts_offsets"], f["sigma"], m["dists"], f["rgb"], g_rgb, None)
     (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = P["layers"]
     grads = {}

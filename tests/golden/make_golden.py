@@ -42,6 +42,9 @@ def _install_stubs():
     stub("nerfacc", ContractionType=_CT)
     stub("wandb")
     stub("torch.utils.tensorboard", SummaryWriter=object)
+    # cameras.py imports cv2 / torchvision for Cameras.to_json (JPEG thumbnails) only; generate_rays never touches them
+    for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        stub(name)
 
 
 def gen_mlp(out):
@@ -185,13 +188,88 @@ def gen_adam(out):
     out["adam_p3"] = p.detach().numpy()
 
 
+def gen_rays(out):
+    """Cameras.generate_rays (cameras.py:560-734, perspective, no distortion) incl. GF's
+    lookat_directions (:704) -- random poses, explicit (camera, pixel) pairs like the pixel sampler produces and a
+    row of full-image coordinates (get_image_coords, pixel_offset 0.5) like render.py:109 uses."""
+    from nerfstudio.cameras.cameras import Cameras, CameraType
+
+    rng = np.random.default_rng(21)
+    n_cams = 5
+    c2w = np.zeros((n_cams, 3, 4), np.float32)
+    for i in range(n_cams):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        c2w[i, :, :3] = q * np.sign(np.linalg.det(q))
+        c2w[i, :, 3] = rng.uniform(-40, 40, 3)
+    fx = rng.uniform(800, 1200, n_cams).astype(np.float32); fy = rng.uniform(800, 1200, n_cams).astype(np.float32)
+    cx = rng.uniform(500, 650, n_cams).astype(np.float32); cy = rng.uniform(380, 480, n_cams).astype(np.float32)
+    cams = Cameras(camera_to_worlds=torch.from_numpy(c2w), fx=torch.from_numpy(fx), fy=torch.from_numpy(fy), cx=torch.from_numpy(cx),
+                   cy=torch.from_numpy(cy), width=1152, height=864, camera_type=CameraType.PERSPECTIVE)
+    n = 600
+    cam_idx = rng.integers(0, n_cams, n)
+    coords = np.stack([rng.integers(0, 864, n) + 0.5, rng.integers(0, 1152, n) + 0.5], -1).astype(np.float32)  # (y, x)
+    coords[:40] = np.stack([rng.uniform(0, 864, 40), rng.uniform(0, 1152, 40)], -1)  # sub-pixel positions too
+    rb = cams.generate_rays(camera_indices=torch.from_numpy(cam_idx)[:, None], coords=torch.from_numpy(coords))
+    out["rays_c2w"] = c2w; out["rays_intr"] = np.stack([fx, fy, cx, cy], -1)
+    out["rays_cam_idx"] = cam_idx.astype(np.int32); out["rays_coords"] = coords
+    out["rays_origins"] = rb.origins.numpy(); out["rays_directions"] = rb.directions.numpy()
+    out["rays_pixel_area"] = rb.pixel_area.numpy(); out["rays_lookat"] = rb.lookat_directions.numpy()
+    out["rays_dir_norm"] = rb.metadata["directions_norm"].numpy()
+    # one image row through the camera-level entry point render.py uses
+    full = cams.generate_rays(camera_indices=2)
+    out["rays_row_directions"] = full.directions[431].numpy()  # [W,3], row y = 431
+    out["rays_row_pixel_area"] = full.pixel_area[431].numpy()
+
+
+def gen_scheduler(out):
+    """GFNerfExponentialDecayScheduler (engine/schedulers.py:113-184) LR multiplier curve as configured
+    by gfnerf/config.py:135 (lr_final 1e-4, max_steps = steps_perssampler_init), through torch's LambdaLR."""
+    from nerfstudio.engine.schedulers import GFNerfExponentialDecayScheduler, GFNerfExponentialDecaySchedulerConfig
+
+    cfgs = dict(default=dict(lr_final=1e-4, max_steps=300, n_split_dataset=4, steps_per_split_dataset=100, steps_perssampler_init=300),
+                warm=dict(lr_final=1e-4, max_steps=200, warmup_steps=40, n_split_dataset=3, steps_per_split_dataset=80,
+                          steps_perssampler_init=150))
+    for tag, kw in cfgs.items():
+        conf = GFNerfExponentialDecaySchedulerConfig(**kw)
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-2)
+        sched = GFNerfExponentialDecayScheduler(conf).get_scheduler(opt, 1e-2)
+        lrs = []
+        for _ in range(900):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step(); sched.step()
+        out[f"sched_{tag}_lr"] = np.asarray(lrs, np.float64)
+        out[f"sched_{tag}_cfg"] = np.asarray([kw.get("lr_final"), kw.get("max_steps"), kw.get("warmup_steps", 0), kw["n_split_dataset"],
+                                              kw["steps_per_split_dataset"], kw["steps_perssampler_init"]], np.float64)
+
+
+def gen_s3im(out):
+    """S3IM (losses.py:713-794) as configured by gfnerf/config.py:96-100 (kernel 4, stride 4, 10 repeats,
+    virtual patch height 32) and called by get_loss_dict (nerfacto.py:688): s3im_loss(image, outputs["rgb"]).
+    The 9 random permutations are re-drawn from the same seed so the fixture carries the index vector."""
+    from nerfstudio.model_components.losses import S3IM
+
+    R = 256
+    torch.manual_seed(31)
+    image = torch.rand(R, 3)
+    pred = (image + 0.1 * torch.randn(R, 3)).clamp(0, 1).requires_grad_(True)
+    crit = S3IM(s3im_kernel_size=4, s3im_stride=4, s3im_repeat_time=10, s3im_patch_height=32)
+    torch.manual_seed(77)
+    loss = crit(image, pred)
+    loss.backward()
+    torch.manual_seed(77)
+    idx = torch.cat([torch.arange(R)] + [torch.randperm(R) for _ in range(9)])
+    out["s3im_image"] = image.numpy(); out["s3im_pred"] = pred.detach().numpy(); out["s3im_index"] = idx.numpy().astype(np.int32)
+    out["s3im_loss"] = np.asarray(loss.item(), np.float64); out["s3im_gpred"] = pred.grad.numpy()
+
+
 def main():
     assert os.path.isdir(REF), "reference tree not mounted; fixtures can only be regenerated in the build container"
     _install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(1)
     out = {}
-    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam):
+    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam, gen_rays, gen_scheduler, gen_s3im):
         fn(out)
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)

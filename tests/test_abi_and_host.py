@@ -113,3 +113,27 @@ def test_primes_are_prime_and_in_range():
     small = [q for q in range(2, 1 << 15) if all(q % r for r in range(2, int(q ** 0.5) + 1))]
     for v in flat:
         assert all(v % q for q in small if q * q <= v)
+
+
+def test_gf_scheduler_matches_reference_curve(golden):
+    """Product scheduler (host logic) against the LR curve captured from the reference's LambdaLR."""
+    import torch
+
+    import gfnerf_amd
+    from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig, lr_multiplier
+
+    for tag in ("default", "warm"):
+        lr_final, max_steps, warm, n_split, per_split, init = golden[f"sched_{tag}_cfg"]
+        cfg = GFNerfExponentialDecaySchedulerConfig(lr_final=float(lr_final), max_steps=int(max_steps), warmup_steps=int(warm),
+                                                    n_split_dataset=int(n_split), steps_per_split_dataset=int(per_split),
+                                                    steps_perssampler_init=int(init))
+        want = golden[f"sched_{tag}_lr"]
+        got = [1e-2 * lr_multiplier(s, 1e-2, cfg) for s in range(want.shape[0])]
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+        # and through the same LambdaLR wiring the reference uses
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-2)
+        sched = cfg.setup().get_scheduler(opt, 1e-2)
+        for s in range(120):
+            assert abs(opt.param_groups[0]["lr"] - want[s]) <= 1e-12 * want[s]
+            opt.step(); sched.step()

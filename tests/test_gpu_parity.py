@@ -594,3 +594,43 @@ def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid):
     mag = (np.abs(dz[:n, :m_valid]).astype(np.float64).T @ np.abs(a[:n, :k_valid]).astype(np.float64)).max()
     assert np.abs(got - want).max() < 2e-6 * mag, (np.abs(got - want).max(), mag)
     np.testing.assert_allclose(db.cpu().numpy(), dz[:n, :m_valid].astype(np.float64).sum(0), rtol=1e-4, atol=2e-6 * np.abs(dz[:n]).sum(0).max())
+
+
+def test_generate_rays_matches_golden_and_oracle(oracle, ops, dev, golden):
+    """gfn_generate_rays against the vectors captured from the reference's Cameras.generate_rays, explicit and raster mode."""
+    import torch
+
+    g = golden
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    c2w, intr = t(g["rays_c2w"]), t(g["rays_intr"])
+    r = ops.generate_rays(c2w, intr, cam_idx=t(g["rays_cam_idx"]), coords=t(g["rays_coords"]))
+    assert np.array_equal(r["origins"].cpu().numpy(), g["rays_origins"]) and np.array_equal(r["lookat"].cpu().numpy(), g["rays_lookat"])
+    np.testing.assert_allclose(r["directions"].cpu().numpy(), g["rays_directions"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(r["dir_norm"].cpu().numpy(), g["rays_dir_norm"][:, 0], rtol=2e-7)
+    o = oracle.generate_rays(g["rays_c2w"], g["rays_intr"], g["rays_cam_idx"], g["rays_coords"])
+    np.testing.assert_allclose(r["pixel_area"].cpu().numpy(), o["pixel_area"], rtol=1e-3)
+    np.testing.assert_allclose(r["pixel_area"].cpu().numpy(), g["rays_pixel_area"][:, 0], rtol=2e-3)
+    # raster mode: row 431 of camera 2's 1152-wide image
+    W = g["rays_row_directions"].shape[0]
+    row = ops.generate_rays(c2w, intr, cam0=2, first_pixel=431 * W, width=W, n=W)
+    np.testing.assert_allclose(row["directions"].cpu().numpy(), g["rays_row_directions"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(row["pixel_area"].cpu().numpy(), g["rays_row_pixel_area"][:, 0], rtol=2e-3)
+
+
+def test_s3im_matches_golden(ops, dev, golden):
+    """gfn_s3im (loss + gradient, accumulating) against the reference's S3IM + autograd."""
+    import torch
+
+    g = golden
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    loss, grad = ops.s3im(t(g["s3im_image"]), t(g["s3im_pred"]), t(g["s3im_index"]), patch_h=32)
+    np.testing.assert_allclose(loss.item(), float(g["s3im_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["s3im_gpred"], rtol=2e-3, atol=2e-6)
+    # accumulation semantics: loss += mult * s3im, g_pred += mult * grad
+    base_loss = torch.full((1,), 0.25, device=dev); base_g = torch.ones_like(grad)
+    ops.s3im(t(g["s3im_image"]), t(g["s3im_pred"]), t(g["s3im_index"]), patch_h=32, mult=0.5, loss=base_loss, g_pred=base_g)
+    np.testing.assert_allclose(base_loss.item(), 0.25 + 0.5 * float(g["s3im_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(base_g.cpu().numpy(), 1.0 + 0.5 * g["s3im_gpred"], rtol=1e-5, atol=1e-6)
+    idx = ops.s3im_index(256, 10, device=dev)
+    assert idx.shape == (2560,) and idx.dtype == torch.int32 and torch.equal(idx[:256].cpu(), torch.arange(256, dtype=torch.int32))
+    assert all(sorted(idx[256 * k: 256 * (k + 1)].cpu().tolist()) == list(range(256)) for k in range(1, 10))

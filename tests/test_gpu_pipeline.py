@@ -138,9 +138,15 @@ def test_training_gradients_match_oracle(setup, stage):
     S = setup
     hp, t = S["hp"], S["t"]
     block = 0 if stage == "focal" else None
-    loss, aux = hp.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage=stage, block=block)
+    # Charbonnier + 1.0 * S3IM (gfnerf/config.py:96, nerfacto.py:636,687-688) with an explicit permutation index
+    R = S["o"].shape[0]
+    rng = np.random.default_rng(17)
+    s3 = np.concatenate([np.arange(R)] + [rng.permutation(R) for _ in range(9)]).astype(np.int32)
+    loss, aux = hp.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage=stage, block=block,
+                                    s3im_index=t(s3))
     ref_loss, g, ref_aux = S["opipe"].loss_and_grads(S["P"], S["o"], S["d"], S["cam"], S["gt"], S["noise"], S["cfg"].log2_T,
-                                                      block=block)
+                                                      block=block, s3im_index=s3, s3im_mult=hp.cfg.s3im_loss_mult)
+    assert hp.cfg.s3im_loss_mult == 1.0
     np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
     tg, tg_ref = hp.table_grad.cpu().numpy(), g["table"]
     assert (tg_ref != 0).sum() > 1000
@@ -165,12 +171,14 @@ def test_training_f16_gradient_pool(setup):
     S = setup
     t = S["t"]
     hp32 = S["hp"]
-    hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global")
+    from gfnerf_amd import ops
+    s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")  # the same permutations in both runs
+    hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global", s3im_index=s3)
     ref = hp32.table_grad.cpu().numpy()
     old = hp32.cfg.grad_f16
     try:
         hp32.cfg.grad_f16, hp32.table_grad = True, None
-        hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global")
+        hp32.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="global", s3im_index=s3)
         got = hp32.table_grad.float().cpu().numpy() / 128.0
     finally:
         hp32.cfg.grad_f16, hp32.table_grad = old, None
