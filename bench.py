@@ -41,8 +41,10 @@ def parse():
     ap.add_argument("--log2-T", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
-    ap.add_argument("--cpu-rays", type=int, default=96, help="rays in the bounded cpu_baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the bounded cpu_baseline sample")
     ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
+    ap.add_argument("--render-frames", type=int, default=2,
+                    help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     ap.add_argument("--share-block-primes", action="store_true",
@@ -86,6 +88,34 @@ def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     return dict(value=n_rays / dt, unit="rays/s", cores=os.cpu_count(), kind="port",
                 sample=f"{n_rays} rays ({n_samples} samples) of the same batch, oracle fwd+bwd (no Adam), {dt:.1f} s; "
                        "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
+
+
+def render_bench(hp, sc, args, fineness, torch):
+    """BASELINE configs[4]: full-res camera-path pass, 1920x1080, hipGraph-captured per-tile inference (eval-mode ray
+    march: noise = ones * fineness; same fineness as the training batches).  Untimed: graph capture + one warm-up frame."""
+    from gfnerf_amd import render as rmod
+
+    H, W = 1080, 1920
+    c2w = torch.from_numpy(sc["c2w"]).cuda()
+    K = sc["intri"]
+    zoom = W / 1152.0  # the synthetic capture's 1152-wide intrinsics scaled to the output width
+    intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
+                            .astype(np.float32)).cuda()
+    block = 0 if (args.stage == "focal" and hp.blocks) else None
+    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=N_RAYS, block=block, fineness=fineness, use_graph=True)
+    n_cams = c2w.shape[0]
+    tr.render_camera(0, H, W)  # capture + warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(args.render_frames):
+        img = tr.render_camera((37 * (f + 1)) % n_cams, H, W)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mpix = args.render_frames * H * W / 1e6
+    return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=args.render_frames, frame=f"{W}x{H}",
+                ms_per_frame=dt * 1e3 / args.render_frames, rays_per_sec=args.render_frames * H * W / dt, tile_rays=N_RAYS, hipgraph=True,
+                table="global + focal block 0" if block is not None else "global", fineness=fineness,
+                mean_accumulation=float(img["accumulation"].mean().item()))
 
 
 def main():
@@ -228,6 +258,8 @@ def main():
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
                                scene_build_s=round(t_build, 1), loss=float(loss.item())),
                    roofline=roofline)
+        if args.render_frames > 0:
+            out["render"] = render_bench(hp, sc, args, fineness, torch)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
                                                0 if args.stage == "focal" else None, scene)

@@ -1,0 +1,108 @@
+"""Full-image inference: Model.get_outputs_for_camera_ray_bundle (nerfstudio/models/base_model.py:163-186) as
+scripts/render.py drives it (:109-120), for the GF-NeRF hot path.
+
+The reference loops over chunks of eval_num_rays_per_chunk = 2048 rays (gfnerf/config.py:109) and runs the whole Python
+model per chunk: 1013 forwards per 1920x1080 frame, each with several host synchronisations.  Here the rays of the frame
+come from one gfn_generate_rays launch, a tile of `tile_rays` rays runs sampler -> hash -> decoder -> compositing with
+the live sample count on the device (no synchronisation), and that per-tile launch sequence is captured ONCE in a
+hipGraph (torch.cuda.CUDAGraph) over static tile buffers and replayed for every tile.  Frames shard over ranks
+(frame_shard) with one gather of the finished images at the end -- rays are independent, nothing else is exchanged.
+"""
+import torch
+
+from . import ops
+
+
+def frame_shard(n_frames, world_size, rank):
+    """Frames of a camera path rendered by `rank` (round robin: neighbouring frames cost about the same)."""
+    return list(range(rank, n_frames, world_size))
+
+
+class TileRenderer:
+    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True):
+        """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
+        cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
+        validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
+        self.hp, self.c2w, self.intr = hp, c2w.contiguous(), intr.contiguous()
+        self.T, self.block, self.early_T = int(tile_rays), block, early_T
+        dev = hp.dev
+        self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + self.T + 10,), float(fineness), dtype=torch.float32, device=dev)
+        self.o = torch.zeros((self.T, 3), dtype=torch.float32, device=dev)
+        self.d = torch.zeros((self.T, 3), dtype=torch.float32, device=dev)
+        self.d[:, 2] = -1.0
+        self.cam = torch.zeros(self.T, dtype=torch.int32, device=dev)
+        self.graph, self.out = None, None
+        self.use_graph = use_graph
+
+    def _tile(self):
+        out = self.hp.render(self.o, self.d, self.cam, self.noise, block=self.block, early_T=self.early_T)
+        return out["rgb"], out["accumulation"], out["depth"]
+
+    def _capture(self):
+        """Warm up on a side stream (workspaces, kernel attributes, weight images), then capture one tile."""
+        s = torch.cuda.Stream(device=self.hp.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._tile()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._tile()
+
+    @torch.no_grad()
+    def render_camera(self, cam, height, width, embed_idx=None):
+        """One image of camera `cam` -> dict(rgb [H,W,3], accumulation [H,W], depth [H,W]) on the device.
+        embed_idx: appearance-embedding row (render.py --embedding-indices); default = the camera's own index."""
+        hp, T = self.hp, self.T
+        n = height * width
+        rays = ops.generate_rays(self.c2w, self.intr, cam0=int(cam), first_pixel=0, width=int(width), n=n, want_extras=False)
+        O, D = rays["origins"], rays["directions"]
+        self.cam.fill_(int(cam if embed_idx is None else embed_idx))
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=hp.dev)
+        acc = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
+        depth = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
+        if self.use_graph and self.graph is None:
+            self.o.copy_(O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))
+            self.d.copy_(D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))
+            self._capture()
+        for a in range(0, n, T):
+            b = min(a + T, n)
+            m = b - a
+            self.o[:m].copy_(O[a:b]); self.d[:m].copy_(D[a:b])
+            if m < T:  # ragged last tile: repeat the last ray, its outputs are dropped
+                self.o[m:].copy_(O[b - 1:b].expand(T - m, 3)); self.d[m:].copy_(D[b - 1:b].expand(T - m, 3))
+            if self.use_graph:
+                self.graph.replay()
+                t_rgb, t_acc, t_depth = self.out
+            else:
+                t_rgb, t_acc, t_depth = self._tile()
+            rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
+        return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width), depth=depth.view(height, width))
+
+    def render_path(self, cams, height, width, world_size=1, rank=0):
+        """Camera path sharded over ranks by frame -> {frame index: outputs} of this rank's frames."""
+        return {f: self.render_camera(cams[f], height, width) for f in frame_shard(len(cams), world_size, rank)}
+
+
+def gather_frames(local, n_frames, height, width, dst=0):
+    """Collect every rank's rgb frames on `dst` -> [n_frames,H,W,3] (None elsewhere).  One collective per path."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return torch.stack([local[f]["rgb"] for f in range(n_frames)])
+    w, r = dist.get_world_size(), dist.get_rank()
+    dev = next(iter(local.values()))["rgb"].device if local else torch.device("cpu")
+    per = (n_frames + w - 1) // w
+    mine = torch.zeros((per, height, width, 3), dtype=torch.float32, device=dev)
+    for k, f in enumerate(frame_shard(n_frames, w, r)):
+        mine[k] = local[f]["rgb"]
+    bufs = [torch.empty_like(mine) for _ in range(w)] if r == dst else None
+    dist.gather(mine, bufs, dst=dst)
+    if r != dst:
+        return None
+    out = torch.empty((n_frames, height, width, 3), dtype=torch.float32, device=dev)
+    for rr in range(w):
+        for k, f in enumerate(frame_shard(n_frames, w, rr)):
+            out[f] = bufs[rr][k]
+    return out
