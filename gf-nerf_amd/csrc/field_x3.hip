@@ -18,41 +18,10 @@
 // every workgroup (146 KiB forward, 112 KiB backward; 512 threads = two waves per SIMD so one
 // wave's split/ReLU VALU work overlaps the other's MFMAs).
 #include "gfn_common.h"
+#include "x3_device.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using h8 = __attribute__((ext_vector_type(8))) _Float16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-
-constexpr int FWD_CHUNKS = 72, BWD_CHUNKS = 64, FWD_BIAS = 448;
-static_assert(GFN_FIELD_X3_FWD_BYTES == FWD_CHUNKS * 2048 + FWD_BIAS * 4, "forward image size");
-static_assert(GFN_FIELD_X3_BWD_BYTES == BWD_CHUNKS * 2048, "backward image size");
-static_assert(GFN_FIELD_X3_FWD_BYTES <= 160 * 1024, "forward LDS image must fit one CU");
-
-// forward chunk bases
-constexpr int C_B0 = 0;    // base L1: [u 2][ot 4]
-constexpr int C_B1 = 8;    // base L2: [u 8]
-constexpr int C_H0 = 16;   // head L1: [u 4][ot 4]   u0 = geo rows of the base tile, u1 = SH, u2,u3 = appearance
-constexpr int C_H1 = 32;   // head L2: [u 8][ot 4]
-constexpr int C_H2 = 64;   // head L3: [u 8]
-// backward chunk bases (A = W^T: rows = layer inputs, k = layer outputs)
-constexpr int D_G3 = 0;    // d c2 = hW2^T dz3 : [it 4]
-constexpr int D_G2 = 4;    // d c1 = hW1^T dz2 : [u 8][it 4]
-constexpr int D_G1 = 36;   // d h[1:16] = hW0[:,16:31]^T dz1 : [u 8]
-constexpr int D_GB1 = 44;  // d a1 = bW1^T dh : [it 4]
-constexpr int D_GB0 = 48;  // d feat = bW0^T dz : [u 8]
-constexpr int D_GE = 56;   // d appearance = hW0[:,31:63]^T dz1 : [u 8]   (global stage only)
-// split-f16 planes kept for the weight gradients (global stage): one hi and one lo' buffer of cap * LD f16 each,
-// PLANE-MAJOR: the plane with first column C and width W is the contiguous array [cap][W] at element offset cap * C
-// (so gfn_wgrad_x3 streams whole 128-byte lines).  Columns:
-constexpr int FP_LD = GFN_FIELD_X3_FWD_PLANE_LD;   // feat 0..31 | a1 32..159 | xp 160..223 | c1 224..351 | c2 352..479
-constexpr int FP_FEAT = 0, FP_A1 = 32, FP_XP = 160, FP_C1 = 224, FP_C2 = 352;
-constexpr int BP_LD = GFN_FIELD_X3_BWD_PLANE_LD;   // dz3 0..7 | dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407
-constexpr int BP_DZ3 = 0, BP_DH = 8, BP_DZ2 = 24, BP_DZ1 = 152, BP_DZA1 = 280;
-static_assert(FP_LD == 480 && BP_LD == 408, "plane row widths");
-
-__device__ __forceinline__ int acc_row(int t, int s, int h, int i) { return 32 * t + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
 
 struct FieldWeights {
   const float* bW0; const float* bb0; const float* bW1; const float* bb1; const float* hW0; const float* hb0;
@@ -81,13 +50,6 @@ __device__ float bwd_weight(const FieldWeights& w, int c, int h, int r, int i) {
   if (c < D_GE) { const int u = c - D_GB0; return w.bW0[acc_row(u >> 1, u & 1, h, i) * 32 + r]; }
   const int u = c - D_GE;
   return w.hW0[acc_row(u >> 1, u & 1, h, i) * 63 + 31 + r];
-}
-
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-  const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // round toward zero: saturates at 65504, never rounds to inf
-  const float r0 = (x0 - (float)hv[0]) * 2048.f, r1 = (x1 - (float)hv[1]) * 2048.f;  // exact
-  hi = __builtin_bit_cast(uint32_t, hv);
-  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 
 // one thread per (chunk, lane): 8 weights -> 16 B of the hi image and 16 B of the lo image
@@ -132,100 +94,6 @@ __global__ void field_pack_x3_kernel(FieldWeights w, u32x4* __restrict__ fwd, u3
   }
 }
 
-struct Acc2 {
-  f32x16 m, c;
-};
-
-__device__ __forceinline__ void mma3(Acc2& a, const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, int chunk, int lane,
-                                     const u32x4& bhi, const u32x4& blo) {
-  const h8 ah = __builtin_bit_cast(h8, Ihi[chunk * 64 + lane]);
-  const h8 al = __builtin_bit_cast(h8, Ilo[chunk * 64 + lane]);
-  const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
-  a.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a.m, 0, 0, 0);
-  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a.c, 0, 0, 0);
-  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a.c, 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting every later operand read (register blow-up)
-}
-
-__device__ __forceinline__ void acc_init_bias(Acc2& a, const float* __restrict__ bias, int ot, int h) {
-#pragma unroll
-  for (int g = 0; g < 4; g++) {  // registers 4g..4g+3 = rows 32ot + 8g + 4h + 0..3
-    const float4 b = *reinterpret_cast<const float4*>(bias + 32 * ot + 8 * g + 4 * h);
-    a.m[4 * g] = b.x; a.m[4 * g + 1] = b.y; a.m[4 * g + 2] = b.z; a.m[4 * g + 3] = b.w;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; r++) a.c[r] = 0.f;
-}
-__device__ __forceinline__ void acc_init_zero(Acc2& a) {
-#pragma unroll
-  for (int r = 0; r < 16; r++) { a.m[r] = 0.f; a.c[r] = 0.f; }
-}
-__device__ __forceinline__ float acc_get(const Acc2& a, int r) { return __builtin_fmaf(a.c[r], 0x1p-11f, a.m[r]); }
-
-// a finished tile -> (ReLU, mask bits,) the two k-step fragments of the next layer
-struct Frag {
-  u32x4 hi[2], lo[2];
-};
-template <bool RELU>
-__device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t) {
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    v[r] = acc_get(a, r);
-    if (RELU) {
-      const bool on = v[r] > 0.f;
-      v[r] = on ? v[r] : 0.f;
-      mask |= (unsigned long long)on << (t * 16 + r);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      uint32_t a_, b_;
-      split2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1], a_, b_);
-      f.hi[s][p] = a_; f.lo[s][p] = b_;
-    }
-}
-__device__ __forceinline__ void split8(const float* x, u32x4& hi, u32x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    uint32_t a_, b_;
-    split2(x[2 * p], x[2 * p + 1], a_, b_);
-    hi[p] = a_; lo[p] = b_;
-  }
-}
-__device__ __forceinline__ void load8(const float* p, float* x) {
-  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-}
-
-// a tile's two fragments -> columns col0 .. col0+31 of this sample's plane rows (registers 8s+4g..+3 = rows 16s+8g+4h..+3)
-__device__ __forceinline__ void store_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const Frag& f, int h) {
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-      *reinterpret_cast<uint2*>(row_hi + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.hi[s][2 * g], f.hi[s][2 * g + 1]);
-      *reinterpret_cast<uint2*>(row_lo + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.lo[s][2 * g], f.lo[s][2 * g + 1]);
-    }
-}
-// the first k-step of a tile (rows 0..15) -> 16 columns
-__device__ __forceinline__ void store_half_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
-                                                const u32x4& fl, int h) {
-#pragma unroll
-  for (int g = 0; g < 2; g++) {
-    *reinterpret_cast<uint2*>(row_hi + col0 + 8 * g + 4 * h) = make_uint2(fh[2 * g], fh[2 * g + 1]);
-    *reinterpret_cast<uint2*>(row_lo + col0 + 8 * g + 4 * h) = make_uint2(fl[2 * g], fl[2 * g + 1]);
-  }
-}
-// a natural-order fragment (k = 8h + i) -> 16 columns
-__device__ __forceinline__ void store_nat(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
-                                          const u32x4& fl, int h) {
-  *reinterpret_cast<u32x4*>(row_hi + col0 + 8 * h) = fh;
-  *reinterpret_cast<u32x4*>(row_lo + col0 + 8 * h) = fl;
-}
-
 template <bool SAVE, bool PLANES>
 __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
@@ -239,8 +107,6 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + FWD_CHUNKS * 64;
   const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
-  const float* Bb0 = bias; const float* Bb1 = bias + 128; const float* Bh0 = bias + 160; const float* Bh1 = bias + 288; const float* Bh2 = bias + 416;
-
   const int64_t n = gfn_live_n(n_max, n_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, j = lane & 31;
@@ -249,135 +115,30 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const int64_t s = tile * 32 + j;
     const bool valid = s < n;
     const int64_t q = valid ? s : n - 1;
-    // plane-major buffers: plane P (width W, first column C) is the contiguous array [cap][W] at element offset cap * C;
-    // invalid lanes rewrite the last live row with the same values
-#define FPL(half, C, W) (planes_##half + cap * (C) + q * (W))
-    // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
+    // ---- k-step u of the feature row: columns 16u + 8h + i (invalid lanes rewrite the last live row with the same values)
     u32x4 xh[2], xl[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       float x[8];
       load8(feat + q * 32 + 16 * u + 8 * h, x);
       split8(x, xh[u], xl[u]);
-      if (PLANES) store_nat(FPL(hi, FP_FEAT, 32), FPL(lo, FP_FEAT, 32), 16 * u, xh[u], xl[u], h);
+      if (PLANES) store_nat(planes_hi + cap * FP_FEAT + q * 32, planes_lo + cap * FP_FEAT + q * 32, 16 * u, xh[u], xl[u], h);
     }
-    Frag a1[4];
-    unsigned long long m_a1 = 0;
-#pragma unroll
-    for (int ot = 0; ot < 4; ot++) {
-      Acc2 a;
-      acc_init_bias(a, Bb0, ot, h);
-#pragma unroll
-      for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
-      tile_to_frag<true>(a, a1[ot], m_a1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_A1, 128), FPL(lo, FP_A1, 128), 32 * ot, a1[ot], h);
-    }
-    // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
-    Acc2 hh;
-    acc_init_bias(hh, Bb1, 0, h);
-#pragma unroll
-    for (int u = 0; u < 8; u++) mma3(hh, Ihi, Ilo, C_B1 + u, lane, a1[u >> 1].hi[u & 1], a1[u >> 1].lo[u & 1]);
-    const float h0v = acc_get(hh, 0);  // row 0 = density channel: register 0 of the h=0 lanes
-    if (valid && h == 0) {
-      sigma[s] = expf(h0v + 1.0f);  // trunc_exp(h0 + 1), nerfacto_field.py:499
-      if (SAVE) h0_out[s] = h0v;
-    }
-    u32x4 gh, gl;  // rows 0..15 of the tile = k-step 0 (row 0 meets zero weights)
-    {
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
-      split8(v, gh, gl);
-      if (PLANES) store_half_tile(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 0, gh, gl, h);
-    }
-    // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
     const int ray = ray_id[q];
-    u32x4 sh_h, sh_l, e_h[2], e_l[2];
-    {
-      float x[8];
-      load8(sh + (int64_t)ray * 16 + 8 * h, x);
-      split8(x, sh_h, sh_l);
-      if (emb) {
-        const float* ep = emb + (int64_t)cam_idx[ray] * 32;
-#pragma unroll
-        for (int u = 0; u < 2; u++) { load8(ep + 16 * u + 8 * h, x); split8(x, e_h[u], e_l[u]); }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-          for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
-      }
-      if (PLANES) {
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 16, sh_h, sh_l, h);
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 32, e_h[0], e_l[0], h);
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 48, e_h[1], e_l[1], h);
-      }
-    }
-    Frag c1[4];
-    unsigned long long m_c1 = 0;
-#pragma unroll
-    for (int ot = 0; ot < 4; ot++) {
-      Acc2 a;
-      acc_init_bias(a, Bh0, ot, h);
-      mma3(a, Ihi, Ilo, C_H0 + 0 * 4 + ot, lane, gh, gl);
-      mma3(a, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, sh_h, sh_l);
-      mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
-      mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
-      tile_to_frag<true>(a, c1[ot], m_c1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C1, 128), FPL(lo, FP_C1, 128), 32 * ot, c1[ot], h);
-    }
-    // ---- head layer 2: 128 -> 128, ReLU
-    Frag c2[4];
-    unsigned long long m_c2 = 0;
-#pragma unroll
-    for (int ot = 0; ot < 4; ot++) {
-      Acc2 a;
-      acc_init_bias(a, Bh1, ot, h);
-#pragma unroll
-      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
-      tile_to_frag<true>(a, c2[ot], m_c2, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C2, 128), FPL(lo, FP_C2, 128), 32 * ot, c2[ot], h);
-    }
-    // ---- head layer 3: 128 -> 3 (padded), sigmoid
-    Acc2 o3;
-    acc_init_bias(o3, Bh2, 0, h);
-#pragma unroll
-    for (int u = 0; u < 8; u++) mma3(o3, Ihi, Ilo, C_H2 + u, lane, c2[u >> 1].hi[u & 1], c2[u >> 1].lo[u & 1]);
+    const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh + (int64_t)ray * 16,
+                                              emb ? emb + (int64_t)cam_idx[ray] * 32 : nullptr, planes_hi, planes_lo, cap, q);
     if (valid) {
-      if (h == 0) {  // rows 0..2 = registers 0..2 of the h=0 lanes
-        rgb[3 * s] = 1.f / (1.f + expf(-acc_get(o3, 0)));
-        rgb[3 * s + 1] = 1.f / (1.f + expf(-acc_get(o3, 1)));
-        rgb[3 * s + 2] = 1.f / (1.f + expf(-acc_get(o3, 2)));
+      if (h == 0) {
+        sigma[s] = o.sigma;
+        if (SAVE) h0_out[s] = o.h0;
+        rgb[3 * s] = o.r; rgb[3 * s + 1] = o.g; rgb[3 * s + 2] = o.b;
       }
       if (SAVE) {
         unsigned long long* mp = masks + s * 6 + h;
-        mp[0] = m_a1; mp[2] = m_c1; mp[4] = m_c2;
+        mp[0] = o.m_a1; mp[2] = o.m_c1; mp[4] = o.m_c2;
       }
     }
   }
-#undef FPL
-}
-
-template <bool RELU_MASK>
-__device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t) {
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    v[r] = acc_get(a, r);
-    if (RELU_MASK) v[r] = ((mask >> (t * 16 + r)) & 1ull) ? v[r] : 0.f;  // ReLU'
-  }
-#pragma unroll
-  for (int s = 0; s < 2; s++) split8(v + 8 * s, f.hi[s], f.lo[s]);
-}
-
-// Sum v over the lanes [lane, run_end] of this 32-lane half (runs = consecutive samples of one ray).
-__device__ __forceinline__ float half_run_sum(float v, int j, int run_end) {
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const float u = __shfl_down(v, off, 32);
-    if (j + off <= run_end) v += u;
-  }
-  return v;
 }
 
 // PLANES = false: the focal stage (decoder frozen): d feat only, per-sample gradient scale.

@@ -1,0 +1,244 @@
+// fused_fwd.hip -- the forward of GFNeRFModel.get_outputs after the sampler, in ONE persistent kernel:
+// Hash3DAnchored lookup (+ the focal stage's residual table) -> base_network -> density / head input ->
+// mlp_head -> front-to-back compositing WITH early termination (gfnerf/nerfacto.py:531-547,
+// nerfacto_field.py:412-591, rays.py:178-200, renderers.py:69-283).
+//
+// Why one kernel: the lookup is bound by the L2-miss request rate of the memory fabric (DESIGN.md section 4:
+// 57 G requests/s whatever the kernel does), the decoder by the matrix pipe -- different resources, so the decoder's
+// MFMAs run for free beside the gathers of the other waves of the CU; and a ray that has become opaque stops costing
+// gathers: a wave walks ITS ray front to back in 32-sample tiles and leaves the ray as soon as the transmittance is
+// below early_T (the separate kernels look up and decode every sample, then discard).  Nothing but sigma / rgb / h0 /
+// ReLU masks (what the backward needs) leaves the chip: the [N,32] feature tensor is never written.
+//
+// A wave (64 lanes) owns a tile of 32 consecutive samples of one ray: lane (h, j) gathers 8 of sample j's 16 levels --
+// exactly the 16 features that lane holds as B operand of the first layer (k-step u: features 16u + 8h + i =
+// levels 8u + 4h + i/2) -- then runs decoder_tile (x3_device.h), then the lower half composites the 32 samples with a
+// wave scan.  Rays are handed out through an atomic counter (rays differ 100x in length).  Samples behind the
+// termination point get sigma = rgb = weight = alpha = 0 so that the unchanged backward kernels see no gradient there.
+#include "gfn_common.h"
+#include "hash_device.h"
+#include "x3_device.h"
+
+namespace {
+
+struct FusedArgs {
+  const int* pts_offsets; int n_rays;
+  const float* pts; const int* anchors; const float* dt; const float* ts;
+  const void* table_a; const void* table_b; const int* prim_a; const int* prim_b; const float* bias_pool;
+  int64_t n_volumes; int log2_T;
+  const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
+  float early_T;
+  float* sigma; float* rgb; float* h0; unsigned long long* masks; float* weights; float* alphas; float* feat;
+  uint16_t* planes_hi; uint16_t* planes_lo; int64_t cap;
+  float* out_rgb; float* out_acc; float* out_depth; float* t_minmax;
+  int* counter;
+};
+
+__device__ __forceinline__ float incl_scan64(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ float sum64(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float nan_to_num_f(float x) {  // torch.nan_to_num defaults (rays.py:198)
+  if (x != x) return 0.f;
+  if (x == INFINITY) return 3.4028234663852886e38f;
+  if (x == -INFINITY) return -3.4028234663852886e38f;
+  return x;
+}
+
+constexpr int FUSED_LDS_BYTES = GFN_FIELD_X3_FWD_BYTES + 64;
+
+template <bool DUAL, bool SAVE, bool PLANES>
+__global__ __launch_bounds__(512) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 L[];
+  for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
+  float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_FWD_BYTES / 16);
+  if (threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = sc.s[threadIdx.x];
+  __syncthreads();
+  const u32x4* Ihi = L;
+  const u32x4* Ilo = L + FWD_CHUNKS * 64;
+  const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const uint32_t T = 1u << A.log2_T;
+  const float early_T = A.early_T;
+
+  // every wave leaves after at most n_rays + 1 fetches and a ray has at most 1024 / 32 tiles: bounded loops, so the grid
+  // always drains
+  for (int fetch = 0; fetch <= A.n_rays; fetch++) {
+    int ray = 0;
+    if (lane == 0) ray = atomicAdd(A.counter, 1);
+    ray = __shfl(ray, 0, 64);
+    if (ray >= A.n_rays) break;  // wave-uniform
+    const int s = A.pts_offsets[ray], e = A.pts_offsets[ray + 1];
+    const float* sh_row = A.sh + (int64_t)ray * 16;
+    const float* emb_row = A.emb ? A.emb + (int64_t)A.cam_idx[ray] * 32 : nullptr;
+    float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f, tmin = INFINITY, tmax = 0.f;
+    int base = s;
+    for (int tile = 0; tile < GFN_MAX_SAMPLE_PER_RAY / 32 + 1 && base < e; tile++, base += 32) {
+      const int i = base + j;
+      const bool valid = i < e;
+      const int64_t q = valid ? i : e - 1;  // lanes past the ray's end redo its last sample and store nothing
+      // ---- lookup: this lane's 8 levels of sample q
+      const float px = A.pts[3 * q], py = A.pts[3 * q + 1], pz = A.pts[3 * q + 2];
+      const int64_t vol = (int64_t)A.anchors[3 * q];
+      u32x4 xh[2], xl[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        float x[8];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int level = 8 * u + 4 * h + m;
+          const int64_t tr = (int64_t)level * A.n_volumes + vol;
+          Corners c;
+          uint32_t cell[3];
+          hash_corners(px, py, pz, s_scale[level], A.prim_a + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+          float2 r = gather_level<true>(A.table_a, (int64_t)level * T, c);
+          if (DUAL) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
+            if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+            const float2 r2 = gather_level<true>(A.table_b, (int64_t)level * T, c);
+            r.x = r.x + r2.x; r.y = r.y + r2.y;
+          }
+          x[2 * m] = r.x; x[2 * m + 1] = r.y;
+        }
+        if (A.feat && valid) {
+          float4* fp = reinterpret_cast<float4*>(A.feat + q * 32 + 16 * u + 8 * h);
+          fp[0] = make_float4(x[0], x[1], x[2], x[3]); fp[1] = make_float4(x[4], x[5], x[6], x[7]);
+        }
+        split8(x, xh[u], xl[u]);
+        if (PLANES) store_nat(A.planes_hi + A.cap * FP_FEAT + q * 32, A.planes_lo + A.cap * FP_FEAT + q * 32, 16 * u, xh[u], xl[u], h);
+      }
+      // ---- decoder
+      const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, A.planes_hi, A.planes_lo, A.cap, q);
+      if (valid) {
+        if (h == 0) {
+          A.sigma[i] = o.sigma;
+          if (SAVE) A.h0[i] = o.h0;
+          A.rgb[3 * (int64_t)i] = o.r; A.rgb[3 * (int64_t)i + 1] = o.g; A.rgb[3 * (int64_t)i + 2] = o.b;
+        }
+        if (SAVE) {
+          unsigned long long* mp = A.masks + (int64_t)i * 6 + h;
+          mp[0] = o.m_a1; mp[2] = o.m_c1; mp[4] = o.m_c2;
+        }
+      }
+      // ---- compositing of these 32 samples (get_weights_f2nerf + renderers), lower half of the wave
+      const bool mine = valid && h == 0;
+      const float ti = mine ? A.ts[i] : 0.f;
+      const float ds = mine ? A.dt[i] * o.sigma : 0.f;
+      const float incl = incl_scan64(ds, lane);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 0.f;
+      const float Tr = expf(-(carry + excl));
+      const float alpha = 1.f - expf(-ds);
+      float w = nan_to_num_f(alpha * Tr);
+      if (early_T > 0.f && Tr < early_T) w = 0.f;
+      if (mine) {
+        if (A.weights) A.weights[i] = w;
+        if (A.alphas) A.alphas[i] = alpha;
+        cr += w * o.r; cg += w * o.g; cb += w * o.b; ca += w; cd += w * ti;
+        tmin = fminf(tmin, ti); tmax = fmaxf(tmax, ti);
+      }
+      carry += __shfl(incl, 31, 64);
+      if (early_T > 0.f && expf(-carry) < early_T) { base += 32; break; }  // the ray is opaque: leave it
+    }
+    // samples behind the termination point: no lookup, no decoder; zero what the backward reads
+    for (int i = base + lane; i < e; i += 64) {
+      A.sigma[i] = 0.f;
+      A.rgb[3 * (int64_t)i] = 0.f; A.rgb[3 * (int64_t)i + 1] = 0.f; A.rgb[3 * (int64_t)i + 2] = 0.f;
+      if (A.weights) A.weights[i] = 0.f;
+      if (A.alphas) A.alphas[i] = 0.f;
+      const float ti = A.ts[i];
+      tmin = fminf(tmin, ti); tmax = fmaxf(tmax, ti);
+    }
+    cr = sum64(cr); cg = sum64(cg); cb = sum64(cb); ca = sum64(ca); cd = sum64(cd);
+    if (A.t_minmax) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+      }
+      if (lane == 0) {
+        if (e - s < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
+        atomicMin(reinterpret_cast<unsigned*>(A.t_minmax), __float_as_uint(tmin));
+        atomicMax(reinterpret_cast<unsigned*>(A.t_minmax + 1), __float_as_uint(tmax));
+      }
+    }
+    if (lane == 0) {
+      A.out_rgb[3 * ray] = cr; A.out_rgb[3 * ray + 1] = cg; A.out_rgb[3 * ray + 2] = cb;
+      if (A.out_acc) A.out_acc[ray] = ca;
+      if (A.out_depth) A.out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
+    }
+  }
+}
+
+__global__ void fused_init_kernel(int* counter, float* t_minmax) {
+  counter[0] = 0;
+  if (t_minmax) { t_minmax[0] = INFINITY; t_minmax[1] = 0.f; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
+                      const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                      const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                      const float* sh, const float* emb, const int32_t* cam_idx, float early_T, float* sigma, float* rgb,
+                      float* h0, uint64_t* masks, float* weights, float* alphas, float* feat, uint16_t* planes_hi,
+                      uint16_t* planes_lo, int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth,
+                      float* t_minmax, int32_t* work_counter, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts && table_f16 && prim_pool && fwd_image && sh && sigma && rgb && out_rgb &&
+                    work_counter, "gfn_fused_forward: null pointer");
+  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_fused_forward: n_rays=%lld", (long long)n_rays);
+  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 26) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");
+  GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
+  GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
+  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 8 == 0)),
+                "gfn_fused_forward: planes need both halves, the masks and a capacity that is a multiple of 8");
+  GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(emb) |
+                  reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
+                "gfn_fused_forward: image, sh, emb, feat and planes must be 16-byte aligned");
+  FusedArgs A;
+  A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
+  A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
+  A.n_volumes = n_volumes; A.log2_T = log2_T;
+  A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
+  A.sigma = sigma; A.rgb = rgb; A.h0 = h0; A.masks = reinterpret_cast<unsigned long long*>(masks); A.weights = weights; A.alphas = alphas;
+  A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap;
+  A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
+  LevelScales sc;
+  gfn_hash_level_scales_host(sc.s);
+  hipStream_t st = gfn_stream(stream);
+  static bool attr_set = false;
+#define GFN_FUSED_ALL(X) X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
+  if (!attr_set) {
+#define GFN_SET(D, S, P) \
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<D, S, P>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_FUSED_ALL(GFN_SET)
+#undef GFN_SET
+    attr_set = true;
+  }
+  fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
+  GFN_CHECK_LAUNCH();
+  int64_t waves = n_rays;  // one ray at a time per wave
+  int64_t blocks = (waves + 7) / 8;
+  if (blocks > 256) blocks = 256;
+  const bool dual = table2_f16 != nullptr, save = masks != nullptr, planes = planes_hi != nullptr;
+#define GFN_LAUNCH(D, S, P) \
+  if (dual == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, 512, FUSED_LDS_BYTES, st>>>(A, sc);
+  GFN_FUSED_ALL(GFN_LAUNCH)
+#undef GFN_LAUNCH
+#undef GFN_FUSED_ALL
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+}  // extern "C"

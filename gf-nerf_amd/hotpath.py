@@ -41,6 +41,8 @@ class HotPathConfig:
     s3im_loss_mult: float = 1.0      # gfnerf/config.py:96 (0 disables the S3IM term of get_loss_dict, nerfacto.py:687-688)
     s3im_patch_height: int = 32      # config.py:100
     s3im_repeat_time: int = 10       # config.py:99
+    fused_forward: bool = True       # lookup + decoder + compositing in one persistent kernel that leaves a ray once it is opaque
+    keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
@@ -125,8 +127,10 @@ class HotPath:
         the packed sample buffers and kept across steps."""
         if self._plane_bufs is None or self._plane_bufs[0][0].numel() < cap * ops.FIELD_X3_FWD_PLANE_LD:
             cap = (cap + 7) // 8 * 8
-            mk = lambda ld: (torch.empty(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
-                             torch.empty(cap * ld, dtype=torch.float16, device=self.dev))
+            # zero-initialised: rows of samples the fused forward skips (behind a ray's termination point) keep whatever finite
+            # values they held, and meet zero gradients in gfn_wgrad_x3 -- garbage f16 could be NaN
+            mk = lambda ld: (torch.zeros(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
+                             torch.zeros(cap * ld, dtype=torch.float16, device=self.dev))
             self._plane_bufs = (mk(ops.FIELD_X3_FWD_PLANE_LD), mk(ops.FIELD_X3_BWD_PLANE_LD))
             # xp plane column -> hW0 column: base rows 1..15 = geo (16..30), row 0 = density channel (none), SH, appearance
             cm = np.concatenate([[-1], 15 + np.arange(1, 16), np.arange(16), 31 + np.arange(32)]).astype(np.int32)
@@ -216,13 +220,36 @@ class HotPath:
         rgb = self._timed("head_fwd", ops.linear_fwd, c2, hW2, hb2, "sigmoid", n_dev=n_dev)
         return dict(feat=feat, a1=a1, h=h, xh=xh, c1=c1, c2=c2, rgb=rgb, sigma=sigma)
 
+    def _fused_ok(self, block):
+        c = self.cfg
+        return (c.fused_forward and c.fused_field and c.hidden == 128 and c.mlp_precision == "x3" and c.table_f16_shadow
+                and not (block is not None and c.share_block_primes))
+
+    def _forward_fused(self, s, cam_idx, block, early_T, save=False, planes=None, want_weights=True):
+        """Hash lookup + decoder + compositing in one launch (csrc/fused_fwd.hip) -> (field dict, comp dict)."""
+        if block is not None and self._pairs_stale:
+            self.refresh_shadows()
+        sh = ops.sh4(s["dirs_unit"])
+        emb = self.emb if self.cfg.use_appearance_embedding else None
+        out = self._timed("fused_fwd", ops.fused_forward, s, self.table16, self.prim, self.n_volumes, self.cfg.log2_T, self._x3()[0], sh, emb,
+                          cam_idx, table2_f16=self.blocks16[block] if block is not None else None,
+                          prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg, early_T=early_T,
+                          save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes)
+        f = dict(sigma=out["sigma"], rgb=out["rgb_samples"], h0=out["h0"], masks=out["masks"], feat=out["feat"])
+        comp = dict(weights=out["weights"], alphas=out["alphas"], rgb=out["rgb"], acc=out["acc"], depth_raw=out["depth_raw"],
+                    t_minmax=out["t_minmax"])
+        return f, comp
+
     def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None):
         """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         s = self.sample(rays_o, rays_d_raw, noise)
-        f = self._field_forward(s, cam_idx, block)
-        comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)
+        if self._fused_ok(block):
+            f, comp = self._forward_fused(s, cam_idx, block, early)
+        else:
+            f = self._field_forward(s, cam_idx, block)
+            comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)
         depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
         rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)  # eval branch of RGBRenderer (renderers.py:131-137)
         return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
@@ -255,9 +282,13 @@ class HotPath:
         # every layer input as split-f16 planes for the weight gradients (the exact-f32 fused kernels have no such form)
         fused = c.fused_field and c.hidden == 128 and (not train_mlp or c.mlp_precision == "x3")
         planes = self._planes(s["ts"].shape[0])[0] if (fused and train_mlp) else None
-        f = self._field_forward(s, cam_idx, block if stage == STAGE_FOCAL else None, fused=fused, save=fused, planes=planes)
-        comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
-                           early_T=c.early_T)
+        blk = block if stage == STAGE_FOCAL else None
+        if fused and self._fused_ok(blk):
+            f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
+        else:
+            f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes)
+            comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
+                               early_T=c.early_T)
         ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)
         self._last_train_ctx = ctx
         return comp, ctx

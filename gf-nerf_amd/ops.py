@@ -593,6 +593,46 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
     return dfeat
 
 
+def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
+                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None):
+    """gfn_fused_forward on the packed sampler outputs `s` (dict of ops.sample_rays with table_space=True).
+    -> dict(sigma, rgb_samples, h0, masks, weights, alphas, feat, rgb [R,3], acc [R], depth_raw [R], t_minmax [2])."""
+    po = s["pts_offsets"]
+    R = po.numel() - 1
+    n = s["ts"].shape[0]
+    dev = po.device
+    for nm, t, dt_, last in (("pts_offsets", po, torch.int32, None), ("warped_pts", s["warped_pts"], torch.float32, 3),
+                             ("anchors", s["anchors"], torch.int32, 3), ("dists", s["dists"], torch.float32, None), ("ts", s["ts"], torch.float32, None),
+                             ("table", table_f16, torch.float16, None), ("table2", table2_f16, torch.float16, None),
+                             ("prim_pool", prim_pool, torch.int32, None), ("prim_pool2", prim_pool2, torch.int32, None),
+                             ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
+                             ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
+        _chk(t, dt_, nm, last)
+    for t in (table_f16, table2_f16):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2:
+            raise _lib.GfnError("f16 table has the wrong size")
+    if prim_pool.numel() != 16 * n_volumes * 3 or (prim_pool2 is not None and prim_pool2.numel() != prim_pool.numel()):
+        raise _lib.GfnError("prim_pool does not match n_volumes")
+    if image.numel() != FIELD_X3_FWD_BYTES or sh.shape[0] != R or (cam_idx is not None and cam_idx.numel() != R):
+        raise _lib.GfnError("weight image / sh / cam_idx do not match the batch")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(sigma=f32(n), rgb_samples=f32(n, 3), h0=f32(n) if save else None,
+               masks=torch.empty((n, 6), dtype=torch.int64, device=dev) if save else None,
+               weights=f32(n) if want_weights else None, alphas=f32(n) if want_weights else None, feat=f32(n, 32) if want_feat else None,
+               rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
+    ph, pl = planes if planes is not None else (None, None)
+    cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)
+    counter = torch.empty(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().gfn_fused_forward(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
+                                      _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T, _ptr(image),
+                                      _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), _ptr(out["sigma"]), _ptr(out["rgb_samples"]),
+                                      _ptr(out["h0"]), _ptr(out["masks"]), _ptr(out["weights"]), _ptr(out["alphas"]), _ptr(out["feat"]),
+                                      _ptr(ph), _ptr(pl), cap, _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]),
+                                      _ptr(counter), _stream())
+    _lib.check(rc, "gfn_fused_forward")
+    return out
+
+
 def sh4(dirs):
     _chk(dirs, torch.float32, "dirs", 3)
     out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)

@@ -290,6 +290,24 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
                  const float* gmax_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
                  float* db, void* stream);
 
+/* Everything after the sampler in ONE persistent kernel (csrc/fused_fwd.hip): f16-shadow hash lookup
+ * (+ residual table2 with its own primes, or NULL) -> x3 decoder -> front-to-back compositing with early
+ * termination.  A wave walks one ray in 32-sample tiles and leaves it once the transmittance is below
+ * early_T (early_T <= 0: every sample, the reference's semantics); samples behind that point are never
+ * looked up and get sigma = rgb = weight = alpha = 0.  Inputs: the packed sampler outputs (pts in table
+ * space, anchors i32 [n,3], dt, ts), sh f32 [R,16], emb / cam_idx, a forward weight image.  Per-sample
+ * outputs sigma [n], rgb [n,3] (always), h0 + masks (training), weights / alphas / feat [n,32] (optional),
+ * activation planes (global stage); per-ray outputs out_rgb [R,3], out_acc, out_depth (un-clipped),
+ * t_minmax [2] (for gfn_depth_finalize).  work_counter: one device i32 of scratch. */
+int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
+                      const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
+                      const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
+                      int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
+                      const int32_t* cam_idx, float early_T, float* sigma, float* rgb, float* h0, uint64_t* masks,
+                      float* weights, float* alphas, float* feat, uint16_t* planes_hi, uint16_t* planes_lo,
+                      int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax,
+                      int32_t* work_counter, void* stream);
+
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
  * default output.  dirs f32 [R,3] -> out f32 [R,16]. */

@@ -22,7 +22,7 @@ def setup():
     import pipeline as opipe
 
     sc = small_scene()
-    cfg = hotpath.HotPathConfig(log2_T=14, early_T=0.0, grad_f16=False)
+    cfg = hotpath.HotPathConfig(log2_T=14, early_T=0.0, grad_f16=False, keep_features=True)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
     rng = np.random.default_rng(11)
     hp.blocks[0].copy_(torch.from_numpy(rng.uniform(-1e-2, 1e-2, tuple(hp.blocks[0].shape)).astype(np.float32)))
@@ -251,3 +251,56 @@ def test_tile_renderer_matches_direct_render_and_oracle(setup, use_graph):
     direct2 = hp.render(rays2["origins"], rays2["directions"], cam, noise, block=0, early_T=0.0)
     np.testing.assert_allclose(img2["rgb"].reshape(-1, 3).cpu().numpy(), direct2["rgb"].cpu().numpy(), atol=1e-6)
     assert rmod.frame_shard(10, 4, 1) == [1, 5, 9]
+
+
+@pytest.mark.parametrize("block", [None, 0])
+def test_fused_forward_matches_separate_kernels(setup, block):
+    """gfn_fused_forward (lookup + decoder + compositing in one kernel) against the three separate kernels on the same
+    samples: every sample (early_T = 0), then with early termination (skipped samples zeroed, colour within 1e-3)."""
+    import torch
+
+    from gfnerf_amd import ops
+
+    S = setup
+    hp, t = S["hp"], S["t"]
+    cam = t(S["cam"])
+    s = hp.sample(t(S["o"]), t(S["d"]), t(S["noise"]))
+    N = int(s["pts_offsets"][-1].item())
+    assert hp._fused_ok(block)
+    f, comp = hp._forward_fused(s, cam, block, 0.0, save=True)
+    sep = hp._field_forward(s, cam, block=block, fused=True, save=True)
+    csep = ops.composite_fwd(s["pts_offsets"], sep["sigma"], s["dists"], s["ts"], sep["rgb"], early_T=0.0)
+    assert np.array_equal(f["feat"].cpu().numpy()[:N], sep["feat"].cpu().numpy()[:N])          # same lookups, bit for bit
+    assert np.array_equal(f["sigma"].cpu().numpy()[:N], sep["sigma"].cpu().numpy()[:N])        # same decoder tile code
+    assert np.array_equal(f["rgb"].cpu().numpy()[:N], sep["rgb"].cpu().numpy()[:N])
+    assert np.array_equal(f["h0"].cpu().numpy()[:N], sep["h0"].cpu().numpy()[:N])
+    assert np.array_equal(f["masks"].cpu().numpy()[:N], sep["masks"].cpu().numpy()[:N])
+    np.testing.assert_allclose(comp["weights"].cpu().numpy()[:N], csep["weights"].cpu().numpy()[:N], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(comp["alphas"].cpu().numpy()[:N], csep["alphas"].cpu().numpy()[:N], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(comp["rgb"].cpu().numpy(), csep["rgb"].cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(comp["acc"].cpu().numpy(), csep["acc"].cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(comp["depth_raw"].cpu().numpy(), csep["depth_raw"].cpu().numpy(), rtol=2e-5, atol=1e-5)
+    assert np.array_equal(comp["t_minmax"].cpu().numpy(), csep["t_minmax"].cpu().numpy())
+    # early termination: rays leave after the 32-sample tile in which T drops below 1e-4 (denser medium: h0 bias + 3)
+    hp.layers[1][1][0] += 3.0
+    hp._x3_stale = True
+    try:
+        sep = hp._field_forward(s, cam, block=block, fused=True, save=True)
+        csep = ops.composite_fwd(s["pts_offsets"], sep["sigma"], s["dists"], s["ts"], sep["rgb"], early_T=0.0)
+        fe, ce = hp._forward_fused(s, cam, block, 1e-4, save=True)
+    finally:
+        hp.layers[1][1][0] -= 3.0
+        hp._x3_stale = True
+    sig = fe["sigma"].cpu().numpy()[:N]
+    skipped = sig == 0
+    assert 0.05 < skipped.mean() < 0.9, skipped.mean()
+    assert np.all(fe["rgb"].cpu().numpy()[:N][skipped] == 0) and np.all(ce["weights"].cpu().numpy()[:N][skipped] == 0)
+    assert np.array_equal(sig[~skipped], sep["sigma"].cpu().numpy()[:N][~skipped])
+    po = s["pts_offsets"].cpu().numpy()
+    for r in range(0, po.size - 1, 13):  # skipped samples form a suffix of their ray, starting on a 32-sample tile boundary
+        k = skipped[po[r]:po[r + 1]]
+        if k.any():
+            first = int(np.argmax(k))
+            assert k[first:].all() and first % 32 == 0
+    assert np.abs(ce["rgb"].cpu().numpy() - csep["rgb"].cpu().numpy()).max() < 1e-3
+    assert np.array_equal(ce["t_minmax"].cpu().numpy(), csep["t_minmax"].cpu().numpy())
