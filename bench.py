@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the bounded cpu_baseline sample")
     ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
+    ap.add_argument("--no-oct-update", action="store_true", help="global stage: skip the per-step UpdateOctNodes (K5/K6)")
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
@@ -182,12 +183,15 @@ def main():
     def step(i):
         o, d, cam, gt = batches[i % 4]
         block = (i % n_blocks) if args.stage == "focal" else None
-        return hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3im_idx[i % 4])
+        out = hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3im_idx[i % 4])
+        if args.stage == "global" and not args.no_oct_update:
+            hp._timed("oct_update", hp.update_oct_nodes, out[1])  # UpdateOctNodes K5/K6 every global-stage step (nerfacto.py:605-613)
+        return out
 
     for i in range(args.warmup):
         step(i)
     # dominant kernel: timed live with events on the launch stream (torch's current stream)
-    hp.timed_ops = {"*"} if args.stage_times else {"hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
+    hp.timed_ops = {"*"} if args.stage_times else {"fused_fwd", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -219,7 +223,11 @@ def main():
         # table (512 B/table) + 16 B point/anchor + 128 B features written; hash scatter = 16 x 8 x 4 B
         # packed-f16 atomic adds + 128 B gradient read + 16 B point/anchor.
         n_tables = 2 if args.stage == "focal" else 1
-        alg = {"hash_fwd": n_live * (512 * n_tables + 16 + 128), "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)}
+        # fused forward: only samples in front of each ray's termination point are looked up (sigma > 0 marks them); per such
+        # sample 512 B of gathers per table + 16 B point/anchor + 8 B dt/t in, sigma 4 + rgb 12 + h0 4 + masks 48 + weight/alpha 8 out
+        n_eval = int((aux["field"]["sigma"][:n_live] > 0).sum().item())
+        alg = {"fused_fwd": n_eval * (512 * n_tables + 24 + 76), "hash_fwd": n_live * (512 * n_tables + 16 + 128),
+               "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)}
         kern = {}
         for name, ev in hp.timings.items():
             kern[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -252,6 +260,7 @@ def main():
                                rays_per_batch=N_RAYS, mean_samples_per_ray=n_live / N_RAYS, log2_table_size=args.log2_T,
                                n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
                                fineness=fineness, stage=args.stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
+                               evaluated_sample_frac=n_eval / max(n_live, 1), fused_forward=bool(cfg.fused_forward),
                                block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"

@@ -25,7 +25,7 @@ struct FusedArgs {
   const int* pts_offsets; int n_rays;
   const float* pts; const int* anchors; const float* dt; const float* ts;
   const void* table_a; const void* table_b; const int* prim_a; const int* prim_b; const float* bias_pool;
-  int64_t n_volumes; int log2_T;
+  int64_t n_volumes; int log2_T; int pair;  // pair: table_a is the interleaved {global, block} image (shared primes)
   const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
   float early_T;
   float* sigma; float* rgb; float* h0; unsigned long long* masks; float* weights; float* alphas; float* feat;
@@ -55,9 +55,10 @@ __device__ __forceinline__ float nan_to_num_f(float x) {  // torch.nan_to_num de
 }
 
 constexpr int FUSED_LDS_BYTES = GFN_FIELD_X3_FWD_BYTES + 64;
+constexpr int FUSED_THREADS = 256;  // one wave per SIMD: the 512-entry register file holds a tile without spilling
 
 template <bool DUAL, bool SAVE, bool PLANES>
-__global__ __launch_bounds__(512) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
+__global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_FWD_BYTES / 16);
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(512) void fused_fwd_kernel(FusedArgs A, LevelScales
           Corners c;
           uint32_t cell[3];
           hash_corners(px, py, pz, s_scale[level], A.prim_a + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
-          float2 r = gather_level<true>(A.table_a, (int64_t)level * T, c);
+          float2 r;
+          if (!DUAL && A.pair) r = gather_level_pair(A.table_a, (int64_t)level * T, c);  // one 8-byte gather per corner for both tables
+          else r = gather_level<true>(A.table_a, (int64_t)level * T, c);
           if (DUAL) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
             if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
             const float2 r2 = gather_level<true>(A.table_b, (int64_t)level * T, c);
@@ -189,7 +192,7 @@ extern "C" {
 
 int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
                       const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                      const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                      const int32_t* prim_pool2, int pair_table, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
                       const float* sh, const float* emb, const int32_t* cam_idx, float early_T, float* sigma, float* rgb,
                       float* h0, uint64_t* masks, float* weights, float* alphas, float* feat, uint16_t* planes_hi,
                       uint16_t* planes_lo, int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth,
@@ -200,6 +203,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_fused_forward: n_rays=%lld", (long long)n_rays);
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 26) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
+  GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_forward: an interleaved pair image already holds the second table");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
   GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 8 == 0)),
                 "gfn_fused_forward: planes need both halves, the masks and a capacity that is a multiple of 8");
@@ -209,7 +213,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   FusedArgs A;
   A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
   A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
-  A.n_volumes = n_volumes; A.log2_T = log2_T;
+  A.n_volumes = n_volumes; A.log2_T = log2_T; A.pair = pair_table;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.sigma = sigma; A.rgb = rgb; A.h0 = h0; A.masks = reinterpret_cast<unsigned long long*>(masks); A.weights = weights; A.alphas = alphas;
   A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap;
@@ -229,11 +233,11 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t waves = n_rays;  // one ray at a time per wave
-  int64_t blocks = (waves + 7) / 8;
+  int64_t blocks = (waves + FUSED_THREADS / 64 - 1) / (FUSED_THREADS / 64);
   if (blocks > 256) blocks = 256;
   const bool dual = table2_f16 != nullptr, save = masks != nullptr, planes = planes_hi != nullptr;
 #define GFN_LAUNCH(D, S, P) \
-  if (dual == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, 512, FUSED_LDS_BYTES, st>>>(A, sc);
+  if (dual == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, FUSED_THREADS, FUSED_LDS_BYTES, st>>>(A, sc);
   GFN_FUSED_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_FUSED_ALL

@@ -222,8 +222,7 @@ class HotPath:
 
     def _fused_ok(self, block):
         c = self.cfg
-        return (c.fused_forward and c.fused_field and c.hidden == 128 and c.mlp_precision == "x3" and c.table_f16_shadow
-                and not (block is not None and c.share_block_primes))
+        return c.fused_forward and c.fused_field and c.hidden == 128 and c.mlp_precision == "x3" and c.table_f16_shadow
 
     def _forward_fused(self, s, cam_idx, block, early_T, save=False, planes=None, want_weights=True):
         """Hash lookup + decoder + compositing in one launch (csrc/fused_fwd.hip) -> (field dict, comp dict)."""
@@ -231,10 +230,13 @@ class HotPath:
             self.refresh_shadows()
         sh = ops.sh4(s["dirs_unit"])
         emb = self.emb if self.cfg.use_appearance_embedding else None
-        out = self._timed("fused_fwd", ops.fused_forward, s, self.table16, self.prim, self.n_volumes, self.cfg.log2_T, self._x3()[0], sh, emb,
-                          cam_idx, table2_f16=self.blocks16[block] if block is not None else None,
-                          prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg, early_T=early_T,
-                          save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes)
+        pair = block is not None and self.cfg.share_block_primes  # blocks16[block] is then the interleaved {global, block} image
+        out = self._timed("fused_fwd", ops.fused_forward, s, self.blocks16[block] if pair else self.table16, self.prim, self.n_volumes,
+                          self.cfg.log2_T, self._x3()[0], sh, emb, cam_idx,
+                          table2_f16=self.blocks16[block] if (block is not None and not pair) else None,
+                          prim_pool2=self.block_prims[block] if (block is not None and not pair) else None, bias_pool=self.bias_arg,
+                          early_T=early_T, save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes,
+                          pair_table=pair)
         f = dict(sigma=out["sigma"], rgb=out["rgb_samples"], h0=out["h0"], masks=out["masks"], feat=out["feat"])
         comp = dict(weights=out["weights"], alphas=out["alphas"], rgb=out["rgb"], acc=out["acc"], depth_raw=out["depth_raw"],
                     t_minmax=out["t_minmax"])

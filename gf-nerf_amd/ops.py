@@ -594,7 +594,7 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
 
 
 def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None):
+                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None, pair_table=False):
     """gfn_fused_forward on the packed sampler outputs `s` (dict of ops.sample_rays with table_space=True).
     -> dict(sigma, rgb_samples, h0, masks, weights, alphas, feat, rgb [R,3], acc [R], depth_raw [R], t_minmax [2])."""
     po = s["pts_offsets"]
@@ -608,8 +608,8 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
                              ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
                              ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
         _chk(t, dt_, nm, last)
-    for t in (table_f16, table2_f16):
-        if t is not None and t.numel() != 16 * (1 << log2_T) * 2:
+    for t, mult in ((table_f16, 2 if pair_table else 1), (table2_f16, 1)):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2 * mult:
             raise _lib.GfnError("f16 table has the wrong size")
     if prim_pool.numel() != 16 * n_volumes * 3 or (prim_pool2 is not None and prim_pool2.numel() != prim_pool.numel()):
         raise _lib.GfnError("prim_pool does not match n_volumes")
@@ -624,7 +624,8 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
     cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)
     counter = torch.empty(1, dtype=torch.int32, device=dev)
     rc = _lib.lib().gfn_fused_forward(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
-                                      _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T, _ptr(image),
+                                      _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), int(bool(pair_table)), _ptr(bias_pool), n_volumes, log2_T,
+                                      _ptr(image),
                                       _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), _ptr(out["sigma"]), _ptr(out["rgb_samples"]),
                                       _ptr(out["h0"]), _ptr(out["masks"]), _ptr(out["weights"]), _ptr(out["alphas"]), _ptr(out["feat"]),
                                       _ptr(ph), _ptr(pl), cap, _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]),

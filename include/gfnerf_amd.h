@@ -291,7 +291,8 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
                  float* db, void* stream);
 
 /* Everything after the sampler in ONE persistent kernel (csrc/fused_fwd.hip): f16-shadow hash lookup
- * (+ residual table2 with its own primes, or NULL) -> x3 decoder -> front-to-back compositing with early
+ * (+ residual table2 with its own primes, or NULL; or pair_table != 0: table_f16 is the interleaved
+ * gfn_table_pair_f16 image of both tables) -> x3 decoder -> front-to-back compositing with early
  * termination.  A wave walks one ray in 32-sample tiles and leaves it once the transmittance is below
  * early_T (early_T <= 0: every sample, the reference's semantics); samples behind that point are never
  * looked up and get sigma = rgb = weight = alpha = 0.  Inputs: the packed sampler outputs (pts in table
@@ -301,7 +302,7 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
  * t_minmax [2] (for gfn_depth_finalize).  work_counter: one device i32 of scratch. */
 int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
                       const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
-                      const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
+                      const int32_t* prim_pool, const int32_t* prim_pool2, int pair_table, const float* bias_pool,
                       int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                       const int32_t* cam_idx, float early_T, float* sigma, float* rgb, float* h0, uint64_t* masks,
                       float* weights, float* alphas, float* feat, uint16_t* planes_hi, uint16_t* planes_lo,

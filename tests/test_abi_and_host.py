@@ -137,3 +137,32 @@ def test_gf_scheduler_matches_reference_curve(golden):
         for s in range(120):
             assert abs(opt.param_groups[0]["lr"] - want[s]) <= 1e-12 * want[s]
             opt.step(); sched.step()
+
+
+def test_matrix_kernels_do_not_spill():
+    """The MFMA kernels are sized to the register file (256 VGPRs at two waves per SIMD, 512 at one): a build that spills
+    to scratch is a performance bug, and on this toolchain the spilling 512-thread form of the fused forward also
+    produced wrong lookups intermittently.  Cross-compiles the three sources and reads the resource remarks."""
+    import concurrent.futures as cf
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "gf-nerf_amd", "csrc")
+
+    def remarks(src):
+        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-c",
+               os.path.join(csrc, src), "-o", os.devnull, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stderr
+
+    with cf.ThreadPoolExecutor(3) as ex:
+        outs = dict(zip(("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip"), ex.map(remarks, ("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip"))))
+    for src, text in outs.items():
+        spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", text)]
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
+        assert spills and all(s == 0 for s in spills), (src, spills)
+        assert all(s == 0 for s in scratch), (src, scratch)
