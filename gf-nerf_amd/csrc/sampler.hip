@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void march_group_kernel(
     const CompactNode* __restrict__ nodes, const float* __restrict__ transes, int* __restrict__ counts,
     const int* __restrict__ pts_offsets, float* __restrict__ world_pts, float* __restrict__ warped_pts,
     float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
-    int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow) {
+    int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow,
+    float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf} for fill_from_rec_kernel, or NULL */) {
   const int g = threadIdx.x & (kGroup - 1);          // projection index owned by this lane (0..11 live)
   const int ray = blockIdx.x * kRaysPerBlock + (threadIdx.x / kGroup);
   const bool in_range = ray < n_rays;
@@ -558,6 +559,12 @@ __global__ __launch_bounds__(256) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
+      if (!FILL && rec && !first && g == 0) {  // what the sample-parallel fill needs to rebuild this sample
+        float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * 3;
+        rp[0] = cur_t;
+        rp[1] = exp_march_step * (pnorm + 1e-6f);
+        rp[2] = __int_as_float(cur_oct_idx);
+      }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
         oct_ptr++;
@@ -576,6 +583,63 @@ __global__ __launch_bounds__(256) void march_group_kernel(
     }
   }
   if (!FILL && in_range && g == 0) counts[ray] = pts_ptr;
+}
+
+__device__ __forceinline__ float sum12_tree(const float* q) {  // the association of row_sum12 / Eigen's redux
+  return ((q[0] + (q[1] + q[2])) + (q[3] + (q[4] + q[5]))) + ((q[6] + (q[7] + q[8])) + (q[9] + (q[10] + q[11])));
+}
+
+// Second half of K4 when the count pass has recorded (t, dist, leaf) per sample: every sample is independent now, so
+// the warped point (QueryFrameTransform, PersSampler_cuda.cu:155-170) is rebuilt one thread per sample instead of
+// re-running the serial march -- same expressions and the same summation order as march_group_kernel<true>.
+__global__ __launch_bounds__(256) void fill_from_rec_kernel(
+    int n_rays, int table_space, int max_hits, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const int* __restrict__ hit_counts, const float2* __restrict__ hit_nf, const CompactNode* __restrict__ nodes,
+    const float* __restrict__ transes, const float* __restrict__ rec, const int* __restrict__ pts_offsets,
+    float* __restrict__ world_pts, float* __restrict__ warped_pts, float* __restrict__ dirs, float* __restrict__ dists,
+    float* __restrict__ ts, int* __restrict__ anchors, int* __restrict__ ray_id, float* __restrict__ first_oct_dis,
+    int64_t pts_cap, int* __restrict__ overflow) {
+  const int ray = blockIdx.x;
+  if (ray >= n_rays) return;
+  const int64_t base = pts_offsets[ray];
+  int64_t end = pts_offsets[ray + 1];
+  if (end > pts_cap) { end = pts_cap; if (overflow && threadIdx.x == 0) atomicOr(overflow, 4); }
+  if (threadIdx.x == 0 && first_oct_dis) first_oct_dis[ray] = hit_counts[ray] > 0 ? hit_nf[(int64_t)ray * max_hits].x : 1e9f;
+  const int n = (int)(end > base ? end - base : 0);
+  const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+  const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + k) * 3;
+    const float t = rp[0], dist = rp[1];
+    const int oct = __float_as_int(rp[2]);
+    const CompactNode* nd = nodes + oct;
+    const int trans_idx = nd->trans_idx, block_idx = nd->block_idx;
+    const float* tp = transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4);
+    const float xyz[3] = {o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t};
+    float q0[12], q1[12], q2[12];
+#pragma unroll
+    for (int i = 0; i < GFN_N_PROS; i++) {
+      const float4 m0 = *reinterpret_cast<const float4*>(tp + i * 8);
+      const float4 m1 = *reinterpret_cast<const float4*>(tp + i * 8 + 4);
+      const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
+      const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
+      const float v = x0 / x1;
+      q0[i] = tp[96 + i] * v; q1[i] = tp[96 + 12 + i] * v; q2[i] = tp[96 + 24 + i] * v;
+    }
+    float wp[3] = {sum12_tree(q0), sum12_tree(q1), sum12_tree(q2)};
+    if (table_space) {
+      const float inv3 = 1.0f / 3.0f;
+      wp[0] = (wp[0] + 1.5f) * inv3; wp[1] = (wp[1] + 1.5f) * inv3; wp[2] = (wp[2] + 1.5f) * inv3;
+    }
+    const int64_t p = base + k;
+    if (world_pts) { world_pts[3 * p] = xyz[0]; world_pts[3 * p + 1] = xyz[1]; world_pts[3 * p + 2] = xyz[2]; }
+    if (dirs) { dirs[3 * p] = d[0]; dirs[3 * p + 1] = d[1]; dirs[3 * p + 2] = d[2]; }
+    warped_pts[3 * p] = wp[0]; warped_pts[3 * p + 1] = wp[1]; warped_pts[3 * p + 2] = wp[2];
+    ts[p] = t;
+    dists[p] = dist;
+    anchors[3 * p] = trans_idx; anchors[3 * p + 1] = oct; anchors[3 * p + 2] = block_idx;
+    if (ray_id) ray_id[p] = ray;
+  }
 }
 
 __global__ void normalize_dirs_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
@@ -628,38 +692,53 @@ __global__ void fill_i64_kernel(long long* p, long long v, int64_t n) {
   if (i < n) p[i] = v;
 }
 
-// K5 MarkVistNodeKernel (:518-574) on packed samples.
-__global__ __launch_bounds__(kRayBlock) void mark_visit_kernel(
+// K5 MarkVistNodeKernel (:518-574) on packed samples.  The reference walks a ray with one thread: per contiguous run
+// of samples in one node it takes max weight / max alpha / the run length and atomicMax'es
+//   (max_w_run > w_thres ? OCC_WEIGHT_BASE : -1),  (max_a_run > a_thres ? OCC_ALPHA_BASE : -1),  run length
+// into per-node arrays initialised to -1 / 0.  Every one of these is a max, so a wave per ray can let the samples speak
+// for themselves: a sample above the threshold raises its node's adder to the base (the -1 case is the initial value),
+// every sample marks its node visited, and each sample's 1-based position inside its run bounds the run length from
+// below -- the last sample of the run (or of the 64-sample sweep) posts it.
+__global__ __launch_bounds__(256) void mark_visit_kernel(
     int n_rays, const int* __restrict__ pts_offsets, const int* __restrict__ anchors,
     const float* __restrict__ weights, const float* __restrict__ alphas, long long* w_adder,
     long long* a_adder, long long* mark, long long* visit_cnt) {
-  const int ray = blockIdx.x * kRayBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
   if (s >= e) return;
   float max_w = 0.f, max_a = 0.f;
-  for (int i = s; i < e; i++) { max_w = fmaxf(max_w, weights[i]); max_a = fmaxf(max_a, alphas[i]); }
+  for (int i = s + lane; i < e; i += 64) { max_w = fmaxf(max_w, weights[i]); max_a = fmaxf(max_a, alphas[i]); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    max_w = fmaxf(max_w, __shfl_xor(max_w, off, 64));
+    max_a = fmaxf(max_a, __shfl_xor(max_a, off, 64));
+  }
   const float w_thres = fminf((float)(max_w * REL_WEIGHT_THRES), (float)ABS_WEIGHT_THRES);  // :544 (double math)
   const float a_thres = fminf((float)(max_a * REL_ALPHA_THRES), (float)ABS_ALPHA_THRES);
-  float cw = 0.f, ca = 0.f;
-  int cur = -1;
-  long long cnt = 0;
-  for (int i = s; i <= e; i++) {
-    const int oi = (i < e) ? anchors[3 * i + 1] : -2;
-    if (cur != oi) {
-      if (cur >= 0) {
-        atomicMax(w_adder + cur, (long long)(cw > w_thres ? OCC_WEIGHT_BASE : -1));
-        atomicMax(a_adder + cur, (long long)(ca > a_thres ? OCC_ALPHA_BASE : -1));
-        atomicMax(visit_cnt + cur, cnt);
-        mark[cur] = 1;
-      }
-      cur = oi; cw = 0.f; ca = 0.f; cnt = 0;
+  int carry_oi = -1;          // node of the previous sweep's last sample
+  long long carry_cnt = 0;    // its position inside its run
+  for (int base = s; base < e; base += 64) {
+    const int i = base + lane;
+    const bool v = i < e;
+    const int oi = v ? anchors[3 * i + 1] : -2;
+    int prev = __shfl_up(oi, 1, 64);
+    if (lane == 0) prev = carry_oi;
+    const bool head = oi != prev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes <= this one
+    const long long cnt = upto ? (long long)(lane - (63 - __builtin_clzll(upto)) + 1) : (long long)(lane + 1) + carry_cnt;
+    const int next = __shfl_down(oi, 1, 64);
+    const bool last = lane == 63 || next != oi;
+    if (v && oi >= 0) {
+      mark[oi] = 1;
+      if (weights[i] > w_thres) atomicMax(w_adder + oi, (long long)OCC_WEIGHT_BASE);
+      if (alphas[i] > a_thres) atomicMax(a_adder + oi, (long long)OCC_ALPHA_BASE);
+      if (last) atomicMax(visit_cnt + oi, cnt);
     }
-    if (i < e) {
-      cw = fmaxf(cw, weights[i]);
-      ca = fmaxf(ca, alphas[i]);
-      cnt += 1;
-    }
+    carry_oi = __shfl(oi, 63, 64);
+    carry_cnt = __shfl((int)cnt, 63, 64);
   }
 }
 
@@ -826,7 +905,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, void* stream) {
+                    int32_t* overflow_dev, float* march_rec, void* stream) {
   GFN_CHECK_ARG(pts_offsets, "gfn_sample_rays: null pts_offsets");
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
@@ -851,14 +930,20 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
   march_group_kernel<false><<<grid, 256, 0, st>>>(
       (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
       reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts, nullptr, nullptr,
-      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev);
+      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev, march_rec);
   GFN_CHECK_LAUNCH();
   scan_kernel<<<1, 1024, 0, st>>>(counts, (int)n_rays, pts_offsets);
   GFN_CHECK_LAUNCH();
-  march_group_kernel<true><<<grid, 256, 0, st>>>(
-      (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
-      reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), nullptr, pts_offsets,
-      world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev);
+  if (march_rec)
+    fill_from_rec_kernel<<<(unsigned)n_rays, 256, 0, st>>>(
+        (int)n_rays, table_space, max_hits, rays_o, rays_d, hit_counts, reinterpret_cast<const float2*>(hit_near_far), cn,
+        reinterpret_cast<const float*>(transes), march_rec, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
+        first_oct_dis, pts_cap, overflow_dev);
+  else
+    march_group_kernel<true><<<grid, 256, 0, st>>>(
+        (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
+        reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), nullptr, pts_offsets,
+        world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev, nullptr);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -895,7 +980,7 @@ int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* 
   GFN_CHECK_LAUNCH();
   GFN_CHECK_HIP(hipMemsetAsync(mark, 0, sizeof(long long) * n_nodes, st));
   if (n_rays > 0) {
-    mark_visit_kernel<<<(unsigned)((n_rays + kRayBlock - 1) / kRayBlock), kRayBlock, 0, st>>>(
+    mark_visit_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(
         (int)n_rays, pts_offsets, anchors, weights, alphas, w_adder, a_adder, mark,
         reinterpret_cast<long long*>(visit_cnt));
     GFN_CHECK_LAUNCH();

@@ -257,7 +257,8 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
     if workspace is None or workspace["hit_idx"].numel() < R * max_hits:
         workspace = dict(hit_counts=torch.empty(max(R, 1), dtype=torch.int32, device=dev),
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
-                         hit_nf=f(max(R * max_hits, 1), 2))
+                         hit_nf=f(max(R * max_hits, 1), 2),
+                         march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * 3))  # (t, dist, leaf) per sample slot of the counting march
     out = dict(
         pts_offsets=torch.empty(R + 1, dtype=torch.int32, device=dev),
         world_pts=f(pts_cap, 3) if want_world else None, warped_pts=f(pts_cap, 3), dirs=f(pts_cap, 3) if want_dirs else None,
@@ -270,7 +271,7 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
                                     _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]), _ptr(workspace["hit_nf"]),
                                     _ptr(out["pts_offsets"]), _ptr(out["world_pts"]), _ptr(out["warped_pts"]), _ptr(out["dirs"]),
                                     _ptr(out["dists"]), _ptr(out["ts"]), _ptr(out["anchors"]), _ptr(out["ray_id"]),
-                                    _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _stream())
+                                    _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _ptr(workspace.get("march_rec")), _stream())
     _lib.check(rc, "gfn_sample_rays")
     return out
 
