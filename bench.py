@@ -191,7 +191,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     # dominant kernel: timed live with events on the launch stream (torch's current stream)
-    hp.timed_ops = {"*"} if args.stage_times else {"fused_fwd", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
+    hp.timed_ops = {"*"} if args.stage_times else {"fused_fwd", "bwd_scatter", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -227,7 +227,8 @@ def main():
         # sample 512 B of gathers per table + 16 B point/anchor + 8 B dt/t in, sigma 4 + rgb 12 + h0 4 + masks 48 + weight/alpha 8 out
         n_eval = int((aux["field"]["sigma"][:n_live] > 0).sum().item())
         alg = {"fused_fwd": n_eval * (512 * n_tables + 24 + 76), "hash_fwd": n_live * (512 * n_tables + 16 + 128),
-               "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16)}
+               "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16),
+               "bwd_scatter": n_eval * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 16 + 16 + 56)}
         kern = {}
         for name, ev in hp.timings.items():
             kern[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))

@@ -18,6 +18,7 @@
 // every workgroup (146 KiB forward, 112 KiB backward; 512 threads = two waves per SIMD so one
 // wave's split/ReLU VALU work overlaps the other's MFMAs).
 #include "gfn_common.h"
+#include "hash_device.h"
 #include "x3_device.h"
 
 namespace {
@@ -145,16 +146,100 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 // PLANES = true : the global stage: also writes dz of every layer as split-f16 planes (for gfn_wgrad_x3) under ONE
 //                 power-of-two scale for the whole batch (gfn_grad_scale_of(*gmax)), and reduces the appearance-embedding
 //                 gradient over each ray's samples into demb.
-template <bool PLANES>
-__global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
+// SCATTER: instead of writing d feat, scatter it straight into the hash table's gradient pool
+// (Hash3DAnchoredFunction::backward, Hash3DAnchored_cuda.cu:81-155,198-239): the accumulator tile of d feat holds, on
+// lane (h, j), sample j's gradient for the 8 levels {2h, 2h+1, 4+2h, 5+2h, 8+2h, 9+2h, 12+2h, 13+2h} -- each lane hashes
+// those levels of its sample and issues the (run-length reduced) packed-f16 / f32 atomics itself.  The [N,32] d feat
+// tensor is never written and the decoder's MFMAs run beside the other waves' atomics.
+struct ScatterArgs {
+  const float* pts; const int* anchors; const int* prim_pool; const float* bias_pool; int64_t n_volumes; int log2_T;
+  void* grad_pool; int grad_f16; LevelScales sc;
+};
+
+// sum v over the lanes [j, run_end] of this 32-lane half (runs = consecutive samples in one cell of one volume)
+__device__ __forceinline__ float half_run_sum32(float v, int j, int run_end) {
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const float u = __shfl_down(v, off, 32);
+    if (j + off <= run_end) v += u;
+  }
+  return v;
+}
+
+template <bool GRAD_F16>
+__device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float* __restrict__ s_scale, int level, float px, float py, float pz,
+                                              int64_t vol, float gx, float gy, bool valid, int h, int j, uint32_t T) {
+  const int64_t tr = (int64_t)level * S.n_volumes + vol;
+  Corners c;
+  uint32_t cell[3];
+  hash_corners(px, py, pz, s_scale[level], S.prim_pool + 3 * tr, S.bias_pool ? S.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+  float g0 = gfn_round_f16(gx * 128.f);  // :219 grad_in = (grad * 128).half()
+  float g1 = gfn_round_f16(gy * 128.f);
+  const bool live = valid && (g0 != 0.f || g1 != 0.f);  // :149
+  if (!live) { g0 = 0.f; g1 = 0.f; }
+  const uint32_t pvol = __shfl_up((uint32_t)vol, 1, 32), pcx = __shfl_up(cell[0], 1, 32);
+  const uint32_t pcy = __shfl_up(cell[1], 1, 32), pcz = __shfl_up(cell[2], 1, 32);
+  const bool head = (j == 0) || pvol != (uint32_t)vol || pcx != cell[0] || pcy != cell[1] || pcz != cell[2];
+  const unsigned long long heads64 = __ballot(head);
+  float c0[8], c1[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) {  // :150 (half)(w0*ws[d]) -- each contribution quantised like the reference
+    c0[d] = gfn_round_f16(g0 * c.w[d]);
+    c1[d] = gfn_round_f16(g1 * c.w[d]);
+  }
+  bool issue = live;
+  if (__popcll(heads64) <= 40) {  // wave-uniform: runs are long enough to pay for the shuffles
+    const uint32_t heads = (uint32_t)(heads64 >> (32 * h));
+    const uint32_t later = (j == 31) ? 0u : (heads >> (j + 1));
+    const int run_end = later ? j + __builtin_ctz(later) : 31;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      c0[d] = half_run_sum32(c0[d], j, run_end);
+      c1[d] = half_run_sum32(c1[d], j, run_end);
+    }
+    issue = head;  // zero sums are skipped below
+  }
+  if (issue) {
+    if (GRAD_F16) {
+      half2_t* baseh = reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(S.grad_pool) + (int64_t)level * T);
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        if (c0[d] != 0.f || c1[d] != 0.f) {
+          const half2_t v = {(_Float16)c0[d], (_Float16)c1[d]};  // x128-scaled, like the reference's pool (:222,:151)
+          __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(baseh + c.pos[d]), v);
+        }
+      }
+    } else {
+      float* basef = reinterpret_cast<float*>(S.grad_pool) + (int64_t)level * T;
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        if (c0[d] != 0.f || c1[d] != 0.f) {
+          float* dstp = basef + (size_t)c.pos[d] * 2;
+          atomicAdd(dstp, c0[d] * (1.f / 128.f));  // the reference's final /128 (:238), exact (power of two)
+          atomicAdd(dstp + 1, c1[d] * (1.f / 128.f));
+        }
+      }
+    }
+  }
+}
+
+// PLANES + SCATTER together need more than 256 registers: that form runs 256-thread workgroups (one wave per SIMD with the
+// 512-entry file) -- no build of these kernels may spill (tests/test_abi_and_host.py)
+template <bool PLANES, int SCATTER>
+constexpr int bwd_threads() { return (PLANES && SCATTER) ? 256 : 512; }
+
+template <bool PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool */>
+__global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
     const u32x4* __restrict__ image, float* __restrict__ dfeat, const float* __restrict__ gmax_dev,
     uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, int64_t cap, const int* __restrict__ ray_id,
-    const int* __restrict__ cam_idx, float* __restrict__ demb) {
+    const int* __restrict__ cam_idx, float* __restrict__ demb, ScatterArgs S) {
 #define BPL(half, C, W) (planes_##half + cap * (C) + s * (W))
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
+  float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
+  if (SCATTER && threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = S.sc.s[threadIdx.x];
   __syncthreads();
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + BWD_CHUNKS * 64;
@@ -164,7 +249,8 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
   const int64_t n_tiles = (n + 31) / 32;
   float g_sc = 1.f, g_inv = 1.f;
   if (PLANES) { g_sc = gfn_grad_scale_of(gmax_dev[0]); g_inv = 1.0f / g_sc; }
-  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+  constexpr int kWaves = bwd_threads<PLANES, SCATTER>() / 64;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWaves) {
     const int64_t s = tile * 32 + j;
     const bool valid = s < n;
     const int64_t q = valid ? s : n - 1;
@@ -178,11 +264,13 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
       dz3[c] = g * y * (1.f - y);  // sigmoid'
       any_grad = any_grad || g != 0.f;
     }
-    float4* dst = reinterpret_cast<float4*>(dfeat + s * 32);
+    float4* dst = SCATTER ? nullptr : reinterpret_cast<float4*>(dfeat + s * 32);
     if (!__any(any_grad)) {  // wave-uniform: the whole tile lies behind its rays' termination points
       if (valid) {
+        if (!SCATTER) {
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) dst[2 * qd + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int qd = 0; qd < 4; qd++) dst[2 * qd + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (PLANES) {  // zero this sample's rows of the five gradient planes (lane half h: its half of each row)
           const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -295,7 +383,19 @@ __global__ __launch_bounds__(512) void field_bwd_dx_x3_kernel(
     acc_init_zero(gf);
 #pragma unroll
     for (int u = 0; u < 8; u++) mma3(gf, Ihi, Ilo, D_GB0 + u, lane, ga[u >> 1].hi[u & 1], ga[u >> 1].lo[u & 1]);
-    if (valid) {
+    if (SCATTER) {
+      // registers (2a, 2a+1) of the tile = channels (0, 1) of level 2h + (a & 1) + 4 (a >> 1) of sample j
+      const uint32_t T = 1u << S.log2_T;
+      const float px = S.pts[3 * q], py = S.pts[3 * q + 1], pz = S.pts[3 * q + 2];
+      const int64_t vol = (int64_t)S.anchors[3 * q];
+#pragma unroll
+      for (int a = 0; a < 8; a++) {
+        const int level = 2 * h + (a & 1) + 4 * (a >> 1);
+        const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
+        if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
+        else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
+      }
+    } else if (valid) {
 #pragma unroll
       for (int qd = 0; qd < 4; qd++)  // rows 8qd+4h .. +3
         dst[2 * qd + h] = make_float4(acc_get(gf, 4 * qd) * inv, acc_get(gf, 4 * qd + 1) * inv, acc_get(gf, 4 * qd + 2) * inv,
@@ -389,31 +489,50 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   return GFN_OK;
 }
 
+struct ScatterHost {  // optional: scatter d feat into a table gradient pool instead of writing it
+  const float* pts = nullptr; const int32_t* anchors = nullptr; const int32_t* prim_pool = nullptr; const float* bias_pool = nullptr;
+  int64_t n_volumes = 0; int log2_T = 0; void* grad_pool = nullptr; int grad_f16 = 0;
+};
+
 static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                              const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
-                             const int32_t* cam_idx, float* demb, void* stream) {
+                             const int32_t* cam_idx, float* demb, const ScatterHost& sh, void* stream) {
   if (n_max == 0) return GFN_OK;
-  GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && dfeat, "%s: null pointer", fn);
+  const bool scatter = sh.grad_pool != nullptr;
+  GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && (dfeat || scatter), "%s: null pointer", fn);
+  GFN_CHECK_ARG(!scatter || (sh.pts && sh.anchors && sh.prim_pool && sh.n_volumes > 0 && sh.n_volumes < (1ll << 26) && sh.log2_T >= 4 && sh.log2_T <= 26),
+                "%s: scatter needs pts, anchors, primes, n_volumes and log2_T", fn);
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "%s: n_max=%lld", fn, (long long)n_max);
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "%s: plane_cap=%lld must be >= n_max and a multiple of 8", fn, (long long)plane_cap);
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(dfeat) | reinterpret_cast<uintptr_t>(planes_hi) |
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
+  constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue
   static bool attr_set = false;
+#define GFN_BWD_ALL(X) X(false, 0) X(false, 1) X(false, 2) X(true, 0) X(true, 1) X(true, 2)
   if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_BWD_BYTES));
+#define GFN_SET(P, SC) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<P, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    GFN_BWD_ALL(GFN_SET)
+#undef GFN_SET
     attr_set = true;
   }
   const unsigned grid = persistent_grid8(n_max);
   const u32x4* img = reinterpret_cast<const u32x4*>(bwd_image);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(masks);
-  if (planes_hi)
-    field_bwd_dx_x3_kernel<true><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev,
-                                                                                           planes_hi, planes_lo, plane_cap, ray_id, cam_idx, demb);
-  else
-    field_bwd_dx_x3_kernel<false><<<grid, 512, GFN_FIELD_X3_BWD_BYTES, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, nullptr,
-                                                                                            nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+  ScatterArgs S;
+  S.pts = sh.pts; S.anchors = sh.anchors; S.prim_pool = sh.prim_pool; S.bias_pool = sh.bias_pool; S.n_volumes = sh.n_volumes; S.log2_T = sh.log2_T;
+  S.grad_pool = sh.grad_pool; S.grad_f16 = sh.grad_f16;
+  gfn_hash_level_scales_host(S.sc.s);
+  const bool planes = planes_hi != nullptr;
+  const int mode = !scatter ? 0 : (sh.grad_f16 ? 1 : 2);
+  if (!planes) { gmax_dev = nullptr; plane_cap = 0; ray_id = nullptr; cam_idx = nullptr; demb = nullptr; }
+#define GFN_LAUNCH(P, SC)                                                                                                        \
+  if (planes == P && mode == SC)                                                                                                 \
+    field_bwd_dx_x3_kernel<P, SC><<<grid, bwd_threads<P, SC>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi, \
+                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S);
+  GFN_BWD_ALL(GFN_LAUNCH)
+#undef GFN_LAUNCH
+#undef GFN_BWD_ALL
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -421,7 +540,23 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
                         const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, void* stream) {
   return field_bwd_x3_impl("gfn_field_bwd_dx_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, nullptr, nullptr, nullptr, 0,
-                           nullptr, nullptr, nullptr, stream);
+                           nullptr, nullptr, nullptr, ScatterHost{}, stream);
+}
+
+int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
+                             const void* bwd_image, int64_t n_max, const int32_t* n_dev, const float* pts, const int32_t* anchors,
+                             const int32_t* prim_pool, const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
+                             const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
+                             const int32_t* cam_idx, float* demb, void* stream) {
+  GFN_CHECK_ARG(n_max == 0 || grad_pool, "gfn_field_bwd_scatter_x3: null gradient pool");
+  GFN_CHECK_ARG(n_max == 0 || (planes_hi == nullptr) == (planes_lo == nullptr), "gfn_field_bwd_scatter_x3: planes need both halves");
+  GFN_CHECK_ARG(n_max == 0 || !planes_hi || gmax_dev, "gfn_field_bwd_scatter_x3: planes need gmax");
+  GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_scatter_x3: demb needs ray_id and cam_idx");
+  ScatterHost sh;
+  sh.pts = pts; sh.anchors = anchors; sh.prim_pool = prim_pool; sh.bias_pool = bias_pool; sh.n_volumes = n_volumes; sh.log2_T = log2_T;
+  sh.grad_pool = grad_pool; sh.grad_f16 = grad_f16;
+  return field_bwd_x3_impl("gfn_field_bwd_scatter_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, nullptr, gmax_dev, planes_hi, planes_lo,
+                           plane_cap, ray_id, cam_idx, demb, sh, stream);
 }
 
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
@@ -431,7 +566,7 @@ int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb,
   GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi && planes_lo), "gfn_field_bwd_x3: gmax and both plane halves are required");
   GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_x3: demb needs ray_id and cam_idx");
   return field_bwd_x3_impl("gfn_field_bwd_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, gmax_dev, planes_hi, planes_lo,
-                           plane_cap, ray_id, cam_idx, demb, stream);
+                           plane_cap, ray_id, cam_idx, demb, ScatterHost{}, stream);
 }
 
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max, const int32_t* n_dev, float* gmax_dev,

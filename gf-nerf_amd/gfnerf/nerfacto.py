@@ -133,6 +133,7 @@ class GFNeRFModel(nn.Module):
                 ctx = self._last_ctx()
                 nat.last_packed = ctx["samples"]
                 nat.UpdateOctNodes(None, None, ctx["comp"]["weights"], ctx["comp"]["alphas"], step)
+                self._relink_tree()  # ProcOctree (milestones / compact_freq) replaces the node blob
             else:
                 nat.UpdateMode(1)                                       # :616
             return outputs
@@ -141,6 +142,13 @@ class GFNeRFModel(nn.Module):
             out = self.hot.render(o, d, cam, noise, block=use_block)
         assert float(out["oct_depth"].min()) > 0 or o.shape[0] == 0    # nerfacto.py:556
         return {"rgb": out["rgb"], "accumulation": out["accumulation"], "depth": out["depth"], "oct_depth": out["oct_depth"]}
+
+    def _relink_tree(self):
+        """The sampler object owns the tree; the engine samples from the same blob and 64-byte image."""
+        nat = self.persampler.sampler
+        if self.hot.nodes is not nat.tree_nodes_gpu_ or self.hot.nodes_compact is not nat.nodes_compact_:
+            self.hot.nodes, self.hot.nodes_compact, self.hot.n_nodes = nat.tree_nodes_gpu_, nat.nodes_compact_, nat.n_nodes
+            self.hot._sampler_ws = None
 
     def _last_ctx(self):
         return self.hot._last_train_ctx

@@ -42,6 +42,7 @@ class HotPathConfig:
     s3im_patch_height: int = 32      # config.py:100
     s3im_repeat_time: int = 10       # config.py:99
     fused_forward: bool = True       # lookup + decoder + compositing in one persistent kernel that leaves a ray once it is opaque
+    fused_backward: bool = True      # decoder backward + hash scatter in one kernel (d feat never written)
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
@@ -308,8 +309,15 @@ class HotPath:
             ops.fill_zero(self._gmax)
             self._timed("field_bwd", ops.grad_max, d_sigma, d_rgb, f["h0"], self._gmax, n_dev=n_dev)
             demb = self.emb_grad if c.use_appearance_embedding else None
-            dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
-                                bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+            scattered = c.fused_backward
+            if scattered:
+                self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                            s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
+                            gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+                dfeat = None
+            else:
+                dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
+                                    bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
             g = self.layer_grads
             fv = lambda k: (ops.plane_view(fp[0], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE),  # noqa: E731
                             ops.plane_view(fp[1], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE))
@@ -320,6 +328,11 @@ class HotPath:
                                           (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None)):
                 self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
                             gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
+        elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
+            self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                        s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
+                        self.table_grad, n_dev=n_dev)
+            dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision
             dfeat = self._timed("field_bwd", ops.field_bwd_dx, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self.layers, n_dev=n_dev,
@@ -336,6 +349,8 @@ class HotPath:
             da1, _, _ = self._timed("base_bwd", ops.linear_bwd, f["a1"], bW1, f["h"], dh, "none", dW=gw(1)[0], db=gw(1)[1], need_dw=train_mlp, n_dev=n_dev)
             dfeat, _, _ = self._timed("base_bwd", ops.linear_bwd, f["feat"], bW0, f["a1"], da1, "relu", dW=gw(0)[0], db=gw(0)[1], need_dw=train_mlp, n_dev=n_dev)
         # both tables see the same d(feat) (sum of two lookups); only the trainable one is scattered, through ITS primes
+        if dfeat is None:
+            return  # already scattered by the fused kernel
         prim = self.prim if train_mlp else self.block_prims[ctx["block"]]
         self._timed("hash_bwd", ops.hash_bwd, prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)

@@ -635,6 +635,30 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
     return out
 
 
+def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, prim_pool, bias_pool, n_volumes, log2_T, grad_pool,
+                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None):
+    """Decoder backward + hash scatter in one kernel: accumulates into grad_pool (f16 x128-scaled or f32, like hash_bwd); with
+    planes / gmax (global stage) it also writes the dz planes for wgrad_x3 and the appearance-embedding gradient."""
+    _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
+    _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6); _chk(image, torch.uint8, "image")
+    _chk(pts, torch.float32, "pts", 3); _chk(anchors, torch.int32, "anchors", 3); _chk(prim_pool, torch.int32, "prim_pool")
+    _chk(bias_pool, torch.float32, "bias_pool"); _chk(gmax, torch.float32, "gmax")
+    _chk(ray_id, torch.int32, "ray_id"); _chk(cam_idx, torch.int32, "cam_idx"); _chk(demb, torch.float32, "demb", 32)
+    if grad_pool.dtype not in (torch.float16, torch.float32) or grad_pool.numel() != 16 * (1 << log2_T) * 2:
+        raise _lib.GfnError("grad_pool must be an f16 or f32 tensor of 16*T*2 elements")
+    if image.numel() != FIELD_X3_BWD_BYTES or prim_pool.numel() != 16 * n_volumes * 3:
+        raise _lib.GfnError("weight image or prim_pool of the wrong size")
+    n = d_sigma.shape[0]
+    ph, pl = planes if planes is not None else (None, None)
+    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
+    rc = _lib.lib().gfn_field_bwd_scatter_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev), _ptr(pts),
+                                             _ptr(anchors), _ptr(prim_pool), _ptr(bias_pool), n_volumes, log2_T, _ptr(grad_pool),
+                                             int(grad_pool.dtype == torch.float16), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id),
+                                             _ptr(cam_idx), _ptr(demb), _stream())
+    _lib.check(rc, "gfn_field_bwd_scatter_x3")
+    return grad_pool
+
+
 def sh4(dirs):
     _chk(dirs, torch.float32, "dirs", 3)
     out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)

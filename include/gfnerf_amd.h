@@ -269,6 +269,16 @@ int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb,
                      float* dfeat, const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo,
                      int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx, float* demb,
                      void* stream);
+/* Decoder backward + hash scatter in one kernel: d feat never leaves the chip -- each lane of the d-feat
+ * tile hashes 8 levels of its sample and adds into grad_pool (same quantisation / accumulation rules as
+ * gfn_hash_bwd; grad_f16 as there; pts / anchors [n,3] i32 / prim_pool of the table being trained).
+ * planes_* / gmax_dev / ray_id / cam_idx / demb as in gfn_field_bwd_x3 (all NULL in the focal stage). */
+int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
+                             const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
+                             const float* pts, const int32_t* anchors, const int32_t* prim_pool,
+                             const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
+                             const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap,
+                             const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* stream);
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);
