@@ -484,8 +484,8 @@ int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
 }
 
 int gfn_depth_finalize(float* depth, int64_t n_rays, const float* t_minmax, float scale_factor, void* stream) {
-  GFN_CHECK_ARG(depth && t_minmax && n_rays >= 0 && scale_factor != 0.f, "gfn_depth_finalize: bad arguments");
-  if (n_rays == 0) return GFN_OK;
+  if (n_rays == 0) return GFN_OK;  // empty batch: pointers may be null
+  GFN_CHECK_ARG(depth && t_minmax && n_rays > 0 && scale_factor != 0.f, "gfn_depth_finalize: bad arguments");
   depth_finalize_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, gfn_stream(stream)>>>(depth, n_rays, t_minmax, scale_factor);
   GFN_CHECK_LAUNCH();
   return GFN_OK;

@@ -337,3 +337,43 @@ def test_fused_forward_pair_table(setup):
     for _ in range(4):
         l1, _ = hp.train_step(t(S["o"]), t(S["d"]), cam, gt, t(S["noise"]), stage="focal", block=0)
     assert l1.item() < l0.item()
+
+
+def test_fused_paths_edge_cases(setup):
+    """Rays that miss the scene (no samples), rays that hit the 1024-sample cap, an all-miss batch and an empty batch
+    through the fused forward / backward; every output stays finite and rays without samples render black."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    hp, t, sc = S["hp"], S["t"], S["sc"]
+    R = 96
+    o = S["o"][:R].copy(); d = S["d"][:R].copy(); cam = S["cam"][:R].copy()
+    o[::3] = np.array([0.0, 0.0, 4000.0], np.float32)          # far above the octree's bounding box ...
+    d[::3] = np.array([0.0, 0.0, 1.0], np.float32)             # ... looking away: no leaf is ever hit
+    from gfnerf_amd import scene
+    noise = t(scene.make_noise(R, True, 0.25, seed=5))          # tiny steps: the rays that do hit run into the 1024 cap
+    out = hp.render(t(o), t(d), t(cam), noise, block=0, early_T=0.0)
+    po = out["samples"]["pts_offsets"].cpu().numpy()
+    cnt = np.diff(po)
+    assert np.all(cnt[::3] == 0) and cnt.max() == 1024
+    rgb = out["rgb"].cpu().numpy()
+    assert np.isfinite(rgb).all() and np.all(rgb[::3] == 0) and np.all(out["accumulation"].cpu().numpy()[::3] == 0)
+    ref = S["opipe"].render(S["P"], o, d, cam, noise.cpu().numpy(), S["cfg"].log2_T, block=0, early_T=0.0, scale_factor=S["cfg"].scale_factor)
+    assert np.array_equal(po.astype(np.int64), ref["samples"]["pts_offsets"])
+    np.testing.assert_allclose(rgb, ref["rgb"], atol=1e-3)
+    # training step on the same batch (fused backward): finite loss and gradients
+    gt = t(S["gt"][:R])
+    loss, aux = hp.forward_backward(t(o), t(d), t(cam), gt, noise, stage="focal", block=0)
+    assert np.isfinite(loss.item()) and torch.isfinite(hp.table_grad.float()).all()
+    # every ray misses
+    o2 = np.tile(np.array([[0.0, 0.0, 4000.0]], np.float32), (R, 1)); d2 = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (R, 1))
+    out2 = hp.render(t(o2), t(d2), t(cam), noise, block=None)
+    assert int(out2["samples"]["pts_offsets"][-1].item()) == 0 and float(out2["rgb"].abs().max()) == 0.0
+    loss2, _ = hp.forward_backward(t(o2), t(d2), t(cam), gt, noise, stage="global")
+    assert np.isfinite(loss2.item()) and float(hp.table_grad.float().abs().max()) == 0.0
+    # empty batch
+    e3 = torch.zeros((0, 3), device="cuda"); c3 = torch.zeros(0, dtype=torch.int32, device="cuda")
+    out3 = hp.render(e3, e3, c3, noise, block=0)
+    assert out3["rgb"].shape == (0, 3)
