@@ -240,7 +240,11 @@ def main():
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             traffic = pmc.get(f"{dom}:{args.stage}")
-            n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests")
+            # the PMC pass was taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21, 400 cameras)
+            default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == 20
+            if not default_cfg:
+                traffic = None
+            n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests") if default_cfg else None
             if n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
                 req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
                            frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
