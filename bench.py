@@ -130,10 +130,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (not used by the driver): several ranks on ONE card need the gloo backend (RCCL refuses duplicate GPUs)
+    backend = os.environ.get("GFN_BENCH_BACKEND", "nccl")
+    if "GFN_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["GFN_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -153,7 +160,8 @@ def main():
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
                                 mlp_precision=args.mlp_precision)
-    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks)
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
+                         device=f"cuda:{local_rank if world > 1 else 0}")
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
         g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
         b.uniform_(-1e-3, 1e-3, generator=g)
@@ -203,7 +211,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     n_live = aux["samples"]["pts_offsets"][-1].item()
