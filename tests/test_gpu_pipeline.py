@@ -377,3 +377,51 @@ def test_fused_paths_edge_cases(setup):
     e3 = torch.zeros((0, 3), device="cuda"); c3 = torch.zeros(0, dtype=torch.int32, device="cuda")
     out3 = hp.render(e3, e3, c3, noise, block=0)
     assert out3["rgb"].shape == (0, 3)
+
+
+def test_training_trajectory_matches_oracle_psnr(setup):
+    """North-star gate 'PSNR within 0.1 dB of the reference path': the same 12 Adam steps (global stage: table, both MLPs
+    and the embedding train; Charbonnier + S3IM; f16 x128 gradient pool like the reference) on the HIP path and on the
+    CPU oracle from identical parameters, noise and S3IM permutations."""
+    import torch
+
+    from gfnerf_amd import hotpath
+
+    S = setup
+    sc, t, opipe = S["sc"], S["t"], S["opipe"]
+    import oracle as O
+
+    cfg = hotpath.HotPathConfig(log2_T=12, early_T=0.0)
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=5)
+    hp.table.mul_(30.0)
+    hp.refresh_shadows()
+    P = hp.export_params()
+    R = 128
+    o, d, cam, gt = S["o"][:R], S["d"][:R], S["cam"][:R], S["gt"][:R]
+    noise = S["noise"][: 1024 + R + 10].copy()
+    rng = np.random.default_rng(23)
+    # oracle state
+    names = ["bW0", "bb0", "bW1", "bb1", "hW0", "hb0", "hW1", "hb1", "hW2", "hb2"]
+    params = {"table": P["table"].copy(), "emb": P["emb"].copy()}
+    for i, (W, b) in enumerate(P["layers"]):
+        params[names[2 * i]], params[names[2 * i + 1]] = W.copy(), b.copy()
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in params.items()}
+    psnr_gpu, psnr_cpu, loss_gpu, loss_cpu = [], [], [], []
+    n_steps = 12
+    for step in range(1, n_steps + 1):
+        s3 = np.concatenate([np.arange(R)] + [rng.permutation(R) for _ in range(9)]).astype(np.int32)
+        loss, aux = hp.train_step(t(o), t(d), t(cam), t(gt), t(noise), stage="global", s3im_index=t(s3))
+        rgb = aux["comp"]["rgb"].cpu().numpy()
+        psnr_gpu.append(-10 * np.log10(np.mean((rgb - gt) ** 2))); loss_gpu.append(loss.item())
+        Pc = dict(P, table=params["table"], emb=params["emb"], layers=[(params[names[2 * i]], params[names[2 * i + 1]]) for i in range(5)])
+        l, g, ra = opipe.loss_and_grads(Pc, o, d, cam, gt, noise, cfg.log2_T, s3im_index=s3, s3im_mult=cfg.s3im_loss_mult)
+        psnr_cpu.append(-10 * np.log10(np.mean((ra["comp"]["rgb"] - gt) ** 2))); loss_cpu.append(l)
+        for k in params:
+            m, v = mom[k]
+            O.adam_step(params[k].reshape(-1), np.ascontiguousarray(g[k], np.float32).reshape(-1), m.reshape(-1), v.reshape(-1), step,
+                        lr=cfg.lr, eps=cfg.adam_eps)
+    psnr_gpu, psnr_cpu = np.asarray(psnr_gpu), np.asarray(psnr_cpu)
+    assert psnr_cpu[-1] > psnr_cpu[0] + 0.5, psnr_cpu                      # it does train
+    assert np.abs(psnr_gpu - psnr_cpu).max() < 0.1, (psnr_gpu, psnr_cpu)    # every step within 0.1 dB
+    np.testing.assert_allclose(loss_gpu, loss_cpu, rtol=5e-3)
+    np.testing.assert_allclose(hp.layers[4][0].cpu().numpy(), params["hW2"], atol=3e-3)
