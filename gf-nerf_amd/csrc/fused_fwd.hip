@@ -71,13 +71,24 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
   const uint32_t T = 1u << A.log2_T;
   const float early_T = A.early_T;
 
-  // every wave leaves after at most n_rays + 1 fetches and a ray has at most 1024 / 32 tiles: bounded loops, so the grid
-  // always drains
-  for (int fetch = 0; fetch <= A.n_rays; fetch++) {
-    int ray = 0;
-    if (lane == 0) ray = atomicAdd(A.counter, 1);
-    ray = __shfl(ray, 0, 64);
-    if (ray >= A.n_rays) break;  // wave-uniform
+  // Rays are handed out through 8 atomic counters, one per eighth of the batch; a workgroup starts on the eighth of its
+  // XCD group (blockIdx % 8 labels the workgroups that share an XCD and its L2) and steals from the others when that runs
+  // dry.  Training batches are random rays, where it makes no difference; a render tile is a block of neighbouring pixels
+  // whose rays cross the same cells, and this keeps their table lines in ONE L2 instead of eight.
+  // Bounded loops (<= n_rays + 8 fetches per wave, <= 1024 / 32 tiles per ray): the grid always drains.
+  const int seg_len = (A.n_rays + 7) / 8;
+  int seg_k = 0, fetches = 0;
+  for (;;) {
+    if (seg_k >= 8 || fetches > A.n_rays + 8) break;
+    const int seg = ((int)(blockIdx.x & 7) + seg_k) & 7;
+    const int seg_lo = seg * seg_len;
+    const int seg_n = min(seg_len, A.n_rays - seg_lo);
+    int idx = 0;
+    if (lane == 0) idx = seg_n > 0 ? atomicAdd(A.counter + seg, 1) : 0;
+    idx = __shfl(idx, 0, 64);
+    fetches++;
+    if (seg_n <= 0 || idx >= seg_n) { seg_k++; continue; }  // wave-uniform
+    const int ray = seg_lo + idx;
     const int s = A.pts_offsets[ray], e = A.pts_offsets[ray + 1];
     const float* sh_row = A.sh + (int64_t)ray * 16;
     const float* emb_row = A.emb ? A.emb + (int64_t)A.cam_idx[ray] * 32 : nullptr;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
 }
 
 __global__ void fused_init_kernel(int* counter, float* t_minmax) {
-  counter[0] = 0;
+  for (int i = 0; i < 8; i++) counter[i] = 0;
   if (t_minmax) { t_minmax[0] = INFINITY; t_minmax[1] = 0.f; }
 }
 

@@ -623,7 +623,7 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
                rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
     ph, pl = planes if planes is not None else (None, None)
     cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)
-    counter = torch.empty(1, dtype=torch.int32, device=dev)
+    counter = torch.empty(8, dtype=torch.int32, device=dev)
     rc = _lib.lib().gfn_fused_forward(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
                                       _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), int(bool(pair_table)), _ptr(bias_pool), n_volumes, log2_T,
                                       _ptr(image),

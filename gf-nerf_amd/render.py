@@ -19,12 +19,15 @@ def frame_shard(n_frames, world_size, rank):
 
 
 class TileRenderer:
-    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True):
+    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=64):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
         self.hp, self.c2w, self.intr = hp, c2w.contiguous(), intr.contiguous()
         self.T, self.block, self.early_T = int(tile_rays), block, early_T
+        # a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (0 = a raster run): neighbouring rays cross the
+        # same table cells, and the fused forward keeps each eighth of the tile (a strip of rows) on one XCD's L2
+        self.tw = int(tile_width) if tile_width and tile_rays % tile_width == 0 else 0
         dev = hp.dev
         self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + self.T + 10,), float(fineness), dtype=torch.float32, device=dev)
         self.o = torch.zeros((self.T, 3), dtype=torch.float32, device=dev)
@@ -66,18 +69,35 @@ class TileRenderer:
             self.o.copy_(O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))
             self.d.copy_(D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))
             self._capture()
-        for a in range(0, n, T):
-            b = min(a + T, n)
-            m = b - a
-            self.o[:m].copy_(O[a:b]); self.d[:m].copy_(D[a:b])
-            if m < T:  # ragged last tile: repeat the last ray, its outputs are dropped
-                self.o[m:].copy_(O[b - 1:b].expand(T - m, 3)); self.d[m:].copy_(D[b - 1:b].expand(T - m, 3))
+        if self.tw:
+            tw, th = self.tw, T // self.tw
+            O2, D2 = O.view(height, width, 3), D.view(height, width, 3)
+            rgb2, acc2, dep2 = rgb.view(height, width, 3), acc.view(height, width, 1), depth.view(height, width, 1)
+            tiles = [(y, min(y + th, height), x, min(x + tw, width)) for y in range(0, height, th) for x in range(0, width, tw)]
+        else:
+            tiles = [(a, min(a + T, n), 0, 0) for a in range(0, n, T)]
+        for (a, b, x0, x1) in tiles:
+            if self.tw:
+                h, w = b - a, x1 - x0
+                m = h * w
+                if m == T:
+                    self.o.view(h, w, 3).copy_(O2[a:b, x0:x1]); self.d.view(h, w, 3).copy_(D2[a:b, x0:x1])
+                else:  # ragged border tile
+                    self.o[:m].copy_(O2[a:b, x0:x1].reshape(m, 3)); self.d[:m].copy_(D2[a:b, x0:x1].reshape(m, 3))
+            else:
+                m = b - a
+                self.o[:m].copy_(O[a:b]); self.d[:m].copy_(D[a:b])
+            if m < T:  # ragged tile: repeat its last ray, the extra outputs are dropped
+                self.o[m:].copy_(self.o[m - 1:m].expand(T - m, 3)); self.d[m:].copy_(self.d[m - 1:m].expand(T - m, 3))
             if self.use_graph:
                 self.graph.replay()
                 t_rgb, t_acc, t_depth = self.out
             else:
                 t_rgb, t_acc, t_depth = self._tile()
-            rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
+            if self.tw:
+                rgb2[a:b, x0:x1] = t_rgb[:m].view(h, w, 3); acc2[a:b, x0:x1] = t_acc[:m].view(h, w, 1); dep2[a:b, x0:x1] = t_depth[:m].view(h, w, 1)
+            else:
+                rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
         return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width), depth=depth.view(height, width))
 
     def render_path(self, cams, height, width, world_size=1, rank=0):

@@ -311,7 +311,8 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
  * space, anchors i32 [n,3], dt, ts), sh f32 [R,16], emb / cam_idx, a forward weight image.  Per-sample
  * outputs sigma [n], rgb [n,3] (always), h0 + masks (training), weights / alphas / feat [n,32] (optional),
  * activation planes (global stage); per-ray outputs out_rgb [R,3], out_acc, out_depth (un-clipped),
- * t_minmax [2] (for gfn_depth_finalize).  work_counter: one device i32 of scratch. */
+ * t_minmax [2] (for gfn_depth_finalize).  work_counter: 8 device i32 of scratch (one ray queue per
+ * eighth of the batch, drained first by the workgroups of one XCD: neighbouring rays share an L2). */
 int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
                       const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
                       const int32_t* prim_pool, const int32_t* prim_pool2, int pair_table, const float* bias_pool,
