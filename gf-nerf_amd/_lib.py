@@ -18,6 +18,8 @@ SIGNATURES = {
     "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_pair_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "gfn_hash_fwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "gfn_hash_fwd_part_workspace": (_i64, [_i64]),
+    "gfn_hash_fwd_part": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
