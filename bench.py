@@ -121,6 +121,40 @@ def render_bench(hp, sc, args, fineness, torch):
                 mean_accumulation=float(img["accumulation"].mean().item()))
 
 
+def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
+    """SURVEY 8(f) row 3 beside the step it feeds: ErrorPixelSampler draw (20 % by error map, 80 % uniform, without
+    replacement) + pixel gather from a u8 image stack resident in HBM + ray generation + the error-map write-back, per
+    4096-ray batch.  Reported beside the headline number, not folded into it (the metric's batches are resident)."""
+    from gfnerf_amd import data
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev).manual_seed(11)
+    images = torch.randint(0, 256, (n_images, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    em = data.ErrorMap(torch.rand((n_images, H, W, 1), device=dev, generator=gen))
+    c2w = torch.from_numpy(sc["c2w"][:n_images]).to(dev)
+    K = sc["intri"][:n_images]
+    intr = torch.from_numpy(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32)).to(dev)
+    idx = torch.arange(n_images, dtype=torch.int32, device=dev)
+    batch = dict(image=images, image_idx=idx, rel_camera_idx=idx, error_map=em)
+    sampler, rg = data.ErrorPixelSampler(N_RAYS, generator=gen), data.RayGenerator(c2w, intr)
+    pred = torch.rand((N_RAYS, 3), device=dev, generator=gen)
+
+    def one():
+        rays, b, ray_idx = data.next_train(batch, sampler, rg)
+        em.update(torch.cat([b["slot"][:, None], ray_idx[:, 1:3]], 1), pred, b["image"])
+
+    for _ in range(5):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return dict(ms_per_batch=ms, rays=N_RAYS, image_stack=f"{n_images} x {W}x{H} u8 in HBM", sampler="ErrorPixelSampler 20% weighted / 80% uniform",
+                includes="index draw, pixel gather, ray generation, error-map write-back + CDF upkeep", duplicates_left=int(sampler.last_status[1].item()))
+
+
 def main():
     args = parse()
     import torch
@@ -284,6 +318,7 @@ def main():
                    roofline=roofline)
         if args.render_frames > 0:
             out["render"] = render_bench(hp, sc, args, fineness, torch)
+            out["batch_assembly"] = batch_assembly_bench(sc, torch)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
                                                0 if args.stage == "focal" else None, scene)

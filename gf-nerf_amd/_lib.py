@@ -55,6 +55,12 @@ SIGNATURES = {
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gfn_generate_rays": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_pixel_uniform": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "gfn_pixel_collate": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_errmap_block_sums": (_i32, [_vp, _i64, _vp, _vp]),
+    "gfn_errmap_update": (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gfn_errmap_table_slots": (_i64, [_i64]),
+    "gfn_errmap_sample": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_composite_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_depth_finalize": (_i32, [_vp, _i64, _vp, _f32, _vp]),
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),

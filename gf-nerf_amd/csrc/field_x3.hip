@@ -428,6 +428,10 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
 
 int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
 
+}  // namespace
+int gfn_decoder_cu_cap() { return (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256; }
+namespace {
+
 unsigned persistent_grid8(int64_t n_max) {
   int64_t tiles = (n_max + 31) / 32;
   int64_t blocks = (tiles + 7) / 8;

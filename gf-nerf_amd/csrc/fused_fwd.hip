@@ -245,7 +245,8 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_LAUNCH();
   int64_t waves = n_rays;  // one ray at a time per wave
   int64_t blocks = (waves + FUSED_THREADS / 64 - 1) / (FUSED_THREADS / 64);
-  if (blocks > 256) blocks = 256;
+  const int cu_cap = gfn_decoder_cu_cap();  // gfn_set_decoder_cus: leave CUs to kernels of another stream
+  if (blocks > cu_cap) blocks = cu_cap;
   const bool dual = table2_f16 != nullptr, save = masks != nullptr, planes = planes_hi != nullptr;
 #define GFN_LAUNCH(D, S, P) \
   if (dual == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, FUSED_THREADS, FUSED_LDS_BYTES, st>>>(A, sc);

@@ -31,6 +31,9 @@ void gfn_set_error(const char* fmt, ...);
   } while (0)
 #define GFN_CHECK_LAUNCH() GFN_CHECK_HIP(hipGetLastError())
 
+// cap on the workgroups (= CUs) of the persistent decoder kernels (gfn_set_decoder_cus), 256 = every CU; field_x3.hip
+int gfn_decoder_cu_cap();
+
 static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // live element count: device value if given, else the host capacity.

@@ -405,6 +405,97 @@ def generate_rays(c2w, intr, cam_idx=None, coords=None, cam0=0, first_pixel=0, w
     return res
 
 
+# ------------------------------------------------------------------ batch assembly
+ERRMAP_BLOCK, PIXEL_CHUNK, PIXEL_ATTEMPTS = 4096, 1 << 24, 64
+
+
+def pixel_uniform(u, n_images, height, width):
+    """PixelSampler.sample_method without a mask: u f32 [n,3] in [0,1) -> lin i64 [n] = (c*H + y)*W + x."""
+    _chk(u, torch.float32, "u", 3)
+    lin = torch.empty(u.shape[0], dtype=torch.int64, device=u.device)
+    _lib.check(_lib.lib().gfn_pixel_uniform(_ptr(u), u.shape[0], int(n_images), int(height), int(width), _ptr(lin), _stream()), "gfn_pixel_uniform")
+    return lin
+
+
+def pixel_collate(lin, images, image_idx=None, rel_cam_idx=None, shape=None, want_coords=True):
+    """collate_image_dataset_batch for the pixels lin i64 [n] of the cached stack images [n_images,H,W,3] (f32 or u8; None
+    with shape=(n_images,H,W) skips the colour gather) -> dict(indices i32 [n,3] (abs cam, y, x), slot, rel_camera_indices
+    i32 [n], image f32 [n,3], coords f32 [n,2])."""
+    _chk(lin, torch.int64, "lin"); _chk(image_idx, torch.int32, "image_idx"); _chk(rel_cam_idx, torch.int32, "rel_cam_idx")
+    if images is not None:
+        if images.dtype not in (torch.float32, torch.uint8):
+            raise _lib.GfnError("pixel_collate: images must be float32 or uint8")
+        _chk(images, images.dtype, "images", 3)
+        if images.dim() != 4:
+            raise _lib.GfnError("pixel_collate: images must be [n_images,H,W,3]")
+        shape = images.shape[:3]
+    if shape is None:
+        raise _lib.GfnError("pixel_collate: need images or shape")
+    n_img, H, W = (int(v) for v in shape)
+    for t, nm in ((image_idx, "image_idx"), (rel_cam_idx, "rel_cam_idx")):
+        if t is not None and t.numel() != n_img:
+            raise _lib.GfnError(f"pixel_collate: {nm} must have one entry per cached image")
+    n, dev = lin.numel(), lin.device
+    out = dict(indices=torch.empty((n, 3), dtype=torch.int32, device=dev), slot=torch.empty(n, dtype=torch.int32, device=dev),
+               rel_camera_indices=torch.empty(n, dtype=torch.int32, device=dev),
+               image=torch.empty((n, 3), dtype=torch.float32, device=dev) if images is not None else None,
+               coords=torch.empty((n, 2), dtype=torch.float32, device=dev) if want_coords else None)
+    rc = _lib.lib().gfn_pixel_collate(_ptr(lin), n, n_img, H, W, _ptr(images), int(images is not None and images.dtype == torch.uint8),
+                                      _ptr(image_idx), _ptr(rel_cam_idx), _ptr(out["indices"]), _ptr(out["slot"]),
+                                      _ptr(out["rel_camera_indices"]), _ptr(out["image"]), _ptr(out["coords"]), _stream())
+    _lib.check(rc, "gfn_pixel_collate")
+    return out
+
+
+def errmap_block_sums(error_map, out=None):
+    """f64 partial sums per ERRMAP_BLOCK pixels of error_map f32 [n_images,H,W(,1)]."""
+    _chk(error_map, torch.float32, "error_map")
+    n = error_map.numel()
+    nb = (n + ERRMAP_BLOCK - 1) // ERRMAP_BLOCK
+    if out is None:
+        out = torch.empty(nb, dtype=torch.float64, device=error_map.device)
+    _chk(out, torch.float64, "block_sums")
+    if out.numel() != nb:
+        raise _lib.GfnError("errmap_block_sums: wrong number of partial sums")
+    _lib.check(_lib.lib().gfn_errmap_block_sums(_ptr(error_map), n, _ptr(out), _stream()), "gfn_errmap_block_sums")
+    return out
+
+
+def errmap_update(error_map, block_sums, indices, pred, gt):
+    """CacheDataloader._update_error_map with error = |gt - pred|.sum(-1): error_map [n_images,H,W(,1)] in place."""
+    _chk(error_map, torch.float32, "error_map"); _chk(block_sums, torch.float64, "block_sums"); _chk(indices, torch.int32, "indices", 3)
+    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3)
+    n = indices.shape[0]
+    if pred.shape[0] != n or gt.shape[0] != n or error_map.dim() < 3:
+        raise _lib.GfnError("errmap_update: one (c, y, x) row per ray and an error map [n_images,H,W]")
+    n_img, H, W = error_map.shape[:3]
+    if block_sums is not None and block_sums.numel() != (error_map.numel() + ERRMAP_BLOCK - 1) // ERRMAP_BLOCK:
+        raise _lib.GfnError("errmap_update: block_sums does not belong to this error map")
+    _lib.check(_lib.lib().gfn_errmap_update(_ptr(indices), n, _ptr(pred), _ptr(gt), n_img, H, W, _ptr(error_map), _ptr(block_sums), _stream()),
+               "gfn_errmap_update")
+
+
+def errmap_sample(error_map, block_sums, bits, n_weighted, workspace=None):
+    """ErrorPixelSampler.sample_method: bits i64 [n] random -> (lin i64 [n], status i32 [2], workspace)."""
+    _chk(error_map, torch.float32, "error_map"); _chk(block_sums, torch.float64, "block_sums"); _chk(bits, torch.int64, "bits")
+    n, npix, dev = bits.numel(), error_map.numel(), error_map.device
+    nb = (npix + ERRMAP_BLOCK - 1) // ERRMAP_BLOCK
+    if block_sums.numel() != nb:
+        raise _lib.GfnError("errmap_sample: block_sums does not belong to this error map")
+    slots = _lib.lib().gfn_errmap_table_slots(max(int(n_weighted), n - int(n_weighted)))
+    ws = workspace or {}
+    if ws.get("key") != (n, nb, slots):
+        ws = dict(key=(n, nb, slots), prefix=torch.empty(nb + 1, dtype=torch.float64, device=dev),
+                  cand=torch.empty(n, dtype=torch.int64, device=dev), pending=torch.empty(max(n, 1), dtype=torch.int32, device=dev),
+                  table=torch.empty(slots * 2, dtype=torch.int64, device=dev) if slots * 16 > 128 * 1024 else None)
+    lin = torch.empty(n, dtype=torch.int64, device=dev)
+    status = torch.empty(2, dtype=torch.int32, device=dev)
+    rc = _lib.lib().gfn_errmap_sample(_ptr(error_map), npix, _ptr(block_sums), _ptr(bits), n, int(n_weighted), _ptr(ws["prefix"]), _ptr(ws["cand"]),
+                                      _ptr(ws["pending"]), _ptr(ws["table"]), _ptr(lin), _ptr(status), _stream())
+    _lib.check(rc, "gfn_errmap_sample")
+    return lin, status, ws
+
+
 # ---------------------------------------------------------------------------- MLP
 ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 

@@ -384,6 +384,50 @@ int gfn_composite_bwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
                       float early_T, float* d_sigma, float* d_rgb, void* stream);
 
 /* ====================================================================== *
+ * Batch assembly (upstream of ray generation): PixelSampler /
+ * ErrorPixelSampler (nerfstudio/data/pixel_samplers.py:47-117,636-723) and the error-map upkeep
+ * (gfnerf/gf_pipeline.py:180-185 -> nerfstudio/data/utils/dataloaders.py:140-142).  Images, error map
+ * and its two-level CDF stay in HBM; random numbers are INPUTS, so every call is a pure function.
+ * A pixel is addressed by lin = (c * H + y) * W + x over the cached image stack [n_images,H,W].
+ * ====================================================================== */
+#define GFN_ERRMAP_BLOCK 4096      /* pixels per f64 partial sum of the error-map CDF */
+#define GFN_PIXEL_CHUNK (1 << 24)  /* weighted_choice_multinomial's chunk (pixel_samplers.py:639) */
+#define GFN_PIXEL_ATTEMPTS 64      /* redraws of a duplicate before it is kept (and counted in status[1]) */
+
+/* PixelSampler.sample_method without a mask (:63-67): lin[i] of floor(u[i] * (n_images, H, W)), u f32 [n,3]
+ * in [0,1) (f32 product like torch's; clamped where the reference would index out of range). */
+int gfn_pixel_uniform(const float* u, int64_t n, int32_t n_images, int32_t height, int32_t width, int64_t* lin,
+                      void* stream);
+/* collate_image_dataset_batch (:73-103) + RayGenerator's coordinate lookup (ray_generators.py:47-52) for the
+ * pixels lin i64 [n].  images: f32 [n_images,H,W,3], or u8 (images_u8 != 0; converted as u8 / 255.0f like the
+ * dataset does); image_idx / rel_cam_idx i32 [n_images] (NULL = identity).  Outputs, each may be NULL:
+ * indices i32 [n,3] = (image_idx[c], y, x); slot i32 [n] = c; rel_cam i32 [n] = rel_cam_idx[c];
+ * gt f32 [n,3]; coords f32 [n,2] = (y + 0.5, x + 0.5), the form gfn_generate_rays takes. */
+int gfn_pixel_collate(const int64_t* lin, int64_t n, int32_t n_images, int32_t height, int32_t width,
+                      const void* images, int32_t images_u8, const int32_t* image_idx,
+                      const int32_t* rel_cam_idx, int32_t* indices, int32_t* slot, int32_t* rel_cam, float* gt,
+                      float* coords, void* stream);
+/* block_sums f64 [ceil(n_pixels / GFN_ERRMAP_BLOCK)] of error_map f32 [n_pixels], from scratch. */
+int gfn_errmap_block_sums(const float* error_map, int64_t n_pixels, double* block_sums, void* stream);
+/* error_map[c,y,x] = |gt - pred| summed over rgb for indices i32 [n,3] = (c, y, x) (out-of-range rows are
+ * skipped); block_sums (may be NULL) follows by the exact f64 difference. */
+int gfn_errmap_update(const int32_t* indices, int64_t n, const float* pred, const float* gt, int32_t n_images,
+                      int32_t height, int32_t width, float* error_map, double* block_sums, void* stream);
+/* ErrorPixelSampler.sample_method (:676-723): draws [0, n_weighted) follow weighted_choice_multinomial
+ * (probability proportional to error_map, without replacement, per-2^24-pixel-chunk quota and left-over rule
+ * of :636-674), draws [n_weighted, n) are uniform without replacement; the two groups are independent.
+ * bits i64 [n]: 64 random bits per draw (attempt a of draw d uses splitmix64(bits[d] + (a+1) * golden)).
+ * Workspaces: prefix_ws f64 [blocks + 1], cand_ws i64 [n], pending_ws i32 [n], table_ws 16 B x
+ * gfn_errmap_table_slots(larger group) (may be NULL when that is <= 128 KiB: the set then lives in LDS).
+ * Out: lin i64 [n]; status i32 [2] = {weighted draws whose range had zero total weight (torch.multinomial
+ * raises; drawn uniformly here), duplicates left after GFN_PIXEL_ATTEMPTS redraws (a map with nearly all of
+ * its weight on fewer pixels than draws)}. */
+int64_t gfn_errmap_table_slots(int64_t n);
+int gfn_errmap_sample(const float* error_map, int64_t n_pixels, const double* block_sums, const int64_t* bits,
+                      int64_t n, int64_t n_weighted, double* prefix_ws, int64_t* cand_ws, int32_t* pending_ws,
+                      void* table_ws, int64_t* lin, int32_t* status, void* stream);
+
+/* ====================================================================== *
  * Loss + optimiser (nerfstudio losses.py:73-84,
  * torch.optim.Adam as configured in gfnerf/config.py:130)
  * ====================================================================== */

@@ -43,8 +43,9 @@ def _install_stubs():
     stub("wandb")
     stub("torch.utils.tensorboard", SummaryWriter=object)
     # cameras.py imports cv2 / torchvision for Cameras.to_json (JPEG thumbnails) only; generate_rays never touches them
+    # (data_utils.py names cv2.INTER_NEAREST as a default argument of its depth-image loader, never called here)
     for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
-        stub(name)
+        stub(name, INTER_NEAREST=0)
 
 
 def gen_mlp(out):
@@ -263,13 +264,74 @@ def gen_s3im(out):
     out["s3im_loss"] = np.asarray(loss.item(), np.float64); out["s3im_gpred"] = pred.grad.numpy()
 
 
+def gen_pixel_samplers(out):
+    """SURVEY 8(f) row 3, batch assembly: PixelSampler / ErrorPixelSampler (nerfstudio/data/pixel_samplers.py:26-209,594-844)
+    and CacheDataloader._update_error_map (nerfstudio/data/utils/dataloaders.py:140-142) fed the error of
+    gfnerf/gf_pipeline.py:181-184.  The uniform sampler's torch.rand draws are re-drawn from the same seed so the fixture
+    carries them; the weighted sampler is captured as inclusion counts over many seeded calls (its random streams --
+    torch.multinomial + Python's random.sample -- cannot be injected)."""
+    import random
+
+    from nerfstudio.data.pixel_samplers import ErrorPixelSampler, PixelSampler
+    from nerfstudio.data.utils.dataloaders import CacheDataloader
+
+    g = torch.Generator().manual_seed(5)
+    n, H, W, B = 5, 12, 17, 96
+    batch = dict(image=torch.rand(n, H, W, 3, generator=g), image_idx=torch.tensor([7, 3, 9, 0, 4]), rel_camera_idx=torch.tensor([2, 1, 4, 0, 3]))
+    ps = PixelSampler(B)
+    torch.manual_seed(123)
+    got = ps.sample(batch)
+    torch.manual_seed(123)
+    u = torch.rand((B, 3))
+    out["pix_image"] = batch["image"].numpy(); out["pix_image_idx"] = batch["image_idx"].numpy().astype(np.int32)
+    out["pix_rel_idx"] = batch["rel_camera_idx"].numpy().astype(np.int32); out["pix_u"] = u.numpy()
+    out["pix_indices"] = got["indices"].numpy().astype(np.int32); out["pix_gt"] = got["image"].numpy()
+    out["pix_rel"] = got["rel_camera_indices"].numpy().astype(np.int32)
+    # the same arithmetic at Rubble-scale extents (f32 rounding of u * extent)
+    torch.manual_seed(321)
+    big = ps.sample_method(4096, 1600, 864, 1152)
+    torch.manual_seed(321)
+    out["pix_big_u"] = torch.rand((4096, 3)).numpy(); out["pix_big_indices"] = big.numpy().astype(np.int32)
+
+    # weighted sampler: 2048 pixels, four heavy ones (without replacement shows as saturation), a zero-weight region
+    n, H, W, B = 4, 16, 32, 40
+    em = torch.rand(n, H, W, 1, generator=g) * 0.05
+    em[1, :, 16:] = 0.0
+    for (c, y, x) in ((0, 3, 5), (2, 9, 30), (3, 0, 0), (3, 15, 31)):
+        em[c, y, x, 0] = 20.0
+    eps = ErrorPixelSampler(B)
+    calls = 1500
+    cnt_w = np.zeros(n * H * W, np.int64); cnt_u = np.zeros(n * H * W, np.int64)
+    k_w = int(B * eps.weighted_choice_ratio)
+    for k in range(calls):
+        torch.manual_seed(1000 + k); random.seed(1000 + k)
+        idx = eps.sample_method(B, n, H, W, error_map=em, device="cpu")
+        lin = ((idx[:, 0] * H + idx[:, 1]) * W + idx[:, 2]).numpy()
+        assert len(set(lin[:k_w])) == k_w and len(set(lin[k_w:])) == B - k_w
+        np.add.at(cnt_w, lin[:k_w], 1); np.add.at(cnt_u, lin[k_w:], 1)
+    out["errpix_map"] = em.numpy(); out["errpix_cfg"] = np.asarray([B, k_w, calls], np.int64)
+    out["errpix_count_weighted"] = cnt_w; out["errpix_count_uniform"] = cnt_u
+
+    # error-map write
+    class _Loader:
+        cached_collated_batch = {"error_map": em.clone()}
+    R = 64
+    ray_idx = torch.stack([torch.randint(0, n, (R,), generator=g), torch.randint(0, H, (R,), generator=g), torch.randint(0, W, (R,), generator=g)], 1)
+    pred, gt = torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+    error = torch.abs(gt - pred)          # gf_pipeline.py:183
+    error = torch.sum(error, dim=-1)      # :184
+    CacheDataloader._update_error_map(_Loader, ray_idx, error)
+    out["errupd_indices"] = ray_idx.numpy().astype(np.int32); out["errupd_pred"] = pred.numpy(); out["errupd_gt"] = gt.numpy()
+    out["errupd_map_after"] = _Loader.cached_collated_batch["error_map"].numpy()
+
+
 def main():
     assert os.path.isdir(REF), "reference tree not mounted; fixtures can only be regenerated in the build container"
     _install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(1)
     out = {}
-    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam, gen_rays, gen_scheduler, gen_s3im):
+    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam, gen_rays, gen_scheduler, gen_s3im, gen_pixel_samplers):
         fn(out)
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)

@@ -159,8 +159,9 @@ def test_matrix_kernels_do_not_spill():
         assert r.returncode == 0, r.stderr[-2000:]
         return r.stderr
 
-    with cf.ThreadPoolExecutor(3) as ex:
-        outs = dict(zip(("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip"), ex.map(remarks, ("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip"))))
+    srcs = ("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip", "batch.hip")
+    with cf.ThreadPoolExecutor(4) as ex:
+        outs = dict(zip(srcs, ex.map(remarks, srcs)))
     for src, text in outs.items():
         spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", text)]
         scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]

@@ -162,3 +162,79 @@ def test_s3im_matches_reference(oracle, golden):
     loss, d = oracle.s3im(g["s3im_image"], g["s3im_pred"], g["s3im_index"], patch_h=32)
     np.testing.assert_allclose(loss, float(g["s3im_loss"]), rtol=2e-5)
     np.testing.assert_allclose(d, g["s3im_gpred"], rtol=2e-3, atol=2e-6)
+
+
+# ------------------------------------------------------------------ batch assembly
+def _obatch():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import batch  # oracle/batch.py
+
+    return batch
+
+
+def test_pixel_sampler_matches_reference(golden):
+    """PixelSampler.sample_method + collate_image_dataset_batch: indices, colours and relative camera indices exactly."""
+    ob, g = _obatch(), golden
+    n, H, W = g["pix_image"].shape[:3]
+    lin = ob.pixel_uniform(g["pix_u"], n, H, W)
+    c = ob.pixel_collate(lin, g["pix_image"], g["pix_image_idx"], g["pix_rel_idx"])
+    assert np.array_equal(c["indices"], g["pix_indices"])
+    assert np.array_equal(c["image"], g["pix_gt"])
+    assert np.array_equal(c["rel_camera_indices"], g["pix_rel"])
+    assert np.array_equal(c["coords"], g["pix_indices"][:, 1:3].astype(np.float32) + 0.5)
+    # Rubble-scale extents: the f32 product u * extent rounds like torch's
+    lin = ob.pixel_uniform(g["pix_big_u"], 1600, 864, 1152)
+    big = np.stack([lin // (864 * 1152), (lin // 1152) % 864, lin % 1152], 1)
+    assert np.array_equal(big, g["pix_big_indices"])
+    # u8 images are converted like the dataset does
+    img8 = (g["pix_image"] * 255).astype(np.uint8)
+    c8 = ob.pixel_collate(lin[:0], img8)
+    assert c8["image"].shape == (0, 3)
+    c8 = ob.pixel_collate(ob.pixel_uniform(g["pix_u"], n, H, W), img8)
+    assert np.array_equal(c8["image"], img8.reshape(-1, 3)[ob.pixel_uniform(g["pix_u"], n, H, W)].astype(np.float32) / np.float32(255))
+
+
+def test_error_map_update_matches_reference(golden):
+    ob, g = _obatch(), golden
+    em = g["errpix_map"].copy()
+    ob.errmap_update(em, g["errupd_indices"], g["errupd_pred"], g["errupd_gt"])
+    # duplicate indices: the reference's index_put keeps one of the writers, which one is unspecified -> compare where unique
+    idx = g["errupd_indices"]
+    lin = (idx[:, 0] * em.shape[1] + idx[:, 1]) * em.shape[2] + idx[:, 2]
+    uniq, counts = np.unique(lin, return_counts=True)
+    dup = np.isin(np.arange(em.size), uniq[counts > 1])
+    assert np.array_equal(em.reshape(-1)[~dup], g["errupd_map_after"].reshape(-1)[~dup])
+
+
+def _inclusion_z(count, calls, p_incl):
+    """z-scores of observed inclusion counts against binomial(calls, p_incl)."""
+    var = np.maximum(calls * p_incl * (1 - p_incl), 1e-9)
+    return (count - calls * p_incl) / np.sqrt(var)
+
+
+def test_error_pixel_sampler_matches_reference_in_distribution(golden):
+    """ErrorPixelSampler.sample_method: same group sizes, no repeats within a group, zero-weight pixels never drawn by the
+    weighted group, and the inclusion frequencies of the reference (1500 seeded calls) are reproduced."""
+    ob, g = _obatch(), golden
+    em = g["errpix_map"]
+    B, k_w, calls = (int(v) for v in g["errpix_cfg"])
+    rng = np.random.default_rng(99)
+    cw, cu = np.zeros(em.size, np.int64), np.zeros(em.size, np.int64)
+    for _ in range(calls):
+        bits = rng.integers(-2**63, 2**63 - 1, B, dtype=np.int64)
+        lin, status = ob.errmap_sample(em, bits, k_w)
+        assert len(set(lin[:k_w])) == k_w and len(set(lin[k_w:])) == B - k_w and status[0] == 0 and status[1] == 0
+        np.add.at(cw, lin[:k_w], 1); np.add.at(cu, lin[k_w:], 1)
+    w = em.reshape(-1)
+    assert cw[w == 0].sum() == 0 and g["errpix_count_weighted"][w == 0].sum() == 0
+    # the four heavy pixels are in (almost) every weighted group -- with replacement they would not be
+    heavy = np.argsort(w)[-4:]
+    ref_heavy = g["errpix_count_weighted"][heavy] / calls
+    assert (ref_heavy > 0.8).all() and np.abs(cw[heavy] / calls - ref_heavy).max() < 0.04, (ref_heavy, cw[heavy] / calls)
+    # everything else: pool both samplers' frequencies and test homogeneity pixel by pixel
+    for mine, ref in ((cw, g["errpix_count_weighted"]), (cu, g["errpix_count_uniform"])):
+        p = (mine + ref) / (2.0 * calls)
+        z = (mine - ref) / np.sqrt(np.maximum(2 * calls * p * (1 - p), 1e-9))
+        live = p > 0
+        assert np.abs(z[live]).max() < 5.0 and abs(z[live].mean()) < 0.15 and 0.8 < z[live].std() < 1.2
