@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import ops, scene
+from . import _lib, ops, scene
 
 STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
 STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
@@ -44,6 +44,7 @@ class HotPathConfig:
     fused_forward: bool = True       # lookup + decoder + compositing in one persistent kernel that leaves a ray once it is opaque
     fused_backward: bool = True      # decoder backward + hash scatter in one kernel (d feat never written)
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
+    prefetch_cus: int = 224          # CUs left to the fused backward while a prefetched sampler runs beside it
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
@@ -66,6 +67,7 @@ class HotPath:
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
+        self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
         self.prim = t(scene.make_primes(self.n_volumes, seed=seed + 2))
@@ -168,6 +170,16 @@ class HotPath:
     def sample(self, rays_o, rays_d_raw, noise, need_world=False):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points."""
         c = self.cfg
+        pre, self._pre = self._pre, None
+        if pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._side)
+            for v in list(pre[4].values()) + list(pre[4]["workspace"].values()):
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(main)  # allocated on the side stream, consumed on this one
+            return pre[4]
+        elif pre is not None:
+            torch.cuda.current_stream().wait_stream(self._side)  # a prefetch nobody collects still owns the workspace
         d = ops.normalize_dirs(rays_d_raw)
         R = rays_o.shape[0]
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
@@ -178,6 +190,19 @@ class HotPath:
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
         return s
+
+    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False):
+        """Run the sampler of the NEXT batch on a second stream now; the next self.sample(...) with the very same tensors
+        collects it.  The ray march is latency-bound and the fused backward beside it fabric-bound, so the two share the
+        chip (the backward is capped to cfg.prefetch_cus CUs meanwhile).  Only valid while the octree does not change
+        between the two steps, i.e. in the focal stage (UpdateOctNodes is global-stage only, nerfacto.py:598-616)."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            s = self.sample(rays_o, rays_d_raw, noise, need_world)
+        self._pre = (rays_o, rays_d_raw, noise, need_world, s)
 
     # -------------------------------------------------------------------- field
     def _field_forward(self, s, cam_idx, block=None, fused=None, save=False, planes=None):
@@ -244,11 +269,12 @@ class HotPath:
                     t_minmax=out["t_minmax"])
         return f, comp
 
-    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None):
-        """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566)."""
+    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None):
+        """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566).
+        samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
-        s = self.sample(rays_o, rays_d_raw, noise)
+        s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
         if self._fused_ok(block):
             f, comp = self._forward_fused(s, cam_idx, block, early)
         else:
@@ -330,9 +356,13 @@ class HotPath:
                 self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
                             gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
+            cap = self._pre is not None and 0 < c.prefetch_cus < 256
+            prev = _lib.lib().gfn_set_decoder_cus(c.prefetch_cus) if cap else 0
             self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                         s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                         self.table_grad, n_dev=n_dev)
+            if cap:
+                _lib.lib().gfn_set_decoder_cus(prev)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision
@@ -356,11 +386,14 @@ class HotPath:
         self._timed("hash_bwd", ops.hash_bwd, prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
-    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None):
+    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None):
         """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
-        s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent."""
+        s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent.
+        prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage)."""
         c = self.cfg
         comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block)
+        if prefetch is not None and stage == STAGE_FOCAL:
+            self.prefetch_sample(*prefetch)
         loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
         R = rays_o.shape[0]
         if c.s3im_loss_mult > 0 and (R * c.s3im_repeat_time) % c.s3im_patch_height == 0 and R * c.s3im_repeat_time >= 4 * c.s3im_patch_height:
@@ -406,9 +439,10 @@ class HotPath:
             return out
         return [live]
 
-    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None, s3im_index=None):
+    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None, s3im_index=None,
+                   prefetch=None):
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
-        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index)
+        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch)
         if allreduce is not None:
             allreduce(self.grads(stage))
         self.optimizer_step(stage, block)

@@ -5,7 +5,10 @@ The reference loops over chunks of eval_num_rays_per_chunk = 2048 rays (gfnerf/c
 model per chunk: 1013 forwards per 1920x1080 frame, each with several host synchronisations.  Here the rays of the frame
 come from one gfn_generate_rays launch, a tile of `tile_rays` rays runs sampler -> hash -> decoder -> compositing with
 the live sample count on the device (no synchronisation), and that per-tile launch sequence is captured ONCE in a
-hipGraph (torch.cuda.CUDAGraph) over static tile buffers and replayed for every tile.  Frames shard over ranks
+hipGraph (torch.cuda.CUDAGraph) over static tile buffers and replayed for every tile.  With `pipeline` = P > 1 one
+replay renders P tiles as a producer / consumer pair of graph branches: the (latency-bound) samplers of all P tiles
+run back to back on one branch while the (fabric-bound) fused forward of tile i starts as soon as sampler i is done
+on the other, its grid capped to `decoder_cus` CUs so the sampler's workgroups find free ones.  Frames shard over ranks
 (frame_shard) with one gather of the finished images at the end -- rays are independent, nothing else is exchanged.
 """
 import torch
@@ -19,7 +22,8 @@ def frame_shard(n_frames, world_size, rank):
 
 
 class TileRenderer:
-    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=64):
+    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=64,
+                 pipeline=1, decoder_cus=224):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
@@ -30,16 +34,45 @@ class TileRenderer:
         self.tw = int(tile_width) if tile_width and tile_rays % tile_width == 0 else 0
         dev = hp.dev
         self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + self.T + 10,), float(fineness), dtype=torch.float32, device=dev)
-        self.o = torch.zeros((self.T, 3), dtype=torch.float32, device=dev)
-        self.d = torch.zeros((self.T, 3), dtype=torch.float32, device=dev)
-        self.d[:, 2] = -1.0
+        self.P = max(int(pipeline), 1) if use_graph else 1
+        self.decoder_cus = int(decoder_cus)
+        self.o = torch.zeros((self.P, self.T, 3), dtype=torch.float32, device=dev)
+        self.d = torch.zeros((self.P, self.T, 3), dtype=torch.float32, device=dev)
+        self.d[..., 2] = -1.0
         self.cam = torch.zeros(self.T, dtype=torch.int32, device=dev)
         self.graph, self.out = None, None
         self.use_graph = use_graph
+        self._side = torch.cuda.Stream(device=dev) if self.P > 1 else None
 
     def _tile(self):
-        out = self.hp.render(self.o, self.d, self.cam, self.noise, block=self.block, early_T=self.early_T)
-        return out["rgb"], out["accumulation"], out["depth"]
+        """-> [(rgb, accumulation, depth)] of the P tiles in the input buffers."""
+        hp = self.hp
+        if self.P == 1:
+            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T)
+            return [(out["rgb"], out["accumulation"], out["depth"])]
+        from . import _lib
+
+        main, side = torch.cuda.current_stream(), self._side
+        prev = _lib.lib().gfn_set_decoder_cus(self.decoder_cus)  # the grid is baked into the captured launches
+        try:
+            side.wait_stream(main)
+            done, samples = [], []
+            with torch.cuda.stream(side):  # producer branch: P samplers back to back (they share one workspace)
+                for i in range(self.P):
+                    samples.append(hp.sample(self.o[i], self.d[i], self.noise))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    done.append(ev)
+            outs = []
+            for i in range(self.P):  # consumer branch: the fused forward of tile i beside the samplers of the tiles after it
+                main.wait_event(done[i])
+                out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i])
+                outs.append((out["rgb"], out["accumulation"], out["depth"]))
+            main.wait_stream(side)
+            self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
+        finally:
+            _lib.lib().gfn_set_decoder_cus(prev)
+        return outs
 
     def _capture(self):
         """Warm up on a side stream (workspaces, kernel attributes, weight images), then capture one tile."""
@@ -66,8 +99,8 @@ class TileRenderer:
         acc = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         depth = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         if self.use_graph and self.graph is None:
-            self.o.copy_(O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))
-            self.d.copy_(D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))
+            self.o.copy_((O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))[None].expand_as(self.o))
+            self.d.copy_((D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))[None].expand_as(self.d))
             self._capture()
         if self.tw:
             tw, th = self.tw, T // self.tw
@@ -76,28 +109,39 @@ class TileRenderer:
             tiles = [(y, min(y + th, height), x, min(x + tw, width)) for y in range(0, height, th) for x in range(0, width, tw)]
         else:
             tiles = [(a, min(a + T, n), 0, 0) for a in range(0, n, T)]
-        for (a, b, x0, x1) in tiles:
-            if self.tw:
-                h, w = b - a, x1 - x0
-                m = h * w
-                if m == T:
-                    self.o.view(h, w, 3).copy_(O2[a:b, x0:x1]); self.d.view(h, w, 3).copy_(D2[a:b, x0:x1])
-                else:  # ragged border tile
-                    self.o[:m].copy_(O2[a:b, x0:x1].reshape(m, 3)); self.d[:m].copy_(D2[a:b, x0:x1].reshape(m, 3))
-            else:
-                m = b - a
-                self.o[:m].copy_(O[a:b]); self.d[:m].copy_(D[a:b])
-            if m < T:  # ragged tile: repeat its last ray, the extra outputs are dropped
-                self.o[m:].copy_(self.o[m - 1:m].expand(T - m, 3)); self.d[m:].copy_(self.d[m - 1:m].expand(T - m, 3))
+        P = self.P
+        for g0 in range(0, len(tiles), P):
+            group = tiles[g0:g0 + P]
+            group = group + [group[-1]] * (P - len(group))  # a short last group renders its last tile again
+            sizes = []
+            for i, (a, b, x0, x1) in enumerate(group):
+                o, d = self.o[i], self.d[i]
+                if self.tw:
+                    h, w = b - a, x1 - x0
+                    m = h * w
+                    if m == T:
+                        o.view(h, w, 3).copy_(O2[a:b, x0:x1]); d.view(h, w, 3).copy_(D2[a:b, x0:x1])
+                    else:  # ragged border tile
+                        o[:m].copy_(O2[a:b, x0:x1].reshape(m, 3)); d[:m].copy_(D2[a:b, x0:x1].reshape(m, 3))
+                else:
+                    m = b - a
+                    o[:m].copy_(O[a:b]); d[:m].copy_(D[a:b])
+                if m < T:  # ragged tile: repeat its last ray, the extra outputs are dropped
+                    o[m:].copy_(o[m - 1:m].expand(T - m, 3)); d[m:].copy_(d[m - 1:m].expand(T - m, 3))
+                sizes.append(m)
             if self.use_graph:
                 self.graph.replay()
-                t_rgb, t_acc, t_depth = self.out
+                outs = self.out
             else:
-                t_rgb, t_acc, t_depth = self._tile()
-            if self.tw:
-                rgb2[a:b, x0:x1] = t_rgb[:m].view(h, w, 3); acc2[a:b, x0:x1] = t_acc[:m].view(h, w, 1); dep2[a:b, x0:x1] = t_depth[:m].view(h, w, 1)
-            else:
-                rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
+                outs = self._tile()
+            for i, (a, b, x0, x1) in enumerate(tiles[g0:g0 + P]):
+                t_rgb, t_acc, t_depth = outs[i]
+                m = sizes[i]
+                if self.tw:
+                    h, w = b - a, x1 - x0
+                    rgb2[a:b, x0:x1] = t_rgb[:m].view(h, w, 3); acc2[a:b, x0:x1] = t_acc[:m].view(h, w, 1); dep2[a:b, x0:x1] = t_depth[:m].view(h, w, 1)
+                else:
+                    rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
         return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width), depth=depth.view(height, width))
 
     def render_path(self, cams, height, width, world_size=1, rank=0):

@@ -211,8 +211,8 @@ def test_train_steps_reduce_loss(setup):
     assert int((hp.visit_cnt > 0).sum().item()) > 10
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_tile_renderer_matches_direct_render_and_oracle(setup, use_graph):
+@pytest.mark.parametrize("use_graph,pipeline", [(True, 1), (False, 1), (True, 3)])
+def test_tile_renderer_matches_direct_render_and_oracle(setup, use_graph, pipeline):
     """render.py path: gfn_generate_rays + hipGraph-replayed tiles == the same rays pushed through HotPath.render in one
     go == the oracle pipeline (ragged last tile included)."""
     import torch
@@ -229,7 +229,8 @@ def test_tile_renderer_matches_direct_render_and_oracle(setup, use_graph):
     # a small off-centre image of camera 3 (principal point shifted so the 24 x 20 window looks at the scene centre)
     H, W = 20, 24
     intr2 = intr.clone(); intr2[:, 2] = W / 2; intr2[:, 3] = H / 2; intr2[:, 0] *= 0.02; intr2[:, 1] *= 0.02
-    tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=128, block=0, fineness=5.0, early_T=0.0, use_graph=use_graph)
+    tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=128, block=0, fineness=5.0, early_T=0.0, use_graph=use_graph, pipeline=pipeline,
+                           decoder_cus=192)  # pipeline 3: 4 tiles (one ragged) in groups of 3, samplers beside the capped fused forward
     img = tr.render_camera(3, H, W)
     assert img["rgb"].shape == (H, W, 3) and img["depth"].shape == (H, W)
     rays = ops.generate_rays(c2w, intr2, cam0=3, first_pixel=0, width=W, n=H * W)
@@ -425,3 +426,39 @@ def test_training_trajectory_matches_oracle_psnr(setup):
     assert np.abs(psnr_gpu - psnr_cpu).max() < 0.1, (psnr_gpu, psnr_cpu)    # every step within 0.1 dB
     np.testing.assert_allclose(loss_gpu, loss_cpu, rtol=5e-3)
     np.testing.assert_allclose(hp.layers[4][0].cpu().numpy(), params["hW2"], atol=3e-3)
+
+
+def test_prefetched_sampler_is_the_same_sampler(setup):
+    """HotPath.prefetch_sample: the next batch's sampler on a second stream beside the (CU-capped) fused backward returns
+    bit-identical samples, is collected only by a call with the very same tensors, and the training losses agree."""
+    import torch
+
+    from gfnerf_amd import hotpath
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    o2, d2 = o.flip(0).contiguous(), d.flip(0).contiguous()
+    from gfnerf_amd import ops
+    s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
+    runs = []
+    for pre in (False, True):
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14), seed=1, n_blocks=1)
+        hp.blocks[0].uniform_(-1e-3, 1e-3); hp.refresh_shadows()
+        losses = []
+        for it in range(4):
+            a, b = ((o, d), (o2, d2)) if it % 2 == 0 else ((o2, d2), (o, d))
+            loss, aux = hp.train_step(a[0], a[1], cam, gt, noise, stage="focal", block=0, s3im_index=s3,
+                                      prefetch=(b[0], b[1], noise) if pre else None)
+            assert (hp._pre is not None) == pre
+            losses.append(loss.item())
+        runs.append((losses, aux["samples"]))
+        if pre:  # a stale prefetch is dropped, not handed to other rays
+            s_other = hp.sample(o, d, noise * 1.0)
+            assert hp._pre is None and s_other["pts_offsets"].data_ptr() != runs[-1][1]["pts_offsets"].data_ptr()
+    (l0, s0), (l1, s1) = runs
+    assert torch.equal(s0["pts_offsets"], s1["pts_offsets"])
+    n = int(s0["pts_offsets"][-1])
+    for k in ("anchors", "warped_pts", "dists", "ts"):
+        assert torch.equal(s0[k][:n], s1[k][:n]), k
+    np.testing.assert_allclose(l0, l1, rtol=2e-3)
