@@ -80,7 +80,8 @@ Tree compact_tree(const gfn_tree_node* t, int64_t n, const int64_t* w, const int
   out.nodes.resize(m); out.w.resize(m); out.a.resize(m); out.origin.resize(m);
   for (int64_t u = 0; u < n; u++) {
     if (new_idx[u] < 0) continue;
-    gfn_tree_node nd = t[u];
+    gfn_tree_node nd;
+    memcpy(&nd, &t[u], sizeof(nd));  // padding bytes are part of the checkpoint blob: they travel with the node
     for (int st = 0; st < 8; st++) {
       int64_t c = nd.childs[st];
       if (c >= 0 && !alive[c]) c = -1;
@@ -99,7 +100,7 @@ Tree compact_tree(const gfn_tree_node* t, int64_t n, const int64_t* w, const int
       // a node the pruning left without children is a leaf (the reference re-flags every childless non-root node, :193-207)
     }
     const int64_t k = new_idx[u];
-    out.nodes[k] = nd; out.w[k] = w[u]; out.a[k] = a[u]; out.origin[k] = u;
+    memcpy(&out.nodes[k], &nd, sizeof(nd)); out.w[k] = w[u]; out.a[k] = a[u]; out.origin[k] = u;
   }
   return out;
 }
@@ -115,7 +116,8 @@ Tree subdivide_tree(const Tree& in, const int64_t* visit_cnt, bool brute_force) 
     const Item it = stack.back();
     stack.pop_back();
     const int64_t nu = (int64_t)out.nodes.size();
-    out.nodes.push_back(in.nodes[it.u]); out.w.push_back(in.w[it.u]); out.a.push_back(in.a[it.u]);
+    out.nodes.emplace_back(); memcpy(&out.nodes[nu], &in.nodes[it.u], sizeof(gfn_tree_node));
+    out.w.push_back(in.w[it.u]); out.a.push_back(in.a[it.u]);
     out.nodes[nu].parent = it.parent;
     if (it.parent >= 0) out.nodes[it.parent].childs[it.slot] = nu;
     const gfn_tree_node& src = in.nodes[it.u];
@@ -133,7 +135,8 @@ Tree subdivide_tree(const Tree& in, const int64_t* visit_cnt, bool brute_force) 
         kid.is_leaf_node = 1;
         kid.trans_idx = src.trans_idx;
         out.nodes[nu].childs[st] = (int64_t)out.nodes.size();
-        out.nodes.push_back(kid); out.w.push_back(in.w[it.u]); out.a.push_back(in.a[it.u]);
+        out.nodes.emplace_back(); memcpy(&out.nodes.back(), &kid, sizeof(kid));
+        out.w.push_back(in.w[it.u]); out.a.push_back(in.a[it.u]);
       }
       out.nodes[nu].is_leaf_node = 0;
       out.nodes[nu].trans_idx = -1;

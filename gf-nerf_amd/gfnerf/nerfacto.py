@@ -9,6 +9,8 @@ from dataclasses import dataclass, field as dc_field
 from typing import Dict, List
 
 import numpy as np
+import types
+
 import torch
 from torch import nn
 
@@ -89,6 +91,8 @@ class GFNeRFModel(nn.Module):
         self.embedding_appearance = nn.Parameter(self.hot.emb, requires_grad=True)
         self.block_pools = nn.ParameterList([nn.Parameter(b, requires_grad=True) for b in self.hot.blocks])
         self._params_version = None
+        # the reference reads model.field.cur_stage (gf_pipeline.py:180); here the field is fused into the engine
+        self.field = types.SimpleNamespace(cur_stage="init_stage")
 
     # ----------------------------------------------------------------------------------------------
     def stage_of(self, step: int):
@@ -115,6 +119,7 @@ class GFNeRFModel(nn.Module):
         cam = cam.reshape(-1).to(torch.int32).contiguous()
         step = -1 if ray_bundle.steps is None else int(ray_bundle.steps.reshape(-1)[0])
         stage, blk = self.stage_of(step)
+        self.field.cur_stage = "block_stage" if stage == hp_mod.STAGE_FOCAL else "init_stage"
         blk = blk if block is None else block
         nat = self.persampler.sampler
         noise = nat.make_noise(o.shape[0])

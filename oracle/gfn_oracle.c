@@ -799,7 +799,8 @@ static void o_vec_push(o_vec* v, const gfn_o_tree_node* nd, int64_t w, int64_t a
     v->w = (int64_t*)realloc(v->w, (size_t)v->cap * sizeof(int64_t));
     v->a = (int64_t*)realloc(v->a, (size_t)v->cap * sizeof(int64_t));
   }
-  if (nd) v->nodes[v->n] = *nd; else memset(&v->nodes[v->n], 0, sizeof(gfn_o_tree_node));
+  /* memcpy, not struct assignment: padding bytes (part of the checkpoint blob) must travel too */
+  if (nd) memcpy(&v->nodes[v->n], nd, sizeof(gfn_o_tree_node)); else memset(&v->nodes[v->n], 0, sizeof(gfn_o_tree_node));
   v->w[v->n] = w;
   v->a[v->n] = a;
   v->n++;
@@ -915,7 +916,8 @@ void gfn_o_proc_octree(const gfn_o_tree_node* nodes, int64_t n_nodes, const int6
   o_vec nv = {0};
   for (int64_t u = 0; u < n_nodes; u++) {
     if (new_idx[u] < 0) continue;
-    gfn_o_tree_node node = t[u];
+    gfn_o_tree_node node;
+    memcpy(&node, &t[u], sizeof(node));
     if (node.parent >= 0) node.parent = new_idx[node.parent];
     for (int64_t st = 0; st < 8; st++)
       if (node.childs[st] >= 0) node.childs[st] = new_idx[node.childs[st]];

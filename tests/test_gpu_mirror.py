@@ -342,3 +342,46 @@ def test_update_oct_nodes_milestone_runs_proc_octree(oracle, dev):
     assert np.array_equal(s2["pts_offsets"].cpu().numpy().astype(np.int64), m["pts_offsets"])
     assert np.array_equal(s2["anchors"].cpu().numpy()[:N2].astype(np.int64), m["anchors"])
     assert np.array_equal(s2["ts"].cpu().numpy()[:N2], m["ts"])
+
+
+def test_pipeline_with_image_stack_datamanager(dev):
+    """get_train_loss_dict over an HBM-resident image stack: PixelSampler in the init stage, ErrorPixelSampler + error-map
+    write-back in the block stage (gf_pipeline.py:146-192), rays generated from the sampled pixels."""
+    import torch
+
+    from gfnerf_amd import scene
+    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipeline, ImageStackDataManager
+    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
+
+    c2w, intri, _ = scene.make_cameras(n_side=5, seed=3)
+    n, H, W = c2w.shape[0], 36, 48
+    K = intri.copy()
+    K[:, 0, 0] *= W / 1152.0; K[:, 1, 1] *= W / 1152.0; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
+    intr = torch.from_numpy(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    images = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    em0 = torch.full((n, H, W, 1), 0.5, device=dev)
+    cfg = GFNeRFModelConfig(log2_hashmap_size=13, steps_perssampler_init=3, steps_per_split_dataset=4, n_split_dataset=2, n_blocks=2,
+                            resident_blocks=[0, 1], early_T=0.0)
+    dm = ImageStackDataManager(images, torch.from_numpy(c2w).to(dev), intr, rays_per_batch=256, error_maps=em0.clone(), generator=gen)
+    pipe = GFNerfPipeline(cfg, c2w, K, device=dev, rays_per_batch=256, datamanager=dm)
+    model = pipe.model
+    model.train(); model.persampler.update_mode(0)
+    opt = torch.optim.Adam(pipe.get_param_groups()["fields"], lr=1e-2, eps=1e-15)
+    touched = 0
+    for step in range(6):
+        opt.zero_grad(set_to_none=True)
+        before = dm.error_map.map.clone()
+        outputs, loss_dict, metrics = pipe.get_train_loss_dict(step)
+        assert outputs["rgb"].shape == (256, 3) and torch.isfinite(loss_dict["rgb_loss"])
+        sum(loss_dict.values()).backward()
+        opt.step()
+        changed = int((dm.error_map.map != before).sum())
+        if model.field.cur_stage == "block_stage":
+            assert 200 <= changed <= 256  # one error per sampled pixel (duplicates across the two groups aside)
+            touched += changed
+        else:
+            assert changed == 0
+    assert touched > 0 and float(dm.error_map.map.max()) <= 3.0
+    np.testing.assert_allclose(dm.error_map.block_sums.cpu().numpy(),
+                               __import__("gfnerf_amd").ops.errmap_block_sums(dm.error_map.map).cpu().numpy(), rtol=1e-12)
