@@ -40,7 +40,7 @@ SIGNATURES = {
     "gfn_field_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_field_bwd_dx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_field_pack_x3": (_i32, [_vp, _vp, _vp, _vp]),
-    "gfn_field_fwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gfn_field_fwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "gfn_field_bwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_field_bwd_scatter_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp]),
@@ -55,6 +55,7 @@ SIGNATURES = {
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gfn_generate_rays": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_hash_fwd_lm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "gfn_pixel_uniform": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "gfn_pixel_collate": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_errmap_block_sums": (_i32, [_vp, _i64, _vp, _vp]),

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
     const u32x4* __restrict__ image, float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ h0_out,
     unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo,
-    int64_t cap) {
+    int64_t cap, int64_t feat_stride /* 0: feat is [n,32]; else level-major float2 [16][feat_stride] (gfn_hash_fwd_lm) */) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
@@ -121,7 +121,15 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       float x[8];
-      load8(feat + q * 32 + 16 * u + 8 * h, x);
+      if (feat_stride) {  // columns 16u + 8h + i = levels 8u + 4h .. + 3 of sample q
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const float2 v = reinterpret_cast<const float2*>(feat)[(int64_t)(8 * u + 4 * h + m) * feat_stride + q];
+          x[2 * m] = v.x; x[2 * m + 1] = v.y;
+        }
+      } else {
+        load8(feat + q * 32 + 16 * u + 8 * h, x);
+      }
       split8(x, xh[u], xl[u]);
       if (PLANES) store_nat(planes_hi + cap * FP_FEAT + q * 32, planes_lo + cap * FP_FEAT + q * 32, 16 * u, xh[u], xl[u], h);
     }
@@ -457,9 +465,10 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
                      const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
-                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, void* stream) {
+                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
+  GFN_CHECK_ARG(feat_stride == 0 || feat_stride >= n_max, "gfn_field_fwd_x3: feat_stride=%lld must be 0 or >= n_max", (long long)feat_stride);
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 8", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
@@ -482,13 +491,13 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
   if (planes_hi)
     field_fwd_x3_kernel<true, true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                              planes_hi, planes_lo, plane_cap);
+                                                                              planes_hi, planes_lo, plane_cap, feat_stride);
   else if (masks)
     field_fwd_x3_kernel<true, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                               nullptr, nullptr, 0);
+                                                                               nullptr, nullptr, 0, feat_stride);
   else
     field_fwd_x3_kernel<false, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb,
-                                                                                nullptr, nullptr, nullptr, nullptr, 0);
+                                                                                nullptr, nullptr, nullptr, nullptr, 0, feat_stride);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -44,6 +44,9 @@ class HotPathConfig:
     fused_forward: bool = True       # lookup + decoder + compositing in one persistent kernel that leaves a ray once it is opaque
     fused_backward: bool = True      # decoder backward + hash scatter in one kernel (d feat never written)
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
+    level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
+                                     # as three kernels instead of the one fused kernel (which stays the inference path)
+    lm_halves_from: int = 8          # levels >= this are gathered one 4 MB address half at a time
     prefetch_cus: int = 224          # CUs left to the fused backward while a prefetched sampler runs beside it
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
@@ -205,18 +208,24 @@ class HotPath:
         self._pre = (rays_o, rays_d_raw, noise, need_world, s)
 
     # -------------------------------------------------------------------- field
-    def _field_forward(self, s, cam_idx, block=None, fused=None, save=False, planes=None):
+    def _field_forward(self, s, cam_idx, block=None, fused=None, save=False, planes=None, lm=False):
         """GFNeRFField.get_density + get_outputs (nerfacto_field.py:412-591) on packed samples.
         fused: one decoder kernel (sigma, rgb [+ ReLU masks when save]); else the per-layer kernels,
         which keep every activation (needed for the weight gradients of the global stage)."""
         n_dev = s["n_dev"]
         T, V = self.cfg.log2_T, self.n_volumes
         fused = (self.cfg.fused_field and self.cfg.hidden == 128) if fused is None else fused
+        lm = lm and fused and self.cfg.mlp_precision == "x3"  # the x3 decoder reads level-major features
         if block is not None and self._pairs_stale:  # the global table moved since the interleaved images were built
             self.refresh_shadows()
         if self.cfg.table_f16_shadow and block is not None and self.cfg.share_block_primes:
             feat = self._timed("hash_fwd", ops.hash_fwd_pair, self.blocks16[block], self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, n_dev=n_dev)
+        elif self.cfg.table_f16_shadow and lm:
+            feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
+                               table2_f16=self.blocks16[block] if block is not None else None,
+                               prim_pool2=self.block_prims[block] if block is not None else None, n_dev=n_dev,
+                               halves_from=self.cfg.lm_halves_from, planar=True)
         elif self.cfg.table_f16_shadow and block is not None:  # residual block table (nerfacto_field.py:485-486) fused in
             feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, table2_f16=self.blocks16[block], prim_pool2=self.block_prims[block], n_dev=n_dev)
@@ -313,10 +322,13 @@ class HotPath:
         fused = c.fused_field and c.hidden == 128 and (not train_mlp or c.mlp_precision == "x3")
         planes = self._planes(s["ts"].shape[0])[0] if (fused and train_mlp) else None
         blk = block if stage == STAGE_FOCAL else None
-        if fused and self._fused_ok(blk):
+        # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
+        lm = (c.level_major and fused and c.mlp_precision == "x3" and c.table_f16_shadow and not c.keep_features
+              and not (blk is not None and c.share_block_primes))
+        if fused and self._fused_ok(blk) and not lm:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
         else:
-            f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes)
+            f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes, lm=lm)
             comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
                                early_T=c.early_T)
         ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)

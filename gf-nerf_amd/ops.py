@@ -106,6 +106,25 @@ def hash_fwd_part(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2
     return out, overflow
 
 
+def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
+                halves_from=8, planar=False, accumulate=False):
+    """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time.
+    planar: out is float2 [16, n] (level-major) instead of f32 [n, 32]."""
+    _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16"); _chk(prim_pool, torch.int32, "prim_pool")
+    _chk(prim_pool2, torch.int32, "prim_pool2"); _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
+    _chk(anchors, torch.int32, "anchors")
+    n = pts.shape[0]
+    if out is None:
+        out = torch.empty((16, n, 2) if planar else (n, 32), dtype=torch.float32, device=pts.device)
+    _chk(out, torch.float32, "out", 2 if planar else 32)
+    if out.numel() != n * 32:
+        raise _lib.GfnError("hash_fwd_lm: out must hold 32 features per sample")
+    rc = _lib.lib().gfn_hash_fwd_lm(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
+                                    _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(bool(planar)), int(bool(accumulate)), _ptr(out), _stream())
+    _lib.check(rc, "gfn_hash_fwd_lm")
+    return out
+
+
 def table_to_f16(feat_pool, out=None):
     """f16 shadow of a master table (same flat indexing, incl. the level-overlap quirk)."""
     _chk(feat_pool, torch.float32, "feat_pool")
@@ -603,10 +622,14 @@ def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bw
 def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None, planes=None):
     """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None).
     precision "x3": split-f16 MFMA (f32 accuracy, ~5x the f32 matrix rate; `image` = a current forward image from
-    field_pack_x3, built here when absent); "f32": exact f32 MFMA."""
-    _chk(feat, torch.float32, "feat", 32); _chk(ray_id, torch.int32, "ray_id"); _chk(sh, torch.float32, "sh", 16)
+    field_pack_x3, built here when absent); "f32": exact f32 MFMA.
+    feat: f32 [n,32], or the level-major [16,n,2] of hash_fwd_lm(planar=True) (x3 only)."""
+    planar = feat.dim() == 3
+    _chk(feat, torch.float32, "feat", 2 if planar else 32); _chk(ray_id, torch.int32, "ray_id"); _chk(sh, torch.float32, "sh", 16)
     _chk(emb, torch.float32, "emb", 32); _chk(cam_idx, torch.int32, "cam_idx")
-    n = feat.shape[0]
+    if planar and (feat.shape[0] != 16 or precision != "x3"):
+        raise _lib.GfnError("field_fwd: level-major features are [16,n,2] and need the x3 decoder")
+    n = feat.shape[1] if planar else feat.shape[0]
     dev = feat.device
     sigma = torch.empty(n, dtype=torch.float32, device=dev)
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -618,7 +641,7 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
         ph, pl = planes if planes is not None else (None, None)
         cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)  # split-f16 activation planes for the weight gradients (global stage)
         rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
-                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, _stream())
+                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, n if planar else 0, _stream())
         _lib.check(rc, "gfn_field_fwd_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)

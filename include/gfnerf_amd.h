@@ -113,6 +113,16 @@ int gfn_table_pair_f16(const float* global_pool, const float* block_pool, uint16
 int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const float* bias_pool, const float* pts,
                       const void* anchors, int anchors_i64, int anchor_stride, int64_t n_max, const int32_t* n_dev,
                       int64_t n_volumes, int log2_T, float* out, void* stream);
+/* The same lookup as gfn_hash_fwd_f16 in LEVEL-MAJOR order (csrc/lm_lookup.hip): every workgroup owns a run of
+ * samples and all workgroups sweep level by level, table by table, and -- for levels >= halves_from -- one
+ * 4 MB address half at a time, so that the slots being gathered fit the XCDs' L2 instead of missing to the
+ * fabric.  Bit-identical features.  anchors i32, element i at anchors[i*anchor_stride].  planar != 0: out is
+ * level-major, float2 [16][n_max] (coalesced stores; what gfn_field_fwd_x3 reads with feat_stride = n_max).
+ * accumulate != 0: out += features.  One launch per table. */
+int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                    const int32_t* prim_pool2, const float* bias_pool, const float* pts, const int32_t* anchors,
+                    int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
+                    int halves_from, int planar, int accumulate, float* out, void* stream);
 /* The same lookup as gfn_hash_fwd_f16 for ONE table, organised as a radix-partitioned join
  * (csrc/part_lookup.hip): requests are sorted by the CU that owns the slot's address range, answered
  * from a 144 KiB LDS slice of the table and streamed back -- no random access to HBM.  Bit-identical
@@ -261,7 +271,8 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * dz3 C=0 W=8 | dh C=8 W=16 | dz2 C=24 W=128 | dz1 C=152 W=128 | dza1 C=280 W=128, all multiplied by the power-of-two scale
  * gfn_grad_scale_host(*gmax_dev) (gmax_dev: device f32 = largest |gradient| entering the decoder,
  * from gfn_grad_max into a zeroed word), and accumulates the appearance-embedding gradient into
- * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients. */
+ * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients.
+ * feat_stride: 0 = feat is f32 [n,32]; else feat is level-major float2 [16][feat_stride] (gfn_hash_fwd_lm, planar). */
 #define GFN_FIELD_X3_FWD_BYTES 149248
 #define GFN_FIELD_X3_BWD_BYTES 131072
 #define GFN_FIELD_X3_FWD_PLANE_LD 480
@@ -270,7 +281,7 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
                      float* sigma, float* rgb, float* h0, uint64_t* masks, uint16_t* planes_hi,
-                     uint16_t* planes_lo, int64_t plane_cap, void* stream);
+                     uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, void* stream);
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                         float* dfeat, void* stream);

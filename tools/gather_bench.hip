@@ -31,6 +31,40 @@ __global__ __launch_bounds__(256) void gather(const uint32_t* __restrict__ table
   out[tid] = acc;
 }
 
+// random packed-f16 atomic adds (what the hash backward issues), no return value
+template <int K>
+__global__ __launch_bounds__(256) void scatter(uint32_t* __restrict__ table, uint32_t mask, int iters) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 one = {(_Float16)1.0f, (_Float16)0.5f};
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t idx = mix(tid * 977u + it * 131071u + k * 7919u) & mask;
+      __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(table + idx), one);
+    }
+  }
+}
+
+int run_scatter(uint32_t* table, uint32_t mask, int blocks, int iters) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  scatter<8><<<blocks, 256>>>(table, mask, iters);
+  CK(hipDeviceSynchronize());
+  float best = 1e9;
+  for (int r = 0; r < 3; r++) {
+    CK(hipEventRecord(e0));
+    scatter<8><<<blocks, 256>>>(table, mask, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  const double n = (double)blocks * 256 * iters * 8;
+  printf("%-34s table %4u MB blocks %5d K  8: %7.3f ms  %7.1f G atomics/s\n", "global_atomic_pk_add_f16", (mask + 1) / 262144, blocks, best, n / best / 1e6);
+  return 0;
+}
+
 template <int KIND, int K>
 int run(const char* name, const uint32_t* table, uint32_t mask, int blocks, int iters, uint32_t* out) {
   hipEvent_t e0, e1;
@@ -68,5 +102,8 @@ int main() {
       run<2, 16>("buffer dwordx2", table, mask, blocks, iters / 2, out);
     }
   }
+  // table-size sweep around the 4 MB L2 of one XCD, and the scattered atomics of the backward
+  for (uint32_t mb : {1u, 2u, 4u, 8u, 16u, 32u}) run<1, 8>("buffer dword (size sweep)", table, mb * 262144u - 1u, 2048, 24, out);
+  for (uint32_t mb : {4u, 8u, 64u, 128u}) run_scatter(table, mb * 262144u - 1u, 2048, 24);
   return 0;
 }
