@@ -323,8 +323,9 @@ class HotPath:
         planes = self._planes(s["ts"].shape[0])[0] if (fused and train_mlp) else None
         blk = block if stage == STAGE_FOCAL else None
         # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
-        lm = (c.level_major and fused and c.mlp_precision == "x3" and c.table_f16_shadow and not c.keep_features
-              and not (blk is not None and c.share_block_primes))
+        # (two tables; with one table the fused kernel's early termination and resident features make it a tie)
+        lm = (c.level_major and blk is not None and fused and c.mlp_precision == "x3" and c.table_f16_shadow and not c.keep_features
+              and not c.share_block_primes)
         if fused and self._fused_ok(blk) and not lm:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
         else:

@@ -269,7 +269,7 @@ def test_mark_invisible_nodes_matches_oracle(oracle, dev):
     from gfnerf_amd import ops
 
     sc = small_scene()
-    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE).copy()
+    nodes = sc["nodes"].copy().view(oracle.TREE_NODE_DTYPE)  # raw-byte copy: a structured copy leaves the padding bytes undefined
     rng = np.random.default_rng(2)
     far = rng.choice(np.nonzero(nodes["trans_idx"] >= 0)[0], 40, replace=False)
     nodes["center"][far[:20], 2] += 900.0          # far above the cameras, behind them
@@ -313,7 +313,7 @@ def test_update_oct_nodes_milestone_runs_proc_octree(oracle, dev):
     a = (rng.random(s["ts"].shape[0]) * 0.05).astype(np.float32)
     w[rng.random(w.size) < 0.5] = 0
     # oracle sequence on host copies
-    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE).copy()
+    nodes = sc["nodes"].copy().view(oracle.TREE_NODE_DTYPE)  # raw-byte copy: a structured copy leaves the padding bytes undefined
     ws = np.full(nodes.shape[0], 1000, np.int64); as_ = ws.copy(); vc = np.zeros(nodes.shape[0], np.int64)
     po = s["pts_offsets"].cpu().numpy().astype(np.int64)
     anchors = s["anchors"].cpu().numpy()[:N].astype(np.int64)

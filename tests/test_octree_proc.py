@@ -8,7 +8,7 @@ from helpers import small_scene
 
 def _random_state(nodes, rng, kill):
     n = nodes.shape[0]
-    nodes = nodes.copy()
+    nodes = nodes.view(np.uint8).copy().view(nodes.dtype)  # raw-byte copy keeps the padding bytes defined
     leaves = np.nonzero((nodes["is_leaf_node"] == 1) & (nodes["trans_idx"] >= 0))[0]
     dead = rng.random(leaves.size) < kill
     nodes["trans_idx"][leaves[dead]] = -1          # what K6 / K7 do
@@ -72,7 +72,7 @@ def test_proc_octree_rejects_malformed_blob(oracle):
     from gfnerf_amd import _lib, ops
 
     sc = small_scene()
-    nodes = sc["nodes"].view(oracle.TREE_NODE_DTYPE).copy()
+    nodes = sc["nodes"].copy().view(oracle.TREE_NODE_DTYPE)  # raw-byte copy: a structured copy leaves the padding bytes undefined
     nodes["parent"][5] = 3 if nodes["parent"][5] != 3 else 4
     z = np.zeros(nodes.shape[0], np.int64)
     with pytest.raises(_lib.GfnError):
