@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-oct-update", action="store_true", help="global stage: skip the per-step UpdateOctNodes (K5/K6)")
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
+    ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
     ap.add_argument("--prefetch-cus", type=int, default=224, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=8,
@@ -201,7 +202,8 @@ def main():
     n_cams = sc["c2w"].shape[0]
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
-                                mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus)
+                                mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus,
+                                fused_backward=not args.unfused_backward)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
                          device=f"cuda:{local_rank if world > 1 else 0}")
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
@@ -288,6 +290,15 @@ def main():
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
         kern_ms = kern[dom]
         alg_bytes = alg[dom]
+        kernel_name, launches = dom + "_kernel", 1
+        lm = getattr(hp, "last_forward", "") == "lm" and dom == "hash_fwd"
+        if lm:
+            # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region.  Per launch and
+            # sample: 512 B gathered + 16 B point/anchor + 128 B of level-major features written (+ the second table's launch
+            # reads the first one's 128 B back to add to them: 64 B averaged over the two launches)
+            kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
+            kern_ms = kern_ms / launches
+            alg_bytes = n_live * (512 + 16 + 128 + 64)
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
         traffic, req = None, None
         if os.path.exists(pmc_path):
@@ -298,11 +309,16 @@ def main():
             if not default_cfg:
                 traffic = None
             n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests") if default_cfg else None
-            if n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
+            if lm:  # the level-major kernel is bound by how fast a CU's address unit walks 64 divergent lanes, not by the fabric
+                n_g = n_live * 128
+                req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
+                           frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
+                           source="16 levels x 8 corners per sample and launch over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
+            elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
                 req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
                            frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
                            source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
-        roofline = dict(bound="hbm", kernel=dom + "_kernel", achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+        roofline = dict(bound="hbm", kernel=kernel_name, launches_per_step=launches, achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
                         alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()}, request_rate=req)
         w = aux["comp"]["weights"][:n_live]

@@ -326,6 +326,7 @@ class HotPath:
         # (two tables; with one table the fused kernel's early termination and resident features make it a tie)
         lm = (c.level_major and blk is not None and fused and c.mlp_precision == "x3" and c.table_f16_shadow and not c.keep_features
               and not c.share_block_primes)
+        self.last_forward = "lm" if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
         if fused and self._fused_ok(blk) and not lm:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
         else:
