@@ -132,10 +132,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float early_T, float* __restrict__ weights, float* __restrict__ alphas,
     float* __restrict__ out_rgb, float* __restrict__ out_acc, float* __restrict__ out_depth,
     float* __restrict__ t_minmax) {
-  const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= n_rays) return;
-  const int s = pts_offsets[ray], e = pts_offsets[ray + 1];
+  __shared__ float s_tmin[4], s_tmax[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wave;
+  const bool has_ray = ray < n_rays;  // wave-uniform; idle waves still join the workgroup's min / max
+  const int s = has_ray ? pts_offsets[ray] : 0, e = has_ray ? pts_offsets[ray + 1] : 0;
   float carry = 0.f;  // sum of dt*sigma of all earlier chunks
   float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
   float tmin = INFINITY, tmax = 0.f;
@@ -175,13 +176,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
       tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
     }
     if (lane == 0) {
-      if (e - s < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
+      if (has_ray && e - s < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
+      s_tmin[wave] = tmin; s_tmax[wave] = tmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one pair of same-address atomics per workgroup, not per ray: they serialise at the memory side
+      tmin = fminf(fminf(s_tmin[0], s_tmin[1]), fminf(s_tmin[2], s_tmin[3]));
+      tmax = fmaxf(fmaxf(s_tmax[0], s_tmax[1]), fmaxf(s_tmax[2], s_tmax[3]));
       // non-negative floats order like their bit patterns
       atomicMin(reinterpret_cast<unsigned*>(t_minmax), __float_as_uint(tmin));
       atomicMax(reinterpret_cast<unsigned*>(t_minmax + 1), __float_as_uint(tmax));
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && has_ray) {
     out_rgb[3 * ray] = cr; out_rgb[3 * ray + 1] = cg; out_rgb[3 * ray + 2] = cb;
     if (out_acc) out_acc[ray] = ca;
     if (out_depth) out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
