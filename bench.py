@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stage", choices=["focal", "global"], default="focal")
     ap.add_argument("--n-side", type=int, default=20, help="cameras per side of the synthetic capture grid")
     ap.add_argument("--log2-T", type=int, default=21)
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-oct-update", action="store_true", help="global stage: skip the per-step UpdateOctNodes (K5/K6)")
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
+    ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
     ap.add_argument("--prefetch-cus", type=int, default=224, help="CUs left to the fused backward while the prefetched sampler runs beside it")
@@ -203,7 +204,7 @@ def main():
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
                                 mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus,
-                                fused_backward=not args.unfused_backward)
+                                fused_backward=not args.unfused_backward, lm_halves_from=args.lm_halves_from)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
                          device=f"cuda:{local_rank if world > 1 else 0}")
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables

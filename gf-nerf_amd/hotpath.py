@@ -46,7 +46,7 @@ class HotPathConfig:
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
-    lm_halves_from: int = 8          # levels >= this are gathered one 4 MB address half at a time
+    lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
     prefetch_cus: int = 224          # CUs left to the fused backward while a prefetched sampler runs beside it
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved

@@ -107,7 +107,7 @@ def hash_fwd_part(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2
 
 
 def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
-                halves_from=8, planar=False, accumulate=False):
+                halves_from=6, planar=False, accumulate=False):
     """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time.
     planar: out is float2 [16, n] (level-major) instead of f32 [n, 32]."""
     _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16"); _chk(prim_pool, torch.int32, "prim_pool")
