@@ -95,7 +95,7 @@ __global__ void field_pack_x3_kernel(FieldWeights w, u32x4* __restrict__ fwd, u3
   }
 }
 
-template <bool SAVE, bool PLANES>
+template <bool SAVE, bool PLANES, bool PLANAR>
 __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       float x[8];
-      if (feat_stride) {  // columns 16u + 8h + i = levels 8u + 4h .. + 3 of sample q
+      if (PLANAR) {  // columns 16u + 8h + i = levels 8u + 4h .. + 3 of sample q
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           const float2 v = reinterpret_cast<const float2*>(feat)[(int64_t)(8 * u + 4 * h + m) * feat_stride + q];
@@ -469,6 +469,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
   GFN_CHECK_ARG(feat_stride == 0 || feat_stride >= n_max, "gfn_field_fwd_x3: feat_stride=%lld must be 0 or >= n_max", (long long)feat_stride);
+  GFN_CHECK_ARG(feat_stride == 0 || !planes_hi, "gfn_field_fwd_x3: level-major features and activation planes are not combined (the register file holds one or the other)");
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 8", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
@@ -479,25 +480,26 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
                   reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
                 "gfn_field_fwd_x3: image, feat, sh, emb and planes must be 16-byte aligned");
   static bool attr_set = false;
+#define GFN_FWD_ALL(X) X(true, true, false) X(true, false, false) X(false, false, false) X(true, false, true) X(false, false, true)
   if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+#define GFN_SET(S, P, L) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<S, P, L>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
+    GFN_FWD_ALL(GFN_SET)
+#undef GFN_SET
     attr_set = true;
   }
   const unsigned grid = persistent_grid8(n_max);
   const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
   hipStream_t st = gfn_stream(stream);
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
-  if (planes_hi)
-    field_fwd_x3_kernel<true, true><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                              planes_hi, planes_lo, plane_cap, feat_stride);
-  else if (masks)
-    field_fwd_x3_kernel<true, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk,
-                                                                               nullptr, nullptr, 0, feat_stride);
-  else
-    field_fwd_x3_kernel<false, false><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb,
-                                                                                nullptr, nullptr, nullptr, nullptr, 0, feat_stride);
+  const bool save = masks != nullptr, planes = planes_hi != nullptr, planar = feat_stride != 0;
+  if (!save) h0 = nullptr;
+#define GFN_LAUNCH(S, P, L)                                                                                                         \
+  if (save == S && planes == P && planar == L)                                                                                       \
+    field_fwd_x3_kernel<S, P, L><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk, \
+                                                                           planes_hi, planes_lo, plane_cap, feat_stride);
+  GFN_FWD_ALL(GFN_LAUNCH)
+#undef GFN_LAUNCH
+#undef GFN_FWD_ALL
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
   // Bounded loops (<= n_rays + 8 fetches per wave, <= 1024 / 32 tiles per ray): the grid always drains.
   const int seg_len = (A.n_rays + 7) / 8;
   int seg_k = 0, fetches = 0;
-  float wave_tmin = INFINITY, wave_tmax = 0.f;  // over every ray of this wave: ONE pair of same-address atomics at the end
+  // t range over every ray of this wave, kept in LDS (the register file is full): ONE pair of same-address atomics at the end
+  __shared__ float s_tmin[FUSED_THREADS / 64], s_tmax[FUSED_THREADS / 64];
+  const int wave_id = threadIdx.x >> 6;
+  if (lane == 0) { s_tmin[wave_id] = INFINITY; s_tmax[wave_id] = 0.f; }
   for (;;) {
     if (seg_k >= 8 || fetches > A.n_rays + 8) break;
     const int seg = ((int)(blockIdx.x & 7) + seg_k) & 7;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
         tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
       }
       if (e - s < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
-      wave_tmin = fminf(wave_tmin, tmin); wave_tmax = fmaxf(wave_tmax, tmax);
+      if (lane == 0) { s_tmin[wave_id] = fminf(s_tmin[wave_id], tmin); s_tmax[wave_id] = fmaxf(s_tmax[wave_id], tmax); }
     }
     if (lane == 0) {
       A.out_rgb[3 * ray] = cr; A.out_rgb[3 * ray + 1] = cg; A.out_rgb[3 * ray + 2] = cb;
@@ -188,9 +191,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
       if (A.out_depth) A.out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
     }
   }
-  if (A.t_minmax && lane == 0 && wave_tmin <= wave_tmax) {  // non-negative floats order like their bit patterns
-    atomicMin(reinterpret_cast<unsigned*>(A.t_minmax), __float_as_uint(wave_tmin));
-    atomicMax(reinterpret_cast<unsigned*>(A.t_minmax + 1), __float_as_uint(wave_tmax));
+  if (A.t_minmax && lane == 0 && s_tmin[wave_id] <= s_tmax[wave_id]) {  // non-negative floats order like their bit patterns
+    atomicMin(reinterpret_cast<unsigned*>(A.t_minmax), __float_as_uint(s_tmin[wave_id]));
+    atomicMax(reinterpret_cast<unsigned*>(A.t_minmax + 1), __float_as_uint(s_tmax[wave_id]));
   }
 }
 

@@ -159,8 +159,8 @@ def test_matrix_kernels_do_not_spill():
         assert r.returncode == 0, r.stderr[-2000:]
         return r.stderr
 
-    srcs = ("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip", "batch.hip")
-    with cf.ThreadPoolExecutor(4) as ex:
+    srcs = ("fused_fwd.hip", "field_x3.hip", "wgrad_x3.hip", "batch.hip", "lm_lookup.hip")
+    with cf.ThreadPoolExecutor(5) as ex:
         outs = dict(zip(srcs, ex.map(remarks, srcs)))
     for src, text in outs.items():
         spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", text)]

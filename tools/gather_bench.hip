@@ -105,5 +105,7 @@ int main() {
   // table-size sweep around the 4 MB L2 of one XCD, and the scattered atomics of the backward
   for (uint32_t mb : {1u, 2u, 4u, 8u, 16u, 32u}) run<1, 8>("buffer dword (size sweep)", table, mb * 262144u - 1u, 2048, 24, out);
   for (uint32_t mb : {4u, 8u, 64u, 128u}) run_scatter(table, mb * 262144u - 1u, 2048, 24);
+  // how many CUs does it take to saturate the memory-side atomic rate?  (256 threads per block, one block per CU up to 256)
+  for (int blocks : {16, 32, 64, 128, 256, 512, 1024}) run_scatter(table, 64u * 262144u - 1u, blocks, 24 * 2048 / blocks / 4);
   return 0;
 }
