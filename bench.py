@@ -94,7 +94,8 @@ def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     loss, grads, aux = opipe.loss_and_grads(P, o, d, cam, gt, noise, log2_T, block=block)
     dt = time.perf_counter() - t0
     n_samples = int(aux["samples"]["pts_offsets"][-1])
-    return dict(value=n_rays / dt, unit="rays/s", cores=os.cpu_count(), kind="port",
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()  # what OpenMP may run on
+    return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
                 sample=f"{n_rays} rays ({n_samples} samples) of the same batch, oracle fwd+bwd (no Adam), {dt:.1f} s; "
                        "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
 
