@@ -100,6 +100,19 @@ def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
                        "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
 
 
+def cpu_reference_field():
+    """BASELINE configs[0]: the reference's pure-PyTorch CPU field path (TorchNerfactoField, torch HashEncoding 2^19, SH, MLPs,
+    cumsum compositing) at 1024 rays x 48 samples, through oracle/torch_field.py -- the restatement pinned to the reference's
+    own classes by tests/golden (the reference cannot travel to the GPU box).  5 warm-up + 20 timed iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_field as tf
+
+    r = tf.time_config0(n_rays=1024, n_samples=48, warmup=5, iters=20, log2_hashmap_size=19)
+    return dict(workload="Nerfstudio nerfacto field (torch HashEncoding 16 levels 16..1024, 2^19) on synthetic Lego-like rays, 1024 rays x 48 samples",
+                fwd_ms=r["fwd_ms"], fwd_bwd_ms=r["fwd_bwd_ms"], train_rays_per_sec=1024 / (r["fwd_bwd_ms"] * 1e-3),
+                infer_rays_per_sec=1024 / (r["fwd_ms"] * 1e-3), threads=r["threads"], kind="port of the reference's torch path, pinned by golden vectors")
+
+
 def render_bench(hp, sc, args, fineness, torch):
     """BASELINE configs[4]: full-res camera-path pass, 1920x1080, hipGraph-captured per-tile inference (eval-mode ray
     march: noise = ones * fineness; same fineness as the training batches).  Untimed: graph capture + one warm-up frame."""
@@ -347,6 +360,7 @@ def main():
             out["render"] = render_bench(hp, sc, args, fineness, torch)
             out["batch_assembly"] = batch_assembly_bench(sc, torch)
         if not args.no_cpu_baseline:
+            out["cpu_reference_field"] = cpu_reference_field()
             out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
                                                0 if args.stage == "focal" else None, scene)
         print(json.dumps(out))

@@ -325,13 +325,51 @@ def gen_pixel_samplers(out):
     out["errupd_map_after"] = _Loader.cached_collated_batch["error_map"].numpy()
 
 
+def gen_torch_field(out):
+    """BASELINE configs[0] / SURVEY 8(c) item 5: the reference's pure-PyTorch field (TorchNerfactoField with the torch
+    HashEncoding) + get_weights + renderers on a small seeded batch, parameters included (a 2^12-entry table keeps the
+    fixture small), training mode (appearance embedding live), field evaluated on the flattened samples."""
+    from nerfstudio.cameras.rays import RayBundle
+    from nerfstudio.field_components.encodings import HashEncoding, SHEncoding
+    from nerfstudio.field_components.field_heads import FieldHeadNames
+    from nerfstudio.fields.nerfacto_field import TorchNerfactoField
+    from nerfstudio.model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+    torch.manual_seed(11)
+    n_img, R, S = 7, 24, 12
+    f = TorchNerfactoField(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=n_img,
+                           position_encoding=HashEncoding(log2_hashmap_size=12, implementation="torch"), direction_encoding=SHEncoding())
+    with torch.no_grad():
+        f.position_encoding.hash_table.mul_(300.0)  # the 1e-3 init gives an almost constant field
+    f.train()
+    o = torch.randn(R, 3) * 1.5
+    d = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+    cam = torch.randint(0, n_img, (R, 1))
+    rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones(R, 1), lookat_directions=d.clone(), camera_indices=cam)
+    bins = torch.linspace(0.2, 4.0, S + 1)[None].expand(R, S + 1)
+    rs = rb.get_ray_samples(bin_starts=bins[:, :-1, None], bin_ends=bins[:, 1:, None])
+    fo = f(rs.flatten())
+    density = fo[FieldHeadNames.DENSITY].view(R, S, 1)
+    rgb = fo[FieldHeadNames.RGB].view(R, S, 3)
+    w = rs.get_weights(density)
+    out["torchfield_origins"] = o.numpy(); out["torchfield_directions"] = d.numpy(); out["torchfield_cam"] = cam[:, 0].numpy().astype(np.int64)
+    out["torchfield_starts"] = bins[:, :-1, None].numpy().copy(); out["torchfield_ends"] = bins[:, 1:, None].numpy().copy()
+    for k, v in f.state_dict().items():
+        out["torchfield_param/" + k] = v.detach().numpy()
+    out["torchfield_density"] = density.detach().numpy(); out["torchfield_rgb_samples"] = rgb.detach().numpy()
+    out["torchfield_weights"] = w.detach().numpy()
+    out["torchfield_rgb"] = RGBRenderer(background_color="random")(rgb=rgb, weights=w).detach().numpy()
+    out["torchfield_acc"] = AccumulationRenderer()(weights=w).detach().numpy()
+    out["torchfield_depth"] = DepthRenderer(method="expected")(weights=w, ray_samples=rs).detach().numpy()
+
+
 def main():
     assert os.path.isdir(REF), "reference tree not mounted; fixtures can only be regenerated in the build container"
     _install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(1)
     out = {}
-    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam, gen_rays, gen_scheduler, gen_s3im, gen_pixel_samplers):
+    for fn in (gen_mlp, gen_composite, gen_activations, gen_sh, gen_losses, gen_adam, gen_rays, gen_scheduler, gen_s3im, gen_pixel_samplers, gen_torch_field):
         fn(out)
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)

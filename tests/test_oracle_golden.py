@@ -238,3 +238,29 @@ def test_error_pixel_sampler_matches_reference_in_distribution(golden):
         z = (mine - ref) / np.sqrt(np.maximum(2 * calls * p * (1 - p), 1e-9))
         live = p > 0
         assert np.abs(z[live]).max() < 5.0 and abs(z[live].mean()) < 0.15 and 0.8 < z[live].std() < 1.2
+
+
+def test_torch_field_port_matches_reference(golden):
+    """BASELINE configs[0]: oracle/torch_field.py (what bench.py times as the reference's pure-PyTorch CPU field path) against
+    the reference's TorchNerfactoField + get_weights + renderers, parameters loaded from the fixture."""
+    import os, sys
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import torch_field as tf
+
+    g = golden
+    params = {k.split("/", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("torchfield_param/")}
+    field = tf.TorchNerfactoFieldPort(num_images=params["embedding_appearance.embedding.weight"].shape[0], log2_hashmap_size=12)
+    missing = field.load_state_dict(params, strict=True)
+    field.train()
+    t = lambda k: torch.from_numpy(g["torchfield_" + k])  # noqa: E731
+    with torch.no_grad():
+        out = tf.render(field, t("origins"), t("directions"), t("starts"), t("ends"), t("cam"))
+    assert float(out["accumulation"].max()) > 0.3  # a field with structure, not the near-empty initial one
+    for mine, ref, tol in (("density", "density", 1e-6), ("rgb_samples", "rgb_samples", 1e-6), ("weights", "weights", 1e-6),
+                           ("rgb", "rgb", 1e-6), ("accumulation", "acc", 1e-6), ("depth", "depth", 1e-5)):
+        np.testing.assert_allclose(out[mine].numpy(), g["torchfield_" + ref], rtol=tol, atol=tol, err_msg=mine)
+    # the timing harness runs (tiny sizes here; bench.py uses 1024 x 48, 2^19)
+    r = tf.time_config0(n_rays=32, n_samples=8, warmup=1, iters=2, log2_hashmap_size=10)
+    assert r["fwd_ms"] > 0 and r["fwd_bwd_ms"] > 0 and r["threads"] >= 1
