@@ -70,7 +70,55 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
           const int* p = A.prim + 3 * ((int64_t)level * A.n_volumes + vol[k]);
           prim[k][0] = p[0]; prim[k][1] = p[1]; prim[k][2] = p[2];
         }
-        for (int h = split ? 0 : 1; h < 2; h++) {
+        if (!split) {
+          // coarse levels: consecutive samples of a ray sit in the same cell of the same volume and need the same 8 slots.
+          // Only the first lane of such a run gathers; the others take its values through the LDS crossbar (ds_bpermute),
+          // which costs the address path nothing -- and the address path is what bounds this kernel.
+          const int lane = tid & 63;
+#pragma unroll
+          for (int k = 0; k < kLmK; k++) {
+            const int s = tid + k * kLmThreads;
+            const bool valid = s < cnt;
+            Corners c;
+            uint32_t cell[3];
+            const int64_t tr = (int64_t)level * A.n_volumes + vol[k];
+            hash_corners(px[k], py[k], pz[k], scale, prim[k], A.bias ? A.bias + 3 * tr : nullptr, mask, c, cell);
+            const int pvol = __shfl_up(vol[k], 1, 64);
+            const uint32_t pcx = __shfl_up(cell[0], 1, 64), pcy = __shfl_up(cell[1], 1, 64), pcz = __shfl_up(cell[2], 1, 64);
+            const bool head = lane == 0 || pvol != vol[k] || pcx != cell[0] || pcy != cell[1] || pcz != cell[2];
+            const unsigned long long heads = __ballot(head);
+            half2_t v[8];
+            if (__popcll(heads) <= 40) {  // wave-uniform: enough lanes saved to pay for the shuffles
+              if (head) {
+#pragma unroll
+                for (int d = 0; d < 8; d++) v[d] = base[c.pos[d]];
+              }
+              const int src = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));  // the run's first lane
+#pragma unroll
+              for (int d = 0; d < 8; d++) v[d] = __builtin_bit_cast(half2_t, __shfl(__builtin_bit_cast(int, v[d]), src, 64));
+            } else {
+#pragma unroll
+              for (int d = 0; d < 8; d++) v[d] = base[c.pos[d]];
+            }
+            if (valid) {
+              float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + b0 + s
+                                   : reinterpret_cast<float2*>(A.out + (b0 + s) * 32 + 2 * level);
+              float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+              for (int d = 0; d < 8; d++) {
+                const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];  // :74-77, left-to-right sum (as gather_level)
+                a0 = (d == 0) ? t0 : a0 + t0;
+                a1 = (d == 0) ? t1 : a1 + t1;
+              }
+              const float2 rr = make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
+              if (ACC) { const float2 prev = *dst; *dst = make_float2(prev.x + rr.x, prev.y + rr.y); }
+              else *dst = rr;
+            }
+          }
+          __syncthreads();
+          continue;
+        }
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
           for (int k = 0; k < kLmK; k++) {
             const int s = tid + k * kLmThreads;
@@ -91,7 +139,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
                 half2_t v[8];
 #pragma unroll
                 for (int d = 0; d < 8; d++) {
-                  if (!split || (c.pos[d] >> top)) v[d] = base[c.pos[d]];
+                  if (c.pos[d] >> top) v[d] = base[c.pos[d]];
                   else v[d] = __builtin_bit_cast(half2_t, s_val[d * A.cap + s]);
                 }
                 float a0 = 0.f, a1 = 0.f;
