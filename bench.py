@@ -251,11 +251,10 @@ def main():
         o, d, cam, gt = batches[i % 4]
         block = (i % n_blocks) if args.stage == "focal" else None
         nxt = batches[(i + 1) % 4]
-        pre = None if args.no_prefetch else (nxt[0], nxt[1], noises[(i + 1) % 4])  # the data loader knows the next batch (focal stage only)
+        pre = None if args.no_prefetch else (nxt[0], nxt[1], noises[(i + 1) % 4])  # the data loader knows the next batch
+        # global stage: UpdateOctNodes K5/K6 every step, right after the forward like GFNeRFModel.get_outputs (nerfacto.py:598-616)
         out = hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3im_idx[i % 4],
-                            prefetch=pre)
-        if args.stage == "global" and not args.no_oct_update:
-            hp._timed("oct_update", hp.update_oct_nodes, out[1])  # UpdateOctNodes K5/K6 every global-stage step (nerfacto.py:605-613)
+                            prefetch=pre, update_oct=args.stage == "global" and not args.no_oct_update)
         return out
 
     for i in range(args.warmup):

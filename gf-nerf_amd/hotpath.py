@@ -194,16 +194,21 @@ class HotPath:
         s["n_dev"] = s["pts_offsets"][R:R + 1]
         return s
 
-    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False):
+    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None):
         """Run the sampler of the NEXT batch on a second stream now; the next self.sample(...) with the very same tensors
         collects it.  The ray march is latency-bound and the fused backward beside it fabric-bound, so the two share the
         chip (the backward is capped to cfg.prefetch_cus CUs meanwhile).  Only valid while the octree does not change
-        between the two steps, i.e. in the focal stage (UpdateOctNodes is global-stage only, nerfacto.py:598-616)."""
+        between the two steps, i.e. in the focal stage (UpdateOctNodes is global-stage only, nerfacto.py:598-616) -- or, in the
+        global stage, when `first` is this step's octree update: the reference runs UpdateOctNodes inside get_outputs, right
+        after the forward and before the backward (nerfacto.py:598-616), so update -> next sampler on the second stream is its
+        order."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
+            if first is not None:
+                first()
             s = self.sample(rays_o, rays_d_raw, noise, need_world)
         self._pre = (rays_o, rays_d_raw, noise, need_world, s)
 
@@ -352,9 +357,13 @@ class HotPath:
             demb = self.emb_grad if c.use_appearance_embedding else None
             scattered = c.fused_backward
             if scattered:
+                cap = self._pre is not None and 0 < c.prefetch_cus < 256  # leave CUs to the octree update + sampler on the second stream
+                prev = _lib.lib().gfn_set_decoder_cus(c.prefetch_cus) if cap else 0
                 self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                             s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                             gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+                if cap:
+                    _lib.lib().gfn_set_decoder_cus(prev)
                 dfeat = None
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -400,13 +409,21 @@ class HotPath:
         self._timed("hash_bwd", ops.hash_bwd, prim, self.bias_arg, s["warped_pts"], s["anchors"], dfeat, self.n_volumes,
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
-    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None):
+    def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None,
+                         update_oct=False):
         """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
         s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent.
-        prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage)."""
+        prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage; global
+        stage only together with update_oct).  update_oct (global stage): run UpdateOctNodes on this step's samples right after
+        the forward, like GFNeRFModel.get_outputs does."""
         c = self.cfg
         comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block)
-        if prefetch is not None and stage == STAGE_FOCAL:
+        if stage == STAGE_GLOBAL and update_oct:
+            if prefetch is not None:
+                self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx))
+            else:
+                self._timed("oct_update", self.update_oct_nodes, ctx)
+        elif prefetch is not None and stage == STAGE_FOCAL:
             self.prefetch_sample(*prefetch)
         loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
         R = rays_o.shape[0]
@@ -454,9 +471,10 @@ class HotPath:
         return [live]
 
     def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None, s3im_index=None,
-                   prefetch=None):
+                   prefetch=None, update_oct=False):
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
-        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch)
+        loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch,
+                                          update_oct=update_oct)
         if allreduce is not None:
             allreduce(self.grads(stage))
         self.optimizer_step(stage, block)
