@@ -8,6 +8,7 @@ and for training the matching backward, the Charbonnier loss and Adam.  Every st
 call through the C ABI into hand-written HIP kernels (ops.py); samples stay PACKED and the
 live sample count stays on the device (no host synchronisation inside a step).
 """
+import contextlib
 import math
 from dataclasses import dataclass
 
@@ -342,6 +343,17 @@ class HotPath:
         self._last_train_ctx = ctx
         return comp, ctx
 
+    @contextlib.contextmanager
+    def _cu_cap(self):
+        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it cfg.prefetch_cus CUs."""
+        cap = self._pre is not None and 0 < self.cfg.prefetch_cus < 256
+        prev = _lib.lib().gfn_set_decoder_cus(self.cfg.prefetch_cus) if cap else 0
+        try:
+            yield
+        finally:
+            if cap:
+                _lib.lib().gfn_set_decoder_cus(prev)
+
     def backward(self, ctx, g_rgb, g_acc=None):
         """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R])."""
         c = self.cfg
@@ -357,13 +369,10 @@ class HotPath:
             demb = self.emb_grad if c.use_appearance_embedding else None
             scattered = c.fused_backward
             if scattered:
-                cap = self._pre is not None and 0 < c.prefetch_cus < 256  # leave CUs to the octree update + sampler on the second stream
-                prev = _lib.lib().gfn_set_decoder_cus(c.prefetch_cus) if cap else 0
-                self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
-                            s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
-                            gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
-                if cap:
-                    _lib.lib().gfn_set_decoder_cus(prev)
+                with self._cu_cap():  # leave CUs to the octree update + sampler on the second stream
+                    self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                                s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
+                                gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
                 dfeat = None
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -379,13 +388,10 @@ class HotPath:
                 self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
                             gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
-            cap = self._pre is not None and 0 < c.prefetch_cus < 256
-            prev = _lib.lib().gfn_set_decoder_cus(c.prefetch_cus) if cap else 0
-            self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
-                        s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
-                        self.table_grad, n_dev=n_dev)
-            if cap:
-                _lib.lib().gfn_set_decoder_cus(prev)
+            with self._cu_cap():
+                self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                            s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
+                            self.table_grad, n_dev=n_dev)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision
