@@ -109,7 +109,7 @@ class HotPath:
         self._x3_images = [None, None]   # split-f16 weight images of the fused decoder (forward, backward)
         self._x3_stale = True
         self.refresh_shadows()
-        self._adam = {}
+        self._adam, self._adam_t = {}, {}
         self.step = 0
         self.weight_stats = torch.full((self.n_nodes,), 1000, dtype=torch.int64, device=self.dev)  # INIT_NODE_STAT
         self.alpha_stats = torch.full((self.n_nodes,), 1000, dtype=torch.int64, device=self.dev)
@@ -305,7 +305,32 @@ class HotPath:
     def _adam_state(self, name, p):
         if name not in self._adam:
             self._adam[name] = (torch.zeros_like(p), torch.zeros_like(p))
+            self._adam_t[name] = 0
         return self._adam[name]
+
+    def _adam_tick(self, name):
+        """Every parameter group is its own torch.optim.Adam in the reference (Optimizers, engine/optimizers.py:100-133): its
+        bias correction counts that group's steps, not the trainer's."""
+        self._adam_t[name] += 1
+        return self._adam_t[name]
+
+    def delete_optimizer(self, name):
+        """Optimizers.delete_optimizer (engine/optimizers.py:161-168; called by the update_optimizer callback,
+        gfnerf/nerfacto.py:448-488, for the groups that leave the active set): the group's Adam moments and step count go; a
+        later step of the group starts a fresh optimizer, like add_optimizer does.  Groups: "table", "mlp", "emb", "block<i>"."""
+        self._adam.pop(name, None)
+        self._adam_t.pop(name, None)
+
+    def update_optimizer(self, stage, active_blocks=()):
+        """The update_optimizer callback (gfnerf/nerfacto.py:448-488): init stage keeps the global encoding + fields and drops
+        every block's optimizer; block stage drops those and keeps only the active blocks' (added lazily at lr_block = 5e-3)."""
+        if stage == STAGE_GLOBAL:
+            for name in [k for k in self._adam if k.startswith("block")]:
+                self.delete_optimizer(name)
+        else:
+            keep = {f"block{b}" for b in active_blocks}
+            for name in [k for k in self._adam if k not in keep]:
+                self.delete_optimizer(name)
 
     def zero_grads(self, stage, block=None):
         if self.table_grad is None:
@@ -449,7 +474,7 @@ class HotPath:
         n_live = 17 * (1 << c.log2_T)
         if stage == STAGE_GLOBAL:
             m, v = self._adam_state("table", self.table)
-            self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self.step, lr=c.lr, eps=c.adam_eps,
+            self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self._adam_tick("table"), lr=c.lr, eps=c.adam_eps,
                         shadow_f16=self.table16, n=n_live)
             self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
             self._x3_stale = True
@@ -457,11 +482,11 @@ class HotPath:
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
                 m, v = self._adam_state(name, p)
-                self._timed("adam", ops.adam_step, p, gr, m, v, self.step, lr=c.lr, eps=c.adam_eps)
+                self._timed("adam", ops.adam_step, p, gr, m, v, self._adam_tick(name), lr=c.lr, eps=c.adam_eps)
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
-            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self.step, lr=c.lr_block, eps=c.adam_eps,
+            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(f"block{block}"), lr=c.lr_block, eps=c.adam_eps,
                         shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live,
                         shadow_pair=c.share_block_primes)
 

@@ -494,3 +494,38 @@ def test_global_stage_prefetch_keeps_the_reference_order(setup):
     # a handful of nodes agree exactly
     assert (w0 != w1).float().mean() < 0.01 and (a0 != a1).float().mean() < 0.01
     assert torch.equal(s0["pts_offsets"], s1["pts_offsets"])
+
+
+def test_optimizer_groups_follow_the_reference(setup):
+    """Every parameter group is its own Adam (bias correction counts the GROUP's steps); delete_optimizer / update_optimizer
+    drop a group's moments and step count like Optimizers.delete_optimizer + the update_optimizer callback."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14), seed=1, n_blocks=2)
+    for _ in range(3):
+        hp.train_step(o, d, cam, gt, noise, stage="global", s3im_index=s3)
+    assert hp._adam_t == {"table": 3, "mlp": 3, "emb": 3}
+    # first step of a block: a fresh Adam -> the update is lr_block * sign(g) wherever the gradient is not tiny (t = 1)
+    hp.update_optimizer("focal", active_blocks=[0])
+    assert set(hp._adam) == set()
+    before = hp.blocks[0].clone()
+    hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
+    g = hp.table_grad.float().view(-1)[: before.numel()].clone() / 128.0
+    hp.optimizer_step("focal", 0)
+    delta = (hp.blocks[0] - before).view(-1)
+    big = g.abs() > 1e-6
+    assert int(big.sum()) > 100
+    assert torch.allclose(delta[big], -hp.cfg.lr_block * torch.sign(g[big]), rtol=1e-3, atol=1e-9)
+    assert hp._adam_t == {"block0": 1}
+    hp.train_step(o, d, cam, gt, noise, stage="focal", block=1, s3im_index=s3)
+    assert hp._adam_t == {"block0": 1, "block1": 1}
+    hp.update_optimizer("focal", active_blocks=[1])     # block 0 leaves the active set: its optimizer is deleted
+    assert set(hp._adam) == {"block1"}
+    hp.update_optimizer("global")
+    assert set(hp._adam) == set()
