@@ -103,21 +103,31 @@ __global__ void errmap_update_kernel(const int32_t* __restrict__ idx, int64_t B,
 }
 
 // exclusive prefix of the block sums, one workgroup (n_blocks <= a few 1e5): prefix[0] = 0, prefix[b+1] = prefix[b] + sums[b].
+// Thread t owns a contiguous segment; the 1024 segment totals are scanned with wave shuffles (a serial loop over them in
+// one thread cost 40 us).  f64 throughout: exact, hence order independent, whenever the weights are dyadic (the parity tests).
+__device__ __forceinline__ double shfl_up_f64(double v, int off) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_up(lo, off, 64); hi = __shfl_up(hi, off, 64);
+  return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(1024) void errmap_prefix_kernel(const double* __restrict__ sums, int64_t nb, double* __restrict__ prefix) {
-  __shared__ double part[1024];
-  const int t = threadIdx.x;
+  __shared__ double wave_tot[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t per = (nb + 1023) / 1024;
   const int64_t a = min((int64_t)t * per, nb), b = min(a + per, nb);
   double acc = 0.0;
   for (int64_t k = a; k < b; k++) acc += sums[k];
-  part[t] = acc;
-  __syncthreads();
-  if (t == 0) {
-    double run = 0.0;
-    for (int k = 0; k < 1024; k++) { const double v = part[k]; part[k] = run; run += v; }
+  double incl = acc;  // inclusive scan over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double u = shfl_up_f64(incl, off);
+    if (lane >= off) incl += u;
   }
+  if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  double run = part[t];
+  double base = 0.0;
+  for (int w = 0; w < wave; w++) base += wave_tot[w];
+  double run = base + (incl - acc);  // exclusive prefix of this thread's segment
   if (t == 0) prefix[0] = 0.0;
   for (int64_t k = a; k < b; k++) { run += sums[k]; prefix[k + 1] = run; }
 }
@@ -231,12 +241,14 @@ __global__ __launch_bounds__(1024) void errmap_dedupe_kernel(const float* __rest
   extern __shared__ Slot l_table[];
   __shared__ int n_pending;
   Slot* table = use_lds ? l_table : g_table;
-  const unsigned long long mask = (unsigned long long)slots - 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int group = 0; group < 2; group++) {
     const int64_t g0 = group == 0 ? 0 : n_weighted, g1 = group == 0 ? n_weighted : B;
     if (g1 <= g0) continue;
-    for (int64_t k = t; k < slots; k += 1024) { table[k].key = kEmpty; table[k].owner = 0xffffffffu; }
+    int64_t gs = 1024;  // this group's share of the table: a power of two >= twice its draws
+    while (gs < 2 * (g1 - g0) && gs < slots) gs <<= 1;
+    const unsigned long long mask = (unsigned long long)gs - 1;
+    for (int64_t k = t; k < gs; k += 1024) { table[k].key = kEmpty; table[k].owner = 0xffffffffu; }
     for (int64_t d = g0 + t; d < g1; d += 1024) lin[d] = -1;  // -1 = pending; each draw belongs to one thread throughout
     __syncthreads();
     for (int a = 0; a < kAttempts; a++) {
