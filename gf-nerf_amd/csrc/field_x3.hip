@@ -162,6 +162,11 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
 struct ScatterArgs {
   const float* pts; const int* anchors; const int* prim_pool; const float* bias_pool; int64_t n_volumes; int log2_T;
   void* grad_pool; int grad_f16; LevelScales sc;
+  // record mode (f16 pool only): instead of issuing its atomics -- the L2 executes ~21 G scattered atomics/s whatever their
+  // scope or footprint (tools/gather_bench.hip) -- every add becomes a (slot, packed f16x2) record appended to the stream of
+  // (32 Ki-slot range, this workgroup): rec[(range * 256 + workgroup) * rec_cap + position], positions from LDS cursors;
+  // csrc/grad_part.hip then accumulates every range in LDS (gfn_grad_records_reduce)
+  uint2* rec; unsigned int* rec_count; unsigned int rec_cap; int n_ranges;
 };
 
 // sum v over the lanes [j, run_end] of this 32-lane half (runs = consecutive samples in one cell of one volume)
@@ -176,7 +181,8 @@ __device__ __forceinline__ float half_run_sum32(float v, int j, int run_end) {
 
 template <bool GRAD_F16>
 __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float* __restrict__ s_scale, int level, float px, float py, float pz,
-                                              int64_t vol, float gx, float gy, bool valid, int h, int j, uint32_t T) {
+                                              int64_t vol, float gx, float gy, bool valid, int h, int j, uint32_t T,
+                                              unsigned int* s_cursor = nullptr) {
   const int64_t tr = (int64_t)level * S.n_volumes + vol;
   Corners c;
   uint32_t cell[3];
@@ -206,6 +212,24 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
       c1[d] = half_run_sum32(c1[d], j, run_end);
     }
     issue = head;  // zero sums are skipped below
+  }
+  if (GRAD_F16 && S.rec) {  // wave-uniform
+    half2_t* baseh = reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(S.grad_pool) + (int64_t)level * T);
+    const uint32_t slot0 = (uint32_t)level * (T >> 1);
+    if (issue) {
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        if (c0[d] != 0.f || c1[d] != 0.f) {
+          const half2_t v = {(_Float16)c0[d], (_Float16)c1[d]};
+          const uint32_t slot = slot0 + c.pos[d];
+          const uint32_t range = slot >> GFN_GRAD_RANGE_LOG2;
+          const unsigned int pos = atomicAdd(s_cursor + range, 1u);  // LDS: this workgroup's cursor of the range
+          if (pos < S.rec_cap) S.rec[((size_t)range * 256 + blockIdx.x) * S.rec_cap + pos] = make_uint2(slot, __builtin_bit_cast(uint32_t, v));
+          else __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(baseh + c.pos[d]), v);  // stream full
+        }
+      }
+    }
+    return;
   }
   if (issue) {
     if (GRAD_F16) {
@@ -247,7 +271,10 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
+  __shared__ unsigned int s_rec_cursor[SCATTER == 1 ? GFN_GRAD_MAX_RANGES : 1];
   if (SCATTER && threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = S.sc.s[threadIdx.x];
+  if (SCATTER == 1)
+    for (int e = threadIdx.x; e < GFN_GRAD_MAX_RANGES; e += blockDim.x) s_rec_cursor[e] = 0;
   __syncthreads();
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + BWD_CHUNKS * 64;
@@ -400,7 +427,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       for (int a = 0; a < 8; a++) {
         const int level = 2 * h + (a & 1) + 4 * (a >> 1);
         const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
-        if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
+        if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, s_rec_cursor);
         else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
       }
     } else if (valid) {
@@ -409,6 +436,11 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         dst[2 * qd + h] = make_float4(acc_get(gf, 4 * qd) * inv, acc_get(gf, 4 * qd + 1) * inv, acc_get(gf, 4 * qd + 2) * inv,
                                       acc_get(gf, 4 * qd + 3) * inv);
     }
+  }
+  if (SCATTER == 1 && S.rec) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < S.n_ranges; e += blockDim.x)
+      S.rec_count[e * 256 + blockIdx.x] = s_rec_cursor[e] < S.rec_cap ? s_rec_cursor[e] : S.rec_cap;
   }
 }
 
@@ -507,6 +539,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
 struct ScatterHost {  // optional: scatter d feat into a table gradient pool instead of writing it
   const float* pts = nullptr; const int32_t* anchors = nullptr; const int32_t* prim_pool = nullptr; const float* bias_pool = nullptr;
   int64_t n_volumes = 0; int log2_T = 0; void* grad_pool = nullptr; int grad_f16 = 0;
+  void* rec = nullptr; unsigned int* rec_count = nullptr; int64_t rec_cap_total = 0;  // record mode (see ScatterArgs)
 };
 
 static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
@@ -537,6 +570,18 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   ScatterArgs S;
   S.pts = sh.pts; S.anchors = sh.anchors; S.prim_pool = sh.prim_pool; S.bias_pool = sh.bias_pool; S.n_volumes = sh.n_volumes; S.log2_T = sh.log2_T;
   S.grad_pool = sh.grad_pool; S.grad_f16 = sh.grad_f16;
+  S.rec = reinterpret_cast<uint2*>(sh.rec); S.rec_count = sh.rec_count; S.rec_cap = 0; S.n_ranges = 0;
+  if (sh.rec) {
+    const int64_t T = 1ll << sh.log2_T;
+    const int64_t n_ranges = (8 * T + T / 2 + (1ll << GFN_GRAD_RANGE_LOG2) - 1) >> GFN_GRAD_RANGE_LOG2;
+    GFN_CHECK_ARG(sh.grad_f16 && sh.rec_count && (reinterpret_cast<uintptr_t>(sh.rec) & 15) == 0 && n_ranges <= GFN_GRAD_MAX_RANGES,
+                  "%s: records need the f16 pool, a count array, a 16-byte aligned buffer and log2_T <= 21", fn);
+    const int64_t cap = (sh.rec_cap_total / (n_ranges * 256)) & ~1ll;  // 256 workgroup streams per range whatever the grid
+    GFN_CHECK_ARG(cap >= 2, "%s: record buffer too small (%lld ranges x 256 streams)", fn, (long long)n_ranges);
+    S.rec_cap = (unsigned int)(cap > 0x7ffffffe ? 0x7ffffffe : cap);
+    S.n_ranges = (int)n_ranges;
+    GFN_CHECK_HIP(hipMemsetAsync(sh.rec_count, 0, (size_t)n_ranges * 256 * sizeof(unsigned int), gfn_stream(stream)));
+  }
   gfn_hash_level_scales_host(S.sc.s);
   const bool planes = planes_hi != nullptr;
   const int mode = !scatter ? 0 : (sh.grad_f16 ? 1 : 2);
@@ -562,7 +607,8 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const void* bwd_image, int64_t n_max, const int32_t* n_dev, const float* pts, const int32_t* anchors,
                              const int32_t* prim_pool, const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
-                             const int32_t* cam_idx, float* demb, void* stream) {
+                             const int32_t* cam_idx, float* demb, void* records, uint32_t* record_counts, int64_t record_capacity,
+                             void* stream) {
   GFN_CHECK_ARG(n_max == 0 || grad_pool, "gfn_field_bwd_scatter_x3: null gradient pool");
   GFN_CHECK_ARG(n_max == 0 || (planes_hi == nullptr) == (planes_lo == nullptr), "gfn_field_bwd_scatter_x3: planes need both halves");
   GFN_CHECK_ARG(n_max == 0 || !planes_hi || gmax_dev, "gfn_field_bwd_scatter_x3: planes need gmax");
@@ -570,6 +616,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
   ScatterHost sh;
   sh.pts = pts; sh.anchors = anchors; sh.prim_pool = prim_pool; sh.bias_pool = bias_pool; sh.n_volumes = n_volumes; sh.log2_T = log2_T;
   sh.grad_pool = grad_pool; sh.grad_f16 = grad_f16;
+  sh.rec = records; sh.rec_count = record_counts; sh.rec_cap_total = record_capacity;
   return field_bwd_x3_impl("gfn_field_bwd_scatter_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, nullptr, gmax_dev, planes_hi, planes_lo,
                            plane_cap, ray_id, cam_idx, demb, sh, stream);
 }

@@ -48,6 +48,8 @@ class HotPathConfig:
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
+    lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
+    record_capacity: int = 1 << 26   # 8-byte record slots (512 MiB) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 224          # CUs left to the fused backward while a prefetched sampler runs beside it
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
@@ -71,6 +73,7 @@ class HotPath:
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
+        self._records = None
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
@@ -368,6 +371,14 @@ class HotPath:
         self._last_train_ctx = ctx
         return comp, ctx
 
+    def _record_buffers(self):
+        c = self.cfg
+        if not (c.lds_accumulate and c.grad_f16 and c.log2_T <= 21):
+            return None
+        if self._records is None:
+            self._records = ops.grad_records_buffers(c.log2_T, c.record_capacity, self.dev)
+        return self._records
+
     @contextlib.contextmanager
     def _cu_cap(self):
         """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it cfg.prefetch_cus CUs."""
@@ -394,10 +405,13 @@ class HotPath:
             demb = self.emb_grad if c.use_appearance_embedding else None
             scattered = c.fused_backward
             if scattered:
+                rec = self._record_buffers()
                 with self._cu_cap():  # leave CUs to the octree update + sampler on the second stream
                     self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
-                                gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+                                gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
+                if rec is not None:
+                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T)
                 dfeat = None
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -413,10 +427,13 @@ class HotPath:
                 self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
                             gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
+            rec = self._record_buffers()
             with self._cu_cap():
                 self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
-                            self.table_grad, n_dev=n_dev)
+                            self.table_grad, n_dev=n_dev, records=rec)
+            if rec is not None:
+                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision

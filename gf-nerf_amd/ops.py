@@ -778,7 +778,7 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
 
 
 def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, prim_pool, bias_pool, n_volumes, log2_T, grad_pool,
-                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None):
+                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None):
     """Decoder backward + hash scatter in one kernel: accumulates into grad_pool (f16 x128-scaled or f32, like hash_bwd); with
     planes / gmax (global stage) it also writes the dz planes for wgrad_x3 and the appearance-embedding gradient."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
@@ -793,12 +793,34 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
     n = d_sigma.shape[0]
     ph, pl = planes if planes is not None else (None, None)
     cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
+    rec, cnt = (records[0], records[1]) if records is not None else (None, None)
+    if rec is not None:
+        _chk(rec, torch.int64, "records"); _chk(cnt, torch.int32, "counts")
+        if cnt.numel() != _lib.lib().gfn_grad_record_ranges(int(log2_T)) * 256 or grad_pool.dtype != torch.float16:
+            raise _lib.GfnError("field_bwd_scatter_x3: records need counts int32 [ranges * 256] and the f16 gradient pool")
     rc = _lib.lib().gfn_field_bwd_scatter_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev), _ptr(pts),
                                              _ptr(anchors), _ptr(prim_pool), _ptr(bias_pool), n_volumes, log2_T, _ptr(grad_pool),
                                              int(grad_pool.dtype == torch.float16), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id),
-                                             _ptr(cam_idx), _ptr(demb), _stream())
+                                             _ptr(cam_idx), _ptr(demb), _ptr(rec), _ptr(cnt), rec.numel() if rec is not None else 0, _stream())
     _lib.check(rc, "gfn_field_bwd_scatter_x3")
     return grad_pool
+
+
+def grad_records_buffers(log2_T, capacity, device):
+    """(records int64 [capacity], counts int32 [ranges * 256]) for the deferred-atomics backward: one record stream per
+    (32 Ki-slot range, producing workgroup)."""
+    n_ranges = _lib.lib().gfn_grad_record_ranges(int(log2_T))
+    if capacity < n_ranges * 256 * 2:
+        raise _lib.GfnError(f"grad_records_buffers: capacity must be at least {n_ranges * 512} records")
+    return (torch.empty(int(capacity), dtype=torch.int64, device=device), torch.empty(n_ranges * 256, dtype=torch.int32, device=device))
+
+
+def grad_records_reduce(records, grad_pool, log2_T):
+    """Accumulate the (slot, value) records of field_bwd_scatter_x3(records=...) into grad_pool, one slot range per workgroup, in LDS."""
+    rec, cnt = records
+    _chk(rec, torch.int64, "records"); _chk(cnt, torch.int32, "counts"); _chk(grad_pool, torch.float16, "grad_pool")
+    rc = _lib.lib().gfn_grad_records_reduce(_ptr(rec), _ptr(cnt), rec.numel(), int(log2_T), _ptr(grad_pool), _stream())
+    _lib.check(rc, "gfn_grad_records_reduce")
 
 
 def sh4(dirs):

@@ -300,7 +300,21 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const float* pts, const int32_t* anchors, const int32_t* prim_pool,
                              const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap,
-                             const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* stream);
+                             const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* records,
+                             uint32_t* record_counts, int64_t record_capacity, void* stream);
+/* records != NULL (f16 pool only) DEFERS the atomics of gfn_field_bwd_scatter_x3: the pool's live slots (f16
+ * pairs [0, 17T/2)) are cut into ranges of 2^GFN_GRAD_RANGE_LOG2 slots, and every add becomes a record (slot u32,
+ * packed f16x2 value) in the stream of (range, workgroup): records[(range * 256 + workgroup) * cap + i] with
+ * cap = record_capacity / (n_ranges * 256) 8-byte records (16-byte aligned buffer), counts in record_counts u32
+ * [n_ranges * 256] (gfn_grad_record_ranges(log2_T) ranges); a full stream falls back to the atomic.
+ * gfn_grad_records_reduce then lets the workgroup that owns a range add its 256 streams into a 128 KiB LDS image
+ * (ds_pk_add_f16: the reference's f16 accumulation) and add the image to grad_pool_f16 with plain stores
+ * (csrc/grad_part.hip) -- the L2 executes only ~21 G scattered atomics/s.  log2_T <= 21. */
+#define GFN_GRAD_RANGE_LOG2 15
+#define GFN_GRAD_MAX_RANGES 544
+int gfn_grad_record_ranges(int log2_T);
+int gfn_grad_records_reduce(const void* records, const uint32_t* record_counts, int64_t record_capacity, int log2_T,
+                            void* grad_pool_f16, void* stream);
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);
