@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--atomic-backward", action="store_true", help="backward issues its table adds as global atomics instead of records accumulated in LDS")
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
-    ap.add_argument("--prefetch-cus", type=int, default=224, help="CUs left to the fused backward while the prefetched sampler runs beside it")
+    ap.add_argument("--prefetch-cus", type=int, default=192, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=8,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
     ap.add_argument("--render-decoder-cus", type=int, default=240, help="CUs the fused forward may occupy while a sampler runs beside it")
@@ -218,7 +218,7 @@ def main():
     n_cams = sc["c2w"].shape[0]
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
-                                mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus,
+                                mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
                                 fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, lm_halves_from=args.lm_halves_from)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
                          device=f"cuda:{local_rank if world > 1 else 0}")

@@ -50,7 +50,8 @@ class HotPathConfig:
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
     record_capacity: int = 1 << 26   # 8-byte record slots (512 MiB) shared by the (range, workgroup) streams; a full stream falls back to atomics
-    prefetch_cus: int = 224          # CUs left to the fused backward while a prefetched sampler runs beside it
+    prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
+    prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
@@ -380,10 +381,11 @@ class HotPath:
         return self._records
 
     @contextlib.contextmanager
-    def _cu_cap(self):
-        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it cfg.prefetch_cus CUs."""
-        cap = self._pre is not None and 0 < self.cfg.prefetch_cus < 256
-        prev = _lib.lib().gfn_set_decoder_cus(self.cfg.prefetch_cus) if cap else 0
+    def _cu_cap(self, stage=STAGE_FOCAL):
+        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it some of the CUs."""
+        n = self.cfg.prefetch_cus_global if stage == STAGE_GLOBAL else self.cfg.prefetch_cus
+        cap = self._pre is not None and 0 < n < 256
+        prev = _lib.lib().gfn_set_decoder_cus(n) if cap else 0
         try:
             yield
         finally:
@@ -406,7 +408,7 @@ class HotPath:
             scattered = c.fused_backward
             if scattered:
                 rec = self._record_buffers()
-                with self._cu_cap():  # leave CUs to the octree update + sampler on the second stream
+                with self._cu_cap(STAGE_GLOBAL):  # leave CUs to the octree update + sampler on the second stream
                     self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
