@@ -108,7 +108,14 @@ def cpu_reference_field():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_field as tf
 
-    r = tf.time_config0(n_rays=1024, n_samples=48, warmup=5, iters=20, log2_hashmap_size=19)
+    import torch
+
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(prev, 16))  # a one-GPU box's CPU share; 128 oversubscribed threads ran this 10x slower
+    try:
+        r = tf.time_config0(n_rays=1024, n_samples=48, warmup=5, iters=20, log2_hashmap_size=19)
+    finally:
+        torch.set_num_threads(prev)
     return dict(workload="Nerfstudio nerfacto field (torch HashEncoding 16 levels 16..1024, 2^19) on synthetic Lego-like rays, 1024 rays x 48 samples",
                 fwd_ms=r["fwd_ms"], fwd_bwd_ms=r["fwd_bwd_ms"], train_rays_per_sec=1024 / (r["fwd_bwd_ms"] * 1e-3),
                 infer_rays_per_sec=1024 / (r["fwd_ms"] * 1e-3), threads=r["threads"], kind="port of the reference's torch path, pinned by golden vectors")
