@@ -299,16 +299,19 @@ __global__ __launch_bounds__(256) void adam_ex_kernel(float* __restrict__ p, con
                                                       int64_t n, float one_m_b1, float beta2, float one_m_b2,
                                                       float step_size, float bc2_sqrt, float eps,
                                                       _Float16* __restrict__ shadow, int shadow_pair) {
+  // non-temporal accesses: 1 GB streams through once per step and must not evict what the level-major lookup of the next
+  // step keeps in L2 when this kernel runs beside it (HotPathConfig.async_adam)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float gi = G16 ? (float)reinterpret_cast<const _Float16*>(g)[i] : reinterpret_cast<const float*>(g)[i];
+    float gi = G16 ? (float)__builtin_nontemporal_load(reinterpret_cast<const _Float16*>(g) + i) : __builtin_nontemporal_load(reinterpret_cast<const float*>(g) + i);
     gi = gi * g_scale;
-    const float mi = m[i] + (gi - m[i]) * one_m_b1;
-    const float vi = v[i] * beta2 + (one_m_b2 * gi) * gi;
-    m[i] = mi;
-    v[i] = vi;
+    const float m0 = __builtin_nontemporal_load(m + i), v0 = __builtin_nontemporal_load(v + i), p0 = __builtin_nontemporal_load(p + i);
+    const float mi = m0 + (gi - m0) * one_m_b1;
+    const float vi = v0 * beta2 + (one_m_b2 * gi) * gi;
+    __builtin_nontemporal_store(mi, m + i);
+    __builtin_nontemporal_store(vi, v + i);
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    const float pi = p[i] - step_size * (mi / denom);
-    p[i] = pi;
+    const float pi = p0 - step_size * (mi / denom);
+    __builtin_nontemporal_store(pi, p + i);
     // plain shadow: element i; pair layout {g0,g1,b0,b1} per slot: the block half of slot i/2
     if (shadow) shadow[shadow_pair ? ((i >> 1) * 4 + 2 + (i & 1)) : i] = (_Float16)pi;
   }

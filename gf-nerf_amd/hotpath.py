@@ -48,6 +48,8 @@ class HotPathConfig:
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
+    async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
+                                     # frozen global table (HBM-bound beside address-path-bound)
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
     record_capacity: int = 1 << 26   # 8-byte record slots (512 MiB) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
@@ -75,6 +77,7 @@ class HotPath:
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
         self._records = None
+        self._opt_stream, self._opt_pending = None, False
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
@@ -168,6 +171,7 @@ class HotPath:
         return r
 
     def export_params(self):
+        self._sync_opt()
         """Host copies of every parameter / state blob (for checkpoints and for the test oracle)."""
         c = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
         return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[c(b) for b in self.blocks],
@@ -226,11 +230,20 @@ class HotPath:
         T, V = self.cfg.log2_T, self.n_volumes
         fused = (self.cfg.fused_field and self.cfg.hidden == 128) if fused is None else fused
         lm = lm and fused and self.cfg.mlp_precision == "x3"  # the x3 decoder reads level-major features
+        if not (lm and block is not None):
+            self._sync_opt()
         if block is not None and self._pairs_stale:  # the global table moved since the interleaved images were built
             self.refresh_shadows()
         if self.cfg.table_f16_shadow and block is not None and self.cfg.share_block_primes:
             feat = self._timed("hash_fwd", ops.hash_fwd_pair, self.blocks16[block], self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, n_dev=n_dev)
+        elif self.cfg.table_f16_shadow and lm and block is not None and self._opt_pending:
+            # the frozen global table first, beside the previous step's Adam on the block table; then wait for that Adam
+            feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
+                               n_dev=n_dev, halves_from=self.cfg.lm_halves_from, planar=True)
+            self._sync_opt()
+            self._timed("hash_fwd", ops.hash_fwd_lm, self.blocks16[block], self.block_prims[block], self.bias_arg, s["warped_pts"], s["anchors"],
+                        V, T, n_dev=n_dev, halves_from=self.cfg.lm_halves_from, planar=True, out=feat, accumulate=True)
         elif self.cfg.table_f16_shadow and lm:
             feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
                                table2_f16=self.blocks16[block] if block is not None else None,
@@ -272,6 +285,7 @@ class HotPath:
 
     def _forward_fused(self, s, cam_idx, block, early_T, save=False, planes=None, want_weights=True):
         """Hash lookup + decoder + compositing in one launch (csrc/fused_fwd.hip) -> (field dict, comp dict)."""
+        self._sync_opt()
         if block is not None and self._pairs_stale:
             self.refresh_shadows()
         sh = ops.sh4(s["dirs_unit"])
@@ -336,11 +350,18 @@ class HotPath:
             for name in [k for k in self._adam if k not in keep]:
                 self.delete_optimizer(name)
 
+    def _sync_opt(self):
+        """Everything after this point sees the last (asynchronous) optimiser step and its zeroed gradient pool."""
+        if self._opt_pending:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._opt_pending = False
+
     def zero_grads(self, stage, block=None):
         if self.table_grad is None:
             self.table_grad = torch.zeros(self.table.shape, dtype=torch.float16 if self.cfg.grad_f16 else torch.float32,
                                           device=self.dev)
-        ops.fill_zero(self.table_grad)
+        if not self._opt_pending:  # else: zeroed behind the asynchronous Adam
+            ops.fill_zero(self.table_grad)
         if stage == STAGE_GLOBAL:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
@@ -395,6 +416,7 @@ class HotPath:
     def backward(self, ctx, g_rgb, g_acc=None):
         """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R])."""
         c = self.cfg
+        self._sync_opt()  # the gradient pool is zeroed behind the asynchronous Adam
         s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
         train_mlp = ctx["stage"] == STAGE_GLOBAL
         n_dev = s["n_dev"]
@@ -505,12 +527,23 @@ class HotPath:
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
-            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(f"block{block}"), lr=c.lr_block, eps=c.adam_eps,
-                        shadow_f16=self.blocks16[block] if c.table_f16_shadow else None, n=n_live,
-                        shadow_pair=c.share_block_primes)
+            run = lambda: self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(f"block{block}"),  # noqa: E731
+                                      lr=c.lr_block, eps=c.adam_eps, shadow_f16=self.blocks16[block] if c.table_f16_shadow else None,
+                                      n=n_live, shadow_pair=c.share_block_primes)
+            if c.async_adam and c.level_major and not c.share_block_primes:
+                if self._opt_stream is None:
+                    self._opt_stream = torch.cuda.Stream(device=self.dev)
+                self._opt_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._opt_stream):
+                    run()
+                    ops.fill_zero(self.table_grad)  # the next step's zero_grads
+                self._opt_pending = True
+            else:
+                run()
 
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
+        self._sync_opt()
         # only elements [0, 17T) of a table can receive a gradient (level-overlap quirk): reduce 71 MB, not 134 MB
         live = self.table_grad.view(-1)[: 17 * (1 << self.cfg.log2_T)]
         if stage == STAGE_GLOBAL:
