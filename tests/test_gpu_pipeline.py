@@ -564,3 +564,37 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
         assert np.abs(got - ref).max() <= max(2.0 * noise_floor, 2e-2 * scale)
         np.testing.assert_allclose(np.abs(got).sum(), np.abs(ref).sum(), rtol=2e-2)  # (the signed sum cancels to almost nothing)
         assert ((ref != 0) != (got != 0)).mean() < 2e-3
+
+
+def test_async_adam_is_the_same_training_run(setup):
+    """HotPathConfig.async_adam: Adam + pool zeroing on a third stream beside the next step's global-table lookup gives the
+    same losses and (up to the f16 gradient noise) the same block table as the synchronous order."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    sc, t = S["sc"], S["t"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
+    runs = []
+    for flag in (False, True):
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14, async_adam=flag),
+                             seed=1, n_blocks=1)
+        hp.blocks[0].uniform_(-1e-3, 1e-3); hp.refresh_shadows()
+        losses = []
+        for _ in range(6):
+            loss, _ = hp.train_step(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
+            losses.append(loss)
+        assert hp._opt_pending == flag
+        P = hp.export_params()  # synchronises with the optimiser stream
+        assert not hp._opt_pending
+        runs.append(([float(x) for x in losses], hp.blocks[0].clone(), hp.table_grad.clone()))
+    (l0, b0, g0), (l1, b1, g1) = runs
+    np.testing.assert_allclose(l0, l1, rtol=2e-3)
+    assert l0[-1] < l0[0]
+    # Adam normalises every gradient to about +-lr_block per step, so an entry whose tiny gradient comes out with the other
+    # sign (f16 accumulation order) walks the other way: a few lr_block apart at most, almost all entries much closer
+    assert float((b0 - b1).abs().max()) <= 6 * 5e-3 * 2 * 1.2
+    assert float((b0 - b1).abs().mean()) < 3e-3
+    assert float(g1.abs().max()) == 0.0  # the pool was zeroed behind the last asynchronous Adam
