@@ -4,11 +4,14 @@
 // level of every table at once (142 MB of f16 slots): each corner of a fine level is an L2 miss, and the memory fabric
 // serves only ~57 G such 64-byte requests per second whatever the instruction form (tools/gather_bench.hip).  The same
 // benchmark gathers 262 G/s from a table that fits the 4 MB L2 of an XCD and 121 G/s from an 8 MB one.  So here every
-// workgroup owns a contiguous run of samples (points parked in LDS) and ALL workgroups sweep the table together:
-//     for table: for level: for address half h (4 MB of f16 pairs): every sample's corners that fall into that half
+// workgroup owns a contiguous run of samples (thread t keeps samples t, t + 1024, ... in registers for the whole
+// kernel) and ALL workgroups sweep the table together, one launch per table:
+//     for level: for address half h (4 MB of f16 pairs): every sample's corners that fall into that half
 // Corners of the first half wait in LDS; the second half completes the level: blend (same order as the direct kernel,
-// so the features are bit-identical), round to f16, store (the second table adds to the first's result).  Level l's upper half and level l+1's
-// lower half are the same addresses (the reference's level-overlap quirk), so consecutive passes share a warm L2.
+// so the features are bit-identical), round to f16, store (the second table's launch adds to the first's result).
+// Level l's upper half and level l+1's lower half are the same addresses (the reference's level-overlap quirk), so
+// consecutive passes share a warm L2.  Coarse levels (< halves_from) are not split; there the first lane of a run of
+// samples in one cell gathers for the whole run.
 #include "gfn_common.h"
 #include "hash_device.h"
 
@@ -22,7 +25,7 @@ struct LmArgs {
   const void* table; const int* prim; const float* bias;
   int64_t n_volumes; int log2_T; int halves_from;  // levels >= halves_from are split into address halves
   int cap;  // samples of one workgroup per round (LDS capacity)
-  float* out;  // f32 [n,32], row-major
+  float* out;  // f32 [n,32] row-major, or level-major float2 [16][n_max]
   LevelScales sc;
 };
 
