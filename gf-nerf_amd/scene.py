@@ -127,14 +127,20 @@ def build_scene(n_side=20, max_depth=16, seed=1234, cache_dir=None, threads=0):
     c2w, intri, bounds = make_cameras(n_side=n_side, seed=seed)
     key = f"scene_s{n_side}_d{max_depth}_seed{seed}.npz"
     path = os.path.join(cache_dir, key) if cache_dir else None
+    nodes = None
     if path and os.path.exists(path):
-        z = np.load(path)
-        nodes, transes = z["nodes"], z["transes"]
-    else:
+        try:
+            z = np.load(path)
+            nodes, transes = z["nodes"], z["transes"]
+        except Exception:  # a torn or foreign file: rebuild
+            nodes = None
+    if nodes is None:
         nodes, transes = ops.octree_build(c2w, intri, bounds, max_depth=max_depth, bbox_side_len=BBOX_SIDE, seed=seed,
                                           threads=threads)
-        if path:
+        if path:  # several ranks of one node may get here at once: write privately, publish atomically
             os.makedirs(cache_dir, exist_ok=True)
-            np.savez(path, nodes=nodes, transes=transes)
+            tmp = f"{path}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, nodes=nodes, transes=transes)
+            os.replace(tmp, path)
     return dict(c2w=c2w, intri=intri, bounds=bounds, nodes=nodes, transes=transes,
                 n_nodes=nodes.size // 128, n_trans=transes.size // 576)
