@@ -48,6 +48,7 @@ def parse():
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
     ap.add_argument("--async-adam", action="store_true", help="focal stage: Adam on a third stream beside the next step's global-table lookup")
+    ap.add_argument("--lm-global-forward", action="store_true", help="global stage: level-major lookup + decoder + compositing instead of the fused forward kernel")
     ap.add_argument("--atomic-backward", action="store_true", help="backward issues its table adds as global atomics instead of records accumulated in LDS")
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
@@ -227,7 +228,7 @@ def main():
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
                                 mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
-                                fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, lm_halves_from=args.lm_halves_from)
+                                fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
                          device=f"cuda:{local_rank if world > 1 else 0}")
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables

@@ -122,9 +122,10 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     for (int u = 0; u < 2; u++) {
       float x[8];
       if (PLANAR) {  // columns 16u + 8h + i = levels 8u + 4h .. + 3 of sample q
+        const float2* fq = reinterpret_cast<const float2*>(feat) + (int64_t)(4 * h) * feat_stride + q;  // per lane; the rest is uniform
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-          const float2 v = reinterpret_cast<const float2*>(feat)[(int64_t)(8 * u + 4 * h + m) * feat_stride + q];
+          const float2 v = fq[(int64_t)(8 * u + m) * feat_stride];
           x[2 * m] = v.x; x[2 * m + 1] = v.y;
         }
       } else {
@@ -501,7 +502,6 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
   GFN_CHECK_ARG(feat_stride == 0 || feat_stride >= n_max, "gfn_field_fwd_x3: feat_stride=%lld must be 0 or >= n_max", (long long)feat_stride);
-  GFN_CHECK_ARG(feat_stride == 0 || !planes_hi, "gfn_field_fwd_x3: level-major features and activation planes are not combined (the register file holds one or the other)");
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 8", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
@@ -512,7 +512,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
                   reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
                 "gfn_field_fwd_x3: image, feat, sh, emb and planes must be 16-byte aligned");
   static bool attr_set = false;
-#define GFN_FWD_ALL(X) X(true, true, false) X(true, false, false) X(false, false, false) X(true, false, true) X(false, false, true)
+#define GFN_FWD_ALL(X) X(true, true, false) X(true, false, false) X(false, false, false) X(true, false, true) X(false, false, true) X(true, true, true)
   if (!attr_set) {
 #define GFN_SET(S, P, L) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<S, P, L>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
     GFN_FWD_ALL(GFN_SET)

@@ -47,6 +47,7 @@ class HotPathConfig:
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
+    level_major_global: bool = False # also in the global stage (one table): measured 2.69 vs 2.40 ms/step early, 2.80 vs 2.79 after 200 steps
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
@@ -379,9 +380,10 @@ class HotPath:
         planes = self._planes(s["ts"].shape[0])[0] if (fused and train_mlp) else None
         blk = block if stage == STAGE_FOCAL else None
         # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
-        # (two tables; with one table the fused kernel's early termination and resident features make it a tie)
-        lm = (c.level_major and blk is not None and fused and c.mlp_precision == "x3" and c.table_f16_shadow and not c.keep_features
-              and not c.share_block_primes)
+        # (with one table the fused kernel's early termination makes it a tie at first and a loss once the scene has density:
+        # cfg.level_major_global)
+        lm = (c.level_major and (blk is not None or c.level_major_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
+              and not c.keep_features and not (blk is not None and c.share_block_primes))
         self.last_forward = "lm" if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
         if fused and self._fused_ok(blk) and not lm:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)

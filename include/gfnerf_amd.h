@@ -272,8 +272,7 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * gfn_grad_scale_host(*gmax_dev) (gmax_dev: device f32 = largest |gradient| entering the decoder,
  * from gfn_grad_max into a zeroed word), and accumulates the appearance-embedding gradient into
  * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients.
- * feat_stride: 0 = feat is f32 [n,32]; else feat is level-major float2 [16][feat_stride] (gfn_hash_fwd_lm, planar;
- * not together with planes). */
+ * feat_stride: 0 = feat is f32 [n,32]; else feat is level-major float2 [16][feat_stride] (gfn_hash_fwd_lm, planar). */
 #define GFN_FIELD_X3_FWD_BYTES 149248
 #define GFN_FIELD_X3_BWD_BYTES 131072
 #define GFN_FIELD_X3_FWD_PLANE_LD 480
