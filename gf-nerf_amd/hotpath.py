@@ -52,7 +52,7 @@ class HotPathConfig:
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
-    record_capacity: int = 1 << 26   # 8-byte record slots (512 MiB) shared by the (range, workgroup) streams; a full stream falls back to atomics
+    record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
     prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
