@@ -180,7 +180,7 @@ __device__ __forceinline__ float half_run_sum32(float v, int j, int run_end) {
   return v;
 }
 
-template <bool GRAD_F16>
+template <bool GRAD_F16, bool RECORD = false>
 __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float* __restrict__ s_scale, int level, float px, float py, float pz,
                                               int64_t vol, float gx, float gy, bool valid, int h, int j, uint32_t T,
                                               unsigned int* s_cursor = nullptr) {
@@ -214,7 +214,7 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
     }
     issue = head;  // zero sums are skipped below
   }
-  if (GRAD_F16 && S.rec) {  // wave-uniform
+  if (GRAD_F16 && RECORD) {  // compile-time: the atomic form below is not even compiled into the record kernels
     half2_t* baseh = reinterpret_cast<half2_t*>(reinterpret_cast<_Float16*>(S.grad_pool) + (int64_t)level * T);
     const uint32_t slot0 = (uint32_t)level * (T >> 1);
     if (issue) {
@@ -261,7 +261,7 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
 template <bool PLANES, int SCATTER>
 constexpr int bwd_threads() { return (PLANES && SCATTER) ? 256 : 512; }
 
-template <bool PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool */>
+template <bool PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records */>
 __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
@@ -272,9 +272,9 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
-  __shared__ unsigned int s_rec_cursor[SCATTER == 1 ? GFN_GRAD_MAX_RANGES : 1];
+  __shared__ unsigned int s_rec_cursor[SCATTER == 3 ? GFN_GRAD_MAX_RANGES : 1];
   if (SCATTER && threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = S.sc.s[threadIdx.x];
-  if (SCATTER == 1)
+  if (SCATTER == 3)
     for (int e = threadIdx.x; e < GFN_GRAD_MAX_RANGES; e += blockDim.x) s_rec_cursor[e] = 0;
   __syncthreads();
   const u32x4* Ihi = L;
@@ -428,7 +428,8 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       for (int a = 0; a < 8; a++) {
         const int level = 2 * h + (a & 1) + 4 * (a >> 1);
         const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
-        if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, s_rec_cursor);
+        if (SCATTER == 3) scatter_level<true, true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, s_rec_cursor);
+        else if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
         else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
       }
     } else if (valid) {
@@ -438,7 +439,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
                                       acc_get(gf, 4 * qd + 3) * inv);
     }
   }
-  if (SCATTER == 1 && S.rec) {
+  if (SCATTER == 3) {
     __syncthreads();
     for (int e = threadIdx.x; e < S.n_ranges; e += blockDim.x)
       S.rec_count[e * 256 + blockIdx.x] = s_rec_cursor[e] < S.rec_cap ? s_rec_cursor[e] : S.rec_cap;
@@ -557,7 +558,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue
   static bool attr_set = false;
-#define GFN_BWD_ALL(X) X(false, 0) X(false, 1) X(false, 2) X(true, 0) X(true, 1) X(true, 2)
+#define GFN_BWD_ALL(X) X(false, 0) X(false, 1) X(false, 2) X(false, 3) X(true, 0) X(true, 1) X(true, 2) X(true, 3)
   if (!attr_set) {
 #define GFN_SET(P, SC) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<P, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     GFN_BWD_ALL(GFN_SET)
@@ -584,7 +585,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   }
   gfn_hash_level_scales_host(S.sc.s);
   const bool planes = planes_hi != nullptr;
-  const int mode = !scatter ? 0 : (sh.grad_f16 ? 1 : 2);
+  const int mode = !scatter ? 0 : (sh.rec ? 3 : (sh.grad_f16 ? 1 : 2));
   if (!planes) { gmax_dev = nullptr; plane_cap = 0; ray_id = nullptr; cam_idx = nullptr; demb = nullptr; }
 #define GFN_LAUNCH(P, SC)                                                                                                        \
   if (planes == P && mode == SC)                                                                                                 \
