@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--prefetch-cus", type=int, default=192, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=8,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
-    ap.add_argument("--render-decoder-cus", type=int, default=240, help="CUs the fused forward may occupy while a sampler runs beside it")
-    ap.add_argument("--render-tile-width", type=int, default=64, help="render tiles are blocks of this width (0 = raster runs of 4096 pixels)")
+    ap.add_argument("--render-decoder-cus", type=int, default=252, help="CUs the fused forward may occupy while a sampler runs beside it")
+    ap.add_argument("--render-tile-rays", type=int, default=8192, help="rays per render tile")
+    ap.add_argument("--render-tile-width", type=int, default=128, help="render tiles are blocks of this width (0 = raster runs of 4096 pixels)")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     ap.add_argument("--share-block-primes", action="store_true",
@@ -135,7 +136,7 @@ def render_bench(hp, sc, args, fineness, torch):
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
     block = 0 if (args.stage == "focal" and hp.blocks) else None
-    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=N_RAYS, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
+    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
                            pipeline=args.render_pipeline, decoder_cus=args.render_decoder_cus)
     n_cams = c2w.shape[0]
     tr.render_camera(0, H, W)  # capture + warm-up
@@ -147,8 +148,8 @@ def render_bench(hp, sc, args, fineness, torch):
     dt = time.perf_counter() - t0
     mpix = args.render_frames * H * W / 1e6
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=args.render_frames, frame=f"{W}x{H}",
-                ms_per_frame=dt * 1e3 / args.render_frames, rays_per_sec=args.render_frames * H * W / dt, tile_rays=N_RAYS, hipgraph=True, tiles_per_replay=args.render_pipeline,
-                tile=(f"{args.render_tile_width}x{N_RAYS // args.render_tile_width} pixel blocks" if args.render_tile_width else "raster runs"),
+                ms_per_frame=dt * 1e3 / args.render_frames, rays_per_sec=args.render_frames * H * W / dt, tile_rays=args.render_tile_rays, hipgraph=True, tiles_per_replay=args.render_pipeline,
+                tile=(f"{args.render_tile_width}x{args.render_tile_rays // args.render_tile_width} pixel blocks" if args.render_tile_width else "raster runs"),
                 table="global + focal block 0" if block is not None else "global", fineness=fineness,
                 mean_accumulation=float(img["accumulation"].mean().item()))
 

@@ -22,8 +22,8 @@ def frame_shard(n_frames, world_size, rank):
 
 
 class TileRenderer:
-    def __init__(self, hp, c2w, intr, tile_rays=4096, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=64,
-                 pipeline=1, decoder_cus=224):
+    def __init__(self, hp, c2w, intr, tile_rays=8192, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=128,
+                 pipeline=1, decoder_cus=252):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
