@@ -236,6 +236,13 @@ def main():
         g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
         b.uniform_(-1e-3, 1e-3, generator=g)
     hp.refresh_shadows()
+    # optimiser state and the gradient-record buffers exist before the first step (allocation is set-up, not training)
+    if args.stage == "focal":
+        for i, b in enumerate(hp.blocks):
+            hp._adam_state(f"block{i}", b)
+    else:
+        hp._adam_state("table", hp.table)
+    hp._record_buffers()
 
     # ---- batches resident in HBM before the timed region (4 rotated batches per rank)
     batches_np, batches = [], []
@@ -268,8 +275,13 @@ def main():
                             prefetch=pre, update_oct=args.stage == "global" and not args.no_oct_update)
         return out
 
-    for i in range(args.warmup):
+    # two priming steps before the W warm-up steps: code objects are loaded, workspaces and the caching allocator's blocks
+    # exist (set-up; reported as config.priming_steps)
+    PRIMING = 2
+    for i in range(PRIMING):
         step(i)
+    for i in range(args.warmup):
+        step(PRIMING + i)
     # dominant kernel: timed live with events on the launch stream (torch's current stream)
     hp.timed_ops = {"*"} if args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
     torch.cuda.synchronize()
@@ -277,7 +289,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, aux = step(args.warmup + i)
+        loss, aux = step(PRIMING + args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -364,7 +376,7 @@ def main():
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
-                               scene_build_s=round(t_build, 1), loss=float(loss.item())),
+                               scene_build_s=round(t_build, 1), priming_steps=2, loss=float(loss.item())),
                    roofline=roofline)
         if args.render_frames > 0:
             out["render"] = render_bench(hp, sc, args, fineness, torch)
