@@ -385,3 +385,32 @@ def test_pipeline_with_image_stack_datamanager(dev):
     assert touched > 0 and float(dm.error_map.map.max()) <= 3.0
     np.testing.assert_allclose(dm.error_map.block_sums.cpu().numpy(),
                                __import__("gfnerf_amd").ops.errmap_block_sums(dm.error_map.map).cpu().numpy(), rtol=1e-12)
+
+
+def test_block_table_checkpoints_round_trip(dev, tmp_path):
+    """GFNeRFField.update_active_blocks / save_table / load_table (nerfacto_field.py:336-403): a block table that leaves the
+    active set is written to encodings_ckpt/base_encoding_<i>.ckpt and comes back with the same features, primes and bias
+    when it is activated again."""
+    import torch
+
+    from gfnerf_amd.gfnerf.nerfacto_field import GFNeRFField
+
+    fld = GFNeRFField(num_images=4, log2_hashmap_size=12, n_volumes=7, n_blocks=3, device=dev, base_dir=str(tmp_path), steps_perssampler_init=10)
+    fld.train()
+    fld.update_active_blocks(1)
+    assert fld.active_block_idxs == [1] and hasattr(fld, "base_encoding_1") and not hasattr(fld, "base_encoding_0")
+    enc = fld.base_encoding_1
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.uniform_(-0.01, 0.01)
+    keep = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    assert len(keep) == 4 and any(v.abs().max() > 0 for v in keep.values())
+    fld.update_active_blocks(2)  # block 1 leaves the active set: saved and released
+    assert fld.active_block_idxs == [2] and not hasattr(fld, "base_encoding_1")
+    assert (tmp_path / "encodings_ckpt" / "base_encoding_1.ckpt").exists()
+    fld.update_active_blocks(1)  # and comes back from its checkpoint
+    back = fld.base_encoding_1.state_dict()
+    assert set(back) == set(keep)
+    for k in keep:
+        assert torch.equal(back[k].cpu(), keep[k].cpu()), k
+    assert (tmp_path / "encodings_ckpt" / "base_encoding_2.ckpt").exists()
