@@ -400,7 +400,8 @@ class HotPath:
         if not (c.lds_accumulate and c.grad_f16 and c.log2_T <= 21):
             return None
         if self._records is None:
-            self._records = ops.grad_records_buffers(c.log2_T, c.record_capacity, self.dev)
+            n_streams = _lib.lib().gfn_grad_record_ranges(c.log2_T) * 256
+            self._records = ops.grad_records_buffers(c.log2_T, min(c.record_capacity, n_streams * 1024), self.dev)  # <= 1024 records per stream
         return self._records
 
     @contextlib.contextmanager
