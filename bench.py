@@ -253,10 +253,24 @@ def main():
         batches.append(tuple(torch.from_numpy(a).cuda() for a in (o, d, cam, gt)))
     target = TARGET_SAMPLES[args.stage]
     fineness, mean_samples = pick_fineness(hp, batches[0][0], batches[0][1], target, scene, torch)
-    noises = [torch.from_numpy(scene.make_noise(N_RAYS, True, fineness, seed=k + 1)).cuda() for k in range(4)]
-    # S3IM's arange + 9 randperm index vectors (losses.py:780-789), like the noise: drawn before the timed region
+    # The march noise (PersSampler_cuda.cu:380-389) and S3IM's arange + 9 permutations (losses.py:780-789) are drawn on the
+    # device EVERY step, inside the timed region like the reference does: step i draws them for step i + 1 on a third stream
+    # (they depend on nothing), beside the step's own kernels.
     from gfnerf_amd import ops as _ops
-    s3im_idx = [_ops.s3im_index(N_RAYS, cfg.s3im_repeat_time, device="cuda") for _ in range(4)]
+    draw_stream = torch.cuda.Stream()
+    drawn = {}
+
+    def draw(i):
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(draw_stream):
+            nz = _ops.sampler_noise(N_RAYS, fineness, train=True, device="cuda")
+            s3 = _ops.s3im_index(N_RAYS, cfg.s3im_repeat_time, device="cuda")
+        for t_ in (nz, s3):
+            t_.record_stream(main)
+            if hp._side is not None:
+                t_.record_stream(hp._side)
+        drawn[i] = (nz, s3)
+        main.wait_stream(draw_stream)
 
     allreduce = None
     if world > 1 and args.stage == "global":
@@ -269,9 +283,13 @@ def main():
         o, d, cam, gt = batches[i % 4]
         block = (i % n_blocks) if args.stage == "focal" else None
         nxt = batches[(i + 1) % 4]
-        pre = None if args.no_prefetch else (nxt[0], nxt[1], noises[(i + 1) % 4])  # the data loader knows the next batch
+        if i not in drawn:
+            draw(i)
+        draw(i + 1)
+        noise, s3 = drawn.pop(i)
+        pre = None if args.no_prefetch else (nxt[0], nxt[1], drawn[i + 1][0])  # the data loader knows the next batch
         # global stage: UpdateOctNodes K5/K6 every step, right after the forward like GFNeRFModel.get_outputs (nerfacto.py:598-616)
-        out = hp.train_step(o, d, cam, gt, noises[i % 4], stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3im_idx[i % 4],
+        out = hp.train_step(o, d, cam, gt, noise, stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3,
                             prefetch=pre, update_oct=args.stage == "global" and not args.no_oct_update)
         return out
 
@@ -376,7 +394,7 @@ def main():
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
-                               scene_build_s=round(t_build, 1), priming_steps=2, loss=float(loss.item())),
+                               scene_build_s=round(t_build, 1), priming_steps=2, per_step_draws="march noise + S3IM permutations drawn on the device every timed step", loss=float(loss.item())),
                    roofline=roofline)
         if args.render_frames > 0:
             out["render"] = render_bench(hp, sc, args, fineness, torch)

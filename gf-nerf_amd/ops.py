@@ -903,10 +903,24 @@ def charbonnier(pred, gt, eps=1e-6):
 
 
 def s3im_index(n_rays, repeat_time=10, generator=None, device=None):
-    """The index vector S3IM.forward builds (losses.py:780-789): arange followed by repeat_time - 1 random permutations."""
-    parts = [torch.arange(n_rays, device=device, dtype=torch.int64)]
-    parts += [torch.randperm(n_rays, device=device, generator=generator) for _ in range(repeat_time - 1)]
-    return torch.cat(parts).to(torch.int32)
+    """The index vector S3IM.forward builds (losses.py:780-789): arange followed by repeat_time - 1 random permutations.
+    The permutations come from ONE batched argsort of f64 uniforms (three launches instead of 9 x torch.randperm: this runs
+    every training step)."""
+    out = torch.empty((repeat_time, n_rays), dtype=torch.int32, device=device)
+    out[0] = torch.arange(n_rays, device=device, dtype=torch.int32)
+    if repeat_time > 1:
+        keys = torch.rand((repeat_time - 1, n_rays), dtype=torch.float64, device=device, generator=generator)
+        out[1:] = torch.argsort(keys, dim=1)
+    return out.view(-1)
+
+
+def sampler_noise(n_rays, fineness, train=True, generator=None, device=None):
+    """rays_noise of GetSamples (PersSampler_cuda.cu:380-389): (U[0,1) + 0.5) * fineness in training, fineness in eval mode,
+    1024 + R + 10 values (the march reads a sliding window of it, :204,270)."""
+    n = 1024 + n_rays + 10
+    if not train:
+        return torch.full((n,), float(fineness), dtype=torch.float32, device=device)
+    return torch.rand(n, dtype=torch.float32, device=device, generator=generator).add_(0.5).mul_(float(fineness))
 
 
 def s3im(gt, pred, index, patch_h=32, mult=1.0, loss=None, g_pred=None, want_grad=True):

