@@ -47,9 +47,10 @@ def parse():
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
-    ap.add_argument("--sync-adam", action="store_true",
-                    help="focal stage: keep Adam on the main stream (default: HotPathConfig.async_adam -- Adam of step i on a third stream "
-                         "beside the frozen global table's lookup of step i + 1; the block lookup waits for it)")
+    ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
+    ap.add_argument("--async-adam", action="store_true",
+                    help="focal stage: Adam of step i on a third stream beside the frozen global table's lookup of step i + 1 (about "
+                         "-1.5 percent per step; off by default so that the roofline kernel is timed running alone)")
     ap.add_argument("--lm-global-forward", action="store_true", help="global stage: level-major lookup + decoder + compositing instead of the fused forward kernel")
     ap.add_argument("--atomic-backward", action="store_true", help="backward issues its table adds as global atomics instead of records accumulated in LDS")
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
@@ -231,7 +232,7 @@ def main():
     n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
     cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
                                 mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
-                                fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=not args.sync_adam, level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from)
+                                fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, **({'record_capacity': args.record_capacity} if args.record_capacity else {}), level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
                          device=f"cuda:{local_rank if world > 1 else 0}")
     for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
@@ -343,7 +344,7 @@ def main():
                "bwd_scatter": n_eval * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 16 + 16 + 56)}
         kern = {}
         for name, ev in hp.timings.items():
-            kern[name] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            kern[name] = float(sum(a.elapsed_time(b) for a, b in ev)) / args.steps  # per step, however many regions a step times
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
         kern_ms = kern[dom]
         alg_bytes = alg[dom]
