@@ -172,8 +172,8 @@ class HotPath:
         return r
 
     def export_params(self):
-        self._sync_opt()
         """Host copies of every parameter / state blob (for checkpoints and for the test oracle)."""
+        self._sync_opt()
         c = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
         return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[c(b) for b in self.blocks],
                     block_prims=[c(p) for p in self.block_prims],
