@@ -89,6 +89,29 @@ def pick_fineness(hp, o, d, target, scene, torch):
     return best
 
 
+def lm_issued_gathers(samples, n_live, halves_from, torch):
+    """Gathers one lm_lookup_kernel launch issues for this batch: 8 per (sample, level), except that below level `halves_from`
+    only the first lane of a run of consecutive samples in one cell of one volume gathers when a wave holds <= 40 such runs
+    (csrc/lm_lookup.hip).  Waves are taken as aligned groups of 64 samples (the kernel's start at its workgroup's run)."""
+    pts = samples["warped_pts"][:n_live]
+    vol = samples["anchors"][:n_live, 0]
+    total = 0
+    lane0 = (torch.arange(n_live, device=pts.device) % 64) == 0
+    pad = (-n_live) % 64
+    for level in range(16):
+        if level >= halves_from:
+            total += 8 * n_live
+            continue
+        cell = torch.floor(pts * float(np.float32(2.0 ** (7.0 * level / 15.0 + 3.0)))).to(torch.int32)
+        head = torch.ones(n_live, dtype=torch.bool, device=pts.device)
+        head[1:] = (vol[1:] != vol[:-1]) | (cell[1:] != cell[:-1]).any(1)
+        head |= lane0
+        per_wave = torch.nn.functional.pad(head.to(torch.int32), (0, pad)).view(-1, 64).sum(1)
+        shared = torch.repeat_interleave(per_wave <= 40, 64)[:n_live]
+        total += 8 * int(torch.where(shared, head, torch.ones_like(head)).sum().item())
+    return total
+
+
 def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     """The oracle (a CPU port of the same path) on a bounded slice of the same batch, all host threads
     for the OpenMP-parallel pieces.  fwd + bwd, no optimiser step."""
@@ -368,10 +391,12 @@ def main():
                 traffic = None
             n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests") if default_cfg else None
             if lm:  # the level-major kernel is bound by how fast a CU's address unit walks 64 divergent lanes, not by the fabric
-                n_g = n_live * 128
+                n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch)
                 req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
                            frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
-                           source="16 levels x 8 corners per sample and launch over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
+                           nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
+                           source="gathers the kernel issues per launch (16 levels x 8 corners per sample, minus the corners that runs of samples in one "
+                                  "cell share below level lm_halves_from: counted from this batch) over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
             elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
                 req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
                            frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
