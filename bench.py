@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
+    ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
     ap.add_argument("--async-adam", action="store_true",
                     help="focal stage: Adam of step i on a third stream beside the frozen global table's lookup of step i + 1 (about "
@@ -162,6 +163,7 @@ def render_bench(hp, sc, args, fineness, torch):
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
     block = 0 if (args.stage == "focal" and hp.blocks) else None
+    hp.cfg.level_major_render = bool(args.render_lm)
     tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
                            pipeline=args.render_pipeline, decoder_cus=args.render_decoder_cus)
     n_cams = c2w.shape[0]

@@ -47,6 +47,7 @@ class HotPathConfig:
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
+    level_major_render: bool = False # inference with two tables: level-major lookups + decoder + compositing kernels instead of the fused forward
     level_major_global: bool = False # also in the global stage (one table): measured 2.69 vs 2.40 ms/step early, 2.80 vs 2.79 after 200 steps
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
@@ -309,7 +310,10 @@ class HotPath:
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
-        if self._fused_ok(block):
+        if c.level_major_render and block is not None and self._fused_ok(block) and not c.share_block_primes:
+            f = self._field_forward(s, cam_idx, block, fused=True, lm=True)
+            comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)
+        elif self._fused_ok(block):
             f, comp = self._forward_fused(s, cam_idx, block, early)
         else:
             f = self._field_forward(s, cam_idx, block)

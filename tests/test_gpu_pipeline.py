@@ -566,6 +566,25 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
         assert ((ref != 0) != (got != 0)).mean() < 2e-3
 
 
+def test_render_with_level_major_lookups_matches_fused_forward(setup):
+    """HotPathConfig.level_major_render: inference through the level-major lookups + decoder + compositing kernels gives the
+    fused forward's image (same features bit for bit, same decoder tile; the compositing scans differ in summation order)."""
+    S = setup
+    hp, t = S["hp"], S["t"]
+    args = (t(S["o"]), t(S["d"]), t(S["cam"]), t(S["noise"]))
+    ref = hp.render(*args, block=0)
+    hp.cfg.level_major_render = True
+    try:
+        got = hp.render(*args, block=0)
+        assert hp.render(*args, block=None)["rgb"].shape == ref["rgb"].shape  # one table: falls back to the fused forward
+    finally:
+        hp.cfg.level_major_render = False
+    n = int(ref["samples"]["pts_offsets"][-1].item())
+    assert np.array_equal(got["field"]["sigma"][:n].cpu().numpy(), ref["field"]["sigma"][:n].cpu().numpy())
+    for k in ("rgb", "accumulation", "depth"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].cpu().numpy(), atol=2e-6, rtol=1e-5)
+
+
 def test_async_adam_is_the_same_training_run(setup):
     """HotPathConfig.async_adam: Adam + pool zeroing on a third stream beside the next step's global-table lookup gives the
     same losses and (up to the f16 gradient noise) the same block table as the synchronous order."""
