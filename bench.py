@@ -426,10 +426,10 @@ def main():
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
                                scene_build_s=round(t_build, 1), priming_steps=2, async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step", loss=float(loss.item())),
                    roofline=roofline)
-        if args.render_frames > 0:
+        if args.render_frames > 0 and world == 1:  # the side measurements belong to the single-GPU line
             out["render"] = render_bench(hp, sc, args, fineness, torch)
             out["batch_assembly"] = batch_assembly_bench(sc, torch)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_reference_field"] = cpu_reference_field()
             out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
                                                0 if args.stage == "focal" else None, scene)
