@@ -69,6 +69,40 @@ def test_hash3danchored_module(oracle, dev):
     assert not list(enc.parameters())[0].requires_grad
 
 
+def test_hash3danchored_overfits_like_the_reference_self_test(dev):
+    """The reference's only exercise of the encoder, the `__main__` block of gfnerf/hash_3d_anchored.py:142-203: a
+    Hash3DAnchored(19, 500) + a 32 -> 128 -> 17 ReLU network driven by two torch Adam optimisers (lr 1e-2) until the network
+    answers 1 on 100 random points with random anchors, loss = sum |results - 1|.  Here: through the mirror classes (HIP
+    lookup / scatter / MLP kernels behind torch.autograd), the loss must fall by more than an order of magnitude (an L1 loss under Adam at lr 1e-2 keeps jittering around its floor)."""
+    import torch
+
+    from gfnerf_amd.gfnerf.hash_3d_anchored import Hash3DAnchored
+    from gfnerf_amd.gfnerf.mlp import MLPNetwork
+
+    torch.manual_seed(0)
+    hash3d = Hash3DAnchored(19, 500, seed=1)
+    base_network = MLPNetwork(n_input_dims=16 * 2, n_output_dims=1 + 16,
+                              network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                              "n_neurons": 128, "n_hidden_layers": 2 - 1}).to(dev)
+    assert sorted(hash3d.state_dict()) == ["bias_pool", "feat_pool", "n_volumes", "prime_pool"]
+    optimizer = torch.optim.Adam(list(hash3d.parameters()), lr=1e-2)
+    optimizer_2 = torch.optim.Adam(base_network.parameters(), lr=1e-2)
+    points = 2 * torch.rand((100, 3), device=dev, dtype=torch.float32)
+    anchors = torch.randint(0, 500, (100,), device=dev, dtype=torch.int32)  # (the reference draws < 1000 for 500 volumes: out of range)
+    losses = []
+    for _ in range(300):
+        feats = hash3d.anchored_query(points, anchors)
+        assert feats.shape == (100, 32)
+        results = base_network(feats)
+        loss = (torch.abs(results - 1)).sum()
+        optimizer.zero_grad(); optimizer_2.zero_grad()
+        loss.backward()
+        optimizer.step(); optimizer_2.step()
+        losses.append(float(loss.item()))
+    assert np.isfinite(losses).all() and losses[0] > 1000 and min(losses[-20:]) < 0.05 * losses[0], (losses[0], losses[-1])
+    assert float(list(hash3d.parameters())[0].abs().max()) > 1e-2  # the table moved, not only the network
+
+
 def test_mlpnetwork_module(dev, golden):
     import torch
 
