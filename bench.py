@@ -336,6 +336,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss, aux = step(PRIMING + args.warmup + i)
+    host_enqueue = time.perf_counter() - t0  # when the host had launched everything: (well) below `elapsed` = the GPU is the bound
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -424,7 +425,7 @@ def main():
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
                                             else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
-                               scene_build_s=round(t_build, 1), priming_steps=2, async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step", loss=float(loss.item())),
+                               scene_build_s=round(t_build, 1), priming_steps=2, host_enqueue_ms_per_step=host_enqueue / args.steps * 1e3, async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step", loss=float(loss.item())),
                    roofline=roofline)
         if args.render_frames > 0 and world == 1:  # the side measurements belong to the single-GPU line
             out["render"] = render_bench(hp, sc, args, fineness, torch)

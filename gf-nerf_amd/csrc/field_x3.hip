@@ -584,7 +584,6 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
     GFN_CHECK_ARG(cap >= 2, "%s: record buffer too small (%lld ranges x 256 streams)", fn, (long long)n_ranges);
     S.rec_cap = (unsigned int)(cap > 0x7ffffffe ? 0x7ffffffe : cap);
     S.n_ranges = (int)n_ranges;
-    GFN_CHECK_HIP(hipMemsetAsync(sh.rec_count, 0, (size_t)n_ranges * 256 * sizeof(unsigned int), gfn_stream(stream)));
   }
   gfn_hash_level_scales_host(S.sc.s);
   const bool planes = planes_hi != nullptr;

@@ -16,9 +16,9 @@ namespace {
 
 constexpr int kSlice = 1 << GFN_GRAD_RANGE_LOG2;  // slots (f16 pairs) per range: 32 Ki x 4 B = 128 KiB of LDS
 
-__global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __restrict__ rec, const unsigned int* __restrict__ rec_count,
+__global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __restrict__ rec, unsigned int* __restrict__ rec_count,
                                                               unsigned int rec_cap, int n_ranges, int64_t pool_slots,
-                                                              half2_t* __restrict__ pool) {
+                                                              half2_t* __restrict__ pool, unsigned int* __restrict__ counts_seen) {
   extern __shared__ __attribute__((aligned(16))) half2_t image[];  // [kSlice]
   __shared__ unsigned int s_cnt[256];
   __shared__ unsigned int s_any;
@@ -28,6 +28,8 @@ __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __re
     __syncthreads();
     if (tid < 256) {
       const unsigned int c = rec_count[b * 256 + tid];
+      rec_count[b * 256 + tid] = 0;  // consumed: the next backward finds its counters zero without a fill in between
+      if (counts_seen) counts_seen[b * 256 + tid] = c;
       s_cnt[tid] = c < rec_cap ? c : rec_cap;
       if (c) s_any = 1;  // benign race: every writer stores 1
     }
@@ -105,8 +107,8 @@ int gfn_grad_record_ranges(int log2_T) {
   return (int)((8 * T + T / 2 + kSlice - 1) >> GFN_GRAD_RANGE_LOG2);  // live f16 pairs [0, 17T/2): the level-overlap quirk
 }
 
-int gfn_grad_records_reduce(const void* records, const uint32_t* record_counts, int64_t record_capacity, int log2_T, void* grad_pool_f16,
-                            void* stream) {
+int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T, void* grad_pool_f16,
+                            uint32_t* counts_seen, void* stream) {
   GFN_CHECK_ARG(records && record_counts && grad_pool_f16, "gfn_grad_records_reduce: null pointer");
   GFN_CHECK_ARG(log2_T >= 4 && log2_T <= 21, "gfn_grad_records_reduce: log2_T=%d must be in [4,21]", log2_T);
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(records) & 15) == 0, "gfn_grad_records_reduce: records must be 16-byte aligned");
@@ -123,7 +125,7 @@ int gfn_grad_records_reduce(const void* records, const uint32_t* record_counts, 
     attr_set = true;
   }
   grad_accumulate_kernel<<<n_ranges, 1024, kSlice * 4, gfn_stream(stream)>>>(reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap,
-                                                                           n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16));
+                                                                           n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -111,6 +111,7 @@ class HotPath:
         self.emb = t(rng.standard_normal((n_cams, 32)).astype(np.float32))  # nn.Embedding init N(0,1)
         self.emb_grad = torch.zeros_like(self.emb)
         self.table_grad = None
+        self.record_counts_seen = None  # int32 like _records[1]: receives the stream counters each accumulate consumes (diagnostics, tests)
         self.table16 = None
         self.blocks16 = []
         self._pairs_stale = False
@@ -442,7 +443,7 @@ class HotPath:
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
                 if rec is not None:
-                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T)
+                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen)
                 dfeat = None
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -464,7 +465,7 @@ class HotPath:
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                             self.table_grad, n_dev=n_dev, records=rec)
             if rec is not None:
-                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T)
+                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision

@@ -812,14 +812,19 @@ def grad_records_buffers(log2_T, capacity, device):
     n_ranges = _lib.lib().gfn_grad_record_ranges(int(log2_T))
     if capacity < n_ranges * 256 * 2:
         raise _lib.GfnError(f"grad_records_buffers: capacity must be at least {n_ranges * 512} records")
-    return (torch.empty(int(capacity), dtype=torch.int64, device=device), torch.empty(n_ranges * 256, dtype=torch.int32, device=device))
+    # the counters start at zero and every gfn_grad_records_reduce leaves them zero again
+    return (torch.empty(int(capacity), dtype=torch.int64, device=device), torch.zeros(n_ranges * 256, dtype=torch.int32, device=device))
 
 
-def grad_records_reduce(records, grad_pool, log2_T):
-    """Accumulate the (slot, value) records of field_bwd_scatter_x3(records=...) into grad_pool, one slot range per workgroup, in LDS."""
+def grad_records_reduce(records, grad_pool, log2_T, counts_seen=None):
+    """Accumulate the (slot, value) records of field_bwd_scatter_x3(records=...) into grad_pool, one slot range per workgroup, in
+    LDS.  Consumes the stream counters (they are zero again afterwards); counts_seen (int32, same shape) receives a copy."""
     rec, cnt = records
     _chk(rec, torch.int64, "records"); _chk(cnt, torch.int32, "counts"); _chk(grad_pool, torch.float16, "grad_pool")
-    rc = _lib.lib().gfn_grad_records_reduce(_ptr(rec), _ptr(cnt), rec.numel(), int(log2_T), _ptr(grad_pool), _stream())
+    _chk(counts_seen, torch.int32, "counts_seen")
+    if counts_seen is not None and counts_seen.numel() != cnt.numel():
+        raise _lib.GfnError("grad_records_reduce: counts_seen must have the size of the counters")
+    rc = _lib.lib().gfn_grad_records_reduce(_ptr(rec), _ptr(cnt), rec.numel(), int(log2_T), _ptr(grad_pool), _ptr(counts_seen), _stream())
     _lib.check(rc, "gfn_grad_records_reduce")
 
 

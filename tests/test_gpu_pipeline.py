@@ -549,10 +549,13 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
         cfg = hotpath.HotPathConfig(log2_T=14, lds_accumulate=lds, record_capacity=capacity)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.blocks[0].uniform_(-1e-3, 1e-3); hp.refresh_shadows()
+        if lds:
+            hp.record_counts_seen = torch.zeros_like(hp._record_buffers()[1])
         loss, aux = hp.forward_backward(o, d, cam, gt, noise, stage=stage, block=0 if stage == "focal" else None, s3im_index=s3)
         pools.append(hp.table_grad.float().cpu().numpy().copy())
         if lds:
-            counts = hp._records[1].cpu().numpy()
+            assert int(hp._records[1].abs().max().item()) == 0  # the accumulate kernel consumed the counters
+            counts = hp.record_counts_seen.cpu().numpy()
             assert counts.shape == (n_ranges * 256,) and counts.sum() > 0 and counts.max() <= hp._records[0].numel() // (n_ranges * 256)
     ref, again = pools[0], pools[1]
     scale = np.abs(ref).max()

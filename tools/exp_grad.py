@@ -18,9 +18,11 @@ def run(lds, cap=1 << 22):
     cfg = hotpath.HotPathConfig(log2_T=14, lds_accumulate=lds, record_capacity=cap)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
     hp.blocks[0].uniform_(-1e-3, 1e-3); hp.refresh_shadows()
+    if lds:
+        hp.record_counts_seen = torch.zeros_like(hp._record_buffers()[1])
     hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
     torch.cuda.synchronize()
-    extra = hp._records[1].cpu().numpy() if lds else None
+    extra = hp.record_counts_seen.cpu().numpy() if lds else None
     return hp.table_grad.float().cpu().numpy().copy(), extra
 a1, _ = run(False); a2, _ = run(False); l1, cnt = run(True); l2, cnt2 = run(True, 512 * 40)
 scale = np.abs(a1).max()

@@ -20,12 +20,13 @@ for k in range(4):
     o, d, cam = scene.make_rays(sc["c2w"], 4096, seed=k)
     B.append((t(o), t(d), t(cam), t(np.random.default_rng(k).random((4096, 3)).astype(np.float32)), t(scene.make_noise(4096, True, fin, seed=k + 1))))
 s3 = ops.s3im_index(4096, 10, device="cuda")
+hp.record_counts_seen = torch.zeros_like(hp._record_buffers()[1])
 for i in range(steps):
     o, d, cam, gt, noise = B[i % 4]
     hp.train_step(o, d, cam, gt, noise, stage=stage, block=0 if stage == "focal" else None, s3im_index=s3, update_oct=stage == "global")
     if i in (0, 19, 49, steps - 1):
         torch.cuda.synchronize()
-        cnt = hp._records[1].cpu().numpy()
+        cnt = hp.record_counts_seen.cpu().numpy()
         cap = hp._records[0].numel() // cnt.size
         print(f"step {i}: records {int(cnt.sum())}, stream capacity {cap}, streams at capacity {int((cnt >= cap).sum())} of {cnt.size}, "
               f"mean {cnt.mean():.1f}, p99 {np.percentile(cnt, 99):.0f}, max {cnt.max()}", flush=True)
