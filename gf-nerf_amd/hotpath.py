@@ -204,6 +204,10 @@ class HotPath:
         self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
+        # per-ray leftovers of the step that only depend on the rays: computed here so that a prefetched sampler takes them off the
+        # main stream too (SH basis of the unit directions, nerfacto_field.py:519-521; the zero the loss kernels add to)
+        s["sh"] = ops.sh4(d)
+        s["loss0"] = torch.zeros(1, dtype=torch.float32, device=self.dev)
         return s
 
     def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None):
@@ -266,7 +270,7 @@ class HotPath:
                             s["warped_pts"], s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
         emb = self.emb if self.cfg.use_appearance_embedding else None
         if fused:
-            sh = ops.sh4(s["dirs_unit"])
+            sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
             prec = self.cfg.mlp_precision
             out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save,
                               precision=prec, image=self._x3()[0] if prec == "x3" else None, planes=planes)
@@ -275,7 +279,7 @@ class HotPath:
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
         a1 = self._timed("base_fwd", ops.linear_fwd, feat, bW0, bb0, "relu", n_dev=n_dev)
         h = self._timed("base_fwd", ops.linear_fwd, a1, bW1, bb1, "none", n_dev=n_dev)
-        sh = ops.sh4(s["dirs_unit"])
+        sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
         sigma, xh = self._timed("head_pack", ops.head_pack, h, sh, emb, cam_idx, s["ray_id"], n_dev=n_dev)
         c1 = self._timed("head_fwd", ops.linear_fwd, xh, hW0, hb0, "relu", n_dev=n_dev, in_dim=63)
         c2 = self._timed("head_fwd", ops.linear_fwd, c1, hW1, hb1, "relu", n_dev=n_dev)
@@ -291,7 +295,7 @@ class HotPath:
         self._sync_opt()
         if block is not None and self._pairs_stale:
             self.refresh_shadows()
-        sh = ops.sh4(s["dirs_unit"])
+        sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
         emb = self.emb if self.cfg.use_appearance_embedding else None
         pair = block is not None and self.cfg.share_block_primes  # blocks16[block] is then the interleaved {global, block} image
         out = self._timed("fused_fwd", ops.fused_forward, s, self.blocks16[block] if pair else self.table16, self.prim, self.n_volumes,
@@ -372,9 +376,11 @@ class HotPath:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
 
-    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None):
+    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None, want_depth=True):
         """Training forward of get_outputs.  Returns (comp, ctx): comp holds rgb [R,3], acc, depth_raw, weights,
-        alphas; ctx is what backward() needs (the reference keeps the whole autograd graph alive instead)."""
+        alphas; ctx is what backward() needs (the reference keeps the whole autograd graph alive instead).
+        want_depth=False (the native train step, whose losses do not read depth) skips the batch-global t range that
+        DepthRenderer's clip needs (renderers.py:281): comp["t_minmax"] is then None."""
         c = self.cfg
         train_mlp = stage == STAGE_GLOBAL
         self._timed("zero_grads", self.zero_grads, stage, block)
@@ -395,7 +401,7 @@ class HotPath:
         else:
             f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes, lm=lm)
             comp = self._timed("composite_fwd", ops.composite_fwd, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"],
-                               early_T=c.early_T)
+                               early_T=c.early_T, want_t_range=want_depth)
         ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)
         self._last_train_ctx = ctx
         return comp, ctx
@@ -497,7 +503,7 @@ class HotPath:
         stage only together with update_oct).  update_oct (global stage): run UpdateOctNodes on this step's samples right after
         the forward, like GFNeRFModel.get_outputs does."""
         c = self.cfg
-        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block)
+        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False)
         if stage == STAGE_GLOBAL and update_oct:
             if prefetch is not None:
                 self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx))
@@ -505,7 +511,7 @@ class HotPath:
                 self._timed("oct_update", self.update_oct_nodes, ctx)
         elif prefetch is not None and stage == STAGE_FOCAL:
             self.prefetch_sample(*prefetch)
-        loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb)  # rgb_loss (nerfacto.py:636)
+        loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb, loss=ctx["samples"].pop("loss0", None))  # rgb_loss (nerfacto.py:636)
         R = rays_o.shape[0]
         if c.s3im_loss_mult > 0 and (R * c.s3im_repeat_time) % c.s3im_patch_height == 0 and R * c.s3im_repeat_time >= 4 * c.s3im_patch_height:
             if s3im_index is None:

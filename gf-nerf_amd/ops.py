@@ -859,7 +859,7 @@ def head_unpack_bwd(h, dsigma, dxh, cam_idx, pts_offsets, demb=None, n_dev=None)
 
 
 # --------------------------------------------------------------------- compositing
-def composite_fwd(pts_offsets, sigma, dt, t, rgb, early_T=0.0, want_weights=True):
+def composite_fwd(pts_offsets, sigma, dt, t, rgb, early_T=0.0, want_weights=True, want_t_range=True):
     _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(sigma, torch.float32, "sigma"); _chk(dt, torch.float32, "dt")
     _chk(t, torch.float32, "t"); _chk(rgb, torch.float32, "rgb", 3)
     R = pts_offsets.numel() - 1
@@ -870,7 +870,7 @@ def composite_fwd(pts_offsets, sigma, dt, t, rgb, early_T=0.0, want_weights=True
     out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
     out_acc = torch.empty(R, dtype=torch.float32, device=dev)
     out_depth = torch.empty(R, dtype=torch.float32, device=dev)
-    t_minmax = torch.empty(2, dtype=torch.float32, device=dev)
+    t_minmax = torch.empty(2, dtype=torch.float32, device=dev) if want_t_range else None  # (min t, max t) over the batch: the depth clip
     rc = _lib.lib().gfn_composite_fwd(_ptr(pts_offsets), R, _ptr(sigma), _ptr(dt), _ptr(t), _ptr(rgb), float(early_T),
                                       _ptr(weights), _ptr(alphas), _ptr(out_rgb), _ptr(out_acc), _ptr(out_depth),
                                       _ptr(t_minmax), _stream())
@@ -898,9 +898,11 @@ def composite_bwd(pts_offsets, sigma, dt, rgb, g_rgb, g_acc=None, early_T=0.0):
 
 
 # ------------------------------------------------------------------ loss / optimiser
-def charbonnier(pred, gt, eps=1e-6):
-    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3)
-    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+def charbonnier(pred, gt, eps=1e-6, loss=None):
+    """loss[0] += Charbonnier(pred, gt) (losses.py:73-84); loss: a zeroed f32 [1] to add to (allocated when absent)."""
+    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3); _chk(loss, torch.float32, "loss")
+    if loss is None:
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
     g = torch.empty_like(pred)
     _lib.check(_lib.lib().gfn_charbonnier(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(loss), _ptr(g), _stream()),
                "gfn_charbonnier")
