@@ -366,12 +366,17 @@ class HotPath:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._opt_pending = False
 
+    def _grad_live(self):
+        """Elements [0, 17T) of the gradient pool: the only ones a backward can write (level-overlap quirk), so the only ones to
+        zero, reduce across ranks and hand to Adam."""
+        return self.table_grad.view(-1)[: 17 * (1 << self.cfg.log2_T)]
+
     def zero_grads(self, stage, block=None):
         if self.table_grad is None:
             self.table_grad = torch.zeros(self.table.shape, dtype=torch.float16 if self.cfg.grad_f16 else torch.float32,
                                           device=self.dev)
         if not self._opt_pending:  # else: zeroed behind the asynchronous Adam
-            ops.fill_zero(self.table_grad)
+            ops.fill_zero(self._grad_live())
         if stage == STAGE_GLOBAL:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
@@ -550,7 +555,7 @@ class HotPath:
                 self._opt_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._opt_stream):
                     run()
-                    ops.fill_zero(self.table_grad)  # the next step's zero_grads
+                    ops.fill_zero(self._grad_live())  # the next step's zero_grads
                 self._opt_pending = True
             else:
                 run()
@@ -559,7 +564,7 @@ class HotPath:
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
         self._sync_opt()
         # only elements [0, 17T) of a table can receive a gradient (level-overlap quirk): reduce 71 MB, not 134 MB
-        live = self.table_grad.view(-1)[: 17 * (1 << self.cfg.log2_T)]
+        live = self._grad_live()
         if stage == STAGE_GLOBAL:
             out = [live, self.mlp_grad]
             if self.cfg.use_appearance_embedding:
