@@ -165,7 +165,7 @@ struct ScatterArgs {
   void* grad_pool; int grad_f16; LevelScales sc;
   // record mode (f16 pool only): instead of issuing its atomics -- the L2 executes ~21 G scattered atomics/s whatever their
   // scope or footprint (tools/gather_bench.hip) -- every add becomes a (slot, packed f16x2) record appended to the stream of
-  // (32 Ki-slot range, this workgroup): rec[(range * 256 + workgroup) * rec_cap + position], positions from LDS cursors;
+  // (16 Ki-slot range, this workgroup): rec[(range * 256 + workgroup) * rec_cap + position], positions from LDS cursors;
   // csrc/grad_part.hip then accumulates every range in LDS (gfn_grad_records_reduce)
   uint2* rec; unsigned int* rec_count; unsigned int rec_cap; int n_ranges;
 };

@@ -2,29 +2,49 @@
 // accumulated in LDS instead of by scattered global atomics.
 //
 // The L2 executes ~21 G scattered atomics per second whatever their scope, type or footprint (tools/gather_bench.hip,
-// tools/README.md): the 12.8 M packed-f16 adds of a focal-stage step cost 0.6 ms that way, 30 M+ in the global stage.
+// tools/README.md): the 17 M packed-f16 adds of a focal-stage step cost 0.8 ms that way, 30 M+ in the global stage.
 // The decoder backward (csrc/field_x3.hip, record mode) therefore only WRITES its adds, as (slot, packed f16x2) records
-// appended to the stream of (32 Ki-slot range, producing workgroup) -- positions come from per-range cursors in the
-// producer's LDS, so nothing is sorted afterwards.  Here the workgroup that owns a range adds its 256 streams into a
-// 128 KiB LDS image with ds_pk_add_f16 (the f16 accumulation of the reference's half-precision pool, :151,:222) and adds
-// the image to the pool with plain coalesced stores: nobody else touches those slots.  16 streamed bytes per add instead
-// of one L2 atomic; a stream that overflows falls back to the atomic in the producer.
+// appended to the stream of (16 Ki-slot range, producing workgroup) -- positions come from per-range cursors in the
+// producer's LDS, so nothing is sorted afterwards.  Here the workgroup that owns a range adds its 256 streams into an LDS
+// image and adds the image to the pool with plain coalesced stores: nobody else touches those slots.  16 streamed bytes
+// per add instead of one L2 atomic; a stream that overflows falls back to the atomic in the producer.
+//
+// The image.  LDS executes FLOATING-POINT atomics (ds_pk_add_f16, ds_add_f32) at one lane per ~3.2 clocks per CU and INTEGER
+// ones (ds_add_u32 / ds_add_u64) at one per ~0.5 clocks, the rate of plain stores (tools/lds_atom_bench.hip).  Every f16
+// value is an integer multiple of 2^-24, so the two halves of a record go into ONE ds_add_u64 of (c1 << 32) + c0 in units
+// of 2^-24: the sum is EXACT and independent of the order of the adds, and is rounded to f16 once at the end (the
+// reference's atomicAdd(half2) rounds after every add, :151; its result depends on the order the hardware took them).  A
+// 32-bit field holds |sum| < 128 (x128-scaled, i.e. a gradient of 1 per slot and step).  Every lane therefore also sums
+// the magnitudes of what it adds: if the whole range's sum of |component| stays below 2^31 units no field can have
+// left its 32 bits at any moment and the image is valid; otherwise (or with f16_accumulate) the range is done again the
+// reference's way, with ds_pk_add_f16 into an f16 image -- decided per range, workgroup-uniform.
 #include "gfn_common.h"
 #include "hash_device.h"
 
 namespace {
 
-constexpr int kSlice = 1 << GFN_GRAD_RANGE_LOG2;  // slots (f16 pairs) per range: 32 Ki x 4 B = 128 KiB of LDS
+constexpr int kSlice = 1 << GFN_GRAD_RANGE_LOG2;  // slots (f16 pairs) per range: 16 Ki x 8 B = 128 KiB of LDS
+constexpr float kFixed = 16777216.f;               // 2^24: the f16 grid
 
+__device__ __forceinline__ uint32_t fixed_to_half2(unsigned long long S) {
+  const int lo = (int)(unsigned int)(S & 0xffffffffull);            // the low field, signed
+  const int hi = (int)(((long long)S - (long long)lo) >> 32);       // what is left once its borrow is taken back
+  const half2_t v = {(_Float16)((float)lo * (1.f / kFixed)), (_Float16)((float)hi * (1.f / kFixed))};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// mode 0: exact fixed-point accumulation wherever it provably fits; 1: always the reference's f16 accumulation
 __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __restrict__ rec, unsigned int* __restrict__ rec_count,
                                                               unsigned int rec_cap, int n_ranges, int64_t pool_slots,
-                                                              half2_t* __restrict__ pool, unsigned int* __restrict__ counts_seen) {
-  extern __shared__ __attribute__((aligned(16))) half2_t image[];  // [kSlice]
+                                                              half2_t* __restrict__ pool, unsigned int* __restrict__ counts_seen, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long img64[];  // [kSlice] fixed-point pairs, or [kSlice] half2 in its first half
+  half2_t* image = reinterpret_cast<half2_t*>(img64);
   __shared__ unsigned int s_cnt[256];
   __shared__ unsigned int s_any;
+  __shared__ unsigned long long s_mag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int b = blockIdx.x; b < n_ranges; b += gridDim.x) {
-    if (tid == 0) s_any = 0;
+    if (tid == 0) { s_any = 0; s_mag = 0ull; }
     __syncthreads();
     if (tid < 256) {
       const unsigned int c = rec_count[b * 256 + tid];
@@ -33,64 +53,93 @@ __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __re
       s_cnt[tid] = c < rec_cap ? c : rec_cap;
       if (c) s_any = 1;  // benign race: every writer stores 1
     }
-    for (int i = tid; i < kSlice / 4; i += 1024) reinterpret_cast<uint4*>(image)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     if (!s_any) continue;  // workgroup-uniform
-    // a wave takes 16 of the 256 producer streams, four at a time so that their (short, dependent) loads overlap; a
-    // stream is contiguous: 16 bytes (two records) per lane and load
-    auto add = [&](uint32_t slot, uint32_t val) {
-      __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(image + (slot & (kSlice - 1))), __builtin_bit_cast(half2_t, val));
-    };
-    for (int w0 = wave * 16; w0 < wave * 16 + 16; w0 += 4) {
-      unsigned int n[4];
-      const uint2* src[4];
-      uint4 r[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        n[q] = s_cnt[w0 + q];
-        src[q] = rec + ((size_t)b * 256 + w0 + q) * rec_cap;
-        r[q] = make_uint4(0u, 0u, 0u, 0u);
-        if (2u * lane < n[q]) r[q] = *reinterpret_cast<const uint4*>(src[q] + 2 * lane);  // rec_cap is even, the buffer 16-byte aligned
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (2u * lane < n[q]) {
-          add(r[q].x, r[q].y);
-          if (2u * lane + 1 < n[q]) add(r[q].z, r[q].w);
+    bool exact = mode == 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      for (int i = tid; i < (exact ? kSlice / 2 : kSlice / 4); i += 1024) reinterpret_cast<uint4*>(img64)[i] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+      float mag = 0.f;  // this lane's sum of max(|c0|, |c1|) in 2^-24 units (an upper bound of what any field saw; inf / NaN stay)
+      // a wave takes 16 of the 256 producer streams, four at a time so that their (short, dependent) loads overlap; a
+      // stream is contiguous: 16 bytes (two records) per lane and load
+      auto add = [&](uint32_t slot, uint32_t val) {
+        const uint32_t local = slot & (kSlice - 1);
+        const half2_t v = __builtin_bit_cast(half2_t, val);
+        if (exact) {
+          const float f0 = (float)v[0] * kFixed, f1 = (float)v[1] * kFixed;  // exact: an integer below 2^40
+          mag += fmaxf(fabsf(f0), fabsf(f1));
+          const int c0 = (int)f0, c1 = (int)f1;  // (saturates beyond 2^31: such a range is done again below)
+          atomicAdd(img64 + local, ((unsigned long long)(unsigned int)c1 << 32) + (unsigned long long)(long long)c0);
+        } else {
+          __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(image + local), v);
         }
-        for (unsigned int i = 2 * lane + 128; i < n[q]; i += 128) {  // streams longer than 128 records
-          const uint4 t = *reinterpret_cast<const uint4*>(src[q] + i);
-          add(t.x, t.y);
-          if (i + 1 < n[q]) add(t.z, t.w);
+      };
+      for (int w0 = wave * 16; w0 < wave * 16 + 16; w0 += 4) {
+        unsigned int n[4];
+        const uint2* src[4];
+        uint4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          n[q] = s_cnt[w0 + q];
+          src[q] = rec + ((size_t)b * 256 + w0 + q) * rec_cap;
+          r[q] = make_uint4(0u, 0u, 0u, 0u);
+          if (2u * lane < n[q]) r[q] = *reinterpret_cast<const uint4*>(src[q] + 2 * lane);  // rec_cap is even, the buffer 16-byte aligned
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (2u * lane < n[q]) {
+            add(r[q].x, r[q].y);
+            if (2u * lane + 1 < n[q]) add(r[q].z, r[q].w);
+          }
+          for (unsigned int i = 2 * lane + 128; i < n[q]; i += 128) {  // streams longer than 128 records
+            const uint4 t = *reinterpret_cast<const uint4*>(src[q] + i);
+            add(t.x, t.y);
+            if (i + 1 < n[q]) add(t.z, t.w);
+          }
         }
       }
+      if (exact) {  // f32 sums of <= a few thousand terms: relative error < 1e-3, hence the margin below; NaN / inf -> 2^40
+        const unsigned long long m = (mag < 1.0995e12f) ? (unsigned long long)mag : (1ull << 40);
+        if (m) atomicAdd(&s_mag, m);
+      }
+      __syncthreads();
+      if (!exact || s_mag < 2140000000ull) break;  // workgroup-uniform: no field can have left its 32 bits (2^31 = 2147483648)
+      exact = false;                              // they may have: once more, the reference's way
     }
-    __syncthreads();
-    // image += pool range, 16 bytes (4 slots) per lane, all eight loads of a thread in flight before the first add; this
+    // pool range += image, 16 bytes (4 slots) per lane, all loads of a thread in flight before the first add; this
     // workgroup owns the range: no atomics (overflow atomics were issued by the producer, an earlier kernel)
     const int64_t s0 = (int64_t)b << GFN_GRAD_RANGE_LOG2;
     const bool whole = s0 + kSlice <= pool_slots;  // workgroup-uniform; the last range may be partial
     if (whole) {
       uint4* dst = reinterpret_cast<uint4*>(pool + s0);
-      uint4 p[8];
+      constexpr int kIt = kSlice / 4 / 1024;
+      uint4 p[kIt];
 #pragma unroll
-      for (int k = 0; k < 8; k++) p[k] = dst[tid + 1024 * k];
+      for (int k = 0; k < kIt; k++) p[k] = dst[tid + 1024 * k];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint4 v = reinterpret_cast<const uint4*>(image)[tid + 1024 * k];
-        if (v.x | v.y | v.z | v.w) {
+      for (int k = 0; k < kIt; k++) {
+        const int i4 = tid + 1024 * k;
+        uint4 v;
+        if (exact) {
+          const uint4 a = reinterpret_cast<const uint4*>(img64)[2 * i4], c = reinterpret_cast<const uint4*>(img64)[2 * i4 + 1];
+          v.x = fixed_to_half2(((unsigned long long)a.y << 32) | a.x); v.y = fixed_to_half2(((unsigned long long)a.w << 32) | a.z);
+          v.z = fixed_to_half2(((unsigned long long)c.y << 32) | c.x); v.w = fixed_to_half2(((unsigned long long)c.w << 32) | c.z);
+        } else {
+          v = reinterpret_cast<const uint4*>(image)[i4];
+        }
+        if ((v.x | v.y | v.z | v.w) & 0x7fff7fffu) {
           uint4 o;
           o.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, p[k].x) + __builtin_bit_cast(half2_t, v.x));
           o.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, p[k].y) + __builtin_bit_cast(half2_t, v.y));
           o.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, p[k].z) + __builtin_bit_cast(half2_t, v.z));
           o.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, p[k].w) + __builtin_bit_cast(half2_t, v.w));
-          dst[tid + 1024 * k] = o;
+          dst[i4] = o;
         }
       }
     } else {
       for (int i = tid; i < kSlice; i += 1024) {
         const int64_t s = s0 + i;
-        const half2_t v = image[i];
+        const half2_t v = exact ? __builtin_bit_cast(half2_t, fixed_to_half2(img64[i])) : image[i];
         if (s < pool_slots && (v[0] != (_Float16)0.f || v[1] != (_Float16)0.f)) pool[s] = pool[s] + v;
       }
     }
@@ -108,7 +157,7 @@ int gfn_grad_record_ranges(int log2_T) {
 }
 
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T, void* grad_pool_f16,
-                            uint32_t* counts_seen, void* stream) {
+                            uint32_t* counts_seen, int f16_accumulate, void* stream) {
   GFN_CHECK_ARG(records && record_counts && grad_pool_f16, "gfn_grad_records_reduce: null pointer");
   GFN_CHECK_ARG(log2_T >= 4 && log2_T <= 21, "gfn_grad_records_reduce: log2_T=%d must be in [4,21]", log2_T);
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(records) & 15) == 0, "gfn_grad_records_reduce: records must be 16-byte aligned");
@@ -121,11 +170,12 @@ int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_
   if (cap > 0x7ffffffe) cap = 0x7ffffffe;
   static bool attr_set = false;
   if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSlice * 4));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSlice * 8));
     attr_set = true;
   }
-  grad_accumulate_kernel<<<n_ranges, 1024, kSlice * 4, gfn_stream(stream)>>>(reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap,
-                                                                           n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen);
+  grad_accumulate_kernel<<<n_ranges, 1024, kSlice * 8, gfn_stream(stream)>>>(reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap,
+                                                                           n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen,
+                                                                           f16_accumulate ? 1 : 0);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

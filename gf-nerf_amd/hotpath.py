@@ -47,6 +47,7 @@ class HotPathConfig:
     keep_features: bool = False      # also write the [N,32] hash features from the fused forward (tests / debugging)
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
+    lds_accumulate_exact: bool = True  # exact fixed-point LDS sums (rounded to f16 once) where they provably fit; False: the reference's f16 adds
     level_major_render: bool = False # inference with two tables: level-major lookups + decoder + compositing kernels instead of the fused forward
     level_major_global: bool = False # also in the global stage (one table): measured 2.69 vs 2.40 ms/step early, 2.80 vs 2.79 after 200 steps
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
@@ -454,7 +455,7 @@ class HotPath:
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
                 if rec is not None:
-                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen)
+                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
                 dfeat = None
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -476,7 +477,7 @@ class HotPath:
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                             self.table_grad, n_dev=n_dev, records=rec)
             if rec is not None:
-                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen)
+                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision

@@ -306,17 +306,21 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
  * packed f16x2 value) in the stream of (range, workgroup): records[(range * 256 + workgroup) * cap + i] with
  * cap = record_capacity / (n_ranges * 256) 8-byte records (16-byte aligned buffer), counts in record_counts u32
  * [n_ranges * 256] (gfn_grad_record_ranges(log2_T) ranges); a full stream falls back to the atomic.
- * gfn_grad_records_reduce then lets the workgroup that owns a range add its 256 streams into a 128 KiB LDS image
- * (ds_pk_add_f16: the reference's f16 accumulation) and add the image to grad_pool_f16 with plain stores
- * (csrc/grad_part.hip) -- the L2 executes only ~21 G scattered atomics/s.  log2_T <= 21.
+ * gfn_grad_records_reduce then lets the workgroup that owns a range add its 256 streams into a 128 KiB LDS image and
+ * add the image to grad_pool_f16 with plain stores (csrc/grad_part.hip) -- the L2 executes only ~21 G scattered
+ * atomics/s.  The image holds EXACT fixed-point sums (one ds_add_u64 of both halves in units of 2^-24, the f16 grid;
+ * rounded to f16 once) for every range whose sum of |component| stays below 128, i.e. whose 32-bit fields cannot
+ * have overflowed -- LDS integer atomics run 6x faster than floating-point ones (tools/lds_atom_bench.hip) -- and
+ * the reference's own f16 accumulation (ds_pk_add_f16, Hash3DAnchored_cuda.cu:151) for the others, or for all of
+ * them with f16_accumulate != 0.  log2_T <= 21.
  * record_counts must be all zero before the FIRST backward in record form; gfn_grad_records_reduce CONSUMES
  * them (leaves them zero for the next backward; counts_seen, when not NULL, receives a copy of what it
  * consumed), so a training loop never fills them. */
-#define GFN_GRAD_RANGE_LOG2 15
-#define GFN_GRAD_MAX_RANGES 544
+#define GFN_GRAD_RANGE_LOG2 14
+#define GFN_GRAD_MAX_RANGES 1088
 int gfn_grad_record_ranges(int log2_T);
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T,
-                            void* grad_pool_f16, uint32_t* counts_seen, void* stream);
+                            void* grad_pool_f16, uint32_t* counts_seen, int f16_accumulate, void* stream);
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);

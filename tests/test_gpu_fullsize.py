@@ -195,27 +195,29 @@ def full_engine():
 
 
 def test_full_size_focal_step_record_streams_against_atomics(full_engine):
-    """One focal-stage forward + backward at 4096 rays / T = 2^21 (all 544 slot ranges of the record streams in use).  The
+    """One focal-stage forward + backward at 4096 rays / T = 2^21 (all 1088 slot ranges of the record streams in use).  The
     f32 gradient pool (exact sum of the f16-quantised contributions) is the yardstick: the reference's f16 pool (x128) as
-    accumulated by scattered atomics and as accumulated in LDS from the record streams both equal it up to the f16
-    additions -- the record form adds every contribution on its own like the reference's atomicAdd(half2) does
-    (Hash3DAnchored_cuda.cu:151), the atomic form merges runs in f32 first and is closer -- and every record was counted."""
+    accumulated by scattered atomics and as accumulated in LDS from the record streams equals it up to f16 rounding: the
+    record form sums exactly in fixed point and rounds once; with lds_accumulate_exact=False it adds every contribution on
+    its own in f16 like the reference's atomicAdd(half2) does (Hash3DAnchored_cuda.cu:151) and is the least accurate of the
+    three; the atomic form merges runs in f32 first.  Every record was counted."""
     make, B, _ = full_engine
     pools, losses = {}, {}
-    for name, kw in (("exact", dict(grad_f16=False)), ("atomic", dict(lds_accumulate=False)), ("records", dict(lds_accumulate=True))):
+    for name, kw in (("exact", dict(grad_f16=False)), ("atomic", dict(lds_accumulate=False)), ("records", dict(lds_accumulate=True)),
+                     ("records_f16", dict(lds_accumulate=True, lds_accumulate_exact=False))):
         hp = make(**kw)
-        if name == "records":
+        if name.startswith("records"):
             import torch
             hp.record_counts_seen = torch.zeros_like(hp._record_buffers()[1])
         loss, aux = hp.forward_backward(B["o"], B["d"], B["cam"], B["gt"], B["noise"], stage="focal", block=0, s3im_index=B["s3"])
         pools[name] = hp.table_grad.double().cpu().numpy() * (128.0 if name == "exact" else 1.0)
         losses[name] = float(loss.item())
-        if name == "records":
+        if name.startswith("records"):
             from gfnerf_amd import _lib
-            counts = hp.record_counts_seen.cpu().numpy().astype(np.int64)
             n_ranges = _lib.lib().gfn_grad_record_ranges(LOG2_T)
+            counts = hp.record_counts_seen.cpu().numpy().astype(np.int64)[: n_ranges * 256]
             cap = hp._records[0].numel() // (n_ranges * 256)
-            assert n_ranges == 544 and counts.shape == (n_ranges * 256,) and counts.max() <= cap and counts.sum() > 5_000_000
+            assert n_ranges == 1088 and counts.shape == (n_ranges * 256,) and counts.max() <= cap and counts.sum() > 5_000_000
             assert (counts.reshape(n_ranges, 256).sum(1) > 0).all()  # every range of every level received records
         del hp
     assert np.isfinite(list(losses.values())).all()
@@ -223,7 +225,7 @@ def test_full_size_focal_step_record_streams_against_atomics(full_engine):
     ex = pools["exact"]
     scale, mass = np.abs(ex).max(), np.abs(ex).sum()
     assert scale > 0 and (ex != 0).sum() > 5_000_000
-    for name, l1_tol, max_tol in (("atomic", 3e-4, 3e-2), ("records", 3e-3, 0.2)):
+    for name, l1_tol, max_tol in (("atomic", 3e-4, 3e-2), ("records", 3e-4, 3e-2), ("records_f16", 3e-3, 0.2)):
         err = np.abs(pools[name] - ex)
         assert err.sum() <= l1_tol * mass, (name, err.sum() / mass)
         assert err.max() <= max_tol * scale, (name, err.max() / scale)

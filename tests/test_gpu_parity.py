@@ -698,3 +698,59 @@ def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from):
     ref = ops.hash_fwd_f16(tabs[0], prims[0], None, pts, anc, V, log2_T, table2_f16=tabs[1])
     got = ops.hash_fwd_lm(tabs[0], prims[0], None, pts, anc, V, log2_T, table2_f16=tabs[1], halves_from=halves_from)
     assert torch.equal(ref, got)
+
+
+def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
+    """gfn_grad_records_reduce on hand-made record streams (the layout include/gfnerf_amd.h documents): small values take the
+    exact fixed-point path -- the pool is f16(exact sum), whatever the order --; a range that could overflow the 32-bit
+    fields (sum of |component| >= 128) is done again on the f16 path instead of wrapping; f16_accumulate forces the
+    reference's f16 adds; the counters are consumed."""
+    import torch
+
+    from gfnerf_amd import _lib
+
+    log2_T = 12
+    T = 1 << log2_T
+    n_ranges = _lib.lib().gfn_grad_record_ranges(log2_T)
+    assert n_ranges == 3  # 8.5 T = 34816 f16 pairs in ranges of 16 Ki
+    pool_slots = 8 * T + T // 2
+    rng = np.random.default_rng(5)
+    cap = 64
+    rec, cnt = ops.grad_records_buffers(log2_T, n_ranges * 256 * cap, dev)
+    rec_np = np.zeros((n_ranges, 256, cap, 2), np.uint32)
+    cnt_np = np.zeros((n_ranges, 256), np.int32)
+    want = np.zeros((pool_slots, 2), np.float64)
+
+    def fill(r, wg, slots, vals):
+        n = len(slots)
+        rec_np[r, wg, :n, 0] = slots
+        rec_np[r, wg, :n, 1] = vals.astype(np.float16).view(np.uint16).astype(np.uint32) @ np.array([1, 65536], np.uint32)
+        cnt_np[r, wg] = n
+        np.add.at(want, slots, vals.astype(np.float16).astype(np.float64))
+
+    # range 0: thousands of small contributions, many per slot (f16 adds would swamp them); range 1: big values -> f16 path;
+    # range 2 (partial: slots up to 34816): a few records in its last slots
+    for wg in range(256):
+        fill(0, wg, rng.integers(0, 64, cap), (rng.standard_normal((cap, 2)) * 1e-3 + 2e-3))
+        fill(1, wg, 16384 + rng.integers(0, 8, cap), np.full((cap, 2), 0.5) * np.array([1.0, -1.0]))
+    fill(2, 7, np.array([pool_slots - 1, pool_slots - 2, pool_slots - 1]), np.array([[1e-4, 2e-4], [3e-5, 0.0], [-5e-5, 6.1e-5]]))
+    upload = lambda: (rec.copy_(torch.from_numpy(rec_np.reshape(-1, 2).view(np.int64).reshape(-1).copy()).to(dev)),  # noqa: E731
+                      cnt.copy_(torch.from_numpy(cnt_np.reshape(-1)).to(dev)))
+    got = {}
+    for mode in ("auto", "f16"):
+        upload()
+        pool = torch.zeros((16 * T, 2), dtype=torch.float16, device=dev)
+        seen = torch.zeros_like(cnt)
+        ops.grad_records_reduce((rec, cnt), pool, log2_T, counts_seen=seen, f16_accumulate=mode == "f16")
+        assert int(cnt.abs().max().item()) == 0 and np.array_equal(seen.cpu().numpy(), cnt_np.reshape(-1))
+        got[mode] = pool.float().cpu().numpy()[:pool_slots].astype(np.float64)
+        assert float(pool[pool_slots:].abs().max()) == 0.0
+    exact16 = want.astype(np.float16).astype(np.float64)
+    # exact path (ranges 0 and 2): bit-identical to rounding the exact sum once
+    assert np.array_equal(got["auto"][:16384], exact16[:16384]) and np.array_equal(got["auto"][32768:], exact16[32768:])
+    # range 1 holds 256 * 64 * 0.5 / 8 slots = +-1024 per slot: beyond a 32-bit field of 2^-24 units -> the f16 image
+    big = got["auto"][16384:16392]
+    assert (big[:, 0] > 500).all() and (big[:, 1] < -500).all() and np.abs(big - want[16384:16392]).max() <= 0.6 * 1024
+    # the reference's accumulation everywhere: small sums lose what the running f16 value swallows, but stay close
+    assert np.abs(got["f16"][:64] - want[:64]).max() <= 2e-2 * np.abs(want[:64]).max()
+    assert np.abs(got["f16"][:64] - exact16[:64]).max() > 0  # (and is indeed not the exact sum)

@@ -544,9 +544,12 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
     o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
     s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
     pools = []
-    n_ranges = 5  # T = 2^14: 8.5 T f16 pairs / 32 Ki
-    for lds, capacity in ((False, 1 << 22), (False, 1 << 22), (True, 1 << 22), (True, n_ranges * 256 * 8)):
-        cfg = hotpath.HotPathConfig(log2_T=14, lds_accumulate=lds, record_capacity=capacity)
+    from gfnerf_amd import _lib
+    n_ranges = _lib.lib().gfn_grad_record_ranges(14)  # T = 2^14: 8.5 T f16 pairs in ranges of 16 Ki
+    assert n_ranges == 9
+    for lds, capacity, exact in ((False, 1 << 22, True), (False, 1 << 22, True), (True, 1 << 22, True), (True, n_ranges * 256 * 8, True),
+                                 (True, 1 << 22, False)):
+        cfg = hotpath.HotPathConfig(log2_T=14, lds_accumulate=lds, record_capacity=capacity, lds_accumulate_exact=exact)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.blocks[0].uniform_(-1e-3, 1e-3); hp.refresh_shadows()
         if lds:
