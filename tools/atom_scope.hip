@@ -13,7 +13,10 @@ __global__ __launch_bounds__(256) void scatter(float* __restrict__ table, uint32
       if (SCOPE == 0) __hip_atomic_fetch_add(table + idx, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if (SCOPE == 1) __hip_atomic_fetch_add(table + idx, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else if (SCOPE == 2) __hip_atomic_fetch_add(table + idx, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      else __hip_atomic_fetch_add(table + idx, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      else if (SCOPE == 3) __hip_atomic_fetch_add(table + idx, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      else if (SCOPE == 4) __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(table) + idx, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // integer
+      else if (SCOPE == 5) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(table) + (idx >> 1), 0x300000005ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else table[idx] = 1.0f;  // plain scattered 4-byte store
     }
   }
 }
@@ -30,6 +33,7 @@ int main() {
   for (uint32_t mb : {4u, 64u}) {
     const uint32_t mask = mb * 262144u - 1u;
     run<0>("agent", table, mask); run<1>("workgroup", table, mask); run<3>("wavefront", table, mask); run<2>("system", table, mask);
+    run<4>("u32 add", table, mask); run<5>("u64 add", table, mask); run<6>("store", table, mask);
   }
   // sanity: did every add land?  (sum of the table after one known launch)
   return 0;
