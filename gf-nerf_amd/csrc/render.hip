@@ -141,16 +141,27 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
   float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
   float tmin = INFINITY, tmax = 0.f;
   bool dead = false;  // wave-uniform: transmittance already below early_T
+  // the chunk's six inputs are requested together and one chunk ahead: the loop is a chain of dependent round trips otherwise
+  struct In { float t, dt, sg, r, g, b; };
+  auto fetch = [&](int base) {
+    In x = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int i = base + lane;
+    if (i < e) { x.t = t[i]; x.dt = dt[i]; x.sg = sigma[i]; x.r = rgb[3 * i]; x.g = rgb[3 * i + 1]; x.b = rgb[3 * i + 2]; }
+    return x;
+  };
+  In nxt = fetch(s);
   for (int base = s; base < e; base += 64) {
     const int i = base + lane;
     const bool v = i < e;
-    const float ti = v ? t[i] : 0.f;
+    const In x = nxt;
+    if (base + 64 < e) nxt = fetch(base + 64);
+    const float ti = x.t;
     if (v) { tmin = fminf(tmin, ti); tmax = fmaxf(tmax, ti); }
     if (dead) {
-      if (v) { if (weights) weights[i] = 0.f; if (alphas) alphas[i] = 1.f - expf(-(dt[i] * sigma[i])); }
+      if (v) { if (weights) weights[i] = 0.f; if (alphas) alphas[i] = 1.f - expf(-(x.dt * x.sg)); }
       continue;
     }
-    const float ds = v ? dt[i] * sigma[i] : 0.f;
+    const float ds = v ? x.dt * x.sg : 0.f;
     const float incl = wave_incl_scan(ds, lane);
     float excl = __shfl_up(incl, 1, 64);
     if (lane == 0) excl = 0.f;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     if (v) {
       if (weights) weights[i] = w;
       if (alphas) alphas[i] = alpha;
-      cr += w * rgb[3 * i]; cg += w * rgb[3 * i + 1]; cb += w * rgb[3 * i + 2];
+      cr += w * x.r; cg += w * x.g; cb += w * x.b;
       ca += w;
       cd += w * ti;
     }
