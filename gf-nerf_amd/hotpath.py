@@ -49,7 +49,10 @@ class HotPathConfig:
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
     lds_accumulate_exact: bool = True  # exact fixed-point LDS sums (rounded to f16 once) where they provably fit; False: the reference's f16 adds
     level_major_render: bool = False # inference with two tables: level-major lookups + decoder + compositing kernels instead of the fused forward
-    level_major_global: bool = False # also in the global stage (one table): measured 2.69 vs 2.40 ms/step early, 2.80 vs 2.79 after 200 steps
+    level_major_global: bool = False # also in the global stage (one table), from the first step on
+    level_major_global_after: int = 50  # ... or from this optimiser step on (-1: never): while the scene is empty the fused forward's
+                                     # early termination wins (2.40 vs 2.69 ms/step); once nearly every sample is alive (a few dozen
+                                     # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
@@ -398,8 +401,9 @@ class HotPath:
         blk = block if stage == STAGE_FOCAL else None
         # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
         # (with one table the fused kernel's early termination makes it a tie at first and a loss once the scene has density:
-        # cfg.level_major_global)
-        lm = (c.level_major and (blk is not None or c.level_major_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
+        # cfg.level_major_global / level_major_global_after)
+        lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
+        lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
               and not c.keep_features and not (blk is not None and c.share_block_primes))
         self.last_forward = "lm" if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
         if fused and self._fused_ok(blk) and not lm:

@@ -572,6 +572,39 @@ def test_lds_accumulated_gradient_matches_atomics(setup, stage):
         assert ((ref != 0) != (got != 0)).mean() < 2e-3
 
 
+def test_global_stage_level_major_forward_matches_fused_forward(setup):
+    """The global stage switches from the fused forward to the level-major lookup + decoder + compositing kernels after
+    level_major_global_after optimiser steps: same features bit for bit, so the loss and every gradient of the step agree
+    (early_T = 0 here: the fused kernel's early termination is the only other difference)."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    sc, t = S["sc"], S["t"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
+    out = {}
+    for name, kw in (("fused", dict(level_major_global_after=-1)), ("lm", dict(level_major_global_after=0))):
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14, early_T=0.0, **kw), seed=1)
+        hp.table.mul_(100.0); hp.refresh_shadows()
+        loss, _ = hp.forward_backward(o, d, cam, gt, noise, stage="global", s3im_index=s3)
+        assert hp.last_forward == name
+        out[name] = (float(loss.item()), hp.table_grad.float().cpu().numpy(), hp.mlp_grad.cpu().numpy(), hp.emb_grad.cpu().numpy())
+    (l0, tg0, mg0, eg0), (l1, tg1, mg1, eg1) = out["fused"], out["lm"]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for a, b in ((tg0, tg1), (mg0, mg1), (eg0, eg1)):
+        scale = np.abs(a).max()
+        assert scale > 0 and np.abs(a - b).max() <= 2e-3 * scale
+    # and the default: fused for the first steps, level-major from step 50 on
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14), seed=1)
+    hp.forward_backward(o, d, cam, gt, noise, stage="global", s3im_index=s3)
+    assert hp.last_forward == "fused"
+    hp.step = 50
+    hp.forward_backward(o, d, cam, gt, noise, stage="global", s3im_index=s3)
+    assert hp.last_forward == "lm"
+
+
 def test_exact_lds_accumulation_makes_the_table_gradient_reproducible(setup):
     """With the fixed-point image the table gradient no longer depends on the order in which the hardware took the adds: two
     focal backward passes of the same batch (Charbonnier only -- S3IM scatters its ray gradients with f32 atomics) give the
