@@ -7,18 +7,27 @@
 One "step" = one full training pass of the hot path over one batch of 4096 synthetic rays:
 PersSampler trace+march -> Hash3DAnchored (global + active focal table) -> base MLP -> density /
 SH / appearance head input -> head MLP -> compositing -> Charbonnier + S3IM loss -> full backward ->
-Adam.  Workload (BASELINE.json configs[2]): "GF-NeRF global+focal, 4 sub-encoder blocks on 1 GPU,
-Rubble-scale synthetic cameras, 4096 rays x 192 samples".  With N > 1 (configs[3]) every rank
-owns one focal block and its own rays (weak scaling); the reference freezes the global table
-and the decoder in this stage, so there is no data-path collective; `--stage
-global` exercises the ray-data-parallel global stage with an RCCL all-reduce of the gradients.
+Adam.  Workload at N = 1 (BASELINE.json configs[2]): "GF-NeRF global+focal, 4 sub-encoder blocks on 1
+GPU, Rubble-scale synthetic cameras (1,600), 4096 rays x 192 samples".  With N > 1 (configs[3]) the
+cameras are clustered into N equal blocks, every rank owns one focal block and draws its rays only from
+its block's cameras (weak scaling); the reference freezes the global table and the decoder in this
+stage, so there is no data-path collective.  The line also carries `global_stage`
+(configs[1], 4096 x 128, all parameters train; at N > 1 ray data parallel: octree statistics MAX-reduced,
+gradients averaged by a direct all-reduce over RCCL, both inside HotPath.train_step) and `render`
+(configs[4]; at N > 1 every frame goes to the rank that owns its block).
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (child
+processes, before anything touches a GPU); under torchrun it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,6 +38,8 @@ sys.path.insert(0, ROOT)
 N_RAYS = 4096
 TARGET_SAMPLES = {"focal": 192, "global": 128}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PRIMING = 2            # set-up steps before the W warm-up steps (code objects, workspaces, allocator blocks)
+CTL_DEV = "cuda"       # where the few control scalars of the job (timings, fineness) are exchanged: the device under RCCL, the host under gloo
 
 
 def parse():
@@ -37,7 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stage", choices=["focal", "global"], default="focal")
-    ap.add_argument("--n-side", type=int, default=20, help="cameras per side of the synthetic capture grid")
+    ap.add_argument("--n-side", type=int, default=40, help="cameras per side of the synthetic capture grid (SURVEY 8(d): 40 x 40 = 1,600)")
     ap.add_argument("--log2-T", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
@@ -45,7 +56,13 @@ def parse():
     ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
     ap.add_argument("--no-oct-update", action="store_true", help="global stage: skip the per-step UpdateOctNodes (K5/K6)")
     ap.add_argument("--render-frames", type=int, default=2,
-                    help="also time N full 1920x1080 frames through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
+                    help="also time N full 1920x1080 frames (per rank) through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
+    ap.add_argument("--global-steps", type=int, default=200,
+                    help="timed steps of the `global_stage` sub-record (configs[1], 4096 x 128); 0 = skip.  Its warm-up is --global-warmup")
+    ap.add_argument("--global-warmup", type=int, default=60, help="past the level-major switch at optimiser step 50")
+    ap.add_argument("--sub-timeout", type=float, default=240.0, help="seconds a sub-record may take before the line is printed without it")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
     ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
@@ -71,6 +88,78 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start one child process per rank (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in its environment, like torch.distributed.run does) and wait for them.  This parent never touches a GPU
+    (device_count() does not initialise HIP), so nothing that holds a GPU is ever replaced or forked."""
+    import torch
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_gpu:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible (use --share-gpu to rehearse ranks on shared cards)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus))
+        # rank 0 owns stdout (the JSON line); the others only report on stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:  # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+class Deadline:
+    """Safety net around a sub-record that talks to other ranks: if it has not finished after `seconds`, `on_expire` runs
+    on a helper thread (rank 0 prints the line without the sub-record) and the process leaves with os._exit."""
+
+    def __init__(self, seconds, on_expire):
+        self.seconds, self.on_expire, self._done = seconds, on_expire, threading.Event()
+
+    def __enter__(self):
+        def watch():
+            if not self._done.wait(self.seconds):
+                try:
+                    self.on_expire()
+                finally:
+                    sys.stdout.flush()
+                    os._exit(0)
+
+        threading.Thread(target=watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def pick_fineness(hp, o, d, target, scene, torch):
     """Bisect the ray-march fineness so the mean valid samples per ray hits the config's budget."""
     lo, hi = 0.5, 64.0
@@ -114,6 +203,10 @@ def lm_issued_gathers(samples, n_live, halves_from, torch):
     return total
 
 
+def _cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+
+
 def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     """The oracle (a CPU port of the same path) on a bounded slice of the same batch, all host threads
     for the OpenMP-parallel pieces.  fwd + bwd, no optimiser step."""
@@ -126,10 +219,57 @@ def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     loss, grads, aux = opipe.loss_and_grads(P, o, d, cam, gt, noise, log2_T, block=block)
     dt = time.perf_counter() - t0
     n_samples = int(aux["samples"]["pts_offsets"][-1])
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()  # what OpenMP may run on
-    return dict(value=n_rays / dt, unit="rays/s", cores=cores, kind="port",
+    return dict(value=n_rays / dt, unit="rays/s", cores=_cores(), kind="port",
                 sample=f"{n_rays} rays ({n_samples} samples) of the same batch, oracle fwd+bwd (no Adam), {dt:.1f} s; "
                        "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
+
+
+def cpu_baseline_global(P, batch, log2_T, fineness, scene, n_packed=1024, n_dense=48):
+    """BASELINE.md section 3, row C2 (configs[1], global stage 4096 x 128) on the host cores, bounded samples of the same batch:
+    `packed` = the oracle forward on the valid samples only (per-stage split); `dense1024` = the same forward run the way the
+    reference executes it -- every ray padded to MAX_SAMPLE_PER_RAY = 1024 points (anchors 0, points 0, delta 0:
+    PersSampler_cuda.cu:437-444) that all go through hash + both MLPs (nerfacto_field.py:443)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    import pipeline as opipe
+
+    out = {}
+    o, d, cam, _ = (a[:n_packed] for a in batch)
+    noise = scene.make_noise(n_packed, True, fineness, seed=1)
+    t = [time.perf_counter()]
+    m = opipe.sample(P, o, d, noise); t.append(time.perf_counter())
+    f = opipe.field_forward(P, m, cam, log2_T); t.append(time.perf_counter())
+    O.composite_fwd(m["pts_offsets"], f["sigma"], m["dists"], m["ts"], f["rgb"]); t.append(time.perf_counter())
+    n = int(m["pts_offsets"][-1])
+    tot = t[-1] - t[0]
+    out["packed"] = dict(value=n_packed / tot, unit="rays/s (forward)", samples_per_sec=n / tot, cores=_cores(), kind="port",
+                         sample=f"{n_packed} rays ({n} samples) of the global-stage batch, oracle forward, {tot:.1f} s",
+                         stage_ms=dict(sampler=(t[1] - t[0]) * 1e3, field=(t[2] - t[1]) * 1e3, composite=(t[3] - t[2]) * 1e3))
+    # reference-emulating dense mode: [R,1024] points per ray, padding = zeros
+    o, d, cam, _ = (a[:n_dense] for a in batch)
+    noise = scene.make_noise(n_dense, True, fineness, seed=1)
+    t0 = time.perf_counter()
+    m = opipe.sample(P, o, d, noise)
+    off = m["pts_offsets"]
+    M = 1024
+    cnt = np.minimum(np.diff(off), M)
+    md = dict(m)
+    x = np.full((n_dense * M, 3), (np.float32(0.0) + np.float32(1.5)) * (np.float32(1.0) / np.float32(3.0)), np.float32)
+    anchors = np.zeros((n_dense * M, 3), m["anchors"].dtype)
+    dists = np.zeros(n_dense * M, np.float32)
+    ts = np.zeros(n_dense * M, np.float32)
+    for r in range(n_dense):
+        a, c = off[r], cnt[r]
+        x[r * M:r * M + c] = m["x"][a:a + c]; anchors[r * M:r * M + c] = m["anchors"][a:a + c]
+        dists[r * M:r * M + c] = m["dists"][a:a + c]; ts[r * M:r * M + c] = m["ts"][a:a + c]
+    md.update(x=x, anchors=anchors, dists=dists, ts=ts, ray_id=np.repeat(np.arange(n_dense), M).astype(np.int64),
+              pts_offsets=(np.arange(n_dense + 1) * M).astype(off.dtype))
+    f = opipe.field_forward(P, md, cam, log2_T)
+    O.composite_fwd(md["pts_offsets"], f["sigma"], md["dists"], md["ts"], f["rgb"])
+    dt = time.perf_counter() - t0
+    out["dense1024"] = dict(value=n_dense / dt, unit="rays/s (forward)", samples_per_sec=n_dense * M / dt, cores=_cores(), kind="port",
+                            sample=f"{n_dense} rays x 1024 padded points ({int(cnt.sum())} valid), oracle forward as the reference executes it, {dt:.1f} s")
+    return out
 
 
 def cpu_reference_field():
@@ -152,9 +292,11 @@ def cpu_reference_field():
                 infer_rays_per_sec=1024 / (r["fwd_ms"] * 1e-3), threads=r["threads"], kind="port of the reference's torch path, pinned by golden vectors")
 
 
-def render_bench(hp, sc, args, fineness, torch):
+def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, owners=None, dist=None):
     """BASELINE configs[4]: full-res camera-path pass, 1920x1080, hipGraph-captured per-tile inference (eval-mode ray
-    march: noise = ones * fineness; same fineness as the training batches).  Untimed: graph capture + one warm-up frame."""
+    march: noise = ones * fineness; same fineness as the training batches).  Untimed: graph capture + one warm-up frame.
+    cams: the path's cameras (global ids); with world > 1 `owners[f]` is the rank that renders frame f (the owner of the
+    frame's block), every rank renders its own frames, rank 0 gathers the finished images."""
     from gfnerf_amd import render as rmod
 
     H, W = 1080, 1920
@@ -163,24 +305,37 @@ def render_bench(hp, sc, args, fineness, torch):
     zoom = W / 1152.0  # the synthetic capture's 1152-wide intrinsics scaled to the output width
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
-    block = 0 if (args.stage == "focal" and hp.blocks) else None
     hp.cfg.level_major_render = bool(args.render_lm)
     tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
                            pipeline=args.render_pipeline, decoder_cus=args.render_decoder_cus)
-    n_cams = c2w.shape[0]
-    tr.render_camera(0, H, W)  # capture + warm-up
+    mine = [f for f in range(len(cams)) if owners is None or owners[f] == rank]
+    tr.render_camera(int(cams[mine[0]]) if mine else 0, H, W)  # capture + warm-up
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    for f in range(args.render_frames):
-        img = tr.render_camera((37 * (f + 1)) % n_cams, H, W)
+    local = {}
+    for f in mine:
+        local[f] = tr.render_camera(int(cams[f]), H, W)
     torch.cuda.synchronize()
+    if world > 1:
+        frames = rmod.gather_frames(local, len(cams), H, W, dst=0, owners=owners)  # the path's one collective
+        dist.barrier()
     dt = time.perf_counter() - t0
-    mpix = args.render_frames * H * W / 1e6
-    return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=args.render_frames, frame=f"{W}x{H}",
-                ms_per_frame=dt * 1e3 / args.render_frames, rays_per_sec=args.render_frames * H * W / dt, tile_rays=args.render_tile_rays, hipgraph=True, tiles_per_replay=args.render_pipeline,
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=CTL_DEV)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    n_frames = len(cams)
+    mpix = n_frames * H * W / 1e6
+    acc = float(local[mine[-1]]["accumulation"].mean().item()) if mine else None
+    return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}",
+                ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=args.render_tile_rays, hipgraph=True,
+                tiles_per_replay=args.render_pipeline,
                 tile=(f"{args.render_tile_width}x{args.render_tile_rays // args.render_tile_width} pixel blocks" if args.render_tile_width else "raster runs"),
-                table="global + focal block 0" if block is not None else "global", fineness=fineness,
-                mean_accumulation=float(img["accumulation"].mean().item()))
+                table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
+                routing=("single GPU" if world == 1 else f"{n_frames} frames routed to the rank owning each frame's block "
+                         f"({len(mine)} on rank 0), images gathered on rank 0 inside the timed region"))
 
 
 def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
@@ -217,32 +372,200 @@ def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
                 includes="index draw, pixel gather, ray generation, error-map write-back + CDF upkeep", duplicates_left=int(sampler.last_status[1].item()))
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------ one timed training run
+class StageRun:
+    """K timed training steps of one stage on this rank (the same code for the headline and the `global_stage` sub-record)."""
+
+    def __init__(self, args, stage, sc, world, rank, sync, torch, cams=None, n_blocks=0, block_seed=0):
+        from gfnerf_amd import hotpath, ops, scene
+
+        self.args, self.stage, self.world, self.rank, self.torch, self.scene = args, stage, world, rank, torch, scene
+        self.ops = ops
+        ga = args.lm_global_after
+        self.cfg = cfg = hotpath.HotPathConfig(
+            log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
+            prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
+            fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
+            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from,
+            **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
+            **({"level_major_global_after": ga} if ga is not None else {}))
+        self.n_blocks = n_blocks
+        # every rank builds the SAME replica (seed 0): the data-parallel global stage keeps them bit-identical from there on
+        self.hp = hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=n_blocks, sync=sync)
+        for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables (a rank's block is its own)
+            g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * block_seed)
+            b.uniform_(-1e-3, 1e-3, generator=g)
+        hp.refresh_shadows()
+        # optimiser state and the gradient-record buffers exist before the first step (allocation is set-up, not training)
+        if stage == "focal":
+            for i, b in enumerate(hp.blocks):
+                hp._adam_state(f"block{i}", b)
+        else:
+            hp._adam_state("table", hp.table)
+        hp._record_buffers()
+        # batches resident in HBM before the timed region (4 rotated batches per rank); cams = this rank's camera cluster
+        self.batches_np, self.batches = [], []
+        for k in range(4):
+            o, d, cam = scene.make_rays(sc["c2w"], N_RAYS, seed=1000 * rank + k + (0 if stage == "focal" else 500), cams=cams)
+            gt = np.random.default_rng(7 + k).random((N_RAYS, 3)).astype(np.float32)
+            self.batches_np.append((o, d, cam, gt))
+            self.batches.append(tuple(torch.from_numpy(a).cuda() for a in (o, d, cam, gt)))
+        self.target = TARGET_SAMPLES[stage]
+        self.fineness, self.mean_samples = pick_fineness(hp, self.batches[0][0], self.batches[0][1], self.target, scene, torch)
+        if world > 1:  # one fineness for the whole job (rank 0's): replicas must march alike in the global stage
+            import torch.distributed as dist
+
+            f = torch.tensor([self.fineness], dtype=torch.float64, device=CTL_DEV)
+            dist.broadcast(f, src=0)
+            self.fineness = float(f.item())
+        # The march noise (PersSampler_cuda.cu:380-389) and S3IM's arange + 9 permutations (losses.py:780-789) are drawn on the
+        # device EVERY step, inside the timed region like the reference does: step i draws them for step i + 1 on a third stream
+        # (they depend on nothing), beside the step's own kernels.
+        self.draw_stream = torch.cuda.Stream()
+        self.drawn = {}
+        self.i = 0
+
+    def _draw(self, i):
+        torch, hp = self.torch, self.hp
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.draw_stream):
+            nz = self.ops.sampler_noise(N_RAYS, self.fineness, train=True, device="cuda")
+            s3 = self.ops.s3im_index(N_RAYS, self.cfg.s3im_repeat_time, device="cuda")
+        for t_ in (nz, s3):
+            t_.record_stream(main)
+            if hp._side is not None:
+                t_.record_stream(hp._side)
+        self.drawn[i] = (nz, s3)
+        main.wait_stream(self.draw_stream)
+
+    def step(self):
+        i, args = self.i, self.args
+        self.i += 1
+        o, d, cam, gt = self.batches[i % 4]
+        block = (i % self.n_blocks) if self.stage == "focal" else None
+        nxt = self.batches[(i + 1) % 4]
+        if i not in self.drawn:
+            self._draw(i)
+        self._draw(i + 1)
+        noise, s3 = self.drawn.pop(i)
+        pre = None if args.no_prefetch else (nxt[0], nxt[1], self.drawn[i + 1][0])  # the data loader knows the next batch
+        # global stage: UpdateOctNodes K5/K6 every step, right after the forward like GFNeRFModel.get_outputs (nerfacto.py:598-616);
+        # with N > 1 ranks train_step MAX-reduces the octree statistics and averages the gradients (HotPath.sync)
+        return self.hp.train_step(o, d, cam, gt, noise, stage=self.stage, block=block, s3im_index=s3, prefetch=pre,
+                                  update_oct=self.stage == "global" and not args.no_oct_update)
+
+    def run(self, steps, warmup, dist=None):
+        """-> dict(elapsed (max over ranks), host_enqueue, loss, aux) for `steps` timed steps after PRIMING + warmup untimed ones."""
+        torch, hp, world = self.torch, self.hp, self.world
+        for _ in range(PRIMING + warmup):
+            self.step()
+        hp.timings = {}
+        hp.timed_ops = {"*"} if self.args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd", "wgrad", "adam"}
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, aux = self.step()
+        host_enqueue = time.perf_counter() - t0  # when the host had launched everything: (well) below `elapsed` = the GPU is the bound
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=CTL_DEV)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        hp.timed_ops = set()
+        return dict(elapsed=elapsed, host_enqueue=host_enqueue, loss=loss, aux=aux, steps=steps)
+
+    def roofline(self, res):
+        """Dominant kernel by event time per step + its algorithmic bytes (DESIGN.md "Kernels")."""
+        torch, hp, cfg, args = self.torch, self.hp, self.cfg, self.args
+        aux, steps = res["aux"], res["steps"]
+        n_live = aux["samples"]["pts_offsets"][-1].item()
+        n_tables = 2 if self.stage == "focal" else 1
+        # fused forward: only samples in front of each ray's termination point are looked up (sigma > 0 marks them); per such
+        # sample 512 B of gathers per table + 16 B point/anchor + 8 B dt/t in, sigma 4 + rgb 12 + h0 4 + masks 48 + weight/alpha 8 out
+        n_eval = int((aux["field"]["sigma"][:n_live] > 0).sum().item())
+        # SURVEY 8(d): hash lookup per table and sample = 512 B gathered + 12 B point + 8 B anchor + 128 B features written = 660 B
+        # (unfused); hash scatter = 16 x 8 x 4 B packed-f16 adds + point/anchor (+ 56 B of decoder state in the fused kernel)
+        alg = {"fused_fwd": n_eval * (512 * n_tables + 24 + 76), "hash_fwd": n_live * 660 * n_tables,
+               "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16),
+               "bwd_scatter": n_eval * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 16 + 16 + 56)}
+        kern = {name: float(sum(a.elapsed_time(b) for a, b in ev)) / steps for name, ev in hp.timings.items()}
+        dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
+        kern_ms, alg_bytes = kern[dom], alg[dom]
+        kernel_name, launches = dom + "_kernel", 1
+        lm = getattr(hp, "last_forward", "") == "lm" and dom == "hash_fwd"
+        if lm:  # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region
+            kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
+            kern_ms = kern_ms / launches
+            alg_bytes = n_live * 660
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
+        traffic, req = None, None
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            # the PMC passes were taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21)
+            default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
+            traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
+            n_req = pmc.get(f"{dom}:{self.stage}:fetch_requests") if default_cfg else None
+            if lm:  # the level-major kernel is bound by how fast a CU's address unit walks 64 divergent lanes, not by the fabric
+                n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch)
+                req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
+                           frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
+                           nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
+                           source="gathers the kernel issues per launch (16 levels x 8 corners per sample, minus the corners that runs of samples in one "
+                                  "cell share below level lm_halves_from: counted from this batch) over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
+            elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second (DESIGN.md section 4)
+                req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
+                           frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
+                           source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
+        return dict(bound="hbm", kernel=kernel_name, launches_per_step=launches, achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
+                    alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()}, request_rate=req), n_live, n_eval
+
+    def print_stage_times(self, res):
+        tot = 0.0
+        for name, ev in self.hp.timings.items():
+            t = sum(a.elapsed_time(b) for a, b in ev) / res["steps"]
+            tot += t
+            print(f"[stage] {self.stage:6s} {name:16s} {t:8.3f} ms/step ({len(ev) // res['steps']} launches)", file=sys.stderr)
+        print(f"[stage] {self.stage:6s} {'sum':16s} {tot:8.3f} ms/step", file=sys.stderr)
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
-    import gfnerf_amd
-    from gfnerf_amd import _lib, hotpath, scene
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import _lib, cluster, dist as gdist, scene
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal knobs (not used by the driver): several ranks on ONE card need the gloo backend (RCCL refuses duplicate GPUs)
-    backend = os.environ.get("GFN_BENCH_BACKEND", "nccl")
-    if "GFN_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["GFN_BENCH_DEVICE"])
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    n_dev = torch.cuda.device_count()
+    backend = "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if n_dev < world:
+            if not args.share_gpu:
+                raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible (--share-gpu rehearses ranks on shared cards)")
+            backend, local_rank = "gloo", local_rank % max(n_dev, 1)  # RCCL refuses two ranks on one device
+            global CTL_DEV
+            CTL_DEV = "cpu"
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     _lib.require_device()  # the HIP extension + a gfx950 device, or fail loudly
+    sync = gdist.TrainSync()
+    ranks_seen = sync.ranks_seen(device=CTL_DEV)
 
     # ---- synthetic scene (untimed): cameras + octree from the host C++ builder, cached per box
     cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene")
@@ -255,189 +578,125 @@ def main():
         sc = scene.build_scene(n_side=args.n_side, max_depth=16, seed=1234, cache_dir=cache)
     t_build = time.perf_counter() - t_build
     n_cams = sc["c2w"].shape[0]
-    n_blocks = 4 if (args.stage == "focal" and world == 1) else (1 if args.stage == "focal" else 0)
-    cfg = hotpath.HotPathConfig(log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes,
-                                mlp_precision=args.mlp_precision, prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
-                                fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, **({'record_capacity': args.record_capacity} if args.record_capacity else {}), level_major_global=args.lm_global_forward, **({'level_major_global_after': args.lm_global_after} if args.lm_global_after is not None else {}), lm_halves_from=args.lm_halves_from)
-    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=cfg, seed=0, n_blocks=n_blocks,
-                         device=f"cuda:{local_rank if world > 1 else 0}")
-    for i, b in enumerate(hp.blocks):  # mid-training state: non-zero residual tables
-        g = torch.Generator(device="cuda").manual_seed(100 + i + 16 * rank)
-        b.uniform_(-1e-3, 1e-3, generator=g)
-    hp.refresh_shadows()
-    # optimiser state and the gradient-record buffers exist before the first step (allocation is set-up, not training)
-    if args.stage == "focal":
-        for i, b in enumerate(hp.blocks):
-            hp._adam_state(f"block{i}", b)
-    else:
-        hp._adam_state("table", hp.table)
-    hp._record_buffers()
+    # focal blocks = equal-size clusters of the training cameras (perssampler.py:216-242): 4 blocks on one GPU, one per rank beyond
+    n_clusters = 4 if world == 1 else world
+    labels = cluster.equal_size_clusters(sc["c2w"][:, :, 3], n_clusters, seed=1234)
+    my_block = gdist.my_blocks(n_clusters, world, rank)[0] if world > 1 else None
+    my_cams = cluster.cameras_of(labels, my_block) if world > 1 else None
 
-    # ---- batches resident in HBM before the timed region (4 rotated batches per rank)
-    batches_np, batches = [], []
-    for k in range(4):
-        o, d, cam = scene.make_rays(sc["c2w"], N_RAYS, seed=1000 * rank + k)
-        gt = np.random.default_rng(7 + k).random((N_RAYS, 3)).astype(np.float32)
-        batches_np.append((o, d, cam, gt))
-        batches.append(tuple(torch.from_numpy(a).cuda() for a in (o, d, cam, gt)))
-    target = TARGET_SAMPLES[args.stage]
-    fineness, mean_samples = pick_fineness(hp, batches[0][0], batches[0][1], target, scene, torch)
-    # The march noise (PersSampler_cuda.cu:380-389) and S3IM's arange + 9 permutations (losses.py:780-789) are drawn on the
-    # device EVERY step, inside the timed region like the reference does: step i draws them for step i + 1 on a third stream
-    # (they depend on nothing), beside the step's own kernels.
-    from gfnerf_amd import ops as _ops
-    draw_stream = torch.cuda.Stream()
-    drawn = {}
-
-    def draw(i):
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(draw_stream):
-            nz = _ops.sampler_noise(N_RAYS, fineness, train=True, device="cuda")
-            s3 = _ops.s3im_index(N_RAYS, cfg.s3im_repeat_time, device="cuda")
-        for t_ in (nz, s3):
-            t_.record_stream(main)
-            if hp._side is not None:
-                t_.record_stream(hp._side)
-        drawn[i] = (nz, s3)
-        main.wait_stream(draw_stream)
-
-    allreduce = None
-    if world > 1 and args.stage == "global":
-        def allreduce(grads):  # ray data parallelism: sum of per-rank mean losses -> average
-            for g in grads:
-                dist.all_reduce(g)
-                g.mul_(1.0 / world)
-
-    def step(i):
-        o, d, cam, gt = batches[i % 4]
-        block = (i % n_blocks) if args.stage == "focal" else None
-        nxt = batches[(i + 1) % 4]
-        if i not in drawn:
-            draw(i)
-        draw(i + 1)
-        noise, s3 = drawn.pop(i)
-        pre = None if args.no_prefetch else (nxt[0], nxt[1], drawn[i + 1][0])  # the data loader knows the next batch
-        # global stage: UpdateOctNodes K5/K6 every step, right after the forward like GFNeRFModel.get_outputs (nerfacto.py:598-616)
-        out = hp.train_step(o, d, cam, gt, noise, stage=args.stage, block=block, allreduce=allreduce, s3im_index=s3,
-                            prefetch=pre, update_oct=args.stage == "global" and not args.no_oct_update)
-        return out
-
-    # two priming steps before the W warm-up steps: code objects are loaded, workspaces and the caching allocator's blocks
-    # exist (set-up; reported as config.priming_steps)
-    PRIMING = 2
-    for i in range(PRIMING):
-        step(i)
-    for i in range(args.warmup):
-        step(PRIMING + i)
-    # dominant kernel: timed live with events on the launch stream (torch's current stream)
-    hp.timed_ops = {"*"} if args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd"}
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, aux = step(PRIMING + args.warmup + i)
-    host_enqueue = time.perf_counter() - t0  # when the host had launched everything: (well) below `elapsed` = the GPU is the bound
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-    n_live = aux["samples"]["pts_offsets"][-1].item()
-
+    headline_stage = args.stage
+    run = StageRun(args, headline_stage, sc, world, rank, sync, torch,
+                   cams=my_cams if headline_stage == "focal" else None,
+                   n_blocks=(4 if world == 1 else 1) if headline_stage == "focal" else 0, block_seed=rank)
+    res = run.run(args.steps, args.warmup, dist)
     if rank == 0 and args.stage_times:
-        tot = 0.0
-        for name, ev in hp.timings.items():
-            t = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-            tot += t
-            print(f"[stage] {name:16s} {t:8.3f} ms/step ({len(ev) // args.steps} launches)", file=sys.stderr)
-        print(f"[stage] {'sum':16s} {tot:8.3f} ms/step", file=sys.stderr)
+        run.print_stage_times(res)
+    roofline, n_live, n_eval = run.roofline(res)
+    cfg, hp = run.cfg, run.hp
+    out = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = N_RAYS * world * args.steps / elapsed
-        # per-kernel event timings over the timed region; the dominant one carries the roofline.
-        # Algorithmic bytes per sample (DESIGN.md "Kernels"): hash lookup = 16 levels x 8 corners x 4 B f16x2 per
-        # table (512 B/table) + 16 B point/anchor + 128 B features written; hash scatter = 16 x 8 x 4 B
-        # packed-f16 atomic adds + 128 B gradient read + 16 B point/anchor.
-        n_tables = 2 if args.stage == "focal" else 1
-        # fused forward: only samples in front of each ray's termination point are looked up (sigma > 0 marks them); per such
-        # sample 512 B of gathers per table + 16 B point/anchor + 8 B dt/t in, sigma 4 + rgb 12 + h0 4 + masks 48 + weight/alpha 8 out
-        n_eval = int((aux["field"]["sigma"][:n_live] > 0).sum().item())
-        alg = {"fused_fwd": n_eval * (512 * n_tables + 24 + 76), "hash_fwd": n_live * (512 * n_tables + 16 + 128),
-               "hash_bwd": n_live * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 128 + 16),
-               "bwd_scatter": n_eval * (16 * 8 * 2 * (2 if cfg.grad_f16 else 4) + 16 + 16 + 56)}
-        kern = {}
-        for name, ev in hp.timings.items():
-            kern[name] = float(sum(a.elapsed_time(b) for a, b in ev)) / args.steps  # per step, however many regions a step times
-        dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
-        kern_ms = kern[dom]
-        alg_bytes = alg[dom]
-        kernel_name, launches = dom + "_kernel", 1
-        lm = getattr(hp, "last_forward", "") == "lm" and dom == "hash_fwd"
-        if lm:
-            # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region.  Per launch and
-            # sample: 512 B gathered + 16 B point/anchor + 128 B of level-major features written (+ the second table's launch
-            # reads the first one's 128 B back to add to them: 64 B averaged over the two launches)
-            kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
-            kern_ms = kern_ms / launches
-            alg_bytes = n_live * (512 + 16 + 128 + 64)
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
-        traffic, req = None, None
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get(f"{dom}:{args.stage}")
-            # the PMC pass was taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21, 400 cameras)
-            default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == 20
-            if not default_cfg:
-                traffic = None
-            n_req = pmc.get(f"{dom}:{args.stage}:fetch_requests") if default_cfg else None
-            if lm:  # the level-major kernel is bound by how fast a CU's address unit walks 64 divergent lanes, not by the fabric
-                n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch)
-                req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
-                           frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
-                           nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
-                           source="gathers the kernel issues per launch (16 levels x 8 corners per sample, minus the corners that runs of samples in one "
-                                  "cell share below level lm_halves_from: counted from this batch) over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
-            elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
-                req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
-                           frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
-                           source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
-        roofline = dict(bound="hbm", kernel=kernel_name, launches_per_step=launches, achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
-                        alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()}, request_rate=req)
-        w = aux["comp"]["weights"][:n_live]
+        ms = res["elapsed"] / args.steps * 1e3
+        value = N_RAYS * world * args.steps / res["elapsed"]
+        w = res["aux"]["comp"]["weights"][:n_live]
         alive_frac = float((w > 0).float().mean().item()) if w is not None else None
         out = dict(metric="train_rays_per_sec", value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   samples_per_sec=value * n_live / N_RAYS,
+                   samples_per_sec=value * n_live / N_RAYS, ranks_seen=ranks_seen,
                    config=dict(workload=("GF-NeRF global+focal train step, 4 focal blocks resident (1 active/step), "
-                                         if args.stage == "focal" and world == 1 else
-                                         "GF-NeRF focal stage, 1 block per GPU, " if args.stage == "focal" else
+                                         if headline_stage == "focal" and world == 1 else
+                                         "GF-NeRF focal stage, 1 block per GPU, rays from the block's camera cluster, " if headline_stage == "focal" else
                                          "GF-NeRF global stage train step (ray data parallel), ") +
-                                        f"4096 rays x {target} samples, Rubble-scale synthetic cameras",
+                                        f"4096 rays x {run.target} samples, Rubble-scale synthetic cameras",
                                rays_per_batch=N_RAYS, mean_samples_per_ray=n_live / N_RAYS, log2_table_size=args.log2_T,
-                               n_cameras=n_cams, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
-                               fineness=fineness, stage=args.stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
+                               n_cameras=n_cams, n_cameras_spec=1600, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
+                               fineness=run.fineness, stage=headline_stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
                                evaluated_sample_frac=n_eval / max(n_live, 1), fused_forward=bool(cfg.fused_forward),
                                block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
-                               parallelism=("1 focal block per GPU, no data-path collective" if args.stage == "focal"
-                                            else f"dp{world} all-reduce(table,mlp,emb grads)") if world > 1 else "single GPU",
-                               scene_build_s=round(t_build, 1), priming_steps=2, host_enqueue_ms_per_step=host_enqueue / args.steps * 1e3, async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step", loss=float(loss.item())),
+                               parallelism=("single GPU" if world == 1 else
+                                            f"{world} focal blocks, 1 per GPU, {len(my_cams)} cameras per block, no data-path collective" if headline_stage == "focal"
+                                            else f"dp{world}: MAX all-reduce of octree statistics + direct all-reduce (all-to-all, shard sum, all-gather) of table / decoder / embedding gradients"),
+                               backend=backend if world > 1 else None,
+                               scene_build_s=round(t_build, 1), priming_steps=PRIMING, host_enqueue_ms_per_step=res["host_enqueue"] / args.steps * 1e3,
+                               async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step",
+                               loss=float(res["loss"].item())),
                    roofline=roofline)
-        if args.render_frames > 0 and world == 1:  # the side measurements belong to the single-GPU line
-            out["render"] = render_bench(hp, sc, args, fineness, torch)
-            out["batch_assembly"] = batch_assembly_bench(sc, torch)
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            out["cpu_reference_field"] = cpu_reference_field()
-            out["cpu_baseline"] = cpu_baseline(hp.export_params(), batches_np[0], args.log2_T, fineness, args.cpu_rays,
-                                               0 if args.stage == "focal" else None, scene)
-        print(json.dumps(out))
+
+    def emit():
+        if rank == 0 and out is not None:
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+    # ---- configs[4]: render (every rank renders the frames of the block it owns)
+    if args.render_frames > 0:
+        if world == 1:
+            path = [(37 * (f + 1)) % n_cams for f in range(args.render_frames)]
+            owners = None
+            rblock = 0 if (headline_stage == "focal" and hp.blocks) else None
+        else:  # render_frames frames per block, each routed to the block's owner (perssampler.py:369-376: the frame's block = the nearest camera's)
+            path, owners = [], []
+            for b in range(n_clusters):
+                cb = cluster.cameras_of(labels, b)
+                for f in range(args.render_frames):
+                    path.append(int(cb[(37 * (f + 1)) % cb.size]))
+            owners = gdist.frame_owner(labels[np.asarray(path)], world)
+            rblock = 0 if (headline_stage == "focal" and hp.blocks) else None
+        with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
+            r = render_bench(hp, sc, args, run.fineness, torch, path, rblock, world, rank, owners, dist)
+        if out is not None:
+            out["render"] = r
+    if world == 1 and args.render_frames > 0:
+        out["batch_assembly"] = batch_assembly_bench(sc, torch)
+    P_focal = hp.export_params() if (world == 1 and not args.no_cpu_baseline) else None
+    fine_focal, batches_focal = run.fineness, run.batches_np
+    # ---- configs[1]: the global stage under the same clock (sub-record); data parallel at N > 1
+    grun = None
+    if args.global_steps > 0 and headline_stage != "global":
+        del run, hp, res
+        torch.cuda.empty_cache()
+
+        def global_record():
+            nonlocal grun
+            grun = StageRun(args, "global", sc, world, rank, sync, torch, cams=None, n_blocks=0)
+            gres = grun.run(args.global_steps, args.global_warmup, dist)
+            if rank == 0 and args.stage_times:
+                grun.print_stage_times(gres)
+            groof, g_live, g_eval = grun.roofline(gres)
+            identical = sync.replicas_identical([grun.hp.table, grun.hp.mlp_flat, grun.hp.emb, grun.hp.nodes]) if world > 1 else None
+            if out is not None:
+                gv = N_RAYS * world * args.global_steps / gres["elapsed"]
+                out["global_stage"] = dict(
+                    metric="train_rays_per_sec", value=gv, unit="rays/s", ms_per_step=gres["elapsed"] / args.global_steps * 1e3,
+                    steps=args.global_steps, warmup=args.global_warmup, samples_per_sec=gv * g_live / N_RAYS,
+                    workload="GF-NeRF global stage, single Hash3DAnchored encoder + tiny MLP, 4096 rays x 128 samples (BASELINE configs[1]); all parameters "
+                             "train, UpdateOctNodes (K5/K6) every step", mean_samples_per_ray=g_live / N_RAYS, evaluated_sample_frac=g_eval / max(g_live, 1),
+                    forward=grun.hp.last_forward, fineness=grun.fineness, host_enqueue_ms_per_step=gres["host_enqueue"] / args.global_steps * 1e3,
+                    parallelism="single GPU" if world == 1 else f"dp{world}: octree statistics MAX-reduced, gradients averaged (direct all-reduce) inside HotPath.train_step",
+                    replicas_bit_identical=identical, sync=dict(sync.stats) if world > 1 else None, loss=float(gres["loss"].item()), roofline=groof)
+
+        try:
+            with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
+                global_record()
+        except Exception as e:  # the headline stands on its own
+            if out is not None:
+                out["global_stage"] = dict(error=f"{type(e).__name__}: {e}")
+    if out is not None and not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
+        out["cpu_reference_field"] = cpu_reference_field()
+        out["cpu_baseline"] = cpu_baseline(P_focal, batches_focal[0], args.log2_T, fine_focal, args.cpu_rays,
+                                           0 if headline_stage == "focal" else None, scene)
+        if grun is not None:
+            out["cpu_baseline_global"] = cpu_baseline_global(grun.hp.export_params(), grun.batches_np[0], args.log2_T, grun.fineness, scene)
+    emit()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

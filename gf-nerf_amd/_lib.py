@@ -31,6 +31,9 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_update_nodes_mark": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gfn_update_nodes_apply": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_query_tree_nodes_centers": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gfn_mark_invisible_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gfn_octree_proc_host": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
                                     C.POINTER(_vp)]),
@@ -72,6 +75,7 @@ SIGNATURES = {
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
+    "gfn_reduce_shards": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),
     "gfn_octree_build_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _u64, _i32, C.POINTER(_vp),
                                      C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),
     "gfn_free_host": (None, [_vp]),

@@ -6,6 +6,27 @@
 
 namespace {
 thread_local char g_err[512] = "";
+
+// Local step of the direct all-reduce (gfnerf_amd/dist.py): recv holds n_shards copies of this rank's shard, one per
+// peer; out = (sum of the copies, in f32, in rank order) * scale.  8 elements per lane and copy, 16-byte (f16) / 32-byte
+// (f32) loads; HBM stream.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_shards_kernel(const T* __restrict__ recv, int n_shards, int64_t shard, float scale,
+                                                            T* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= shard) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < n_shards; s++) {
+    T v[8];
+    __builtin_memcpy(v, recv + (int64_t)s * shard + i, sizeof(v));
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] += (float)v[k];
+  }
+  T r[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) r[k] = (T)(acc[k] * scale);
+  __builtin_memcpy(out + i, r, sizeof(r));
+}
 }
 
 void gfn_set_error(const char* fmt, ...) {
@@ -33,6 +54,23 @@ int gfn_device_count(void) {
     if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
   }
   return ok;
+}
+
+int gfn_reduce_shards(const void* recv, int n_shards, int64_t shard_elems, int is_f16, float scale, void* out, void* stream) {
+  if (shard_elems == 0) return GFN_OK;
+  GFN_CHECK_ARG(recv && out && n_shards > 0 && shard_elems > 0 && shard_elems % 8 == 0,
+                "gfn_reduce_shards: shard_elems=%lld must be a positive multiple of 8", (long long)shard_elems);
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(recv) & 31) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "gfn_reduce_shards: buffers must be 32-byte (recv) / 16-byte (out) aligned");
+  const unsigned grid = (unsigned)((shard_elems / 8 + 255) / 256);
+  if (is_f16)
+    reduce_shards_kernel<_Float16><<<grid, 256, 0, gfn_stream(stream)>>>(reinterpret_cast<const _Float16*>(recv), n_shards, shard_elems, scale,
+                                                                         reinterpret_cast<_Float16*>(out));
+  else
+    reduce_shards_kernel<float><<<grid, 256, 0, gfn_stream(stream)>>>(reinterpret_cast<const float*>(recv), n_shards, shard_elems, scale,
+                                                                      reinterpret_cast<float*>(out));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
 }
 
 }  // extern "C"

@@ -701,7 +701,7 @@ __global__ void fill_i64_kernel(long long* p, long long v, int64_t n) {
 // below -- the last sample of the run (or of the 64-sample sweep) posts it.
 __global__ __launch_bounds__(256) void mark_visit_kernel(
     int n_rays, const int* __restrict__ pts_offsets, const int* __restrict__ anchors,
-    const float* __restrict__ weights, const float* __restrict__ alphas, long long* w_adder,
+    const float* __restrict__ weights, const float* __restrict__ alphas, int n_nodes, long long* w_adder,
     long long* a_adder, long long* mark, long long* visit_cnt) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void mark_visit_kernel(
     const long long cnt = upto ? (long long)(lane - (63 - __builtin_clzll(upto)) + 1) : (long long)(lane + 1) + carry_cnt;
     const int next = __shfl_down(oi, 1, 64);
     const bool last = lane == 63 || next != oi;
-    if (v && oi >= 0) {
+    if (v && oi >= 0 && oi < n_nodes) {  // samples marched through an older (larger) tree must not write past the arrays
       mark[oi] = 1;
       if (weights[i] > w_thres) atomicMax(w_adder + oi, (long long)OCC_WEIGHT_BASE);
       if (alphas[i] > a_thres) atomicMax(a_adder + oi, (long long)OCC_ALPHA_BASE);
@@ -797,6 +797,18 @@ __global__ __launch_bounds__(256) void mark_invisible_kernel(int64_t n_nodes, in
     seen = __any(v);
   }
   if (!seen && lane == 0) nd->trans_idx = -1;
+}
+
+// K12 QueryTreeNodeCenterKernel (PersSampler_cuda.cu:984-1005): centre of the node each index names; indices outside
+// [0, n_nodes) leave their (zero-initialised by the caller, :1013) row untouched.
+__global__ void query_centers_kernel(int64_t n_pts, int64_t n_nodes, const uint8_t* __restrict__ nodes,
+                                     const long long* __restrict__ anchors, float* __restrict__ centers) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pts) return;
+  const long long a = anchors[i];
+  if (a < 0 || a >= n_nodes) return;
+  const float* c = reinterpret_cast<const float*>(nodes + a * GFN_TREE_NODE_BYTES);
+  centers[3 * i] = c[0]; centers[3 * i + 1] = c[1]; centers[3 * i + 2] = c[2];
 }
 
 }  // namespace
@@ -964,29 +976,54 @@ int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float
   return GFN_OK;
 }
 
-int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
-                     const float* weights, const float* alphas, int64_t n_nodes,
-                     int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
-                     int64_t* scratch, void* stream) {
-  GFN_CHECK_ARG(pts_offsets && anchors && weights && alphas && weight_stats && alpha_stats && visit_cnt && nodes && scratch,
-                "gfn_update_nodes: null pointer");
-  GFN_CHECK_ARG(n_rays >= 0 && n_nodes > 0, "gfn_update_nodes: bad sizes");
+int gfn_update_nodes_mark(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
+                          const float* weights, const float* alphas, int64_t n_nodes, int64_t* visit_cnt,
+                          int64_t* scratch, void* stream) {
+  GFN_CHECK_ARG(pts_offsets && anchors && weights && alphas && visit_cnt && scratch, "gfn_update_nodes_mark: null pointer");
+  GFN_CHECK_ARG(n_rays >= 0 && n_nodes > 0 && n_nodes < (1ll << 31), "gfn_update_nodes_mark: bad sizes");
   hipStream_t st = gfn_stream(stream);
   long long* w_adder = reinterpret_cast<long long*>(scratch);
   long long* a_adder = w_adder + n_nodes;
   long long* mark = a_adder + n_nodes;
-  const unsigned gn = (unsigned)((n_nodes + 255) / 256);
   fill_i64_kernel<<<(unsigned)((2 * n_nodes + 255) / 256), 256, 0, st>>>(w_adder, -1, 2 * n_nodes);  // :617-618
   GFN_CHECK_LAUNCH();
   GFN_CHECK_HIP(hipMemsetAsync(mark, 0, sizeof(long long) * n_nodes, st));
   if (n_rays > 0) {
     mark_visit_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(
-        (int)n_rays, pts_offsets, anchors, weights, alphas, w_adder, a_adder, mark,
+        (int)n_rays, pts_offsets, anchors, weights, alphas, (int)n_nodes, w_adder, a_adder, mark,
         reinterpret_cast<long long*>(visit_cnt));
     GFN_CHECK_LAUNCH();
   }
-  node_stats_kernel<<<gn, 256, 0, st>>>(n_nodes, w_adder, a_adder, mark, reinterpret_cast<long long*>(weight_stats),
-                                        reinterpret_cast<long long*>(alpha_stats), reinterpret_cast<uint8_t*>(nodes));
+  return GFN_OK;
+}
+
+int gfn_update_nodes_apply(int64_t n_nodes, const int64_t* scratch, int64_t* weight_stats, int64_t* alpha_stats,
+                           void* nodes, void* stream) {
+  GFN_CHECK_ARG(scratch && weight_stats && alpha_stats && nodes, "gfn_update_nodes_apply: null pointer");
+  GFN_CHECK_ARG(n_nodes > 0 && n_nodes < (1ll << 31), "gfn_update_nodes_apply: bad sizes");
+  const long long* w_adder = reinterpret_cast<const long long*>(scratch);
+  node_stats_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, gfn_stream(stream)>>>(
+      n_nodes, w_adder, w_adder + n_nodes, w_adder + 2 * n_nodes, reinterpret_cast<long long*>(weight_stats),
+      reinterpret_cast<long long*>(alpha_stats), reinterpret_cast<uint8_t*>(nodes));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
+                     const float* weights, const float* alphas, int64_t n_nodes,
+                     int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
+                     int64_t* scratch, void* stream) {
+  const int rc = gfn_update_nodes_mark(pts_offsets, n_rays, anchors, weights, alphas, n_nodes, visit_cnt, scratch, stream);
+  if (rc != GFN_OK) return rc;
+  return gfn_update_nodes_apply(n_nodes, scratch, weight_stats, alpha_stats, nodes, stream);
+}
+
+int gfn_query_tree_nodes_centers(const void* nodes, int64_t n_nodes, const int64_t* anchors, int64_t n_pts, float* centers,
+                                 void* stream) {
+  if (n_pts == 0) return GFN_OK;
+  GFN_CHECK_ARG(nodes && anchors && centers && n_nodes > 0 && n_pts > 0, "gfn_query_tree_nodes_centers: bad arguments");
+  query_centers_kernel<<<(unsigned)((n_pts + 255) / 256), 256, 0, gfn_stream(stream)>>>(
+      n_pts, n_nodes, reinterpret_cast<const uint8_t*>(nodes), reinterpret_cast<const long long*>(anchors), centers);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

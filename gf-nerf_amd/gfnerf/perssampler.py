@@ -62,6 +62,9 @@ class _NativePersSampler:
         self.generator = torch.Generator(device=dev)
         self.generator.manual_seed(seed)
         self.last_packed = None
+        # ray data parallelism: set to gfnerf_amd.dist.TrainSync.reduce_octree_stats and K5's per-node maxima are MAX-reduced
+        # over the ranks before the statistics update + K6 (every replica then keeps the same tree)
+        self.reduce_max = None
         self.initialised = True
 
     def _set_tree(self, nodes, transes):
@@ -126,7 +129,7 @@ class _NativePersSampler:
         else:
             w, a = sampled_weights.contiguous().float(), sampled_alpha.contiguous().float()
         ops.update_nodes(s["pts_offsets"], s["anchors"], w, a, self.tree_weight_stats_, self.tree_alpha_stats_,
-                         self.tree_visit_cnt_, self.tree_nodes_gpu_)
+                         self.tree_visit_cnt_, self.tree_nodes_gpu_, reduce_max=self.reduce_max)
         # subdivision milestones and the periodic compaction (:667-676)
         changed = False
         while self.sub_div_milestones_ and self.sub_div_milestones_[-1] <= iter_step:
@@ -181,6 +184,11 @@ class _NativePersSampler:
         idx = dist.argmin(dim=1)
         nodes[:, 104:112] = idx.view(-1, 1).contiguous().view(torch.uint8).view(self.n_nodes, 8)
         ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)
+
+    def qurey_tree_nodes_centers(self, anchors):
+        """PersSampler::QueryTreeNodeCenters (K12, PersSampler_cuda.cu:984-1029; the binding's spelling, bindings.cpp:396):
+        anchors i64 [n,1] node indices -> centers f32 [n,3] (zeros where out of range)."""
+        return ops.query_tree_nodes_centers(self.tree_nodes_gpu_, anchors.to(self.device).contiguous())
 
     # ------------------------------------------------------------------ state
     def States(self) -> List[torch.Tensor]:
@@ -274,7 +282,8 @@ class PersSampler(nn.Module):
                                  sampled_oct_per_ray, ray_march_fineness, ray_march_init_fineness,
                                  ray_march_fineness_decay_end_iter, seed=seed)
         self._register_state_dict_hook(self.state_dict_hook)
-        for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts", "cameras_labels"):
+        for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts", "cameras_rays_nodes_centers", "cameras_labels",
+                  "cameras_valid_mask"):
             self.register_buffer(k, None)
         self.register_buffer("c2w", c2w)
         self.n_split_dataset = n_split_dataset
@@ -303,6 +312,61 @@ class PersSampler(nn.Module):
         return RaySamples(f2samples=f2, camera_indices=ray_bundle.camera_indices, rel_camera_indices=ray_bundle.rel_camera_indices,
                           deltas=None if f2 is None else f2.sampled_dists, cur_step=cur_step,
                           cur_split_dataset_idx=cur_split_idx, packed=packed)
+
+    # ------------------------------------------------------------------ block routing (perssampler.py:138-260)
+    def get_nearest_split_dataset(self, origin, direction=None):
+        """perssampler.py:138-165: the split (= focal block) of the training camera nearest to `origin` -> (split, camera)."""
+        cameras_pos = self.c2w[:, 0:3, -1]
+        dists = torch.norm(cameras_pos - origin.to(cameras_pos).view(1, 3), dim=1, p=2)
+        nearest_image_idx = int(torch.argmin(dists).item())
+        return int(self.cameras_labels[nearest_image_idx].item()), nearest_image_idx
+
+    def get_nearest_split_dataset_orig(self, origin):
+        """perssampler.py:244-260: before the cameras are clustered, splits are consecutive runs of n_cameras // n_split images."""
+        n_cameras = self.c2w.shape[0]
+        per = max(n_cameras // self.n_split_dataset, 1)
+        cameras_pos = self.c2w[:, 0:3, -1]
+        nearest_image_idx = int(torch.argmin(torch.norm(cameras_pos - origin.to(cameras_pos).view(1, 3), dim=1)).item())
+        return min(nearest_image_idx // per, self.n_split_dataset - 1), nearest_image_idx
+
+    def split_of_origin(self, origin, direction=None):
+        """The eval branch of generate_ray_samples (perssampler.py:365-376): clustered labels when they exist, else the runs."""
+        if self.cameras_labels is not None:
+            return self.get_nearest_split_dataset(origin, direction)
+        return self.get_nearest_split_dataset_orig(origin)
+
+    def query_tree_nodes_centers(self, anchors):
+        assert anchors.shape[1] == 1 and anchors.dtype == torch.int64  # perssampler.py:500-501
+        return self.sampler.qurey_tree_nodes_centers(anchors)
+
+    def get_distance_matrix_oct(self):
+        """perssampler.py:170-214: one ray per training camera along its optical axis; the centres of the nodes it crosses are
+        kept (cameras_rays_nodes_centers / cameras_valid_mask, used by get_oct_split_dataset); the matrix the clustering gets
+        is the plain camera-position distance matrix (:201-207), built here in one cdist instead of n^2 .item() calls."""
+        rays_o = self.c2w[:, 0:3, -1].contiguous()
+        rays_d = self.c2w[:, :, 2].contiguous()
+        n_cams = rays_o.shape[0]
+        dense = self.sampler.GetSamples(rays_o, rays_d, self.bounds)
+        anchors = dense[5]
+        # the reference indexes QueryTreeNodeCenters with anchors[..., 0] (:189); column 0 is trans_idx, kept as is
+        centers = self.query_tree_nodes_centers(anchors[:, :, 0].reshape(-1, 1).contiguous())
+        self.cameras_rays_nodes_centers = centers.view(n_cams, self.max_pts_per_ray, 3)
+        self.cameras_valid_mask = anchors[:, :, 0] > 0
+        distance_matrix = torch.cdist(rays_o.double(), rays_o.double()).float().cpu()
+        return distance_matrix, torch.ones(n_cams, dtype=torch.bool)
+
+    def train_cameras_clustering_oct(self, k):
+        """perssampler.py:216-242: cameras_labels [n,1] int64, k non-empty equal-size clusters.  The reference's
+        SpectralEqualSizeClustering (sklearn, SURVEY 2a OUT) is replaced by gfnerf_amd.cluster's capacity-constrained k-means
+        over the same camera positions; the contract (equal sizes, none empty, seed 1234) is the reference's."""
+        from .. import cluster
+
+        assert self.cameras_labels is None
+        pos = self.c2w[:, 0:3, -1].detach().cpu().numpy()
+        labels = cluster.equal_size_clusters(pos, int(k), seed=1234)
+        self.cameras_labels = torch.from_numpy(labels).view(-1, 1).to(torch.int64)
+        self.num_cams_per_cluster = [int((self.cameras_labels == i).sum().item()) for i in range(int(k))]
+        assert 0 not in self.num_cams_per_cluster
 
     def update_oct_nodes(self, sampled_anchors, pts_idx_bounds, sampled_weights, sampled_alpha, iter_step: int):
         self.sampler.UpdateOctNodes(sampled_anchors, pts_idx_bounds, sampled_weights, sampled_alpha, iter_step)

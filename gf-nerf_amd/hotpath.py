@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import _lib, ops, scene
+from . import _lib, dist as gdist, ops, scene
 
 STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
 STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
@@ -66,9 +66,13 @@ class HotPathConfig:
 
 
 class HotPath:
-    def __init__(self, nodes, transes, n_cams, cfg=None, device=None, seed=0, n_blocks=0):
-        """device: None = the process's current HIP device (one process per GPU: torch.cuda.set_device(LOCAL_RANK))."""
+    def __init__(self, nodes, transes, n_cams, cfg=None, device=None, seed=0, n_blocks=0, sync=None):
+        """device: None = the process's current HIP device (one process per GPU: torch.cuda.set_device(LOCAL_RANK)).
+        sync: gfnerf_amd.dist.TrainSync of this process (default: one over the default process group, the identity when
+        torch.distributed is not initialised): the global stage exchanges octree statistics (MAX) and gradients (mean)
+        through it, so N ranks that start from the same seed stay bit-identical replicas."""
         self.cfg = cfg or HotPathConfig()
+        self.sync = sync if sync is not None else gdist.TrainSync()
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
 
@@ -130,6 +134,7 @@ class HotPath:
         self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)
         self.timed_ops = set()  # stage names to bracket with events on the launch stream (bench.py)
         self.timings = {}
+        self._last_train_ctx = None
 
     def refresh_shadows(self):
         """(Re)build the f16 shadow tables after the masters were written from outside the optimiser."""
@@ -461,6 +466,9 @@ class HotPath:
                 if rec is not None:
                     self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
                 dfeat = None
+                # data parallel: the table gradient is final here -- its exchange runs beside the weight-gradient kernels below
+                self.sync.start_grads([self._grad_live()])
+                ctx["table_exchange_started"] = True
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
                                     bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
@@ -577,27 +585,51 @@ class HotPath:
             return out
         return [live]
 
-    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, allreduce=None, s3im_index=None,
+    def sync_grads(self, stage, ctx=None):
+        """Data-parallel global stage (scripts/train.py:124-137, gf_pipeline.py:136-138 -- DDP there, which misses the hash
+        table): average this step's gradients over the ranks before Adam.  The table exchange may already be in flight
+        (backward starts it as soon as the table gradient is final); the decoder / embedding gradients follow here.  The focal
+        stage trains one block table per rank with everything shared frozen: nothing to exchange."""
+        if self.sync.world == 1 or stage != STAGE_GLOBAL:
+            return
+        g = self.grads(stage)
+        if ctx is not None and ctx.pop("table_exchange_started", False):
+            self.sync.finish_grads(g[1:])
+        else:
+            self.sync.start_grads(g[:1])
+            self.sync.finish_grads(g[1:])
+
+    def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None,
                    prefetch=None, update_oct=False):
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
         loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch,
                                           update_oct=update_oct)
-        if allreduce is not None:
-            allreduce(self.grads(stage))
+        self.sync_grads(stage, aux)
         self.optimizer_step(stage, block)
         return loss, aux
 
     def update_oct_nodes(self, aux):
-        """persampler.update_oct_nodes (nerfacto.py:606-613) on the packed samples of the last step."""
+        """persampler.update_oct_nodes (nerfacto.py:606-613) on the packed samples of the last step.  Data parallel: the
+        per-node maxima K5 produced from this rank's rays are MAX-reduced over the ranks before the statistics update and K6."""
         s, comp = aux["samples"], aux["comp"]
         ops.update_nodes(s["pts_offsets"], s["anchors"], comp["weights"], comp["alphas"], self.weight_stats,
-                         self.alpha_stats, self.visit_cnt, self.nodes)
+                         self.alpha_stats, self.visit_cnt, self.nodes,
+                         reduce_max=self.sync.reduce_octree_stats if self.sync.world > 1 else None)
         ops.tree_compact(self.nodes, self.nodes_compact)  # K6 may have invalidated leaves
+
+    def _drop_stale_samples(self):
+        """The tree is about to change: samples marched through the old tree (a prefetched next batch, the last step's
+        context) carry old node indices and must not be collected or fed to UpdateOctNodes."""
+        if self._pre is not None:
+            torch.cuda.current_stream().wait_stream(self._side)  # the prefetch still owns the sampler workspace
+            self._pre = None
+        self._last_train_ctx = None
 
 
     def proc_octree(self, compact=True, subdivide=False, brute_force=False):
         """PersOctree::ProcOctree (PersSampler.cpp:154-417) on this path's tree: host round trip like the reference,
         then the 64-byte sampler image is rebuilt.  Node indices change; hash volumes (trans_idx) do not."""
+        self._drop_stale_samples()
         nodes, w, a = ops.octree_proc_host(self.nodes.cpu().numpy(), self.weight_stats.cpu().numpy(), self.alpha_stats.cpu().numpy(),
                                            self.visit_cnt.cpu().numpy(), compact=compact, subdivide=subdivide, brute_force=brute_force)
         self.nodes = torch.from_numpy(nodes).to(self.dev)
@@ -610,6 +642,7 @@ class HotPath:
 
     def mark_invisible_nodes(self, intri, w2c, bounds):
         """K7 MarkInvisibleNodes (PersSampler_cuda.cu:709-742)."""
+        self._drop_stale_samples()
         ops.mark_invisible_nodes(self.nodes, intri, w2c, bounds)
         ops.tree_compact(self.nodes, self.nodes_compact)
 

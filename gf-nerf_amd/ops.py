@@ -340,7 +340,10 @@ def samples_to_dense(s, n_rays):
     return [d_world, d_warped, d_dirs, d_dists, d_ts, d_anchors, d_se, s["first_oct_dis"].view(n_rays, 1)]
 
 
-def update_nodes(pts_offsets, anchors, weights, alphas, weight_stats, alpha_stats, visit_cnt, nodes):
+def update_nodes(pts_offsets, anchors, weights, alphas, weight_stats, alpha_stats, visit_cnt, nodes, reduce_max=None):
+    """UpdateOctNodes' device part (K5, statistics, K6).  reduce_max: callable taking a list of int64 tensors and replacing each
+    with its elementwise maximum over the ranks (gfnerf_amd.dist.allreduce_max_) -- run between K5 and the statistics update, it
+    gives every ray-data-parallel replica the tree ONE process would have computed from all ranks' rays."""
     _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(anchors, torch.int32, "anchors", 3)
     _chk(weights, torch.float32, "weights"); _chk(alphas, torch.float32, "alphas")
     for t, nm in ((weight_stats, "weight_stats"), (alpha_stats, "alpha_stats"), (visit_cnt, "visit_cnt")):
@@ -350,10 +353,26 @@ def update_nodes(pts_offsets, anchors, weights, alphas, weight_stats, alpha_stat
     if weight_stats.numel() != n_nodes or alpha_stats.numel() != n_nodes or visit_cnt.numel() != n_nodes:
         raise _lib.GfnError("stat tensors must have n_nodes entries")
     scratch = torch.empty(3 * n_nodes, dtype=torch.int64, device=nodes.device)
-    rc = _lib.lib().gfn_update_nodes(_ptr(pts_offsets), pts_offsets.numel() - 1, _ptr(anchors), _ptr(weights),
-                                     _ptr(alphas), n_nodes, _ptr(weight_stats), _ptr(alpha_stats), _ptr(visit_cnt),
-                                     _ptr(nodes), _ptr(scratch), _stream())
-    _lib.check(rc, "gfn_update_nodes")
+    L = _lib.lib()
+    rc = L.gfn_update_nodes_mark(_ptr(pts_offsets), pts_offsets.numel() - 1, _ptr(anchors), _ptr(weights), _ptr(alphas), n_nodes,
+                                 _ptr(visit_cnt), _ptr(scratch), _stream())
+    _lib.check(rc, "gfn_update_nodes_mark")
+    if reduce_max is not None:
+        reduce_max([scratch, visit_cnt])
+    rc = L.gfn_update_nodes_apply(n_nodes, _ptr(scratch), _ptr(weight_stats), _ptr(alpha_stats), _ptr(nodes), _stream())
+    _lib.check(rc, "gfn_update_nodes_apply")
+
+
+def query_tree_nodes_centers(nodes, anchors):
+    """PersSampler::QueryTreeNodeCenters (K12): anchors i64 [n,1] (node indices) -> centers f32 [n,3], zeros where out of range."""
+    _chk(nodes, torch.uint8, "nodes"); _chk(anchors, torch.int64, "anchors")
+    n = anchors.shape[0]
+    if anchors.numel() != n:
+        raise _lib.GfnError("anchors must be [n, 1]")
+    out = torch.zeros((n, 3), dtype=torch.float32, device=nodes.device)
+    rc = _lib.lib().gfn_query_tree_nodes_centers(_ptr(nodes), nodes.numel() // TREE_NODE_BYTES, _ptr(anchors), n, _ptr(out), _stream())
+    _lib.check(rc, "gfn_query_tree_nodes_centers")
+    return out
 
 
 def mark_invisible_nodes(nodes, intri, w2c, bounds):
@@ -979,6 +998,18 @@ def fill_zero(t):
 
 
 # ---------------------------------------------------------------- octree (host side)
+def reduce_shards(recv, n_shards, out, scale=1.0):
+    """out = scale * sum of the n_shards consecutive copies in recv (f32 accumulation); f16 or f32, see gfn_reduce_shards."""
+    if recv.dtype not in (torch.float16, torch.float32):
+        raise _lib.GfnError("reduce_shards: f16 or f32")
+    _chk(recv, recv.dtype, "recv"); _chk(out, recv.dtype, "out")
+    shard = out.numel()
+    if recv.numel() != n_shards * shard:
+        raise _lib.GfnError("reduce_shards: recv must hold n_shards copies of out")
+    rc = _lib.lib().gfn_reduce_shards(_ptr(recv), n_shards, shard, int(recv.dtype == torch.float16), float(scale), _ptr(out), _stream())
+    _lib.check(rc, "gfn_reduce_shards")
+
+
 def octree_build(c2w, intri, bounds, max_depth=16, bbox_side_len=512.0, split_dist_thres=1.5, seed=1234, threads=0):
     """Host C++ builder -> (nodes uint8 [n_nodes*128], transes uint8 [n_trans*576]) numpy blobs."""
     c2w = np.ascontiguousarray(c2w, np.float32)

@@ -144,22 +144,31 @@ class TileRenderer:
                     rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
         return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width), depth=depth.view(height, width))
 
-    def render_path(self, cams, height, width, world_size=1, rank=0):
-        """Camera path sharded over ranks by frame -> {frame index: outputs} of this rank's frames."""
-        return {f: self.render_camera(cams[f], height, width) for f in frame_shard(len(cams), world_size, rank)}
+    def render_path(self, cams, height, width, world_size=1, rank=0, owners=None):
+        """Camera path sharded over ranks by frame -> {frame index: outputs} of this rank's frames.  owners[f] (see
+        gfnerf_amd.dist.frame_owner) routes frame f to the rank holding its block's table; default: round robin."""
+        mine = frame_shard(len(cams), world_size, rank) if owners is None else [f for f in range(len(cams)) if owners[f] == rank]
+        return {f: self.render_camera(cams[f], height, width) for f in mine}
 
 
-def gather_frames(local, n_frames, height, width, dst=0):
-    """Collect every rank's rgb frames on `dst` -> [n_frames,H,W,3] (None elsewhere).  One collective per path."""
+def gather_frames(local, n_frames, height, width, dst=0, owners=None):
+    """Collect every rank's rgb frames on `dst` -> [n_frames,H,W,3] (None elsewhere).  One collective per path.
+    owners[f]: the rank that rendered frame f (gfnerf_amd.dist.frame_owner: the owner of the frame's block); default: round
+    robin (frame_shard)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return torch.stack([local[f]["rgb"] for f in range(n_frames)])
     w, r = dist.get_world_size(), dist.get_rank()
-    dev = next(iter(local.values()))["rgb"].device if local else torch.device("cpu")
-    per = (n_frames + w - 1) // w
+    if owners is None:
+        owners = [f % w for f in range(n_frames)]
+    frames_of = [[f for f in range(n_frames) if owners[f] == rr] for rr in range(w)]
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if local:
+        dev = next(iter(local.values()))["rgb"].device
+    per = max(max(len(fr) for fr in frames_of), 1)  # gather needs equal shapes: pad to the busiest rank
     mine = torch.zeros((per, height, width, 3), dtype=torch.float32, device=dev)
-    for k, f in enumerate(frame_shard(n_frames, w, r)):
+    for k, f in enumerate(frames_of[r]):
         mine[k] = local[f]["rgb"]
     bufs = [torch.empty_like(mine) for _ in range(w)] if r == dst else None
     dist.gather(mine, bufs, dst=dst)
@@ -167,6 +176,6 @@ def gather_frames(local, n_frames, height, width, dst=0):
         return None
     out = torch.empty((n_frames, height, width, 3), dtype=torch.float32, device=dev)
     for rr in range(w):
-        for k, f in enumerate(frame_shard(n_frames, w, rr)):
+        for k, f in enumerate(frames_of[rr]):
             out[f] = bufs[rr][k]
     return out

@@ -47,11 +47,16 @@ def make_cameras(n_side=20, extent=40.0, height=12.0, tilt_deg=15.0, seed=1234):
     return c2w, intri, bounds
 
 
-def make_rays(c2w, n_rays, seed=0):
+def make_rays(c2w, n_rays, seed=0, cams=None):
     """Uniformly random (camera, pixel) rays, nerfstudio pinhole convention
-    (cameras.py generate_rays: d = R [(x-cx)/fx, -(y-cy)/fy, -1], normalised)."""
+    (cameras.py generate_rays: d = R [(x-cx)/fx, -(y-cy)/fy, -1], normalised).
+    cams: draw only from these camera indices (a focal block's camera cluster); the returned camera ids are global."""
     rng = np.random.default_rng(seed)
-    cam = rng.integers(0, c2w.shape[0], n_rays)
+    if cams is None:
+        cam = rng.integers(0, c2w.shape[0], n_rays)
+    else:
+        cams = np.asarray(cams, np.int64)
+        cam = cams[rng.integers(0, cams.size, n_rays)]
     px = rng.uniform(0, WIDTH, n_rays)
     py = rng.uniform(0, HEIGHT, n_rays)
     d_cam = np.stack([(px - WIDTH / 2) / FOCAL, -(py - HEIGHT / 2) / FOCAL, -np.ones(n_rays)], -1)

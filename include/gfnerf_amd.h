@@ -211,6 +211,23 @@ int gfn_update_nodes(const int32_t* pts_offsets, int64_t n_rays, const int32_t* 
                      int64_t* weight_stats, int64_t* alpha_stats, int64_t* visit_cnt, void* nodes,
                      int64_t* scratch, void* stream);
 
+/* The same in two phases, for ray-data-parallel training: _mark is K5 (:518-574) into scratch
+ * ([w_adder | a_adder | mark] i64 [3*n_nodes], initialised here) and visit_cnt; every quantity is a
+ * maximum over rays, so ranks combine scratch and visit_cnt with an elementwise MAX all-reduce and
+ * _apply (the statistics update :641-655 + K6 :576-582) then gives every replica the tree one
+ * process would have computed from all the rays.  Sample node indices >= n_nodes are skipped. */
+int gfn_update_nodes_mark(const int32_t* pts_offsets, int64_t n_rays, const int32_t* anchors,
+                          const float* weights, const float* alphas, int64_t n_nodes, int64_t* visit_cnt,
+                          int64_t* scratch, void* stream);
+int gfn_update_nodes_apply(int64_t n_nodes, const int64_t* scratch, int64_t* weight_stats, int64_t* alpha_stats,
+                           void* nodes, void* stream);
+
+/* K12 QueryTreeNodeCenterKernel / PersSampler::QueryTreeNodeCenters (PersSampler_cuda.cu:984-1029;
+ * `qurey_tree_nodes_centers`, bindings.cpp:396): centers[i] = tree_nodes[anchors[i]].center for
+ * anchors i64 [n_pts] in [0, n_nodes); other rows are left as the caller initialised them (zeros). */
+int gfn_query_tree_nodes_centers(const void* nodes, int64_t n_nodes, const int64_t* anchors, int64_t n_pts, float* centers,
+                                 void* stream);
+
 /* K7 MarkInvisibleNodes (PersSampler_cuda.cu:680-742): trans_idx = -1 for every node that no camera
  * sees.  intri f32 [n_cams,3,3], w2c f32 [n_cams,3,4], bounds f32 [n_cams,2], row-major (the tensors
  * InitSampler receives, bindings.cpp:24-35). */
@@ -482,6 +499,12 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
                      int shadow_pair, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
+
+/* Local step of the direct (all-to-all + all-gather) gradient all-reduce of the ray-data-parallel global stage
+ * (replaces DDP's bucketed all-reduce, gf_pipeline.py:136-138, which never sees the hash table): recv holds
+ * n_shards copies [n_shards][shard_elems] of this rank's shard (f16 when is_f16, else f32), one per peer;
+ * out[i] = (sum over copies, accumulated in f32 in rank order) * scale.  shard_elems % 8 == 0. */
+int gfn_reduce_shards(const void* recv, int n_shards, int64_t shard_elems, int is_f16, float scale, void* out, void* stream);
 
 /* ====================================================================== *
  * Host-side octree construction (replaces PersOctree::PersOctree,

@@ -1,8 +1,13 @@
-"""World-size-2 gloo tests (CPU) of the multi-GPU path: gradient averaging of the ray-data-parallel global
-stage, max-reduction of octree statistics, one-block-per-rank ownership and the checkpoint gather."""
+"""World-size-2 gloo tests (CPU) of the multi-GPU path: the exchanges HotPath.train_step drives through
+gfnerf_amd.dist.TrainSync (MAX-reduce of the octree statistics between K5 and K6, the direct all-reduce of the table
+gradient started inside the backward, the late decoder / embedding gradients), one-block-per-rank ownership, block-owner
+frame routing and the checkpoint gather.  The ranks run the product's host code on CPU tensors; the one device kernel of
+that path (gfn_reduce_shards, the local shard sum) is replaced by an injected torch restatement, which the GPU test
+`test_reduce_shards_matches_torch` holds equal to the kernel."""
 import os
 import socket
 import sys
+import types
 
 import numpy as np
 import pytest
@@ -21,12 +26,21 @@ def _free_port():
     return p
 
 
+def torch_shard_mean(recv, n_shards, out):
+    """What gfn_reduce_shards computes: f32 sum of the copies in rank order, x 1/n, rounded once to the buffer's type."""
+    acc = torch.zeros(out.numel(), dtype=torch.float32)
+    for s in range(n_shards):
+        acc += recv.view(n_shards, -1)[s].float()
+    out.copy_((acc * (1.0 / n_shards)).to(out.dtype))
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     import gfnerf_amd  # noqa: F401
     from gfnerf_amd import dist as gd
+    from gfnerf_amd import hotpath
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,15 +53,48 @@ def _worker(rank, world, port, q):
         blocks = gd.my_blocks(5)
         tables = {b: torch.full((4, 2), float(b)) for b in blocks}
         gathered = gd.gather_block_tables(tables, 5, dst=0)
+        # dst owns no block (n_blocks < world): the receive buffer comes from `shape`, not from a local table
+        lone = gd.gather_block_tables({0: torch.full((4, 2), 7.0)} if rank == 0 else {}, 1, dst=1, shape=(4, 2))
         shared = [torch.full((3,), float(rank))]
         gd.broadcast_from(shared, src=0)
-        q.put((rank, [m.numpy() for m in mine], [t.numpy() for t in grads], stats[0].numpy(), blocks,
-               None if gathered is None else {b: t.numpy() for b, t in gathered.items()}, shared[0].numpy()))
+
+        # ---- the HotPath-level hooks, on fake tensors
+        sync = gd.TrainSync(direct=True, shard_mean=torch_shard_mean)
+        n_nodes = 37
+        scratch = torch.randint(-1, 600, (3 * n_nodes,), generator=g, dtype=torch.int64)
+        visit = torch.randint(0, 50, (n_nodes,), generator=g, dtype=torch.int64)
+        oct_mine = (scratch.clone(), visit.clone())
+        sync.reduce_octree_stats([scratch, visit])  # what ops.update_nodes calls between K5 and K6
+        n_tab = 17 * (1 << 16)  # the live part of a T = 2^16 table: a multiple of 8 * world, above DIRECT_MIN_ELEMS
+        table_grad = (torch.randn(n_tab, generator=g) * 40).half()
+        table_grad[5] = 60000.0 if rank == 0 else 50000.0  # a plain f16 SUM of these overflows to inf
+        mlp_grad, emb_grad = torch.randn(31251, generator=g), torch.randn(40, 32, generator=g)
+        g_mine = (table_grad.clone(), mlp_grad.clone(), emb_grad.clone())
+        fake = types.SimpleNamespace(sync=sync, grads=lambda stage: [table_grad, mlp_grad, emb_grad])
+        # 1) the fused backward started the table exchange itself (ctx flag), sync_grads sends the late ones and waits
+        sync.start_grads([table_grad])
+        hotpath.HotPath.sync_grads(fake, hotpath.STAGE_GLOBAL, {"table_exchange_started": True})
+        first = (table_grad.clone(), mlp_grad.clone(), emb_grad.clone())
+        # 2) nothing started yet (unfused paths): sync_grads does everything; the focal stage exchanges nothing
+        t2, m2, e2 = g_mine[0].clone(), g_mine[1].clone(), g_mine[2].clone()
+        fake2 = types.SimpleNamespace(sync=sync, grads=lambda stage: [t2, m2, e2])
+        hotpath.HotPath.sync_grads(fake2, hotpath.STAGE_GLOBAL, {})
+        t3 = g_mine[0].clone()
+        hotpath.HotPath.sync_grads(types.SimpleNamespace(sync=sync, grads=lambda stage: [t3]), hotpath.STAGE_FOCAL, {})
+        same = sync.replicas_identical([table_grad, mlp_grad])
+        differ = sync.replicas_identical([torch.full((9,), float(rank))])
+        q.put(dict(rank=rank, mine=[m.numpy() for m in mine], avg=[t.numpy() for t in grads], stats=stats[0].numpy(), blocks=blocks,
+                   gathered=None if gathered is None else {b: t.numpy() for b, t in gathered.items()},
+                   lone=None if lone is None else {b: t.numpy() for b, t in lone.items()}, shared=shared[0].numpy(),
+                   oct_mine=[t.numpy() for t in oct_mine], oct=[scratch.numpy(), visit.numpy()],
+                   g_mine=[t.float().numpy() for t in g_mine], first=[t.float().numpy() for t in first],
+                   second=[t.float().numpy() for t in (t2, m2, e2)], focal_untouched=bool(torch.equal(t3, g_mine[0])),
+                   same=same, differ=differ, ranks_seen=sync.ranks_seen(), stats_sync=dict(sync.stats)))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_collectives():
+def test_two_rank_collectives_and_hotpath_hooks():
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -55,20 +102,38 @@ def test_two_rank_collectives():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x["rank"])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, mine0, avg0, st0, b0, g0, sh0), (r1, mine1, avg1, st1, b1, g1, sh1) = res
-    for a0, a1, m0, m1 in zip(avg0, avg1, mine0, mine1):
+    r0, r1 = res
+    for a0, a1, m0, m1 in zip(r0["avg"], r1["avg"], r0["mine"], r1["mine"]):
         np.testing.assert_allclose(a0, (m0 + m1) / 2, rtol=1e-6)
         assert np.array_equal(a0, a1)  # replicas stay bit-identical
-    assert st0.tolist() == [1000, -3, 513, 7] and st1.tolist() == st0.tolist()
-    assert b0 == [0, 2, 4] and b1 == [1, 3]
-    assert g1 is None and sorted(g0) == [0, 1, 2, 3, 4]
-    for b, t in g0.items():
+    assert r0["stats"].tolist() == [1000, -3, 513, 7] and r1["stats"].tolist() == r0["stats"].tolist()
+    assert r0["blocks"] == [0, 2, 4] and r1["blocks"] == [1, 3]
+    assert r1["gathered"] is None and sorted(r0["gathered"]) == [0, 1, 2, 3, 4]
+    for b, t in r0["gathered"].items():
         assert np.all(t == b)
-    assert np.all(sh0 == 0) and np.all(sh1 == 0)
+    assert r0["lone"] is None and list(r1["lone"]) == [0] and np.all(r1["lone"][0] == 7.0)
+    assert np.all(r0["shared"] == 0) and np.all(r1["shared"] == 0)
+    # octree statistics: elementwise maximum of the two ranks' K5 results, identical on both
+    for k in range(2):
+        want = np.maximum(r0["oct_mine"][k], r1["oct_mine"][k])
+        assert np.array_equal(r0["oct"][k], want) and np.array_equal(r1["oct"][k], want)
+    # gradients: the mean of the two ranks' (f32 sum, one rounding), no overflow, identical bits on both ranks, both call orders
+    for key in ("first", "second"):
+        for k in range(3):
+            want = (r0["g_mine"][k] + r1["g_mine"][k]) / 2
+            if k == 0:
+                want = want.astype(np.float16).astype(np.float32)
+            np.testing.assert_allclose(r0[key][k], want, rtol=2e-6 if k else 0, atol=0)
+            assert np.array_equal(r0[key][k], r1[key][k])
+        assert np.isfinite(r0[key][0]).all() and r0[key][0][5] == np.float32(np.float16(54976.0))  # (59968 + 49984) / 2
+    assert r0["focal_untouched"] and r1["focal_untouched"]
+    assert r0["same"] and r1["same"] and not r0["differ"] and not r1["differ"]
+    assert r0["ranks_seen"] == 2 and r1["ranks_seen"] == 2
+    assert r0["stats_sync"]["octree_max_reduces"] == 1 and r0["stats_sync"]["direct_reduces"] == 2
 
 
 def test_single_process_is_identity():
@@ -79,3 +144,34 @@ def test_single_process_is_identity():
     t = [torch.ones(3)]
     assert gd.allreduce_mean(t)[0].tolist() == [1, 1, 1]
     assert gd.my_blocks(3) == [0, 1, 2] and gd.world() == 1 and gd.rank() == 0
+    sync = gd.TrainSync()
+    assert sync.world == 1 and sync.ranks_seen() == 1 and sync.replicas_identical(t)
+    sync.start_grads(t); sync.finish_grads(t)
+    assert sync.reduce_octree_stats(t)[0].tolist() == [1, 1, 1]
+
+
+def test_frame_routing_follows_block_ownership():
+    sys.path.insert(0, ROOT)
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import cluster, dist as gd
+
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-40, 40, (203, 3))
+    for k in (2, 4, 8):
+        labels = cluster.equal_size_clusters(pos, k)
+        sizes = np.bincount(labels, minlength=k)
+        assert sorted(sizes.tolist(), reverse=True) == cluster.cluster_sizes(203, k)  # equal up to one, none empty
+        assert np.array_equal(labels, cluster.equal_size_clusters(pos, k))           # deterministic
+        # compact: a camera is on average closer to its own cluster's centre than to the other centres
+        cen = np.stack([pos[labels == j].mean(0) for j in range(k)])
+        d = np.linalg.norm(pos[:, None] - cen[None], axis=-1)
+        assert (d.argmin(1) == labels).mean() > 0.8
+        # rank r's cameras are all in cluster r; a frame goes to the rank owning the block of its camera
+        for r in range(k):
+            cams = cluster.cameras_of(labels, gd.my_blocks(k, k, r)[0])
+            assert np.all(labels[cams] == r) and cams.size == sizes[r]
+        path = rng.integers(0, 203, 25)
+        owners = gd.frame_owner(labels[path], k)
+        assert owners == [int(labels[c]) % k for c in path]
+        shards = [gd.frame_shard_by_block(labels[path], k, r) for r in range(k)]
+        assert sorted(f for s in shards for f in s) == list(range(25))

@@ -1,0 +1,102 @@
+"""The multi-GPU product path on the one card a test box has: two ranks share cuda:0 over gloo (RCCL refuses two ranks
+on one device; the collectives' meaning is the backend's contract, their use is what these tests hold).
+  * test_two_rank_global_stage_replicas_stay_identical: HotPath.train_step under two ranks (tests/dp_worker.py);
+  * test_bench_self_spawns_two_ranks: `python bench.py --gpus 2` started as the driver starts it, from a process that has
+    no torchrun environment;
+  * test_reduce_shards_matches_torch: the local shard sum of the direct all-reduce against torch.
+Child processes are started with subprocess (never exec'd over this process) and ended by their exact pids."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, has_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(argv_of_rank, n, timeout):
+    procs = [subprocess.Popen(argv_of_rank(r), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out)
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        raise
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+@pytest.mark.parametrize("mode", ["allreduce", "direct"])
+def test_two_rank_global_stage_replicas_stay_identical(tmp_path, mode):
+    port, out = str(_free_port()), str(tmp_path / "dp.json")
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    codes, outs = _run_ranks(lambda r: [sys.executable, worker, str(r), "2", port, out, mode], 2, timeout=420)
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    assert codes == [0, 0] and res.get("ok"), (codes, res.get("error"), outs)
+    assert res["ranks_seen"] == 2
+    # the exchanged gradients are the mean of the ranks' local gradients (f16 pool: one rounding of the f32 mean, or f16 adds)
+    assert res["table_grad_nonzero"] > 1000
+    assert res["grad_rel_err"][0] < 2e-3 and all(e < 1e-5 for e in res["grad_rel_err"][1:]), res["grad_rel_err"]
+    # K5 MAX-reduced before K6: the tree ONE process would have computed from both ranks' rays, bit for bit
+    assert res["union_tree_equal"] and res["visited_nodes"] > 10
+    # and after three steps every replica holds the same bits
+    assert res["replicas_identical"] and res["drift_detected"]
+    assert res["sync_stats"]["octree_max_reduces"] == 3 and res["sync_stats"]["grad_reduces"] >= 6
+    if mode == "direct":
+        assert res["sync_stats"]["direct_reduces"] == 3
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_bench_self_spawns_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--n-side", "6", "--log2-T", "16", "--steps", "3",
+           "--warmup", "0", "--global-steps", "3", "--global-warmup", "0", "--render-frames", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "1 block per GPU" in d["config"]["workload"] and "no data-path collective" in d["config"]["parallelism"]
+    g = d["global_stage"]
+    assert "error" not in g, g
+    assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and g["sync"]["grad_reduces"] >= 3
+    assert d["render"]["frames"] == 2 and "routed" in d["render"]["routing"]
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_reduce_shards_matches_torch(dtype):
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n_shards, shard in ((2, 8), (8, 8 * 1000 + 8), (3, 4096)):
+        recv = (torch.randn(n_shards * shard, device="cuda", generator=g) * 100).to(dtype)
+        if dtype == torch.float16:
+            recv[:n_shards * shard:shard] = 60000.0  # element 0 of every copy: the f32 sum must not overflow before the scale
+        out = torch.empty(shard, dtype=dtype, device="cuda")
+        ops.reduce_shards(recv, n_shards, out, scale=1.0 / n_shards)
+        acc = torch.zeros(shard, dtype=torch.float32, device="cuda")
+        for s in range(n_shards):
+            acc += recv.view(n_shards, shard)[s].float()
+        want = (acc * (1.0 / n_shards)).to(dtype)
+        assert torch.equal(out, want)
+        assert torch.isfinite(out).all()

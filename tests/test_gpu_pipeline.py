@@ -161,7 +161,11 @@ def test_training_gradients_match_oracle(setup, stage):
                 np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=1e-4 * np.abs(want).max() + 1e-9)
         np.testing.assert_allclose(hp.emb_grad.cpu().numpy(), g["emb"], rtol=1e-3, atol=1e-4 * np.abs(g["emb"]).max())
     else:
-        assert hp.mlp_grad.abs().max().item() == 0 or True  # MLP grads are not produced in the focal stage
+        # the focal stage freezes decoder and embedding (nerfacto_field.py:460-461,528,549): its backward writes neither gradient
+        hp.mlp_grad.fill_(7.0); hp.emb_grad.fill_(7.0)
+        hp.forward_backward(t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"]), stage="focal", block=0, s3im_index=None)
+        assert hp.mlp_grad.min().item() == 7.0 and hp.mlp_grad.max().item() == 7.0
+        assert hp.emb_grad.min().item() == 7.0 and hp.emb_grad.max().item() == 7.0
 
 
 def test_training_f16_gradient_pool(setup):
@@ -494,6 +498,50 @@ def test_global_stage_prefetch_keeps_the_reference_order(setup):
     # a handful of nodes agree exactly
     assert (w0 != w1).float().mean() < 0.01 and (a0 != a1).float().mean() < 0.01
     assert torch.equal(s0["pts_offsets"], s1["pts_offsets"])
+
+
+def test_tree_change_drops_prefetched_samples(setup):
+    """A prefetched sampler (and the last step's context) marched through the OLD tree: ProcOctree / MarkInvisibleNodes
+    renumber or shrink the node blob, so the next step must sample again instead of collecting them, and UpdateOctNodes must
+    never be fed node indices of a tree that no longer exists (mark_visit_kernel also skips indices >= n_nodes)."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(o.shape[0], 10, device="cuda")
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14), seed=1)
+    hp.table.mul_(100.0); hp.refresh_shadows()
+    for _ in range(3):
+        hp.train_step(o, d, cam, gt, noise, stage="global", s3im_index=s3, update_oct=True, prefetch=(o, d, noise))
+    assert hp._pre is not None and hp._last_train_ctx is not None
+    n_before = hp.n_nodes
+    # invalidate every leaf the statistics have not confirmed, then compact: the tree shrinks and is renumbered
+    hp.weight_stats.fill_(-5); hp.alpha_stats.fill_(-5)
+    keep = hp.visit_cnt > 0
+    hp.weight_stats[keep] = 1000; hp.alpha_stats[keep] = 1000
+    ops.update_nodes(hp._last_train_ctx["samples"]["pts_offsets"], hp._last_train_ctx["samples"]["anchors"], hp._last_train_ctx["comp"]["weights"],
+                     hp._last_train_ctx["comp"]["alphas"], hp.weight_stats, hp.alpha_stats, hp.visit_cnt, hp.nodes)
+    hp.proc_octree(compact=True)
+    assert hp.n_nodes < n_before and hp._pre is None and hp._last_train_ctx is None
+    fresh = hp.sample(o, d, noise)
+    torch.cuda.synchronize()
+    assert int(fresh["anchors"][: int(fresh["pts_offsets"][-1]), 1].max()) < hp.n_nodes  # node indices of the NEW tree
+    loss, aux = hp.train_step(o, d, cam, gt, noise, stage="global", s3im_index=s3, update_oct=True, prefetch=(o, d, noise))
+    torch.cuda.synchronize()
+    assert torch.equal(aux["samples"]["pts_offsets"], fresh["pts_offsets"]) and bool(torch.isfinite(loss).all())
+    assert hp.weight_stats.numel() == hp.n_nodes and int(hp.visit_cnt.max()) > 0
+    # stale indices handed to K5 anyway are skipped, not written past the arrays
+    stale = aux["samples"]["anchors"].clone()
+    stale[:, 1] += hp.n_nodes
+    guard = torch.full((3 * hp.n_nodes + 64,), -7, dtype=torch.int64, device="cuda")
+    w, a, v = guard[: hp.n_nodes], guard[hp.n_nodes: 2 * hp.n_nodes], guard[2 * hp.n_nodes: 3 * hp.n_nodes]
+    w.fill_(1000); a.fill_(1000); v.fill_(0)
+    ops.update_nodes(aux["samples"]["pts_offsets"], stale, aux["comp"]["weights"], aux["comp"]["alphas"], w, a, v, hp.nodes.clone())
+    torch.cuda.synchronize()
+    assert int(v.max()) == 0 and bool((guard[3 * hp.n_nodes:] == -7).all())
 
 
 def test_optimizer_groups_follow_the_reference(setup):
