@@ -79,6 +79,11 @@ SIGNATURES = {
     "gfn_octree_build_host": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _u64, _i32, C.POINTER(_vp),
                                      C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),
     "gfn_free_host": (None, [_vp]),
+    "gfn_octree_distance_summary_host": (_f32, [_vp, _i64]),
+    "gfn_octree_pca12_host": (_i32, [_vp, _i64, _vp, _vp]),
+    "gfn_octree_visible_cams_host": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp]),
+    "gfn_octree_construct_trans_host": (_i32, [_vp, _vp, _i64, _vp, _f32, _i64, _vp, _i64, _u64, _vp, _vp]),
+    "gfn_octree_fit_weight_host": (_i32, [_vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -225,8 +225,66 @@ struct Builder {
     for (int i = 0; i < n; i++) evals[i] = A[i][i];
   }
 
+  // PCA (PersSampler.cpp:593-611): eigen-decomposition of the 12x12 covariance of the projected values, eigenvalues in
+  // descending order, V[:, k] the k-th eigenvector (f32 like the reference's .to(kFloat32))
+  static void pca12(const float* tv, int n_pts, double evals_sorted[12], float V[12][12]) {
+    double mean[GFN_N_PROS] = {0};
+    for (int p = 0; p < n_pts; p++)
+      for (int i = 0; i < GFN_N_PROS; i++) mean[i] += tv[(size_t)p * GFN_N_PROS + i];
+    for (int i = 0; i < GFN_N_PROS; i++) mean[i] /= n_pts;
+    double cov[12][12] = {{0}};
+    for (int p = 0; p < n_pts; p++) {
+      double m[GFN_N_PROS];
+      for (int i = 0; i < GFN_N_PROS; i++) m[i] = tv[(size_t)p * GFN_N_PROS + i] - mean[i];
+      for (int i = 0; i < GFN_N_PROS; i++)
+        for (int j = i; j < GFN_N_PROS; j++) cov[i][j] += m[i] * m[j];
+    }
+    for (int i = 0; i < GFN_N_PROS; i++)
+      for (int j = i; j < GFN_N_PROS; j++) { cov[i][j] /= n_pts; cov[j][i] = cov[i][j]; }
+    double evals[12], evecs[12][12];
+    eigh12(cov, evals, evecs);
+    int order[12];
+    for (int i = 0; i < 12; i++) order[i] = i;
+    std::sort(order, order + 12, [&](int a, int b) { return evals[a] > evals[b]; });
+    for (int k = 0; k < 12; k++) {
+      evals_sorted[k] = evals[order[k]];
+      for (int i = 0; i < 12; i++) V[i][k] = (float)evecs[i][order[k]];
+    }
+  }
+
   // PersSampler.cpp:613-831
-  bool construct_trans(const std::vector<int64_t>& visi, Vec3 center, float side, gfn_trans_info* out) {
+  // first: the camera (index into visi) the farthest-point selection starts from, -1 = drawn (torch::randint in the reference,
+  // :641); pts_in: probe points [n_pts_in,3], NULL = 32^3 drawn uniformly in the node (torch::rand, :540); good_out: the six
+  // selected cameras (indices into visi)
+  bool construct_trans(const std::vector<int64_t>& visi, Vec3 center, float side, gfn_trans_info* out, int64_t first = -1,
+                       const float* pts_in = nullptr, int n_pts_in = 0, int64_t* good_out = nullptr) {
+    float frame[GFN_N_PROS][2][4];
+    float dis_summary;
+    if (!select_frames(visi, center, first, frame, &dis_summary, good_out)) return false;
+    std::vector<float> own;
+    int n_pts = n_pts_in;
+    if (!pts_in) {  // probe points in the node (:539-540)
+      n_pts = 32 * 32 * 32;
+      own.resize((size_t)n_pts * 3);
+      for (int i = 0; i < n_pts * 3; i += 3) {
+        own[i] = (rng.uniform() - .5f) * side + center.x;
+        own[i + 1] = (rng.uniform() - .5f) * side + center.y;
+        own[i + 2] = (rng.uniform() - .5f) * side + center.z;
+      }
+      pts_in = own.data();
+    }
+    memset(out, 0, sizeof(*out));
+    if (!fit_weight(frame, pts_in, n_pts, out->weight)) return false;
+    memcpy(out->w2xz, frame, sizeof(frame));
+    out->center[0] = center.x; out->center[1] = center.y; out->center[2] = center.z;
+    out->side_len = side;
+    out->dis_summary = dis_summary;
+    return true;
+  }
+
+  // first and second step of ConstructTrans (:619-768): align distances, pick six cameras, re-aim them at the node centre
+  bool select_frames(const std::vector<int64_t>& visi, Vec3 center, int64_t first, float frame[GFN_N_PROS][2][4],
+                     float* dis_summary_out, int64_t* good_out) {
     const int n_virt = GFN_N_PROS / 2;
     const int64_t n_cur = (int64_t)visi.size();
     std::vector<Vec3> cpos(n_cur);
@@ -241,7 +299,7 @@ struct Builder {
     // farthest-point selection of 6 cameras (:638-673)
     std::vector<int64_t> good;
     std::vector<uint8_t> mark(n_cur, 0);
-    good.push_back(rng.randint(n_cur));
+    good.push_back(first >= 0 && first < n_cur ? first : rng.randint(n_cur));
     mark[good[0]] = 1;
     std::vector<float> mind(n_cur, 1e8f);
     for (int cnt = 1; cnt < n_virt && cnt < n_cur; cnt++) {
@@ -258,8 +316,10 @@ struct Builder {
       good.push_back(candi);
     }
     for (size_t i = 0; good.size() < (size_t)n_virt; i++) good.push_back(good[i]);
+    if (good_out)
+      for (int g = 0; g < n_virt; g++) good_out[g] = good[g];
+    *dis_summary_out = dis_summary;
 
-    float frame[GFN_N_PROS][2][4];
     const float focal = intri[0] / intri[2];  // :755
     for (int g = 0; g < n_virt; g++) {
       const int64_t ci = good[g];
@@ -299,14 +359,12 @@ struct Builder {
       }
     }
 
-    // probe points in the node (:539-540) and their projections
-    const int n_pts = 32 * 32 * 32;
-    std::vector<float> pts((size_t)n_pts * 3);
-    for (int i = 0; i < n_pts * 3; i += 3) {
-      pts[i] = (rng.uniform() - .5f) * side + center.x;
-      pts[i + 1] = (rng.uniform() - .5f) * side + center.y;
-      pts[i + 2] = (rng.uniform() - .5f) * side + center.z;
-    }
+    return true;
+  }
+
+  // third step of ConstructTrans (:770-815): project the probe points through the 12 frames, PCA of the projected values,
+  // rows normalised by the mean expected step
+  bool fit_weight(const float frame[GFN_N_PROS][2][4], const float* pts, int n_pts, float weight[3][GFN_N_PROS]) {
     std::vector<float> tv((size_t)n_pts * GFN_N_PROS);          // transed value a/b
     std::vector<float> dvd((size_t)n_pts * GFN_N_PROS * 3);     // dv/dxyz
     bool bad = false;
@@ -326,27 +384,12 @@ struct Builder {
     if (bad) return false;
 
     // PCA (:593-611, :803-804)
-    double mean[GFN_N_PROS] = {0};
-    for (int p = 0; p < n_pts; p++)
-      for (int i = 0; i < GFN_N_PROS; i++) mean[i] += tv[(size_t)p * GFN_N_PROS + i];
-    for (int i = 0; i < GFN_N_PROS; i++) mean[i] /= n_pts;
-    double cov[12][12] = {{0}};
-    for (int p = 0; p < n_pts; p++) {
-      double m[GFN_N_PROS];
-      for (int i = 0; i < GFN_N_PROS; i++) m[i] = tv[(size_t)p * GFN_N_PROS + i] - mean[i];
-      for (int i = 0; i < GFN_N_PROS; i++)
-        for (int j = i; j < GFN_N_PROS; j++) cov[i][j] += m[i] * m[j];
-    }
-    for (int i = 0; i < GFN_N_PROS; i++)
-      for (int j = i; j < GFN_N_PROS; j++) { cov[i][j] /= n_pts; cov[j][i] = cov[i][j]; }
-    double evals[12], evecs[12][12];
-    eigh12(cov, evals, evecs);
-    int order[12];
-    for (int i = 0; i < 12; i++) order[i] = i;
-    std::sort(order, order + 12, [&](int a, int b) { return evals[a] > evals[b]; });
+    double evals[12];
+    float Vall[12][12];
+    pca12(tv.data(), n_pts, evals, Vall);
     float V[3][GFN_N_PROS];
     for (int r = 0; r < 3; r++)
-      for (int i = 0; i < GFN_N_PROS; i++) V[r][i] = (float)evecs[i][order[r]];
+      for (int i = 0; i < GFN_N_PROS; i++) V[r][i] = Vall[i][r];
 
     // step normalisation (:807-815)
     double mean_step[3] = {0, 0, 0};
@@ -382,19 +425,14 @@ struct Builder {
       }
     }
     if (singular) return false;
-    memset(out, 0, sizeof(*out));
     for (int r = 0; r < 3; r++) {
       const float ms = (float)(mean_step[r] / n_pts);
       for (int i = 0; i < GFN_N_PROS; i++) {
         const float v = V[r][i] / ms;
         if (!std::isfinite(v)) return false;
-        out->weight[r][i] = v;
+        weight[r][i] = v;
       }
     }
-    memcpy(out->w2xz, frame, sizeof(frame));
-    out->center[0] = center.x; out->center[1] = center.y; out->center[2] = center.z;
-    out->side_len = side;
-    out->dis_summary = dis_summary;
     return true;
   }
 
@@ -486,6 +524,93 @@ int gfn_octree_build_host(const float* c2w_host, const float* intri_host, const 
   if (!b.trans.empty()) memcpy(tp, b.trans.data(), b.trans.size() * sizeof(gfn_trans_info));
   *nodes_out_host = np; *n_nodes_out = (int64_t)b.nodes.size();
   *trans_out_host = tp; *n_trans_out = (int64_t)b.trans.size();
+  return GFN_OK;
+}
+
+/* ---- pieces of the build, exposed so that tests can hold them against the reference's own Python statement of them
+ * (gfnerf/persoctree.py: distance_summary :234-246, PCA :183-194, get_visi_cams :248-290, construct_trans :86-181) ---- */
+
+float gfn_octree_distance_summary_host(const float* dis, int64_t n) {
+  return distance_summary(std::vector<float>(dis, dis + (n > 0 ? n : 0)));
+}
+
+int gfn_octree_pca12_host(const float* vals, int64_t n_pts, float* evals_out, float* evecs_out) {
+  if (!vals || !evals_out || !evecs_out || n_pts <= 0 || n_pts > (1 << 24)) {
+    gfn_set_error("gfn_octree_pca12_host: bad arguments");
+    return GFN_ERR_ARG;
+  }
+  double ev[12];
+  float V[12][12];
+  Builder::pca12(vals, (int)n_pts, ev, V);
+  for (int i = 0; i < 12; i++) evals_out[i] = (float)ev[i];
+  memcpy(evecs_out, V, sizeof(V));
+  return GFN_OK;
+}
+
+static int make_builder(Builder& b, const float* c2w, const float* intri, const float* bounds, int64_t n_cams, const char* who) {
+  if (!c2w || !intri || !bounds || n_cams <= 0) {
+    gfn_set_error("%s: bad arguments", who);
+    return GFN_ERR_ARG;
+  }
+  b.n_cams = n_cams; b.c2w = c2w; b.intri = intri; b.bounds = bounds;
+  b.max_depth = 0; b.split_dist_thres = 1.5f; b.threads = 1;
+  b.init();
+  if (b.failed) {
+    gfn_set_error("%s: singular camera rotation", who);
+    return GFN_ERR_ARG;
+  }
+  return GFN_OK;
+}
+
+int gfn_octree_visible_cams_host(const float* c2w, const float* intri, const float* bounds, int64_t n_cams, const float* center,
+                                 float side, uint8_t* visible_out) {
+  Builder b(0);
+  if (!center || !visible_out) {
+    gfn_set_error("gfn_octree_visible_cams_host: bad arguments");
+    return GFN_ERR_ARG;
+  }
+  const int rc = make_builder(b, c2w, intri, bounds, n_cams, "gfn_octree_visible_cams_host");
+  if (rc != GFN_OK) return rc;
+  for (int64_t c = 0; c < n_cams; c++) visible_out[c] = b.cam_sees(c, {center[0], center[1], center[2]}, side) ? 1 : 0;
+  return GFN_OK;
+}
+
+int gfn_octree_construct_trans_host(const float* c2w_visible, const float* intri, int64_t n_visible, const float* center, float side,
+                                    int64_t first_cam, const float* pts, int64_t n_pts, uint64_t seed, void* trans_out,
+                                    int64_t* good_cams_out) {
+  Builder b(seed);
+  if (!center || !trans_out || (pts && n_pts <= 0) || n_pts > (1 << 24)) {
+    gfn_set_error("gfn_octree_construct_trans_host: bad arguments");
+    return GFN_ERR_ARG;
+  }
+  std::vector<float> bounds((size_t)std::max<int64_t>(n_visible, 1) * 2, 0.f);
+  const int rc = make_builder(b, c2w_visible, intri, bounds.data(), n_visible, "gfn_octree_construct_trans_host");
+  if (rc != GFN_OK) return rc;
+  std::vector<int64_t> visi((size_t)n_visible);
+  for (int64_t i = 0; i < n_visible; i++) visi[i] = i;
+  if (!b.construct_trans(visi, {center[0], center[1], center[2]}, side, reinterpret_cast<gfn_trans_info*>(trans_out), first_cam, pts,
+                         (int)n_pts, good_cams_out)) {
+    gfn_set_error("gfn_octree_construct_trans_host: degenerate frames (a probe point behind a virtual camera, or a singular Jacobian)");
+    return GFN_ERR_ARG;
+  }
+  return GFN_OK;
+}
+
+int gfn_octree_fit_weight_host(const float* w2xz, const float* pts, int64_t n_pts, float* weight_out) {
+  if (!w2xz || !pts || !weight_out || n_pts <= 0 || n_pts > (1 << 24)) {
+    gfn_set_error("gfn_octree_fit_weight_host: bad arguments");
+    return GFN_ERR_ARG;
+  }
+  Builder b(0);
+  b.threads = 1;
+  float frame[GFN_N_PROS][2][4];
+  memcpy(frame, w2xz, sizeof(frame));
+  float weight[3][GFN_N_PROS];
+  if (!b.fit_weight(frame, pts, (int)n_pts, weight)) {
+    gfn_set_error("gfn_octree_fit_weight_host: degenerate frames");
+    return GFN_ERR_ARG;
+  }
+  memcpy(weight_out, weight, sizeof(weight));
   return GFN_OK;
 }
 

@@ -1032,3 +1032,54 @@ def octree_build(c2w, intri, bounds, max_depth=16, bbox_side_len=512.0, split_di
         L.gfn_free_host(np_)
         L.gfn_free_host(tp_)
     return nodes, transes[: nt.value * TRANS_INFO_BYTES] if nt.value else transes[:0]
+
+
+# ---- pieces of the host octree build (numpy in, numpy out), see include/gfnerf_amd.h
+def _np32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def octree_distance_summary(dis):
+    d = _np32(dis).reshape(-1)
+    return float(_lib.lib().gfn_octree_distance_summary_host(_vp(d), d.size))
+
+
+def octree_pca12(vals):
+    """vals [n,12] -> (evals f32 [12] descending, evecs f32 [12,12], column k = k-th eigenvector)."""
+    v = _np32(vals)
+    if v.ndim != 2 or v.shape[1] != 12:
+        raise _lib.GfnError("octree_pca12: vals must be [n, 12]")
+    L, V = np.zeros(12, np.float32), np.zeros((12, 12), np.float32)
+    _lib.check(_lib.lib().gfn_octree_pca12_host(_vp(v), v.shape[0], _vp(L), _vp(V)), "gfn_octree_pca12_host")
+    return L, V
+
+
+def octree_visible_cams(c2w, intri, bounds, center, side):
+    c2w, intri, bounds, center = _np32(c2w), _np32(intri), _np32(bounds), _np32(center).reshape(3)
+    out = np.zeros(c2w.shape[0], np.uint8)
+    _lib.check(_lib.lib().gfn_octree_visible_cams_host(_vp(c2w), _vp(intri), _vp(bounds), c2w.shape[0], _vp(center), float(side), _vp(out)),
+               "gfn_octree_visible_cams_host")
+    return out.astype(bool)
+
+
+def octree_construct_trans(c2w_visible, intri, center, side, first_cam=-1, pts=None, seed=0):
+    """-> (trans_info blob u8 [576], good camera indices i64 [6])."""
+    c2w, intri, center = _np32(c2w_visible), _np32(intri).reshape(-1), _np32(center).reshape(3)
+    p = None if pts is None else _np32(pts)
+    out = np.zeros(TRANS_INFO_BYTES, np.uint8)
+    good = np.zeros(6, np.int64)
+    rc = _lib.lib().gfn_octree_construct_trans_host(_vp(c2w), _vp(intri), c2w.shape[0], _vp(center), float(side), int(first_cam),
+                                                   None if p is None else _vp(p), 0 if p is None else p.shape[0], int(seed), _vp(out), _vp(good))
+    _lib.check(rc, "gfn_octree_construct_trans_host")
+    return out, good
+
+
+def octree_fit_weight(w2xz, pts):
+    w, p = _np32(w2xz).reshape(12, 2, 4), _np32(pts)
+    out = np.zeros((3, 12), np.float32)
+    _lib.check(_lib.lib().gfn_octree_fit_weight_host(_vp(w), _vp(p), p.shape[0], _vp(out)), "gfn_octree_fit_weight_host")
+    return out

@@ -518,6 +518,29 @@ int gfn_octree_build_host(const float* c2w_host /*[n_cams,3,4]*/, const float* i
                           int64_t* n_trans_out);
 void gfn_free_host(void* p);
 
+/* The pieces gfn_octree_build_host is made of, each with the reference function it replaces; tests hold them against
+ * vectors captured from the reference's own PyTorch statement of the same functions (gfnerf/persoctree.py).  Host only.
+ *   distance_summary  DistanceSummary (PersSampler.cpp:12-26; persoctree.py:234-246): exp of the mean log distance below
+ *                     the 25 % quantile (linear interpolation), 1e8 for an empty set.
+ *   pca12             PCA (PersSampler.cpp:593-611; persoctree.py:183-194) of vals [n_pts,12]: evals f32 [12] descending,
+ *                     evecs f32 [12,12] row-major with column k the k-th eigenvector.
+ *   visible_cams      GetVisiCams (PersSampler.cpp:45-88): visible_out[c] = 1 iff one of camera c's 128 x res_h pixel rays
+ *                     crosses the box (center, side) inside the camera's [near, far] (persoctree.py:248-290 samples every
+ *                     100th pixel instead, so only cameras away from the visibility border must agree).
+ *   construct_trans   PersOctree::ConstructTrans (PersSampler.cpp:613-831) for the cameras c2w_visible [n,3,4] (intri f32
+ *                     [9] of camera 0, :755): first_cam >= 0 injects the farthest-point selection's random first pick
+ *                     (:641), pts [n_pts,3] the probe points (:540; NULL: 32^3 drawn from `seed`); trans_out receives one
+ *                     gfn_trans_info, good_cams_out (may be NULL) the six selected camera indices.
+ *   fit_weight        its third step alone (:770-815) for given frames w2xz f32 [12,2,4]: weight_out f32 [3,12]. */
+float gfn_octree_distance_summary_host(const float* dis, int64_t n);
+int gfn_octree_pca12_host(const float* vals, int64_t n_pts, float* evals_out, float* evecs_out);
+int gfn_octree_visible_cams_host(const float* c2w, const float* intri, const float* bounds, int64_t n_cams, const float* center,
+                                 float side, uint8_t* visible_out);
+int gfn_octree_construct_trans_host(const float* c2w_visible, const float* intri, int64_t n_visible, const float* center, float side,
+                                    int64_t first_cam, const float* pts, int64_t n_pts, uint64_t seed, void* trans_out,
+                                    int64_t* good_cams_out);
+int gfn_octree_fit_weight_host(const float* w2xz, const float* pts, int64_t n_pts, float* weight_out);
+
 #ifdef __cplusplus
 }
 #endif

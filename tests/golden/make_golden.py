@@ -363,6 +363,137 @@ def gen_torch_field(out):
     out["torchfield_depth"] = DepthRenderer(method="expected")(weights=w, ray_samples=rs).detach().numpy()
 
 
+def _aerial_cameras(n_side, seed, extent=40.0, height=12.0):
+    """A small serpentine aerial capture (the same kind of scene bench.py uses): c2w [n,3,4] f32, OpenGL convention."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-extent, extent, n_side)
+    c2w = []
+    for iy, y in enumerate(xs):
+        for x in (xs if iy % 2 == 0 else xs[::-1]):
+            pos = np.array([x, y, height]) + rng.normal(0, 0.3, 3)
+            a, b, c = rng.uniform(0, 2 * np.pi), np.radians(rng.uniform(-15, 15)), np.radians(rng.uniform(-15, 15))
+            rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+            ry = np.array([[np.cos(c), 0, np.sin(c)], [0, 1, 0], [-np.sin(c), 0, np.cos(c)]])
+            c2w.append(np.concatenate([rz @ rx @ ry, pos[:, None]], axis=1))
+    return np.asarray(c2w, np.float32)
+
+
+def gen_persoctree(out):
+    """a3 warp + f1 octree build, pinned from the reference's pure-PyTorch prototype gfnerf/persoctree.py ("useful as a
+    readable restatement of ConstructTrans"): distance_summary (:234-246), PCA (:183-194), get_visi_cams (:248-290),
+    construct_trans (:86-181) on three camera sets with the random first pick re-drawn from the same seed, and -- captured from
+    INSIDE that call by wrapping self.PCA / torch.linalg.inv for its duration -- the projected values transed_pts [n,12] (:155),
+    PCA's (L, V) and the warp Jacobian jac = V . dv_dxyz [n,3,3] (:160-168) at the probe points; plus the warp of a 32^3 grid
+    exactly as vis_transed_pts computes and prints it (:334-371; its .obj output is parsed back).
+    The prototype re-aims the six virtual cameras with a look-at (utils.adjust_cameras_lookat, up = +z) where the C++ build
+    uses the minimal rotation (Eigen::AngleAxisf, PersSampler.cpp:718-746): the z rows / offsets of w2xz, dis_summary, the camera
+    selection, PCA and the step normalisation are common to both and are what the tests compare."""
+    import tempfile
+
+    from gfnerf import persoctree as po
+    from nerfstudio.cameras.cameras import Cameras
+
+    W, H, F = 1152, 864, 1000.0
+    oct_ = po.PersOctree.__new__(po.PersOctree)  # __init__ would build a whole tree and write .obj files into the cwd
+    oct_.device = torch.device("cpu")
+
+    # ---- distance_summary
+    g = torch.Generator().manual_seed(3)
+    dis_sets = [torch.rand(n, 1, generator=g) * 30 + 5 for n in (1, 2, 6, 7, 40, 200)] + [torch.full((9, 1), 12.5)]
+    out["po_ds_sizes"] = np.asarray([d.numel() for d in dis_sets], np.int64)
+    out["po_ds_dis"] = np.concatenate([d.view(-1).numpy() for d in dis_sets])
+    out["po_ds_summary"] = np.asarray([oct_.distance_summary(d) for d in dis_sets], np.float64)
+    out["po_ds_empty"] = np.asarray(oct_.distance_summary(torch.zeros(0, 1)), np.float64)
+
+    # ---- PCA on random [n,12] values
+    pts12 = torch.randn(4096, 12, generator=g) * torch.linspace(3.0, 0.2, 12)[None, :] + torch.randn(1, 12, generator=g)
+    pts12 = pts12 @ torch.linalg.qr(torch.randn(12, 12, generator=g))[0]
+    L, V = oct_.PCA(pts12)
+    out["po_pca_pts"] = pts12.numpy(); out["po_pca_L"] = L.numpy(); out["po_pca_V"] = V.numpy()
+
+    # ---- construct_trans on three camera sets
+    c2w_all = _aerial_cameras(7, seed=21)
+    n = c2w_all.shape[0]
+    cams_all = Cameras(fx=torch.full((n,), F), fy=torch.full((n,), F), cx=torch.full((n,), W / 2), cy=torch.full((n,), H / 2),
+                       camera_to_worlds=torch.from_numpy(c2w_all), width=W, height=H)
+    out["po_c2w"] = c2w_all
+    out["po_intr"] = np.asarray([F, F, W / 2, H / 2], np.float32)
+    cases = [(np.arange(n), (0.0, 0.0, 0.0), 16.0, 101), (np.asarray([0, 1, 2, 7, 8, 9, 14, 15, 16, 21, 22]), (-30.0, -28.0, 1.0), 8.0, 102),
+             (np.asarray([3, 10, 17, 24, 31, 38, 45]), (5.0, 2.0, -2.0), 4.0, 103)]
+    for ci, (idx, center, side, seed) in enumerate(cases):
+        visible = cams_all[torch.from_numpy(idx)]
+        cen = torch.tensor(center, dtype=torch.float32).view(3, 1)
+        gp = torch.Generator().manual_seed(seed)
+        rand_pts = (torch.rand((4096, 3), generator=gp) - 0.5) * side + cen.permute(1, 0)
+        cap = {}
+        orig_pca, orig_inv = oct_.PCA, torch.linalg.inv
+
+        def pca_spy(pts, _cap=cap, _orig=orig_pca):
+            _cap["transed"] = pts.clone()
+            Lr, Vr = _orig(pts)
+            _cap["L"], _cap["V"] = Lr.clone(), Vr.clone()
+            return Lr, Vr
+
+        def inv_spy(x, _cap=cap, _orig=orig_inv):
+            _cap.setdefault("inv_inputs", []).append(x.clone())
+            return _orig(x)
+
+        oct_.PCA = pca_spy
+        torch.linalg.inv = inv_spy
+        try:
+            torch.manual_seed(seed)
+            first = torch.randint(len(idx), (1,), dtype=torch.int32).item()  # the draw construct_trans is about to make (:107)
+            torch.manual_seed(seed)
+            ti = oct_.construct_trans(visible_cameras=visible, rand_pts=rand_pts, center=cen)
+        finally:
+            oct_.PCA = orig_pca
+            torch.linalg.inv = orig_inv
+        jac = cap["inv_inputs"][-1]  # the last inverse of the call is jac_warp2world = inv(V . dv_dxyz) (:169-170)
+        assert jac.shape == (4096, 3, 3)
+        out[f"po_ct{ci}_cams"] = idx.astype(np.int64); out[f"po_ct{ci}_center"] = np.asarray(center, np.float32)
+        out[f"po_ct{ci}_side"] = np.asarray(side, np.float32); out[f"po_ct{ci}_first"] = np.asarray(first, np.int64)
+        out[f"po_ct{ci}_pts"] = rand_pts.numpy()
+        out[f"po_ct{ci}_w2xz"] = ti.w2xz.numpy(); out[f"po_ct{ci}_weight"] = ti.weight.numpy()
+        out[f"po_ct{ci}_dis_summary"] = np.asarray(ti.dis_summary, np.float64)
+        out[f"po_ct{ci}_transed"] = cap["transed"].numpy(); out[f"po_ct{ci}_L"] = cap["L"].numpy(); out[f"po_ct{ci}_V"] = cap["V"].numpy()
+        out[f"po_ct{ci}_jac"] = jac.numpy()
+        # the warp of a 32^3 grid as vis_transed_pts evaluates it (:334-371): run it, read its .obj back
+        node = po.TreeNode(center=cen, side_len=side, pers_trans=ti)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "w.obj")
+            oct_.vis_transed_pts(node, path)
+            warped = np.asarray([[float(v) for v in ln.split()[1:]] for ln in open(path)], np.float64)
+        assert warped.shape == (32 ** 3, 3)
+        out[f"po_ct{ci}_grid_warped"] = warped[::7].astype(np.float32)  # every 7th point of the (deterministic) grid
+
+    # ---- get_visi_cams (:248-290) on five boxes.  It casts one ray per 100th pixel of the image, GetVisiCams of the C++ build a
+    # 128 x res_h grid (PersSampler.cpp:51-65): the two can only be compared as a sandwich.  `lower` = the prototype as it is
+    # (every camera it reports does see the box); `upper` = the prototype run on cameras whose image is extended by a margin and
+    # whose principal point is shifted in 25-pixel steps -- the union over the 16 shifts samples every 25th pixel of a slightly
+    # larger image, on the box grown by 5 %: a camera outside `upper` sees nothing of the box.
+    oct_.cameras = cams_all
+    bounds = torch.zeros((n, 2)); bounds[:, 0] = 0.01; bounds[:, 1] = 512.0
+    boxes = [((0.0, 0.0, 0.0), 64.0), ((-20.0, 10.0, -4.0), 16.0), ((30.0, -30.0, 2.0), 8.0), ((0.0, 0.0, -200.0), 32.0), ((3.0, 4.0, 40.0), 8.0)]
+    lower, upper = [], []
+    for center, side in boxes:
+        cen = torch.tensor(center, dtype=torch.float32).view(3, 1)
+        oct_.cameras = cams_all
+        lower.append(oct_.get_visi_cams(side, cen, bounds).numpy())
+        up = np.zeros(n, bool)
+        for dx in (0, 25, 50, 75):
+            for dy in (0, 25, 50, 75):
+                oct_.cameras = Cameras(fx=torch.full((n,), F), fy=torch.full((n,), F), cx=torch.full((n,), W / 2 + 100 + dx),
+                                       cy=torch.full((n,), H / 2 + 100 + dy), camera_to_worlds=torch.from_numpy(c2w_all), width=W + 300,
+                                       height=H + 300)
+                up |= oct_.get_visi_cams(side * 1.05, cen, bounds).numpy()
+        upper.append(up)
+    out["po_visi_boxes"] = np.asarray([list(c) + [s] for c, s in boxes], np.float32)
+    out["po_visi_lower"] = np.stack(lower)  # [box, camera] bool
+    out["po_visi_upper"] = np.stack(upper)
+    out["po_visi_bounds"] = bounds.numpy()
+
+
 def main():
     assert os.path.isdir(REF), "reference tree not mounted; fixtures can only be regenerated in the build container"
     _install_stubs()
@@ -374,6 +505,11 @@ def main():
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+    po_out = {}
+    gen_persoctree(po_out)
+    path = os.path.join(HERE, "persoctree_vectors.npz")
+    np.savez_compressed(path, **po_out)
+    print(f"wrote {path}: {len(po_out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
 
 
 if __name__ == "__main__":

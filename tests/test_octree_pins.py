@@ -1,0 +1,173 @@
+"""Pins from the reference's own PyTorch statement of the octree build and the perspective warp, gfnerf/persoctree.py
+(tests/golden/persoctree_vectors.npz, captured by tests/golden/make_golden.py::gen_persoctree by importing and RUNNING it):
+
+  * the oracle's QueryFrameTransform / QueryFrameTransformJac (oracle/gfn_oracle.c: gfn_o_warp_point / gfn_o_warp_jac, the
+    arithmetic of K4 that the HIP march kernels are bit-compared against) against the prototype's projected values
+    (persoctree.py:151-155), its warp Jacobian (:160-168) and the warp vis_transed_pts prints (:358-371);
+  * the product's host build (csrc/octree_build.cpp through the C ABI): DistanceSummary, PCA, GetVisiCams and
+    ConstructTrans against the prototype's distance_summary / PCA / get_visi_cams / construct_trans on the same cameras,
+    the same injected random first camera and the same probe points.
+
+What cannot agree and is not compared: the prototype re-aims the virtual cameras with a look-at (up = +z), the C++ build
+with Eigen::AngleAxisf's minimal rotation (PersSampler.cpp:718-746), so the x / y rows of w2xz differ by a roll about the
+viewing axis (their lengths, their orthogonality to the z row and everything derived from a GIVEN set of frames agree);
+get_visi_cams samples every 100th pixel where GetVisiCams casts a 128 x res_h grid, so the build's answer is held between
+two runs of the prototype (a lower and an upper bound that differ by a few border cameras).  CPU only: host code + oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def po():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "persoctree_vectors.npz")))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import ops as _ops
+
+    return _ops
+
+
+def _trans(oracle, w2xz, weight, center=(0, 0, 0), side=1.0, dis_summary=1.0):
+    t = np.zeros(1, oracle.TRANS_INFO_DTYPE)
+    t["w2xz"][0], t["weight"][0], t["center"][0], t["side_len"][0], t["dis_summary"][0] = w2xz, weight, center, side, dis_summary
+    return t
+
+
+def _grid(center, side):
+    """The points vis_transed_pts warps (persoctree.py:334-357): meshgrid of 32 f32 linspaces, default 'xy' indexing."""
+    ax = np.linspace(-0.5, 0.5, 32, dtype=np.float32)
+    X, Y, Z = np.meshgrid(ax, ax, ax)
+    pts = np.column_stack((X.ravel(), Y.ravel(), Z.ravel())).astype(np.float32)
+    return (pts * np.float32(side) + np.asarray(center, np.float32)[None]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ oracle: the warp (a3)
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_oracle_warp_matches_reference_prototype(po, oracle, case):
+    k = f"po_ct{case}_"
+    w2xz, weight, pts = po[k + "w2xz"], po[k + "weight"], po[k + "pts"]
+    # (1) the 12 projected values x0 / x1 per point: one-hot weight rows read them out of gfn_o_warp_point
+    got = np.zeros((pts.shape[0], 12), np.float32)
+    for base in range(0, 12, 3):
+        onehot = np.zeros((3, 12), np.float32)
+        onehot[np.arange(3), base + np.arange(3)] = 1.0
+        tr = _trans(oracle, w2xz, onehot)
+        got[:, base:base + 3] = np.stack([oracle.warp_point(tr, p) for p in pts])
+    want = po[k + "transed"]
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    # (2) the warp Jacobian with the un-normalised PCA rows, as construct_trans forms it (jac = V . dv_dxyz, :160-168)
+    V = po[k + "V"].T[0:3].copy()
+    tr = _trans(oracle, w2xz, V)
+    jac = np.stack([oracle.warp_jac(tr, p).reshape(3, 3) for p in pts[:1500]])
+    wj = po[k + "jac"][:1500]
+    np.testing.assert_allclose(jac, wj, rtol=1e-5, atol=1e-5 * np.abs(wj).max())
+    # (3) the finished warp of the 32^3 grid, exactly what vis_transed_pts evaluated (:358-371) -- every 7th point is kept
+    tr = _trans(oracle, w2xz, weight)
+    grid = _grid(po[k + "center"], float(po[k + "side"]))[::7]
+    warped = np.stack([oracle.warp_point(tr, p) for p in grid])
+    ww = po[k + "grid_warped"]
+    assert ww.shape == warped.shape
+    np.testing.assert_allclose(warped, ww, rtol=1e-5, atol=1e-5 * np.abs(ww).max())
+
+
+# ------------------------------------------------------------------------------------------ product host build (f1)
+def test_distance_summary_matches_reference(po, ops):
+    off = 0
+    for n, want in zip(po["po_ds_sizes"], po["po_ds_summary"]):
+        got = ops.octree_distance_summary(po["po_ds_dis"][off:off + n])
+        off += n
+        np.testing.assert_allclose(got, want, rtol=2e-6)
+    assert ops.octree_distance_summary(np.zeros(0, np.float32)) == float(po["po_ds_empty"]) == 1e8
+
+
+def _same_up_to_sign(a, b, tol):
+    d = np.abs((a * b).sum()) / (np.linalg.norm(a) * np.linalg.norm(b))
+    return d > 1.0 - tol
+
+
+def test_pca_matches_reference(po, ops):
+    L, V = ops.octree_pca12(po["po_pca_pts"])
+    np.testing.assert_allclose(L, po["po_pca_L"], rtol=2e-5, atol=1e-6 * po["po_pca_L"][0])
+    for k in range(12):  # the spectrum of the fixture is well separated: every eigenvector is determined up to its sign
+        assert _same_up_to_sign(V[:, k], po["po_pca_V"][:, k], 1e-5), k
+    for c in range(3):  # and on the projected values of the three real camera sets (what ConstructTrans feeds it)
+        L, V = ops.octree_pca12(po[f"po_ct{c}_transed"])
+        wL, wV = po[f"po_ct{c}_L"], po[f"po_ct{c}_V"]
+        np.testing.assert_allclose(L[:4], wL[:4], rtol=1e-4)
+        for k in range(3):
+            assert _same_up_to_sign(V[:, k], wV[:, k], 1e-4), (c, k)
+
+
+def _intr9(po):
+    fx, fy, cx, cy = po["po_intr"]
+    return np.asarray([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_construct_trans_matches_reference_prototype(po, ops, oracle, case):
+    k = f"po_ct{case}_"
+    cams, center, side, first = po[k + "cams"], po[k + "center"], float(po[k + "side"]), int(po[k + "first"])
+    c2w = po["po_c2w"][cams]
+    blob, good = ops.octree_construct_trans(c2w, _intr9(po), center, side, first_cam=first, pts=po[k + "pts"])
+    t = blob.view(oracle.TRANS_INFO_DTYPE)[0]
+    ref_w2xz = po[k + "w2xz"]
+    # distance summary of the visible cameras
+    np.testing.assert_allclose(t["dis_summary"], po[k + "dis_summary"], rtol=2e-6)
+    # the farthest-point selection from the injected first pick: the prototype's choice is read off its z rows
+    # (row = normalised camera position relative to the centre, :137-141)
+    pos = c2w[:, :, 3] - center[None]
+    normed = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    ref_good = [int(np.argmax(normed @ ref_w2xz[g, 1, 0:3])) for g in range(6)]
+    assert ref_good[0] == first and list(good) == ref_good
+    # z rows and their offsets (common to look-at and minimal rotation); x / y rows: same length, orthogonal to z, both
+    # sets span the same image plane
+    w2xz = t["w2xz"]
+    # direction: to 2e-3, the bound the reference itself names for this difference (the CHECK_LT it carries commented out at
+    # PersSampler.cpp:752; the prototype asserts 1e-3, :146) -- the C++ re-aim goes through angle = asin(|z x z'|), which loses
+    # half the digits when a camera has to turn by about 90 degrees; the look-at of the prototype does not
+    np.testing.assert_allclose(w2xz[:, 1, 0:3], ref_w2xz[:, 1, 0:3], rtol=0, atol=2e-3)
+    assert np.abs(w2xz[:, 1, 0:3] - ref_w2xz[:, 1, 0:3]).max(axis=1).min() < 2e-6  # and exact where the turn is small
+    np.testing.assert_allclose(w2xz[:, 1, 3], ref_w2xz[:, 1, 3], rtol=0, atol=2e-3 * np.abs(ref_w2xz[:, 1, 3]).max())
+    for g in range(6):
+        x, y, z = w2xz[g, 0, 0:3], w2xz[g + 6, 0, 0:3], w2xz[g, 1, 0:3]
+        rx, ry = ref_w2xz[g, 0, 0:3], ref_w2xz[g + 6, 0, 0:3]
+        np.testing.assert_allclose([np.linalg.norm(x), np.linalg.norm(y)], [np.linalg.norm(rx), np.linalg.norm(ry)], rtol=1e-5)
+        assert abs(x @ z) < 1e-4 * np.linalg.norm(x) and abs(y @ z) < 1e-4 * np.linalg.norm(y) and abs(x @ y) < 1e-4 * (x @ x)
+        # the offsets put the camera at the same (distance-aligned) position: frame . [pos, 1] = 0 for all three rows
+        cam = center + normed[good[g]] * max(np.linalg.norm(pos[good[g]]), t["dis_summary"])
+        assert abs(x @ cam + w2xz[g, 0, 3]) < 1e-3 * np.linalg.norm(x) * np.linalg.norm(cam)
+        assert abs(y @ cam + w2xz[g + 6, 0, 3]) < 1e-3 * np.linalg.norm(y) * np.linalg.norm(cam)
+        assert abs(z @ cam + w2xz[g, 1, 3]) < 1e-3 * np.linalg.norm(cam)
+    # third step on the prototype's OWN frames and probe points: PCA rows + step normalisation = its weight, up to the sign
+    # of an eigenvector
+    w = ops.octree_fit_weight(ref_w2xz, po[k + "pts"])
+    ref_w = po[k + "weight"]
+    for r in range(3):
+        s = np.sign((w[r] * ref_w[r]).sum())
+        np.testing.assert_allclose(s * w[r], ref_w[r], rtol=2e-3, atol=2e-4 * np.abs(ref_w[r]).max())
+    # and the product's own warp is a proper one: orthonormal-ish step (every axis's mean expected step is 1 by construction)
+    assert np.isfinite(t["weight"]).all() and np.abs(t["weight"]).max() > 0
+
+
+def test_visible_cams_sandwiched_by_reference(po, ops):
+    """GetVisiCams (128 x res_h pixel rays) between two runs of the prototype's get_visi_cams (one ray per 100th pixel): every
+    camera the prototype reports is visible (lower bound); no camera outside its 16-fold shifted, margin-extended, 5 %-grown
+    run is (upper bound).  The bounds differ by a few border cameras per box."""
+    c2w, bounds, K = po["po_c2w"], po["po_visi_bounds"], _intr9(po)
+    intri = np.repeat(K[None], c2w.shape[0], 0)
+    gap = 0
+    for b, box in enumerate(po["po_visi_boxes"]):
+        lower, upper = po["po_visi_lower"][b], po["po_visi_upper"][b]
+        assert not (lower & ~upper).any()
+        got = ops.octree_visible_cams(c2w, intri, bounds, box[:3], float(box[3]))
+        assert not (lower & ~got).any(), (b, np.nonzero(lower & ~got)[0])
+        assert not (got & ~upper).any(), (b, np.nonzero(got & ~upper)[0])
+        gap += int((upper & ~lower).sum())
+    assert po["po_visi_lower"].sum() > 90 and gap < 0.1 * po["po_visi_lower"].size  # the sandwich is tight and not vacuous
