@@ -51,12 +51,15 @@ class _AnchoredQueryFn(torch.autograd.Function):
 
 
 class _NativeHash3DAnchored:
-    def __init__(self, log2_table_size: int, n_volumes: int, lr: float = 1e-1, device="cuda", seed=None):
+    def __init__(self, log2_table_size: int, n_volumes: int, lr: float = 1e-1, device="cuda", seed=None, allocate=True):
         self.log2_table_size_ = int(log2_table_size)
         self.n_volumes_ = int(n_volumes)
         self.learn_rate_ = lr
         self.pool_size_ = (1 << self.log2_table_size_) * N_LEVELS
         dev = torch.device(device)
+        if not allocate:  # the caller aliases existing storage (an engine-backed field): nothing to draw or allocate
+            self.feat_pool_ = self.prim_pool_ = self.bias_pool_ = torch.empty(0, device=dev)
+            return
         rng = np.random.default_rng(seed)
         # Hash3DAnchored.cpp:26: (rand * .2 - 1) * 1e-4, overwritten by Reset()/Zero() by every caller
         self.feat_pool_ = ((torch.rand((self.pool_size_, N_CHANNELS), device=dev) * 0.2 - 1.0) * 1e-4).requires_grad_(True)
@@ -103,9 +106,9 @@ class _NativeHash3DAnchored:
 
 
 class Hash3DAnchored(nn.Module):
-    def __init__(self, log2_table_size: int, n_volumes: int, device="cuda", seed=None) -> None:
+    def __init__(self, log2_table_size: int, n_volumes: int, device="cuda", seed=None, allocate=True) -> None:
         super().__init__()
-        self.hash_3d = _NativeHash3DAnchored(log2_table_size, n_volumes, 1e-1, device=device, seed=seed)
+        self.hash_3d = _NativeHash3DAnchored(log2_table_size, n_volumes, 1e-1, device=device, seed=seed, allocate=allocate)
         self.register_parameter("feat_pool", None)
         self.register_buffer("prime_pool", None)
         self.register_buffer("bias_pool", None)
@@ -115,6 +118,10 @@ class Hash3DAnchored(nn.Module):
     def unregister_hooks(self):
         for h in self.hook_handles:
             h.remove()
+
+    def __del__(self):
+        """hash_3d_anchored.py:34-36: the reference announces the destruction (its tables die with the C++ object); here the
+        tensors are ordinary torch storage and go with the last reference."""
 
     def state_dict_hook(self, *args):
         destination, prefix = args[1], args[2]

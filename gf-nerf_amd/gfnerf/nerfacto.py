@@ -1,48 +1,105 @@
-"""GFNeRFModel (gfnerf/nerfacto.py:200-747), the Model-level boundary: populate_modules builds the sampler and the
-field, get_outputs(ray_bundle) -> {"rgb", "accumulation", "depth", "oct_depth"} (nerfacto.py:522-619).
+"""GFNeRFModel (gfnerf/nerfacto.py:200-747), the Model-level boundary: the reference's constructor protocol
+(`config.model.setup(scene_box=, num_train_data=, metadata=, cameras=, bounds=, base_dir=)`, gf_pipeline.py:124-131),
+populate_modules / get_param_groups / get_training_callbacks / get_outputs / get_metrics_dict / get_loss_dict /
+get_image_metrics_and_images / load_state_dict with the reference's names, parameter groups and state-dict keys.
 
-The engine is `HotPath` (packed samples, fused kernels); this class gives it the reference's Model surface and an
-autograd bridge, so `loss.backward()` + `torch.optim.Adam` of the reference's Trainer work unchanged: parameters
-are nn.Parameters aliasing HotPath's tensors, `_RenderFn.backward` runs the HIP backward and hands the gradients to
-autograd.  (HotPath.train_step with its fused Adam is the faster native loop; bench.py measures that one.)"""
+The engine is `HotPath` (packed samples, fused HIP kernels).  `self.field` is a real GFNeRFField whose tensors alias the
+engine's storage, `self.persampler` shares its tree with the engine, and an autograd bridge (`_RenderFn`) makes the
+reference Trainer's `loss.backward()` + torch.optim.Adam work unchanged: its backward runs the HIP backward and hands the
+gradients to autograd -- averaged over the ranks first when the job is data parallel (the reference wraps the model in
+DDP, gf_pipeline.py:136-138, which never sees the hash table: hash_3d_anchored.py:26,73-78).  (HotPath.train_step with
+its fused Adam is the faster native loop; bench.py measures that one.)"""
+import os
 from dataclasses import dataclass, field as dc_field
-from typing import Dict, List
+from pathlib import Path
+from typing import Any, Dict, List, Mapping, Tuple, Type
 
 import numpy as np
-import types
-
 import torch
 from torch import nn
 
 from .. import hotpath as hp_mod
 from .. import ops
+from ._host import Model, ModelConfig, TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation
+from .nerfacto_field import GFNeRFField
 from .perssampler import PersSampler
 from .rays import RayBundle
 
 
 @dataclass
-class GFNeRFModelConfig:
-    """Subset of gfnerf/nerfacto.py:72-196 that the hot path reads (defaults = gfnerf/config.py)."""
-    hidden_dim: int = 128
-    hidden_dim_color: int = 128
-    log2_hashmap_size: int = 21
-    n_blocks: int = 10
-    n_split_dataset: int = 10
-    steps_per_split_dataset: int = 10000
-    steps_perssampler_init: int = 30000
-    scale_factor: float = 10.0
-    use_appearance_embedding: bool = True
-    use_ch_loss: bool = True
-    early_T: float = 1e-4
-    resident_blocks: List[int] = dc_field(default_factory=list)  # block tables to keep in HBM (288 GB: all of them fit)
+class GFNeRFModelConfig(ModelConfig):
+    """gfnerf/nerfacto.py:72-196: the reference's fields with the reference's defaults (the method config, gfnerf/config.py,
+    overrides them).  Options of other model families that GF-NeRF leaves off are carried for config-file compatibility and
+    refused where they would change the result."""
+    _target: Type = dc_field(default_factory=lambda: GFNeRFModel)
+    near_plane: float = 0.05
+    far_plane: float = 300.0
+    background_color: str = "last_sample"
+    patch_size: int = 32
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    hidden_dim_transient: int = 64
+    num_levels: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = dc_field(default_factory=list)
+    proposal_initial_sampler: str = "piecewise"
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    orientation_loss_mult: float = 0.0001
+    pred_normal_loss_mult: float = 0.001
+    perceptual_loss_mult: float = 1.0
+    mono_depth_loss_mult: float = 0.0
+    use_proposal_weight_anneal: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    predict_normals: bool = False
+    disable_scene_contraction: bool = False
+    use_ch_loss: bool = False
+    use_perceptual_loss: bool = False
+    use_aabb_collider: bool = False
+    use_mask: bool = False
+    use_normal_loss: bool = False
+    use_depth_loss: bool = False
+    use_semantics: bool = False
+    num_semantic_classes: int = 2
+    semantic_loss_weight: float = 0.1
+    n_blocks: int = 1
+    n_split_dataset: int = 1
+    steps_per_split_dataset: int = 30000
+    n_activate_block: int = 3
+    steps_perssampler_init: int = 10000
+    use_appearance_embedding: bool = False
+    scale_factor: float = 1.0
+    s3im_loss_mult: float = 0.0
+    s3im_kernel_size: int = 4
+    s3im_stride: int = 4
+    s3im_repeat_time: int = 10
+    s3im_patch_height: int = 32
+    # ---- this build's engine options (not in the reference)
+    early_T: float = 1e-4               # early-termination transmittance of the compositing (0 = the reference: none)
+    keep_blocks_resident: bool = True   # inactive block tables stay in HBM instead of being swapped through disk
+    engine_seed: int = 0                # parameter initialisation of the engine (every rank uses the same)
+    render_tile_rays: int = 8192        # rays per hipGraph-captured inference tile (get_outputs_for_camera_ray_bundle)
 
 
 class _RenderFn(torch.autograd.Function):
+    """forward: HotPath.forward_train; backward: HotPath.backward (+ the data-parallel exchange) -> autograd gradients of the
+    aliased parameters, in the order (table, block table, embedding weight, 10 decoder tensors)."""
+
     @staticmethod
-    def forward(ctx, table, mlp_flat, emb, block_table, model, o, d, cam, noise, stage, block):
+    def forward(ctx, model, stage, block, o, d, cam, noise, table, block_table, emb, *decoder):
         hot = model.hot
         comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block)
-        ctx.model, ctx.hctx, ctx.stage, ctx.block = model, hctx, stage, block
+        ctx.model, ctx.hctx, ctx.stage, ctx.n_dec = model, hctx, stage, len(decoder)
         depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], hot.cfg.scale_factor)
         ctx.mark_non_differentiable(depth)
         return comp["rgb"], comp["acc"], depth
@@ -52,127 +109,408 @@ class _RenderFn(torch.autograd.Function):
         hot = ctx.model.hot
         g_acc = None if g_acc is None or not bool(g_acc.any()) else g_acc.contiguous()
         hot.backward(ctx.hctx, g_rgb.contiguous(), g_acc)
+        hot.sync_grads(ctx.stage, ctx.hctx)  # ray data parallelism: averaged over the ranks before any optimiser sees them
         tg = hot.table_grad
         tg = tg.float() / 128.0 if tg.dtype == torch.float16 else tg.clone()
+        none7 = (None,) * 7
         if ctx.stage == hp_mod.STAGE_GLOBAL:
             emb_g = hot.emb_grad.clone() if hot.cfg.use_appearance_embedding else None
-            return tg, hot.mlp_grad.clone(), emb_g, None, None, None, None, None, None, None, None
-        return None, None, None, tg, None, None, None, None, None, None, None
+            dec = []
+            for gW, gB in hot.layer_grads:
+                dec += [gW.clone(), gB.clone()]
+            return none7 + (tg, None, emb_g) + tuple(dec)
+        return none7 + (None, tg, None) + (None,) * ctx.n_dec
 
 
-class GFNeRFModel(nn.Module):
-    def __init__(self, config: GFNeRFModelConfig, cameras, bounds, num_train_data, device="cuda:0", base_dir="", seed=0):
-        super().__init__()
-        self.config = config
-        self.cameras = cameras
-        self.num_train_data = num_train_data
-        self.device_ = torch.device(device)
-        self.base_dir = base_dir
-        self.scale_factor = config.scale_factor
-        self.populate_modules(bounds, seed)
+class _S3IMFn(torch.autograd.Function):
+    """s3im_loss_mult * S3IM(image, rgb) (nerfacto.py:687-688; losses.py:713-794) on the device kernel."""
 
-    def populate_modules(self, bounds, seed=0):
+    @staticmethod
+    def forward(ctx, pred, gt, index, patch_h, mult):
+        loss, g = ops.s3im(gt.contiguous(), pred.contiguous(), index, patch_h=patch_h, mult=mult)
+        ctx.save_for_backward(g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (g,) = ctx.saved_tensors
+        return g * g_out, None, None, None, None
+
+
+def _ssim(img0, img1, data_range=1.0):
+    """structural_similarity_index_measure (torchmetrics defaults: 11x11 gaussian window, sigma 1.5, k1 0.01, k2 0.03) of two
+    [1,C,H,W] images; an evaluation-time metric on whole images (nerfacto.py:736), plain tensor arithmetic."""
+    import torch.nn.functional as F
+
+    C = img0.shape[1]
+    k = torch.arange(11, dtype=torch.float32, device=img0.device) - 5
+    g = torch.exp(-(k ** 2) / (2 * 1.5 ** 2))
+    g = g / g.sum()
+    win = (g[:, None] * g[None, :]).expand(C, 1, 11, 11).contiguous()
+    pad = 5
+    x = F.pad(img0, (pad, pad, pad, pad), mode="reflect")
+    y = F.pad(img1, (pad, pad, pad, pad), mode="reflect")
+    mu_x, mu_y = F.conv2d(x, win, groups=C), F.conv2d(y, win, groups=C)
+    sxx = F.conv2d(x * x, win, groups=C) - mu_x ** 2
+    syy = F.conv2d(y * y, win, groups=C) - mu_y ** 2
+    sxy = F.conv2d(x * y, win, groups=C) - mu_x * mu_y
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    ssim = ((2 * mu_x * mu_y + c1) * (2 * sxy + c2)) / ((mu_x ** 2 + mu_y ** 2 + c1) * (sxx + syy + c2))
+    return ssim[..., pad:-pad, pad:-pad].mean() if min(ssim.shape[-2:]) > 2 * pad else ssim.mean()
+
+
+class GFNeRFModel(Model):
+    config: GFNeRFModelConfig
+
+    def populate_modules(self):
+        """Set the fields and modules (nerfacto.py:209-301)."""
+        super().populate_modules()
         c = self.config
+        self.cameras = self.kwargs["cameras"]
+        bounds = self.kwargs["bounds"]
+        self.base_dir = self.kwargs.get("base_dir", "")
+        dev = self.kwargs.get("device", None)
+        if dev is None:
+            cdev = self.cameras.camera_to_worlds.device
+            dev = cdev if cdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(dev)
+        if c.predict_normals or c.use_normal_loss or c.use_semantics or c.use_perceptual_loss or c.use_mask:
+            raise NotImplementedError("normals / semantics / LPIPS / masks: off in the gf-nerf method config (gfnerf/config.py:103-113), not on this path")
+        self.density_fns = []
         self.persampler = PersSampler(cameras=self.cameras, bounds=bounds, bbox_levels=10, max_level=16,
-                                      steps_per_split_dataset=c.steps_per_split_dataset,
-                                      steps_perssampler_init=c.steps_perssampler_init, n_split_dataset=c.n_split_dataset,
-                                      device=self.device_, seed=1234 + seed)   # nerfacto.py:223-227
+                                      steps_per_split_dataset=c.steps_per_split_dataset, steps_perssampler_init=c.steps_perssampler_init,
+                                      n_split_dataset=c.n_split_dataset, device=dev, seed=1234 + c.engine_seed)   # :223-227
+        self.scale_factor = c.scale_factor
+        self.sample_tmp_dir = None
+        n_blocks = c.n_blocks
+        step_n = max(len(self.cameras) // n_blocks, 1)
+        self.block_centers = torch.stack([self.cameras.camera_to_worlds[min(i * step_n, len(self.cameras) - 1), :, 3] for i in range(n_blocks)], dim=0).to(dev)
+        self.n_blocks = n_blocks
+        # the engine: one tree shared with the sampler object, one set of tensors shared with the field
         nat = self.persampler.sampler
-        cfg = hp_mod.HotPathConfig(log2_T=c.log2_hashmap_size, hidden=c.hidden_dim, scale_factor=c.scale_factor,
-                                   early_T=c.early_T, use_appearance_embedding=c.use_appearance_embedding)
-        n_res = (max(c.resident_blocks) + 1) if c.resident_blocks else 0
-        self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg,
-                                  device=self.device_, seed=seed, n_blocks=n_res)
-        # the sampler object and the engine share one tree (blob + compact copy)
+        assert c.hidden_dim == c.hidden_dim_color, "the fused decoder uses one hidden width (gfnerf/config.py:124-125: 128 / 128)"
+        cfg = hp_mod.HotPathConfig(log2_T=c.log2_hashmap_size, hidden=c.hidden_dim, scale_factor=c.scale_factor, early_T=c.early_T,
+                                   use_appearance_embedding=c.use_appearance_embedding, s3im_loss_mult=c.s3im_loss_mult,
+                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time)
+        self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg, device=dev,
+                                  seed=c.engine_seed, n_blocks=0, sync=self.kwargs.get("sync", None))
         self.hot.nodes, self.hot.transes, self.hot.nodes_compact = nat.tree_nodes_gpu_, nat.pers_trans_gpu_, nat.nodes_compact_
-        # nn.Parameters that ALIAS the engine's tensors (what get_param_groups hands to the optimisers)
-        self.feat_pool = nn.Parameter(self.hot.table, requires_grad=True)
-        self.mlp_params = nn.Parameter(self.hot.mlp_flat, requires_grad=True)
-        self.embedding_appearance = nn.Parameter(self.hot.emb, requires_grad=True)
-        self.block_pools = nn.ParameterList([nn.Parameter(b, requires_grad=True) for b in self.hot.blocks])
+        if self.hot.sync.world > 1:  # K5's per-node maxima are MAX-reduced over the ranks before K6 (every replica keeps the same tree)
+            nat.reduce_max = self.hot.sync.reduce_octree_stats
+        self.field = GFNeRFField(
+            None if self.scene_box is None else self.scene_box.aabb, hidden_dim=c.hidden_dim, num_levels=c.num_levels, max_res=c.max_res,
+            log2_hashmap_size=c.log2_hashmap_size, hidden_dim_color=c.hidden_dim_color, hidden_dim_transient=c.hidden_dim_transient,
+            spatial_distortion=None, num_images=self.num_train_data, use_pred_normals=c.predict_normals,
+            use_average_appearance_embedding=c.use_average_appearance_embedding, n_blocks=self.n_blocks, block_centers=self.block_centers,
+            n_active_block=c.n_activate_block, steps_perssampler_init=c.steps_perssampler_init, use_semantics=c.use_semantics,
+            num_semantic_classes=c.num_semantic_classes, base_dir=self.base_dir, use_appearance_embedding=c.use_appearance_embedding,
+            n_volumes=len(self.persampler.to_proposal_sampler_oct_tree_nodes()), device=dev, engine=self.hot,
+            keep_blocks_resident=c.keep_blocks_resident)
         self._params_version = None
-        # the reference reads model.field.cur_stage (gf_pipeline.py:180); here the field is fused into the engine
-        self.field = types.SimpleNamespace(cur_stage="init_stage")
+        self._tile_renderer = None
+        self._s3im_gen = torch.Generator(device=dev)
+        self._s3im_gen.manual_seed(77 + c.engine_seed)
 
     # ----------------------------------------------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """nerfacto.py:303-321: "fields" = the field's named parameters (decoder, embedding), "base_encoding_init" = the global
+        table (the one extra entry of the overridden parameters()); block tables join through update_optimizer."""
+        params = list(self.field.parameters())
+        n_named = len(list(self.field.named_parameters()))
+        return {"fields": params[0:n_named], "base_encoding_init": [params[n_named]]}
+
     def stage_of(self, step: int):
         c = self.config
         if step < 0 or (c.steps_perssampler_init > 0 and step < c.steps_perssampler_init):
             return hp_mod.STAGE_GLOBAL, None
         return hp_mod.STAGE_FOCAL, ((step - c.steps_perssampler_init) // c.steps_per_split_dataset) % c.n_split_dataset
 
-    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
-        return {"fields": [self.feat_pool, self.mlp_params, self.embedding_appearance] + list(self.block_pools)}
-
-    def _sync_after_external_update(self):
-        """torch.optim writes the aliased masters in place; the f16 shadows the lookups read must follow."""
-        ver = (self.feat_pool._version, tuple(p._version for p in self.block_pools))
-        if ver != self._params_version:
-            self.hot.refresh_shadows()
-            self._params_version = ver
-
-    def get_outputs(self, ray_bundle: RayBundle, block=None):
+    def get_training_callbacks(self, training_callback_attributes: TrainingCallbackAttributes) -> List[TrainingCallback]:
+        """nerfacto.py:323-520.  update_optimizer / render_init_error_maps / train_cameras_clustering / update_datamanager as the
+        reference registers them, plus update_field_stage, which the reference defines (:432-436) and forgets to register --
+        without it the block stage never starts."""
         c = self.config
-        o = ray_bundle.origins.contiguous().float()
-        d = ray_bundle.directions.contiguous().float()
-        cam = ray_bundle.rel_camera_indices if ray_bundle.rel_camera_indices is not None else ray_bundle.camera_indices
-        cam = cam.reshape(-1).to(torch.int32).contiguous()
+
+        def update_field_stage(step, *args, **kwargs):
+            self.field.cur_stage = "init_stage" if (c.steps_perssampler_init > 0 and 0 <= step < c.steps_perssampler_init) else "block_stage"
+
+        def train_cameras_clustering(step, *args, **kwargs):
+            if self.field.cur_stage == "block_stage" and self.persampler.cameras_labels is None:
+                self.persampler.train_cameras_clustering_oct(kwargs["n_blocks"])
+
+        def render_init_error_maps(step, *args, **kwargs):
+            """:354-430: at the switch to the block stage render every training image at 1/8 resolution with the global-stage
+            model and keep |gt - pred| summed over the channels as that image's initial error map.  The maps go to the
+            datamanager (`set_error_maps`) when it keeps them in HBM, and to sample_tmp/npy like the reference otherwise."""
+            if not (self.field.cur_stage == "block_stage" and self.persampler.cameras_labels is None):
+                return
+            dm = kwargs["pipeline"].datamanager
+            if not hasattr(dm, "train_images_for_error_maps"):
+                return
+            self.sample_tmp_dir = str(Path(self.base_dir) / "sample_tmp")
+            was_training = self.training
+            self.eval()
+            maps = []
+            for image_idx, (gt, bundle) in enumerate(dm.train_images_for_error_maps(down_scale_factor=8, step=step)):
+                pred = self.get_outputs_for_camera_ray_bundle(bundle)["rgb"]                 # [h,w,3]
+                H, W = gt.shape[:2]
+                up = torch.nn.functional.interpolate(pred.permute(2, 0, 1)[None], (H, W), mode="nearest")[0].permute(1, 2, 0)
+                maps.append(torch.abs(gt.to(up) - up).sum(-1))
+            self.train(was_training)
+            if maps and hasattr(dm, "set_error_maps"):
+                dm.set_error_maps(torch.stack(maps))
+            else:
+                os.makedirs(Path(self.sample_tmp_dir) / "npy", exist_ok=True)
+                for i, m in enumerate(maps):
+                    np.save(str(Path(self.sample_tmp_dir) / "npy" / f"{i:06d}.npy"), m.cpu().numpy())
+
+        def update_datamanager(step, *args, **kwargs):
+            split_idx = self.field.cur_split_dataset_idx
+            dm = kwargs["pipeline"].datamanager
+            if hasattr(dm, "setup_train_split_oct") and self.persampler.cameras_labels is not None and split_idx is not None:
+                dm.setup_train_split_oct(self.persampler.cameras_labels, split_idx, self.sample_tmp_dir)
+
+        def update_optimizer(step, *args, **kwargs):
+            """:448-488: one optimiser per parameter group, created and dropped with the stage and the active blocks."""
+            optimizers = kwargs["optimizer"]
+            list_in_train, list_in_test = self.field.active_block_idxs, self.field.active_block_idxs_test
+            rest = list(set(range(self.n_blocks)).difference(set(list_in_train + list_in_test)))
+            if self.field.cur_stage == "init_stage":
+                optimizers.add_optimizer("base_encoding_init")
+                optimizers.add_optimizer("fields")
+                for idx in range(self.n_blocks):
+                    optimizers.delete_optimizer(f"base_encoding_{idx}")
+            elif step == (c.steps_perssampler_init + c.n_split_dataset * c.steps_per_split_dataset) - 1:
+                for idx in list_in_train:  # save last encoding ckpt
+                    self.field.save_table(idx)
+                    if not self.field.keep_blocks_resident:
+                        self.field.del_table(idx)
+            else:
+                optimizers.delete_optimizer("base_encoding_init")
+                optimizers.delete_optimizer("fields")
+                for idx in list_in_train:
+                    params = list(getattr(self.field, f"base_encoding_{idx}").parameters())
+                    optimizers.add_optimizer(f"base_encoding_{idx}", lr_init=5e-3, params=params)
+                for idx in rest:
+                    optimizers.delete_optimizer(f"base_encoding_{idx}")
+
+        after = [TrainingCallbackLocation.AFTER_TRAIN_ITERATION]
+        pipe = training_callback_attributes.pipeline
+        return [
+            TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], func=update_field_stage, update_every_num_iters=1),
+            TrainingCallback(where_to_run=after, func=update_optimizer, update_every_num_iters=True, args=None,
+                             kwargs={"optimizer": training_callback_attributes.optimizers}),
+            TrainingCallback(where_to_run=after, func=render_init_error_maps, update_every_num_iters=True, args=None, kwargs={"pipeline": pipe}),
+            TrainingCallback(where_to_run=after, func=train_cameras_clustering, update_every_num_iters=True, args=None,
+                             kwargs={"n_blocks": self.n_blocks}),
+            TrainingCallback(where_to_run=after, func=update_datamanager, update_every_num_iters=True, args=None, kwargs={"pipeline": pipe}),
+        ]
+
+    # ----------------------------------------------------------------------------------------------
+    def _sync_after_external_update(self):
+        """torch.optim (or load_state_dict) wrote the aliased masters in place: the f16 shadows and split-f16 weight images the
+        kernels read must follow."""
+        vers = [p._version for p in self.field.parameters()]
+        for i in range(self.n_blocks):
+            enc = getattr(self.field, f"base_encoding_{i}", None)
+            vers.append(-1 if enc is None else enc.hash_3d.feat_pool_._version)
+        if vers != self._params_version:
+            self.hot.refresh_shadows()
+            self._params_version = vers
+
+    def _bundle(self, ray_bundle: RayBundle):
+        o = ray_bundle.origins.reshape(-1, 3).contiguous().float()
+        d = ray_bundle.directions.reshape(-1, 3).contiguous().float()
         step = -1 if ray_bundle.steps is None else int(ray_bundle.steps.reshape(-1)[0])
-        stage, blk = self.stage_of(step)
-        self.field.cur_stage = "block_stage" if stage == hp_mod.STAGE_FOCAL else "init_stage"
-        blk = blk if block is None else block
+        return o, d, step
+
+    def get_outputs(self, ray_bundle: RayBundle):
+        """nerfacto.py:522-619."""
+        if self.field.persampler is None:
+            object.__setattr__(self.field, "persampler", self.persampler)  # for trans_query_frame speed up (:532-533); not re-registered
+        o, d, step = self._bundle(ray_bundle)
+        R = o.shape[0]
         nat = self.persampler.sampler
-        noise = nat.make_noise(o.shape[0])
-        self._sync_after_external_update()
+        stage, blk = self.stage_of(step)
+        if step < 0:  # eval / render: one block per image, the split of the nearest training camera (perssampler.py:365-376)
+            if self.persampler.cameras_labels is not None or self.field.stage_of(step) == "block_stage":
+                blk, nearest = self.persampler.split_of_origin(o[0], None)
+                stage = hp_mod.STAGE_FOCAL
+        cam = ray_bundle.rel_camera_indices
+        if cam is None:  # test mode: the nearest training image's embedding (perssampler.py:431-433)
+            _, nearest = self.persampler.split_of_origin(o[0], None)
+            cam = torch.full((R,), int(nearest), dtype=torch.int32, device=o.device)
+        cam = cam.reshape(-1).to(torch.int32).contiguous()
+        self.field.cur_stage = "block_stage" if stage == hp_mod.STAGE_FOCAL else "init_stage"
+        self.field.cur_split_dataset_idx = -1 if blk is None else blk
+        noise = nat.make_noise(R)
         if self.training and torch.is_grad_enabled():
-            if stage == hp_mod.STAGE_FOCAL and blk >= len(self.hot.blocks):
-                raise RuntimeError(f"block {blk} is not resident; list it in GFNeRFModelConfig.resident_blocks")
-            bt = self.block_pools[blk] if stage == hp_mod.STAGE_FOCAL else None
-            rgb, acc, depth = _RenderFn.apply(self.feat_pool, self.mlp_params, self.embedding_appearance, bt, self, o, d, cam,
-                                              noise, stage, blk)
-            first = self.hot_last_first_oct_dis()
-            outputs = {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None], "oct_depth": first[:, None] / self.scale_factor}
-            nat.UpdateRayMarch(step)                                    # nerfacto.py:603-604
-            nat.UpdateMode(0)
-            if stage == hp_mod.STAGE_GLOBAL:                           # only update oct nodes on init stage (:605-613)
-                ctx = self._last_ctx()
+            if stage == hp_mod.STAGE_FOCAL:
+                self.field.update_active_blocks(blk)                   # nerfacto_field.py:470
+            self._sync_after_external_update()
+            bt = getattr(self.field, f"base_encoding_{blk}").hash_3d.feat_pool_ if stage == hp_mod.STAGE_FOCAL else None
+            rgb, acc, depth = _RenderFn.apply(self, stage, blk, o, d, cam, noise, self.field.base_encoding_init.hash_3d.feat_pool_, bt,
+                                              self.field.embedding_appearance.weight, *self.field.decoder_parameters())
+            ctx = self.hot._last_train_ctx
+            oct_depth = ctx["samples"]["first_oct_dis"][:, None] / self.scale_factor      # :555
+            outputs = {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None], "oct_depth": oct_depth}
+            self.persampler.update_ray_march(step)                      # :603-604
+            self.persampler.update_mode(0)
+            if self.field.cur_stage == "init_stage":                    # only update oct nodes on init stage (:605-613)
                 nat.last_packed = ctx["samples"]
-                nat.UpdateOctNodes(None, None, ctx["comp"]["weights"], ctx["comp"]["alphas"], step)
+                self.persampler.update_oct_nodes(sampled_anchors=None, pts_idx_bounds=None, sampled_weights=ctx["comp"]["weights"],
+                                                 sampled_alpha=ctx["comp"]["alphas"], iter_step=step)
                 self._relink_tree()  # ProcOctree (milestones / compact_freq) replaces the node blob
             else:
-                nat.UpdateMode(1)                                       # :616
+                self.persampler.update_mode(1)                          # :616
             return outputs
         with torch.no_grad():
-            use_block = blk if (stage == hp_mod.STAGE_FOCAL and blk is not None and blk < len(self.hot.blocks)) else None
+            use_block = None
+            if stage == hp_mod.STAGE_FOCAL and blk is not None:
+                was = self.field.training
+                self.field.train(False)
+                try:
+                    self.field.update_active_blocks(blk)                # eval: the block must be resident or have a checkpoint
+                finally:
+                    self.field.train(was)
+                use_block = blk
+            self._sync_after_external_update()
             out = self.hot.render(o, d, cam, noise, block=use_block)
-        assert float(out["oct_depth"].min()) > 0 or o.shape[0] == 0    # nerfacto.py:556
+        assert R == 0 or float(out["oct_depth"].min()) > 0             # :556
         return {"rgb": out["rgb"], "accumulation": out["accumulation"], "depth": out["depth"], "oct_depth": out["oct_depth"]}
 
     def _relink_tree(self):
         """The sampler object owns the tree; the engine samples from the same blob and 64-byte image."""
         nat = self.persampler.sampler
         if self.hot.nodes is not nat.tree_nodes_gpu_ or self.hot.nodes_compact is not nat.nodes_compact_:
+            self.hot._drop_stale_samples()
             self.hot.nodes, self.hot.nodes_compact, self.hot.n_nodes = nat.tree_nodes_gpu_, nat.nodes_compact_, nat.n_nodes
             self.hot._sampler_ws = None
 
-    def _last_ctx(self):
-        return self.hot._last_train_ctx
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, torch.Tensor]:
+        """models/base_model.py:163-186 drives `forward` over chunks of eval_num_rays_per_chunk = 2048 rays: 1013 Python round
+        trips per full-HD frame.  Same contract here ([H,W,.] outputs of every key), but the rays go through the hipGraph tile
+        renderer (gfnerf_amd.render.TileRenderer: sampler -> lookup -> decoder -> compositing captured once, replayed per tile of
+        config.render_tile_rays rays).  One block per image (perssampler.py:365-376)."""
+        from .. import render as rmod
 
-    def hot_last_first_oct_dis(self):
-        return self.hot._last_train_ctx["samples"]["first_oct_dis"]
-
-    def forward(self, ray_bundle: RayBundle):
-        return self.get_outputs(ray_bundle)
+        H, W = camera_ray_bundle.origins.shape[:2]
+        o, d, _ = self._bundle(camera_ray_bundle)
+        blk = None
+        nearest = 0
+        if self.persampler.cameras_labels is not None or self.field.cur_stage == "block_stage":
+            blk, nearest = self.persampler.split_of_origin(o[0], None)
+            was = self.field.training
+            self.field.train(False)
+            try:
+                self.field.update_active_blocks(blk)
+            finally:
+                self.field.train(was)
+        cam = camera_ray_bundle.rel_camera_indices
+        if cam is None:
+            cam = camera_ray_bundle.camera_indices
+        embed_idx = int(nearest) if cam is None else int(cam.reshape(-1)[0])
+        self._sync_after_external_update()
+        key = (blk, float(self.persampler.sampler.ray_march_fineness_), id(self.hot.nodes_compact))
+        if self._tile_renderer is None or self._tile_renderer[0] != key:
+            tr = rmod.TileRenderer(self.hot, None, None, tile_rays=self.config.render_tile_rays, block=blk,
+                                   fineness=float(self.persampler.sampler.ray_march_fineness_), use_graph=True, pipeline=1)
+            self._tile_renderer = (key, tr)
+        out = self._tile_renderer[1].render_rays(o, d, embed_idx, H, W)
+        return {k: v.view(H, W, -1) for k, v in out.items()}
 
     def get_metrics_dict(self, outputs, batch):
-        mse = torch.mean((outputs["rgb"].detach() - batch["image"].to(outputs["rgb"].device)) ** 2)
+        image = batch["image"].to(outputs["rgb"].device)
+        mse = torch.mean((outputs["rgb"].detach() - image) ** 2)
         return {"psnr": -10.0 * torch.log10(mse)}   # torchmetrics PeakSignalNoiseRatio(data_range=1.0), nerfacto.py:300,624
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        """nerfacto.py:628-689: rgb_loss (Charbonnier when use_ch_loss, losses.py:73-84, else MSE) + s3im_loss_mult * S3IM."""
+        c = self.config
         image = batch["image"].to(outputs["rgb"].device)
-        x, y = image, outputs["rgb"]                 # self.rgb_loss(image, outputs["rgb"]) (nerfacto.py:636)
-        if self.config.use_ch_loss:                  # CharbonnierLoss, out_norm "b" (losses.py:73-84)
-            loss = torch.sum(torch.sqrt((x - y).pow(2) + 1e-6 ** 2)) / x.shape[0]
+        x, y = image, outputs["rgb"]
+        loss_dict = {}
+        if c.use_ch_loss:
+            loss_dict["rgb_loss"] = torch.sum(torch.sqrt((x - y).pow(2) + 1e-6 ** 2)) / x.shape[0]
         else:
-            loss = torch.mean((x - y) ** 2)
-        return {"rgb_loss": loss}
+            loss_dict["rgb_loss"] = torch.mean((x - y) ** 2)
+        if c.s3im_loss_mult > 0:
+            R = y.shape[0]
+            if c.s3im_kernel_size != 4 or c.s3im_stride != 4:
+                raise NotImplementedError("the S3IM kernel is the method config's 4x4 window at stride 4 (gfnerf/config.py:97-98)")
+            assert (R * c.s3im_repeat_time) % c.s3im_patch_height == 0, "S3IM folds repeat_time * rays into rows of s3im_patch_height"
+            idx = ops.s3im_index(R, c.s3im_repeat_time, generator=self._s3im_gen, device=y.device)
+            loss_dict["s3im_loss"] = _S3IMFn.apply(y, image, idx, c.s3im_patch_height, c.s3im_loss_mult)
+        return loss_dict
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]):
+        """nerfacto.py:716-747: psnr / ssim (/ lpips where a pretrained LPIPS network is installed) of a full image + the panels."""
+        image = batch["image"].to(outputs["rgb"].device)
+        rgb = outputs["rgb"]
+        acc = _colormap(outputs["accumulation"])
+        depth = _colormap(outputs["depth"], normalize=True, weight=outputs["accumulation"])
+        combined_rgb = torch.cat([image, rgb], dim=1)
+        im, pr = torch.moveaxis(image, -1, 0)[None, ...], torch.moveaxis(rgb, -1, 0)[None, ...]
+        psnr = -10.0 * torch.log10(torch.mean((im - pr) ** 2))
+        metrics_dict = {"psnr": float(psnr.item()), "ssim": float(_ssim(im, pr))}
+        try:  # the reference's LearnedPerceptualImagePatchSimilarity needs torchmetrics + downloaded VGG weights
+            from torchmetrics.image.lpip import LearnedPerceptualImagePatchSimilarity
+
+            if not hasattr(self, "_lpips"):
+                object.__setattr__(self, "_lpips", LearnedPerceptualImagePatchSimilarity().to(rgb.device))
+            metrics_dict["lpips"] = float(self._lpips(im, pr))
+        except Exception:  # noqa: BLE001 -- not installed / no weights offline: the metric is omitted, never faked
+            pass
+        return metrics_dict, {"img": combined_rgb, "accumulation": acc, "depth": depth}
+
+    # ----------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
+        """nerfacto.py:691-714: the global table and the sampler state are loaded by hand from their own keys
+        (field.base_encoding_init.{feat_pool,prime_pool,bias_pool,n_volumes}; persampler.{tree_nodes_gpu,pers_trans_gpu,
+        tree_visit_cnt,milestones_ts} -- the copies under field.persampler.* are dropped), the rest goes to nn.Module."""
+        state_dict = dict(state_dict)
+        self.field.base_encoding_init.load_state_dict(state_dict, prefix="field.base_encoding_init")
+        for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts"):
+            state_dict.pop(f"field.persampler.{k}", None)
+        self.persampler.load_state_dict(state_dict)
+        for i in range(self.n_blocks):  # resident block tables travel inside the model checkpoint too
+            pre = f"field.base_encoding_{i}"
+            if f"{pre}.feat_pool" in state_dict:
+                if not hasattr(self.field, f"base_encoding_{i}"):
+                    self.field.add_table(i)
+                getattr(self.field, f"base_encoding_{i}").load_state_dict(state_dict, prefix=pre)
+                self.hot.block_prims[i] = getattr(self.field, f"base_encoding_{i}").hash_3d.prim_pool_
+        for k in [k for k in state_dict if k.startswith("lpips.") or k.startswith("field.persampler.")]:
+            del state_dict[k]   # the reference's LPIPS network weights / the second registration of the sampler's buffers
+        # the global table's primes may have been replaced (LoadStates): the engine follows; the tree came with the sampler state
+        nat = self.field.base_encoding_init.hash_3d
+        self.hot.prim, self.hot.bias = nat.prim_pool_, nat.bias_pool_
+        self._relink_tree()
+        self.hot.transes = self.persampler.sampler.pers_trans_gpu_
+        self.hot.weight_stats, self.hot.alpha_stats = self.persampler.sampler.tree_weight_stats_, self.persampler.sampler.tree_alpha_stats_
+        self.hot.visit_cnt = self.persampler.sampler.tree_visit_cnt_
+        self._params_version = None
+        self._tile_renderer = None
+        ret = super().load_state_dict(state_dict, strict)
+        self.hot.refresh_shadows()
+        return ret
+
+
+def _colormap(x, normalize=False, weight=None):
+    """utils/colormaps.py apply_colormap / apply_depth_colormap: [H,W,1] -> [H,W,3]; matplotlib's turbo when installed, grey otherwise."""
+    x = x.float()
+    if normalize:
+        lo, hi = float(x.min()), float(x.max())
+        x = (x - lo) / (hi - lo + 1e-10)
+    x = x.clamp(0, 1)
+    try:
+        from matplotlib import cm
+
+        lut = torch.tensor(cm.get_cmap("turbo")(np.linspace(0, 1, 256))[:, :3], dtype=torch.float32, device=x.device)
+        out = lut[(x[..., 0] * 255).long()]
+    except Exception:  # noqa: BLE001
+        out = x.expand(*x.shape[:-1], 3)
+    if weight is not None:
+        out = out * weight + (1 - weight)
+    return out

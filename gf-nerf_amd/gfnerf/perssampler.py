@@ -4,8 +4,8 @@
 with the reference's 18 positional arguments, GetSamples -> the 8 dense tensors of PersSampler_cuda.cu:467-476,
 UpdateOctNodes / UpdateRayMarch / UpdateMode / UpdateBlockIdxs, States / LoadStates with the reference's blobs, and
 the get_*_ accessors.  Internally samples stay packed; the dense tensors are an export for callers that want the
-reference's layout.  Not implemented yet: ProcOctree (compaction / subdivision at milestones, PersSampler.cpp:
-154-417) -- UpdateOctNodes performs K5/K6 and the statistics update only."""
+reference's layout.  `PersSampler` is the nn.Module wrapper (gfnerf/perssampler.py) with the reference's methods, buffers and
+state-dict keys, the block routing (camera clustering, nearest-split lookup) included."""
 import math
 from typing import Any, List, Mapping
 
@@ -251,8 +251,26 @@ class _Cameras:
     def get_intrinsics_matrices(self):
         return self._K
 
+    def to(self, device):
+        return _Cameras(self.camera_to_worlds.to(device), self._K.to(device))
+
+    @property
+    def device(self):
+        return self.camera_to_worlds.device
+
     def __len__(self):
         return self.camera_to_worlds.shape[0]
+
+
+class TreeNodes:
+    """perssampler.py:33-45: the per-node columns of the octree as tensors (what `tree_nodes_` returns)."""
+
+    def __init__(self, center, side_len, block_idx, trans_idx, is_leaf_node):
+        self.center = center
+        self.side_len = side_len
+        self.block_idx = block_idx
+        self.trans_idx = trans_idx
+        self.is_leaf_node = is_leaf_node
 
 
 class PersSampler(nn.Module):
@@ -396,8 +414,144 @@ class PersSampler(nn.Module):
         return destination
 
     def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
+        """perssampler.py:516-548: consumes persampler.{tree_nodes_gpu,pers_trans_gpu,tree_visit_cnt,milestones_ts} and the
+        camera poses the clustering / nearest-split lookups use (field.persampler.c2w there: the sampler is registered a second
+        time under the field; persampler.c2w is accepted too)."""
         keys = ["persampler." + k for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts")]
         states = [state_dict[k] for k in keys]
         for k in keys:
             del state_dict[k]
         self.load_states(states, idx=0)
+        for k in ("field.persampler.c2w", "persampler.c2w"):
+            if k in state_dict:
+                self.c2w = state_dict[k].to(self.device)
+                del state_dict[k]
+        for k in ("cameras_labels", "cameras_rays_nodes_centers", "cameras_valid_mask"):  # the clustering result, when it was saved
+            for pre in ("persampler.", "field.persampler."):
+                if pre + k in state_dict:
+                    setattr(self, k, state_dict.pop(pre + k))
+        return None
+
+    # ------------------------------------------------------------------ the rest of the reference's surface
+    def get_oct_split_dataset(self, cam_origin, cam_direction):
+        """perssampler.py:289-348 (its call sites are commented out, :377-381): the training camera whose optical-axis ray crosses
+        the most similar set of tree nodes -> (split, camera)."""
+        assert self.cameras_labels is not None and self.cameras_rays_nodes_centers is not None
+        dense = self.sampler.GetSamples(cam_origin.view(1, 3).to(self.device), cam_direction.view(1, 3).to(self.device), self.bounds[0, :].view(1, 2))
+        anchors = dense[5]
+        cur_centers = self.query_tree_nodes_centers(anchors[:, :, 0].reshape(-1, 1).contiguous())          # [1024,3]
+        cur_mask = (anchors[:, :, 0] > 0) & self.cameras_valid_mask                                       # [n_cams,1024]
+        dist = torch.norm(cur_centers[None] - self.cameras_rays_nodes_centers, p=2, dim=-1)               # [n_cams,1024]
+        cnt = cur_mask.sum(1)
+        mean = torch.where(cnt > 0, (dist * cur_mask).sum(1) / cnt.clamp(min=1), torch.full_like(cnt, 1e9, dtype=dist.dtype))
+        camera_idx = int(torch.argmin(mean).item())
+        return int(self.cameras_labels[camera_idx].item()), camera_idx
+
+    def vis_octree(self, base_exp_dir):
+        """perssampler.py:449-455 + PersOctree::VisOctree: camera positions and the wireframe of every leaf with a warp, as .obj."""
+        import os
+
+        assert os.path.isdir(base_exp_dir)
+        with open(os.path.join(base_exp_dir, "cam_pos.obj"), "w") as f:
+            for pos in self.c2w[:, :, 3].cpu().tolist():
+                f.write(f"v {pos[0]} {pos[1]} {pos[2]}\n")
+        nd = self.sampler._nodes_np()
+        with open(os.path.join(base_exp_dir, "octree.obj"), "w") as f:
+            for n in nd:
+                for st in range(8):
+                    off = np.array([(st >> 2 & 1) - 0.5, (st >> 1 & 1) - 0.5, (st & 1) - 0.5]) * float(n["side_len"])
+                    x, y, z = (n["center"] + off).tolist()
+                    f.write(f"v {x} {y} {z}\n")
+            for i, n in enumerate(nd):
+                if n["trans_idx"] < 0:
+                    continue
+                for a in range(8):
+                    for b in range(a + 1, 8):
+                        if (a ^ b) in (1, 2, 4):
+                            f.write(f"l {i * 8 + a + 1} {i * 8 + b + 1}\n")
+
+    def visualize_split_cameras(self, output_dir):
+        """perssampler.py:262-283 writes one .ply per camera cluster with plyfile; here the same points as ASCII .ply (positions +
+        viewing axes), no third-party writer."""
+        import os
+
+        assert self.cameras_labels is not None
+        k = int(self.cameras_labels.max().item()) + 1
+        for i in range(k):
+            m = (self.cameras_labels == i).view(-1).to(self.c2w.device)
+            pos, dirs = self.c2w[m, 0:3, -1].cpu().numpy(), self.c2w[m, :, 2].cpu().numpy()
+            with open(os.path.join(output_dir, f"camera_cluster_{i}.ply"), "w") as f:
+                f.write("ply\nformat ascii 1.0\ncomment vertices\n" + f"element vertex {pos.shape[0]}\n" +
+                        "".join(f"property float {c}\n" for c in ("x", "y", "z", "nx", "ny", "nz")) + "end_header\n")
+                for p_, d_ in zip(pos, dirs):
+                    f.write(" ".join(repr(float(v)) for v in list(p_) + list(d_)) + "\n")
+
+    def get_points_anchors(self, rays_o, rays_d, t_starts, t_ends):
+        raise NotImplementedError("K10 GetRaysTreeNodesIntersects / GetTreeNodeIdxFromTs serve the proposal sampler, which the reference never "
+                                  "creates (no `proposal_sampler` assignment anywhere in gfnerf/): dead code, not built (SURVEY 2b)")
+
+    def trans_query_frame(self, world_positions_flat, anchors_flat):
+        raise NotImplementedError("K11 TransQueryFrameKernel serves the dead proposal-sampler path (SURVEY 2b); samples leave GetSamples warped already")
+
+    def get_edge_samples(self, n_pts: int):
+        raise NotImplementedError("K9 GetEdgeSamples (F2-NeRF's TV loss) has no caller in gfnerf/ (SURVEY 2b): not built")
+
+    def to_proposal_sampler_oct_tree_nodes(self):
+        """perssampler.py:552-581: one record per tree node (the model only takes its length: n_volumes, nerfacto.py:268)."""
+        nd = self.sampler._nodes_np()
+        tr = self.sampler.pers_trans_gpu_.cpu().numpy().view(_TRANS_DT) if self.sampler.pers_trans_gpu_.numel() else None
+        out = []
+        for n in nd:
+            ti = int(n["trans_idx"])
+            trans = None if (ti < 0 or tr is None) else dict(w2xz=torch.tensor(tr["w2xz"][ti]), center=torch.tensor(tr["center"][ti]).unsqueeze(-1),
+                                                              weight=torch.tensor(tr["weight"][ti]), dis_summary=float(tr["dis_summary"][ti]))
+            out.append(dict(center=torch.tensor(n["center"]).unsqueeze(-1), side_len=float(n["side_len"]), childs=[], parent=-1,
+                            is_leaf_node=bool(n["is_leaf_node"]), visi_cams=0, pers_trans=trans))
+        return out
+
+    @property
+    def sub_div_milestones_(self):
+        return self.sampler.get_sub_div_milestones_()
+
+    @property
+    def compact_freq_(self):
+        return self.sampler.get_compact_freq_()
+
+    @property
+    def max_oct_intersect_per_ray_(self):
+        return self.sampler.get_max_oct_intersect_per_ray_()
+
+    @property
+    def global_near_(self):
+        return self.sampler.get_global_near_()
+
+    @property
+    def sample_l_(self):
+        return self.sampler.get_sample_l_()
+
+    @property
+    def scale_by_dis_(self):
+        return self.sampler.get_scale_by_dis_()
+
+    @property
+    def mode_(self):
+        return self.sampler.get_mode_()
+
+    @property
+    def n_volumes_(self):
+        return self.sampler.get_n_volumes_()
+
+    @property
+    def sampled_oct_per_ray_(self):
+        return self.sampler.get_sampled_oct_per_ray_()
+
+    @property
+    def ray_march_fineness_(self):
+        return self.sampler.get_ray_march_fineness_()
+
+    @property
+    def tree_nodes_(self):
+        nd = self.sampler._nodes_np()
+        return TreeNodes(center=torch.tensor(nd["center"]), side_len=torch.tensor(nd["side_len"]).unsqueeze(-1),
+                         block_idx=torch.tensor(nd["block_idx"]).unsqueeze(-1), trans_idx=torch.tensor(nd["trans_idx"]).unsqueeze(-1),
+                         is_leaf_node=torch.tensor(nd["is_leaf_node"].astype(bool)).unsqueeze(-1))

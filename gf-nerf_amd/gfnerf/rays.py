@@ -17,8 +17,26 @@ class RayBundle:
     pixel_area: Optional[torch.Tensor] = None
     lookat_directions: Optional[torch.Tensor] = None
 
+    @property
+    def shape(self):
+        return tuple(self.origins.shape[:-1])
+
     def __len__(self):
-        return self.origins.shape[0]
+        n = 1
+        for d in self.origins.shape[:-1]:
+            n *= int(d)
+        return n
+
+    def _map(self, fn):
+        return RayBundle(**{k: (fn(v) if isinstance(v, torch.Tensor) else v) for k, v in self.__dict__.items()})
+
+    def flatten(self):
+        """[..., C] -> [N, C] for every tensor field (TensorDataclass.flatten)."""
+        return self._map(lambda v: v.reshape(-1, v.shape[-1]))
+
+    def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int):
+        """rays.py RayBundle.get_row_major_sliced_ray_bundle: rays [start, end) of the flattened (row-major) image."""
+        return self.flatten()._map(lambda v: v[start_idx:end_idx])
 
 
 @dataclass

@@ -72,6 +72,7 @@ class HotPath:
         torch.distributed is not initialised): the global stage exchanges octree statistics (MAX) and gradients (mean)
         through it, so N ranks that start from the same seed stay bit-identical replicas."""
         self.cfg = cfg or HotPathConfig()
+        self._seed = seed
         self.sync = sync if sync is not None else gdist.TrainSync()
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
@@ -136,16 +137,39 @@ class HotPath:
         self.timings = {}
         self._last_train_ctx = None
 
+    def add_block(self, i, table=None, prims=None):
+        """GFNeRFField.add_table (nerfacto_field.py:336-347): make residual block table i resident -- zeros and fresh primes
+        (Hash3DAnchored.cpp:43-50) unless given (load_table)."""
+        T = self.cfg.log2_T
+        while len(self.blocks) <= i:
+            self.blocks.append(None); self.block_prims.append(None)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
+        self.blocks[i] = torch.zeros((16 * (1 << T), 2), dtype=torch.float32, device=self.dev) if table is None else table
+        if prims is None:
+            prims = self.prim if self.cfg.share_block_primes else t(scene.make_primes(self.n_volumes, seed=self._seed + 100 + i))
+        self.block_prims[i] = prims
+        self.refresh_shadows()
+        return self.blocks[i]
+
+    def drop_block(self, i):
+        """GFNeRFField.del_table (:349-365): release block i's table, its f16 shadow and its optimiser state."""
+        self._sync_opt()
+        if i < len(self.blocks):
+            self.blocks[i] = None; self.block_prims[i] = None
+            if i < len(self.blocks16):
+                self.blocks16[i] = None
+        self.delete_optimizer(f"block{i}")
+
     def refresh_shadows(self):
         """(Re)build the f16 shadow tables after the masters were written from outside the optimiser."""
         if self.cfg.table_f16_shadow:
             self.table16 = ops.table_to_f16(self.table, self.table16)
             if len(self.blocks16) != len(self.blocks):
-                self.blocks16 = [None] * len(self.blocks)
+                self.blocks16 = (self.blocks16 + [None] * len(self.blocks))[: len(self.blocks)]
             if self.cfg.share_block_primes:  # global + block interleaved per slot (one 8-byte gather per corner)
-                self.blocks16 = [ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+                self.blocks16 = [None if b is None else ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
             else:
-                self.blocks16 = [ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
+                self.blocks16 = [None if b is None else ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
         self._pairs_stale = False
         self._x3_stale = True  # callers use this hook after writing parameters from outside the optimiser
 
@@ -186,8 +210,8 @@ class HotPath:
         """Host copies of every parameter / state blob (for checkpoints and for the test oracle)."""
         self._sync_opt()
         c = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
-        return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[c(b) for b in self.blocks],
-                    block_prims=[c(p) for p in self.block_prims],
+        return dict(nodes=c(self.nodes), transes=c(self.transes), table=c(self.table), blocks=[None if b is None else c(b) for b in self.blocks],
+                    block_prims=[None if p is None else c(p) for p in self.block_prims],
                     prim=c(self.prim), bias=c(self.bias), layers=[(c(W), c(B)) for W, B in self.layers], emb=c(self.emb))
 
     # ------------------------------------------------------------------ sampling

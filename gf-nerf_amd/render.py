@@ -27,7 +27,8 @@ class TileRenderer:
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
-        self.hp, self.c2w, self.intr = hp, c2w.contiguous(), intr.contiguous()
+        self.hp = hp
+        self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
         self.T, self.block, self.early_T = int(tile_rays), block, early_T
         # a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (0 = a raster run): neighbouring rays cross the
         # same table cells, and the fused forward keeps each eighth of the tile (a strip of rows) on one XCD's L2
@@ -49,7 +50,7 @@ class TileRenderer:
         hp = self.hp
         if self.P == 1:
             out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T)
-            return [(out["rgb"], out["accumulation"], out["depth"])]
+            return [(out["rgb"], out["accumulation"], out["depth"], out["oct_depth"])]
         from . import _lib
 
         main, side = torch.cuda.current_stream(), self._side
@@ -67,7 +68,7 @@ class TileRenderer:
             for i in range(self.P):  # consumer branch: the fused forward of tile i beside the samplers of the tiles after it
                 main.wait_event(done[i])
                 out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i])
-                outs.append((out["rgb"], out["accumulation"], out["depth"]))
+                outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
             main.wait_stream(side)
             self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
         finally:
@@ -90,14 +91,23 @@ class TileRenderer:
     def render_camera(self, cam, height, width, embed_idx=None):
         """One image of camera `cam` -> dict(rgb [H,W,3], accumulation [H,W], depth [H,W]) on the device.
         embed_idx: appearance-embedding row (render.py --embedding-indices); default = the camera's own index."""
-        hp, T = self.hp, self.T
         n = height * width
         rays = ops.generate_rays(self.c2w, self.intr, cam0=int(cam), first_pixel=0, width=int(width), n=n, want_extras=False)
-        O, D = rays["origins"], rays["directions"]
-        self.cam.fill_(int(cam if embed_idx is None else embed_idx))
+        out = self.render_rays(rays["origins"], rays["directions"], int(cam if embed_idx is None else embed_idx), height, width)
+        return dict(rgb=out["rgb"], accumulation=out["accumulation"].view(height, width), depth=out["depth"].view(height, width))
+
+    @torch.no_grad()
+    def render_rays(self, O, D, embed_idx, height, width):
+        """The rays of one image, row major: O, D f32 [H*W,3] on the device; embed_idx: the appearance-embedding row of the
+        whole image -> dict(rgb [H,W,3], accumulation / depth / oct_depth [H,W,1])."""
+        hp, T = self.hp, self.T
+        n = height * width
+        O, D = O.reshape(n, 3), D.reshape(n, 3)
+        self.cam.fill_(int(embed_idx))
         rgb = torch.empty((n, 3), dtype=torch.float32, device=hp.dev)
         acc = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         depth = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
+        octd = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         if self.use_graph and self.graph is None:
             self.o.copy_((O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))[None].expand_as(self.o))
             self.d.copy_((D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))[None].expand_as(self.d))
@@ -105,7 +115,7 @@ class TileRenderer:
         if self.tw:
             tw, th = self.tw, T // self.tw
             O2, D2 = O.view(height, width, 3), D.view(height, width, 3)
-            rgb2, acc2, dep2 = rgb.view(height, width, 3), acc.view(height, width, 1), depth.view(height, width, 1)
+            rgb2, acc2, dep2, oct2 = rgb.view(height, width, 3), acc.view(height, width, 1), depth.view(height, width, 1), octd.view(height, width, 1)
             tiles = [(y, min(y + th, height), x, min(x + tw, width)) for y in range(0, height, th) for x in range(0, width, tw)]
         else:
             tiles = [(a, min(a + T, n), 0, 0) for a in range(0, n, T)]
@@ -135,14 +145,16 @@ class TileRenderer:
             else:
                 outs = self._tile()
             for i, (a, b, x0, x1) in enumerate(tiles[g0:g0 + P]):
-                t_rgb, t_acc, t_depth = outs[i]
+                t_rgb, t_acc, t_depth, t_oct = outs[i]
                 m = sizes[i]
                 if self.tw:
                     h, w = b - a, x1 - x0
                     rgb2[a:b, x0:x1] = t_rgb[:m].view(h, w, 3); acc2[a:b, x0:x1] = t_acc[:m].view(h, w, 1); dep2[a:b, x0:x1] = t_depth[:m].view(h, w, 1)
+                    oct2[a:b, x0:x1] = t_oct[:m].view(h, w, 1)
                 else:
-                    rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m])
-        return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width), depth=depth.view(height, width))
+                    rgb[a:b].copy_(t_rgb[:m]); acc[a:b].copy_(t_acc[:m]); depth[a:b].copy_(t_depth[:m]); octd[a:b].copy_(t_oct[:m])
+        return dict(rgb=rgb.view(height, width, 3), accumulation=acc.view(height, width, 1), depth=depth.view(height, width, 1),
+                    oct_depth=octd.view(height, width, 1))
 
     def render_path(self, cams, height, width, world_size=1, rank=0, owners=None):
         """Camera path sharded over ranks by frame -> {frame index: outputs} of this rank's frames.  owners[f] (see

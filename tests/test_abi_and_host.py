@@ -167,32 +167,3 @@ def test_matrix_kernels_do_not_spill():
         scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
         assert spills and all(s == 0 for s in spills), (src, spills)
         assert all(s == 0 for s in scratch), (src, scratch)
-
-
-def test_method_registration_is_discovered_like_the_reference_registry_test():
-    """tests/plugins/test_registry.py:27-51 of the reference: an entry point of group `nerfstudio.method_configs` is loaded and
-    must yield a MethodSpecification whose config carries the method name.  Here the entry point is the one the reference's
-    pyproject.toml:174-176 declares (gf-nerf = gfnerf.config:gfnerf_config), resolved against this package's mirror."""
-    from importlib import metadata as importlib_metadata
-
-    import gfnerf_amd  # noqa: F401
-    from gfnerf_amd.gfnerf import config as gcfg
-
-    eps = importlib_metadata.EntryPoints([
-        importlib_metadata.EntryPoint(name="gf-nerf", value="gfnerf_amd.gfnerf.config:gfnerf_config", group="nerfstudio.method_configs"),
-        importlib_metadata.EntryPoint(name="not-a-method", value="gfnerf_amd.gfnerf.config:N_BLOCKS", group="nerfstudio.method_configs"),
-    ]).select(group="nerfstudio.method_configs")
-    methods, descriptions = gcfg.discover_methods(eps)
-    assert list(methods) == ["gf-nerf"] and descriptions["gf-nerf"] == "Nerfacto with depth supervision for multi cameras"
-    cfg = methods["gf-nerf"]
-    assert isinstance(cfg, gcfg.TrainerConfig) and cfg.max_num_iterations == 130000 and cfg.mixed_precision is False
-    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipeline
-    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModel
-
-    assert cfg.pipeline._target is GFNerfPipeline and cfg.pipeline.model._target is GFNeRFModel
-    m = cfg.pipeline.model
-    assert (m.n_blocks, m.log2_hashmap_size, m.hidden_dim, m.scale_factor, m.steps_perssampler_init) == (10, 21, 128, 10.0, 30000)
-    assert cfg.pipeline.datamanager.train_num_rays_per_batch == 8192
-    opt, sch = cfg.optimizers["fields"]["optimizer"], cfg.optimizers["fields"]["scheduler"]
-    assert (opt.lr, opt.eps) == (1e-2, 1e-15) and (sch.lr_final, sch.max_steps, sch.n_split_dataset) == (1e-4, 30000, 10)
-    assert sch.setup() is not None

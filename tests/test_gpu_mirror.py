@@ -204,12 +204,11 @@ def test_field_piecewise_api_matches_engine(dev, sampler):
     ps.sampler.ray_march_fineness_ = 6.0
     n_cams = sc["c2w"].shape[0]
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=n_cams, cfg=hotpath.HotPathConfig(log2_T=13, early_T=0.0), seed=2)
-    fld = GFNeRFField(num_images=n_cams, log2_hashmap_size=13, n_volumes=hp.n_volumes, device=dev, steps_perssampler_init=1000)
-    with torch.no_grad():  # same parameters
-        fld.base_encoding_init.load_states([hp.table, hp.prim, hp.bias, torch.tensor([hp.n_volumes], dtype=torch.int32)], 0)
-        for layer, (W, b) in zip(list(fld.base_network.layers) + list(fld.mlp_head.layers), hp.layers):
-            layer.weight.copy_(W); layer.bias.copy_(b)
-        fld.embedding_appearance.weight.copy_(hp.emb)
+    # the reference's positional order (aabb, num_images, ...) with the method config's sizes; engine=hp: the field's tensors ARE the engine's
+    fld = GFNeRFField(None, n_cams, hidden_dim=128, hidden_dim_color=128, log2_hashmap_size=13, use_appearance_embedding=True,
+                      n_volumes=hp.n_volumes, device=dev, steps_perssampler_init=1000, engine=hp)
+    assert fld.base_encoding_init.hash_3d.feat_pool_.data_ptr() == hp.table.data_ptr()
+    assert fld.mlp_head.layers[2].weight.data_ptr() == hp.layers[4][0].data_ptr() and fld.embedding_appearance.weight.data_ptr() == hp.emb.data_ptr()
     R = 64
     o, d, cam = rays_for(sc, R, seed=9)
     rb = RayBundle(origins=_t(o, dev), directions=_t(d, dev), camera_indices=_t(cam, dev)[:, None], rel_camera_indices=_t(cam, dev)[:, None],
@@ -234,28 +233,47 @@ def test_field_piecewise_api_matches_engine(dev, sampler):
     assert all(g is not None and torch.isfinite(g).all() for g in grads) and len(grads) == 12
 
 
-def test_model_get_outputs_and_training_loop(oracle, dev):
-    """GFNeRFModel.get_outputs through the reference's Trainer contract: loss_dict -> backward -> torch.optim.Adam."""
+def _small_pipeline(dev, n_blocks=2, images=None, error_maps=None, rays=256, base_dir="", intrinsics=None, **model_kw):
+    """A pipeline built the way the reference's Trainer builds it: config.pipeline.setup(device=, test_mode=, world_size=,
+    local_rank=, base_dir=) -> GFNerfPipeline(config, device, ...) -> config.datamanager.setup(...) / config.model.setup(...)."""
+    from gfnerf_amd import scene
+    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipelineConfig, HbmDataManagerConfig
+    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
+
+    c2w, intri, _ = scene.make_cameras(n_side=5, seed=3)
+    mk = dict(log2_hashmap_size=13, hidden_dim=128, hidden_dim_color=128, steps_perssampler_init=6, steps_per_split_dataset=4, n_split_dataset=n_blocks,
+              n_blocks=n_blocks, early_T=0.0, scale_factor=10.0, use_appearance_embedding=True, use_ch_loss=True, s3im_loss_mult=1.0,
+              eval_num_rays_per_chunk=2048)
+    mk.update(model_kw)
+    intri = intri if intrinsics is None else intrinsics
+    cfg = GFNerfPipelineConfig(datamanager=HbmDataManagerConfig(c2w=c2w, intrinsics=intri, images=images, error_maps=error_maps, train_num_rays_per_batch=rays),
+                               model=GFNeRFModelConfig(**mk))
+    return cfg.setup(device=str(dev), test_mode="val", world_size=1, local_rank=0, base_dir=base_dir), c2w, intri
+
+
+def test_model_get_outputs_and_training_loop(oracle, dev, tmp_path):
+    """GFNeRFModel through the reference's Trainer contract: pipeline.get_param_groups -> Optimizers, get_training_callbacks,
+    get_train_loss_dict -> sum(loss_dict) -> backward -> optimizer_step_all, callbacks before / after every iteration
+    (trainer.py:195-231,382-441); global stage, then the focal blocks with their own optimisers at lr 5e-3."""
     import sys, os
     import torch
 
-    from gfnerf_amd import scene
-    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipeline
-    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
+    from gfnerf_amd.gfnerf import _host
+    from gfnerf_amd.gfnerf._host import AdamOptimizerConfig, Optimizers, TrainingCallbackAttributes, TrainingCallbackLocation
+    from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import pipeline as opipe
 
-    c2w, intri, _ = scene.make_cameras(n_side=5, seed=3)
-    cfg = GFNeRFModelConfig(log2_hashmap_size=13, steps_perssampler_init=6, steps_per_split_dataset=4, n_split_dataset=2,
-                            n_blocks=2, resident_blocks=[0, 1], early_T=0.0)
-    pipe = GFNerfPipeline(cfg, c2w, intri, device=dev, rays_per_batch=256)
+    pipe, c2w, intri = _small_pipeline(dev, keep_blocks_resident=False, base_dir=str(tmp_path))
     model = pipe.model
+    assert _host.HOST is None and type(model).__mro__[1] is _host.Model and model.num_train_data == 25
+    assert model.field.base_encoding_init.hash_3d.feat_pool_.data_ptr() == model.hot.table.data_ptr()  # one set of tensors
     # eval forward == oracle render on the exported parameters (VALIDATE noise)
     model.eval()
     model.persampler.update_mode(1)
     model.persampler.sampler.ray_march_fineness_ = 6.0
-    rb, batch = pipe.datamanager.next_train(0)
+    rb, batch, _ = pipe.datamanager.next_train(0)
     rb.steps = None
     out = model(rb)
     P = model.hot.export_params()
@@ -264,32 +282,122 @@ def test_model_get_outputs_and_training_loop(oracle, dev):
     assert set(out) == {"rgb", "accumulation", "depth", "oct_depth"} and out["rgb"].shape == (256, 3) and out["depth"].shape == (256, 1)
     np.testing.assert_allclose(out["rgb"].cpu().numpy(), ref["rgb"], atol=1e-4)
     np.testing.assert_allclose(out["depth"].cpu().numpy()[:, 0], ref["depth"], rtol=1e-4, atol=1e-4)
-    # training: global stage (steps 0..5) then focal blocks 0 and 1, optimiser = torch.optim.Adam over get_param_groups
+    # parameter groups with the reference's names (nerfacto.py:303-321)
+    groups = pipe.get_param_groups()
+    assert list(groups) == ["fields", "base_encoding_init"] and len(groups["fields"]) == 11 and len(groups["base_encoding_init"]) == 1
+    assert groups["base_encoding_init"][0].data_ptr() == model.hot.table.data_ptr()
+    # the Trainer's objects
+    sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=6, n_split_dataset=2, n_dataset_circles=1, steps_per_split_dataset=4,
+                                                  steps_perssampler_init=6)
+    optimizers = Optimizers({"fields": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": sched}}, groups)
+    assert set(optimizers.optimizers) == {"fields", "base_encoding_init"}
+    callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
+    assert len(callbacks) == 5
     model.train()
     model.persampler.update_mode(0)
-    opt = torch.optim.Adam(pipe.get_param_groups()["fields"], lr=1e-2, eps=1e-15)
-    pipe.datamanager.next_train = (lambda f: (lambda step: f(0)))(pipe.datamanager.next_train)  # fixed batch: loss must fall
-    hist = []
-    table0 = model.feat_pool.detach().clone()
-    block0 = model.block_pools[0].detach().clone()
+    pipe.datamanager.next_train = (lambda f: (lambda step: f(0)))(pipe.datamanager.next_train)  # fixed batch: the loss must fall
+    hist, seen_groups = [], []
+    table0 = model.hot.table.detach().clone()
     for step in range(14):
-        rb, batch = pipe.datamanager.next_train(step)
-        rb.steps = torch.full((256, 1), step, dtype=torch.int64, device=dev)
-        opt.zero_grad(set_to_none=True)
-        outputs, loss_dict, metrics = pipe.get_train_loss_dict.__func__(pipe, step) if False else (None, None, None)
-        outputs = model(rb)
-        loss = model.get_loss_dict(outputs, batch)["rgb_loss"]
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        optimizers.zero_grad_all()
+        outputs, loss_dict, metrics = pipe.get_train_loss_dict(step)
+        assert set(loss_dict) == {"rgb_loss", "s3im_loss"} and "psnr" in metrics  # nerfacto.py:636,687-688
+        loss = sum(loss_dict.values())
         loss.backward()
         if step < 6:
-            assert model.feat_pool.grad is not None and model.mlp_params.grad is not None and model.block_pools[0].grad is None
+            assert model.field.cur_stage == "init_stage"
+            assert all(p.grad is not None for p in groups["fields"]) and model.hot.table.grad is not None
         else:
             blk = ((step - 6) // 4) % 2
-            assert model.block_pools[blk].grad is not None and model.feat_pool.grad is None and model.mlp_params.grad is None
-        opt.step()
+            assert model.field.cur_stage == "block_stage" and model.field.active_block_idxs == [blk]
+            g = getattr(model.field, f"base_encoding_{blk}").hash_3d.feat_pool_.grad
+            assert g is not None and float(g.abs().max()) > 0
+        optimizers.optimizer_step_all()
+        optimizers.scheduler_step_all(step)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        seen_groups.append(sorted(optimizers.optimizers))
         hist.append(float(loss))
-    assert hist[5] < hist[0] and hist[9] < hist[6], hist
-    assert not torch.equal(model.feat_pool.detach(), table0) and not torch.equal(model.block_pools[0].detach(), block0)
-    assert float(model.get_metrics_dict(outputs, batch)["psnr"]) > 0
+    assert hist[5] < hist[0] and hist[9] < hist[7] and hist[13] < hist[11], hist  # (the batch changes with the camera cluster at 7 and 11)
+    assert not torch.equal(model.hot.table.detach(), table0)
+    # update_optimizer (nerfacto.py:448-488): global stage keeps the table + fields; a block stage keeps only its block, at lr 5e-3
+    assert seen_groups[0] == ["base_encoding_init", "fields"] and seen_groups[7] == ["base_encoding_0"] and seen_groups[11] == ["base_encoding_1"]
+    assert optimizers.optimizers["base_encoding_1"].param_groups[0]["initial_lr"] == 5e-3
+    # the cameras were clustered at the stage switch and block 0 went to disk when block 1 took over (keep_blocks_resident=False)
+    assert model.persampler.cameras_labels is not None and sorted(np.bincount(model.persampler.cameras_labels.view(-1).numpy()).tolist()) == [12, 13]
+    assert (tmp_path / "encodings_ckpt" / "base_encoding_0.ckpt").exists() and not hasattr(model.field, "base_encoding_0")
+    assert pipe.datamanager.cams is not None and set(model.persampler.cameras_labels.view(-1)[pipe.datamanager.cams].tolist()) == {1}  # block 1's rays come from cluster 1
+    # S3IM through get_loss_dict = the device kernel's value with the same permutation (golden-pinned in test_gpu_parity)
+    from gfnerf_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    model._s3im_gen.manual_seed(5)
+    idx = ops.s3im_index(256, 10, generator=g, device=dev)
+    pred = outputs["rgb"].detach()
+    want, _ = ops.s3im(batch["image"], pred.contiguous(), idx, patch_h=32, mult=1.0)
+    got = model.get_loss_dict({"rgb": pred}, batch)["s3im_loss"]
+    np.testing.assert_allclose(float(got), float(want), rtol=1e-6)
+
+
+def test_model_state_dict_routing_and_full_image_outputs(dev, tmp_path):
+    """load_state_dict (nerfacto.py:691-714) with the reference's key names; get_outputs_for_camera_ray_bundle
+    (base_model.py:163-186) through the hipGraph tile renderer against the chunked loop of the base class;
+    get_image_metrics_and_images (nerfacto.py:716-747)."""
+    import torch
+
+    from gfnerf_amd.gfnerf import _host
+    from gfnerf_amd.gfnerf.rays import RayBundle
+
+    pipe, c2w, intri = _small_pipeline(dev, n_blocks=2)
+    model = pipe.model
+    model.train()
+    rb, batch, _ = pipe.datamanager.next_train(0)
+    model(rb)  # registers field.persampler like the reference's first get_outputs
+    sd = pipe.state_dict()
+    keys = set(sd)
+    for k in ("feat_pool", "prime_pool", "bias_pool", "n_volumes"):
+        assert f"_model.field.base_encoding_init.{k}" in keys
+    for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts", "c2w"):
+        assert f"_model.persampler.{k}" in keys
+    for k in ("base_network.layers.0.weight", "base_network.layers.1.bias", "mlp_head.layers.2.weight", "embedding_appearance.embedding.weight",
+              "aabb", "max_res", "num_levels", "log2_hashmap_size"):
+        assert f"_model.field.{k}" in keys, k
+    assert "_model.device_indicator_param" in keys
+    # a second pipeline (different initialisation) takes the checkpoint and renders the same image
+    pipe2, _, _ = _small_pipeline(dev, n_blocks=2, engine_seed=9)
+    ck = {k: v.clone() for k, v in sd.items()}
+    ck["_model.field.persampler.tree_nodes_gpu"] = ck["_model.persampler.tree_nodes_gpu"]  # the reference's second registration of the sampler
+    ck["_model.field.persampler.pers_trans_gpu"] = ck["_model.persampler.pers_trans_gpu"]
+    ck["_model.field.persampler.tree_visit_cnt"] = ck["_model.persampler.tree_visit_cnt"]
+    ck["_model.field.persampler.milestones_ts"] = ck["_model.persampler.milestones_ts"]
+    ck["_model.field.persampler.c2w"] = ck.pop("_model.persampler.c2w")
+    ck["_model.lpips.net.slice1.0.weight"] = torch.zeros(3)  # the reference checkpoints carry the LPIPS network; dropped
+    pipe2.load_pipeline({k.replace("_model.", "_model.module.", 1) if k.endswith("device_indicator_param") else k: v for k, v in ck.items()}, step=100)  # a DDP-era "module." is stripped
+    m2 = pipe2.model
+    assert torch.equal(m2.hot.table, model.hot.table) and torch.equal(m2.hot.prim, model.hot.prim) and torch.equal(m2.hot.mlp_flat, model.hot.mlp_flat)
+    assert torch.equal(m2.hot.emb, model.hot.emb) and torch.equal(m2.hot.nodes, model.hot.nodes)
+    # full image: 40 x 56 rays of camera 3, first through the base class's chunk loop, then through the tile renderer
+    H, W = 40, 56
+    from gfnerf_amd import ops
+    intr = torch.tensor([[60.0, 60.0, W / 2, H / 2]] * c2w.shape[0], device=dev)
+    rays = ops.generate_rays(torch.from_numpy(c2w).to(dev), intr, cam0=3, first_pixel=0, width=W, n=H * W, want_extras=False)
+    cam = torch.full((H, W, 1), 3, dtype=torch.int32, device=dev)
+    crb = RayBundle(origins=rays["origins"].view(H, W, 3), directions=rays["directions"].view(H, W, 3), camera_indices=cam, rel_camera_indices=cam)
+    for m in (model, m2):
+        m.eval(); m.persampler.update_mode(1); m.persampler.sampler.ray_march_fineness_ = 5.0
+    base = _host.Model.get_outputs_for_camera_ray_bundle(model, crb)
+    tiled = m2.get_outputs_for_camera_ray_bundle(crb)
+    assert set(base) == set(tiled) == {"rgb", "accumulation", "depth", "oct_depth"}
+    for k in base:
+        assert base[k].shape == tiled[k].shape == (H, W, 3 if k == "rgb" else 1)
+        np.testing.assert_allclose(tiled[k].cpu().numpy(), base[k].cpu().numpy(), atol=2e-5, rtol=1e-5)
+    gt = torch.rand((H, W, 3), device=dev)
+    metrics, images = model.get_image_metrics_and_images(tiled, {"image": gt})
+    assert {"psnr", "ssim"} <= set(metrics) and 0 < metrics["psnr"] < 60 and -1 <= metrics["ssim"] <= 1
+    assert images["img"].shape == (H, 2 * W, 3) and images["accumulation"].shape == (H, W, 3) and images["depth"].shape == (H, W, 3)
+    same, _ = model.get_image_metrics_and_images({**tiled, "rgb": gt.clone()}, {"image": gt})
+    assert same["ssim"] > 0.9999
 
 
 def _w2c_of(c2w):
@@ -380,45 +488,52 @@ def test_update_oct_nodes_milestone_runs_proc_octree(oracle, dev):
 
 def test_pipeline_with_image_stack_datamanager(dev):
     """get_train_loss_dict over an HBM-resident image stack: PixelSampler in the init stage, ErrorPixelSampler + error-map
-    write-back in the block stage (gf_pipeline.py:146-192), rays generated from the sampled pixels."""
+    write-back in the block stage (gf_pipeline.py:146-192), rays generated from the sampled pixels; after the switch to the
+    block stage the update_datamanager callback restricts the stack to the active block's camera cluster."""
     import torch
 
     from gfnerf_amd import scene
-    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipeline, ImageStackDataManager
-    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
+    from gfnerf_amd.gfnerf._host import AdamOptimizerConfig, Optimizers, TrainingCallbackAttributes, TrainingCallbackLocation
 
     c2w, intri, _ = scene.make_cameras(n_side=5, seed=3)
     n, H, W = c2w.shape[0], 36, 48
     K = intri.copy()
     K[:, 0, 0] *= W / 1152.0; K[:, 1, 1] *= W / 1152.0; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
-    intr = torch.from_numpy(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32)).to(dev)
     gen = torch.Generator(device=dev).manual_seed(9)
     images = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
     em0 = torch.full((n, H, W, 1), 0.5, device=dev)
-    cfg = GFNeRFModelConfig(log2_hashmap_size=13, steps_perssampler_init=3, steps_per_split_dataset=4, n_split_dataset=2, n_blocks=2,
-                            resident_blocks=[0, 1], early_T=0.0)
-    dm = ImageStackDataManager(images, torch.from_numpy(c2w).to(dev), intr, rays_per_batch=256, error_maps=em0.clone(), generator=gen)
-    pipe = GFNerfPipeline(cfg, c2w, K, device=dev, rays_per_batch=256, datamanager=dm)
-    model = pipe.model
+    pipe, _, _ = _small_pipeline(dev, n_blocks=2, images=images, error_maps=em0.clone(), intrinsics=K, steps_perssampler_init=3)
+    model, dm = pipe.model, pipe.datamanager
     model.train(); model.persampler.update_mode(0)
-    opt = torch.optim.Adam(pipe.get_param_groups()["fields"], lr=1e-2, eps=1e-15)
+    optimizers = Optimizers({"fields": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None}}, pipe.get_param_groups())
+    callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
     touched = 0
     for step in range(6):
-        opt.zero_grad(set_to_none=True)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        optimizers.zero_grad_all()
         before = dm.error_map.map.clone()
         outputs, loss_dict, metrics = pipe.get_train_loss_dict(step)
         assert outputs["rgb"].shape == (256, 3) and torch.isfinite(loss_dict["rgb_loss"])
         sum(loss_dict.values()).backward()
-        opt.step()
+        optimizers.optimizer_step_all()
         changed = int((dm.error_map.map != before).sum())
         if model.field.cur_stage == "block_stage":
             assert 200 <= changed <= 256  # one error per sampled pixel (duplicates across the two groups aside)
             touched += changed
         else:
             assert changed == 0
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        if step >= 3:  # block stage: the cached stack now holds block 0's cluster only, and only its cameras are drawn
+            labels = model.persampler.cameras_labels.view(-1)
+            assert dm.image_batch["image"].shape[0] == int((labels == 0).sum()) and set(labels[dm.image_batch["image_idx"].long().cpu()].tolist()) == {0}
     assert touched > 0 and float(dm.error_map.map.max()) <= 3.0
     np.testing.assert_allclose(dm.error_map.block_sums.cpu().numpy(),
                                __import__("gfnerf_amd").ops.errmap_block_sums(dm.error_map.map).cpu().numpy(), rtol=1e-12)
+    # render_init_error_maps ran at the switch (nerfacto.py:354-430): every training image got a |gt - pred| map from a 1/8-resolution render
+    assert dm._all["error_maps"].shape == (n, H, W, 1) and float(dm._all["error_maps"].min()) >= 0 and float(dm._all["error_maps"].max()) <= 3.0
+    assert float(dm._all["error_maps"].std()) > 0
 
 
 def test_block_table_checkpoints_round_trip(dev, tmp_path):
@@ -429,7 +544,7 @@ def test_block_table_checkpoints_round_trip(dev, tmp_path):
 
     from gfnerf_amd.gfnerf.nerfacto_field import GFNeRFField
 
-    fld = GFNeRFField(num_images=4, log2_hashmap_size=12, n_volumes=7, n_blocks=3, device=dev, base_dir=str(tmp_path), steps_perssampler_init=10)
+    fld = GFNeRFField(None, 4, log2_hashmap_size=12, n_volumes=7, n_blocks=3, device=dev, base_dir=str(tmp_path), steps_perssampler_init=10)
     fld.train()
     fld.update_active_blocks(1)
     assert fld.active_block_idxs == [1] and hasattr(fld, "base_encoding_1") and not hasattr(fld, "base_encoding_0")
