@@ -134,7 +134,7 @@ class ImageStackDataManager(_DataManagerBase):
         self._all["error_maps"] = maps[..., None] if maps.dim() == 3 else maps
         self._select(None)
 
-    def train_images_for_error_maps(self, down_scale_factor=8, step=0):
+    def train_images_for_error_maps(self, down_scale_factor=8, step=None):
         """(gt image [H,W,3] in [0,1], RayBundle of every `down_scale_factor`-th pixel [h,w,.]) per training image (:383-391)."""
         imgs, idx = self._all["image"], self._all["image_idx"]
         H, W = imgs.shape[1:3]
@@ -148,8 +148,9 @@ class ImageStackDataManager(_DataManagerBase):
             shp = (ys.numel(), xs.numel())
             cam_t = torch.full(shp + (1,), cam, dtype=torch.int32, device=imgs.device)
             gt = imgs[k].float() / 255.0 if imgs.dtype == torch.uint8 else imgs[k]
+            steps = None if step is None else torch.full(shp + (1,), int(step), dtype=torch.int64, device=imgs.device)
             yield gt, RayBundle(origins=rays["origins"].view(*shp, 3), directions=rays["directions"].view(*shp, 3), camera_indices=cam_t,
-                                rel_camera_indices=cam_t, steps=None)
+                                rel_camera_indices=cam_t, steps=steps)
 
     def next_train(self, step):
         rays, batch, ray_indices = data.next_train(self.image_batch, self.train_pixel_sampler, self.train_ray_generator)

@@ -396,11 +396,14 @@ class GFNeRFModel(Model):
         from .. import render as rmod
 
         H, W = camera_ray_bundle.origins.shape[:2]
-        o, d, _ = self._bundle(camera_ray_bundle)
+        o, d, step = self._bundle(camera_ray_bundle)
         blk = None
         nearest = 0
-        if self.persampler.cameras_labels is not None or self.field.cur_stage == "block_stage":
+        if step >= 0:  # a bundle stamped with a training step (render_init_error_maps, nerfacto.py:392-394): that step's stage and block
+            stage, blk = self.stage_of(step)
+        elif self.persampler.cameras_labels is not None or self.field.cur_stage == "block_stage":
             blk, nearest = self.persampler.split_of_origin(o[0], None)
+        if blk is not None:
             was = self.field.training
             self.field.train(False)
             try:

@@ -416,16 +416,15 @@ class PersSampler(nn.Module):
     def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
         """perssampler.py:516-548: consumes persampler.{tree_nodes_gpu,pers_trans_gpu,tree_visit_cnt,milestones_ts} and the
         camera poses the clustering / nearest-split lookups use (field.persampler.c2w there: the sampler is registered a second
-        time under the field; persampler.c2w is accepted too)."""
+        time under the field)."""
         keys = ["persampler." + k for k in ("tree_nodes_gpu", "pers_trans_gpu", "tree_visit_cnt", "milestones_ts")]
         states = [state_dict[k] for k in keys]
         for k in keys:
             del state_dict[k]
         self.load_states(states, idx=0)
-        for k in ("field.persampler.c2w", "persampler.c2w"):
-            if k in state_dict:
-                self.c2w = state_dict[k].to(self.device)
-                del state_dict[k]
+        if "field.persampler.c2w" in state_dict:  # :533-534; the copy under persampler.c2w is a registered buffer and loads with the module
+            self.c2w = state_dict["field.persampler.c2w"].to(self.device)
+            del state_dict["field.persampler.c2w"]
         for k in ("cameras_labels", "cameras_rays_nodes_centers", "cameras_valid_mask"):  # the clustering result, when it was saved
             for pre in ("persampler.", "field.persampler."):
                 if pre + k in state_dict:

@@ -295,7 +295,14 @@ def test_model_get_outputs_and_training_loop(oracle, dev, tmp_path):
     assert len(callbacks) == 5
     model.train()
     model.persampler.update_mode(0)
-    pipe.datamanager.next_train = (lambda f: (lambda step: f(0)))(pipe.datamanager.next_train)  # fixed batch: the loss must fall
+    def fixed_batch(f):  # the same rays every step (the loss must fall), stamped with the trainer's step
+        def nxt(step):
+            rb_, batch_, idx_ = f(0)
+            rb_.steps = torch.full_like(rb_.steps, step)
+            return rb_, batch_, idx_
+        return nxt
+
+    pipe.datamanager.next_train = fixed_batch(pipe.datamanager.next_train)
     hist, seen_groups = [], []
     table0 = model.hot.table.detach().clone()
     for step in range(14):
@@ -371,7 +378,7 @@ def test_model_state_dict_routing_and_full_image_outputs(dev, tmp_path):
     ck["_model.field.persampler.pers_trans_gpu"] = ck["_model.persampler.pers_trans_gpu"]
     ck["_model.field.persampler.tree_visit_cnt"] = ck["_model.persampler.tree_visit_cnt"]
     ck["_model.field.persampler.milestones_ts"] = ck["_model.persampler.milestones_ts"]
-    ck["_model.field.persampler.c2w"] = ck.pop("_model.persampler.c2w")
+    ck["_model.field.persampler.c2w"] = ck["_model.persampler.c2w"].clone()
     ck["_model.lpips.net.slice1.0.weight"] = torch.zeros(3)  # the reference checkpoints carry the LPIPS network; dropped
     pipe2.load_pipeline({k.replace("_model.", "_model.module.", 1) if k.endswith("device_indicator_param") else k: v for k, v in ck.items()}, step=100)  # a DDP-era "module." is stripped
     m2 = pipe2.model
