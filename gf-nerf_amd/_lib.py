@@ -37,6 +37,8 @@ SIGNATURES = {
     "gfn_mark_invisible_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gfn_octree_proc_host": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
                                     C.POINTER(_vp)]),
+    "gfn_octree_proc_workspace": (_i64, [_i64, _i32]),
+    "gfn_octree_proc": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_linear_fwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "gfn_linear_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp,
                               _vp]),

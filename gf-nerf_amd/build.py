@@ -18,7 +18,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgfnerf_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-HIP_SOURCES = ["runtime.hip", "hash3d.hip", "part_lookup.hip", "lm_lookup.hip", "sampler.hip", "mlp.hip", "field.hip", "field_x3.hip", "fused_fwd.hip", "wgrad_x3.hip", "render.hip", "batch.hip", "grad_part.hip"]
+HIP_SOURCES = ["runtime.hip", "hash3d.hip", "part_lookup.hip", "lm_lookup.hip", "sampler.hip", "mlp.hip", "field.hip", "field_x3.hip", "fused_fwd.hip", "wgrad_x3.hip", "render.hip", "batch.hip", "grad_part.hip", "octree_proc.hip"]
 CXX_SOURCES = ["octree_build.cpp", "octree_proc.cpp"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
                "-Wno-unused-function", "-I", INCLUDE]
@@ -55,7 +55,7 @@ def build_extension(force=False, verbose=False):
     objs = []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", "_hip.o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o])

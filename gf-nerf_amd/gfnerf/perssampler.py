@@ -145,17 +145,14 @@ class _NativePersSampler:
             ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)  # K6 may have invalidated leaves
 
     def ProcOctree(self, compact: bool, subdivide: bool, brute_force: bool):
-        """PersOctree::ProcOctree (PersSampler.cpp:154-417): blob and statistics to the host, gfn_octree_proc_host, back
-        (the reference makes the same round trip); visit counts restart at zero (:415)."""
-        dev = self.device
-        nodes, w, a = ops.octree_proc_host(self.tree_nodes_gpu_.cpu().numpy(), self.tree_weight_stats_.cpu().numpy(),
-                                           self.tree_alpha_stats_.cpu().numpy(), self.tree_visit_cnt_.cpu().numpy(),
-                                           compact=compact, subdivide=subdivide, brute_force=brute_force)
-        self.tree_nodes_gpu_ = torch.from_numpy(nodes).to(dev)
-        self.n_nodes = nodes.size // ops.TREE_NODE_BYTES
-        self.tree_weight_stats_ = torch.from_numpy(w).to(dev)
-        self.tree_alpha_stats_ = torch.from_numpy(a).to(dev)
-        self.tree_visit_cnt_ = torch.zeros(self.n_nodes, dtype=torch.int64, device=dev)
+        """PersOctree::ProcOctree (PersSampler.cpp:154-417) on the device (gfn_octree_proc): the reference round-trips the blob and
+        the statistics through the host here; only the new node count is read back.  Visit counts restart at zero (:415)."""
+        if not compact:
+            raise ops._lib.GfnError("ProcOctree: compact = False is not a state the reference can be in (PersSampler_cuda.cu:668-675)")
+        self.tree_nodes_gpu_, self.tree_weight_stats_, self.tree_alpha_stats_ = ops.octree_proc(
+            self.tree_nodes_gpu_, self.tree_weight_stats_, self.tree_alpha_stats_, self.tree_visit_cnt_, subdivide=subdivide, brute_force=brute_force)
+        self.n_nodes = self.tree_nodes_gpu_.numel() // ops.TREE_NODE_BYTES
+        self.tree_visit_cnt_ = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.device)
         self.nodes_compact_ = ops.tree_compact(self.tree_nodes_gpu_)
         self._ws = None
         self.last_packed = None  # node indices of the previous samples are stale now

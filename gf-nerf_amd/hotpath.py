@@ -651,16 +651,16 @@ class HotPath:
 
 
     def proc_octree(self, compact=True, subdivide=False, brute_force=False):
-        """PersOctree::ProcOctree (PersSampler.cpp:154-417) on this path's tree: host round trip like the reference,
-        then the 64-byte sampler image is rebuilt.  Node indices change; hash volumes (trans_idx) do not."""
+        """PersOctree::ProcOctree (PersSampler.cpp:154-417) on this path's tree, on the DEVICE (csrc/octree_proc.hip; the reference
+        copies the blob to the host and back, PersSampler_cuda.cu:667-676): only the new node count is read back.  Node indices
+        change; hash volumes (trans_idx) do not.  Then the 64-byte sampler image is rebuilt."""
+        if not compact:
+            raise _lib.GfnError("proc_octree: compact = False is not a state the reference can be in (PersSampler_cuda.cu:668-675)")
         self._drop_stale_samples()
-        nodes, w, a = ops.octree_proc_host(self.nodes.cpu().numpy(), self.weight_stats.cpu().numpy(), self.alpha_stats.cpu().numpy(),
-                                           self.visit_cnt.cpu().numpy(), compact=compact, subdivide=subdivide, brute_force=brute_force)
-        self.nodes = torch.from_numpy(nodes).to(self.dev)
-        self.n_nodes = nodes.size // ops.TREE_NODE_BYTES
-        self.weight_stats = torch.from_numpy(w).to(self.dev)
-        self.alpha_stats = torch.from_numpy(a).to(self.dev)
-        self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)
+        self.nodes, self.weight_stats, self.alpha_stats = ops.octree_proc(self.nodes, self.weight_stats, self.alpha_stats, self.visit_cnt,
+                                                                          subdivide=subdivide, brute_force=brute_force)
+        self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
+        self.visit_cnt = torch.zeros(self.n_nodes, dtype=torch.int64, device=self.dev)  # :415
         self.nodes_compact = ops.tree_compact(self.nodes)
         self._sampler_ws = None
 

@@ -411,6 +411,36 @@ def octree_proc_host(nodes, weight_stats, alpha_stats, visit_cnt, compact=True, 
     return new_nodes, new_w, new_a
 
 
+def octree_proc(nodes, weight_stats, alpha_stats, visit_cnt, subdivide=False, brute_force=False):
+    """PersOctree::ProcOctree on the device (compaction, optionally subdivision): device tensors in, device tensors out
+    -> (nodes u8 blob, weight_stats i64, alpha_stats i64) of the new tree.  The only thing that crosses to the host is the
+    new node count + a status word (16 bytes), read after the launch to size the views."""
+    _chk(nodes, torch.uint8, "nodes")
+    for t, nm in ((weight_stats, "weight_stats"), (alpha_stats, "alpha_stats"), (visit_cnt, "visit_cnt")):
+        _chk(t, torch.int64, nm)
+    n = nodes.numel() // TREE_NODE_BYTES
+    if not (weight_stats.numel() == n and alpha_stats.numel() == n and visit_cnt.numel() == n) or n < 1:
+        raise _lib.GfnError("octree_proc: stat tensors must have n_nodes entries")
+    dev = nodes.device
+    cap = 9 * n if subdivide else n
+    L = _lib.lib()
+    ws = torch.empty(L.gfn_octree_proc_workspace(n, int(subdivide)), dtype=torch.uint8, device=dev)
+    out = torch.empty(cap * TREE_NODE_BYTES, dtype=torch.uint8, device=dev)
+    w_out = torch.empty(cap, dtype=torch.int64, device=dev)
+    a_out = torch.empty(cap, dtype=torch.int64, device=dev)
+    head = torch.zeros(2, dtype=torch.int64, device=dev)  # [new count, status (low 32 bits)]
+    rc = L.gfn_octree_proc(_ptr(nodes), n, None, _ptr(weight_stats), _ptr(alpha_stats), _ptr(visit_cnt), int(subdivide), int(brute_force),
+                           _ptr(out), _ptr(w_out), _ptr(a_out), cap, _ptr(head), C.c_void_p(head.data_ptr() + 8), _ptr(ws), _stream())
+    _lib.check(rc, "gfn_octree_proc")
+    m, status = (int(v) for v in head.tolist())
+    status &= 0xFFFFFFFF
+    if status == 1:
+        raise _lib.GfnError("gfn_octree_proc: node blob is not a tree rooted at node 0 (parent / child links disagree)")
+    if status != 0 or m < 1:
+        raise _lib.GfnError(f"gfn_octree_proc: status {status}, {m} nodes")
+    return out[: m * TREE_NODE_BYTES], w_out[:m], a_out[:m]
+
+
 def generate_rays(c2w, intr, cam_idx=None, coords=None, cam0=0, first_pixel=0, width=0, n=None, out=None, want_extras=True):
     """Cameras.generate_rays (perspective, no distortion).  Explicit (cam_idx i32 [n], coords f32 [n,2] = (y, x)) pairs, or the
     raster run [first_pixel, first_pixel + n) of camera cam0's image of the given width.

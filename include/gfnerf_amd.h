@@ -506,6 +506,16 @@ int gfn_fill_zero(void* p, int64_t bytes, void* stream);
  * out[i] = (sum over copies, accumulated in f32 in rank order) * scale.  shard_elems % 8 == 0. */
 int gfn_reduce_shards(const void* recv, int n_shards, int64_t shard_elems, int is_f16, float scale, void* out, void* stream);
 
+/* ProcOctree on the DEVICE (csrc/octree_proc.hip): the same result as gfn_octree_proc_host, byte for byte, without the
+ * blob ever leaving HBM.  nodes / stats / visit_cnt: device arrays of n_nodes entries (n_nodes_dev, may be NULL: a device
+ * count <= n_nodes that overrides it); outputs: device arrays of out_cap entries (out_cap >= n_nodes, >= 9 * n_nodes when
+ * subdivide); n_out_dev i64[1] receives the new node count, status_dev i32[1] 0 / 1 (blob is not a tree) / 2 (out_cap too
+ * small); workspace: gfn_octree_proc_workspace(n_nodes, subdivide) bytes, 256-byte aligned.  One launch, stream ordered. */
+int64_t gfn_octree_proc_workspace(int64_t n_nodes, int subdivide);
+int gfn_octree_proc(const void* nodes, int64_t n_nodes, const int64_t* n_nodes_dev, const int64_t* weight_stats, const int64_t* alpha_stats,
+                    const int64_t* visit_cnt, int subdivide, int brute_force, void* nodes_out, int64_t* weight_stats_out,
+                    int64_t* alpha_stats_out, int64_t out_cap, int64_t* n_out_dev, int32_t* status_dev, void* workspace, void* stream);
+
 /* ====================================================================== *
  * Host-side octree construction (replaces PersOctree::PersOctree,
  * PersSampler.cpp:92-152,516-831).  Pure host C++; returns malloc'd blobs the
