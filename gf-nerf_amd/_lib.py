@@ -55,7 +55,7 @@ SIGNATURES = {
     "gfn_grad_scale_host": (_f32, [_f32]),
     "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),

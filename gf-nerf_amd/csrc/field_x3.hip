@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
         load8(feat + q * 32 + 16 * u + 8 * h, x);
       }
       split8(x, xh[u], xl[u]);
-      if (PLANES) store_nat(planes_hi + cap * FP_FEAT + q * 32, planes_lo + cap * FP_FEAT + q * 32, 16 * u, xh[u], xl[u], h);
+      if (PLANES) store_nat(planes_hi + cap * FP_FEAT, planes_lo + cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
     }
     const int ray = ray_id[q];
     const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh + (int64_t)ray * 16,
@@ -271,7 +271,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
     const u32x4* __restrict__ image, float* __restrict__ dfeat, const float* __restrict__ gmax_dev,
     uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, int64_t cap, const int* __restrict__ ray_id,
     const int* __restrict__ cam_idx, float* __restrict__ demb, ScatterArgs S) {
-#define BPL(half, C, W) (planes_##half + cap * (C) + s * (W))
+#define BPL(half, C) (planes_##half + cap * (C))
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
@@ -313,13 +313,14 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         if (PLANES) {  // zero this sample's rows of the five gradient planes (lane half h: its half of each row)
           const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int e = 0; e < 8; e++) {  // 128-wide rows = 256 B = 16 pieces, 8 per half
-            reinterpret_cast<u32x4*>(BPL(hi, BP_DZ2, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZ2, 128))[8 * h + e] = z;
-            reinterpret_cast<u32x4*>(BPL(hi, BP_DZ1, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZ1, 128))[8 * h + e] = z;
-            reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1, 128))[8 * h + e] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DZA1, 128))[8 * h + e] = z;
+          for (int e = 0; e < 8; e++) {  // 128-wide rows = 16 octets, 8 per half
+            const int64_t o = plane_off(s, 128, 8 * h + e);
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ2) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ2) + o) = z;
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ1) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ1) + o) = z;
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZA1) + o) = z;
           }
-          reinterpret_cast<u32x4*>(BPL(hi, BP_DH, 16))[h] = z; reinterpret_cast<u32x4*>(BPL(lo, BP_DH, 16))[h] = z;
-          if (h == 0) { *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3, 8)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3, 8)) = z; }
+          *reinterpret_cast<u32x4*>(BPL(hi, BP_DH) + plane_off(s, 16, h)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DH) + plane_off(s, 16, h)) = z;
+          if (h == 0) { *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = z; }
         }
       }
       continue;
@@ -349,8 +350,8 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       if (h == 0) { v[0] = dz3[0] * sc; v[1] = dz3[1] * sc; v[2] = dz3[2] * sc; }
       split8(v, zh, zl);
       if (PLANES && valid && h == 0) {
-        *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3, 8)) = zh;
-        *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3, 8)) = zl;
+        *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = zh;
+        *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = zl;
       }
     }
     Frag g2[4];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
       grad_tile_to_frag<true>(a, g2[it], m_c2, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZ2, 128), BPL(lo, BP_DZ2, 128), 32 * it, g2[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZ2), BPL(lo, BP_DZ2), 128, s, 32 * it, g2[it], h);
     }
     // ---- d c1 = hW1^T dz2
     Frag g1[4];
@@ -371,7 +372,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
       grad_tile_to_frag<true>(a, g1[it], m_c1, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZ1, 128), BPL(lo, BP_DZ1, 128), 32 * it, g1[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZ1), BPL(lo, BP_DZ1), 128, s, 32 * it, g1[it], h);
     }
     // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
     u32x4 dh_h, dh_l;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
       if (h == 0) v[0] = dh0 * sc;
       split8(v, dh_h, dh_l);
-      if (PLANES && valid) store_half_tile(BPL(hi, BP_DH, 16), BPL(lo, BP_DH, 16), 0, dh_h, dh_l, h);
+      if (PLANES && valid) store_half_tile(BPL(hi, BP_DH), BPL(lo, BP_DH), 16, s, 0, dh_h, dh_l, h);
     }
     if (PLANES && demb) {
       // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
@@ -415,7 +416,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       acc_init_zero(a);
       mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
       grad_tile_to_frag<true>(a, ga[it], m_a1, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZA1, 128), BPL(lo, BP_DZA1, 128), 32 * it, ga[it], h);
+      if (PLANES && valid) store_tile(BPL(hi, BP_DZA1), BPL(lo, BP_DZA1), 128, s, 32 * it, ga[it], h);
     }
     // ---- d feat = bW0^T dz
     Acc2 gf;
@@ -506,7 +507,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
   GFN_CHECK_ARG(feat_stride == 0 || feat_stride >= n_max, "gfn_field_fwd_x3: feat_stride=%lld must be 0 or >= n_max", (long long)feat_stride);
-  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 8", (long long)plane_cap);
+  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 32 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 32", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
   GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || masks),
@@ -556,7 +557,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   GFN_CHECK_ARG(!scatter || (sh.pts && sh.anchors && sh.prim_pool && sh.n_volumes > 0 && sh.n_volumes < (1ll << 26) && sh.log2_T >= 4 && sh.log2_T <= 26),
                 "%s: scatter needs pts, anchors, primes, n_volumes and log2_T", fn);
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "%s: n_max=%lld", fn, (long long)n_max);
-  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 8 == 0), "%s: plane_cap=%lld must be >= n_max and a multiple of 8", fn, (long long)plane_cap);
+  GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 32 == 0), "%s: plane_cap=%lld must be >= n_max and a multiple of 32", fn, (long long)plane_cap);
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(dfeat) | reinterpret_cast<uintptr_t>(planes_hi) |
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
           fp[0] = make_float4(x[0], x[1], x[2], x[3]); fp[1] = make_float4(x[4], x[5], x[6], x[7]);
         }
         split8(x, xh[u], xl[u]);
-        if (PLANES) store_nat(A.planes_hi + A.cap * FP_FEAT + q * 32, A.planes_lo + A.cap * FP_FEAT + q * 32, 16 * u, xh[u], xl[u], h);
+        if (PLANES) store_nat(A.planes_hi + A.cap * FP_FEAT, A.planes_lo + A.cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
       }
       // ---- decoder
       const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, A.planes_hi, A.planes_lo, A.cap, q);
@@ -221,7 +221,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
   GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_forward: an interleaved pair image already holds the second table");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
-  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 8 == 0)),
+  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 32 == 0)),
                 "gfn_fused_forward: planes need both halves, the masks and a capacity that is a multiple of 8");
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(emb) |
                   reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,

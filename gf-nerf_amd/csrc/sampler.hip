@@ -696,9 +696,13 @@ __global__ void fill_i64_kernel(long long* p, long long v, int64_t n) {
 // of samples in one node it takes max weight / max alpha / the run length and atomicMax'es
 //   (max_w_run > w_thres ? OCC_WEIGHT_BASE : -1),  (max_a_run > a_thres ? OCC_ALPHA_BASE : -1),  run length
 // into per-node arrays initialised to -1 / 0.  Every one of these is a max, so a wave per ray can let the samples speak
-// for themselves: a sample above the threshold raises its node's adder to the base (the -1 case is the initial value),
-// every sample marks its node visited, and each sample's 1-based position inside its run bounds the run length from
-// below -- the last sample of the run (or of the 64-sample sweep) posts it.
+// for themselves -- and the first two are maxima over {-1, ONE constant}: "raise the adder to the base" is a plain store
+// of that constant (every writer stores the same value over an initial -1; no atomic unit is involved, and stores to one
+// address merge on their way out).  Only the run length needs a real atomicMax, and only the last sample of a run (or
+// of the 64-sample sweep) posts it: each sample's 1-based position inside its run bounds the run length from below.
+// A run's samples above the threshold are reduced to its last lane first (segmented OR by ballot), so a run costs at most
+// two stores and one atomic however long it is (an early version issued two contended atomics per sample: 0.32 ms per
+// 4096 x 128 batch where this takes a few tens of microseconds).
 __global__ __launch_bounds__(256) void mark_visit_kernel(
     int n_rays, const int* __restrict__ pts_offsets, const int* __restrict__ anchors,
     const float* __restrict__ weights, const float* __restrict__ alphas, int n_nodes, long long* w_adder,
@@ -728,14 +732,19 @@ __global__ __launch_bounds__(256) void mark_visit_kernel(
     const bool head = oi != prev;
     const unsigned long long heads = __ballot(head);
     const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));  // heads at lanes <= this one
-    const long long cnt = upto ? (long long)(lane - (63 - __builtin_clzll(upto)) + 1) : (long long)(lane + 1) + carry_cnt;
+    const int first = upto ? 63 - __builtin_clzll(upto) : 0;                                 // first lane of this lane's run in the sweep
+    const long long cnt = upto ? (long long)(lane - first + 1) : (long long)(lane + 1) + carry_cnt;
     const int next = __shfl_down(oi, 1, 64);
     const bool last = lane == 63 || next != oi;
-    if (v && oi >= 0 && oi < n_nodes) {  // samples marched through an older (larger) tree must not write past the arrays
+    // samples of this run (within the sweep) above the thresholds: bits [first, lane] of the ballots
+    const unsigned long long w_hit = __ballot(v && weights[v ? i : s] > w_thres);
+    const unsigned long long a_hit = __ballot(v && alphas[v ? i : s] > a_thres);
+    const unsigned long long run_mask = (lane == 63 ? ~0ull : ((2ull << lane) - 1ull)) & ~((1ull << first) - 1ull);
+    if (v && last && oi >= 0 && oi < n_nodes) {  // samples marched through an older (larger) tree must not write past the arrays
       mark[oi] = 1;
-      if (weights[i] > w_thres) atomicMax(w_adder + oi, (long long)OCC_WEIGHT_BASE);
-      if (alphas[i] > a_thres) atomicMax(a_adder + oi, (long long)OCC_ALPHA_BASE);
-      if (last) atomicMax(visit_cnt + oi, cnt);
+      if (w_hit & run_mask) w_adder[oi] = (long long)OCC_WEIGHT_BASE;
+      if (a_hit & run_mask) a_adder[oi] = (long long)OCC_ALPHA_BASE;
+      atomicMax(visit_cnt + oi, cnt);
     }
     carry_oi = __shfl(oi, 63, 64);
     carry_cnt = __shfl((int)cnt, 63, 64);

@@ -2,8 +2,9 @@
 //
 // The contraction runs over SAMPLES, which the fused forward / backward kernels hold on the lane axis
 // of their accumulator tiles (MFMA lanes index M or N, never K), so both operands come back from HBM:
-// the producers write them as split-f16 "planes" [n][features] (hi and lo' = (x-hi)*2^11, see
-// field_x3.hip), this kernel stages 64-sample slabs in LDS as [feature tile][sample][32] (64-byte rows)
+// the producers write them as split-f16 "planes" (hi and lo' = (x-hi)*2^11, see field_x3.hip) -- tile-major
+// [n / 32][features / 8][32 samples][8 features] (x3_device.h plane_off; `tiled`), or plain rows [n][ld] for callers that
+// build planes themselves --, this kernel stages 64-sample slabs in LDS as [feature tile][sample][32] (64-byte rows)
 // and reads them TRANSPOSED with ds_read_b64_tr_b16: per 16-lane group a 4-sample x 16-feature block
 // comes back feature-major, which is exactly the 32x32x16 operand fragment
 // (lane (h, r): feature r, samples 8h .. 8h+7 of the k-step), for A (= dz^T) and B (= a) alike.
@@ -24,9 +25,11 @@ constexpr int S = 64;  // samples per LDS slab
 struct Plane {
   const uint16_t* hi;
   const uint16_t* lo;
-  int ld;    // row stride in elements (multiple of 8)
+  int ld;    // rows: row stride in elements (multiple of 8); tiled: the plane's width W
   int feat;  // stored features per row (multiple of 8, <= 32 * tiles)
 };
+
+__device__ __forceinline__ int64_t plane_off(int64_t q, int W, int octet) { return (((q >> 5) * (W >> 3) + octet) * 32 + (q & 31)) * 8; }
 
 __device__ __forceinline__ h8 tr_frag(const _Float16* tile /*[S][32]*/, int ks, int lane) {
   // lane 4q+p of 16-lane group g supplies &T[row0+q][col0+4p]; lane i of the group receives column col0+i of rows row0..row0+3
@@ -40,22 +43,30 @@ __device__ __forceinline__ h8 tr_frag(const _Float16* tile /*[S][32]*/, int ks, 
 
 // One slab = 64 samples x (FD + FA) features x {hi, lo'}.  Each thread owns a fixed set of 16-byte pieces; the next
 // slab's pieces are fetched into registers while the matrix pipe works on the current one.
-template <int FEAT>
+template <int FEAT, bool TILED>
 struct Stager {
   static constexpr int PIECES = FEAT / 8;                 // 16-byte pieces per sample row
   static constexpr int TOTAL = S * PIECES;                // pieces per slab
   static constexpr int PER_THREAD = (TOTAL + 255) / 256;
   u32x4 hi[PER_THREAD], lo[PER_THREAD];
 
+  // piece e of a slab -> (sample s, first feature f).  Rows: consecutive threads walk one sample's row; tiled: consecutive
+  // threads walk the 32 samples of one octet (512 contiguous bytes), the order the producers wrote them in.
+  static __device__ __forceinline__ void piece(int e, int& s, int& f) {
+    if (TILED) { s = (e & 31) + 32 * ((e >> 5) / PIECES); f = ((e >> 5) % PIECES) * 8; }
+    else { s = e / PIECES; f = (e % PIECES) * 8; }
+  }
   __device__ __forceinline__ void fetch(const Plane& p, int64_t s0, int64_t n) {
 #pragma unroll
     for (int it = 0; it < PER_THREAD; it++) {
       const int e = it * 256 + (int)threadIdx.x;
-      const int s = e / PIECES, f = (e % PIECES) * 8;
+      int s, f;
+      piece(e, s, f);
       hi[it] = u32x4{0u, 0u, 0u, 0u}; lo[it] = u32x4{0u, 0u, 0u, 0u};
       if (e < TOTAL && s0 + s < n) {
-        hi[it] = *reinterpret_cast<const u32x4*>(p.hi + (s0 + s) * p.ld + f);
-        lo[it] = *reinterpret_cast<const u32x4*>(p.lo + (s0 + s) * p.ld + f);
+        const int64_t o = TILED ? plane_off(s0 + s, p.ld, f >> 3) : (s0 + s) * p.ld + f;
+        hi[it] = *reinterpret_cast<const u32x4*>(p.hi + o);
+        lo[it] = *reinterpret_cast<const u32x4*>(p.lo + o);
       }
     }
   }
@@ -63,7 +74,8 @@ struct Stager {
 #pragma unroll
     for (int it = 0; it < PER_THREAD; it++) {
       const int e = it * 256 + (int)threadIdx.x;
-      const int s = e / PIECES, f = (e % PIECES) * 8;
+      int s, f;
+      piece(e, s, f);
       if (e < TOTAL) {
         *reinterpret_cast<u32x4*>(dst_hi + ((f >> 5) * S + s) * 32 + (f & 31)) = hi[it];
         *reinterpret_cast<u32x4*>(dst_lo + ((f >> 5) * S + s) * 32 + (f & 31)) = lo[it];
@@ -74,7 +86,7 @@ struct Stager {
 
 // WAVE_IS_NI: wave w owns in-tile w and loops over the MO out tiles (NI == 4); else wave w owns out tile w (MO == 4)
 // and loops over the NI in tiles.
-template <int FD, int FA>
+template <int FD, int FA, bool TILED>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int32_t* __restrict__ n_dev, Plane dz, Plane a,
                                                        const float* __restrict__ gmax_dev, float* __restrict__ dW, int ldw,
                                                        int m_valid, int k_valid, const int* __restrict__ col_map,
@@ -99,8 +111,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
     for (int r = 0; r < 16; r++) { accm[t][r] = 0.f; accc[t][r] = 0.f; }
   float bsum = 0.f;
   const int64_t n_slabs = (n + S - 1) / S;
-  Stager<FD> sd;
-  Stager<FA> sa;
+  Stager<FD, TILED> sd;
+  Stager<FA, TILED> sa;
   if ((int64_t)blockIdx.x < n_slabs) { sd.fetch(dz, (int64_t)blockIdx.x * S, n); sa.fetch(a, (int64_t)blockIdx.x * S, n); }
   __syncthreads();
   for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
@@ -165,19 +177,21 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
   }
 }
 
-template <int FD, int FA>
+template <int FD, int FA, bool TILED>
 int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
            int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
   constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   const size_t lds = (size_t)2 * (MO + NI) * S * 32 * sizeof(_Float16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  static int attr_dev = -1;  // the attribute belongs to the (function, device) pair: one process drives one device, but check
+  int dev = 0;
+  GFN_CHECK_HIP(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_dev = dev;
   }
   int64_t blocks = (n_max + S - 1) / S;
   if (blocks > 512) blocks = 512;
-  wgrad_x3_kernel<FD, FA><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
+  wgrad_x3_kernel<FD, FA, TILED><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
@@ -188,7 +202,7 @@ extern "C" {
 
 int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int feat_dz, const uint16_t* a_hi, const uint16_t* a_lo,
                  int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev, const float* gmax_dev, int m_valid, int k_valid,
-                 const int32_t* col_map, float* dW, int ldw, float* db, void* stream) {
+                 const int32_t* col_map, float* dW, int ldw, float* db, int tiled, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(dz_hi && dz_lo && a_hi && a_lo && dW, "gfn_wgrad_x3: null pointer");
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31), "gfn_wgrad_x3: n_max=%lld", (long long)n_max);
@@ -198,9 +212,13 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
   GFN_CHECK_ARG(m_valid >= 1 && m_valid <= feat_dz && k_valid >= 1 && k_valid <= feat_a && ldw >= 1, "gfn_wgrad_x3: bad m/k/ldw");
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(dz_hi) | reinterpret_cast<uintptr_t>(dz_lo) | reinterpret_cast<uintptr_t>(a_hi) |
                   reinterpret_cast<uintptr_t>(a_lo)) & 15) == 0, "gfn_wgrad_x3: planes must be 16-byte aligned");
+  GFN_CHECK_ARG(!tiled || (ld_dz == feat_dz && ld_a == feat_a), "gfn_wgrad_x3: a tile-major plane is addressed whole (ld == width)");
   const Plane dz{dz_hi, dz_lo, ld_dz, feat_dz}, a{a_hi, a_lo, ld_a, feat_a};
   hipStream_t st = gfn_stream(stream);
-#define GFN_WG(D, A) if (feat_dz == D && feat_a == A) return launch<D, A>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
+#define GFN_WG(D, A)                                                                                                       \
+  if (feat_dz == D && feat_a == A)                                                                                         \
+    return tiled ? launch<D, A, true>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)          \
+                 : launch<D, A, false>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
   GFN_WG(128, 128);  // head layer 2
   GFN_WG(8, 128);    // head layer 3 (3 outputs)
   GFN_WG(128, 64);   // head layer 1 (63 inputs)

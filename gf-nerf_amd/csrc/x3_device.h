@@ -29,8 +29,11 @@ constexpr int D_GB1 = 44;  // d a1 = bW1^T dh : [it 4]
 constexpr int D_GB0 = 48;  // d feat = bW0^T dz : [u 8]
 constexpr int D_GE = 56;   // d appearance = hW0[:,31:63]^T dz1 : [u 8]   (global stage only)
 // split-f16 planes kept for the weight gradients (global stage): one hi and one lo' buffer of cap * LD f16 each,
-// PLANE-MAJOR: the plane with first column C and width W is the contiguous array [cap][W] at element offset cap * C
-// (so gfn_wgrad_x3 streams whole 128-byte lines).  Columns:
+// PLANE-MAJOR: the plane with first column C and width W is a contiguous array of cap * W elements at element offset cap * C,
+// and inside it TILE-MAJOR: [cap / 32 tiles][W / 8 octets][32 samples][8 features] (plane_off).  A wave of the decoder kernels
+// holds 32 samples on its lanes and 4 (or 8) consecutive features of each in one register pair, so one store instruction
+// writes 32 samples x 16 bytes = 512 contiguous bytes (sample-major rows made it 32 pieces of 16 bytes 2 * W bytes apart:
+// 1.9 GB per step written as 120 M partial-line requests); gfn_wgrad_x3 reads the same 16-byte pieces back.  Columns:
 constexpr int FP_LD = GFN_FIELD_X3_FWD_PLANE_LD;   // feat 0..31 | a1 32..159 | xp 160..223 | c1 224..351 | c2 352..479
 constexpr int FP_FEAT = 0, FP_A1 = 32, FP_XP = 160, FP_C1 = 224, FP_C2 = 352;
 constexpr int BP_LD = GFN_FIELD_X3_BWD_PLANE_LD;   // dz3 0..7 | dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407
@@ -38,6 +41,9 @@ constexpr int BP_DZ3 = 0, BP_DH = 8, BP_DZ2 = 24, BP_DZ1 = 152, BP_DZA1 = 280;
 static_assert(FP_LD == 480 && BP_LD == 408, "plane row widths");
 
 __device__ __forceinline__ int acc_row(int t, int s, int h, int i) { return 32 * t + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
+
+// element offset of features 8 * octet .. 8 * octet + 7 of sample q inside a tile-major plane of width W
+__host__ __device__ __forceinline__ int64_t plane_off(int64_t q, int W, int octet) { return (((q >> 5) * (W >> 3) + octet) * 32 + (q & 31)) * 8; }
 
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // round toward zero: saturates at 65504, never rounds to inf
@@ -115,30 +121,35 @@ __device__ __forceinline__ void load8(const float* p, float* x) {
   x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
 }
 
-// a tile's two fragments -> columns col0 .. col0+31 of this sample's plane rows (registers 8s+4g..+3 = rows 16s+8g+4h..+3)
-__device__ __forceinline__ void store_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const Frag& f, int h) {
+// a tile's two fragments -> columns col0 .. col0+31 of sample q in the plane (base_hi, base_lo) of width W
+// (registers 8s+4g..+3 = rows 16s+8g+4h..+3: lane half h owns 4 of the 8 features of octet (col0 + 16s + 8g) / 8)
+__device__ __forceinline__ void store_tile(uint16_t* __restrict__ base_hi, uint16_t* __restrict__ base_lo, int W, int64_t q, int col0, const Frag& f,
+                                           int h) {
 #pragma unroll
   for (int s = 0; s < 2; s++)
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-      *reinterpret_cast<uint2*>(row_hi + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.hi[s][2 * g], f.hi[s][2 * g + 1]);
-      *reinterpret_cast<uint2*>(row_lo + col0 + 16 * s + 8 * g + 4 * h) = make_uint2(f.lo[s][2 * g], f.lo[s][2 * g + 1]);
+      const int64_t o = plane_off(q, W, (col0 >> 3) + 2 * s + g) + 4 * h;
+      *reinterpret_cast<uint2*>(base_hi + o) = make_uint2(f.hi[s][2 * g], f.hi[s][2 * g + 1]);
+      *reinterpret_cast<uint2*>(base_lo + o) = make_uint2(f.lo[s][2 * g], f.lo[s][2 * g + 1]);
     }
 }
 // the first k-step of a tile (rows 0..15) -> 16 columns
-__device__ __forceinline__ void store_half_tile(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
-                                                const u32x4& fl, int h) {
+__device__ __forceinline__ void store_half_tile(uint16_t* __restrict__ base_hi, uint16_t* __restrict__ base_lo, int W, int64_t q, int col0,
+                                                const u32x4& fh, const u32x4& fl, int h) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
-    *reinterpret_cast<uint2*>(row_hi + col0 + 8 * g + 4 * h) = make_uint2(fh[2 * g], fh[2 * g + 1]);
-    *reinterpret_cast<uint2*>(row_lo + col0 + 8 * g + 4 * h) = make_uint2(fl[2 * g], fl[2 * g + 1]);
+    const int64_t o = plane_off(q, W, (col0 >> 3) + g) + 4 * h;
+    *reinterpret_cast<uint2*>(base_hi + o) = make_uint2(fh[2 * g], fh[2 * g + 1]);
+    *reinterpret_cast<uint2*>(base_lo + o) = make_uint2(fl[2 * g], fl[2 * g + 1]);
   }
 }
-// a natural-order fragment (k = 8h + i) -> 16 columns
-__device__ __forceinline__ void store_nat(uint16_t* __restrict__ row_hi, uint16_t* __restrict__ row_lo, int col0, const u32x4& fh,
-                                          const u32x4& fl, int h) {
-  *reinterpret_cast<u32x4*>(row_hi + col0 + 8 * h) = fh;
-  *reinterpret_cast<u32x4*>(row_lo + col0 + 8 * h) = fl;
+// a natural-order fragment (k = 8h + i) -> 16 columns: lane half h owns octet col0 / 8 + h whole
+__device__ __forceinline__ void store_nat(uint16_t* __restrict__ base_hi, uint16_t* __restrict__ base_lo, int W, int64_t q, int col0,
+                                          const u32x4& fh, const u32x4& fl, int h) {
+  const int64_t o = plane_off(q, W, (col0 >> 3) + h);
+  *reinterpret_cast<u32x4*>(base_hi + o) = fh;
+  *reinterpret_cast<u32x4*>(base_lo + o) = fl;
 }
 
 // One 32-sample tile of the decoder (nerfacto_field.py:455-555): split hash features (k-steps xh/xl) -> base_network ->
@@ -156,7 +167,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
   const int h = lane >> 5;
   const float* Bb0 = bias; const float* Bb1 = bias + 128; const float* Bh0 = bias + 160; const float* Bh1 = bias + 288; const float* Bh2 = bias + 416;
   DecoderOut out;
-#define FPL(half, C, W) (planes_##half + cap * (C) + q * (W))
+#define FPL(half, C) (planes_##half + cap * (C))
   {
     // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
     Frag a1[4];
@@ -168,7 +179,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
       for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
       tile_to_frag<true>(a, a1[ot], m_a1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_A1, 128), FPL(lo, FP_A1, 128), 32 * ot, a1[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1[ot], h);
     }
     // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
     Acc2 hh;
@@ -183,7 +194,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
       split8(v, gh, gl);
-      if (PLANES) store_half_tile(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 0, gh, gl, h);
+      if (PLANES) store_half_tile(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 0, gh, gl, h);
     }
     // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
     u32x4 sh_h, sh_l, e_h[2], e_l[2];
@@ -202,9 +213,9 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
           for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
       }
       if (PLANES) {
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 16, sh_h, sh_l, h);
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 32, e_h[0], e_l[0], h);
-        store_nat(FPL(hi, FP_XP, 64), FPL(lo, FP_XP, 64), 48, e_h[1], e_l[1], h);
+        store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 16, sh_h, sh_l, h);
+        store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 32, e_h[0], e_l[0], h);
+        store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 48, e_h[1], e_l[1], h);
       }
     }
     Frag c1[4];
@@ -218,7 +229,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
       mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
       tile_to_frag<true>(a, c1[ot], m_c1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C1, 128), FPL(lo, FP_C1, 128), 32 * ot, c1[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU
     Frag c2[4];
@@ -230,7 +241,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       tile_to_frag<true>(a, c2[ot], m_c2, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C2, 128), FPL(lo, FP_C2, 128), 32 * ot, c2[ot], h);
+      if (PLANES) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2[ot], h);
     }
     // ---- head layer 3: 128 -> 3 (padded), sigmoid
     Acc2 o3;

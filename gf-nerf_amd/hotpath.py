@@ -177,7 +177,7 @@ class HotPath:
         """Split-f16 activation / gradient planes of the global stage (480 + 408 f16 columns, hi and lo' each), sized like
         the packed sample buffers and kept across steps."""
         if self._plane_bufs is None or self._plane_bufs[0][0].numel() < cap * ops.FIELD_X3_FWD_PLANE_LD:
-            cap = (cap + 7) // 8 * 8
+            cap = (cap + 31) // 32 * 32  # whole 32-sample tiles (the planes are tile-major)
             # zero-initialised: rows of samples the fused forward skips (behind a ray's termination point) keep whatever finite
             # values they held, and meet zero gradients in gfn_wgrad_x3 -- garbage f16 could be NaN
             mk = lambda ld: (torch.zeros(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
@@ -497,15 +497,15 @@ class HotPath:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
                                     bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
             g = self.layer_grads
-            fv = lambda k: (ops.plane_view(fp[0], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE),  # noqa: E731
-                            ops.plane_view(fp[1], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE))
-            bv = lambda k: (ops.plane_view(bp[0], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE),  # noqa: E731
-                            ops.plane_view(bp[1], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE))
+            fv = lambda k: (ops.plane_flat(fp[0], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE)[0],  # noqa: E731
+                            *ops.plane_flat(fp[1], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE))
+            bv = lambda k: (ops.plane_flat(bp[0], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE)[0],  # noqa: E731
+                            *ops.plane_flat(bp[1], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE))
             n_cap = s["ts"].shape[0]
             for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
                                           (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None)):
                 self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
-                            gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap)
+                            gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap, tiled=True)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
             rec = self._record_buffers()
             with self._cu_cap():

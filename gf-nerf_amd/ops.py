@@ -643,16 +643,24 @@ def _plane_cap(ph, pl, ld, n):
     if ph.numel() != pl.numel() or ph.numel() % ld:
         raise _lib.GfnError("plane halves differ in size or are not a multiple of the row width")
     cap = ph.numel() // ld
-    if cap < n or cap % 8:
-        raise _lib.GfnError("plane capacity must cover the sample buffers and be a multiple of 8")
+    if cap < n or cap % 32:
+        raise _lib.GfnError("plane capacity must cover the sample buffers and be a multiple of 32")
     return cap
 
 
-def plane_view(buf, ld, name, table):
-    """The [cap, width] view of plane `name` inside a plane-major buffer."""
+def plane_flat(buf, ld, name, table):
+    """Plane `name` of a plane-major buffer as the flat tile-major array the kernels address: (flat f16 [cap * width], width)."""
     cap = buf.numel() // ld
     c0, w = table[name]
-    return buf.view(-1)[cap * c0: cap * (c0 + w)].view(cap, w)
+    return buf.view(-1)[cap * c0: cap * (c0 + w)], w
+
+
+def plane_view(buf, ld, name, table):
+    """The [cap, width] rows of plane `name` (a strided view of the tile-major storage [cap/32][width/8][32][8]): for reading
+    planes back in tests and tools."""
+    flat, w = plane_flat(buf, ld, name, table)
+    cap = flat.numel() // w
+    return flat.view(cap // 32, w // 8, 32, 8).permute(0, 2, 1, 3).reshape(cap, w)
 
 
 def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bwd=True):
@@ -731,12 +739,18 @@ def split_f16(x):
     return hi, lo
 
 
-def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=None, col_map=None, n=None):
+def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=None, col_map=None, n=None, tiled=False):
     """dW[m, col(k)] += sum_s dz[s, m] a[s, k] / gfn_grad_scale(gmax) from split-f16 planes.  dz and a are
-    (hi, lo') pairs of [n, width] tensors, or (hi, lo', col0, width) to address a column range of wider planes."""
+    (hi, lo') pairs of [n, width] tensors, or (hi, lo', col0, width) to address a column range of wider planes; with
+    tiled=True they are (hi_flat, lo_flat, width): whole tile-major planes as the fused kernels write them (plane_flat)."""
     def unpack(p):
         hi, lo = p[0], p[1]
         _chk(hi, torch.float16, "plane"); _chk(lo, torch.float16, "plane")
+        if tiled:
+            width = p[2]
+            if hi.numel() != lo.numel() or hi.numel() % (32 * width):
+                raise _lib.GfnError("tile-major plane halves differ or do not hold a whole number of 32-sample tiles")
+            return hi.data_ptr(), lo.data_ptr(), width, width, hi.numel() // width
         col0, width = (p[2], p[3]) if len(p) == 4 else (0, hi.shape[1])
         if hi.shape != lo.shape or col0 + width > hi.shape[1]:
             raise _lib.GfnError("plane halves differ or the column range is out of bounds")
@@ -751,7 +765,7 @@ def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=No
     if dW.shape[0] < m_valid or (col_map is None and dW.shape[1] < k_valid) or (col_map is not None and col_map.numel() < k_valid):
         raise _lib.GfnError("dW / col_map too small for the requested rows and columns")
     rc = _lib.lib().gfn_wgrad_x3(dzh, dzl, ld_dz, w_dz, ah, al, ld_a, w_a, n, _ptr(n_dev), _ptr(gmax), m_valid, k_valid, _ptr(col_map),
-                                 _ptr(dW), dW.stride(0), _ptr(db), _stream())
+                                 _ptr(dW), dW.stride(0), _ptr(db), int(bool(tiled)), _stream())
     _lib.check(rc, "gfn_wgrad_x3")
     return dW
 

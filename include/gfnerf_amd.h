@@ -350,8 +350,10 @@ int gfn_set_decoder_cus(int n_cus);
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]
  * for m < m_valid, k < k_valid; col(k) = col_map[k] (skipped when negative) or k.  A plane is two
- * u16(f16) arrays [n][ld]: hi and lo' with x ~= hi + lo' * 2^-11; feat_* = stored columns (multiple
- * of 8, <= 128; tile shapes 128x128, 32x128, 128x64, 128x32 after rounding up to 32).  gmax_dev
+ * u16(f16) arrays, hi and lo' with x ~= hi + lo' * 2^-11; feat_* = stored columns (multiple
+ * of 8, <= 128; tile shapes 128x128, 32x128, 128x64, 128x32 after rounding up to 32).  tiled == 0: the
+ * arrays are rows [n][ld]; tiled != 0: the layout the fused decoder kernels write,
+ * [n / 32][feat / 8][32 samples][8 features] (ld == feat, n a multiple of 32 in the allocation).  gmax_dev
  * (device f32, may be NULL = no scale) is the word gfn_field_bwd_x3 took its scale from: the dz plane
  * carries the factor gfn_grad_scale_host(*gmax_dev), divided out here.
  * ACCUMULATES with f32 atomics (caller zeroes).  Replaces autograd's dW = dz^T a of the nn.Linear
@@ -359,7 +361,7 @@ int gfn_set_decoder_cus(int n_cus);
 int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int feat_dz, const uint16_t* a_hi,
                  const uint16_t* a_lo, int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev,
                  const float* gmax_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
-                 float* db, void* stream);
+                 float* db, int tiled, void* stream);
 
 /* Everything after the sampler in ONE persistent kernel (csrc/fused_fwd.hip): f16-shadow hash lookup
  * (+ residual table2 with its own primes, or NULL; or pair_table != 0: table_f16 is the interleaved

@@ -556,20 +556,25 @@ def test_charbonnier_and_adam(oracle, ops, dev, golden):
     np.testing.assert_allclose(p.cpu().numpy(), golden["adam_p3"], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("m_feat,k_feat,m_valid,k_valid", [(128, 128, 128, 128), (8, 128, 3, 128), (128, 64, 128, 63),
                                                            (16, 128, 16, 128), (128, 32, 128, 32)])
-def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid):
-    """gfn_wgrad_x3 (split-f16 planes, transposed LDS reads) against a float64 dz^T a, ragged n, device count, scale, col_map."""
+def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid, tiled):
+    """gfn_wgrad_x3 (split-f16 planes, transposed LDS reads) against a float64 dz^T a, ragged n, device count, scale, col_map;
+    planes as rows [n][width] and in the tile-major layout [n/32][width/8][32][8] the fused decoder kernels write."""
     import torch
 
     rng = np.random.default_rng(5)
-    n_cap, n = 5000, 4321  # not a multiple of the 64-sample slab
+    n_cap, n = 5024, 4321  # whole 32-sample tiles allocated; n not a multiple of the 64-sample slab
     dz = (rng.standard_normal((n_cap, m_feat)) * np.exp(rng.uniform(-6, 0, (n_cap, 1)))).astype(np.float32)
     a = np.maximum(rng.standard_normal((n_cap, k_feat)), 0).astype(np.float32) * 3.0
     dz[:, m_valid:] = 0
     scale = 64.0
     t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
     dzp = ops.split_f16(t(dz * scale)); ap = ops.split_f16(t(a))
+    if tiled:
+        tile = lambda x: x.view(n_cap // 32, 32, x.shape[1] // 8, 8).permute(0, 2, 1, 3).contiguous().view(-1)  # noqa: E731
+        dzp, ap = (tile(dzp[0]), tile(dzp[1]), m_feat), (tile(ap[0]), tile(ap[1]), k_feat)
     n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
     col_map = None
     ldw = k_valid
@@ -581,7 +586,7 @@ def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid):
     db = torch.zeros(m_valid, dtype=torch.float32, device=dev)
     assert ops.grad_scale(0.2) == scale  # gmax in [1/8, 1/4) -> scale 64
     ops.wgrad_x3(dzp, ap, dW, db=db, n_dev=n_dev, gmax=torch.tensor([0.2], device=dev), m_valid=m_valid, k_valid=k_valid,
-                 col_map=col_map)
+                 col_map=col_map, tiled=tiled)
     want = dz[:n, :m_valid].astype(np.float64).T @ a[:n, :k_valid].astype(np.float64)
     if col_map is not None:
         w2 = np.zeros((m_valid, ldw))

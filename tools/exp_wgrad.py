@@ -10,15 +10,15 @@ n = 524288
 dev = "cuda"
 fp = (torch.randn(n * 480, device=dev).half(), torch.randn(n * 480, device=dev).half())
 bp = (torch.randn(n * 408, device=dev).half(), torch.randn(n * 408, device=dev).half())
-fv = lambda k: (ops.plane_view(fp[0], 480, k, ops.FWD_PLANE), ops.plane_view(fp[1], 480, k, ops.FWD_PLANE))
-bv = lambda k: (ops.plane_view(bp[0], 408, k, ops.BWD_PLANE), ops.plane_view(bp[1], 408, k, ops.BWD_PLANE))
+fv = lambda k: (ops.plane_flat(fp[0], 480, k, ops.FWD_PLANE)[0], *ops.plane_flat(fp[1], 480, k, ops.FWD_PLANE))
+bv = lambda k: (ops.plane_flat(bp[0], 408, k, ops.BWD_PLANE)[0], *ops.plane_flat(bp[1], 408, k, ops.BWD_PLANE))
 gmax = torch.tensor([0.2], device=dev)
 F, B = ops.FWD_PLANE, ops.BWD_PLANE
 tot = 0
 for name, dzk, ak, mv, shape in (("hW2", "dz3", "c2", 3, (3, 128)), ("hW1", "dz2", "c1", 128, (128, 128)), ("hW0", "dz1", "xp", 128, (128, 64)),
                                  ("bW1", "dh", "a1", 16, (16, 128)), ("bW0", "dza1", "feat", 128, (128, 32))):
     dW = torch.zeros(shape, device=dev); db = torch.zeros(shape[0], device=dev)
-    fn = lambda: ops.wgrad_x3(bv(dzk), fv(ak), dW, db=db, gmax=gmax, m_valid=mv)
+    fn = lambda: ops.wgrad_x3(bv(dzk), fv(ak), dW, db=db, gmax=gmax, m_valid=mv, tiled=True)
     fn(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
