@@ -61,6 +61,9 @@ def parse():
                     help="timed steps of the `global_stage` sub-record (configs[1], 4096 x 128); 0 = skip.  Its warm-up is --global-warmup")
     ap.add_argument("--global-warmup", type=int, default=60, help="past the level-major switch at optimiser step 50")
     ap.add_argument("--sub-timeout", type=float, default=240.0, help="seconds a sub-record may take before the line is printed without it")
+    ap.add_argument("--graph-experiment", choices=["off", "eager", "graph"], default="off",
+                    help="experiment: ONE fixed batch every step, eagerly launched or as one captured hipGraph replayed per step "
+                         "(isolates launch overhead; the captured step's optimiser scalars are frozen, so not a training run)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
@@ -454,6 +457,44 @@ class StageRun:
         return self.hp.train_step(o, d, cam, gt, noise, stage=self.stage, block=block, s3im_index=s3, prefetch=pre,
                                   update_oct=self.stage == "global" and not args.no_oct_update)
 
+    def run_graph_experiment(self, steps, warmup, mode):
+        torch, hp = self.torch, self.hp
+        o, d, cam, gt = self.batches[0]
+        noise = self.ops.sampler_noise(N_RAYS, self.fineness, train=True, device="cuda")
+        s3 = self.ops.s3im_index(N_RAYS, self.cfg.s3im_repeat_time, device="cuda")
+        block = 0 if self.stage == "focal" else None
+
+        def one():
+            return hp.train_step(o, d, cam, gt, noise, stage=self.stage, block=block, s3im_index=s3, prefetch=(o, d, noise),
+                                 update_oct=self.stage == "global" and not self.args.no_oct_update)
+
+        for _ in range(PRIMING + warmup):
+            loss, aux = one()
+        torch.cuda.synchronize()
+        g = None
+        if mode == "graph":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, aux = one()
+                torch.cuda.current_stream().wait_stream(hp._side)  # the prefetched sampler is a branch of this step's graph
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if g is not None:
+                g.replay()
+            else:
+                loss, aux = one()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(json.dumps(dict(experiment=mode, stage=self.stage, ms_per_step=el / steps * 1e3, host_enqueue_ms_per_step=host / steps * 1e3, loss=float(loss.item()))))
+
     def run(self, steps, warmup, dist=None):
         """-> dict(elapsed (max over ranks), host_enqueue, loss, aux) for `steps` timed steps after PRIMING + warmup untimed ones."""
         torch, hp, world = self.torch, self.hp, self.world
@@ -588,6 +629,9 @@ def run_rank(args):
     run = StageRun(args, headline_stage, sc, world, rank, sync, torch,
                    cams=my_cams if headline_stage == "focal" else None,
                    n_blocks=(4 if world == 1 else 1) if headline_stage == "focal" else 0, block_seed=rank)
+    if args.graph_experiment != "off":
+        run.run_graph_experiment(args.steps, args.warmup, args.graph_experiment)
+        return
     res = run.run(args.steps, args.warmup, dist)
     if rank == 0 and args.stage_times:
         run.print_stage_times(res)

@@ -18,8 +18,6 @@ SIGNATURES = {
     "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_pair_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "gfn_hash_fwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
-    "gfn_hash_fwd_part_workspace": (_i64, [_i64]),
-    "gfn_hash_fwd_part": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
@@ -96,7 +94,9 @@ class GfnError(RuntimeError):
 
 
 def lib():
-    """Load (building first if the .so is absent and hipcc exists) and return the CDLL."""
+    """Load and return the CDLL.  When hipcc is on the machine the (incremental, lock-protected) build runs first, so an edited
+    csrc/ file can never be measured through a stale binary; without hipcc the shipped library is loaded as it is, and its
+    absence is an error (there is no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -104,10 +104,17 @@ def lib():
     # system libamdhip64 first leaves torch with "No HIP GPUs are available"), so load torch first.
     import torch  # noqa: F401
 
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build  # raises if hipcc is missing
+    from . import build as _build
 
+    have_hipcc = True
+    try:
+        _build._hipcc()
+    except RuntimeError:
+        have_hipcc = False
+    if have_hipcc and os.environ.get("GFN_NO_REBUILD") != "1":
         _build.build_extension()
+    elif not os.path.exists(LIB_PATH):
+        raise GfnError(f"the HIP extension {LIB_PATH} is missing and there is no hipcc to build it")
     try:
         handle = C.CDLL(LIB_PATH)
     except OSError as e:  # no fallback

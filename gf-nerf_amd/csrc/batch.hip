@@ -380,10 +380,9 @@ int gfn_errmap_sample(const float* error_map, int64_t n_pixels, const double* bl
   const int use_lds = slots * (int64_t)sizeof(Slot) <= 128 * 1024;
   GFN_CHECK_ARG(use_lds || table_ws, "gfn_errmap_sample: %lld draws need the table workspace", (long long)n);
   const size_t lds = use_lds ? (size_t)slots * sizeof(Slot) : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute((const void*)errmap_dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_set = true;
   }
   errmap_dedupe_kernel<<<1, 1024, lds, st>>>(error_map, n_pixels, prefix_ws, bits, cand_ws, n, n_weighted, (Slot*)table_ws, slots, use_lds, pending_ws,
                                             lin, status);

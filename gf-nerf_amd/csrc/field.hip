@@ -373,11 +373,10 @@ int gfn_field_fwd(const float* feat, const int32_t* ray_id, const float* sh, con
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_fwd: n_max=%lld", (long long)n_max);
   FieldWeights w{weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6], weights[7], weights[8], weights[9]};
   if (int rc = check_weights("gfn_field_fwd", w)) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F_TOTAL * 4));
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F_TOTAL * 4));
-    attr_set = true;
   }
   const unsigned grid = persistent_grid(n_max);
   if (masks)
@@ -398,10 +397,9 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_bwd_dx: n_max=%lld", (long long)n_max);
   FieldWeights w{weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6], weights[7], weights[8], weights[9]};
   if (int rc = check_weights("gfn_field_bwd_dx", w)) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B_TOTAL * 4));
-    attr_set = true;
   }
   field_bwd_dx_kernel<<<persistent_grid(n_max), 256, B_TOTAL * 4, gfn_stream(stream)>>>(
       n_max, n_dev, d_sigma, d_rgb, rgb, h0, reinterpret_cast<const unsigned long long*>(masks), w, dfeat);

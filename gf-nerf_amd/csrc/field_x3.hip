@@ -516,13 +516,12 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(sh) |
                   reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
                 "gfn_field_fwd_x3: image, feat, sh, emb and planes must be 16-byte aligned");
-  static bool attr_set = false;
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
 #define GFN_FWD_ALL(X) X(true, true, false) X(true, false, false) X(false, false, false) X(true, false, true) X(false, false, true) X(true, true, true)
-  if (!attr_set) {
+  if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(S, P, L) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<S, P, L>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
     GFN_FWD_ALL(GFN_SET)
 #undef GFN_SET
-    attr_set = true;
   }
   const unsigned grid = persistent_grid8(n_max);
   const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
@@ -561,13 +560,12 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(bwd_image) | reinterpret_cast<uintptr_t>(dfeat) | reinterpret_cast<uintptr_t>(planes_hi) |
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue
-  static bool attr_set = false;
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
 #define GFN_BWD_ALL(X) X(false, 0) X(false, 1) X(false, 2) X(false, 3) X(true, 0) X(true, 1) X(true, 2) X(true, 3)
-  if (!attr_set) {
+  if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(P, SC) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<P, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     GFN_BWD_ALL(GFN_SET)
 #undef GFN_SET
-    attr_set = true;
   }
   const unsigned grid = persistent_grid8(n_max);
   const u32x4* img = reinterpret_cast<const u32x4*>(bwd_image);

@@ -237,14 +237,13 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   LevelScales sc;
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
-  static bool attr_set = false;
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
 #define GFN_FUSED_ALL(X) X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
-  if (!attr_set) {
+  if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(D, S, P) \
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<D, S, P>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     GFN_FUSED_ALL(GFN_SET)
 #undef GFN_SET
-    attr_set = true;
   }
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();

@@ -36,6 +36,17 @@ int gfn_decoder_cu_cap();
 
 static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// One-time set-up per (call site, device), e.g. hipFuncSetAttribute for a kernel's dynamic LDS size: true the first time it is
+// reached with the current device selected (`seen`: a function-local static, one bit per device ordinal).
+static inline bool gfn_first_call_on_device(unsigned long long& seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
+
 // live element count: device value if given, else the host capacity.
 __device__ __forceinline__ int64_t gfn_live_n(int64_t n_max, const int32_t* n_dev) {
   if (n_dev) {

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __re
     for (int attempt = 0; attempt < 2; attempt++) {
       for (int i = tid; i < (exact ? kSlice / 2 : kSlice / 4); i += 1024) reinterpret_cast<uint4*>(img64)[i] = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
-      float mag = 0.f;  // this lane's sum of max(|c0|, |c1|) in 2^-24 units (an upper bound of what any field saw; inf / NaN stay)
+      float mag = 0.f;  // this lane's sum of |c0| + |c1| in 2^-24 units: an upper bound (by up to 2x) of what any field saw, and -- unlike
+                        // max(|c0|, |c1|), which returns the non-NaN operand -- NaN or inf in EITHER half poisons it, so such a range
+                        // is redone with the reference's f16 adds, which carry the NaN into the pool like atomicAdd(half2) does
       // a wave takes 16 of the 256 producer streams, four at a time so that their (short, dependent) loads overlap; a
       // stream is contiguous: 16 bytes (two records) per lane and load
       auto add = [&](uint32_t slot, uint32_t val) {
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __re
         const half2_t v = __builtin_bit_cast(half2_t, val);
         if (exact) {
           const float f0 = (float)v[0] * kFixed, f1 = (float)v[1] * kFixed;  // exact: an integer below 2^40
-          mag += fmaxf(fabsf(f0), fabsf(f1));
+          mag += fabsf(f0) + fabsf(f1);
           const int c0 = (int)f0, c1 = (int)f1;  // (saturates beyond 2^31: such a range is done again below)
           atomicAdd(img64 + local, ((unsigned long long)(unsigned int)c1 << 32) + (unsigned long long)(long long)c0);
         } else {
@@ -168,10 +170,9 @@ int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_
   int64_t cap = (record_capacity / ((int64_t)n_ranges * 256)) & ~1ll;
   GFN_CHECK_ARG(cap >= 2, "gfn_grad_records_reduce: record buffer too small");
   if (cap > 0x7ffffffe) cap = 0x7ffffffe;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSlice * 8));
-    attr_set = true;
   }
   grad_accumulate_kernel<<<n_ranges, 1024, kSlice * 8, gfn_stream(stream)>>>(reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap,
                                                                            n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen,

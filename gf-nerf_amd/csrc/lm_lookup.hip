@@ -186,14 +186,13 @@ int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const
   if (cap > kLmK * kLmThreads) cap = kLmK * kLmThreads;  // 32 B of LDS and a register slot per sample
   A.cap = (int)cap;
   const size_t lds = (size_t)cap * 32;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen)) {
     const int max_lds = kLmK * kLmThreads * 32;
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_lookup_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_lookup_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_lookup_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lm_lookup_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    attr_set = true;
   }
   hipStream_t st = gfn_stream(stream);
   for (int tb = 0; tb < (table2_f16 ? 2 : 1); tb++) {

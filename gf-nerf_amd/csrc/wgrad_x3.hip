@@ -182,13 +182,9 @@ int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a,
            int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
   constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   const size_t lds = (size_t)2 * (MO + NI) * S * 32 * sizeof(_Float16);
-  static int attr_dev = -1;  // the attribute belongs to the (function, device) pair: one process drives one device, but check
-  int dev = 0;
-  GFN_CHECK_HIP(hipGetDevice(&dev));
-  if (attr_dev != dev) {
+  static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
+  if (gfn_first_call_on_device(attr_seen))
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_dev = dev;
-  }
   int64_t blocks = (n_max + S - 1) / S;
   if (blocks > 512) blocks = 512;
   wgrad_x3_kernel<FD, FA, TILED><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);

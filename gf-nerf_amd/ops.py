@@ -81,31 +81,6 @@ def hash_fwd(feat_pool, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, o
 _part_ws = {}
 
 
-def hash_fwd_part(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, out=None, accumulate=False, n_dev=None):
-    """One table's lookup as a radix-partitioned join (gfn_hash_fwd_part): same features as hash_fwd_f16, no random HBM access."""
-    _chk(table_f16, torch.float16, "table_f16"); _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool")
-    _chk(pts, torch.float32, "pts", 3); _chk(anchors, torch.int32, "anchors")
-    n = pts.shape[0]
-    if table_f16.numel() != 16 * (1 << log2_T) * 2 or prim_pool.numel() != 16 * n_volumes * 3:
-        raise _lib.GfnError("table or prim_pool of the wrong size")
-    stride = _anchor_stride(anchors, n)
-    if out is None:
-        out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
-    _chk(out, torch.float32, "out", 32)
-    need = int(_lib.lib().gfn_hash_fwd_part_workspace(n))
-    key = (pts.device, need)
-    ws = _part_ws.get(key)
-    if ws is None:
-        _part_ws.clear()
-        ws = _part_ws[key] = (torch.empty(need + 256, dtype=torch.uint8, device=pts.device), torch.zeros(1, dtype=torch.int32, device=pts.device))
-    buf, overflow = ws
-    off = (-buf.data_ptr()) % 256
-    rc = _lib.lib().gfn_hash_fwd_part(_ptr(table_f16), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors), stride, n, _ptr(n_dev),
-                                      n_volumes, log2_T, int(bool(accumulate)), _ptr(out), buf.data_ptr() + off, need, _ptr(overflow), _stream())
-    _lib.check(rc, "gfn_hash_fwd_part")
-    return out, overflow
-
-
 def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
                 halves_from=6, planar=False, accumulate=False):
     """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time.

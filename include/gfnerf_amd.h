@@ -123,16 +123,6 @@ int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const
                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const int32_t* anchors,
                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                     int halves_from, int planar, int accumulate, float* out, void* stream);
-/* The same lookup as gfn_hash_fwd_f16 for ONE table, organised as a radix-partitioned join
- * (csrc/part_lookup.hip): requests are sorted by the CU that owns the slot's address range, answered
- * from a 144 KiB LDS slice of the table and streamed back -- no random access to HBM.  Bit-identical
- * features.  anchors i32, element i at anchors[i*anchor_stride].  workspace: gfn_hash_fwd_part_workspace
- * bytes, 256-byte aligned; *overflow_dev |= 8 if an owner's stream overflowed (results invalid). */
-int64_t gfn_hash_fwd_part_workspace(int64_t n_max);
-int gfn_hash_fwd_part(const uint16_t* table_f16, const int32_t* prim_pool, const float* bias_pool, const float* pts,
-                      const int32_t* anchors, int anchor_stride, int64_t n_max, const int32_t* n_dev,
-                      int64_t n_volumes, int log2_T, int accumulate, float* out, void* workspace,
-                      int64_t workspace_bytes, int32_t* overflow_dev, void* stream);
 /* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
 int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
 

@@ -641,34 +641,6 @@ def test_s3im_matches_golden(ops, dev, golden):
     assert all(sorted(idx[256 * k: 256 * (k + 1)].cpu().tolist()) == list(range(256)) for k in range(1, 10))
 
 
-@pytest.mark.parametrize("n,log2_T", [(5000, 14), (777, 12), (20000, 16)])
-def test_partitioned_lookup_is_bit_identical(ops, dev, n, log2_T):
-    """gfn_hash_fwd_part (requests sorted by owning CU, answered from LDS slices) == gfn_hash_fwd_f16, bit for bit, for one
-    table and accumulated over two tables; ragged n, device-side live count smaller than the buffers."""
-    import torch
-
-    rng = np.random.default_rng(n)
-    V = 37
-    from gfnerf_amd import scene
-    prim_a = torch.from_numpy(scene.make_primes(V, seed=4)).to(dev)
-    prim_b = torch.from_numpy(scene.make_primes(V, seed=5)).to(dev)
-    T = 1 << log2_T
-    ta = torch.from_numpy(rng.uniform(-1, 1, (16 * T, 2)).astype(np.float32)).to(dev).to(torch.float16)
-    tb = torch.from_numpy(rng.uniform(-1e-2, 1e-2, (16 * T, 2)).astype(np.float32)).to(dev).to(torch.float16)
-    pts = torch.from_numpy(rng.uniform(0.05, 0.95, (n, 3)).astype(np.float32)).to(dev)
-    pts[: n // 3] = pts[0] + torch.linspace(0, 1e-3, n // 3, device=dev)[:, None]   # a run of near-identical points: skewed owners
-    anchors = torch.from_numpy(np.stack([rng.integers(0, V, n), rng.integers(0, 999, n), np.zeros(n)], -1).astype(np.int32)).to(dev)
-    n_live = n - 123
-    n_dev = torch.tensor([n_live], dtype=torch.int32, device=dev)
-    want1 = ops.hash_fwd_f16(ta, prim_a, None, pts, anchors, V, log2_T, n_dev=n_dev)
-    got1, ovf = ops.hash_fwd_part(ta, prim_a, None, pts, anchors, V, log2_T, n_dev=n_dev)
-    assert int(ovf.item()) == 0
-    assert torch.equal(got1[:n_live], want1[:n_live])
-    want2 = ops.hash_fwd_f16(ta, prim_a, None, pts, anchors, V, log2_T, table2_f16=tb, prim_pool2=prim_b, n_dev=n_dev)
-    got2, ovf = ops.hash_fwd_part(tb, prim_b, None, pts, anchors, V, log2_T, out=got1, accumulate=True, n_dev=n_dev)
-    assert int(ovf.item()) == 0 and torch.equal(got2[:n_live], want2[:n_live])
-
-
 @pytest.mark.parametrize("n,log2_T,halves_from", [(5000, 14, 0), (777, 12, 8), (300000, 16, 6), (1, 12, 0)])
 def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from):
     """gfn_hash_fwd_lm (all workgroups sweep level by level, one L2-sized address half at a time) == gfn_hash_fwd_f16, bit for
