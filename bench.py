@@ -39,6 +39,7 @@ N_RAYS = 4096
 TARGET_SAMPLES = {"focal": 192, "global": 128}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PRIMING = 2            # set-up steps before the W warm-up steps (code objects, workspaces, allocator blocks)
+GRAPH_WARMUP = 4       # untimed replays between the capture and the timed region (launch mode graph)
 CTL_DEV = "cuda"       # where the few control scalars of the job (timings, fineness) are exchanged: the device under RCCL, the host under gloo
 
 
@@ -61,6 +62,11 @@ def parse():
                     help="timed steps of the `global_stage` sub-record (configs[1], 4096 x 128); 0 = skip.  Its warm-up is --global-warmup")
     ap.add_argument("--global-warmup", type=int, default=60, help="past the level-major switch at optimiser step 50")
     ap.add_argument("--sub-timeout", type=float, default=240.0, help="seconds a sub-record may take before the line is printed without it")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
+                    help="graph (default): the timed steps are hipGraph replays of the captured step (gfnerf_amd.stepgraph): one launch "
+                         "per step, immune to a busy host; eager: every kernel enqueued from Python.  Data-parallel global-stage steps "
+                         "are always eager (collectives)")
+    ap.add_argument("--probe-steps", type=int, default=10, help="eager steps after a graph-timed region that time the individual kernels with HIP events")
     ap.add_argument("--graph-experiment", choices=["off", "eager", "graph"], default="off",
                     help="experiment: ONE fixed batch every step, eagerly launched or as one captured hipGraph replayed per step "
                          "(isolates launch overhead; the captured step's optimiser scalars are frozen, so not a training run)")
@@ -495,19 +501,53 @@ class StageRun:
         el = time.perf_counter() - t0
         print(json.dumps(dict(experiment=mode, stage=self.stage, ms_per_step=el / steps * 1e3, host_enqueue_ms_per_step=host / steps * 1e3, loss=float(loss.item()))))
 
+    def _graph(self):
+        """Capture the step (gfnerf_amd.stepgraph) after the eager warm-up; None when the step cannot be captured."""
+        from gfnerf_amd import stepgraph
+
+        hp, args = self.hp, self.args
+        if args.launch != "graph" or (self.world > 1 and self.stage == "global") or args.no_prefetch:
+            return None, "eager (requested)" if args.launch != "graph" else "eager (data-parallel step: collectives)"
+        try:
+            hp._drop_stale_samples()  # the last eager step prefetched a sample nobody will collect
+            blocks = list(range(self.n_blocks)) if self.stage == "focal" else None
+            sg = stepgraph.StepGraph(hp, self.stage, N_RAYS, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update)
+            o, d, _, _ = self.batches[self.i % 4]
+            sg.prime(o, d)
+            sg.p = self.i % sg.cycle  # the block rotation goes on where the eager steps stopped
+            sg.capture()
+            return sg, f"hipGraph replay ({sg.cycle} captured graphs: sample-buffer parity x block rotation)"
+        except Exception as e:  # noqa: BLE001 -- the eager path is always there
+            hp._pre = None
+            return None, f"eager (capture failed: {type(e).__name__}: {e})"
+
+    def graph_step(self, sg):
+        i = self.i
+        self.i += 1
+        _, _, cam, gt = self.batches[i % 4]
+        nxt = self.batches[(i + 1) % 4]
+        return sg.step(cam, gt, nxt[0], nxt[1])
+
     def run(self, steps, warmup, dist=None):
-        """-> dict(elapsed (max over ranks), host_enqueue, loss, aux) for `steps` timed steps after PRIMING + warmup untimed ones."""
+        """-> dict(elapsed (max over ranks), host_enqueue, loss, aux) for `steps` timed steps after PRIMING + warmup untimed ones.
+        Launch mode graph: the eager warm-up is followed by the capture and GRAPH_WARMUP untimed replays; the timed steps are
+        replays; then --probe-steps eager steps time the individual kernels with HIP events (a replay hides them)."""
         torch, hp, world = self.torch, self.hp, self.world
         for _ in range(PRIMING + warmup):
             self.step()
+        sg, self.launch = self._graph()
+        if sg is not None:
+            for _ in range(GRAPH_WARMUP):
+                self.graph_step(sg)
+        events = {"*"} if self.args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd", "wgrad", "adam"}
         hp.timings = {}
-        hp.timed_ops = {"*"} if self.args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd", "wgrad", "adam"}
+        hp.timed_ops = set() if sg is not None else events
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss, aux = self.step()
+            loss, aux = self.graph_step(sg) if sg is not None else self.step()
         host_enqueue = time.perf_counter() - t0  # when the host had launched everything: (well) below `elapsed` = the GPU is the bound
         torch.cuda.synchronize()
         if world > 1:
@@ -517,13 +557,25 @@ class StageRun:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=CTL_DEV)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
+        loss_value = float(loss.item())
+        probe = steps
+        if sg is not None:  # per-kernel event timings: eager steps right after the timed region
+            hp._pre = None
+            hp.timed_ops = events
+            probe = max(self.args.probe_steps, 1)
+            for _ in range(probe):
+                # the stream spins for a few ms first, so that every launch of the step is queued behind it: the events then
+                # bracket GPU time only (with an empty queue and a slow host they would also count the host's launch gaps)
+                torch.cuda._sleep(12_000_000)
+                loss, aux = self.step()
+            torch.cuda.synchronize()
         hp.timed_ops = set()
-        return dict(elapsed=elapsed, host_enqueue=host_enqueue, loss=loss, aux=aux, steps=steps)
+        return dict(elapsed=elapsed, host_enqueue=host_enqueue, loss=loss_value, aux=aux, steps=steps, event_steps=probe)
 
     def roofline(self, res):
         """Dominant kernel by event time per step + its algorithmic bytes (DESIGN.md "Kernels")."""
         torch, hp, cfg, args = self.torch, self.hp, self.cfg, self.args
-        aux, steps = res["aux"], res["steps"]
+        aux, steps = res["aux"], res["event_steps"]
         n_live = aux["samples"]["pts_offsets"][-1].item()
         n_tables = 2 if self.stage == "focal" else 1
         # fused forward: only samples in front of each ray's termination point are looked up (sigma > 0 marks them); per such
@@ -564,14 +616,17 @@ class StageRun:
                            source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
         return dict(bound="hbm", kernel=kernel_name, launches_per_step=launches, achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
+                    timing=("HIP events on the launch stream around every launch of the timed region" if res["event_steps"] == res["steps"] and self.launch.startswith("eager")
+                            else f"HIP events on the launch stream in {res['event_steps']} eager steps run right after the timed region (the timed steps are hipGraph replays, "
+                                 "which hide individual launches from events)"),
                     alg_bytes_per_launch=alg_bytes, kernel_ms={k: round(v, 4) for k, v in kern.items()}, request_rate=req), n_live, n_eval
 
     def print_stage_times(self, res):
         tot = 0.0
         for name, ev in self.hp.timings.items():
-            t = sum(a.elapsed_time(b) for a, b in ev) / res["steps"]
+            t = sum(a.elapsed_time(b) for a, b in ev) / res["event_steps"]
             tot += t
-            print(f"[stage] {self.stage:6s} {name:16s} {t:8.3f} ms/step ({len(ev) // res['steps']} launches)", file=sys.stderr)
+            print(f"[stage] {self.stage:6s} {name:16s} {t:8.3f} ms/step ({len(ev) // res['event_steps']} launches)", file=sys.stderr)
         print(f"[stage] {self.stage:6s} {'sum':16s} {tot:8.3f} ms/step", file=sys.stderr)
 
 
@@ -661,9 +716,11 @@ def run_rank(args):
                                             f"{world} focal blocks, 1 per GPU, {len(my_cams)} cameras per block, no data-path collective" if headline_stage == "focal"
                                             else f"dp{world}: MAX all-reduce of octree statistics + direct all-reduce (all-to-all, shard sum, all-gather) of table / decoder / embedding gradients"),
                                backend=backend if world > 1 else None,
-                               scene_build_s=round(t_build, 1), priming_steps=PRIMING, host_enqueue_ms_per_step=res["host_enqueue"] / args.steps * 1e3,
+                               scene_build_s=round(t_build, 1), priming_steps=PRIMING, launch=run.launch,
+                               graph_warmup_steps=GRAPH_WARMUP if run.launch.startswith("hipGraph") else 0,
+                               host_enqueue_ms_per_step=res["host_enqueue"] / args.steps * 1e3,
                                async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step",
-                               loss=float(res["loss"].item())),
+                               loss=res["loss"]),
                    roofline=roofline)
 
     def emit():
@@ -714,9 +771,10 @@ def run_rank(args):
                     steps=args.global_steps, warmup=args.global_warmup, samples_per_sec=gv * g_live / N_RAYS,
                     workload="GF-NeRF global stage, single Hash3DAnchored encoder + tiny MLP, 4096 rays x 128 samples (BASELINE configs[1]); all parameters "
                              "train, UpdateOctNodes (K5/K6) every step", mean_samples_per_ray=g_live / N_RAYS, evaluated_sample_frac=g_eval / max(g_live, 1),
-                    forward=grun.hp.last_forward, fineness=grun.fineness, host_enqueue_ms_per_step=gres["host_enqueue"] / args.global_steps * 1e3,
+                    forward=grun.hp.last_forward, fineness=grun.fineness, launch=grun.launch,
+                    host_enqueue_ms_per_step=gres["host_enqueue"] / args.global_steps * 1e3,
                     parallelism="single GPU" if world == 1 else f"dp{world}: octree statistics MAX-reduced, gradients averaged (direct all-reduce) inside HotPath.train_step",
-                    replicas_bit_identical=identical, sync=dict(sync.stats) if world > 1 else None, loss=float(gres["loss"].item()), roofline=groof)
+                    replicas_bit_identical=identical, sync=dict(sync.stats) if world > 1 else None, loss=gres["loss"], roofline=groof)
 
         try:
             with Deadline(args.sub_timeout if world > 1 else 1e9, emit):

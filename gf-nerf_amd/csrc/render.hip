@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float one_m_b1, float beta2, float one_m_b2, float step_size,
-                                                   float bc2_sqrt, float eps) {
+                                                   float bc2_sqrt, float eps, const float* __restrict__ hyper) {
+  if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }  // (lr / bias_correction1, sqrt(bias_correction2)) of this step, from the device
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i];
     const float mi = m[i] + (gi - m[i]) * one_m_b1;
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(256) void adam_ex_kernel(float* __restrict__ p, con
                                                       float g_scale, float* __restrict__ m, float* __restrict__ v,
                                                       int64_t n, float one_m_b1, float beta2, float one_m_b2,
                                                       float step_size, float bc2_sqrt, float eps,
-                                                      _Float16* __restrict__ shadow, int shadow_pair) {
+                                                      _Float16* __restrict__ shadow, int shadow_pair, const float* __restrict__ hyper) {
+  if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
   // non-temporal accesses: 1 GB streams through once per step and must not evict what the level-major lookup of the next
   // step keeps in L2 when this kernel runs beside it (HotPathConfig.async_adam)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -537,8 +539,15 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
   return GFN_OK;
 }
 
+void gfn_adam_hyper_host(int step, float lr, float beta1, float beta2, float* out2) {
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  out2[0] = (float)(lr / bc1);
+  out2[1] = (float)sqrt(bc2);
+}
+
 int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
-                  float beta1, float beta2, float eps, void* stream) {
+                  float beta1, float beta2, float eps, const float* hyper_dev, void* stream) {
   GFN_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "gfn_adam_step: bad arguments");
   if (n == 0) return GFN_OK;
   const double bc1 = 1.0 - pow((double)beta1, step);
@@ -546,14 +555,14 @@ int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   adam_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                                                               (float)(lr / bc1), (float)sqrt(bc2), eps);
+                                                               (float)(lr / bc1), (float)sqrt(bc2), eps, hyper_dev);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }
 
 int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
-                     int shadow_pair, void* stream) {
+                     int shadow_pair, const float* hyper_dev, void* stream) {
   if (n == 0) return GFN_OK;
   GFN_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "gfn_adam_step_ex: bad arguments");
   const double bc1 = 1.0 - pow((double)beta1, step);
@@ -563,10 +572,10 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
   _Float16* sh = reinterpret_cast<_Float16*>(shadow_f16);
   if (g_f16)
     adam_ex_kernel<true><<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, g_scale, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                                                                          (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair);
+                                                                          (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair, hyper_dev);
   else
     adam_ex_kernel<false><<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, g_scale, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                                                                           (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair);
+                                                                           (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair, hyper_dev);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -215,8 +215,9 @@ class HotPath:
                     prim=c(self.prim), bias=c(self.bias), layers=[(c(W), c(B)) for W, B in self.layers], emb=c(self.emb))
 
     # ------------------------------------------------------------------ sampling
-    def sample(self, rays_o, rays_d_raw, noise, need_world=False):
-        """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points."""
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None):
+        """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
+        returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph)."""
         c = self.cfg
         pre, self._pre = self._pre, None
         if pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
@@ -228,22 +229,26 @@ class HotPath:
             return pre[4]
         elif pre is not None:
             torch.cuda.current_stream().wait_stream(self._side)  # a prefetch nobody collects still owns the workspace
-        d = ops.normalize_dirs(rays_d_raw)
+        d = ops.normalize_dirs(rays_d_raw, out=None if out is None else out["dirs_unit"])
         R = rays_o.shape[0]
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
                         c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
                         pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world, want_dirs=need_world,
-                        table_space=True, workspace=self._sampler_ws)
+                        table_space=True, workspace=self._sampler_ws, out=out)
         self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
         # per-ray leftovers of the step that only depend on the rays: computed here so that a prefetched sampler takes them off the
         # main stream too (SH basis of the unit directions, nerfacto_field.py:519-521; the zero the loss kernels add to)
-        s["sh"] = ops.sh4(d)
-        s["loss0"] = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        s["sh"] = ops.sh4(d, out=None if out is None else out["sh"])
+        if out is None:
+            s["loss0"] = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        else:
+            s["loss0"] = out["loss0_buf"].zero_()
+        s["loss0_buf"] = s["loss0"]  # forward_backward pops "loss0"; the buffer stays for the next in-place refill
         return s
 
-    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None):
+    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None, out=None):
         """Run the sampler of the NEXT batch on a second stream now; the next self.sample(...) with the very same tensors
         collects it.  The ray march is latency-bound and the fused backward beside it fabric-bound, so the two share the
         chip (the backward is capped to cfg.prefetch_cus CUs meanwhile).  Only valid while the octree does not change
@@ -258,7 +263,7 @@ class HotPath:
         with torch.cuda.stream(self._side):
             if first is not None:
                 first()
-            s = self.sample(rays_o, rays_d_raw, noise, need_world)
+            s = self.sample(rays_o, rays_d_raw, noise, need_world, out=out)
         self._pre = (rays_o, rays_d_raw, noise, need_world, s)
 
     # -------------------------------------------------------------------- field
@@ -414,7 +419,7 @@ class HotPath:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
 
-    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None, want_depth=True):
+    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None, want_depth=True, samples=None):
         """Training forward of get_outputs.  Returns (comp, ctx): comp holds rgb [R,3], acc, depth_raw, weights,
         alphas; ctx is what backward() needs (the reference keeps the whole autograd graph alive instead).
         want_depth=False (the native train step, whose losses do not read depth) skips the batch-global t range that
@@ -422,7 +427,7 @@ class HotPath:
         c = self.cfg
         train_mlp = stage == STAGE_GLOBAL
         self._timed("zero_grads", self.zero_grads, stage, block)
-        s = self.sample(rays_o, rays_d_raw, noise)
+        s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples  # samples: this batch's, made already
         # focal stage (frozen decoder): the ReLU masks are all the backward needs; global stage: the x3 kernels also keep
         # every layer input as split-f16 planes for the weight gradients (the exact-f32 fused kernels have no such form)
         fused = c.fused_field and c.hidden == 128 and (not train_mlp or c.mlp_precision == "x3")
@@ -538,23 +543,23 @@ class HotPath:
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
     def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None,
-                         update_oct=False):
+                         update_oct=False, samples=None, prefetch_out=None):
         """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
         s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent.
         prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage; global
         stage only together with update_oct).  update_oct (global stage): run UpdateOctNodes on this step's samples right after
         the forward, like GFNeRFModel.get_outputs does."""
         c = self.cfg
-        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False)
+        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False, samples=samples)
         if stage == STAGE_GLOBAL and update_oct:
             if prefetch is not None:
-                self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx))
+                self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx), out=prefetch_out)
             else:
                 self._timed("oct_update", self.update_oct_nodes, ctx)
         elif prefetch is not None and stage == STAGE_FOCAL:
-            self.prefetch_sample(*prefetch)
+            self.prefetch_sample(*prefetch, out=prefetch_out)
         loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb, loss=ctx["samples"].pop("loss0", None))  # rgb_loss (nerfacto.py:636)
-        R = rays_o.shape[0]
+        R = gt_rgb.shape[0]
         if c.s3im_loss_mult > 0 and (R * c.s3im_repeat_time) % c.s3im_patch_height == 0 and R * c.s3im_repeat_time >= 4 * c.s3im_patch_height:
             if s3im_index is None:
                 s3im_index = ops.s3im_index(R, c.s3im_repeat_time, device=self.dev)
@@ -563,8 +568,18 @@ class HotPath:
         self.backward(ctx, g_rgb)
         return loss, ctx
 
-    def optimizer_step(self, stage=STAGE_GLOBAL, block=None):
+    def adam_groups(self, stage, block=None):
+        """The parameter groups optimizer_step(stage, block) steps, with their learning rates (nerfacto.py:448-488)."""
         c = self.cfg
+        if stage == STAGE_GLOBAL:
+            return [("table", c.lr), ("mlp", c.lr)] + ([("emb", c.lr)] if c.use_appearance_embedding else [])
+        return [(f"block{block}", c.lr_block)]
+
+    def optimizer_step(self, stage=STAGE_GLOBAL, block=None, hyper=None):
+        """hyper: {group name: device f32 [2]} -- the step-dependent Adam factors read from the device instead of being passed
+        by value (a captured step; the host refreshes them before every replay and advances the group's step count itself)."""
+        c = self.cfg
+        hy = (lambda name: hyper[name]) if hyper is not None else (lambda name: None)
         self.step += 1
         # only elements [0, 17T) of a table are addressable (level-overlap quirk); the rest never receive a
         # gradient, so dense Adam leaves them untouched and they are skipped exactly
@@ -572,20 +587,20 @@ class HotPath:
         if stage == STAGE_GLOBAL:
             m, v = self._adam_state("table", self.table)
             self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self._adam_tick("table"), lr=c.lr, eps=c.adam_eps,
-                        shadow_f16=self.table16, n=n_live)
+                        shadow_f16=self.table16, n=n_live, hyper=hy("table"))
             self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
             self._x3_stale = True
             for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
                 m, v = self._adam_state(name, p)
-                self._timed("adam", ops.adam_step, p, gr, m, v, self._adam_tick(name), lr=c.lr, eps=c.adam_eps)
+                self._timed("adam", ops.adam_step, p, gr, m, v, self._adam_tick(name), lr=c.lr, eps=c.adam_eps, hyper=hy(name))
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
             run = lambda: self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(f"block{block}"),  # noqa: E731
                                       lr=c.lr_block, eps=c.adam_eps, shadow_f16=self.blocks16[block] if c.table_f16_shadow else None,
-                                      n=n_live, shadow_pair=c.share_block_primes)
+                                      n=n_live, shadow_pair=c.share_block_primes, hyper=hy(f"block{block}"))
             if c.async_adam and c.level_major and not c.share_block_primes:
                 if self._opt_stream is None:
                     self._opt_stream = torch.cuda.Stream(device=self.dev)
@@ -624,12 +639,13 @@ class HotPath:
             self.sync.finish_grads(g[1:])
 
     def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None,
-                   prefetch=None, update_oct=False):
-        """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path."""
+                   prefetch=None, update_oct=False, samples=None, prefetch_out=None, hyper=None):
+        """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path.  samples / prefetch_out / hyper: see
+        gfnerf_amd.stepgraph (the step captured in a hipGraph)."""
         loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch,
-                                          update_oct=update_oct)
+                                          update_oct=update_oct, samples=samples, prefetch_out=prefetch_out)
         self.sync_grads(stage, aux)
-        self.optimizer_step(stage, block)
+        self.optimizer_step(stage, block, hyper=hyper)
         return loss, aux
 
     def update_oct_nodes(self, aux):

@@ -189,9 +189,9 @@ def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, gr
 
 
 # ------------------------------------------------------------------------ sampler
-def normalize_dirs(rays_d):
-    _chk(rays_d, torch.float32, "rays_d", 3)
-    out = torch.empty_like(rays_d)
+def normalize_dirs(rays_d, out=None):
+    _chk(rays_d, torch.float32, "rays_d", 3); _chk(out, torch.float32, "out", 3)
+    out = torch.empty_like(rays_d) if out is None else out
     _lib.check(_lib.lib().gfn_normalize_dirs(_ptr(rays_d), _ptr(out), rays_d.shape[0], _stream()), "gfn_normalize_dirs")
     return out
 
@@ -265,8 +265,10 @@ def tree_compact(nodes, out=None):
 
 
 def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8,
-                max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None):
-    """Fast GetSamples: single-pass dense trace + 16-lane-per-ray march.  Same dict as march()."""
+                max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None, out=None):
+    """Fast GetSamples: single-pass dense trace + 16-lane-per-ray march.  Same dict as march().  out: a dict an earlier call
+    returned (same R / pts_cap / options): its tensors are written again instead of allocating new ones (static buffers of a
+    captured step)."""
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
     _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
     R = rays_o.shape[0]
@@ -281,13 +283,19 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
                          hit_nf=f(max(R * max_hits, 1), 2),
                          march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * 3))  # (t, dist, leaf) per sample slot of the counting march
-    out = dict(
-        pts_offsets=torch.empty(R + 1, dtype=torch.int32, device=dev),
-        world_pts=f(pts_cap, 3) if want_world else None, warped_pts=f(pts_cap, 3), dirs=f(pts_cap, 3) if want_dirs else None,
-        dists=f(pts_cap), ts=f(pts_cap), anchors=torch.empty((pts_cap, 3), dtype=torch.int32, device=dev),
-        ray_id=torch.empty(pts_cap, dtype=torch.int32, device=dev), first_oct_dis=f(R),
-        overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace,
-    )
+    if out is not None:
+        if out["pts_offsets"].numel() != R + 1 or out["ts"].numel() != pts_cap or (want_world and out["world_pts"] is None):
+            raise _lib.GfnError("sample_rays: `out` was made for another batch size / capacity / option set")
+        out["overflow"].zero_()
+        out["workspace"] = workspace
+    else:
+        out = dict(
+            pts_offsets=torch.empty(R + 1, dtype=torch.int32, device=dev),
+            world_pts=f(pts_cap, 3) if want_world else None, warped_pts=f(pts_cap, 3), dirs=f(pts_cap, 3) if want_dirs else None,
+            dists=f(pts_cap), ts=f(pts_cap), anchors=torch.empty((pts_cap, 3), dtype=torch.int32, device=dev),
+            ray_id=torch.empty(pts_cap, dtype=torch.int32, device=dev), first_oct_dis=f(R),
+            overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace,
+        )
     rc = _lib.lib().gfn_sample_rays(_ptr(rays_o), _ptr(rays_d), _ptr(noise), R, _ptr(compact_nodes), _ptr(transes), near, far,
                                     max_hits, float(sample_l), int(bool(scale_by_dis)), int(bool(table_space)),
                                     _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]), _ptr(workspace["hit_nf"]),
@@ -871,9 +879,9 @@ def grad_records_reduce(records, grad_pool, log2_T, counts_seen=None, f16_accumu
     _lib.check(rc, "gfn_grad_records_reduce")
 
 
-def sh4(dirs):
-    _chk(dirs, torch.float32, "dirs", 3)
-    out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device)
+def sh4(dirs, out=None):
+    _chk(dirs, torch.float32, "dirs", 3); _chk(out, torch.float32, "out", 16)
+    out = torch.empty((dirs.shape[0], 16), dtype=torch.float32, device=dirs.device) if out is None else out
     _lib.check(_lib.lib().gfn_sh4(_ptr(dirs), dirs.shape[0], _ptr(out), _stream()), "gfn_sh4")
     return out
 
@@ -952,11 +960,11 @@ def charbonnier(pred, gt, eps=1e-6, loss=None):
     return loss, g
 
 
-def s3im_index(n_rays, repeat_time=10, generator=None, device=None):
+def s3im_index(n_rays, repeat_time=10, generator=None, device=None, out=None):
     """The index vector S3IM.forward builds (losses.py:780-789): arange followed by repeat_time - 1 random permutations.
     The permutations come from ONE batched argsort of f64 uniforms (three launches instead of 9 x torch.randperm: this runs
     every training step)."""
-    out = torch.empty((repeat_time, n_rays), dtype=torch.int32, device=device)
+    out = torch.empty((repeat_time, n_rays), dtype=torch.int32, device=device) if out is None else out.view(repeat_time, n_rays)
     out[0] = torch.arange(n_rays, device=device, dtype=torch.int32)
     if repeat_time > 1:
         keys = torch.rand((repeat_time - 1, n_rays), dtype=torch.float64, device=device, generator=generator)
@@ -988,16 +996,25 @@ def s3im(gt, pred, index, patch_h=32, mult=1.0, loss=None, g_pred=None, want_gra
     return loss, g_pred
 
 
-def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15):
+def adam_hyper(step, lr=1e-2, beta1=0.9, beta2=0.999):
+    """(lr / (1 - beta1^step), sqrt(1 - beta2^step)) as the Adam kernels compute them on the host: what `hyper` must hold."""
+    out = np.zeros(2, np.float32)
+    _lib.lib().gfn_adam_hyper_host(int(step), float(lr), float(beta1), float(beta2), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, hyper=None):
+    """hyper: device f32 [2] = adam_hyper(step, lr, ...) read by the kernel instead of the host's `step` / `lr` (hipGraph replay)."""
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, torch.float32, nm)
+    _chk(hyper, torch.float32, "hyper")
     if not (p.numel() == g.numel() == m.numel() == v.numel()):
         raise _lib.GfnError("adam_step: size mismatch")
     _lib.check(_lib.lib().gfn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), float(lr), float(beta1),
-                                        float(beta2), float(eps), _stream()), "gfn_adam_step")
+                                        float(beta2), float(eps), _ptr(hyper), _stream()), "gfn_adam_step")
 
 
-def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None, shadow_pair=False):
+def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None, shadow_pair=False, hyper=None):
     """Adam on (the first n elements of) a hash table; g float32, or float16 carrying the x128 loss scale."""
     _chk(p, torch.float32, "p"); _chk(m, torch.float32, "m"); _chk(v, torch.float32, "v"); _chk(shadow_f16, torch.float16, "shadow")
     if g.dtype not in (torch.float32, torch.float16):
@@ -1009,7 +1026,7 @@ def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15
     g16 = g.dtype == torch.float16
     _lib.check(_lib.lib().gfn_adam_step_ex(_ptr(p), _ptr(g), int(g16), (1.0 / 128.0) if g16 else 1.0, _ptr(m), _ptr(v), n,
                                            int(step), float(lr), float(beta1), float(beta2), float(eps), _ptr(shadow_f16),
-                                           int(bool(shadow_pair)), _stream()), "gfn_adam_step_ex")
+                                           int(bool(shadow_pair)), _ptr(hyper), _stream()), "gfn_adam_step_ex")
 
 
 def fill_zero(t):

@@ -1,0 +1,158 @@
+"""A training step of the hot path as a hipGraph replay.
+
+HotPath.train_step enqueues ~45 launches, fills and stream hand-offs per step from Python.  On a quiet host that costs
+0.5 ms of CPU time per step and hides behind the 1.7 - 2.4 ms the GPU needs; on a busy host (the CPUs of a GPU box are
+shared) it does not, and the step becomes host-bound (measured: 2.5 - 3.7 ms/step instead of 1.74 on boxes whose host took
+1.4 - 3.4 ms to enqueue one).  The step has no host synchronisation and no data-dependent launch, so it is capturable: this
+module captures it ONCE (twice: the sampler ping-pong below) with torch.cuda.graphs and replays it -- one launch per step,
+80 us of host time.
+
+What a replay contains (`StepGraph.step`), exactly one of each like the eager step:
+    side branch:  the NEXT step's S3IM permutations and march noise drawn on the device -> [global stage: UpdateOctNodes of
+                  THIS step, right after the forward] -> sampler of the NEXT batch's rays into the other sample buffer
+    main branch:  forward on THIS batch's samples -> loss -> backward -> table-gradient accumulation -> Adam
+The graphs G[0], G[1] differ only in which of the two static sample buffers S[0], S[1] is read and which is written
+(replay k reads S[k % 2], its side branch fills S[(k + 1) % 2] for replay k + 1); with several focal blocks trained in
+rotation (`block=[0, 1, 2, 3]`: step k trains block k mod 4) there is one graph per position of the cycle lcm(2, blocks).  Inputs live in static device buffers the
+caller refills between replays (`cam / gt` of this batch, `o / d` of the next); Adam's step-dependent factors are read from
+a device vector the host refreshes before every replay (gfn_adam_hyper_host), so bias correction and learning-rate schedule
+advance although the launches are frozen.
+
+Not capturable, and refused: data-parallel steps (collectives run eagerly); a tree that changes size (ProcOctree every
+compact_freq steps: re-capture afterwards -- `StepGraph.invalidate`)."""
+import numpy as np
+import torch
+
+from . import _lib, hotpath as hp_mod, ops
+
+
+class StepGraph:
+    def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None):
+        """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant)."""
+        if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL:
+            raise _lib.GfnError("StepGraph: the data-parallel global stage exchanges gradients with eager collectives; not captured")
+        self.hp, self.stage, self.R = hp, stage, int(n_rays)
+        self.blocks = list(block) if isinstance(block, (list, tuple)) else [block]
+        self.cycle = len(self.blocks) if len(self.blocks) % 2 == 0 else 2 * len(self.blocks)  # lcm(2, number of blocks)
+        self.fineness, self.train_noise, self.update_oct = float(fineness), train_noise, update_oct and stage == hp_mod.STAGE_GLOBAL
+        self.lr_schedule = lr_schedule
+        dev = hp.dev
+        f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)  # noqa: E731
+        self.cam = torch.zeros(self.R, dtype=torch.int32, device=dev)
+        self.gt = f(self.R, 3)
+        self.nxt_o, self.nxt_d = f(self.R, 3), f(self.R, 3)
+        self.nxt_d[:, 2] = -1.0
+        self.groups = []
+        for b in self.blocks:
+            self.groups += [g for g in hp.adam_groups(stage, b) if g not in self.groups]
+        self.hyper_dev = f(len(self.groups), 2)
+        self.hyper_host = torch.zeros((len(self.groups), 2), dtype=torch.float32).pin_memory()
+        self.hyper = {name: self.hyper_dev[i] for i, (name, _) in enumerate(self.groups)}
+        self.S = [None, None]
+        self.s3 = [None, None]  # S3IM permutations of the step that reads S[p], drawn one step ahead like the samples
+        self.G = [None] * self.cycle
+        self.loss = [None] * self.cycle
+        self.aux = [None] * self.cycle
+        self.p = 0  # position in the cycle of the next replay
+        self.primed = False
+        self._tree = None
+
+    # ------------------------------------------------------------------ set-up
+    def _noise(self):
+        return ops.sampler_noise(self.R, self.fineness, train=self.train_noise, device=self.hp.dev)
+
+    def prime(self, rays_o, rays_d):
+        """Sample the FIRST batch's rays (eagerly) into S[0]; from then on every replay samples the next batch itself."""
+        hp = self.hp
+        for k in range(2):  # both buffers exist before anything is captured (same shapes, same options)
+            self.nxt_o.copy_(rays_o); self.nxt_d.copy_(rays_d)
+            self.S[k] = hp.sample(self.nxt_o, self.nxt_d, self._noise(), out=self.S[k])
+            if hp.cfg.s3im_loss_mult > 0:
+                self.s3[k] = ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[k])
+        self.p, self.primed = 0, True  # the first replay reads S[0]
+
+    def _step_eager_or_captured(self, j):
+        """The launches of step j of the cycle: block blocks[j mod n], reading S[j mod 2] and filling the other buffer (called
+        under capture)."""
+        hp = self.hp
+        p, block = j % 2, self.blocks[j % len(self.blocks)]
+        main = torch.cuda.current_stream()
+        if hp._side is None:
+            hp._side = torch.cuda.Stream(device=hp.dev)
+        side = hp._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # the NEXT step's random draws, on the device, beside this step's forward
+            if hp.cfg.s3im_loss_mult > 0:
+                ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[1 - p])
+            noise = self._noise()
+        loss, aux = hp.train_step(None, None, self.cam, self.gt, None, stage=self.stage, block=block, s3im_index=self.s3[p],
+                                  prefetch=(self.nxt_o, self.nxt_d, noise), update_oct=self.update_oct, samples=self.S[p],
+                                  prefetch_out=self.S[1 - p], hyper=self.hyper)
+        assert hp._pre is not None and hp._pre[4]["pts_offsets"] is self.S[1 - p]["pts_offsets"], "the prefetch must fill the other sample buffer"
+        self.S[1 - p] = hp._pre[4]
+        hp._pre = None  # collected: the next replay reads it as its `samples`
+        main.wait_stream(side)
+        return loss, aux
+
+    def capture(self):
+        """One capture per parity.  Everything a step creates lazily and keeps (gradient pool, record streams, activation planes,
+        Adam moments, kernel attributes, weight images) must exist already -- a buffer first allocated under capture would live in
+        the graph's pool and be re-initialised by every replay -- so at least one EAGER train_step of this stage comes first."""
+        assert self.primed, "StepGraph.prime(first batch's rays) before the first step"
+        hp = self.hp
+        if hp.table_grad is None or (self.stage == hp_mod.STAGE_GLOBAL and hp._plane_bufs is None and hp.cfg.fused_field):
+            raise _lib.GfnError("StepGraph: run one eager HotPath.train_step of this stage before capturing (lazily created buffers)")
+        for name, _ in self.groups:
+            hp._adam_state(name, self._param_of(name))
+        self._refresh_hyper(advance=False)
+        torch.cuda.synchronize()
+        steps_before, ticks_before = hp.step, dict(hp._adam_t)
+        pool = None
+        for j in range(self.cycle):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.loss[j], self.aux[j] = self._step_eager_or_captured(j)
+            pool = g.pool()
+            self.G[j] = g
+        hp.step, hp._adam_t = steps_before, ticks_before  # capturing executes nothing: the counters must not move
+        self._tree = (hp.nodes.data_ptr(), hp.n_nodes)
+
+    def invalidate(self):
+        """The tree (or anything else baked into the launches) changed: capture again at the next step."""
+        self.G = [None] * self.cycle
+
+    # ------------------------------------------------------------------ per step
+    def _refresh_hyper(self, advance=True):
+        """Adam's factors of the NEXT step of every group; advance: the groups of the step about to be replayed take it."""
+        hp = self.hp
+        step_for_lr = hp.step
+        active = {n for n, _ in hp.adam_groups(self.stage, self.blocks[self.p % len(self.blocks)])}
+        for i, (name, lr) in enumerate(self.groups):
+            if name not in hp._adam_t:
+                hp._adam_state(name, self._param_of(name))
+            t = hp._adam_t[name] + 1
+            if advance and name in active:
+                hp._adam_t[name] = t
+            mult = 1.0 if self.lr_schedule is None else float(self.lr_schedule(step_for_lr))
+            self.hyper_host[i] = torch.from_numpy(ops.adam_hyper(t, lr * mult))
+        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+        if advance:
+            hp.step += 1
+
+    def _param_of(self, name):
+        hp = self.hp
+        return {"table": hp.table, "mlp": hp.mlp_flat, "emb": hp.emb}.get(name) if not name.startswith("block") else hp.blocks[int(name[5:])]
+
+    def step(self, cam_idx, gt_rgb, next_rays_o, next_rays_d):
+        """One training step on the batch whose rays the previous step (or prime) sampled; next_rays_*: the rays of the batch
+        the NEXT call will train on.  -> (loss [1] device tensor of this step, aux) -- static buffers, overwritten by the next call."""
+        hp = self.hp
+        if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
+            self.capture()
+        self.cam.copy_(cam_idx); self.gt.copy_(gt_rgb)
+        self.nxt_o.copy_(next_rays_o); self.nxt_d.copy_(next_rays_d)
+        self._refresh_hyper(advance=True)
+        j = self.p
+        self.G[j].replay()
+        self.p = (j + 1) % self.cycle
+        return self.loss[j], self.aux[j]

@@ -481,15 +481,20 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
  * NULL).  gt, pred f32 [R,3]. */
 int gfn_s3im(const float* gt, const float* pred, const int32_t* index, int64_t n_idx, int patch_h, float mult,
              float* loss_dev, float* g_pred, void* stream);
+/* torch.optim.Adam (gfnerf/config.py:130), one step of one parameter group.  The two step-dependent factors
+ * (lr / (1 - beta1^step), sqrt(1 - beta2^step)) are computed here from `step` -- or, when hyper_dev (device f32[2]) is not
+ * NULL, read from it by the kernel: a step captured in a hipGraph takes them from memory the host refreshes before every
+ * replay (gfn_adam_hyper_host gives the same two floats).  */
+void gfn_adam_hyper_host(int step, float lr, float beta1, float beta2, float* out2);
 int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
-                  float beta1, float beta2, float eps, void* stream);
+                  float beta1, float beta2, float eps, const float* hyper_dev, void* stream);
 /* Adam for a hash table: g is f32 (g_f16 == 0) or f16 (g_f16 != 0) and is multiplied by
  * g_scale first (1/128 for gfn_hash_bwd's f16 pool); shadow_f16 (may be NULL) receives
  * f16(p) of every updated element so gfn_hash_fwd_f16 stays current (shadow_pair != 0: the
  * shadow is the block half of a gfn_table_pair_f16 image). */
 int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
-                     int shadow_pair, void* stream);
+                     int shadow_pair, const float* hyper_dev, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
 
 /* Local step of the direct (all-to-all + all-gather) gradient all-reduce of the ray-data-parallel global stage

@@ -737,3 +737,70 @@ def test_async_adam_is_the_same_training_run(setup):
     assert float((b0 - b1).abs().max()) <= 6 * 5e-3 * 2 * 1.2
     assert float((b0 - b1).abs().mean()) < 3e-3
     assert float(g1.abs().max()) == 0.0  # the pool was zeroed behind the last asynchronous Adam
+
+
+@pytest.mark.parametrize("stage", ["focal", "global"])
+def test_step_graph_is_the_same_training_run(setup, stage):
+    """gfnerf_amd.stepgraph.StepGraph: K training steps as hipGraph replays (sampler of the next batch on a captured side branch,
+    Adam's step-dependent factors read from the device) against the same K steps launched eagerly -- with the random draws
+    switched off (eval-mode march noise, no S3IM) the two runs must agree: bit for bit in the focal stage (exact LDS
+    accumulation makes the step reproducible), to f16 gradient rounding in the global stage (its weight-gradient atomics are
+    not ordered)."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops, scene, stepgraph
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    R, K = 256, 6
+    batches = []
+    for k in range(K + 1):
+        o, d, cam = scene.make_rays(sc["c2w"], R, seed=40 + k)
+        gt = np.random.default_rng(90 + k).random((R, 3)).astype(np.float32)
+        batches.append(tuple(t(a) for a in (o, d, cam, gt)))
+    fin = 5.0
+    noise = t(scene.make_noise(R, False, fin))
+
+    def make():
+        # focal: a table large enough that no record stream overflows into (unordered) f16 atomics -> the step is reproducible
+        cfg = hotpath.HotPathConfig(log2_T=18 if stage == "focal" else 14, s3im_loss_mult=0.0)
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1 if stage == "focal" else 0)
+        hp.table.mul_(100.0); hp.refresh_shadows()
+        return hp
+
+    blk = 0 if stage == "focal" else None
+    upd = stage == "global"
+    # eager run: K + 1 steps (step 0 is the eager step the graph needs first, too)
+    he = make()
+    losses_e = []
+    for k in range(K + 1):
+        o, d, cam, gt = batches[k]
+        l, _ = he.train_step(o, d, cam, gt, noise, stage=stage, block=blk, update_oct=upd)
+        losses_e.append(float(l.item()))
+    # graph run: the same step 0 eagerly, then K replays
+    hg = make()
+    o, d, cam, gt = batches[0]
+    hg.train_step(o, d, cam, gt, noise, stage=stage, block=blk, update_oct=upd)
+    sg = stepgraph.StepGraph(hg, stage, R, fin, block=blk, update_oct=upd, train_noise=False)
+    sg.prime(batches[1][0], batches[1][1])
+    losses_g = []
+    for k in range(1, K + 1):
+        nxt = batches[k + 1] if k < K else batches[k]
+        l, _ = sg.step(batches[k][2], batches[k][3], nxt[0], nxt[1])
+        losses_g.append(float(l.item()))
+    torch.cuda.synchronize()
+    assert hg.step == he.step == K + 1 and hg._adam_t == he._adam_t
+    pe = he.blocks[0] if stage == "focal" else he.table
+    pg = hg.blocks[0] if stage == "focal" else hg.table
+    assert float((pe - (0 if stage == "focal" else make().table)).abs().max()) > 0  # the run did train
+    if stage == "focal":
+        np.testing.assert_allclose(losses_g, losses_e[1:], rtol=1e-5)  # the loss is a sum of per-wave partial sums added atomically
+        assert torch.equal(pe, pg) and torch.equal(he._adam["block0"][0], hg._adam["block0"][0]) and torch.equal(he._adam["block0"][1], hg._adam["block0"][1])
+    else:
+        np.testing.assert_allclose(losses_g, losses_e[1:], rtol=2e-3)
+        # Adam turns a gradient whose last f16 bit differs (unordered atomics where a record stream overflows at this table size)
+        # into a step of the full learning rate, so a few slots differ by k * lr: all but a vanishing fraction agree
+        far = (pg - pe).abs() > 2e-3 * float(pe.abs().max())
+        assert float(far.float().mean()) < 1e-3 and float((pg - pe).abs().max()) <= 2 * K * 1e-2
+        np.testing.assert_allclose(hg.mlp_flat.cpu().numpy(), he.mlp_flat.cpu().numpy(), atol=2e-2 * float(he.mlp_flat.abs().max()))
+        assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
