@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
     ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
+    ap.add_argument("--table-branch", action="store_true",
+                    help="global stage: table-gradient accumulation + table Adam on a second stream beside the weight-gradient kernels (no gain measured)")
     ap.add_argument("--async-adam", action="store_true",
                     help="focal stage: Adam of step i on a third stream beside the frozen global table's lookup of step i + 1 (about "
                          "-1.5 percent per step; off by default so that the roofline kernel is timed running alone)")
@@ -394,7 +396,7 @@ class StageRun:
         self.cfg = cfg = hotpath.HotPathConfig(
             log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
             prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
-            fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
+            fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, table_branch=args.table_branch,
             level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
             **({"level_major_global_after": ga} if ga is not None else {}))

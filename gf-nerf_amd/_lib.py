@@ -8,6 +8,14 @@ LIB_PATH = os.path.join(_HERE, "libgfnerf_amd.so")
 
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
 
+
+
+class WgradLayer(C.Structure):
+    """gfn_wgrad_layer (include/gfnerf_amd.h)."""
+    _fields_ = [("dz_hi", _vp), ("dz_lo", _vp), ("a_hi", _vp), ("a_lo", _vp), ("feat_dz", C.c_int32), ("feat_a", C.c_int32),
+                ("m_valid", C.c_int32), ("k_valid", C.c_int32), ("col_map", _vp), ("dW", _vp), ("ldw", C.c_int32), ("db", _vp)]
+
+
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {
     "gfn_last_error": (C.c_char_p, []),
@@ -53,6 +61,9 @@ SIGNATURES = {
     "gfn_grad_scale_host": (_f32, [_f32]),
     "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gfn_wgrad_x3_parts": (_i32, []),
+    "gfn_wgrad_x3_layers": (_i32, [C.POINTER(WgradLayer), _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "gfn_wgrad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

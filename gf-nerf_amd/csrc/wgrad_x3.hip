@@ -2,14 +2,18 @@
 //
 // The contraction runs over SAMPLES, which the fused forward / backward kernels hold on the lane axis
 // of their accumulator tiles (MFMA lanes index M or N, never K), so both operands come back from HBM:
-// the producers write them as split-f16 "planes" (hi and lo' = (x-hi)*2^11, see field_x3.hip) -- tile-major
-// [n / 32][features / 8][32 samples][8 features] (x3_device.h plane_off; `tiled`), or plain rows [n][ld] for callers that
-// build planes themselves --, this kernel stages 64-sample slabs in LDS as [feature tile][sample][32] (64-byte rows)
-// and reads them TRANSPOSED with ds_read_b64_tr_b16: per 16-lane group a 4-sample x 16-feature block
-// comes back feature-major, which is exactly the 32x32x16 operand fragment
+// the producers write them as split-f16 "planes" (hi and lo' = (x-hi)*2^11, see field_x3.hip), tile-major
+// [n / 32][features / 8][32 samples][8 features] (x3_device.h plane_off).  Slabs of samples are staged in LDS as
+// [feature tile][sample][32] (64-byte rows) and read TRANSPOSED with ds_read_b64_tr_b16: per 16-lane group a
+// 4-sample x 16-feature block comes back feature-major, which is exactly the 32x32x16 operand fragment
 // (lane (h, r): feature r, samples 8h .. 8h+7 of the k-step), for A (= dz^T) and B (= a) alike.
-// Three MFMAs per (out tile, in tile, k-step) as in field_x3.hip.  Split-K over workgroups, f32 atomics
-// at the end (coalesced rows; 31 k weights x <= 256 workgroups).
+// Three MFMAs per (out tile, in tile, k-step) as in field_x3.hip.  Split-K over workgroups.
+//   wgrad_x3_layers_kernel  the training path: all five layers in one launch, 32-sample slabs by LDS-DMA
+//                           (global_load_lds_dwordx4, two buffers), bias sums from the MFMA fragments, per-workgroup partial
+//                           vectors + wgrad_reduce_kernel instead of final atomics.  1.85 GB of planes in 0.38 ms (4.9 TB/s);
+//                           the five register-staged launches with atomics it replaces took 0.47 ms
+//   wgrad_x3_kernel         planes as plain rows [n][ld] (callers that build planes themselves; tests): 64-sample slabs
+//                           staged through registers, f32 atomics at the end
 #include "gfn_common.h"
 
 namespace {
@@ -43,19 +47,15 @@ __device__ __forceinline__ h8 tr_frag(const _Float16* tile /*[S][32]*/, int ks, 
 
 // One slab = 64 samples x (FD + FA) features x {hi, lo'}.  Each thread owns a fixed set of 16-byte pieces; the next
 // slab's pieces are fetched into registers while the matrix pipe works on the current one.
-template <int FEAT, bool TILED>
+template <int FEAT>
 struct Stager {
   static constexpr int PIECES = FEAT / 8;                 // 16-byte pieces per sample row
   static constexpr int TOTAL = S * PIECES;                // pieces per slab
   static constexpr int PER_THREAD = (TOTAL + 255) / 256;
   u32x4 hi[PER_THREAD], lo[PER_THREAD];
 
-  // piece e of a slab -> (sample s, first feature f).  Rows: consecutive threads walk one sample's row; tiled: consecutive
-  // threads walk the 32 samples of one octet (512 contiguous bytes), the order the producers wrote them in.
-  static __device__ __forceinline__ void piece(int e, int& s, int& f) {
-    if (TILED) { s = (e & 31) + 32 * ((e >> 5) / PIECES); f = ((e >> 5) % PIECES) * 8; }
-    else { s = e / PIECES; f = (e % PIECES) * 8; }
-  }
+  // piece e of a slab -> (sample s, first feature f): consecutive threads walk one sample's row
+  static __device__ __forceinline__ void piece(int e, int& s, int& f) { s = e / PIECES; f = (e % PIECES) * 8; }
   __device__ __forceinline__ void fetch(const Plane& p, int64_t s0, int64_t n) {
 #pragma unroll
     for (int it = 0; it < PER_THREAD; it++) {
@@ -64,7 +64,7 @@ struct Stager {
       piece(e, s, f);
       hi[it] = u32x4{0u, 0u, 0u, 0u}; lo[it] = u32x4{0u, 0u, 0u, 0u};
       if (e < TOTAL && s0 + s < n) {
-        const int64_t o = TILED ? plane_off(s0 + s, p.ld, f >> 3) : (s0 + s) * p.ld + f;
+        const int64_t o = (s0 + s) * p.ld + f;
         hi[it] = *reinterpret_cast<const u32x4*>(p.hi + o);
         lo[it] = *reinterpret_cast<const u32x4*>(p.lo + o);
       }
@@ -86,7 +86,7 @@ struct Stager {
 
 // WAVE_IS_NI: wave w owns in-tile w and loops over the MO out tiles (NI == 4); else wave w owns out tile w (MO == 4)
 // and loops over the NI in tiles.
-template <int FD, int FA, bool TILED>
+template <int FD, int FA>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int32_t* __restrict__ n_dev, Plane dz, Plane a,
                                                        const float* __restrict__ gmax_dev, float* __restrict__ dW, int ldw,
                                                        int m_valid, int k_valid, const int* __restrict__ col_map,
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
     for (int r = 0; r < 16; r++) { accm[t][r] = 0.f; accc[t][r] = 0.f; }
   float bsum = 0.f;
   const int64_t n_slabs = (n + S - 1) / S;
-  Stager<FD, TILED> sd;
-  Stager<FA, TILED> sa;
+  Stager<FD> sd;
+  Stager<FA> sa;
   if ((int64_t)blockIdx.x < n_slabs) { sd.fetch(dz, (int64_t)blockIdx.x * S, n); sa.fetch(a, (int64_t)blockIdx.x * S, n); }
   __syncthreads();
   for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
@@ -177,19 +177,248 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(int64_t n_max, const int3
   }
 }
 
-template <int FD, int FA, bool TILED>
+template <int FD, int FA>
 int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
            int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
   constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   const size_t lds = (size_t)2 * (MO + NI) * S * 32 * sizeof(_Float16);
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
   if (gfn_first_call_on_device(attr_seen))
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<FD, FA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int64_t blocks = (n_max + S - 1) / S;
   if (blocks > 512) blocks = 512;
-  wgrad_x3_kernel<FD, FA, TILED><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
+  wgrad_x3_kernel<FD, FA><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
+}
+
+
+// ---- tile-major planes: slabs go HBM -> LDS directly (global_load_lds_dwordx4), no register staging -------------------------
+// A read-only stream through VGPRs (the kernel above) tops out near 4 TB/s on this chip (the plain-load return path; the
+// same loop without its MFMAs and atomics is no faster); LDS-DMA reads reach 6.  A slab is 32 samples; the LDS image keeps
+// the [feature tile][sample][32] rows tr_frag reads, so each lane fetches the 16-byte piece (sample s, octet 4t + c) that
+// belongs at its lane-linear LDS position: per wave-instruction 4 runs of 256 contiguous bytes (16 samples of one octet).
+// Two buffers: the loads of slab i + 1 are issued right after the barrier that retires slab i's and land under its MFMAs.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int SG = 32;  // samples per slab of the LDS-DMA kernel
+
+template <int FEAT>
+__device__ __forceinline__ void glds_image(const Plane& p, _Float16* img_hi, _Float16* img_lo, int64_t s0, int64_t n) {
+  constexpr int TILES = (FEAT + 31) / 32, PIECES = TILES * SG * 4;  // 16-byte pieces of one image
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int e0 = 0; e0 < PIECES; e0 += 256) {
+    const int e = e0 + (int)threadIdx.x;
+    if (e - lane < PIECES) {  // wave-uniform
+      const int t = e / (4 * SG), s = (e >> 2) % SG, oct = 4 * t + (e & 3);
+      if (oct < FEAT / 8 && s0 + s < n) {  // the other pieces keep the zeros the kernel starts with (tail slab: zeroed below)
+        const int64_t o = plane_off(s0 + s, p.ld, oct);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.hi + o), (lptr_t)(img_hi + (e - lane) * 8), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.lo + o), (lptr_t)(img_lo + (e - lane) * 8), 16, 0, 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float frag_sum(h8 v, float acc) {  // acc + the fragment's 8 values, in f32
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  acc = __builtin_amdgcn_fdot2(h2{v[0], v[1]}, one, acc, false);
+  acc = __builtin_amdgcn_fdot2(h2{v[2], v[3]}, one, acc, false);
+  acc = __builtin_amdgcn_fdot2(h2{v[4], v[5]}, one, acc, false);
+  return __builtin_amdgcn_fdot2(h2{v[6], v[7]}, one, acc, false);
+}
+
+struct LayerArgs {
+  Plane dz, a;
+  float* dW; int ldw; int m_valid, k_valid;
+  const int* col_map;
+  float* db;
+  int shape;  // index into the supported (FD, FA) pairs, see GFN_WGRAD_SHAPES
+};
+
+// One layer's weight gradient from this workgroup's share of the slabs.  parts == nullptr: added to dW / db with f32 atomics;
+// else this workgroup's partial sums are STORED at parts + (dW - base) (every valid entry, zeros included) for wgrad_reduce_kernel:
+// 512 workgroups x 31 k atomics into the same 124 KB took 85 us of the 0.48 ms the five layers needed.
+template <int FD, int FA>
+__device__ __forceinline__ void wgrad_phase(const LayerArgs& L, int64_t n, const float* __restrict__ gmax_dev, float* parts_w,
+                                            float* parts_b, _Float16* lds) {
+  constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
+  constexpr bool WAVE_IS_NI = (NI == 4);
+  static_assert(WAVE_IS_NI || MO == 4, "one of the tile counts must be 4 (one per wave)");
+  constexpr int PPW = WAVE_IS_NI ? MO : NI;
+  constexpr int IMG_A = MO * SG * 32, IMG_B = NI * SG * 32, BUF = 2 * (IMG_A + IMG_B);  // halfs; lds: [2][Ahi | Alo | Bhi | Blo]
+  __syncthreads();  // (several layers in one kernel) nobody still reads the previous layer's images
+  for (int e = threadIdx.x; e < 2 * BUF / 8; e += blockDim.x) reinterpret_cast<u32x4*>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 accm[PPW], accc[PPW];
+#pragma unroll
+  for (int t = 0; t < PPW; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { accm[t][r] = 0.f; accc[t][r] = 0.f; }
+  float bs_hi = 0.f, bs_lo = 0.f;  // bias gradient = column sums of dz, taken from the A fragments on their way to the matrix pipe:
+                                   // lane (h, r) holds feature r of samples 8h .. 8h+7 of the k-step (column reads from LDS cost more
+                                   // than the whole MFMA phase: 2-byte reads, 4-way bank conflicts)
+  const int64_t n_slabs = (n + SG - 1) / SG;
+  __syncthreads();  // the zeros are in place before the first DMA lands on them
+  if ((int64_t)blockIdx.x < n_slabs) {
+    glds_image<FD>(L.dz, lds, lds + IMG_A, (int64_t)blockIdx.x * SG, n);
+    glds_image<FA>(L.a, lds + 2 * IMG_A, lds + 2 * IMG_A + IMG_B, (int64_t)blockIdx.x * SG, n);
+  }
+  int cur = 0;
+  for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x, cur ^= 1) {
+    _Float16* Ahi = lds + cur * BUF;
+    _Float16* Alo = Ahi + IMG_A;
+    _Float16* Bhi = Alo + IMG_A;
+    _Float16* Blo = Bhi + IMG_B;
+    __syncthreads();  // vmcnt(0) + barrier: this slab has landed, and every wave is done reading the other buffer
+    if ((slab + 1) * SG > n) {  // the last, partial slab: rows beyond n still hold an earlier slab
+      const int first = (int)(n - slab * SG);
+      for (int e = threadIdx.x; e < 2 * (MO + NI) * SG * 4; e += blockDim.x)
+        if (((e >> 2) % SG) >= first) reinterpret_cast<u32x4*>(Ahi)[e] = u32x4{0u, 0u, 0u, 0u};
+      __syncthreads();
+    }
+    const int64_t next = slab + gridDim.x;
+    if (next < n_slabs) {
+      _Float16* N = lds + (cur ^ 1) * BUF;
+      glds_image<FD>(L.dz, N, N + IMG_A, next * SG, n);
+      glds_image<FA>(L.a, N + 2 * IMG_A, N + 2 * IMG_A + IMG_B, next * SG, n);
+    }
+#pragma unroll
+    for (int ks = 0; ks < SG / 16; ks++) {
+      if (WAVE_IS_NI) {
+        const h8 bh = tr_frag(Bhi + wave * SG * 32, ks, lane), bl = tr_frag(Blo + wave * SG * 32, ks, lane);
+#pragma unroll
+        for (int t = 0; t < PPW; t++) {
+          const h8 ah = tr_frag(Ahi + t * SG * 32, ks, lane), al = tr_frag(Alo + t * SG * 32, ks, lane);
+          if (t == wave) { bs_hi = frag_sum(ah, bs_hi); bs_lo = frag_sum(al, bs_lo); }  // MO <= 4: wave t sums out tile t
+          accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[t], 0, 0, 0);
+          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
+          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
+        }
+      } else {
+        const h8 ah = tr_frag(Ahi + wave * SG * 32, ks, lane), al = tr_frag(Alo + wave * SG * 32, ks, lane);
+        bs_hi = frag_sum(ah, bs_hi); bs_lo = frag_sum(al, bs_lo);
+#pragma unroll
+        for (int t = 0; t < PPW; t++) {
+          const h8 bh = tr_frag(Bhi + t * SG * 32, ks, lane), bl = tr_frag(Blo + t * SG * 32, ks, lane);
+          accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[t], 0, 0, 0);
+          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
+          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float inv = gmax_dev ? 1.0f / gfn_grad_scale_of(gmax_dev[0]) : 1.0f;  // the producer's power-of-two gradient scale
+  if (L.db && wave < MO) {
+    const float half_sum = __builtin_fmaf(bs_lo, 0x1p-11f, bs_hi);
+    const float bsum = (half_sum + __shfl_xor(half_sum, 32, 64)) * inv;  // samples 8h .. 8h+7: h = 0 and 1
+    const int m = 32 * wave + (lane & 31);
+    if (lane < 32 && m < L.m_valid) {
+      if (parts_b) parts_b[m] = bsum;
+      else if (bsum != 0.f) atomicAdd(L.db + m, bsum);
+    }
+  }
+  const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int t = 0; t < PPW; t++) {
+    const int mo = WAVE_IS_NI ? t : wave, ni = WAVE_IS_NI ? wave : t;
+    if (mo >= MO || ni >= NI) continue;
+    int k = 32 * ni + j;
+    const bool k_ok = k < L.k_valid;
+    if (L.col_map && k_ok) k = L.col_map[k];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = __builtin_fmaf(accc[t][r], 0x1p-11f, accm[t][r]) * inv;
+      if (m < L.m_valid && k_ok && k >= 0) {
+        if (parts_w) parts_w[(int64_t)m * L.ldw + k] = v;
+        else if (v != 0.f) atomicAdd(L.dW + (int64_t)m * L.ldw + k, v);
+      }
+    }
+  }
+}
+
+#define GFN_WGRAD_SHAPES(X) X(0, 128, 128) X(1, 8, 128) X(2, 128, 64) X(3, 16, 128) X(4, 128, 32)
+
+constexpr int kMaxLayers = 5;
+struct LayersArgs {
+  LayerArgs L[kMaxLayers];
+  int n_layers;
+  float* parts; int64_t part_stride;  // workgroup b's partial gradient vector starts at parts + b * part_stride
+  const float* base;                  // dW / db point into the flat gradient vector starting here
+};
+
+// All layers of the decoder in one launch: five kernels of 60-150 us each paid their ramp-up, first-slab latency and tail five times.
+__global__ __launch_bounds__(256, 2) void wgrad_x3_layers_kernel(int64_t n_max, const int32_t* __restrict__ n_dev,
+                                                                 const float* __restrict__ gmax_dev, LayersArgs A) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  const int64_t n = gfn_live_n(n_max, n_dev);
+  float* mine = A.parts ? A.parts + (int64_t)blockIdx.x * A.part_stride : nullptr;
+  for (int l = 0; l < A.n_layers; l++) {
+    const LayerArgs& L = A.L[l];
+    float* pw = mine ? mine + (L.dW - A.base) : nullptr;
+    float* pb = (mine && L.db) ? mine + (L.db - A.base) : nullptr;
+    switch (L.shape) {
+#define GFN_CASE(ID, D, F) case ID: wgrad_phase<D, F>(L, n, gmax_dev, pw, pb, lds); break;
+      GFN_WGRAD_SHAPES(GFN_CASE)
+#undef GFN_CASE
+    }
+  }
+}
+
+// out[i] += sum over the workgroups' partial vectors (split over blockIdx.y; out zeroed by the caller)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t stride, int64_t n,
+                                                           float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int per = (n_parts + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per < n_parts) ? b0 + per : n_parts;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = b0;
+  for (; b + 4 <= b1; b += 4)
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] += parts[(int64_t)(b + u) * stride + i];
+  for (; b < b1; b++) acc[0] += parts[(int64_t)b * stride + i];
+  const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (v != 0.f) atomicAdd(out + i, v);
+}
+
+constexpr int kWgradBlocks = 512;  // two workgroups per CU; also the number of partial vectors
+
+inline size_t lds_bytes_of(int FD, int FA) { return (size_t)2 * 2 * ((FD + 31) / 32 + (FA + 31) / 32) * SG * 32 * sizeof(_Float16); }
+
+inline int shape_id(int fd, int fa) {
+#define GFN_ID(ID, D, F) if (fd == D && fa == F) return ID;
+  GFN_WGRAD_SHAPES(GFN_ID)
+#undef GFN_ID
+  return -1;
+}
+
+int launch_layers(const LayersArgs& A, int64_t n_max, const int32_t* n_dev, const float* gmax_dev, hipStream_t st) {
+  size_t lds = 0;
+  for (int l = 0; l < A.n_layers; l++) {
+    const size_t b = lds_bytes_of(A.L[l].dz.feat, A.L[l].a.feat);
+    if (b > lds) lds = b;
+  }
+  static unsigned long long attr_seen = 0;
+  if (gfn_first_call_on_device(attr_seen))
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_layers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_bytes_of(128, 128)));
+  int64_t blocks = (n_max + SG - 1) / SG;
+  if (blocks > kWgradBlocks) blocks = kWgradBlocks;
+  wgrad_x3_layers_kernel<<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, gmax_dev, A);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int one_layer(int shape, int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
+              int m_valid, int k_valid, const int* col_map, float* db, hipStream_t st) {
+  LayersArgs A{};
+  A.L[0] = LayerArgs{dz, a, dW, ldw, m_valid, k_valid, col_map, db, shape};
+  A.n_layers = 1;
+  return launch_layers(A, n_max, n_dev, gmax_dev, st);
 }
 
 }  // namespace
@@ -213,8 +442,8 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
   hipStream_t st = gfn_stream(stream);
 #define GFN_WG(D, A)                                                                                                       \
   if (feat_dz == D && feat_a == A)                                                                                         \
-    return tiled ? launch<D, A, true>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)          \
-                 : launch<D, A, false>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
+    return tiled ? one_layer(shape_id(D, A), n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)   \
+                 : launch<D, A>(n_max, n_dev, dz, a, gmax_dev, dW, ldw, m_valid, k_valid, col_map, db, st)
   GFN_WG(128, 128);  // head layer 2
   GFN_WG(8, 128);    // head layer 3 (3 outputs)
   GFN_WG(128, 64);   // head layer 1 (63 inputs)
@@ -223,6 +452,44 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
 #undef GFN_WG
   gfn_set_error("gfn_wgrad_x3: unsupported plane widths %d x %d (supported: 128x128, 8x128, 128x64, 16x128, 128x32)", feat_dz, feat_a);
   return GFN_ERR_ARG;
+}
+
+int gfn_wgrad_x3_parts(void) { return kWgradBlocks; }
+
+int gfn_wgrad_x3_layers(const gfn_wgrad_layer* layers, int n_layers, int64_t n_max, const int32_t* n_dev, const float* gmax_dev,
+                        const float* grad_base, int64_t grad_len, float* parts, int64_t part_stride, void* stream) {
+  if (n_max == 0 || n_layers == 0) return GFN_OK;
+  GFN_CHECK_ARG(layers && n_layers > 0 && n_layers <= kMaxLayers, "gfn_wgrad_x3_layers: 1..%d layers", kMaxLayers);
+  GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31), "gfn_wgrad_x3_layers: n_max=%lld", (long long)n_max);
+  GFN_CHECK_ARG(!parts || (grad_base && grad_len > 0 && part_stride >= grad_len), "gfn_wgrad_x3_layers: partial vectors need the flat gradient's base, length and a stride >= it");
+  LayersArgs A{};
+  A.n_layers = n_layers; A.parts = parts; A.part_stride = part_stride; A.base = grad_base;
+  for (int l = 0; l < n_layers; l++) {
+    const gfn_wgrad_layer& g = layers[l];
+    GFN_CHECK_ARG(g.dz_hi && g.dz_lo && g.a_hi && g.a_lo && g.dW, "gfn_wgrad_x3_layers: null pointer in layer %d", l);
+    GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(g.dz_hi) | reinterpret_cast<uintptr_t>(g.dz_lo) | reinterpret_cast<uintptr_t>(g.a_hi) |
+                    reinterpret_cast<uintptr_t>(g.a_lo)) & 15) == 0, "gfn_wgrad_x3_layers: planes must be 16-byte aligned");
+    const int shape = shape_id(g.feat_dz, g.feat_a);
+    GFN_CHECK_ARG(shape >= 0, "gfn_wgrad_x3_layers: unsupported plane widths %d x %d in layer %d", g.feat_dz, g.feat_a, l);
+    GFN_CHECK_ARG(g.m_valid >= 1 && g.m_valid <= g.feat_dz && g.k_valid >= 1 && g.k_valid <= g.feat_a && g.ldw >= 1, "gfn_wgrad_x3_layers: bad m/k/ldw in layer %d", l);
+    if (parts) {  // the partial vectors mirror the flat gradient: every address the layer writes must lie inside it
+      const int64_t w0 = g.dW - grad_base, w1 = w0 + (int64_t)(g.m_valid - 1) * g.ldw + g.ldw;
+      GFN_CHECK_ARG(w0 >= 0 && w1 <= grad_len, "gfn_wgrad_x3_layers: dW of layer %d lies outside the flat gradient", l);
+      GFN_CHECK_ARG(!g.db || (g.db - grad_base >= 0 && g.db - grad_base + g.m_valid <= grad_len), "gfn_wgrad_x3_layers: db of layer %d lies outside the flat gradient", l);
+    }
+    A.L[l] = LayerArgs{Plane{g.dz_hi, g.dz_lo, g.feat_dz, g.feat_dz}, Plane{g.a_hi, g.a_lo, g.feat_a, g.feat_a}, g.dW, g.ldw, g.m_valid,
+                       g.k_valid, g.col_map, g.db, shape};
+  }
+  return launch_layers(A, n_max, n_dev, gmax_dev, gfn_stream(stream));
+}
+
+int gfn_wgrad_reduce(const float* parts, int n_parts, int64_t part_stride, int64_t n, float* out, void* stream) {
+  if (n <= 0 || n_parts <= 0) return GFN_OK;
+  GFN_CHECK_ARG(parts && out && part_stride >= n, "gfn_wgrad_reduce: bad arguments");
+  const dim3 grid((unsigned)((n + 255) / 256), 4);
+  wgrad_reduce_kernel<<<grid, 256, 0, gfn_stream(stream)>>>(parts, n_parts, part_stride, n, out);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
 }
 
 }  // extern "C"

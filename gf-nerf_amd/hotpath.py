@@ -54,6 +54,9 @@ class HotPathConfig:
                                      # early termination wins (2.40 vs 2.69 ms/step); once nearly every sample is alive (a few dozen
                                      # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
+    table_branch: bool = False       # global stage, one rank: table-gradient accumulation + table Adam on a second stream beside the
+                                     # decoder's weight-gradient kernels.  Measured: no gain (2.10-2.17 vs 2.16 ms/step) -- both sides
+                                     # live on LDS (ds_read_tr staging / ds_add_u64), each takes twice as long beside the other
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
@@ -89,6 +92,8 @@ class HotPath:
         self._sampler_ws = None
         self._records = None
         self._opt_stream, self._opt_pending = None, False
+        self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
+        self._table_branch = False  # backward forked the table-gradient branch onto _opt_stream; optimizer_step continues and joins it
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
@@ -404,6 +409,11 @@ class HotPath:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._opt_pending = False
 
+    def _join_table_branch(self):
+        if self._table_branch:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._table_branch = False
+
     def _grad_live(self):
         """Elements [0, 17T) of the gradient pool: the only ones a backward can write (level-overlap quirk), so the only ones to
         zero, reduce across ranks and hand to Adam."""
@@ -471,8 +481,17 @@ class HotPath:
             if cap:
                 _lib.lib().gfn_set_decoder_cus(prev)
 
-    def backward(self, ctx, g_rgb, g_acc=None):
-        """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R])."""
+    def backward(self, ctx, g_rgb, g_acc=None, keep_branch=False):
+        """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]).
+        keep_branch (train_step only): leave the table-gradient branch (cfg.table_branch) open for optimizer_step to continue;
+        otherwise every gradient is final on the current stream when this returns."""
+        try:
+            self._backward(ctx, g_rgb, g_acc)
+        finally:
+            if not keep_branch:
+                self._join_table_branch()
+
+    def _backward(self, ctx, g_rgb, g_acc):
         c = self.cfg
         self._sync_opt()  # the gradient pool is zeroed behind the asynchronous Adam
         s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
@@ -492,7 +511,16 @@ class HotPath:
                     self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
-                if rec is not None:
+                branch = rec is not None and c.table_branch and self.sync.world == 1
+                if branch:  # the records are complete: accumulate them (and later step the table) beside the weight gradients
+                    if self._opt_stream is None:
+                        self._opt_stream = torch.cuda.Stream(device=self.dev)
+                    self._adam_state("table", self.table)  # created (zero-filled on THIS stream) before the fork, not behind it
+                    self._opt_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._opt_stream):
+                        self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
+                    self._table_branch = True
+                elif rec is not None:
                     self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
                 dfeat = None
                 # data parallel: the table gradient is final here -- its exchange runs beside the weight-gradient kernels below
@@ -507,10 +535,12 @@ class HotPath:
             bv = lambda k: (ops.plane_flat(bp[0], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE)[0],  # noqa: E731
                             *ops.plane_flat(bp[1], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE))
             n_cap = s["ts"].shape[0]
-            for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
-                                          (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None)):
-                self._timed("wgrad", ops.wgrad_x3, bv(dzk), fv(ak), g[li][0], db=g[li][1], n_dev=n_dev,
-                            gmax=self._gmax, m_valid=mv, col_map=cmap, n=n_cap, tiled=True)
+            if self._wgrad_parts is None:
+                self._wgrad_parts = ops.wgrad_parts(self.mlp_grad.numel(), self.dev)
+            layers = [(bv(dzk), fv(ak), g[li][0], g[li][1], mv, cmap)
+                      for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
+                                                    (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None))]
+            self._timed("wgrad", ops.wgrad_x3_layers, layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
             rec = self._record_buffers()
             with self._cu_cap():
@@ -543,7 +573,7 @@ class HotPath:
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
     def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None,
-                         update_oct=False, samples=None, prefetch_out=None):
+                         update_oct=False, samples=None, prefetch_out=None, keep_branch=False):
         """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
         s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent.
         prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage; global
@@ -565,7 +595,7 @@ class HotPath:
                 s3im_index = ops.s3im_index(R, c.s3im_repeat_time, device=self.dev)
             self._timed("loss", ops.s3im, gt_rgb, comp["rgb"], s3im_index, patch_h=c.s3im_patch_height, mult=c.s3im_loss_mult,
                         loss=loss, g_pred=g_rgb)
-        self.backward(ctx, g_rgb)
+        self.backward(ctx, g_rgb, keep_branch=keep_branch)
         return loss, ctx
 
     def adam_groups(self, stage, block=None):
@@ -586,15 +616,21 @@ class HotPath:
         n_live = 17 * (1 << c.log2_T)
         if stage == STAGE_GLOBAL:
             m, v = self._adam_state("table", self.table)
-            self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self._adam_tick("table"), lr=c.lr, eps=c.adam_eps,
-                        shadow_f16=self.table16, n=n_live, hyper=hy("table"))
+            step_table = lambda: self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self._adam_tick("table"), lr=c.lr,  # noqa: E731
+                                             eps=c.adam_eps, shadow_f16=self.table16, n=n_live, hyper=hy("table"))
+            if self._table_branch:
+                with torch.cuda.stream(self._opt_stream):
+                    step_table()
+            else:
+                step_table()
             self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
             self._x3_stale = True
             for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
-                m, v = self._adam_state(name, p)
-                self._timed("adam", ops.adam_step, p, gr, m, v, self._adam_tick(name), lr=c.lr, eps=c.adam_eps, hyper=hy(name))
+                mm, vv = self._adam_state(name, p)
+                self._timed("adam", ops.adam_step, p, gr, mm, vv, self._adam_tick(name), lr=c.lr, eps=c.adam_eps, hyper=hy(name))
+            self._join_table_branch()  # the next forward reads the stepped table
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
@@ -615,6 +651,7 @@ class HotPath:
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
         self._sync_opt()
+        self._join_table_branch()
         # only elements [0, 17T) of a table can receive a gradient (level-overlap quirk): reduce 71 MB, not 134 MB
         live = self._grad_live()
         if stage == STAGE_GLOBAL:
@@ -643,7 +680,7 @@ class HotPath:
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path.  samples / prefetch_out / hyper: see
         gfnerf_amd.stepgraph (the step captured in a hipGraph)."""
         loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch,
-                                          update_oct=update_oct, samples=samples, prefetch_out=prefetch_out)
+                                          update_oct=update_oct, samples=samples, prefetch_out=prefetch_out, keep_branch=True)
         self.sync_grads(stage, aux)
         self.optimizer_step(stage, block, hyper=hyper)
         return loss, aux

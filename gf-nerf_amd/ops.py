@@ -753,6 +753,46 @@ def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=No
     return dW
 
 
+def wgrad_parts(grad_len, device):
+    """Zeroed workspace for wgrad_x3_layers: one partial copy of the flat gradient vector per workgroup."""
+    stride = (int(grad_len) + 63) // 64 * 64
+    return torch.zeros((_lib.lib().gfn_wgrad_x3_parts(), stride), dtype=torch.float32, device=device)
+
+
+def wgrad_x3_layers(layers, grad, n, n_dev=None, gmax=None, parts=None):
+    """Weight (and bias) gradients of several decoder layers from tile-major split-f16 planes in ONE launch, added to `grad`.
+    layers: [(dz, a, dW, db, m_valid, col_map)] with dz / a = (hi_flat, lo_flat, width) (plane_flat) and dW / db views INTO the
+    flat f32 vector grad.  parts (wgrad_parts): the workgroups store partial sums there and a second small kernel adds them up
+    (no atomics on the 31 k weights from 512 workgroups); None: f32 atomics straight into grad."""
+    _chk(grad, torch.float32, "grad"); _chk(gmax, torch.float32, "gmax"); _chk(parts, torch.float32, "parts")
+    arr = (_lib.WgradLayer * len(layers))()
+    base, glen = grad.data_ptr(), grad.numel()
+    for i, (dz, a, dW, db, m_valid, col_map) in enumerate(layers):
+        for pl in (dz, a):
+            _chk(pl[0], torch.float16, "plane"); _chk(pl[1], torch.float16, "plane")
+            if pl[0].numel() != pl[1].numel() or pl[0].numel() % (32 * pl[2]) or pl[0].numel() // pl[2] < n:
+                raise _lib.GfnError("wgrad_x3_layers: plane halves differ, are not whole 32-sample tiles, or hold fewer than n samples")
+        _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db"); _chk(col_map, torch.int32, "col_map")
+        for t in (dW, db):
+            if t is not None and not (base <= t.data_ptr() and t.data_ptr() + t.numel() * 4 <= base + glen * 4):
+                raise _lib.GfnError("wgrad_x3_layers: dW / db must be views into grad")
+        k_valid = a[2]
+        if col_map is not None:
+            k_valid = min(k_valid, col_map.numel())
+        if dW.shape[0] < m_valid or (col_map is None and dW.shape[1] < k_valid):
+            raise _lib.GfnError("wgrad_x3_layers: dW too small for the requested rows and columns")
+        arr[i] = _lib.WgradLayer(dz[0].data_ptr(), dz[1].data_ptr(), a[0].data_ptr(), a[1].data_ptr(), dz[2], a[2], int(m_valid), int(k_valid),
+                                 _ptr(col_map), dW.data_ptr(), dW.stride(0), _ptr(db))
+    if parts is not None and (parts.shape[0] != _lib.lib().gfn_wgrad_x3_parts() or parts.shape[1] < glen):
+        raise _lib.GfnError("wgrad_x3_layers: parts must come from wgrad_parts(grad.numel(), ...)")
+    stride = parts.shape[1] if parts is not None else 0
+    rc = _lib.lib().gfn_wgrad_x3_layers(arr, len(layers), int(n), _ptr(n_dev), _ptr(gmax), base, glen, _ptr(parts), stride, _stream())
+    _lib.check(rc, "gfn_wgrad_x3_layers")
+    if parts is not None:
+        n_parts = min((int(n) + 31) // 32, parts.shape[0])  # the launch's grid: workgroups beyond it wrote nothing this time
+        _lib.check(_lib.lib().gfn_wgrad_reduce(_ptr(parts), n_parts, stride, glen, base, _stream()), "gfn_wgrad_reduce")
+
+
 def grad_scale(gmax: float) -> float:
     """The power-of-two scale the global-stage decoder backward derives from the largest incoming gradient."""
     return float(_lib.lib().gfn_grad_scale_host(float(gmax)))

@@ -353,6 +353,26 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
                  const float* gmax_dev, int m_valid, int k_valid, const int32_t* col_map, float* dW, int ldw,
                  float* db, int tiled, void* stream);
 
+/* All layers of the decoder in ONE launch over tile-major planes (the global-stage step: five layers), and without the
+ * final atomics: with parts != NULL workgroup b STORES its partial sums of every valid dW / db entry at
+ * parts + b * part_stride + (dW - grad_base) -- the partial vectors mirror the flat gradient vector
+ * [grad_base, grad_base + grad_len) that all dW / db point into; parts holds gfn_wgrad_x3_parts() such vectors and must
+ * have been zeroed ONCE (entries no layer writes stay zero) -- and gfn_wgrad_reduce adds their sum to the gradient
+ * (out += sum_b parts[b * part_stride + i], i < n).  parts == NULL: f32 atomics into dW / db like gfn_wgrad_x3. */
+typedef struct {
+  const uint16_t *dz_hi, *dz_lo, *a_hi, *a_lo; /* whole tile-major planes [n/32][feat/8][32][8] */
+  int32_t feat_dz, feat_a;                      /* plane widths: 128x128, 8x128, 128x64, 16x128 or 128x32 */
+  int32_t m_valid, k_valid;
+  const int32_t* col_map;                       /* plane column -> dW column (< 0: skipped), or NULL */
+  float* dW; int32_t ldw;
+  float* db;                                    /* or NULL */
+} gfn_wgrad_layer;
+int gfn_wgrad_x3_parts(void);
+int gfn_wgrad_x3_layers(const gfn_wgrad_layer* layers, int n_layers, int64_t n_max, const int32_t* n_dev,
+                        const float* gmax_dev, const float* grad_base, int64_t grad_len, float* parts,
+                        int64_t part_stride, void* stream);
+int gfn_wgrad_reduce(const float* parts, int n_parts, int64_t part_stride, int64_t n, float* out, void* stream);
+
 /* Everything after the sampler in ONE persistent kernel (csrc/fused_fwd.hip): f16-shadow hash lookup
  * (+ residual table2 with its own primes, or NULL; or pair_table != 0: table_f16 is the interleaved
  * gfn_table_pair_f16 image of both tables) -> x3 decoder -> front-to-back compositing with early

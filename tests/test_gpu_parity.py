@@ -601,6 +601,55 @@ def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid, tiled)
     np.testing.assert_allclose(db.cpu().numpy(), dz[:n, :m_valid].astype(np.float64).sum(0), rtol=1e-4, atol=2e-6 * np.abs(dz[:n]).sum(0).max())
 
 
+@pytest.mark.parametrize("with_parts", [True, False])
+def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts):
+    """gfn_wgrad_x3_layers: the five decoder layers in one launch (slabs by LDS-DMA, bias sums from the MFMA fragments), partial
+    vectors + gfn_wgrad_reduce or atomics, against float64 dz^T a; ragged n, device count, scale, col_map, gaps in the flat vector."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    n_cap, n = 6048, 5555
+    scale = 64.0
+    t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+    tile = lambda x: x.view(n_cap // 32, 32, x.shape[1] // 8, 8).permute(0, 2, 1, 3).contiguous().view(-1)  # noqa: E731
+    shapes = [(8, 128, 3, 128), (128, 128, 128, 128), (128, 64, 128, 63), (16, 128, 16, 128), (128, 32, 128, 32)]
+    sizes = [mv * (63 if kv == 63 else kv) + mv for _, _, mv, kv in shapes]
+    grad = torch.zeros(sum(sizes) + 40, dtype=torch.float32, device=dev)  # 40 elements no layer owns
+    grad[-40:] = 7.0
+    layers, wants, off = [], [], 0
+    for (m_feat, k_feat, m_valid, k_valid) in shapes:
+        dz = (rng.standard_normal((n_cap, m_feat)) * np.exp(rng.uniform(-6, 0, (n_cap, 1)))).astype(np.float32)
+        a = np.maximum(rng.standard_normal((n_cap, k_feat)), 0).astype(np.float32) * 3.0
+        dz[:, m_valid:] = 0
+        dzp, ap = ops.split_f16(t(dz * scale)), ops.split_f16(t(a))
+        ldw = k_valid
+        col_map = None
+        want = dz[:n, :m_valid].astype(np.float64).T @ a[:n, :k_valid].astype(np.float64)
+        if k_valid == 63:
+            perm = rng.permutation(63).astype(np.int32)
+            perm[7] = -1
+            col_map = t(np.concatenate([perm, [-1]]).astype(np.int32))
+            w2 = np.zeros((m_valid, ldw))
+            for k in range(k_valid):
+                if perm[k] >= 0:
+                    w2[:, perm[k]] = want[:, k]
+            want = w2
+        dW = grad[off:off + m_valid * ldw].view(m_valid, ldw); off += m_valid * ldw
+        db = grad[off:off + m_valid]; off += m_valid
+        layers.append(((tile(dzp[0]), tile(dzp[1]), m_feat), (tile(ap[0]), tile(ap[1]), k_feat), dW, db, m_valid, col_map))
+        mag = (np.abs(dz[:n, :m_valid]).astype(np.float64).T @ np.abs(a[:n, :k_valid]).astype(np.float64)).max()
+        wants.append((want, dz[:n, :m_valid].astype(np.float64).sum(0), mag, np.abs(dz[:n]).sum(0).max()))
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    parts = ops.wgrad_parts(grad.numel(), dev) if with_parts else None
+    for rep in range(2):  # the partial vectors are reused from step to step without being cleared
+        grad[:-40] = 0
+        ops.wgrad_x3_layers(layers, grad, n_cap, n_dev=n_dev, gmax=torch.tensor([0.2], device=dev), parts=parts)
+        for (dz_, a_, dW, db, m_valid, _), (want, wb, mag, bmag) in zip(layers, wants):
+            assert np.abs(dW.cpu().numpy() - want).max() < 2e-6 * mag
+            np.testing.assert_allclose(db.cpu().numpy(), wb, rtol=1e-4, atol=2e-6 * bmag)
+        assert float(grad[-40:].min()) == 7.0 and float(grad[-40:].max()) == 7.0
+
+
 def test_generate_rays_matches_golden_and_oracle(oracle, ops, dev, golden):
     """gfn_generate_rays against the vectors captured from the reference's Cameras.generate_rays, explicit and raster mode."""
     import torch

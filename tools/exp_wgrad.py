@@ -28,3 +28,23 @@ for name, dzk, ak, mv, shape in (("hW2", "dz3", "c2", 3, (3, 128)), ("hW1", "dz2
     t = float(np.median(ts)); tot += t
     print(f"{name}: {t:.3f} ms  {gb:.2f} GB -> {gb / t * 1e3:.0f} GB/s")
 print("total", tot)
+
+# all five layers in one launch (what the global-stage step runs), with partial vectors + reduce, and with atomics
+grad = torch.zeros(40000, device=dev)
+off = 0
+layers = []
+for name, dzk, ak, mv, shape in (("hW2", "dz3", "c2", 3, (3, 128)), ("hW1", "dz2", "c1", 128, (128, 128)), ("hW0", "dz1", "xp", 128, (128, 64)),
+                                 ("bW1", "dh", "a1", 16, (16, 128)), ("bW0", "dza1", "feat", 128, (128, 32))):
+    dW = grad[off:off + shape[0] * shape[1]].view(shape); off += shape[0] * shape[1]
+    db = grad[off:off + shape[0]]; off += shape[0]
+    layers.append((bv(dzk), fv(ak), dW, db, mv, None))
+parts = ops.wgrad_parts(grad.numel(), dev)
+for label, p in (("layers + partial vectors + reduce", parts), ("layers + atomics", None)):
+    fn = lambda: ops.wgrad_x3_layers(layers, grad, n, gmax=gmax, parts=p)
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    t = float(np.median(ts))
+    print(f"{label}: {t:.3f} ms  {n * 888 * 4 / 1e9 / t * 1e3:.0f} GB/s")
