@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
     ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
+    ap.add_argument("--draws-first", action="store_true",
+                    help="graph launch: start the next step's random draws at the top of the step (beside the lookups) instead of behind them")
     ap.add_argument("--table-branch", action="store_true",
                     help="global stage: table-gradient accumulation + table Adam on a second stream beside the weight-gradient kernels (no gain measured)")
     ap.add_argument("--async-adam", action="store_true",
@@ -513,7 +515,8 @@ class StageRun:
         try:
             hp._drop_stale_samples()  # the last eager step prefetched a sample nobody will collect
             blocks = list(range(self.n_blocks)) if self.stage == "focal" else None
-            sg = stepgraph.StepGraph(hp, self.stage, N_RAYS, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update)
+            sg = stepgraph.StepGraph(hp, self.stage, N_RAYS, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update,
+                                     draws_after_lookup=not args.draws_first)
             o, d, _, _ = self.batches[self.i % 4]
             sg.prime(o, d)
             sg.p = self.i % sg.cycle  # the block rotation goes on where the eager steps stopped

@@ -259,10 +259,11 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
   }
 }
 
-// PLANES + SCATTER together need more than 256 registers: that form runs 256-thread workgroups (one wave per SIMD with the
-// 512-entry file) -- no build of these kernels may spill (tests/test_abi_and_host.py)
+// Every form runs 512-thread workgroups = two waves per SIMD, so that one wave's hashing / record stores run beside the other's
+// MFMAs (the PLANES + SCATTER form used to run 256: 0.68 ms where the MFMA and the store phases add up; it fits 255 registers
+// when asked to) -- no build of these kernels may spill (tests/test_abi_and_host.py)
 template <bool PLANES, int SCATTER>
-constexpr int bwd_threads() { return (PLANES && SCATTER) ? 256 : 512; }
+constexpr int bwd_threads() { return 512; }
 
 template <bool PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records */>
 __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx_x3_kernel(

@@ -92,6 +92,8 @@ class HotPath:
         self._sampler_ws = None
         self._records = None
         self._opt_stream, self._opt_pending = None, False
+        self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
+                                    # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
         self._table_branch = False  # backward forked the table-gradient branch onto _opt_stream; optimizer_step continues and joins it
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
@@ -311,6 +313,8 @@ class HotPath:
             if block is not None:
                 self._timed("hash_fwd_block", ops.hash_fwd, self.blocks[block], self.block_prims[block], self.bias_arg,
                             s["warped_pts"], s["anchors"], V, T, n_dev=n_dev, out=feat, accumulate=True)
+        if self.after_lookup is not None:
+            self.after_lookup()
         emb = self.emb if self.cfg.use_appearance_embedding else None
         if fused:
             sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
@@ -338,6 +342,8 @@ class HotPath:
         self._sync_opt()
         if block is not None and self._pairs_stale:
             self.refresh_shadows()
+        if self.after_lookup is not None:
+            self.after_lookup()
         sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
         emb = self.emb if self.cfg.use_appearance_embedding else None
         pair = block is not None and self.cfg.share_block_primes  # blocks16[block] is then the interleaved {global, block} image

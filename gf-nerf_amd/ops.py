@@ -1012,10 +1012,17 @@ def s3im_index(n_rays, repeat_time=10, generator=None, device=None, out=None):
     return out.view(-1)
 
 
-def sampler_noise(n_rays, fineness, train=True, generator=None, device=None):
+def sampler_noise(n_rays, fineness, train=True, generator=None, device=None, out=None):
     """rays_noise of GetSamples (PersSampler_cuda.cu:380-389): (U[0,1) + 0.5) * fineness in training, fineness in eval mode,
     1024 + R + 10 values (the march reads a sliding window of it, :204,270)."""
     n = 1024 + n_rays + 10
+    if out is not None:
+        _chk(out, torch.float32, "out")
+        if out.numel() != n:
+            raise _lib.GfnError(f"sampler_noise: out must hold {n} values")
+        if not train:
+            return out.fill_(float(fineness))
+        return torch.rand(n, dtype=torch.float32, device=out.device, generator=generator, out=out).add_(0.5).mul_(float(fineness))
     if not train:
         return torch.full((n,), float(fineness), dtype=torch.float32, device=device)
     return torch.rand(n, dtype=torch.float32, device=device, generator=generator).add_(0.5).mul_(float(fineness))

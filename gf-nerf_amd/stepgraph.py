@@ -27,7 +27,7 @@ from . import _lib, hotpath as hp_mod, ops
 
 
 class StepGraph:
-    def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None):
+    def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None, draws_after_lookup=True):
         """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant)."""
         if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL:
             raise _lib.GfnError("StepGraph: the data-parallel global stage exchanges gradients with eager collectives; not captured")
@@ -36,6 +36,7 @@ class StepGraph:
         self.cycle = len(self.blocks) if len(self.blocks) % 2 == 0 else 2 * len(self.blocks)  # lcm(2, number of blocks)
         self.fineness, self.train_noise, self.update_oct = float(fineness), train_noise, update_oct and stage == hp_mod.STAGE_GLOBAL
         self.lr_schedule = lr_schedule
+        self.draws_after_lookup = draws_after_lookup
         dev = hp.dev
         f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)  # noqa: E731
         self.cam = torch.zeros(self.R, dtype=torch.int32, device=dev)
@@ -48,6 +49,7 @@ class StepGraph:
         self.hyper_dev = f(len(self.groups), 2)
         self.hyper_host = torch.zeros((len(self.groups), 2), dtype=torch.float32).pin_memory()
         self.hyper = {name: self.hyper_dev[i] for i, (name, _) in enumerate(self.groups)}
+        self.noise = torch.zeros(1024 + self.R + 10, dtype=torch.float32, device=dev)  # the NEXT batch's march noise
         self.S = [None, None]
         self.s3 = [None, None]  # S3IM permutations of the step that reads S[p], drawn one step ahead like the samples
         self.G = [None] * self.cycle
@@ -58,8 +60,8 @@ class StepGraph:
         self._tree = None
 
     # ------------------------------------------------------------------ set-up
-    def _noise(self):
-        return ops.sampler_noise(self.R, self.fineness, train=self.train_noise, device=self.hp.dev)
+    def _noise(self, out=None):
+        return ops.sampler_noise(self.R, self.fineness, train=self.train_noise, device=self.hp.dev, out=out)
 
     def prime(self, rays_o, rays_d):
         """Sample the FIRST batch's rays (eagerly) into S[0]; from then on every replay samples the next batch itself."""
@@ -80,14 +82,24 @@ class StepGraph:
         if hp._side is None:
             hp._side = torch.cuda.Stream(device=hp.dev)
         side = hp._side
-        side.wait_stream(main)
-        with torch.cuda.stream(side):  # the NEXT step's random draws, on the device, beside this step's forward
-            if hp.cfg.s3im_loss_mult > 0:
-                ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[1 - p])
-            noise = self._noise()
-        loss, aux = hp.train_step(None, None, self.cam, self.gt, None, stage=self.stage, block=block, s3im_index=self.s3[p],
-                                  prefetch=(self.nxt_o, self.nxt_d, noise), update_oct=self.update_oct, samples=self.S[p],
-                                  prefetch_out=self.S[1 - p], hyper=self.hyper)
+
+        def draws():  # the NEXT step's random draws, on the device: started behind this step's lookups (a sort beside them
+            side.wait_stream(main)  # costs the gathers 10 %), beside the decoder, ahead of the next batch's sampler
+            with torch.cuda.stream(side):
+                if hp.cfg.s3im_loss_mult > 0:
+                    ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[1 - p])
+                self._noise(out=self.noise)
+
+        if self.draws_after_lookup:
+            hp.after_lookup = draws
+        else:
+            draws()
+        try:
+            loss, aux = hp.train_step(None, None, self.cam, self.gt, None, stage=self.stage, block=block, s3im_index=self.s3[p],
+                                      prefetch=(self.nxt_o, self.nxt_d, self.noise), update_oct=self.update_oct, samples=self.S[p],
+                                      prefetch_out=self.S[1 - p], hyper=self.hyper)
+        finally:
+            hp.after_lookup = None
         assert hp._pre is not None and hp._pre[4]["pts_offsets"] is self.S[1 - p]["pts_offsets"], "the prefetch must fill the other sample buffer"
         self.S[1 - p] = hp._pre[4]
         hp._pre = None  # collected: the next replay reads it as its `samples`
