@@ -594,7 +594,8 @@ class StageRun:
         kern = {name: float(sum(a.elapsed_time(b) for a, b in ev)) / steps for name, ev in hp.timings.items()}
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
         kern_ms, alg_bytes = kern[dom], alg[dom]
-        kernel_name, launches = dom + "_kernel", 1
+        kernel_name, launches = {"bwd_scatter": "field_bwd_dx_x3_kernel<planes, records>", "hash_fwd": "hash_fwd_kernel",
+                                 "hash_bwd": "hash_bwd_kernel"}.get(dom, dom + "_kernel"), 1
         lm = getattr(hp, "last_forward", "") == "lm" and dom == "hash_fwd"
         if lm:  # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region
             kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
@@ -608,11 +609,16 @@ class StageRun:
             default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
             traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
             n_req = pmc.get(f"{dom}:{self.stage}:fetch_requests") if default_cfg else None
-            if lm:  # the level-major kernel is bound by how fast a CU's address unit walks 64 divergent lanes, not by the fabric
+            if lm:  # the level-major kernel is bound by the L2 -> L1 line fills of its gathers (86 % of them hit the L2), not by the fabric
                 n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch)
                 req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
                            frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
                            nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
+                           l2_to_l1=(dict(line_fills_per_launch=pmc["lm_lookup:focal:l1_miss_requests"], bytes_per_fill=128,
+                                          achieved_TBps=pmc["lm_lookup:focal:l1_miss_requests"] * 128 / (kern_ms * 1e-3) / 1e12, peak_TBps=34.5,
+                                          l2_hit_rate=pmc["lm_lookup:focal:l2_hit_rate"],
+                                          source="TCP_TCC_READ_REQ_sum, TCC_HIT / TCC_MISS (profiles/r02_pmc_focal_per_kernel.csv); peak: MI355X guide, L2")
+                                     if default_cfg and self.stage == "focal" else None),
                            source="gathers the kernel issues per launch (16 levels x 8 corners per sample, minus the corners that runs of samples in one "
                                   "cell share below level lm_halves_from: counted from this batch) over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
             elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
