@@ -753,8 +753,13 @@ def run_rank(args):
                     path.append(int(cb[(37 * (f + 1)) % cb.size]))
             owners = gdist.frame_owner(labels[np.asarray(path)], world)
             rblock = 0 if (headline_stage == "focal" and hp.blocks) else None
-        with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
-            r = render_bench(hp, sc, args, run.fineness, torch, path, rblock, world, rank, owners, dist)
+        try:
+            with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
+                r = render_bench(hp, sc, args, run.fineness, torch, path, rblock, world, rank, owners, dist)
+        except Exception as e:  # noqa: BLE001 -- the headline stands on its own
+            if world == 1:
+                raise
+            r = dict(error=f"{type(e).__name__}: {e}")
         if out is not None:
             out["render"] = r
     if world == 1 and args.render_frames > 0:
