@@ -88,11 +88,13 @@ def parse():
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
     ap.add_argument("--prefetch-cus", type=int, default=192, help="CUs left to the fused backward while the prefetched sampler runs beside it")
-    ap.add_argument("--render-pipeline", type=int, default=8,
+    ap.add_argument("--render-pipeline", type=int, default=0,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
     ap.add_argument("--render-decoder-cus", type=int, default=252, help="CUs the fused forward may occupy while a sampler runs beside it")
-    ap.add_argument("--render-tile-rays", type=int, default=8192, help="rays per render tile")
-    ap.add_argument("--render-tile-width", type=int, default=128, help="render tiles are blocks of this width (0 = raster runs of 4096 pixels)")
+    ap.add_argument("--render-patch-width", type=int, default=8,
+                    help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
+    ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~128 Ki rays that divides the frame)")
+    ap.add_argument("--render-tile-width", type=int, default=128, help="with --render-tile-rays: render tiles are blocks of this width (0 = raster runs)")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     ap.add_argument("--share-block-primes", action="store_true",
@@ -319,6 +321,13 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
     hp.cfg.level_major_render = bool(args.render_lm)
+    hp.cfg.render_patch_width = int(args.render_patch_width)
+    if args.render_tile_rays <= 0:  # a block that divides the frame; tiles per graph replay = the largest divisor of their count <= 5
+        tw, th = rmod.choose_tile(H, W)
+        args.render_tile_rays, args.render_tile_width = tw * th, tw
+    n_tiles = -(-H // (args.render_tile_rays // max(args.render_tile_width, 1))) * -(-W // max(args.render_tile_width, 1)) if args.render_tile_width else -(-H * W // args.render_tile_rays)
+    if args.render_pipeline <= 0:
+        args.render_pipeline = max(p for p in range(1, 6) if n_tiles % p == 0)
     tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
                            pipeline=args.render_pipeline, decoder_cus=args.render_decoder_cus)
     mine = [f for f in range(len(cams)) if owners is None or owners[f] == rank]
@@ -345,6 +354,8 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}",
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=args.render_tile_rays, hipgraph=True,
                 tiles_per_replay=args.render_pipeline,
+                kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep" % (args.render_patch_width, 32 // args.render_patch_width)
+                        if args.render_patch_width > 0 and not args.render_lm else "fused_fwd_kernel: a wave per ray" if not args.render_lm else "level-major kernels"),
                 tile=(f"{args.render_tile_width}x{args.render_tile_rays // args.render_tile_width} pixel blocks" if args.render_tile_width else "raster runs"),
                 table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
                 routing=("single GPU" if world == 1 else f"{n_frames} frames routed to the rank owning each frame's block "

@@ -55,10 +55,47 @@ __device__ __forceinline__ float nan_to_num_f(float x) {  // torch.nan_to_num de
 }
 
 constexpr int FUSED_LDS_BYTES = GFN_FIELD_X3_FWD_BYTES + 64;
-constexpr int FUSED_THREADS = 256;  // one wave per SIMD: the 512-entry register file holds a tile without spilling
+constexpr int FUSED_THREADS = 256;  // SAVE forms: one wave per SIMD, the 512-entry register file holds a tile without spilling
+constexpr int FUSED_THREADS_LEAN = 512;  // forms that keep nothing for a backward: 32-bit table / prime offsets fit them into 256 registers
+template <bool SAVE>
+constexpr int fused_threads() { return SAVE ? FUSED_THREADS : FUSED_THREADS_LEAN; }
 
-template <bool DUAL, bool SAVE, bool PLANES>
-__global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
+// gather_level<true> with the level's base as a 32-bit pair index (same gathers, same left-to-right blend, same bits)
+__device__ __forceinline__ float2 gather_pairs_u32(const half2_t* __restrict__ table, uint32_t slot0, const Corners& c) {
+  half2_t v[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) v[d] = table[slot0 + c.pos[d]];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];
+    a0 = (d == 0) ? t0 : a0 + t0;
+    a1 = (d == 0) ? t1 : a1 + t1;
+  }
+  return make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
+}
+
+// gather_level_pair likewise (interleaved {global, block} image: one 8-byte gather per corner)
+__device__ __forceinline__ float2 gather_quads_u32(const half4_t* __restrict__ table, uint32_t slot0, const Corners& c) {
+  half4_t v[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) v[d] = table[slot0 + c.pos[d]];
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];
+    const float u0 = c.w[d] * (float)v[d][2], u1 = c.w[d] * (float)v[d][3];
+    a0 = (d == 0) ? t0 : a0 + t0; a1 = (d == 0) ? t1 : a1 + t1;
+    b0 = (d == 0) ? u0 : b0 + u0; b1 = (d == 0) ? u1 : b1 + u1;
+  }
+  return make_float2(gfn_round_f16(a0) + gfn_round_f16(b0), gfn_round_f16(a1) + gfn_round_f16(b1));
+}
+
+// TAB: 0 one table, 1 two tables with their own primes (DUAL), 2 one interleaved {global, block} image (shared primes).
+// A compile-time choice on purpose: with `if (A.pair)` inside the unrolled level loop the 512-thread build returned wrong
+// values for whole 16-lane groups of the upper half-wave now and then (hipcc 7.2; the same source is fine at 256 threads).
+template <int TAB, bool SAVE, bool PLANES>
+__global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_FWD_BYTES / 16);
@@ -79,7 +116,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
   const int seg_len = (A.n_rays + 7) / 8;
   int seg_k = 0, fetches = 0;
   // t range over every ray of this wave, kept in LDS (the register file is full): ONE pair of same-address atomics at the end
-  __shared__ float s_tmin[FUSED_THREADS / 64], s_tmax[FUSED_THREADS / 64];
+  __shared__ float s_tmin[fused_threads<SAVE>() / 64], s_tmax[fused_threads<SAVE>() / 64];
   const int wave_id = threadIdx.x >> 6;
   if (lane == 0) { s_tmin[wave_id] = INFINITY; s_tmax[wave_id] = 0.f; }
   for (;;) {
@@ -104,7 +141,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
       const int64_t q = valid ? i : e - 1;  // lanes past the ray's end redo its last sample and store nothing
       // ---- lookup: this lane's 8 levels of sample q
       const float px = A.pts[3 * q], py = A.pts[3 * q + 1], pz = A.pts[3 * q + 2];
-      const int64_t vol = (int64_t)A.anchors[3 * q];
+      const int vol = A.anchors[3 * q];
       u32x4 xh[2], xl[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
@@ -112,16 +149,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           const int level = 8 * u + 4 * h + m;
-          const int64_t tr = (int64_t)level * A.n_volumes + vol;
+          const int tr3 = 3 * (level * (int)A.n_volumes + vol);
+          const uint32_t slot0 = (uint32_t)level << (A.log2_T - 1);
           Corners c;
           uint32_t cell[3];
-          hash_corners(px, py, pz, s_scale[level], A.prim_a + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+          hash_corners(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
           float2 r;
-          if (!DUAL && A.pair) r = gather_level_pair(A.table_a, (int64_t)level * T, c);  // one 8-byte gather per corner for both tables
-          else r = gather_level<true>(A.table_a, (int64_t)level * T, c);
-          if (DUAL) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
-            if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + 3 * tr, A.bias_pool ? A.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
-            const float2 r2 = gather_level<true>(A.table_b, (int64_t)level * T, c);
+          if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);  // one 8-byte gather per corner for both tables
+          else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
+          if (TAB == 1) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
+            if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+            const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
             r.x = r.x + r2.x; r.y = r.y + r2.y;
           }
           x[2 * m] = r.x; x[2 * m + 1] = r.y;
@@ -197,6 +235,140 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_fwd_kernel(FusedArgs A, L
   }
 }
 
+// ---- inference: the same tile of work, dealt the other way round ---------------------------------------------------------------
+// fused_fwd_kernel gives a wave 32 consecutive samples of ONE ray: from level 9 on each of them sits in a cell of its own, 32
+// distinct cells per gather instruction.  A render tile is a block of neighbouring pixels, and the k-th samples of an 8 x 4 patch
+// of neighbouring pixels' rays sit in 1.1 (level 0) ... 10 (level 15) distinct cells -- 0.09 distinct cells per sample and level
+// against 0.73 (tools/exp_patch_sharing.py) -- and lanes of one gather instruction that want the same address cost what ONE
+// lane costs (tools/gather_share.hip: the rate counts distinct addresses).  So here lane (h, j) owns RAY j of the wave's patch
+// for the whole kernel and the wave walks the 32 rays in lockstep, sample index by sample index: lookup (8 of the 16 levels
+// per lane, as above) -> decoder_tile on the 32 rays' k-th samples -> every ray composites its own sample front to back in
+// its lane (no scan) and drops out once its transmittance is below early_T.  Per-sample outputs are not written (inference).
+// tile_w > 0: the rays are a tile_w-wide block of pixels, row major, and a patch is patch_w x (32 / patch_w) pixels;
+// tile_w == 0: a patch is 32 consecutive rays.
+constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / prime offsets the kernel needs 254 registers, no spills
+
+template <int TAB>
+__global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 L[];
+  for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
+  float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_FWD_BYTES / 16);
+  if (threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = sc.s[threadIdx.x];
+  __syncthreads();
+  const u32x4* Ihi = L;
+  const u32x4* Ilo = L + FWD_CHUNKS * 64;
+  const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
+  const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const uint32_t T = 1u << A.log2_T;
+  const float early_T = A.early_T;
+  const int n_vol = (int)A.n_volumes;    // 16 * n_volumes * 3 < 2^31 (checked by the host)
+  const int n_patches = A.n_rays / 32;  // the host guarantees whole patches
+  const int patches_per_row = tile_w > 0 ? tile_w / patch_w : 1, patch_h = tile_w > 0 ? 32 / patch_w : 1;
+  // patches are handed out like fused_fwd_kernel's rays: 8 counters, a workgroup starts on the eighth of its XCD group
+  const int seg_len = (n_patches + 7) / 8;
+  int seg_k = 0, fetches = 0;
+  __shared__ float s_tmin[RENDER_THREADS / 64], s_tmax[RENDER_THREADS / 64];
+  const int wave_id = threadIdx.x >> 6;
+  if (lane == 0) { s_tmin[wave_id] = INFINITY; s_tmax[wave_id] = 0.f; }
+  for (;;) {
+    if (seg_k >= 8 || fetches > n_patches + 8) break;
+    const int seg = ((int)(blockIdx.x & 7) + seg_k) & 7;
+    const int seg_lo = seg * seg_len;
+    const int seg_n = min(seg_len, n_patches - seg_lo);
+    int idx = 0;
+    if (lane == 0) idx = seg_n > 0 ? atomicAdd(A.counter + seg, 1) : 0;
+    idx = __shfl(idx, 0, 64);
+    fetches++;
+    if (seg_n <= 0 || idx >= seg_n) { seg_k++; continue; }  // wave-uniform
+    const int patch = seg_lo + idx;
+    const int ray = tile_w > 0 ? ((patch / patches_per_row) * patch_h + j / patch_w) * tile_w + (patch % patches_per_row) * patch_w + j % patch_w
+                               : patch * 32 + j;
+    const int s = A.pts_offsets[ray], cnt = A.pts_offsets[ray + 1] - s;
+    int kmax = cnt;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    const float* sh_row = A.sh + (int64_t)ray * 16;
+    const float* emb_row = A.emb ? A.emb + (int64_t)A.cam_idx[ray] * 32 : nullptr;
+    float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
+    bool done = false;
+    for (int k = 0; k < kmax; k++) {
+      const bool act = k < cnt && !done;
+      if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
+      const int64_t q = (int64_t)s + k;
+      // ---- lookup: this lane's 8 levels of its ray's k-th sample (rays that have left gather nothing)
+      u32x4 xh[2], xl[2];
+      float x[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int m = 0; m < 8; m++) x[u][m] = 0.f;
+      if (act) {
+        const float px = A.pts[3 * q], py = A.pts[3 * q + 1], pz = A.pts[3 * q + 2];
+        const int vol = A.anchors[3 * q];
+        // 32-bit offsets throughout: the lane's 8 levels are per-lane values, and 64-bit per-level bases (table base, prime row)
+        // hoisted out of the loops cost 2 x 8 x 4 registers -- the difference between one and two waves per SIMD
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int level = 8 * u + 4 * h + m;
+            const int tr3 = 3 * (level * n_vol + vol);
+            const uint32_t slot0 = (uint32_t)level << (A.log2_T - 1);  // level * T halfs = level * T / 2 pairs
+            Corners c;
+            uint32_t cell[3];
+            hash_corners(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+            float2 r;
+            if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);
+            else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
+            if (TAB == 1) {
+              if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+              const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
+              r.x = r.x + r2.x; r.y = r.y + r2.y;
+            }
+            x[u][2 * m] = r.x; x[u][2 * m + 1] = r.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
+      // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
+      const DecoderOut o = decoder_tile<false>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q);
+      // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
+      if (act && h == 0) {
+        const float ti = A.ts[q];
+        const float ds = A.dt[q] * o.sigma;
+        const float Tr = expf(-carry);
+        const float alpha = 1.f - expf(-ds);
+        float w = nan_to_num_f(alpha * Tr);
+        if (early_T > 0.f && Tr < early_T) w = 0.f;
+        cr += w * o.r; cg += w * o.g; cb += w * o.b; ca += w; cd += w * ti;
+        carry += ds;
+        if (early_T > 0.f && expf(-carry) < early_T) done = true;  // the ray is opaque: it gathers nothing from here on
+      }
+      done = __shfl((int)done, j, 64) != 0;  // the upper half (the ray's other 8 levels) follows its ray
+    }
+    if (h == 0) {
+      A.out_rgb[3 * ray] = cr; A.out_rgb[3 * ray + 1] = cg; A.out_rgb[3 * ray + 2] = cb;
+      if (A.out_acc) A.out_acc[ray] = ca;
+      if (A.out_depth) A.out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
+    }
+    if (A.t_minmax) {  // t grows along a ray: its range is its first and its last sample, terminated or not
+      float tmin = cnt > 0 ? A.ts[s] : INFINITY, tmax = cnt > 0 ? A.ts[s + cnt - 1] : 0.f;
+      if (cnt < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+      }
+      if (lane == 0) { s_tmin[wave_id] = fminf(s_tmin[wave_id], tmin); s_tmax[wave_id] = fmaxf(s_tmax[wave_id], tmax); }
+    }
+  }
+  if (A.t_minmax && lane == 0 && s_tmin[wave_id] <= s_tmax[wave_id]) {
+    atomicMin(reinterpret_cast<unsigned*>(A.t_minmax), __float_as_uint(s_tmin[wave_id]));
+    atomicMax(reinterpret_cast<unsigned*>(A.t_minmax + 1), __float_as_uint(s_tmax[wave_id]));
+  }
+}
+
 __global__ void fused_init_kernel(int* counter, float* t_minmax) {
   for (int i = 0; i < 8; i++) counter[i] = 0;
   if (t_minmax) { t_minmax[0] = INFINITY; t_minmax[1] = 0.f; }
@@ -238,7 +410,8 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_FUSED_ALL(X) X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
+#define GFN_FUSED_ALL(X) X(0, false, false) X(0, true, false) X(0, true, true) X(1, false, false) X(1, true, false) X(1, true, true) \
+                         X(2, false, false) X(2, true, false) X(2, true, true)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(D, S, P) \
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<D, S, P>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
@@ -248,15 +421,62 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t waves = n_rays;  // one ray at a time per wave
-  int64_t blocks = (waves + FUSED_THREADS / 64 - 1) / (FUSED_THREADS / 64);
+  const int tab = table2_f16 ? 1 : (pair_table ? 2 : 0);
+  const bool save = masks != nullptr, planes = planes_hi != nullptr;
+  const int threads = save ? FUSED_THREADS : FUSED_THREADS_LEAN;
+  int64_t blocks = (waves + threads / 64 - 1) / (threads / 64);
   const int cu_cap = gfn_decoder_cu_cap();  // gfn_set_decoder_cus: leave CUs to kernels of another stream
   if (blocks > cu_cap) blocks = cu_cap;
-  const bool dual = table2_f16 != nullptr, save = masks != nullptr, planes = planes_hi != nullptr;
 #define GFN_LAUNCH(D, S, P) \
-  if (dual == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, FUSED_THREADS, FUSED_LDS_BYTES, st>>>(A, sc);
+  if (tab == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, fused_threads<S>(), FUSED_LDS_BYTES, st>>>(A, sc);
   GFN_FUSED_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_FUSED_ALL
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
+                     const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                     const int32_t* prim_pool2, int pair_table, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                     const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
+                     float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts && table_f16 && prim_pool && fwd_image && sh && out_rgb && work_counter,
+                "gfn_fused_render: null pointer");
+  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30) && n_rays % 32 == 0, "gfn_fused_render: n_rays=%lld must be a positive multiple of 32", (long long)n_rays);
+  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_render: n_volumes / log2_T out of range");
+  GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_render: emb given without cam_idx");
+  GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_render: an interleaved pair image already holds the second table");
+  GFN_CHECK_ARG(tile_width == 0 || (tile_width > 0 && patch_width > 0 && 32 % patch_width == 0 && tile_width % patch_width == 0 &&
+                                    n_rays % tile_width == 0 && (n_rays / tile_width) % (32 / patch_width) == 0),
+                "gfn_fused_render: a %d-wide tile of %lld rays does not divide into %d x %d patches", tile_width, (long long)n_rays, patch_width,
+                patch_width > 0 ? 32 / patch_width : 0);
+  GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(emb)) & 15) == 0,
+                "gfn_fused_render: image, sh and emb must be 16-byte aligned");
+  FusedArgs A{};
+  A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
+  A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
+  A.n_volumes = n_volumes; A.log2_T = log2_T; A.pair = pair_table;
+  A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
+  A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
+  LevelScales sc;
+  gfn_hash_level_scales_host(sc.s);
+  hipStream_t st = gfn_stream(stream);
+  static unsigned long long attr_seen = 0;
+  if (gfn_first_call_on_device(attr_seen)) {
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+  }
+  fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
+  GFN_CHECK_LAUNCH();
+  int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave
+  const int cu_cap = gfn_decoder_cu_cap();
+  if (blocks > cu_cap) blocks = cu_cap;
+  if (table2_f16) fused_render_patch_kernel<1><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  else if (pair_table) fused_render_patch_kernel<2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  else fused_render_patch_kernel<0><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

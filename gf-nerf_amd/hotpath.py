@@ -54,6 +54,8 @@ class HotPathConfig:
                                      # early termination wins (2.40 vs 2.69 ms/step); once nearly every sample is alive (a few dozen
                                      # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
     lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
+    render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
+                                     # (gfn_fused_render); 0 = a wave per ray like the training forward
     table_branch: bool = False       # global stage, one rank: table-gradient accumulation + table Adam on a second stream beside the
                                      # decoder's weight-gradient kernels.  Measured: no gain (2.10-2.17 vs 2.16 ms/step) -- both sides
                                      # live on LDS (ds_read_tr staging / ds_add_u64), each takes twice as long beside the other
@@ -358,12 +360,32 @@ class HotPath:
                     t_minmax=out["t_minmax"])
         return f, comp
 
-    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None):
+    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None):
         """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566).
-        samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles)."""
+        samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles).
+        tile_width (not None): the rays are neighbours -- a block of pixels this wide, row major, or (0) a run of a row -- and only
+        the four images are wanted: the lookup + decoder + compositing go through gfn_fused_render, which walks patches of 32
+        neighbouring rays in lockstep (field / weights are then not returned)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
+        R = s["pts_offsets"].numel() - 1
+        pw = c.render_patch_width
+        if (tile_width is not None and pw > 0 and self._fused_ok(block) and not c.level_major_render and R % 32 == 0 and
+                (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0))):
+            if block is not None and self._pairs_stale:
+                self.refresh_shadows()
+            sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
+            pair = block is not None and c.share_block_primes
+            comp = self._timed("fused_render", ops.fused_render, s, self.blocks16[block] if pair else self.table16, self.prim, self.n_volumes, c.log2_T,
+                               self._x3()[0], sh, self.emb if c.use_appearance_embedding else None, cam_idx,
+                               table2_f16=self.blocks16[block] if (block is not None and not pair) else None,
+                               prim_pool2=self.block_prims[block] if (block is not None and not pair) else None, bias_pool=self.bias_arg,
+                               early_T=early, pair_table=pair, tile_width=tile_width, patch_width=pw)
+            depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
+            rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)
+            return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
+                        oct_depth=s["first_oct_dis"][:, None] / c.scale_factor, samples=s, field=None, weights=None)
         if c.level_major_render and block is not None and self._fused_ok(block) and not c.share_block_primes:
             f = self._field_forward(s, cam_idx, block, fused=True, lm=True)
             comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)

@@ -863,6 +863,39 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
     return out
 
 
+def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
+                 early_T=0.0, pair_table=False, tile_width=0, patch_width=8):
+    """gfn_fused_render: inference through patches of 32 neighbouring rays walked in lockstep (no per-sample outputs).
+    -> dict(rgb [R,3], acc [R], depth_raw [R], t_minmax [2]).  R must be a multiple of 32; tile_width: the rays are a block of
+    pixels this wide, row major (0: a run of rays)."""
+    po = s["pts_offsets"]
+    R = po.numel() - 1
+    dev = po.device
+    for nm, t, dt_, last in (("pts_offsets", po, torch.int32, None), ("warped_pts", s["warped_pts"], torch.float32, 3),
+                             ("anchors", s["anchors"], torch.int32, 3), ("dists", s["dists"], torch.float32, None), ("ts", s["ts"], torch.float32, None),
+                             ("table", table_f16, torch.float16, None), ("table2", table2_f16, torch.float16, None),
+                             ("prim_pool", prim_pool, torch.int32, None), ("prim_pool2", prim_pool2, torch.int32, None),
+                             ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
+                             ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
+        _chk(t, dt_, nm, last)
+    for t, mult in ((table_f16, 2 if pair_table else 1), (table2_f16, 1)):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2 * mult:
+            raise _lib.GfnError("f16 table has the wrong size")
+    if prim_pool.numel() != 16 * n_volumes * 3 or (prim_pool2 is not None and prim_pool2.numel() != prim_pool.numel()):
+        raise _lib.GfnError("prim_pool does not match n_volumes")
+    if image.numel() != FIELD_X3_FWD_BYTES or sh.shape[0] != R or (cam_idx is not None and cam_idx.numel() != R):
+        raise _lib.GfnError("weight image / sh / cam_idx do not match the batch")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
+    counter = torch.empty(8, dtype=torch.int32, device=dev)
+    rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
+                                     _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), int(bool(pair_table)), _ptr(bias_pool), n_volumes, log2_T,
+                                     _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
+                                     _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
+    _lib.check(rc, "gfn_fused_render")
+    return out
+
+
 def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, prim_pool, bias_pool, n_volumes, log2_T, grad_pool,
                          gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None):
     """Decoder backward + hash scatter in one kernel: accumulates into grad_pool (f16 x128-scaled or f32, like hash_bwd); with

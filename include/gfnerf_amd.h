@@ -393,6 +393,20 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
                       int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax,
                       int32_t* work_counter, void* stream);
 
+/* Inference form of gfn_fused_forward (csrc/fused_fwd.hip, fused_render_patch_kernel): the same lookup + decoder +
+ * compositing with early termination, but a wave owns a PATCH of 32 neighbouring rays (tile_width > 0: the rays are a
+ * tile_width-wide block of pixels, row major, and a patch is patch_width x 32/patch_width pixels; tile_width == 0: 32
+ * consecutive rays) and walks them in lockstep, sample index by sample index -- neighbouring pixels' rays cross the same
+ * table cells, and lanes of one gather that want the same address cost what one lane costs.  Only the per-ray outputs
+ * are written (out_acc / out_depth / t_minmax may be NULL).  n_rays must be a multiple of 32 (and of whole patch rows).
+ * Replaces GFNeRFModel.get_outputs under get_outputs_for_camera_ray_bundle (nerfacto.py:531-566, base_model.py:163-186). */
+int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
+                     const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
+                     const int32_t* prim_pool, const int32_t* prim_pool2, int pair_table, const float* bias_pool,
+                     int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
+                     const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
+                     float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
+
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
  * default output.  dirs f32 [R,3] -> out f32 [R,16]. */

@@ -739,6 +739,58 @@ def test_async_adam_is_the_same_training_run(setup):
     assert float(g1.abs().max()) == 0.0  # the pool was zeroed behind the last asynchronous Adam
 
 
+@pytest.mark.parametrize("block", [None, 0])
+def test_fused_forward_features_repeatably_bit_exact(setup, block):
+    """The inference forms of the fused forward run two waves per SIMD.  A build that chose the table mode with a run-time branch
+    inside the unrolled level loop returned wrong values for whole 16-lane groups of the upper half-wave in ~0.3 % of the rows,
+    differently on every launch (the table mode is a template parameter since): the kept features must equal the stand-alone
+    lookup bit for bit, five launches in a row."""
+    from gfnerf_amd import ops
+
+    S = setup
+    hp, t = S["hp"], S["t"]
+    o, d, cam, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["noise"])
+    for rep in range(5):
+        out = hp.render(o, d, cam, noise, block=block)
+        s = out["samples"]
+        N = int(s["pts_offsets"][-1])
+        ref = ops.hash_fwd_f16(hp.table16, hp.prim, hp.bias_arg, s["warped_pts"], s["anchors"], hp.n_volumes, S["cfg"].log2_T,
+                               table2_f16=hp.blocks16[0] if block is not None else None,
+                               prim_pool2=hp.block_prims[0] if block is not None else None, n_dev=s["n_dev"])[:N]
+        bad = out["field"]["feat"][:N] != ref
+        assert int(bad.sum()) == 0, (rep, int(bad.sum()), bad.sum(0).tolist())
+
+
+@pytest.mark.parametrize("block,early_T,tile_width", [(0, 0.0, 32), (0, 1e-4, 32), (None, 1e-4, 0), (0, 1e-4, 96)])
+def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_width):
+    """gfn_fused_render (a wave walks a patch of 32 neighbouring rays in lockstep, each ray compositing in its own lane) against the
+    wave-per-ray fused forward on the same samples: same lookups, same decoder, the compositing sums in a different order
+    (sequential per ray instead of a 64-lane scan) -> rgb / accumulation / depth to f32 rounding.  Rays of very different
+    lengths share patches (the batch's rays are random, not neighbours): every drop-out path is taken."""
+    import torch
+
+    from gfnerf_amd import hotpath
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=S["cfg"], seed=1, n_blocks=1)
+    hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3); hp.refresh_shadows()
+    R = (S["o"].shape[0] // 64) * 64
+    o, d, cam = t(S["o"][:R]), t(S["d"][:R]), t(S["cam"][:R])
+    noise = t(S["noise"])
+    ref = hp.render(o, d, cam, noise, block=block, early_T=early_T)
+    got = hp.render(o, d, cam, noise, block=block, early_T=early_T, samples=ref["samples"], tile_width=tile_width)
+    assert got["field"] is None and hp.timings is not None
+    for k, tol in (("rgb", 2e-5), ("accumulation", 2e-5), ("depth", 2e-4)):
+        a, b = got[k].cpu().numpy(), ref[k].cpu().numpy()
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol, err_msg=k)
+    assert float(ref["accumulation"].max()) > 0.5  # the comparison is not between empty images
+    # a ray count that does not divide into patches falls back to the wave-per-ray kernel
+    odd = hp.render(o[:40], d[:40], cam[:40], noise, block=block, early_T=early_T, tile_width=0)
+    assert odd["field"] is not None
+
+
 @pytest.mark.parametrize("stage", ["focal", "global"])
 def test_step_graph_is_the_same_training_run(setup, stage):
     """gfnerf_amd.stepgraph.StepGraph: K training steps as hipGraph replays (sampler of the next batch on a captured side branch,
