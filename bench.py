@@ -322,14 +322,9 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
                             .astype(np.float32)).cuda()
     hp.cfg.level_major_render = bool(args.render_lm)
     hp.cfg.render_patch_width = int(args.render_patch_width)
-    if args.render_tile_rays <= 0:  # a block that divides the frame; tiles per graph replay = the largest divisor of their count <= 5
-        tw, th = rmod.choose_tile(H, W)
-        args.render_tile_rays, args.render_tile_width = tw * th, tw
-    n_tiles = -(-H // (args.render_tile_rays // max(args.render_tile_width, 1))) * -(-W // max(args.render_tile_width, 1)) if args.render_tile_width else -(-H * W // args.render_tile_rays)
-    if args.render_pipeline <= 0:
-        args.render_pipeline = max(p for p in range(1, 6) if n_tiles % p == 0)
-    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays, block=block, fineness=fineness, use_graph=True, tile_width=args.render_tile_width,
-                           pipeline=args.render_pipeline, decoder_cus=args.render_decoder_cus)
+    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=True,
+                           tile_width=args.render_tile_width if args.render_tile_rays else None, pipeline=args.render_pipeline or None,
+                           decoder_cus=args.render_decoder_cus)
     mine = [f for f in range(len(cams)) if owners is None or owners[f] == rank]
     tr.render_camera(int(cams[mine[0]]) if mine else 0, H, W)  # capture + warm-up
     torch.cuda.synchronize()
@@ -352,11 +347,11 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     mpix = n_frames * H * W / 1e6
     acc = float(local[mine[-1]]["accumulation"].mean().item()) if mine else None
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}",
-                ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=args.render_tile_rays, hipgraph=True,
-                tiles_per_replay=args.render_pipeline,
+                ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=True,
+                tiles_per_replay=tr.P,
                 kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep" % (args.render_patch_width, 32 // args.render_patch_width)
-                        if args.render_patch_width > 0 and not args.render_lm else "fused_fwd_kernel: a wave per ray" if not args.render_lm else "level-major kernels"),
-                tile=(f"{args.render_tile_width}x{args.render_tile_rays // args.render_tile_width} pixel blocks" if args.render_tile_width else "raster runs"),
+                        if args.render_patch_width > 0 and not args.render_lm and tr.patch_tw is not None else "fused_fwd_kernel: a wave per ray" if not args.render_lm else "level-major kernels"),
+                tile=(f"{tr.tw}x{tr.T // tr.tw} pixel blocks" if tr.tw else "raster runs"),
                 table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
                 routing=("single GPU" if world == 1 else f"{n_frames} frames routed to the rank owning each frame's block "
                          f"({len(mine)} on rank 0), images gathered on rank 0 inside the timed region"))

@@ -88,7 +88,8 @@ class GFNeRFModelConfig(ModelConfig):
     early_T: float = 1e-4               # early-termination transmittance of the compositing (0 = the reference: none)
     keep_blocks_resident: bool = True   # inactive block tables stay in HBM instead of being swapped through disk
     engine_seed: int = 0                # parameter initialisation of the engine (every rank uses the same)
-    render_tile_rays: int = 8192        # rays per hipGraph-captured inference tile (get_outputs_for_camera_ray_bundle)
+    render_tile_rays: int = 0           # rays per hipGraph-captured inference tile (get_outputs_for_camera_ray_bundle); 0 = a block of
+                                        # ~128 Ki rays that divides the image (gfnerf_amd.render.choose_tile)
 
 
 class _RenderFn(torch.autograd.Function):
@@ -417,8 +418,9 @@ class GFNeRFModel(Model):
         self._sync_after_external_update()
         key = (blk, float(self.persampler.sampler.ray_march_fineness_), id(self.hot.nodes_compact))
         if self._tile_renderer is None or self._tile_renderer[0] != key:
-            tr = rmod.TileRenderer(self.hot, None, None, tile_rays=self.config.render_tile_rays, block=blk,
-                                   fineness=float(self.persampler.sampler.ray_march_fineness_), use_graph=True, pipeline=1)
+            tr = rmod.TileRenderer(self.hot, None, None, tile_rays=self.config.render_tile_rays or None, block=blk,
+                                   fineness=float(self.persampler.sampler.ray_march_fineness_), use_graph=True,
+                                   pipeline=1 if self.config.render_tile_rays else None)
             self._tile_renderer = (key, tr)
         out = self._tile_renderer[1].render_rays(o, d, embed_idx, H, W)
         return {k: v.view(H, W, -1) for k, v in out.items()}

@@ -43,34 +43,65 @@ def frame_shard(n_frames, world_size, rank):
 
 
 class TileRenderer:
-    def __init__(self, hp, c2w, intr, tile_rays=8192, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=128,
-                 pipeline=1, decoder_cus=252):
+    PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
+
+    def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
+                 pipeline=None, decoder_cus=252):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
-        validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388)."""
+        validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
+        tile_rays / tile_width: a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (tile_width 0: a raster run);
+        None = chosen per image size by choose_tile (~128 Ki rays, dividing the frame).  pipeline: tiles per graph replay
+        (their samplers run on a second graph branch); None = the largest divisor of the tile count <= 5."""
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
-        self.T, self.block, self.early_T = int(tile_rays), block, early_T
-        # a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (0 = a raster run): neighbouring rays cross the
-        # same table cells, and the fused forward keeps each eighth of the tile (a strip of rows) on one XCD's L2
-        self.tw = int(tile_width) if tile_width and tile_rays % tile_width == 0 else 0
-        dev = hp.dev
-        self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + self.T + 10,), float(fineness), dtype=torch.float32, device=dev)
-        self.P = max(int(pipeline), 1) if use_graph else 1
+        self.block, self.early_T, self.fineness = block, early_T, float(fineness)
+        self._want = (tile_rays, tile_width, pipeline)
         self.decoder_cus = int(decoder_cus)
-        self.o = torch.zeros((self.P, self.T, 3), dtype=torch.float32, device=dev)
-        self.d = torch.zeros((self.P, self.T, 3), dtype=torch.float32, device=dev)
-        self.d[..., 2] = -1.0
-        self.cam = torch.zeros(self.T, dtype=torch.int32, device=dev)
-        self.graph, self.out = None, None
         self.use_graph = use_graph
+        self.T = None  # buffers are made for the first image (_setup)
+        self.graph, self.out = None, None
+        if tile_rays is not None:
+            self._setup(None, None)
+
+    def _setup(self, height, width):
+        """Tile shape, tiles per replay and the static input buffers for images of this size."""
+        tile_rays, tile_width, pipeline = self._want
+        if tile_rays is None:
+            tw, th = choose_tile(height, width)
+            T = tw * th
+        else:
+            T = int(tile_rays)
+            tw = 128 if tile_width is None else int(tile_width)
+            tw = tw if tw and T % tw == 0 else 0
+        if pipeline is None:
+            if height is None:
+                P = 1
+            else:
+                n_tiles = (-(-height // (T // tw)) * -(-width // tw)) if tw else -(-height * width // T)
+                P = max(p for p in range(1, 6) if n_tiles % p == 0)
+        else:
+            P = max(int(pipeline), 1)
+        dev = self.hp.dev
+        self.T, self.tw = T, tw
+        # neighbouring rays cross the same table cells: gfn_fused_render walks patches of them in lockstep (tile_width passed
+        # on); the wave-per-ray fused forward keeps each eighth of a small tile (a strip of rows) on one XCD's L2
+        self.patch_tw = tw if T >= self.PATCH_MIN_RAYS else None
+        self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + T + 10,), self.fineness, dtype=torch.float32, device=dev)
+        self.P = P if self.use_graph else 1
+        self.o = torch.zeros((self.P, T, 3), dtype=torch.float32, device=dev)
+        self.d = torch.zeros((self.P, T, 3), dtype=torch.float32, device=dev)
+        self.d[..., 2] = -1.0
+        self.cam = torch.zeros(T, dtype=torch.int32, device=dev)
+        self.graph, self.out = None, None
         self._side = torch.cuda.Stream(device=dev) if self.P > 1 else None
+        self._size = (height, width)
 
     def _tile(self):
         """-> [(rgb, accumulation, depth)] of the P tiles in the input buffers."""
         hp = self.hp
         if self.P == 1:
-            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, tile_width=self.tw)
+            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, tile_width=self.patch_tw)
             return [(out["rgb"], out["accumulation"], out["depth"], out["oct_depth"])]
         from . import _lib
 
@@ -88,7 +119,7 @@ class TileRenderer:
             outs = []
             for i in range(self.P):  # consumer branch: the fused forward of tile i beside the samplers of the tiles after it
                 main.wait_event(done[i])
-                out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.tw)
+                out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw)
                 outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
             main.wait_stream(side)
             self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
@@ -121,6 +152,8 @@ class TileRenderer:
     def render_rays(self, O, D, embed_idx, height, width):
         """The rays of one image, row major: O, D f32 [H*W,3] on the device; embed_idx: the appearance-embedding row of the
         whole image -> dict(rgb [H,W,3], accumulation / depth / oct_depth [H,W,1])."""
+        if self.T is None or (self._want[0] is None and self._size != (height, width)):
+            self._setup(height, width)
         hp, T = self.hp, self.T
         n = height * width
         O, D = O.reshape(n, 3), D.reshape(n, 3)
