@@ -54,3 +54,17 @@ for cam, (ty, tx) in ((37, (4, 7)), (74, (8, 3)), (111, (12, 11))):
             row.append(f"{name}: {distinct / n:5.3f} cells/sample ({distinct / groups:5.1f} per group of {n / groups:4.1f})")
         print("  ".join(row))
     print("  all levels, distinct cells per sample:", {k_: round(v / n / 16, 3) for k_, v in tot.items()})
+
+# lockstep cost of the patch kernel: a wave runs until the LAST of its 32 rays has ended or become opaque
+hp.table.mul_(100.0); hp.blocks[0].normal_(0, 0.01); hp.refresh_shadows()
+cam_t = torch.full((R,), 37, dtype=torch.int32, device="cuda")
+out = hp.render(O, D, cam_t, noise, block=0, early_T=1e-4)
+w = out["weights"][:n]
+alive = torch.zeros(R, device="cuda").index_add_(0, ray_id, (w > 0).float())
+for name, pid in (("8x4", patch), ("32x1", py * 4 + px // 32), ("4x8", (py // 8) * 32 + px // 4)):
+    npatch = int(pid.max().item()) + 1
+    # per-patch max over its rays (scatter-reduce through sorting: ray -> patch is constant per ray)
+    ray_patch = torch.zeros(R, dtype=torch.long, device="cuda").index_copy_(0, ray_id, pid)
+    mx = torch.zeros(npatch, device="cuda").scatter_reduce_(0, ray_patch, alive, reduce="amax")
+    print(f"patch {name}: mean alive samples per ray {alive.mean().item():.1f} of {n / R:.1f}; mean over patches of the longest ray {mx.mean().item():.1f} "
+          f"-> lockstep efficiency {alive.mean().item() / mx.mean().item():.2f}")
