@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_global_graph -- py
 echo "kt global graph done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_global_eager -- python3 $B --steps 60 --warmup 60 $COMMON --stage global --launch eager > $O/global_eager_under_rocprof.json 2>$O/kt_global_eager.err
 echo "kt global eager done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
+echo "kt render done"
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B" "TCC_HIT TCC_MISS" "TCP_TCC_READ_REQ_sum"; do
   T=$(echo $C | tr ' ' '_')
   rocprofv3 --pmc $C --output-format csv -d $O/pmc_focal_$T -- python3 $B --steps 3 --warmup 2 $COMMON --global-steps 0 --launch eager > $O/pmc_focal_$T.json 2>$O/pmc_focal_$T.err || echo "pmc $T failed"
