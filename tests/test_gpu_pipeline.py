@@ -369,6 +369,13 @@ def test_fused_paths_edge_cases(setup):
     ref = S["opipe"].render(S["P"], o, d, cam, noise.cpu().numpy(), S["cfg"].log2_T, block=0, early_T=0.0, scale_factor=S["cfg"].scale_factor)
     assert np.array_equal(po.astype(np.int64), ref["samples"]["pts_offsets"])
     np.testing.assert_allclose(rgb, ref["rgb"], atol=1e-3)
+    # the same rays through the patch kernel (gfn_fused_render): patches mix rays without samples, short rays and rays at the cap
+    for tw in (0, 24):  # 96 rays: three runs of 32, or a 24-wide block of 4 rows = three 8 x 4 patches
+        pr = hp.render(t(o), t(d), t(cam), noise, block=0, early_T=0.0, samples=out["samples"], tile_width=tw)
+        assert pr["field"] is None
+        np.testing.assert_allclose(pr["rgb"].cpu().numpy(), rgb, atol=2e-6)
+        np.testing.assert_allclose(pr["accumulation"].cpu().numpy(), out["accumulation"].cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(pr["depth"].cpu().numpy(), out["depth"].cpu().numpy(), rtol=1e-5, atol=1e-6)
     # training step on the same batch (fused backward): finite loss and gradients
     gt = t(S["gt"][:R])
     loss, aux = hp.forward_backward(t(o), t(d), t(cam), gt, noise, stage="focal", block=0)
@@ -377,6 +384,9 @@ def test_fused_paths_edge_cases(setup):
     o2 = np.tile(np.array([[0.0, 0.0, 4000.0]], np.float32), (R, 1)); d2 = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (R, 1))
     out2 = hp.render(t(o2), t(d2), t(cam), noise, block=None)
     assert int(out2["samples"]["pts_offsets"][-1].item()) == 0 and float(out2["rgb"].abs().max()) == 0.0
+    out2p = hp.render(t(o2), t(d2), t(cam), noise, block=None, samples=out2["samples"], tile_width=0)
+    assert out2p["field"] is None and float(out2p["rgb"].abs().max()) == 0.0 and float(out2p["accumulation"].abs().max()) == 0.0
+    assert torch.equal(out2p["depth"], out2["depth"])
     loss2, _ = hp.forward_backward(t(o2), t(d2), t(cam), gt, noise, stage="global")
     assert np.isfinite(loss2.item()) and float(hp.table_grad.float().abs().max()) == 0.0
     # empty batch
