@@ -158,7 +158,7 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
           if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);  // one 8-byte gather per corner for both tables
           else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
           if (TAB == 1) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
-            if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+            if (A.prim_b) rehash_corners(cell, A.prim_b + tr3, T - 1u, c);  // same cell, same weights: only the slots change
             const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
             r.x = r.x + r2.x; r.y = r.y + r2.y;
           }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
             if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);
             else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
             if (TAB == 1) {
-              if (A.prim_b) hash_corners(px, py, pz, s_scale[level], A.prim_b + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+              if (A.prim_b) rehash_corners(cell, A.prim_b + tr3, T - 1u, c);  // same cell, same weights: only the slots change
               const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
               r.x = r.x + r2.x; r.y = r.y + r2.y;
             }

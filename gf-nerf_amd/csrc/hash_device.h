@@ -55,6 +55,23 @@ __device__ __forceinline__ void hash_corners(float px, float py, float pz, float
   c.w[7] = (a * b) * cc;
 }
 
+// The same cell through another table's primes (the focal stage's residual table, nerfacto_field.py:485-486): only the 8 slots
+// change -- cell and trilinear weights depend on the point alone (bias pools are shared by the tables here).
+__device__ __forceinline__ void rehash_corners(const uint32_t cell[3], const int* __restrict__ prim, uint32_t mask, Corners& c) {
+  const uint32_t pa = (uint32_t)prim[0], pb = (uint32_t)prim[1], pc = (uint32_t)prim[2];
+  const uint32_t x0 = cell[0] * pa, x1 = (cell[0] + 1u) * pa;
+  const uint32_t y0 = cell[1] * pb, y1 = (cell[1] + 1u) * pb;
+  const uint32_t z0 = cell[2] * pc, z1 = (cell[2] + 1u) * pc;
+  c.pos[0] = (x0 ^ y0 ^ z0) & mask;
+  c.pos[1] = (x0 ^ y0 ^ z1) & mask;
+  c.pos[2] = (x0 ^ y1 ^ z0) & mask;
+  c.pos[3] = (x0 ^ y1 ^ z1) & mask;
+  c.pos[4] = (x1 ^ y0 ^ z0) & mask;
+  c.pos[5] = (x1 ^ y0 ^ z1) & mask;
+  c.pos[6] = (x1 ^ y1 ^ z0) & mask;
+  c.pos[7] = (x1 ^ y1 ^ z1) & mask;
+}
+
 // one level of one table: 8 gathers, trilinear blend in f32, result rounded to f16 (:71-78,:195)
 template <bool F16>
 __device__ __forceinline__ float2 gather_level(const void* __restrict__ table, int64_t level_base, const Corners& c) {
