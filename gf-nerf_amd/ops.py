@@ -1109,6 +1109,19 @@ def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15
                                            int(bool(shadow_pair)), _ptr(hyper), _stream()), "gfn_adam_step_ex")
 
 
+def copy_list(pairs):
+    """[(dst, src)]: up to 8 small same-dtype, same-size contiguous device tensors copied in ONE launch (gfn_copy_list)."""
+    import ctypes as C
+
+    n = len(pairs)
+    src = (C.c_void_p * n)(); dst = (C.c_void_p * n)(); nb = (C.c_int64 * n)()
+    for i, (d, s) in enumerate(pairs):
+        if d.dtype != s.dtype or d.numel() != s.numel() or not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous()):
+            raise _lib.GfnError("copy_list: pairs of contiguous device tensors of one dtype and size")
+        src[i], dst[i], nb[i] = s.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
+    _lib.check(_lib.lib().gfn_copy_list(src, dst, nb, n, _stream()), "gfn_copy_list")
+
+
 def fill_zero(t):
     _lib.check(_lib.lib().gfn_fill_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "gfn_fill_zero")
 

@@ -161,8 +161,8 @@ class StepGraph:
         hp = self.hp
         if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
             self.capture()
-        self.cam.copy_(cam_idx); self.gt.copy_(gt_rgb)
-        self.nxt_o.copy_(next_rays_o); self.nxt_d.copy_(next_rays_d)
+        ops.copy_list([(self.cam, cam_idx.contiguous()), (self.gt, gt_rgb.contiguous()), (self.nxt_o, next_rays_o.contiguous()),
+                       (self.nxt_d, next_rays_d.contiguous())])  # one launch, not four memcpy nodes in front of every replay
         self._refresh_hyper(advance=True)
         j = self.p
         self.G[j].replay()

@@ -530,6 +530,9 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
                      int shadow_pair, const float* hyper_dev, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
+/* n <= 8 small device-to-device copies (src[i] -> dst[i], bytes[i] a multiple of 4, 4-byte aligned) in ONE launch: the batch
+ * hand-over in front of a captured training step (gfnerf_amd.stepgraph).  src / dst / bytes are HOST arrays. */
+int gfn_copy_list(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
 
 /* Local step of the direct (all-to-all + all-gather) gradient all-reduce of the ray-data-parallel global stage
  * (replaces DDP's bucketed all-reduce, gf_pipeline.py:136-138, which never sees the hash table): recv holds
