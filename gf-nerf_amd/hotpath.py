@@ -373,6 +373,7 @@ class HotPath:
         pw = c.render_patch_width
         if (tile_width is not None and pw > 0 and self._fused_ok(block) and not c.level_major_render and R % 32 == 0 and
                 (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0))):
+            self._sync_opt()
             if block is not None and self._pairs_stale:
                 self.refresh_shadows()
             sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
