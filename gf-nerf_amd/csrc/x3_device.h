@@ -90,15 +90,19 @@ struct Frag {
 template <bool RELU>
 __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t) {
   float v[16];
+  uint32_t bits = 0;  // this tile's 16 ReLU bits.  A C++ compare leaves a 64-bit lane mask in an SGPR pair, and with 16 of them per
+                      // tile alive at once the compiler spilled SGPRs through v_writelane / v_readlane (724 of the forward kernel's
+                      // ~2,700 vector instructions per tile).  Here every compare lands in VCC and is shifted into `bits` by the
+                      // next instruction (bits = 2 * bits + carry), registers 15 .. 0 so that bit r ends up as register r's.
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
+  for (int r = 15; r >= 0; r--) {
     v[r] = acc_get(a, r);
     if (RELU) {
-      const bool on = v[r] > 0.f;
-      v[r] = on ? v[r] : 0.f;
-      mask |= (unsigned long long)on << (t * 16 + r);
+      asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[r]) : "vcc");
+      v[r] = fmaxf(v[r], 0.f);  // = v > 0 ? v : 0 (NaN -> 0 either way)
     }
   }
+  if (RELU) mask |= (unsigned long long)bits << (t * 16);
 #pragma unroll
   for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -260,10 +264,12 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 template <bool RELU_MASK>
 __device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t) {
   float v[16];
+  const int bits = (int)(uint32_t)(mask >> (t * 16));  // this tile's 16 ReLU bits
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     v[r] = acc_get(a, r);
-    if (RELU_MASK) v[r] = ((mask >> (t * 16 + r)) & 1ull) ? v[r] : 0.f;  // ReLU'
+    // ReLU': and with the bit stretched to a word (v_bfe_i32 + v_and instead of shift / and / compare / select on 64 bits)
+    if (RELU_MASK) v[r] = __int_as_float(__float_as_int(v[r]) & ((bits << (31 - r)) >> 31));
   }
 #pragma unroll
   for (int s = 0; s < 2; s++) split8(v + 8 * s, f.hi[s], f.lo[s]);
