@@ -228,7 +228,7 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
           const uint32_t slot = slot0 + c.pos[d];
           const uint32_t range = slot >> GFN_GRAD_RANGE_LOG2;
           const unsigned int pos = atomicAdd(s_cursor + range, 1u);  // LDS: this workgroup's cursor of the range
-          if (pos < S.rec_cap) S.rec[((size_t)range * 256 + blockIdx.x) * S.rec_cap + pos] = make_uint2(slot, __builtin_bit_cast(uint32_t, v));
+          if (pos < S.rec_cap) S.rec[(range * 256u + blockIdx.x) * S.rec_cap + pos] = make_uint2(slot, __builtin_bit_cast(uint32_t, v));  // < 2^32 records (host check)
           else __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(baseh + c.pos[d]), v);  // stream full
         }
       }
@@ -590,6 +590,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
     const int64_t cap = (sh.rec_cap_total / (n_ranges * 256)) & ~1ll;  // 256 workgroup streams per range whatever the grid
     GFN_CHECK_ARG(cap >= 2, "%s: record buffer too small (%lld ranges x 256 streams)", fn, (long long)n_ranges);
     S.rec_cap = (unsigned int)(cap > 0x7ffffffe ? 0x7ffffffe : cap);
+    GFN_CHECK_ARG(n_ranges * 256 * (int64_t)S.rec_cap < (1ll << 32), "%s: more than 2^32 records (the kernels index them in 32 bits)", fn);
     S.n_ranges = (int)n_ranges;
   }
   gfn_hash_level_scales_host(S.sc.s);
