@@ -98,7 +98,7 @@ __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned lo
   for (int r = 15; r >= 0; r--) {
     v[r] = acc_get(a, r);
     if (RELU) {
-      asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[r]) : "vcc");
+      asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[r]) : "vcc");  // not volatile: dropped where nobody reads the masks (inference)
       v[r] = fmaxf(v[r], 0.f);  // = v > 0 ? v : 0 (NaN -> 0 either way)
     }
   }
