@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--graph-experiment", choices=["off", "eager", "graph"], default="off",
                     help="experiment: ONE fixed batch every step, eagerly launched or as one captured hipGraph replayed per step "
                          "(isolates launch overhead; the captured step's optimiser scalars are frozen, so not a training run)")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="torch.distributed backend at N > 1 (auto: RCCL, probed with one collective; gloo if that fails or ranks share a card)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
@@ -661,19 +663,37 @@ def run_rank(args):
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     n_dev = torch.cuda.device_count()
     backend = "nccl"
+    global CTL_DEV
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if n_dev < world:
             if not args.share_gpu:
                 raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible (--share-gpu rehearses ranks on shared cards)")
             backend, local_rank = "gloo", local_rank % max(n_dev, 1)  # RCCL refuses two ranks on one device
-            global CTL_DEV
-            CTL_DEV = "cpu"
         torch.cuda.set_device(local_rank)
+        if args.backend != "auto":
+            backend = args.backend
+        backend_note = None
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
+            try:  # RCCL over xGMI; probed with one real collective before anything depends on it
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                assert int(probe.item()) == world
+            except Exception as e:  # noqa: BLE001 -- every rank sees the same failure: fall back together
+                if args.backend == "nccl":
+                    raise
+                backend_note = f"gloo (RCCL could not be used: {type(e).__name__}: {str(e)[:120]})"
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+        if backend == "gloo":
+            CTL_DEV = "cpu"
             dist.init_process_group("gloo")
+        if backend_note:
+            backend = backend_note
     else:
         torch.cuda.set_device(0)
     _lib.require_device()  # the HIP extension + a gfx950 device, or fail loudly
