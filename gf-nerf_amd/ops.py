@@ -1113,11 +1113,15 @@ def copy_list(pairs):
     """[(dst, src)]: up to 8 small same-dtype, same-size contiguous device tensors copied in ONE launch (gfn_copy_list)."""
     import ctypes as C
 
-    n = len(pairs)
-    src = (C.c_void_p * n)(); dst = (C.c_void_p * n)(); nb = (C.c_int64 * n)()
-    for i, (d, s) in enumerate(pairs):
+    for d, s in pairs:
         if d.dtype != s.dtype or d.numel() != s.numel() or not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous()):
             raise _lib.GfnError("copy_list: pairs of contiguous device tensors of one dtype and size")
+    pairs = [(d, s) for d, s in pairs if d.numel()]  # nothing to do for empty tensors (they have no address)
+    n = len(pairs)
+    if n == 0:
+        return
+    src = (C.c_void_p * n)(); dst = (C.c_void_p * n)(); nb = (C.c_int64 * n)()
+    for i, (d, s) in enumerate(pairs):
         src[i], dst[i], nb[i] = s.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
     _lib.check(_lib.lib().gfn_copy_list(src, dst, nb, n, _stream()), "gfn_copy_list")
 

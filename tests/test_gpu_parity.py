@@ -650,6 +650,27 @@ def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts):
         assert float(grad[-40:].min()) == 7.0 and float(grad[-40:].max()) == 7.0
 
 
+def test_copy_list(ops, dev):
+    """gfn_copy_list: several small device copies in one launch; mixed dtypes and sizes, an empty one, argument checks."""
+    import torch
+
+    from gfnerf_amd import _lib
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    srcs = [torch.randint(0, 1 << 30, (4096,), generator=g, dtype=torch.int32).to(dev), torch.rand((4096, 3), generator=g).to(dev),
+            torch.rand((5, 3), generator=g).to(dev), torch.zeros(0, dtype=torch.float32, device=dev), torch.rand((70001,), generator=g).to(dev)]
+    dsts = [torch.full_like(s, 7) for s in srcs]
+    ops.copy_list(list(zip(dsts, srcs)))
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    with pytest.raises(_lib.GfnError):
+        ops.copy_list([(dsts[1], srcs[0])])  # dtype / size mismatch
+    with pytest.raises(_lib.GfnError):
+        ops.copy_list([(torch.zeros(3, dtype=torch.float16, device=dev), torch.zeros(3, dtype=torch.float16, device=dev))])  # 6 bytes
+    with pytest.raises(_lib.GfnError):
+        ops.copy_list([(dsts[0], srcs[0])] * 9)  # more than 8
+
+
 def test_generate_rays_matches_golden_and_oracle(oracle, ops, dev, golden):
     """gfn_generate_rays against the vectors captured from the reference's Cameras.generate_rays, explicit and raster mode."""
     import torch
