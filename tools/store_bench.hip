@@ -44,9 +44,9 @@ int run(uint8_t* buf, uint32_t line_mask, int blocks) {
 int main() {
   uint8_t* buf;
   CK(hipMalloc(&buf, 1ull << 30)); CK(hipMemset(buf, 0, 1ull << 30));
-  for (uint32_t mb : {32u, 1024u}) {
+  for (uint32_t mb : {2u, 4u, 8u, 16u, 32u, 64u, 1024u}) {
     const uint32_t mask = mb * 8192u - 1u;
-    for (int blocks : {768, 2048}) { run<4>(buf, mask, blocks); run<8>(buf, mask, blocks); run<16>(buf, mask, blocks); }
+    for (int blocks : {768, 2048}) { run<8>(buf, mask, blocks); if (mb == 32u || mb == 1024u) { run<4>(buf, mask, blocks); run<16>(buf, mask, blocks); } }
   }
   return 0;
 }
