@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void march_group_kernel(
   // this lane's slice of the current leaf's TransInfo
   int loaded_oct = -1, trans_idx = 0, block_idx = 0;
   float4 m0 = make_float4(0, 0, 0, 0), m1 = make_float4(0, 0, 0, 1);
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f, tcx = 0.f, tcy = 0.f, tcz = 0.f, tdis = 1.f;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, tcx = 0.f, tcy = 0.f, tcz = 0.f, tdis = 1.f, radius_clip = 1.f;
   const int gi = g < GFN_N_PROS ? g : 0;
   while (__any(active)) {
     if (active && loaded_oct != cur_oct_idx) {  // row-uniform: reload on leaf change only
@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256) void march_group_kernel(
       w0 = tp[96 + gi]; w1 = tp[96 + 12 + gi]; w2 = tp[96 + 24 + gi];
       tcx = tp[132]; tcy = tp[133]; tcz = tp[134]; tdis = tp[136];
       loaded_oct = cur_oct_idx;
+      // the ray's distance to the leaf's cameras, in units of their distance summary: constant while the ray stays in the leaf
+      const float dx = o[0] - tcx, dy = o[1] - tcy, dz = o[2] - tcz;
+      radius_clip = fmaxf(sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tdis, 1.f);
     }
     // per-lane projection i = g  (PersSampler_cuda.cu:155-188)
     const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
@@ -536,12 +539,9 @@ __global__ __launch_bounds__(256) void march_group_kernel(
       wp[0] = row_sum12(w0 * v); wp[1] = row_sum12(w1 * v); wp[2] = row_sum12(w2 * v);
     }
     if (active) {
-      const float dx = o[0] - tcx, dy = o[1] - tcy, dz = o[2] - tcz;
-      const float cur_radius = sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tdis;
-      const float cur_radius_clip = fmaxf(cur_radius, 1.f);
       const float warp_step = sample_l * noise[pts_ptr];
       exp_march_step = warp_step / (pnorm + 1e-6f);
-      if (scale_by_dis) exp_march_step *= cur_radius_clip;
+      if (scale_by_dis) exp_march_step *= radius_clip;
       cur_march_step = exp_march_step;
       if (FILL && !first && g == 0) {
         const int64_t p = base + pts_ptr;
