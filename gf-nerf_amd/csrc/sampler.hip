@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void march_group_kernel(
     float pnorm = sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
     pnorm = __shfl(pnorm, 0, 16);  // lane 0 of the row holds the true reductions
     float wp[3] = {0.f, 0.f, 0.f};
-    if (FILL) {  // warped point (:155-170): v_i = x0/x1, out_r = sum12(weight[r][i] * v_i)
+    if (FILL || rec) {  // warped point (:155-170): v_i = x0/x1, out_r = sum12(weight[r][i] * v_i); the counting pass records it too
       const float v = lv ? x0 / x1 : 0.f;
       wp[0] = row_sum12(w0 * v); wp[1] = row_sum12(w1 * v); wp[2] = row_sum12(w2 * v);
     }
@@ -580,10 +580,12 @@ __global__ __launch_bounds__(256) void march_group_kernel(
         if (ray_id) ray_id[p] = ray;
       }
       if (!FILL && rec && !first && g == 0) {  // what the sample-parallel fill needs to rebuild this sample
-        float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * 3;
+        float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * GFN_MARCH_REC_FLOATS;
         rp[0] = cur_t;
         rp[1] = exp_march_step * (pnorm + 1e-6f);
         rp[2] = __int_as_float(cur_oct_idx);
+        rp[3] = wp[0]; rp[4] = wp[1]; rp[5] = wp[2];  // the projections are in this row's lanes anyway: 3 more DPP trees here save
+                                                     // the fill pass 12 projections, 12 divisions and the whole TransInfo per sample
       }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
@@ -609,9 +611,10 @@ __device__ __forceinline__ float sum12_tree(const float* q) {  // the associatio
   return ((q[0] + (q[1] + q[2])) + (q[3] + (q[4] + q[5]))) + ((q[6] + (q[7] + q[8])) + (q[9] + (q[10] + q[11])));
 }
 
-// Second half of K4 when the count pass has recorded (t, dist, leaf) per sample: every sample is independent now, so
-// the warped point (QueryFrameTransform, PersSampler_cuda.cu:155-170) is rebuilt one thread per sample instead of
-// re-running the serial march -- same expressions and the same summation order as march_group_kernel<true>.
+// Second half of K4 when the count pass has recorded (t, dist, leaf, warped point) per sample: with the offsets known every
+// sample is written where it belongs, one thread per sample, instead of re-running the serial march.  (Until round 2 the record
+// held (t, dist, leaf) and this kernel redid the 12 projections per sample: 0.86 ms on a 138 k-ray render tile, 60 loads and 12
+// divisions per sample.)
 __global__ __launch_bounds__(256) void fill_from_rec_kernel(
     int n_rays, int table_space, int max_hits, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const int* __restrict__ hit_counts, const float2* __restrict__ hit_nf, const CompactNode* __restrict__ nodes,
@@ -629,24 +632,13 @@ __global__ __launch_bounds__(256) void fill_from_rec_kernel(
   const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
   const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
   for (int k = threadIdx.x; k < n; k += 256) {
-    const float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + k) * 3;
+    const float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + k) * GFN_MARCH_REC_FLOATS;
     const float t = rp[0], dist = rp[1];
     const int oct = __float_as_int(rp[2]);
     const CompactNode* nd = nodes + oct;
     const int trans_idx = nd->trans_idx, block_idx = nd->block_idx;
-    const float* tp = transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4);
     const float xyz[3] = {o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t};
-    float q0[12], q1[12], q2[12];
-#pragma unroll
-    for (int i = 0; i < GFN_N_PROS; i++) {
-      const float4 m0 = *reinterpret_cast<const float4*>(tp + i * 8);
-      const float4 m1 = *reinterpret_cast<const float4*>(tp + i * 8 + 4);
-      const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
-      const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
-      const float v = x0 / x1;
-      q0[i] = tp[96 + i] * v; q1[i] = tp[96 + 12 + i] * v; q2[i] = tp[96 + 24 + i] * v;
-    }
-    float wp[3] = {sum12_tree(q0), sum12_tree(q1), sum12_tree(q2)};
+    float wp[3] = {rp[3], rp[4], rp[5]};  // as march_group_kernel<true> computes it (same lanes, same DPP trees)
     if (table_space) {
       const float inv3 = 1.0f / 3.0f;
       wp[0] = (wp[0] + 1.5f) * inv3; wp[1] = (wp[1] + 1.5f) * inv3; wp[2] = (wp[2] + 1.5f) * inv3;

@@ -282,7 +282,7 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
         workspace = dict(hit_counts=torch.empty(max(R, 1), dtype=torch.int32, device=dev),
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
                          hit_nf=f(max(R * max_hits, 1), 2),
-                         march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * 3))  # (t, dist, leaf) per sample slot of the counting march
+                         march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * 6))  # (t, dist, leaf, warped point) per sample slot of the counting march
     if out is not None:
         if out["pts_offsets"].numel() != R + 1 or out["ts"].numel() != pts_cap or (want_world and out["world_pts"] is None):
             raise _lib.GfnError("sample_rays: `out` was made for another batch size / capacity / option set")

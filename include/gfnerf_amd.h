@@ -172,7 +172,7 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
  * slots + K4 with a 16-lane wave row per ray; bit-identical samples to gfn_trace + gfn_march.
  * compact_nodes: output of gfn_tree_compact (64 B per node, 64-byte aligned), to be refreshed
  * whenever the node blob changes (gfn_update_nodes).  Workspace: hit_counts i32 [R],
- * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2], and march_rec f32 [R*1024*3] (may be
+ * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2], and march_rec f32 [R*1024*GFN_MARCH_REC_FLOATS] (may be
  * NULL): with it the counting march records (t, dist, leaf) per sample and the outputs are rebuilt one
  * thread per sample instead of marching every ray a second time -- same bits, ~1/3 less time. */
 int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void* stream);
@@ -324,6 +324,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
  * them (leaves them zero for the next backward; counts_seen, when not NULL, receives a copy of what it
  * consumed), so a training loop never fills them. */
 #define GFN_GRAD_RANGE_LOG2 14
+#define GFN_MARCH_REC_FLOATS 6 /* per sample slot of gfn_sample_rays' march_rec: t, dist, leaf, warped point */
 #define GFN_GRAD_MAX_RANGES 1088
 int gfn_grad_record_ranges(int log2_T);
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T,
