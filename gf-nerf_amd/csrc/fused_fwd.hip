@@ -389,7 +389,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts && table_f16 && prim_pool && fwd_image && sh && sigma && rgb && out_rgb &&
                     work_counter, "gfn_fused_forward: null pointer");
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_fused_forward: n_rays=%lld", (long long)n_rays);
-  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 26) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");
+  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");  // 3 * 16 * n_volumes and 16 * T / 2 are 32-bit offsets in the kernel
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
   GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_forward: an interleaved pair image already holds the second table");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
