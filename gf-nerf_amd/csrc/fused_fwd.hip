@@ -153,7 +153,7 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
           const uint32_t slot0 = (uint32_t)level << (A.log2_T - 1);
           Corners c;
           uint32_t cell[3];
-          hash_corners(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
+          hash_corners<(TAB != 1 || SAVE)>(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
           float2 r;
           if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);  // one 8-byte gather per corner for both tables
           else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);

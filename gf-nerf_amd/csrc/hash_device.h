@@ -22,6 +22,10 @@ __device__ __forceinline__ uint32_t sat_u32(float f) {
 }
 
 // :27-69.  Returns the integer cell (ux,uy,uz) through `cell` for run detection.
+// MUL3: (u + 1) * p formed as u * p + p -- the same value in the uint32 wraparound arithmetic of the reference (:48-55) with
+// three quarter-rate multiplies instead of six; false keeps the six multiplies, whose shorter live ranges one register-tight
+// kernel needs (fused_fwd_kernel<1, false, false> spills 4 VGPRs otherwise; tests/test_abi_and_host.py checks for none).
+template <bool MUL3 = true>
 __device__ __forceinline__ void hash_corners(float px, float py, float pz, float scale, const int* __restrict__ prim,
                                              const float* __restrict__ bias, uint32_t mask, Corners& c,
                                              uint32_t cell[3]) {
@@ -31,10 +35,9 @@ __device__ __forceinline__ void hash_corners(float px, float py, float pz, float
   const uint32_t ux = sat_u32(fx), uy = sat_u32(fy), uz = sat_u32(fz);
   cell[0] = ux; cell[1] = uy; cell[2] = uz;
   const uint32_t pa = (uint32_t)prim[0], pb = (uint32_t)prim[1], pc = (uint32_t)prim[2];
-  // (u + 1) * p = u * p + p in the uint32 wraparound arithmetic of the reference (:48-55): three quarter-rate multiplies, not six
-  const uint32_t x0 = ux * pa, x1 = x0 + pa;
-  const uint32_t y0 = uy * pb, y1 = y0 + pb;
-  const uint32_t z0 = uz * pc, z1 = z0 + pc;
+  const uint32_t x0 = ux * pa, x1 = MUL3 ? x0 + pa : (ux + 1u) * pa;
+  const uint32_t y0 = uy * pb, y1 = MUL3 ? y0 + pb : (uy + 1u) * pb;
+  const uint32_t z0 = uz * pc, z1 = MUL3 ? z0 + pc : (uz + 1u) * pc;
   // % local_size with local_size == T == 2^k (:48-55, Hash3DAnchored.cpp:66-67)
   c.pos[0] = (x0 ^ y0 ^ z0) & mask;
   c.pos[1] = (x0 ^ y0 ^ z1) & mask;

@@ -94,16 +94,16 @@ struct Builder {
   int max_depth;
   float split_dist_thres;
   int threads;
-  Rng rng;
   std::vector<gfn_tree_node> nodes;
   std::vector<gfn_trans_info> trans;
   std::vector<float> w2c_rot;  // inverse of c2w[:, :3,:3], [n,9]
+  struct LeafJob { int64_t node; std::vector<int64_t> visi; };
+  std::vector<LeafJob> leaf_jobs;
   // pixel grid of GetVisiCams (PersSampler.cpp:51-65), intrinsics of camera 0 for all
   float half_w, half_h, cx, cy, fx, fy;
   int res_w, res_h;
   bool failed = false;
 
-  Builder(uint64_t seed) : rng(seed) {}
 
   Vec3 cam_pos(int64_t c) const { return {c2w[c * 12 + 3], c2w[c * 12 + 7], c2w[c * 12 + 11]}; }
 
@@ -158,9 +158,13 @@ struct Builder {
     const float py = wr[3] * rel.x + wr[4] * rel.y + wr[5] * rel.z;
     const float pz = wr[6] * rel.x + wr[7] * rel.y + wr[8] * rel.z;
     const float z = -pz;  // depth along the viewing direction
+    // A ray's parameter t is the camera-space depth of the point it reaches (the pixel direction has depth 1), so a hit
+    // needs a point of the node's bounding sphere at a depth inside [near, far] of this camera: clip the sphere's depth
+    // range with the bounds first, then bound the pixels whose rays can reach that slab of the sphere.
+    const float zn = fmaxf(z - rad, bounds[c * 2 + 0]), zf = fminf(z + rad, bounds[c * 2 + 1]);
+    if (zf < zn) return false;
     int j0 = 0, j1 = res_w - 1, i0 = 0, i1 = res_h - 1;
-    if (z > rad * 1.01f) {
-      const float zn = z - rad, zf = z + rad;
+    if (zn > 1e-6f) {
       const float ulo = fminf((px - rad) / zn, (px - rad) / zf), uhi = fmaxf((px + rad) / zn, (px + rad) / zf);
       const float vlo = fminf((py - rad) / zn, (py - rad) / zf), vhi = fmaxf((py + rad) / zn, (py + rad) / zf);
       // pixel coordinate j = u*fx + cx ; i = cy - v*fy ; grid index = (coord - .5) * (res-1)/(2*half-1)
@@ -168,10 +172,8 @@ struct Builder {
       const float jlo = (ulo * fx + cx - .5f) * sj, jhi = (uhi * fx + cx - .5f) * sj;
       const float ilo = (cy - vhi * fy - .5f) * si, ihi = (cy - vlo * fy - .5f) * si;
       if (jhi < -1.f || jlo > (float)res_w || ihi < -1.f || ilo > (float)res_h) return false;
-      j0 = std::max(0, (int)floorf(jlo) - 1); j1 = std::min(res_w - 1, (int)ceilf(jhi) + 1);
-      i0 = std::max(0, (int)floorf(ilo) - 1); i1 = std::min(res_h - 1, (int)ceilf(ihi) + 1);
-    } else if (z < -rad) {
-      return false;  // sphere entirely behind the image plane: every ray has t < 0 < near
+      j0 = std::max(0, (int)floorf(fmaxf(jlo, -1.f)) - 1); j1 = std::min(res_w - 1, (int)ceilf(fminf(jhi, (float)res_w)) + 1);
+      i0 = std::max(0, (int)floorf(fmaxf(ilo, -1.f)) - 1); i1 = std::min(res_h - 1, (int)ceilf(fminf(ihi, (float)res_h)) + 1);
     }
     for (int pi = i0; pi <= i1; pi++)
       for (int pj = j0; pj <= j1; pj++)
@@ -256,11 +258,12 @@ struct Builder {
   // first: the camera (index into visi) the farthest-point selection starts from, -1 = drawn (torch::randint in the reference,
   // :641); pts_in: probe points [n_pts_in,3], NULL = 32^3 drawn uniformly in the node (torch::rand, :540); good_out: the six
   // selected cameras (indices into visi)
-  bool construct_trans(const std::vector<int64_t>& visi, Vec3 center, float side, gfn_trans_info* out, int64_t first = -1,
-                       const float* pts_in = nullptr, int n_pts_in = 0, int64_t* good_out = nullptr) {
+  bool construct_trans(const std::vector<int64_t>& visi, Vec3 center, float side, gfn_trans_info* out, Rng& rng,
+                       int par, int64_t first = -1, const float* pts_in = nullptr, int n_pts_in = 0,
+                       int64_t* good_out = nullptr) const {
     float frame[GFN_N_PROS][2][4];
     float dis_summary;
-    if (!select_frames(visi, center, first, frame, &dis_summary, good_out)) return false;
+    if (!select_frames(visi, center, first, frame, &dis_summary, good_out, rng)) return false;
     std::vector<float> own;
     int n_pts = n_pts_in;
     if (!pts_in) {  // probe points in the node (:539-540)
@@ -274,7 +277,7 @@ struct Builder {
       pts_in = own.data();
     }
     memset(out, 0, sizeof(*out));
-    if (!fit_weight(frame, pts_in, n_pts, out->weight)) return false;
+    if (!fit_weight(frame, pts_in, n_pts, out->weight, par)) return false;
     memcpy(out->w2xz, frame, sizeof(frame));
     out->center[0] = center.x; out->center[1] = center.y; out->center[2] = center.z;
     out->side_len = side;
@@ -284,7 +287,7 @@ struct Builder {
 
   // first and second step of ConstructTrans (:619-768): align distances, pick six cameras, re-aim them at the node centre
   bool select_frames(const std::vector<int64_t>& visi, Vec3 center, int64_t first, float frame[GFN_N_PROS][2][4],
-                     float* dis_summary_out, int64_t* good_out) {
+                     float* dis_summary_out, int64_t* good_out, Rng& rng) const {
     const int n_virt = GFN_N_PROS / 2;
     const int64_t n_cur = (int64_t)visi.size();
     std::vector<Vec3> cpos(n_cur);
@@ -364,11 +367,13 @@ struct Builder {
 
   // third step of ConstructTrans (:770-815): project the probe points through the 12 frames, PCA of the projected values,
   // rows normalised by the mean expected step
-  bool fit_weight(const float frame[GFN_N_PROS][2][4], const float* pts, int n_pts, float weight[3][GFN_N_PROS]) {
+  // par: threads of the per-point loops (1 when the caller already runs one leaf per thread)
+  bool fit_weight(const float frame[GFN_N_PROS][2][4], const float* pts, int n_pts, float weight[3][GFN_N_PROS],
+                  int par) const {
     std::vector<float> tv((size_t)n_pts * GFN_N_PROS);          // transed value a/b
     std::vector<float> dvd((size_t)n_pts * GFN_N_PROS * 3);     // dv/dxyz
     bool bad = false;
-#pragma omp parallel for num_threads(threads) schedule(static) reduction(|| : bad)
+#pragma omp parallel for num_threads(par) schedule(static) reduction(|| : bad)
     for (int p = 0; p < n_pts; p++) {
       const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
       for (int i = 0; i < GFN_N_PROS; i++) {
@@ -394,7 +399,7 @@ struct Builder {
     // step normalisation (:807-815)
     double mean_step[3] = {0, 0, 0};
     bool singular = false;
-#pragma omp parallel num_threads(threads)
+#pragma omp parallel num_threads(par)
     {
       double local[3] = {0, 0, 0};
       bool lsing = false;
@@ -471,12 +476,33 @@ struct Builder {
       nodes[u].is_leaf_node = 1;  // leaf without enough cameras: invalid (:573-577)
     } else {
       nodes[u].is_leaf_node = 1;
-      gfn_trans_info ti;
-      if (construct_trans(visi, center, side, &ti)) {
-        nodes[u].trans_idx = (int64_t)trans.size();
-        trans.push_back(ti);
-      }  // else: the reference would abort on its CHECKs (:790,:799); keep the leaf invalid instead
+      leaf_jobs.push_back({u, visi});  // fitted by fit_leaves(), one leaf per thread
     }
+  }
+
+  // ConstructTrans of every leaf that has enough cameras (:579-588).  The leaves are independent, so they run one per
+  // thread (a leaf's own loops are only 32^3 points long: splitting THOSE over the host's cores is fork/join-bound), each
+  // with its own random stream derived from (seed, position of the leaf in depth-first order), which makes the result
+  // independent of the thread count.  Transform indices are handed out in depth-first order afterwards, as the reference's
+  // recursion does.
+  void fit_leaves(uint64_t seed, int leaf_threads) {
+    const int64_t n = (int64_t)leaf_jobs.size();
+    std::vector<gfn_trans_info> fitted((size_t)n);
+    std::vector<uint8_t> ok((size_t)n, 0);
+#pragma omp parallel for num_threads(leaf_threads) schedule(dynamic, 1)
+    for (int64_t j = 0; j < n; j++) {
+      const gfn_tree_node& nd = nodes[leaf_jobs[j].node];
+      Rng leaf_rng(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(j + 1)));
+      ok[j] = construct_trans(leaf_jobs[j].visi, {nd.center[0], nd.center[1], nd.center[2]}, nd.side_len, &fitted[j],
+                              leaf_rng, 1)
+                  ? 1 : 0;
+    }
+    for (int64_t j = 0; j < n; j++)
+      if (ok[j]) {  // else: the reference would abort on its CHECKs (:790,:799); keep the leaf invalid instead
+        nodes[leaf_jobs[j].node].trans_idx = (int64_t)trans.size();
+        trans.push_back(fitted[j]);
+      }
+    leaf_jobs.clear();
   }
 };
 
@@ -493,13 +519,15 @@ int gfn_octree_build_host(const float* c2w_host, const float* intri_host, const 
     gfn_set_error("gfn_octree_build_host: bad arguments");
     return GFN_ERR_ARG;
   }
+  int leaf_threads = 1;
 #ifdef _OPENMP
   if (threads <= 0) threads = omp_get_max_threads();
-  if (threads > 16) threads = 16;  // the per-node loops are short; more threads only add fork/join cost
+  leaf_threads = threads;            // one leaf per thread: scales with the host
+  if (threads > 16) threads = 16;    // the per-node camera loop is short; more threads only add fork/join cost
 #else
   threads = 1;
 #endif
-  Builder b(seed);
+  Builder b;
   b.n_cams = n_cams; b.c2w = c2w_host; b.intri = intri_host; b.bounds = bounds_host;
   b.max_depth = max_depth; b.split_dist_thres = split_dist_thres; b.threads = threads;
   b.init();
@@ -511,6 +539,7 @@ int gfn_octree_build_host(const float* c2w_host, const float* intri_host, const 
   memset(&b.nodes[0], 0, sizeof(gfn_tree_node));
   b.nodes[0].parent = -1;
   b.construct_node(0, 0, {0.f, 0.f, 0.f}, bbox_side_len);
+  b.fit_leaves(seed, leaf_threads);
   const size_t nb = b.nodes.size() * sizeof(gfn_tree_node);
   const size_t tb = std::max<size_t>(b.trans.size(), 1) * sizeof(gfn_trans_info);
   void* np = malloc(nb);
@@ -564,7 +593,7 @@ static int make_builder(Builder& b, const float* c2w, const float* intri, const 
 
 int gfn_octree_visible_cams_host(const float* c2w, const float* intri, const float* bounds, int64_t n_cams, const float* center,
                                  float side, uint8_t* visible_out) {
-  Builder b(0);
+  Builder b;
   if (!center || !visible_out) {
     gfn_set_error("gfn_octree_visible_cams_host: bad arguments");
     return GFN_ERR_ARG;
@@ -578,7 +607,7 @@ int gfn_octree_visible_cams_host(const float* c2w, const float* intri, const flo
 int gfn_octree_construct_trans_host(const float* c2w_visible, const float* intri, int64_t n_visible, const float* center, float side,
                                     int64_t first_cam, const float* pts, int64_t n_pts, uint64_t seed, void* trans_out,
                                     int64_t* good_cams_out) {
-  Builder b(seed);
+  Builder b;
   if (!center || !trans_out || (pts && n_pts <= 0) || n_pts > (1 << 24)) {
     gfn_set_error("gfn_octree_construct_trans_host: bad arguments");
     return GFN_ERR_ARG;
@@ -588,8 +617,9 @@ int gfn_octree_construct_trans_host(const float* c2w_visible, const float* intri
   if (rc != GFN_OK) return rc;
   std::vector<int64_t> visi((size_t)n_visible);
   for (int64_t i = 0; i < n_visible; i++) visi[i] = i;
-  if (!b.construct_trans(visi, {center[0], center[1], center[2]}, side, reinterpret_cast<gfn_trans_info*>(trans_out), first_cam, pts,
-                         (int)n_pts, good_cams_out)) {
+  Rng rng(seed);
+  if (!b.construct_trans(visi, {center[0], center[1], center[2]}, side, reinterpret_cast<gfn_trans_info*>(trans_out), rng, 1,
+                         first_cam, pts, (int)n_pts, good_cams_out)) {
     gfn_set_error("gfn_octree_construct_trans_host: degenerate frames (a probe point behind a virtual camera, or a singular Jacobian)");
     return GFN_ERR_ARG;
   }
@@ -601,12 +631,12 @@ int gfn_octree_fit_weight_host(const float* w2xz, const float* pts, int64_t n_pt
     gfn_set_error("gfn_octree_fit_weight_host: bad arguments");
     return GFN_ERR_ARG;
   }
-  Builder b(0);
+  Builder b;
   b.threads = 1;
   float frame[GFN_N_PROS][2][4];
   memcpy(frame, w2xz, sizeof(frame));
   float weight[3][GFN_N_PROS];
-  if (!b.fit_weight(frame, pts, (int)n_pts, weight)) {
+  if (!b.fit_weight(frame, pts, (int)n_pts, weight, 1)) {
     gfn_set_error("gfn_octree_fit_weight_host: degenerate frames");
     return GFN_ERR_ARG;
   }

@@ -130,7 +130,7 @@ def build_scene(n_side=20, max_depth=16, seed=1234, cache_dir=None, threads=0):
     from . import ops
 
     c2w, intri, bounds = make_cameras(n_side=n_side, seed=seed)
-    key = f"scene_s{n_side}_d{max_depth}_seed{seed}.npz"
+    key = f"scene_v2_s{n_side}_d{max_depth}_seed{seed}.npz"  # v2: per-leaf random streams
     path = os.path.join(cache_dir, key) if cache_dir else None
     nodes = None
     if path and os.path.exists(path):

@@ -293,6 +293,35 @@ def mark_invisible(nodes, intri, w2c, bounds):
     lib().gfn_o_mark_invisible(_p(nodes), C.c_int64(nodes.shape[0]), _p(intri), _p(w2c), _p(bounds), C.c_int64(intri.shape[0]))
 
 
+def visible_cams(c2w, intri, bounds, center, side):
+    """GetVisiCams (PersSampler.cpp:45-88), every one of the 128 x res_h pixel rays of every camera against the node box:
+    camera c is visible iff any ray has min(far_box, far_c) > max(near_box, near_c).  f32 arithmetic in the order of the
+    reference's expressions; returns a bool array [n_cams]."""
+    c2w, K, bounds = _f32(c2w), _f32(intri).reshape(-1, 3, 3)[0], _f32(bounds)
+    f = np.float32
+    half_w, half_h, cx, cy, fx, fy = K[0, 2], K[1, 2], K[0, 2], K[1, 2], K[0, 0], K[1, 1]
+    res_w = 128
+    res_h = int(np.round(f(res_w) / half_w * half_h))
+    i = (f(.5) + (half_h * f(2) - f(1)) * np.arange(res_h, dtype=f) / f(max(res_h - 1, 1))).astype(f)   # linspace(.5, 2h-.5)
+    j = (f(.5) + (half_w * f(2) - f(1)) * np.arange(res_w, dtype=f) / f(max(res_w - 1, 1))).astype(f)
+    ii, jj = np.meshgrid(i, j, indexing="ij")
+    ccx, ccy, ccz = ((jj - cx) / fx).reshape(-1), (-(ii - cy) / fy).reshape(-1), f(-1)
+    center = _f32(center)
+    lo, hi = center - f(side) * f(.5), center + f(side) * f(.5)
+    out = np.zeros(c2w.shape[0], bool)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for c in range(c2w.shape[0]):
+            m = c2w[c]
+            d = np.stack([m[k, 0] * ccx + m[k, 1] * ccy + m[k, 2] * ccz for k in range(3)], -1)   # [n_pix, 3]
+            o = m[:3, 3]
+            a = np.nan_to_num((lo - o) / d, nan=0.0, posinf=1e6, neginf=-1e6).astype(f)
+            b = np.nan_to_num((hi - o) / d, nan=0.0, posinf=1e6, neginf=-1e6).astype(f)
+            far = np.minimum(np.maximum(a, b).min(-1), bounds[c, 1])
+            near = np.maximum(np.minimum(a, b).max(-1), bounds[c, 0])
+            out[c] = bool((far > near).any())
+    return out
+
+
 def generate_rays(c2w, intr, cam_idx, coords):
     """Cameras.generate_rays (perspective, no distortion) -> dict(origins, directions, lookat, pixel_area, dir_norm)."""
     c2w, intr, coords = _f32(c2w), _f32(intr), _f32(coords)

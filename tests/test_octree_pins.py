@@ -171,3 +171,30 @@ def test_visible_cams_sandwiched_by_reference(po, ops):
         assert not (got & ~upper).any(), (b, np.nonzero(got & ~upper)[0])
         gap += int((upper & ~lower).sum())
     assert po["po_visi_lower"].sum() > 90 and gap < 0.1 * po["po_visi_lower"].size  # the sandwich is tight and not vacuous
+
+
+def test_visible_cams_equal_the_full_pixel_grid(ops, oracle):
+    """The build only casts the pixel rays that can reach the slab of the node's bounding sphere inside a camera's [near, far];
+    the answer must be that of the full 128 x res_h grid (oracle.visible_cams restates GetVisiCams ray by ray), for nodes in
+    front of, beside, behind, around and beyond the far bound of the cameras."""
+    from gfnerf_amd import scene
+
+    c2w, intri, bounds = scene.make_cameras(n_side=5, seed=3)
+    rng = np.random.default_rng(11)
+    pos = c2w[:, :, 3]
+    span = np.abs(pos).max()
+    seen = 0
+    for k in range(40):
+        side = float(2.0 ** rng.integers(-5, 3)) * span * 0.25
+        if k % 4 == 0:    # around a camera
+            center = pos[rng.integers(len(pos))] + rng.normal(size=3) * side * 0.3
+        elif k % 4 == 1:  # level with the cameras, off to the side
+            center = pos[rng.integers(len(pos))] + np.array([rng.normal() * span, rng.normal() * span, rng.normal() * side * 0.2])
+        else:             # anywhere in the scene box, some beyond the far bound
+            center = rng.uniform(-1, 1, 3) * span * (3.0 if k % 4 == 3 else 1.0)
+        center = center.astype(np.float32)
+        want = oracle.visible_cams(c2w, intri, bounds, center, side)
+        got = ops.octree_visible_cams(c2w, intri, bounds, center, side)
+        np.testing.assert_array_equal(got, want, err_msg=f"box {k}: centre {center}, side {side}")
+        seen += int(want.sum())
+    assert 0 < seen < 40 * len(pos)   # both answers occur
