@@ -74,7 +74,8 @@ def parse():
                     help="torch.distributed backend at N > 1 (auto: RCCL, probed with one collective; gloo if that fails or ranks share a card)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
-    ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one 4 MB address half at a time")
+    ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one address part at a time")
+    ap.add_argument("--lm-split-log2", type=int, default=0, help="level-major lookup: 2^this address parts per level (0 / 1: halves; 2: quarters)")
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
     ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
@@ -407,7 +408,7 @@ class StageRun:
             log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
             prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, table_branch=args.table_branch,
-            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from,
+            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
             **({"level_major_global_after": ga} if ga is not None else {}))
         self.n_blocks = n_blocks

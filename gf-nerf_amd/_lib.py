@@ -73,7 +73,7 @@ SIGNATURES = {
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gfn_generate_rays": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gfn_hash_fwd_lm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "gfn_hash_fwd_lm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "gfn_pixel_uniform": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "gfn_pixel_collate": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_errmap_block_sums": (_i32, [_vp, _i64, _vp, _vp]),

@@ -6,11 +6,15 @@
 // benchmark gathers 262 G/s from a table that fits the 4 MB L2 of an XCD and 121 G/s from an 8 MB one.  So here every
 // workgroup owns a contiguous run of samples (thread t keeps samples t, t + 1024, ... in registers for the whole
 // kernel) and ALL workgroups sweep the table together, one launch per table:
-//     for level: for address half h (4 MB of f16 pairs): every sample's corners that fall into that half
-// Corners of the first half wait in LDS; the second half completes the level: blend (same order as the direct kernel,
+//     for level: for address part h (a half = 4 MB of f16 pairs at T = 2^21): every sample's corners that fall into it
+// Corners of the earlier parts wait in LDS; the last part completes the level: blend (same order as the direct kernel,
 // so the features are bit-identical), round to f16, store (the second table's launch adds to the first's result).
 // Level l's upper half and level l+1's lower half are the same addresses (the reference's level-overlap quirk), so
-// consecutive passes share a warm L2.  Coarse levels (< halves_from) are not split; there the first lane of a run of
+// half of the passes find their part warm (with every part warm the kernel takes 0.346 instead of 0.399 ms).  What was tried
+// on the pass structure (tools/README.md, round 2): quarters instead of halves, with and without pulling the next cold quarter
+// into the L2 by one load per line during the pass before it (no gain in the step, see gfn_hash_fwd_lm below), two 512-thread
+// workgroups per CU (0.47 ms: their passes drift apart), the workgroup barrier after the gathers are issued instead of after
+// they are consumed (0.42), two samples' gathers in flight per thread (0.44).  Coarse levels (< halves_from) are not split; there the first lane of a run of
 // samples in one cell gathers for the whole run.
 #include "gfn_common.h"
 #include "hash_device.h"
@@ -23,11 +27,17 @@ struct LmArgs {
   int64_t n_max; const int32_t* n_dev;
   const float* pts; const int* anchors; int anchor_stride;
   const void* table; const int* prim; const float* bias;
-  int64_t n_volumes; int log2_T; int halves_from;  // levels >= halves_from are split into address halves
+  int64_t n_volumes; int log2_T; int halves_from;  // levels >= halves_from are gathered one address part at a time ...
+  int split_log2;                                   // ... of 2^split_log2 parts per level (1: halves, 2: quarters)
   int cap;  // samples of one workgroup per round (LDS capacity)
   float* out;  // f32 [n,32] row-major, or level-major float2 [16][n_max]
   LevelScales sc;
 };
+
+// a gather as (uniform 64-bit base in SGPRs) + (32-bit byte offset per lane): one address register per corner instead of two
+__device__ __forceinline__ half2_t ld_pair(const half2_t* __restrict__ base, uint32_t pos) {
+  return *reinterpret_cast<const half2_t*>(reinterpret_cast<const char*>(base) + (size_t)(uint32_t)(pos << 2));
+}
 
 constexpr int kLmK = 4;  // samples per thread: a workgroup run holds up to 4096 samples
 
@@ -44,7 +54,6 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
   const int64_t n = gfn_live_n(A.n_max, A.n_dev);
   const int64_t per_round = (int64_t)A.cap * gridDim.x;
   const uint32_t mask = (1u << A.log2_T) - 1u;
-  const int top = A.log2_T - 1;
   for (int64_t r0 = 0; r0 < n; r0 += per_round) {
     // this round's samples, dealt in equal contiguous runs so that every workgroup does the same work per pass
     const int64_t left = n - r0 < per_round ? n - r0 : per_round;
@@ -94,14 +103,14 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
             if (__popcll(heads) <= 40) {  // wave-uniform: enough lanes saved to pay for the shuffles
               if (head) {
 #pragma unroll
-                for (int d = 0; d < 8; d++) v[d] = base[c.pos[d]];
+                for (int d = 0; d < 8; d++) v[d] = ld_pair(base, c.pos[d]);
               }
               const int src = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));  // the run's first lane
 #pragma unroll
               for (int d = 0; d < 8; d++) v[d] = __builtin_bit_cast(half2_t, __shfl(__builtin_bit_cast(int, v[d]), src, 64));
             } else {
 #pragma unroll
-              for (int d = 0; d < 8; d++) v[d] = base[c.pos[d]];
+              for (int d = 0; d < 8; d++) v[d] = ld_pair(base, c.pos[d]);
             }
             if (valid) {
               float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + b0 + s
@@ -121,7 +130,10 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
           __syncthreads();
           continue;
         }
-        for (int h = 0; h < 2; h++) {
+        const int pshift = A.log2_T - A.split_log2;  // a slot's part = its top split_log2 bits
+        const int n_parts = 1 << A.split_log2;
+        for (int h = 0; h < n_parts; h++) {
+          const bool last = h == n_parts - 1;
 #pragma unroll
           for (int k = 0; k < kLmK; k++) {
             const int s = tid + k * kLmThreads;
@@ -130,10 +142,10 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
               uint32_t cell[3];
               const int64_t tr = (int64_t)level * A.n_volumes + vol[k];
               hash_corners(px[k], py[k], pz[k], scale, prim[k], A.bias ? A.bias + 3 * tr : nullptr, mask, c, cell);
-              if (h == 0) {  // lower half of the slot range: fetch and park
+              if (!last) {  // an earlier part of the slot range: fetch and park
 #pragma unroll
                 for (int d = 0; d < 8; d++)
-                  if (!(c.pos[d] >> top)) s_val[d * A.cap + s] = __builtin_bit_cast(uint32_t, base[c.pos[d]]);
+                  if ((int)(c.pos[d] >> pshift) == h) s_val[d * A.cap + s] = __builtin_bit_cast(uint32_t, ld_pair(base, c.pos[d]));
               } else {
                 float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + b0 + s
                                      : reinterpret_cast<float2*>(A.out + (b0 + s) * 32 + 2 * level);
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
                 half2_t v[8];
 #pragma unroll
                 for (int d = 0; d < 8; d++) {
-                  if (c.pos[d] >> top) v[d] = base[c.pos[d]];
+                  if ((int)(c.pos[d] >> pshift) == h) v[d] = ld_pair(base, c.pos[d]);
                   else v[d] = __builtin_bit_cast(half2_t, s_val[d * A.cap + s]);
                 }
                 float a0 = 0.f, a1 = 0.f;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
               }
             }
           }
-          __syncthreads();  // keep the workgroup's waves in the same pass
+          __syncthreads();  // keep the workgroup's waves in the same pass: they share the part's lines in the XCD's L2
         }
       }
     }
@@ -170,14 +182,18 @@ extern "C" {
 
 int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2,
                     const float* bias_pool, const float* pts, const int32_t* anchors, int anchor_stride, int64_t n_max, const int32_t* n_dev,
-                    int64_t n_volumes, int log2_T, int halves_from, int planar, int accumulate, float* out, void* stream) {
+                    int64_t n_volumes, int log2_T, int halves_from, int split_log2, int planar, int accumulate, float* out, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG(table_f16 && prim_pool && pts && anchors && out, "gfn_hash_fwd_lm: null pointer");
-  GFN_CHECK_ARG(n_max > 0 && n_volumes > 0 && log2_T >= 4 && log2_T <= 24, "gfn_hash_fwd_lm: bad sizes");
+  GFN_CHECK_ARG(n_max > 0 && n_volumes > 0 && log2_T >= 4 && log2_T <= 24 && split_log2 >= 0 && split_log2 <= 3, "gfn_hash_fwd_lm: bad sizes");
   LmArgs A;
   A.n_max = n_max; A.n_dev = n_dev; A.pts = pts; A.anchors = anchors; A.anchor_stride = anchor_stride;
   A.bias = bias_pool; A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.halves_from = halves_from < 0 ? 0 : halves_from;
+  // 0: halves.  Quarters (2 MB parts at T = 2^21) win 4 % when the lookup runs back to back on an otherwise idle chip (0.371
+  // vs 0.385 ms: the table then sits in the memory-side cache and the cold parts come from there) and lose 2-5 % inside the
+  // training step or behind a 1 GiB stream (0.383 vs 0.376; in the step 0.389 vs 0.370); eighths pay for their passes (0.53)
+  A.split_log2 = split_log2 > 0 ? split_log2 : 1;
   A.out = out;
   gfn_hash_level_scales_host(A.sc.s);
   const int grid = gfn_decoder_cu_cap();  // one workgroup per CU

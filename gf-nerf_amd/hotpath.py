@@ -53,7 +53,8 @@ class HotPathConfig:
     level_major_global_after: int = 50  # ... or from this optimiser step on (-1: never): while the scene is empty the fused forward's
                                      # early termination wins (2.40 vs 2.69 ms/step); once nearly every sample is alive (a few dozen
                                      # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
-    lm_halves_from: int = 6          # levels >= this are gathered one 4 MB address half at a time
+    lm_halves_from: int = 6          # levels >= this are gathered one address part at a time ...
+    lm_split_log2: int = 0           # ... of 2^this parts per level (0 = 1: halves; 2: quarters, no gain inside the step)
     render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     table_branch: bool = False       # global stage, one rank: table-gradient accumulation + table Adam on a second stream beside the
@@ -294,15 +295,15 @@ class HotPath:
         elif self.cfg.table_f16_shadow and lm and block is not None and self._opt_pending:
             # the frozen global table first, beside the previous step's Adam on the block table; then wait for that Adam
             feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
-                               n_dev=n_dev, halves_from=self.cfg.lm_halves_from, planar=True)
+                               n_dev=n_dev, halves_from=self.cfg.lm_halves_from, split_log2=self.cfg.lm_split_log2, planar=True)
             self._sync_opt()
             self._timed("hash_fwd", ops.hash_fwd_lm, self.blocks16[block], self.block_prims[block], self.bias_arg, s["warped_pts"], s["anchors"],
-                        V, T, n_dev=n_dev, halves_from=self.cfg.lm_halves_from, planar=True, out=feat, accumulate=True)
+                        V, T, n_dev=n_dev, halves_from=self.cfg.lm_halves_from, split_log2=self.cfg.lm_split_log2, planar=True, out=feat, accumulate=True)
         elif self.cfg.table_f16_shadow and lm:
             feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
                                table2_f16=self.blocks16[block] if block is not None else None,
                                prim_pool2=self.block_prims[block] if block is not None else None, n_dev=n_dev,
-                               halves_from=self.cfg.lm_halves_from, planar=True)
+                               halves_from=self.cfg.lm_halves_from, split_log2=self.cfg.lm_split_log2, planar=True)
         elif self.cfg.table_f16_shadow and block is not None:  # residual block table (nerfacto_field.py:485-486) fused in
             feat = self._timed("hash_fwd", ops.hash_fwd_f16, self.table16, self.prim, self.bias_arg, s["warped_pts"],
                                s["anchors"], V, T, table2_f16=self.blocks16[block], prim_pool2=self.block_prims[block], n_dev=n_dev)

@@ -82,8 +82,9 @@ _part_ws = {}
 
 
 def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
-                halves_from=6, planar=False, accumulate=False):
-    """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time.
+                halves_from=6, planar=False, accumulate=False, split_log2=0):
+    """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time
+    (levels >= halves_from in 2^split_log2 parts; 0 = halves).
     planar: out is float2 [16, n] (level-major) instead of f32 [n, 32]."""
     _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16"); _chk(prim_pool, torch.int32, "prim_pool")
     _chk(prim_pool2, torch.int32, "prim_pool2"); _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
@@ -95,7 +96,7 @@ def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T
     if out.numel() != n * 32:
         raise _lib.GfnError("hash_fwd_lm: out must hold 32 features per sample")
     rc = _lib.lib().gfn_hash_fwd_lm(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
-                                    _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(bool(planar)), int(bool(accumulate)), _ptr(out), _stream())
+                                    _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(split_log2), int(bool(planar)), int(bool(accumulate)), _ptr(out), _stream())
     _lib.check(rc, "gfn_hash_fwd_lm")
     return out
 

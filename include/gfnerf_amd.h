@@ -115,14 +115,15 @@ int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const 
                       int64_t n_volumes, int log2_T, float* out, void* stream);
 /* The same lookup as gfn_hash_fwd_f16 in LEVEL-MAJOR order (csrc/lm_lookup.hip): every workgroup owns a run of
  * samples and all workgroups sweep level by level, table by table, and -- for levels >= halves_from -- one
- * 4 MB address half at a time, so that the slots being gathered fit the XCDs' L2 instead of missing to the
+ * address part (1 / 2^split_log2 of the level's slots; split_log2 = 0: halves, 4 MB each at T = 2^21)
+ * at a time, so that the slots being gathered fit the XCDs' L2 instead of missing to the
  * fabric.  Bit-identical features.  anchors i32, element i at anchors[i*anchor_stride].  planar != 0: out is
  * level-major, float2 [16][n_max] (coalesced stores; what gfn_field_fwd_x3 reads with feat_stride = n_max).
  * accumulate != 0: out += features.  One launch per table. */
 int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const int32_t* anchors,
                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
-                    int halves_from, int planar, int accumulate, float* out, void* stream);
+                    int halves_from, int split_log2, int planar, int accumulate, float* out, void* stream);
 /* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
 int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
 

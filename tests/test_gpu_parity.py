@@ -711,11 +711,13 @@ def test_s3im_matches_golden(ops, dev, golden):
     assert all(sorted(idx[256 * k: 256 * (k + 1)].cpu().tolist()) == list(range(256)) for k in range(1, 10))
 
 
-@pytest.mark.parametrize("n,log2_T,halves_from", [(5000, 14, 0), (777, 12, 8), (300000, 16, 6), (1, 12, 0)])
-def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from):
-    """gfn_hash_fwd_lm (all workgroups sweep level by level, one L2-sized address half at a time) == gfn_hash_fwd_f16, bit for
-    bit: one table, two tables with their own primes, row-major and level-major output, device-side live count, and a
-    sample count that needs more than one round of workgroup runs."""
+@pytest.mark.parametrize("n,log2_T,halves_from,split_log2", [(5000, 14, 0, 1), (5000, 14, 0, 2), (777, 12, 8, 3), (300000, 16, 6, 0),
+                                                             (300000, 16, 6, 2), (1, 12, 0, 2)])
+def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from, split_log2):
+    """gfn_hash_fwd_lm (all workgroups sweep level by level, one L2-sized address part -- half, quarter, eighth -- at a time)
+    == gfn_hash_fwd_f16, bit for bit: one table, two tables with their own primes, row-major and level-major output, device-side
+    live count, and a sample count that needs more than one round of workgroup runs."""
+    import functools
     import torch
 
     rng = np.random.default_rng(n)
@@ -726,24 +728,25 @@ def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from):
     bias = torch.from_numpy(rng.random((16 * V, 3)).astype(np.float32)).to(dev)
     pts = torch.from_numpy((rng.random((n, 3)) * 1.2 - 0.1).astype(np.float32)).to(dev)
     anc = torch.from_numpy(np.sort(rng.integers(0, V, n)).astype(np.int32)).to(dev)
+    lm = functools.partial(ops.hash_fwd_lm, split_log2=split_log2)
     for b in (None, bias):
         ref1 = ops.hash_fwd_f16(tabs[0], prims[0], b, pts, anc, V, log2_T)
         ref2 = ops.hash_fwd_f16(tabs[0], prims[0], b, pts, anc, V, log2_T, table2_f16=tabs[1], prim_pool2=prims[1])
-        got1 = ops.hash_fwd_lm(tabs[0], prims[0], b, pts, anc, V, log2_T, halves_from=halves_from)
-        got2 = ops.hash_fwd_lm(tabs[0], prims[0], b, pts, anc, V, log2_T, table2_f16=tabs[1], prim_pool2=prims[1], halves_from=halves_from)
+        got1 = lm(tabs[0], prims[0], b, pts, anc, V, log2_T, halves_from=halves_from)
+        got2 = lm(tabs[0], prims[0], b, pts, anc, V, log2_T, table2_f16=tabs[1], prim_pool2=prims[1], halves_from=halves_from)
         assert torch.equal(ref1, got1) and torch.equal(ref2, got2)
-        pl = ops.hash_fwd_lm(tabs[0], prims[0], b, pts, anc, V, log2_T, table2_f16=tabs[1], prim_pool2=prims[1], halves_from=halves_from, planar=True)
+        pl = lm(tabs[0], prims[0], b, pts, anc, V, log2_T, table2_f16=tabs[1], prim_pool2=prims[1], halves_from=halves_from, planar=True)
         assert pl.shape == (16, n, 2) and torch.equal(pl.permute(1, 0, 2).reshape(n, 32), ref2)
     # live count on the device smaller than the buffers: rows beyond it are not written
     if n > 10:
         live = torch.tensor([n - 7], dtype=torch.int32, device=dev)
         out = torch.full((n, 32), -5.0, device=dev)
-        ops.hash_fwd_lm(tabs[0], prims[0], None, pts, anc, V, log2_T, out=out, n_dev=live, halves_from=halves_from)
+        lm(tabs[0], prims[0], None, pts, anc, V, log2_T, out=out, n_dev=live, halves_from=halves_from)
         ref = ops.hash_fwd_f16(tabs[0], prims[0], None, pts, anc, V, log2_T)
         assert torch.equal(out[: n - 7], ref[: n - 7]) and bool((out[n - 7:] == -5.0).all())
     # shared primes (second table without its own pool)
     ref = ops.hash_fwd_f16(tabs[0], prims[0], None, pts, anc, V, log2_T, table2_f16=tabs[1])
-    got = ops.hash_fwd_lm(tabs[0], prims[0], None, pts, anc, V, log2_T, table2_f16=tabs[1], halves_from=halves_from)
+    got = lm(tabs[0], prims[0], None, pts, anc, V, log2_T, table2_f16=tabs[1], halves_from=halves_from)
     assert torch.equal(ref, got)
 
 
