@@ -56,7 +56,7 @@ SIGNATURES = {
     "gfn_field_bwd_scatter_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gfn_grad_record_ranges": (_i32, [_i32]),
-    "gfn_grad_records_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "gfn_grad_records_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "gfn_grad_max": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_grad_scale_host": (_f32, [_f32]),
     "gfn_set_decoder_cus": (_i32, [_i32]),

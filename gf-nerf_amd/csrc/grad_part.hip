@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kSlice = 1 << GFN_GRAD_RANGE_LOG2;  // slots (f16 pairs) per range: 16 Ki x 8 B = 128 KiB of LDS
 constexpr float kFixed = 16777216.f;               // 2^24: the f16 grid
+constexpr int kQ = 2;                              // producer streams a wave reads together
 
 __device__ __forceinline__ uint32_t fixed_to_half2(unsigned long long S) {
   const int lo = (int)(unsigned int)(S & 0xffffffffull);            // the low field, signed
@@ -34,16 +35,19 @@ __device__ __forceinline__ uint32_t fixed_to_half2(unsigned long long S) {
 }
 
 // mode 0: exact fixed-point accumulation wherever it provably fits; 1: always the reference's f16 accumulation
-__global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __restrict__ rec, unsigned int* __restrict__ rec_count,
-                                                              unsigned int rec_cap, int n_ranges, int64_t pool_slots,
-                                                              half2_t* __restrict__ pool, unsigned int* __restrict__ counts_seen, int mode) {
+// A wave reads kQ = 2 of its 16 producer streams at a time (four: 0.115 instead of 0.099 ms per focal step, and 128 registers
+// instead of 64); the register bound (at most 96, so that waves of another kernel -- the table's Adam a chunk of ranges behind, the
+// next batch's sampler -- fit beside a workgroup) costs nothing at that size.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void grad_accumulate_kernel(
+    const uint2* __restrict__ rec, unsigned int* __restrict__ rec_count, unsigned int rec_cap, int range_begin, int n_ranges, int64_t pool_slots,
+    half2_t* __restrict__ pool, unsigned int* __restrict__ counts_seen, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long img64[];  // [kSlice] fixed-point pairs, or [kSlice] half2 in its first half
   half2_t* image = reinterpret_cast<half2_t*>(img64);
   __shared__ unsigned int s_cnt[256];
   __shared__ unsigned int s_any;
   __shared__ unsigned long long s_mag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int b = blockIdx.x; b < n_ranges; b += gridDim.x) {
+  for (int b = range_begin + blockIdx.x; b < n_ranges; b += gridDim.x) {  // n_ranges: end of this launch's ranges
     if (tid == 0) { s_any = 0; s_mag = 0ull; }
     __syncthreads();
     if (tid < 256) {
@@ -76,19 +80,19 @@ __global__ __launch_bounds__(1024) void grad_accumulate_kernel(const uint2* __re
           __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(image + local), v);
         }
       };
-      for (int w0 = wave * 16; w0 < wave * 16 + 16; w0 += 4) {
-        unsigned int n[4];
-        const uint2* src[4];
-        uint4 r[4];
+      for (int w0 = wave * 16; w0 < wave * 16 + 16; w0 += kQ) {
+        unsigned int n[kQ];
+        const uint2* src[kQ];
+        uint4 r[kQ];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kQ; q++) {
           n[q] = s_cnt[w0 + q];
           src[q] = rec + ((size_t)b * 256 + w0 + q) * rec_cap;
           r[q] = make_uint4(0u, 0u, 0u, 0u);
           if (2u * lane < n[q]) r[q] = *reinterpret_cast<const uint4*>(src[q] + 2 * lane);  // rec_cap is even, the buffer 16-byte aligned
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kQ; q++) {
           if (2u * lane < n[q]) {
             add(r[q].x, r[q].y);
             if (2u * lane + 1 < n[q]) add(r[q].z, r[q].w);
@@ -159,7 +163,7 @@ int gfn_grad_record_ranges(int log2_T) {
 }
 
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T, void* grad_pool_f16,
-                            uint32_t* counts_seen, int f16_accumulate, void* stream) {
+                            uint32_t* counts_seen, int f16_accumulate, int range_begin, int range_end, void* stream) {
   GFN_CHECK_ARG(records && record_counts && grad_pool_f16, "gfn_grad_records_reduce: null pointer");
   GFN_CHECK_ARG(log2_T >= 4 && log2_T <= 21, "gfn_grad_records_reduce: log2_T=%d must be in [4,21]", log2_T);
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(records) & 15) == 0, "gfn_grad_records_reduce: records must be 16-byte aligned");
@@ -174,9 +178,12 @@ int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_
   if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grad_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSlice * 8));
   }
-  grad_accumulate_kernel<<<n_ranges, 1024, kSlice * 8, gfn_stream(stream)>>>(reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap,
-                                                                           n_ranges, pool_slots, reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen,
-                                                                           f16_accumulate ? 1 : 0);
+  if (range_end <= 0 || range_end > n_ranges) range_end = n_ranges;  // 0, 0: every range
+  GFN_CHECK_ARG(range_begin >= 0 && range_begin <= range_end, "gfn_grad_records_reduce: ranges [%d, %d)", range_begin, range_end);
+  if (range_begin == range_end) return GFN_OK;
+  grad_accumulate_kernel<<<range_end - range_begin, 1024, kSlice * 8, gfn_stream(stream)>>>(
+      reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap, range_begin, range_end, pool_slots,
+      reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen, f16_accumulate ? 1 : 0);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

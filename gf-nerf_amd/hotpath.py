@@ -63,6 +63,8 @@ class HotPathConfig:
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
+    adam_pipeline_chunks: int = 1    # > 1: the table's Adam runs that many chunks of slot ranges behind their accumulation, on a second
+                                     # stream (measured: no gain -- both are bound by memory, and the sampler on the side stream is as long)
     record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
     prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
@@ -98,6 +100,7 @@ class HotPath:
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
+        self._acc_chunks = None     # [(range_begin, range_end, event)] of the last backward's chunked record accumulation
         self._table_branch = False  # backward forked the table-gradient branch onto _opt_stream; optimizer_step continues and joins it
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
@@ -444,6 +447,54 @@ class HotPath:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._table_branch = False
 
+    def _reduce_records(self, rec, pipelined, state=None):
+        """gfn_grad_records_reduce over every slot range -- in adam_pipeline_chunks launches with an event behind each when the
+        table's optimiser step may follow chunk by chunk (optimizer_step picks the events up)."""
+        c = self.cfg
+        kw = dict(counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
+        n_chunks = c.adam_pipeline_chunks if pipelined else 1
+        self._acc_chunks = None
+        if n_chunks <= 1:
+            self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, **kw)
+            return
+        if state is not None:
+            self._adam_state(*state)  # created (zero-filled on THIS stream) in front of the first chunk's event, not behind the fork
+        n_ranges = ops.grad_record_ranges(c.log2_T)
+        bounds = [n_ranges * i // n_chunks for i in range(n_chunks + 1)]
+        chunks = []
+        for r0, r1 in zip(bounds[:-1], bounds[1:]):
+            self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, ranges=(r0, r1), **kw)
+            ev = torch.cuda.Event()
+            ev.record()
+            chunks.append((r0, r1, ev))
+        self._acc_chunks = chunks
+
+    def _adam_table(self, name, p, m, v, lr, shadow, shadow_pair, hyper):
+        """Adam on the live elements of a table; behind a chunked accumulation: chunk by chunk on the optimiser stream, each
+        as soon as its ranges' gradients are final, joined before returning."""
+        c = self.cfg
+        n_live = 17 * (1 << c.log2_T)
+        t = self._adam_tick(name)
+        chunks, self._acc_chunks = self._acc_chunks, None
+        if not chunks or shadow_pair:
+            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, t, lr=lr, eps=c.adam_eps, shadow_f16=shadow, n=n_live,
+                        shadow_pair=shadow_pair, hyper=hyper)
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.dev)
+        flat = [x.view(-1) for x in (p, self.table_grad, m, v)]
+        sh = shadow.view(-1) if shadow is not None else None
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._opt_stream):  # ordered behind the chunks' events only: not behind whatever else this stream holds
+            for r0, r1, ev in chunks:
+                e0, e1 = r0 << (ops.GRAD_RANGE_LOG2 + 1), min(r1 << (ops.GRAD_RANGE_LOG2 + 1), n_live)
+                if e1 <= e0:
+                    continue
+                self._opt_stream.wait_event(ev)
+                self._timed("adam", ops.adam_step_table, flat[0][e0:e1], flat[1][e0:e1], flat[2][e0:e1], flat[3][e0:e1], t, lr=lr,
+                            eps=c.adam_eps, shadow_f16=sh[e0:e1] if sh is not None else None, hyper=hyper)
+        main.wait_stream(self._opt_stream)
+
     def _grad_live(self):
         """Elements [0, 17T) of the gradient pool: the only ones a backward can write (level-overlap quirk), so the only ones to
         zero, reduce across ranks and hand to Adam."""
@@ -524,6 +575,7 @@ class HotPath:
     def _backward(self, ctx, g_rgb, g_acc):
         c = self.cfg
         self._sync_opt()  # the gradient pool is zeroed behind the asynchronous Adam
+        self._acc_chunks = None
         s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
         train_mlp = ctx["stage"] == STAGE_GLOBAL
         n_dev = s["n_dev"]
@@ -551,7 +603,7 @@ class HotPath:
                         self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
                     self._table_branch = True
                 elif rec is not None:
-                    self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
+                    self._reduce_records(rec, pipelined=self.sync.world == 1, state=("table", self.table))
                 dfeat = None
                 # data parallel: the table gradient is final here -- its exchange runs beside the weight-gradient kernels below
                 self.sync.start_grads([self._grad_live()])
@@ -578,7 +630,8 @@ class HotPath:
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                             self.table_grad, n_dev=n_dev, records=rec)
             if rec is not None:
-                self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
+                blk = ctx["block"]
+                self._reduce_records(rec, pipelined=not (c.async_adam or c.share_block_primes), state=(f"block{blk}", self.blocks[blk]))
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision
@@ -646,8 +699,7 @@ class HotPath:
         n_live = 17 * (1 << c.log2_T)
         if stage == STAGE_GLOBAL:
             m, v = self._adam_state("table", self.table)
-            step_table = lambda: self._timed("adam", ops.adam_step_table, self.table, self.table_grad, m, v, self._adam_tick("table"), lr=c.lr,  # noqa: E731
-                                             eps=c.adam_eps, shadow_f16=self.table16, n=n_live, hyper=hy("table"))
+            step_table = lambda: self._adam_table("table", self.table, m, v, c.lr, self.table16, False, hy("table"))  # noqa: E731
             if self._table_branch:
                 with torch.cuda.stream(self._opt_stream):
                     step_table()
@@ -664,9 +716,8 @@ class HotPath:
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
-            run = lambda: self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(f"block{block}"),  # noqa: E731
-                                      lr=c.lr_block, eps=c.adam_eps, shadow_f16=self.blocks16[block] if c.table_f16_shadow else None,
-                                      n=n_live, shadow_pair=c.share_block_primes, hyper=hy(f"block{block}"))
+            run = lambda: self._adam_table(f"block{block}", p, m, v, c.lr_block, self.blocks16[block] if c.table_f16_shadow else None,  # noqa: E731
+                                           c.share_block_primes, hy(f"block{block}"))
             if c.async_adam and c.level_major and not c.share_block_primes:
                 if self._opt_stream is None:
                     self._opt_stream = torch.cuda.Stream(device=self.dev)

@@ -926,6 +926,14 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
     return grad_pool
 
 
+GRAD_RANGE_LOG2 = 14  # GFN_GRAD_RANGE_LOG2: f16 pairs per slot range of the record streams
+
+
+def grad_record_ranges(log2_T):
+    """Slot ranges of a table's record streams (gfn_grad_record_ranges)."""
+    return int(_lib.lib().gfn_grad_record_ranges(int(log2_T)))
+
+
 def grad_records_buffers(log2_T, capacity, device):
     """(records int64 [capacity], counters int32 [ranges * 256]) for the deferred-atomics backward: one record stream per
     (16 Ki-slot range, producing workgroup)."""
@@ -936,12 +944,13 @@ def grad_records_buffers(log2_T, capacity, device):
     return (torch.empty(int(capacity), dtype=torch.int64, device=device), torch.zeros(n_ranges * 256, dtype=torch.int32, device=device))
 
 
-def grad_records_reduce(records, grad_pool, log2_T, counts_seen=None, f16_accumulate=False):
+def grad_records_reduce(records, grad_pool, log2_T, counts_seen=None, f16_accumulate=False, ranges=None):
     """Accumulate the (slot, value) records of field_bwd_scatter_x3(records=...) into grad_pool, one slot range per workgroup, in
     LDS: exact fixed-point sums rounded to f16 once wherever they provably fit, the reference's f16 accumulation elsewhere (or
     everywhere with f16_accumulate).  Consumes the stream counters (zero again afterwards); counts_seen (int32, same shape)
-    receives a copy."""
+    receives a copy.  ranges: (begin, end) -- only those slot ranges (range r = pool elements [r << 15, (r + 1) << 15))."""
     rec, cnt = records
+    r0, r1 = (0, 0) if ranges is None else ranges
     _chk(rec, torch.int64, "records"); _chk(cnt, torch.int32, "counts"); _chk(grad_pool, torch.float16, "grad_pool")
     _chk(counts_seen, torch.int32, "counts_seen")
     if cnt.numel() != _lib.lib().gfn_grad_record_ranges(int(log2_T)) * 256:
@@ -949,7 +958,7 @@ def grad_records_reduce(records, grad_pool, log2_T, counts_seen=None, f16_accumu
     if counts_seen is not None and counts_seen.numel() != cnt.numel():
         raise _lib.GfnError("grad_records_reduce: counts_seen must have the size of the counters")
     rc = _lib.lib().gfn_grad_records_reduce(_ptr(rec), _ptr(cnt), rec.numel(), int(log2_T), _ptr(grad_pool), _ptr(counts_seen),
-                                            int(bool(f16_accumulate)), _stream())
+                                            int(bool(f16_accumulate)), int(r0), int(r1), _stream())
     _lib.check(rc, "gfn_grad_records_reduce")
 
 

@@ -47,8 +47,9 @@ class StepGraph:
         for b in self.blocks:
             self.groups += [g for g in hp.adam_groups(stage, b) if g not in self.groups]
         self.hyper_dev = f(len(self.groups), 2)
-        self.hyper_host = torch.zeros((len(self.groups), 2), dtype=torch.float32).pin_memory()
         self.hyper = {name: self.hyper_dev[i] for i, (name, _) in enumerate(self.groups)}
+        self._ring = [torch.zeros((len(self.groups), 2), dtype=torch.float32).pin_memory() for _ in range(256)]
+        self._ring_ev, self._ring_pos = [None] * len(self._ring), 0
         self.noise = torch.zeros(1024 + self.R + 10, dtype=torch.float32, device=dev)  # the NEXT batch's march noise
         self.S = [None, None]
         self.s3 = [None, None]  # S3IM permutations of the step that reads S[p], drawn one step ahead like the samples
@@ -139,6 +140,14 @@ class StepGraph:
         hp = self.hp
         step_for_lr = hp.step
         active = {n for n, _ in hp.adam_groups(self.stage, self.blocks[self.p % len(self.blocks)])}
+        # a ring of pinned blocks: the copy below executes when the GPU gets there, steps after the host wrote it -- one buffer
+        # written again by the next call would hand a replay the factors of a LATER step.  A block is written again only once the
+        # copy that read it has run (its event), which also keeps the host at most a ring ahead of the device.
+        k = self._ring_pos
+        self._ring_pos = (k + 1) % len(self._ring)
+        if self._ring_ev[k] is not None:
+            self._ring_ev[k].synchronize()
+        host = self._ring[k]
         for i, (name, lr) in enumerate(self.groups):
             if name not in hp._adam_t:
                 hp._adam_state(name, self._param_of(name))
@@ -146,8 +155,10 @@ class StepGraph:
             if advance and name in active:
                 hp._adam_t[name] = t
             mult = 1.0 if self.lr_schedule is None else float(self.lr_schedule(step_for_lr))
-            self.hyper_host[i] = torch.from_numpy(ops.adam_hyper(t, lr * mult))
-        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+            host[i] = torch.from_numpy(ops.adam_hyper(t, lr * mult))
+        self.hyper_dev.copy_(host, non_blocking=True)
+        self._ring_ev[k] = torch.cuda.Event()
+        self._ring_ev[k].record()
         if advance:
             hp.step += 1
 

@@ -323,13 +323,16 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
  * them with f16_accumulate != 0.  log2_T <= 21.
  * record_counts must be all zero before the FIRST backward in record form; gfn_grad_records_reduce CONSUMES
  * them (leaves them zero for the next backward; counts_seen, when not NULL, receives a copy of what it
- * consumed), so a training loop never fills them. */
+ * consumed), so a training loop never fills them.  range_begin / range_end: only the ranges [begin, end) (0, 0 = all
+ * of them) -- a caller may step the slots of finished ranges (range r = f16 elements [r << 15, (r + 1) << 15) of
+ * the pool) while later ranges still accumulate. */
 #define GFN_GRAD_RANGE_LOG2 14
 #define GFN_MARCH_REC_FLOATS 6 /* per sample slot of gfn_sample_rays' march_rec: t, dist, leaf, warped point */
 #define GFN_GRAD_MAX_RANGES 1088
 int gfn_grad_record_ranges(int log2_T);
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T,
-                            void* grad_pool_f16, uint32_t* counts_seen, int f16_accumulate, void* stream);
+                            void* grad_pool_f16, uint32_t* counts_seen, int f16_accumulate, int range_begin,
+                            int range_end, void* stream);
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);

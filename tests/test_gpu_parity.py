@@ -804,3 +804,15 @@ def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
     # the reference's accumulation everywhere: small sums lose what the running f16 value swallows, but stay close
     assert np.abs(got["f16"][:64] - want[:64]).max() <= 2e-2 * np.abs(want[:64]).max()
     assert np.abs(got["f16"][:64] - exact16[:64]).max() > 0  # (and is indeed not the exact sum)
+    # range by range (ranges=(begin, end)): the same pool, only the named ranges' counters consumed per call
+    upload()
+    pool = torch.zeros((16 * T, 2), dtype=torch.float16, device=dev)
+    ops.grad_records_reduce((rec, cnt), pool, log2_T, ranges=(1, 3))
+    left = cnt.cpu().numpy().reshape(n_ranges, 256)
+    assert np.array_equal(left[0], cnt_np[0]) and not left[1:].any() and float(pool[:16384].abs().max()) == 0.0
+    ops.grad_records_reduce((rec, cnt), pool, log2_T, ranges=(0, 1))
+    ops.grad_records_reduce((rec, cnt), pool, log2_T, ranges=(2, 2))  # empty: nothing to do
+    assert int(cnt.abs().max().item()) == 0
+    assert np.array_equal(pool.float().cpu().numpy()[:pool_slots].astype(np.float64), got["auto"])
+    with pytest.raises(Exception):
+        ops.grad_records_reduce((rec, cnt), pool, log2_T, ranges=(2, 1))

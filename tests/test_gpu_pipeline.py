@@ -801,6 +801,54 @@ def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_wi
     assert odd["field"] is not None
 
 
+def test_pipelined_adam_is_the_same_step(setup):
+    """HotPathConfig.adam_pipeline_chunks = 4: the record accumulation in four launches over slot ranges, the block table's Adam a
+    chunk behind on the optimiser stream -- the same table, moments and f16 shadow, bit for bit, as the one-after-the-other order,
+    eagerly and as hipGraph replays."""
+    import torch
+
+    from gfnerf_amd import hotpath, scene, stepgraph
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    R, K = 256, 5
+    batches = []
+    for k in range(K + 2):
+        o, d, cam = scene.make_rays(sc["c2w"], R, seed=140 + k)
+        gt = np.random.default_rng(190 + k).random((R, 3)).astype(np.float32)
+        batches.append(tuple(t(a) for a in (o, d, cam, gt)))
+    fin = 5.0
+    noise = t(scene.make_noise(R, False, fin))
+
+    def run(chunks, graph):
+        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, adam_pipeline_chunks=chunks)
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
+        hp.table.mul_(100.0); hp.refresh_shadows()
+        o, d, cam, gt = batches[0]
+        hp.train_step(o, d, cam, gt, noise, stage="focal", block=0)
+        if graph:
+            sg = stepgraph.StepGraph(hp, "focal", R, fin, block=0, train_noise=False)
+            sg.prime(batches[1][0], batches[1][1])
+            for k in range(1, K + 1):
+                sg.step(batches[k][2], batches[k][3], batches[k + 1][0], batches[k + 1][1])
+        else:
+            for k in range(1, K + 1):
+                o, d, cam, gt = batches[k]
+                hp.train_step(o, d, cam, gt, noise, stage="focal", block=0)
+        torch.cuda.synchronize()
+        m, v = hp._adam["block0"][:2]
+        return hp.blocks[0].clone(), m.clone(), v.clone(), hp.blocks16[0].clone()
+
+    ref = run(1, False)
+    assert float((ref[0]).abs().max()) > 0 and float(ref[1].abs().max()) > 0  # the block table did train
+    # (1, True): the replays run without a host synchronisation in between, i.e. with the host several steps ahead -- Adam's
+    # step-dependent factors must still be those of the step being replayed (they travel through a pinned block per step)
+    for chunks, graph in ((1, True), (4, False), (4, True), (3, False)):
+        got = run(chunks, graph)
+        for a, b, name in zip(got, ref, ("table", "m", "v", "f16 shadow")):
+            assert torch.equal(a, b), (chunks, graph, name)
+
+
 @pytest.mark.parametrize("stage", ["focal", "global"])
 def test_step_graph_is_the_same_training_run(setup, stage):
     """gfnerf_amd.stepgraph.StepGraph: K training steps as hipGraph replays (sampler of the next batch on a captured side branch,
