@@ -463,6 +463,8 @@ class HotPath:
         bounds = [n_ranges * i // n_chunks for i in range(n_chunks + 1)]
         chunks = []
         for r0, r1 in zip(bounds[:-1], bounds[1:]):
+            if r1 <= r0:  # fewer ranges than chunks ((0, 0) would mean all of them)
+                continue
             self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, ranges=(r0, r1), **kw)
             ev = torch.cuda.Event()
             ev.record()
