@@ -167,7 +167,7 @@ class Deadline:
                 try:
                     self.on_expire()
                 finally:
-                    sys.stdout.flush()
+                    _OUT.flush()
                     os._exit(0)
 
         threading.Thread(target=watch, daemon=True).start()
@@ -513,7 +513,7 @@ class StageRun:
         host = time.perf_counter() - t0
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        print(json.dumps(dict(experiment=mode, stage=self.stage, ms_per_step=el / steps * 1e3, host_enqueue_ms_per_step=host / steps * 1e3, loss=float(loss.item()))))
+        print(json.dumps(dict(experiment=mode, stage=self.stage, ms_per_step=el / steps * 1e3, host_enqueue_ms_per_step=host / steps * 1e3, loss=float(loss.item()))), file=_OUT)
 
     def _graph(self):
         """Capture the step (gfnerf_amd.stepgraph) after the eager warm-up; None when the step cannot be captured."""
@@ -652,9 +652,24 @@ class StageRun:
 
 
 # ------------------------------------------------------------------------------------------------ one rank
+_OUT = sys.stdout  # where the JSON line goes (run_rank points file descriptor 1 itself at stderr)
+
+
+def _own_stdout():
+    """The line on stdout must be the only thing there: libraries write to file descriptor 1 behind Python's back (gloo prints
+    "[Gloo] Rank 0 is connected to ..." at rendezvous), so the descriptor is duplicated for the JSON line and 1 itself is
+    pointed at stderr for everything else."""
+    global _OUT
+    sys.stdout.flush()
+    _OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
+
+    _own_stdout()
 
     import gfnerf_amd  # noqa: F401
     from gfnerf_amd import _lib, cluster, dist as gdist, scene
@@ -764,8 +779,8 @@ def run_rank(args):
 
     def emit():
         if rank == 0 and out is not None:
-            print(json.dumps(out))
-            sys.stdout.flush()
+            print(json.dumps(out), file=_OUT)
+            _OUT.flush()
 
     # ---- configs[4]: render (every rank renders the frames of the block it owns)
     if args.render_frames > 0:
