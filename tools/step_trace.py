@@ -6,7 +6,8 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [r[0] for r in rows if "lm_lookup_kernel<true, false>" in r[2]]
+anchor = sys.argv[3] if len(sys.argv) > 3 else "lm_lookup_kernel<true, false>"
+marks = [r[0] for r in rows if anchor in r[2]]
 lo, hi = marks[-back - 1], marks[-back]
 for s, e, k, q in rows:
     if lo <= s < hi:
