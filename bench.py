@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
     ap.add_argument("--adam-chunks", type=int, default=1, help="the table's Adam runs this many chunks of slot ranges behind their accumulation on a second stream (1: one after the other)")
+    ap.add_argument("--fork-first", action="store_true", help="forward_backward forks the octree update / next sampler before it enqueues the loss kernels (round-2 order)")
     ap.add_argument("--draws-first", action="store_true",
                     help="graph launch: start the next step's random draws at the top of the step (beside the lookups) instead of behind them")
     ap.add_argument("--table-branch", action="store_true",
@@ -409,7 +410,7 @@ class StageRun:
             log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
             prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, table_branch=args.table_branch,
-            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, adam_pipeline_chunks=args.adam_chunks,
+            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, adam_pipeline_chunks=args.adam_chunks, loss_before_fork=not args.fork_first,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
             **({"level_major_global_after": ga} if ga is not None else {}))
         self.n_blocks = n_blocks

@@ -62,6 +62,7 @@ class HotPathConfig:
                                      # live on LDS (ds_read_tr staging / ds_add_u64), each takes twice as long beside the other
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
+    loss_before_fork: bool = True    # forward_backward enqueues the loss kernels before it forks the octree update / next sampler
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
     adam_pipeline_chunks: int = 1    # > 1: the table's Adam runs that many chunks of slot ranges behind their accumulation, on a second
                                      # stream (measured: no gain -- both are bound by memory, and the sampler on the side stream is as long)
@@ -261,7 +262,7 @@ class HotPath:
         s["loss0_buf"] = s["loss0"]  # forward_backward pops "loss0"; the buffer stays for the next in-place refill
         return s
 
-    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None, out=None):
+    def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None, out=None, after=None):
         """Run the sampler of the NEXT batch on a second stream now; the next self.sample(...) with the very same tensors
         collects it.  The ray march is latency-bound and the fused backward beside it fabric-bound, so the two share the
         chip (the backward is capped to cfg.prefetch_cus CUs meanwhile).  Only valid while the octree does not change
@@ -272,7 +273,10 @@ class HotPath:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
-        self._side.wait_stream(main)
+        if after is not None:  # an event of the current stream: what the side branch has to wait for (not everything enqueued since)
+            self._side.wait_event(after)
+        else:
+            self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             if first is not None:
                 first()
@@ -666,13 +670,23 @@ class HotPath:
         the forward, like GFNeRFModel.get_outputs does."""
         c = self.cfg
         comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False, samples=samples)
-        if stage == STAGE_GLOBAL and update_oct:
-            if prefetch is not None:
-                self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx), out=prefetch_out)
-            else:
-                self._timed("oct_update", self.update_oct_nodes, ctx)
-        elif prefetch is not None and stage == STAGE_FOCAL:
-            self.prefetch_sample(*prefetch, out=prefetch_out)
+        fwd_done = None
+        if c.loss_before_fork and prefetch is not None:
+            fwd_done = torch.cuda.Event()
+            fwd_done.record()  # the side branch (octree update, next sampler) starts behind the forward, whatever is enqueued first
+
+        def fork():
+            if stage == STAGE_GLOBAL and update_oct:
+                if prefetch is not None:
+                    self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx), out=prefetch_out,
+                                         after=fwd_done)
+                else:
+                    self._timed("oct_update", self.update_oct_nodes, ctx)
+            elif prefetch is not None and stage == STAGE_FOCAL:
+                self.prefetch_sample(*prefetch, out=prefetch_out, after=fwd_done)
+
+        if not c.loss_before_fork:
+            fork()
         loss, g_rgb = self._timed("loss", ops.charbonnier, comp["rgb"], gt_rgb, loss=ctx["samples"].pop("loss0", None))  # rgb_loss (nerfacto.py:636)
         R = gt_rgb.shape[0]
         if c.s3im_loss_mult > 0 and (R * c.s3im_repeat_time) % c.s3im_patch_height == 0 and R * c.s3im_repeat_time >= 4 * c.s3im_patch_height:
@@ -680,6 +694,8 @@ class HotPath:
                 s3im_index = ops.s3im_index(R, c.s3im_repeat_time, device=self.dev)
             self._timed("loss", ops.s3im, gt_rgb, comp["rgb"], s3im_index, patch_h=c.s3im_patch_height, mult=c.s3im_loss_mult,
                         loss=loss, g_pred=g_rgb)
+        if c.loss_before_fork:
+            fork()
         self.backward(ctx, g_rgb, keep_branch=keep_branch)
         return loss, ctx
 
