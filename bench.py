@@ -95,7 +95,7 @@ def parse():
     ap.add_argument("--prefetch-cus", type=int, default=192, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=0,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
-    ap.add_argument("--render-decoder-cus", type=int, default=252, help="CUs the fused forward may occupy while a sampler runs beside it")
+    ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
     ap.add_argument("--render-patch-width", type=int, default=8,
                     help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
     ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~128 Ki rays that divides the frame)")

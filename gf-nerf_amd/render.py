@@ -46,13 +46,14 @@ class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
-                 pipeline=None, decoder_cus=252):
+                 pipeline=None, decoder_cus=224):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
         tile_rays / tile_width: a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (tile_width 0: a raster run);
         None = chosen per image size by choose_tile (~128 Ki rays, dividing the frame).  pipeline: tiles per graph replay
-        (their samplers run on a second graph branch); None = the largest divisor of the tile count <= 5."""
+        (their samplers run on a second graph branch, through a ring of three sample buffers); None = the largest divisor of the tile
+        count <= 16 (a full-HD frame: its 15 tiles in one replay)."""
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
         self.block, self.early_T, self.fineness = block, early_T, float(fineness)
@@ -79,7 +80,7 @@ class TileRenderer:
                 P = 1
             else:
                 n_tiles = (-(-height // (T // tw)) * -(-width // tw)) if tw else -(-height * width // T)
-                P = max(p for p in range(1, 6) if n_tiles % p == 0)
+                P = max(p for p in range(1, 17) if n_tiles % p == 0)
         else:
             P = max(int(pipeline), 1)
         dev = self.hp.dev
@@ -109,23 +110,39 @@ class TileRenderer:
         prev = _lib.lib().gfn_set_decoder_cus(self.decoder_cus)  # the grid is baked into the captured launches
         try:
             side.wait_stream(main)
-            done, samples = [], []
-            with torch.cuda.stream(side):  # producer branch: P samplers back to back (they share one workspace)
-                for i in range(self.P):
-                    samples.append(hp.sample(self.o[i], self.d[i], self.noise))
+            # producer branch: the P samplers back to back (they share one workspace), into a ring of SLOTS sample buffers -- tile i
+            # is sampled into the buffer of tile i - SLOTS once that tile's fused forward has read it, so a whole frame can be one
+            # replay without one 5 GB sample buffer per tile; consumer branch: the fused forward of tile i beside the samplers
+            # of the tiles after it
+            done, used, samples, outs = [], [], [], []
+            for i in range(self.P):
+                with torch.cuda.stream(side):
+                    if i >= self.SLOTS:
+                        side.wait_event(used[i - self.SLOTS])
+                    samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None))
                     ev = torch.cuda.Event()
                     ev.record(side)
                     done.append(ev)
-            outs = []
-            for i in range(self.P):  # consumer branch: the fused forward of tile i beside the samplers of the tiles after it
-                main.wait_event(done[i])
-                out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw)
-                outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
+                if i >= self.SLOTS - 1:  # (the consumer trails the producer by SLOTS - 1 tiles in enqueue order: a wait needs its event recorded)
+                    self._consume(i - (self.SLOTS - 1), main, done, used, samples, outs)
+            for i in range(max(self.P - (self.SLOTS - 1), 0), self.P):
+                self._consume(i, main, done, used, samples, outs)
             main.wait_stream(side)
             self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
         finally:
             _lib.lib().gfn_set_decoder_cus(prev)
         return outs
+
+    SLOTS = 3  # sample buffers of the tile pipeline
+
+    def _consume(self, i, main, done, used, samples, outs):
+        hp = self.hp
+        main.wait_event(done[i])
+        out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw)
+        outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
+        ev = torch.cuda.Event()
+        ev.record(main)
+        used.append(ev)
 
     def _capture(self):
         """Warm up on a side stream (workspaces, kernel attributes, weight images), then capture one tile."""

@@ -215,7 +215,7 @@ def test_train_steps_reduce_loss(setup):
     assert int((hp.visit_cnt > 0).sum().item()) > 10
 
 
-@pytest.mark.parametrize("use_graph,pipeline", [(True, 1), (False, 1), (True, 3)])
+@pytest.mark.parametrize("use_graph,pipeline", [(True, 1), (False, 1), (True, 3), (True, 4)])  # 4: the fourth tile re-uses the first one's sample buffer
 def test_tile_renderer_matches_direct_render_and_oracle(setup, use_graph, pipeline):
     """render.py path: gfn_generate_rays + hipGraph-replayed tiles == the same rays pushed through HotPath.render in one
     go == the oracle pipeline (ragged last tile included)."""
