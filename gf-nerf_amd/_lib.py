@@ -34,7 +34,7 @@ SIGNATURES = {
                          _vp, _vp, _i64, _vp, _vp]),
     "gfn_tree_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_sample_rays": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_update_nodes_mark": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

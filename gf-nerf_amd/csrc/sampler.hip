@@ -377,14 +377,17 @@ __global__ void compact_nodes_kernel(NodeView nodes, int64_t n_nodes, CompactNod
 // max_hits cut -- is exactly that of the reference's one-child-at-a-time loop (:89-140).
 constexpr int kTG = 8;                      // lanes per ray
 constexpr int kTraceRays = 256 / kTG;       // 32 rays per workgroup
-constexpr int kTraceStack = 7 * kMaxDepth + 2;  // every expansion nets at most +7 entries per level
 
+// stack: entries per ray, 7 * (depth of the tree) + 2 -- the 24 levels the reference allows make 65 KB of stacks per
+// workgroup, i.e. two workgroups per CU; a tree 12 levels deep needs half of that and runs twice as many rays per CU, which is what
+// bounds the traversal when it has to make do with the few CUs a persistent kernel beside it leaves (render: 1.8 ms per tile)
 __global__ __launch_bounds__(256) void trace_group_kernel(
     int n_rays, const CompactNode* __restrict__ nodes, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, float near_bound, float far_bound, int max_hits,
-    int* __restrict__ counts, int* __restrict__ hit_idx, float2* __restrict__ hit_nf, int* __restrict__ overflow) {
-  __shared__ int s_id[kTraceRays][kTraceStack];       // >= 0: internal node to expand; < 0: ~leaf id to emit
-  __shared__ float2 s_nf[kTraceRays][kTraceStack];
+    int* __restrict__ counts, int* __restrict__ hit_idx, float2* __restrict__ hit_nf, int* __restrict__ overflow, int stack) {
+  extern __shared__ __attribute__((aligned(16))) int s_trace[];
+  int* s_id = s_trace + (threadIdx.x / kTG) * stack;                                         // >= 0: internal node to expand; < 0: ~leaf id to emit
+  float2* s_nf = reinterpret_cast<float2*>(s_trace + kTraceRays * stack) + (threadIdx.x / kTG) * stack;  // (kTraceRays * stack * 4 bytes: a multiple of 8)
   const int k = threadIdx.x & (kTG - 1);
   const int slot = threadIdx.x / kTG;
   const int ray = blockIdx.x * kTraceRays + slot;
@@ -405,10 +408,10 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
     if (nr < fr) {
       const bool leaf = w1.x < 0 && w1.y < 0 && w1.z < 0 && w1.w < 0 && w2.x < 0 && w2.y < 0 && w2.z < 0 && w2.w < 0;
       if (!leaf) {
-        if (k == 0) { s_id[slot][0] = 0; s_nf[slot][0] = make_float2(nr, fr); }
+        if (k == 0) { s_id[0] = 0; s_nf[0] = make_float2(nr, fr); }
         sp = 1;
       } else if (w3.x >= 0) {
-        if (k == 0) { s_id[slot][0] = ~0; s_nf[slot][0] = make_float2(nr, fr); }
+        if (k == 0) { s_id[0] = ~0; s_nf[0] = make_float2(nr, fr); }
         sp = 1;
       }
     }
@@ -419,8 +422,8 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
     int ck = -1;
     float cn = 0.f, cf = 0.f;
     if (active) {
-      const int e = s_id[slot][sp - 1];
-      const float2 enf = s_nf[slot][sp - 1];
+      const int e = s_id[sp - 1];
+      const float2 enf = s_nf[sp - 1];
       sp--;
       if (e < 0) {  // leaf with a valid transform: emit (:110-117)
         if (k == 0) {
@@ -443,11 +446,11 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
     const unsigned mask = (unsigned)((__ballot(keep) >> gshift) & 0xFFull);  // wave-uniform call
     if (active && mask) {
       const int n_push = __popc(mask);
-      if (sp + n_push <= kTraceStack) {
+      if (sp + n_push <= stack) {
         if (keep) {
           const int pos = sp + __popc(mask >> (k + 1));  // reverse order: first child ends on top
-          s_id[slot][pos] = leaf_child ? ~ck : ck;
-          s_nf[slot][pos] = make_float2(cn, cf);
+          s_id[pos] = leaf_child ? ~ck : ck;
+          s_nf[pos] = make_float2(cn, cf);
         }
         sp += n_push;
       } else if (overflow && k == 0) {
@@ -938,8 +941,9 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, float* march_rec, void* stream) {
+                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream) {
   GFN_CHECK_ARG(pts_offsets, "gfn_sample_rays: null pts_offsets");
+  GFN_CHECK_ARG(tree_depth <= kMaxDepth, "gfn_sample_rays: tree_depth=%d (at most %d levels)", tree_depth, kMaxDepth);
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
     GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
@@ -954,9 +958,10 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
   GFN_CHECK_ARG(pts_cap >= n_rays && pts_cap * 3 < (1ll << 31), "gfn_sample_rays: pts_cap=%lld must be in [n_rays, 2^31/3)",
                 (long long)pts_cap);
   const CompactNode* cn = reinterpret_cast<const CompactNode*>(compact_nodes);
-  trace_group_kernel<<<(unsigned)((n_rays + kTraceRays - 1) / kTraceRays), 256, 0, st>>>(
+  const int stack = 7 * (tree_depth > 0 ? tree_depth : kMaxDepth) + 2;  // every expansion nets at most +7 entries per level
+  trace_group_kernel<<<(unsigned)((n_rays + kTraceRays - 1) / kTraceRays), 256, (size_t)kTraceRays * stack * 12, st>>>(
       (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
-      reinterpret_cast<float2*>(hit_near_far), overflow_dev);
+      reinterpret_cast<float2*>(hit_near_far), overflow_dev, stack);
   GFN_CHECK_LAUNCH();
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   int* counts = anchors;  // scratch until the fill pass

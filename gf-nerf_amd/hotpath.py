@@ -96,6 +96,7 @@ class HotPath:
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
+        self._depth_key, self._depth_val = None, 0
         self._records = None
         self._opt_stream, self._opt_pending = None, False
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
@@ -229,6 +230,16 @@ class HotPath:
                     prim=c(self.prim), bias=c(self.bias), layers=[(c(W), c(B)) for W, B in self.layers], emb=c(self.emb))
 
     # ------------------------------------------------------------------ sampling
+    def tree_depth(self):
+        """Depth of the deepest node of the current blob (the traversal sizes its stacks by it); recomputed when the blob is
+        replaced (ProcOctree, a loaded checkpoint) -- in-place updates (K6 / K7 invalidations) do not change it.  Synchronises
+        when it recomputes: never under capture (StepGraph.capture and TileRenderer call it first)."""
+        key = (self.nodes.data_ptr(), self.nodes.numel())
+        if key != self._depth_key:
+            self._depth_val = ops.tree_depth(self.nodes.view(-1, ops.TREE_NODE_BYTES))
+            self._depth_key = key
+        return self._depth_val
+
     def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
         returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph)."""
@@ -248,7 +259,7 @@ class HotPath:
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
                         c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
                         pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world, want_dirs=need_world,
-                        table_space=True, workspace=self._sampler_ws, out=out)
+                        table_space=True, workspace=self._sampler_ws, out=out, tree_depth=self.tree_depth())
         self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]

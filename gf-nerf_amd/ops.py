@@ -266,10 +266,11 @@ def tree_compact(nodes, out=None):
 
 
 def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8,
-                max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None, out=None):
+                max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None, out=None,
+                tree_depth=0):
     """Fast GetSamples: single-pass dense trace + 16-lane-per-ray march.  Same dict as march().  out: a dict an earlier call
     returned (same R / pts_cap / options): its tensors are written again instead of allocating new ones (static buffers of a
-    captured step)."""
+    captured step).  tree_depth: depth of the deepest node (see tree_depth()) or 0 for the reference's bound of 24."""
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
     _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
     R = rays_o.shape[0]
@@ -302,9 +303,24 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
                                     _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]), _ptr(workspace["hit_nf"]),
                                     _ptr(out["pts_offsets"]), _ptr(out["world_pts"]), _ptr(out["warped_pts"]), _ptr(out["dirs"]),
                                     _ptr(out["dists"]), _ptr(out["ts"]), _ptr(out["anchors"]), _ptr(out["ray_id"]),
-                                    _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _ptr(workspace.get("march_rec")), _stream())
+                                    _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _ptr(workspace.get("march_rec")), int(tree_depth),
+                                    _stream())
     _lib.check(rc, "gfn_sample_rays")
     return out
+
+
+def tree_depth(nodes):
+    """Depth of the deepest node of a node blob (uint8 [n,128] device tensor; root = 0): parent links walked level by level (a tree
+    changes a few times per training run; this synchronises)."""
+    n = nodes.shape[0]
+    parent = nodes.view(-1).view(torch.int64).view(n, 16)[:, 2].contiguous()  # gfn_tree_node.parent (byte 16)
+    cur, depth = parent.clone(), 0
+    for depth in range(0, 64):
+        alive = cur >= 0
+        if not bool(alive.any()):
+            break
+        cur = torch.where(alive, parent[cur.clamp(min=0)], cur)
+    return depth
 
 
 def samples_to_dense(s, n_rays):

@@ -117,6 +117,7 @@ class StepGraph:
             raise _lib.GfnError("StepGraph: run one eager HotPath.train_step of this stage before capturing (lazily created buffers)")
         for name, _ in self.groups:
             hp._adam_state(name, self._param_of(name))
+        hp.tree_depth()  # (synchronises when the tree is new: not under capture)
         self._refresh_hyper(advance=False)
         torch.cuda.synchronize()
         steps_before, ticks_before = hp.step, dict(hp._adam_t)

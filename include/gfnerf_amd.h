@@ -175,7 +175,9 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
  * whenever the node blob changes (gfn_update_nodes).  Workspace: hit_counts i32 [R],
  * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2], and march_rec f32 [R*1024*GFN_MARCH_REC_FLOATS] (may be
  * NULL): with it the counting march records (t, dist, leaf) per sample and the outputs are rebuilt one
- * thread per sample instead of marching every ray a second time -- same bits, ~1/3 less time. */
+ * thread per sample instead of marching every ray a second time -- same bits, ~1/3 less time.  tree_depth: depth of
+ * the deepest node (root = 0) or an upper bound of it, 0 = the reference's 24: the traversal's per-ray stack in LDS holds
+ * 7 * tree_depth + 2 entries, and a shallower tree lets a CU traverse more rays at once. */
 int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void* stream);
 int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                     const void* compact_nodes, const void* transes, float near_bound, float far_bound,
@@ -183,7 +185,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, float* march_rec, void* stream);
+                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream);
 
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,

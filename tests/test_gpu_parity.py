@@ -304,6 +304,45 @@ def test_fast_sampler_bit_exact(oracle, ops, dev, train, fineness, n_rays):
         assert int(g["overflow"].item()) == 0
 
 
+def test_traversal_stack_sized_by_tree_depth(oracle, ops, dev):
+    """gfn_sample_rays with tree_depth = the blob's real depth (ops.tree_depth: parent links) gives the bits of the default
+    (the reference's 24-level bound): 7 entries per level + 2 is what a depth-first traversal can stack.  A bound below the real
+    depth is reported through the overflow flag, not by a fault."""
+    import torch
+
+    from gfnerf_amd import scene
+
+    sc = small_scene()
+    nodes_np = sc["nodes"].view(oracle.TREE_NODE_DTYPE)
+    depth_np = 0
+    for u in range(nodes_np.shape[0]):  # by hand: walk every node up to the root
+        k, v = 0, int(nodes_np["parent"][u])
+        while v >= 0:
+            k, v = k + 1, int(nodes_np["parent"][v])
+        depth_np = max(depth_np, k)
+    nodes = _t(sc["nodes"], dev)
+    depth = ops.tree_depth(nodes.view(-1, ops.TREE_NODE_BYTES))
+    assert depth == depth_np and 2 <= depth <= 24
+    n_rays = 700
+    o, d, _ = scene.make_rays(sc["c2w"], n_rays, seed=3)
+    d = oracle.normalize_dirs(d)
+    noise = _t(scene.make_noise(n_rays, True, 6.0, seed=2), dev)
+    cn = ops.tree_compact(nodes)
+    args = (_t(o, dev), _t(d, dev), noise, cn, _t(sc["transes"], dev), 1.0 / 256, True)
+    ref = ops.sample_rays(*args)
+    got = ops.sample_rays(*args, tree_depth=depth)
+    assert int(ref["overflow"].item()) == 0 and int(got["overflow"].item()) == 0
+    N = int(ref["pts_offsets"][-1].item())
+    assert N > n_rays and torch.equal(ref["pts_offsets"], got["pts_offsets"])
+    for k in ("ts", "dists", "warped_pts", "anchors", "ray_id"):
+        assert torch.equal(ref[k][:N], got[k][:N]), k
+    assert torch.equal(ref["workspace"]["hit_counts"][:n_rays], got["workspace"]["hit_counts"][:n_rays])
+    low = ops.sample_rays(*args, tree_depth=1)
+    assert int(low["overflow"].item()) & 2  # stacks of 9 entries cannot hold this tree's traversal: said so
+    with pytest.raises(Exception):
+        ops.sample_rays(*args, tree_depth=25)
+
+
 def test_fast_sampler_missing_and_empty(oracle, ops, dev):
     import torch
 
