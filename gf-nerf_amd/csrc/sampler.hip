@@ -469,6 +469,11 @@ template <int N>
 __device__ __forceinline__ float row_down(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
 }
+// lane i of a 16-lane row reads lane i-N of the same row (0 below the row): DPP row_shr
+template <int N>
+__device__ __forceinline__ float row_up(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row_sum12(float q) {
   const float a = q + row_down<1>(q);   // lanes 3k+1: q[3k+1] + q[3k+2]
   const float b = q + row_down<1>(a);   // lanes 3k  : q[3k] + (q[3k+1] + q[3k+2])
@@ -512,6 +517,8 @@ __global__ __launch_bounds__(256) void march_group_kernel(
   }
   bool active = in_range && max_n > 0 && n_oct > 0;
   int pts_ptr = 0, oct_ptr = 0;
+  int nz_base = -1;
+  float nz = 0.f;
   int cur_oct_idx = active ? hit_idx[0] : 0;
   float2 nf = active ? hit_nf[0] : make_float2(0.f, 0.f);
   float cur_t = nf.x, cur_far = nf.y, cur_near = nf.x;
@@ -561,8 +568,15 @@ __global__ __launch_bounds__(256) void march_group_kernel(
       const float v = lv ? x0 / x1 : 0.f;
       wp[0] = row_sum12(w0 * v); wp[1] = row_sum12(w1 * v); wp[2] = row_sum12(w2 * v);
     }
+    // (count pass) the warped point moved from lane 0 to the lanes that store it
+    const float wp3 = row_up<3>(wp[0]), wp4 = row_up<4>(wp[1]), wp5 = row_up<5>(wp[2]);
     if (active) {
-      const float warp_step = sample_l * noise[pts_ptr];
+      // the step's noise: sixteen values per load, one in each lane of the row, handed out through the LDS crossbar -- a global load
+      // per step made every step wait for the memory system (and, loads and stores sharing one counter here, for the stores of
+      // the steps before it)
+      const int nb = pts_ptr & ~(kGroup - 1);
+      if (nb != nz_base) { nz = noise[nb + g]; nz_base = nb; }
+      const float warp_step = sample_l * __shfl(nz, pts_ptr & (kGroup - 1), kGroup);
       exp_march_step = warp_step / (pnorm + 1e-6f);
       if (scale_by_dis) exp_march_step *= radius_clip;
       cur_march_step = exp_march_step;
@@ -582,13 +596,16 @@ __global__ __launch_bounds__(256) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
-      if (!FILL && rec && !first && g == 0) {  // what the sample-parallel fill needs to rebuild this sample
-        float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * GFN_MARCH_REC_FLOATS;
-        rp[0] = cur_t;
-        rp[1] = exp_march_step * (pnorm + 1e-6f);
-        rp[2] = __int_as_float(cur_oct_idx);
-        rp[3] = wp[0]; rp[4] = wp[1]; rp[5] = wp[2];  // the projections are in this row's lanes anyway: 3 more DPP trees here save
-                                                     // the fill pass 12 projections, 12 divisions and the whole TransInfo per sample
+      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE store of the row's lanes 0 .. 5
+        // (six stores from lane 0 were six memory instructions per step, and on this architecture a wave's next load waits for
+        // every store before it: beside a kernel that keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
+        float v = cur_t;
+        v = g == 1 ? exp_march_step * (pnorm + 1e-6f) : v;
+        v = g == 2 ? __int_as_float(cur_oct_idx) : v;
+        v = g == 3 ? wp3 : v;  // the projections are in this row's lanes anyway: 3 more DPP trees here save the fill pass
+        v = g == 4 ? wp4 : v;  // 12 projections, 12 divisions and the whole TransInfo per sample
+        v = g == 5 ? wp5 : v;
+        if (g < GFN_MARCH_REC_FLOATS) rec[((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * GFN_MARCH_REC_FLOATS + g] = v;
       }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
