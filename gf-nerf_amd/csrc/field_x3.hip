@@ -186,11 +186,11 @@ __device__ __forceinline__ float half_run_sum32(float v, int j, int run_end) {
 template <bool GRAD_F16, bool RECORD = false, bool MERGE = true>
 __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float* __restrict__ s_scale, int level, float px, float py, float pz,
                                               int64_t vol, float gx, float gy, bool valid, int h, int j, uint32_t T,
-                                              unsigned int* s_cursor = nullptr) {
+                                              const int (&prim)[3], unsigned int* s_cursor = nullptr) {
   const int64_t tr = (int64_t)level * S.n_volumes + vol;
   Corners c;
   uint32_t cell[3];
-  hash_corners(px, py, pz, s_scale[level], S.prim_pool + 3 * tr, S.bias_pool ? S.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
+  hash_corners(px, py, pz, s_scale[level], prim, S.bias_pool ? S.bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
   float g0 = gfn_round_f16(gx * 128.f);  // :219 grad_in = (grad * 128).half()
   float g1 = gfn_round_f16(gy * 128.f);
   const bool live = valid && (g0 != 0.f || g1 != 0.f);  // :149
@@ -429,13 +429,27 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       const uint32_t T = 1u << S.log2_T;
       const float px = S.pts[3 * q], py = S.pts[3 * q + 1], pz = S.pts[3 * q + 2];
       const int64_t vol = (int64_t)S.anchors[3 * q];
+      // a level's primes are loaded BEFORE the level before it stores its records: the stores may alias anything as far as the
+      // compiler knows, so a load written behind them stays behind them -- and on this architecture then waits for their
+      // acknowledgement (one counter for loads and stores): 0.34 -> 0.31 ms for the focal backward
+      int pr[3], nx[3];
+      {
+        const int* p0 = S.prim_pool + 3 * ((int64_t)(2 * h) * S.n_volumes + vol);
+        pr[0] = p0[0]; pr[1] = p0[1]; pr[2] = p0[2];
+      }
 #pragma unroll
       for (int a = 0; a < 8; a++) {
         const int level = 2 * h + (a & 1) + 4 * (a >> 1);
+        if (a < 7) {
+          const int next = 2 * h + ((a + 1) & 1) + 4 * ((a + 1) >> 1);
+          const int* pn = S.prim_pool + 3 * ((int64_t)next * S.n_volumes + vol);
+          nx[0] = pn[0]; nx[1] = pn[1]; nx[2] = pn[2];
+        }
         const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
-        if (SCATTER == 3) scatter_level<true, true, PLANES>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, s_rec_cursor);
-        else if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
-        else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T);
+        if (SCATTER == 3) scatter_level<true, true, PLANES>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr, s_rec_cursor);
+        else if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
+        else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
+        pr[0] = nx[0]; pr[1] = nx[1]; pr[2] = nx[2];
       }
     } else if (valid) {
 #pragma unroll
