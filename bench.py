@@ -396,6 +396,95 @@ def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
                 includes="index draw, pixel gather, ray generation, error-map write-back + CDF upkeep", duplicates_left=int(sampler.last_status[1].item()))
 
 
+def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True):
+    """The training iteration THROUGH the plugin surface, the way the reference's Trainer drives it (engine/trainer.py:195-231,
+    382-441): callbacks before -> optimizers.zero_grad_all -> pipeline.get_train_loss_dict(step) (incl. datamanager.next_train)
+    -> sum(loss_dict) -> backward -> the NaN check over model.named_parameters() -> optimizers.optimizer_step_all ->
+    scheduler_step_all -> callbacks after; rays/s = rays per batch / iteration wall time (trainer.py:225-231).
+    The pipeline, model, field, sampler, optimizers, scheduler and callbacks are the mirror classes of gfnerf_amd.gfnerf with
+    the `gf-nerf` method config's values (gfnerf/config.py) on the bench scene; the datamanager is the HBM-resident synthetic
+    one (image loading is out of scope).  stage "global": steps 100.., 4096 x 128; "focal": steps 30100.., 4096 x 192, block 0."""
+    from gfnerf_amd.gfnerf._host import AdamOptimizerConfig, Optimizers, TrainingCallbackAttributes, TrainingCallbackLocation
+    from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipelineConfig, HbmDataManagerConfig
+    from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
+    from gfnerf_amd.gfnerf.optim import GfnAdamOptimizerConfig
+    from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
+
+    S_INIT, S_SPLIT, N_SPLIT = 30000, 10000, 4
+    mk = dict(log2_hashmap_size=21, hidden_dim=128, hidden_dim_color=128, steps_perssampler_init=S_INIT, steps_per_split_dataset=S_SPLIT,
+              n_split_dataset=N_SPLIT, n_blocks=N_SPLIT, scale_factor=10.0, use_appearance_embedding=True, use_ch_loss=True, s3im_loss_mult=1.0,
+              eval_num_rays_per_chunk=2048)
+    # the cached image stack of the datamanager (train_num_images_to_sample_from images resident at a time, gfnerf/config.py:77): 64
+    # synthetic 1152 x 864 u8 images of cameras spread over the whole capture, in HBM; pixels are drawn, gathered and turned into
+    # rays on the device (gfnerf_amd.data)
+    n_img = 64
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    images = torch.randint(0, 256, (n_img, 864, 1152, 3), dtype=torch.uint8, device="cuda", generator=gen)
+    image_idx = (np.arange(n_img) * (sc["c2w"].shape[0] // n_img)).astype(np.int32)
+    pcfg = GFNerfPipelineConfig(datamanager=HbmDataManagerConfig(c2w=sc["c2w"], intrinsics=sc["intri"], images=images, image_idx=image_idx,
+                                                                 train_num_rays_per_batch=n_rays),
+                                model=GFNeRFModelConfig(**mk), prefetch_next_batch=prefetch)
+    pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfn_plugin_bench"))
+    model = pipe.model
+    sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=S_INIT, n_split_dataset=N_SPLIT, n_dataset_circles=1,
+                                                  steps_per_split_dataset=S_SPLIT, steps_perssampler_init=S_INIT)
+    ocfg = (GfnAdamOptimizerConfig if fused_optimizer else AdamOptimizerConfig)(lr=1e-2, eps=1e-15)
+    optimizers = Optimizers({"fields": {"optimizer": ocfg, "scheduler": sched}}, pipe.get_param_groups())
+    callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
+    pipe.train()
+    nat = model.persampler.sampler
+    first = 100 if stage == "global" else S_INIT + 100
+    target = TARGET_SAMPLES[stage]
+    # the ray-march fineness that gives the stage's sample budget on this scene, held for the run (UpdateRayMarch follows the step:
+    # 16 -> 1 over the first 10,000 steps, PersSampler.cpp:958-967); tree maintenance (ProcOctree every 1000 steps) outside the window
+    rb = pipe.datamanager.next_train(first)[0]
+    lo, hi = 0.5, 64.0
+    for _ in range(14):
+        f = (lo * hi) ** 0.5
+        nat.ray_march_fineness_ = f
+        mean = nat.sample_packed(rb.origins, rb.directions, table_space=True, want_world=False)["pts_offsets"][-1].item() / n_rays
+        if abs(mean - target) / target < 0.005:
+            break
+        lo, hi = (f, hi) if mean > target else (lo, f)
+    nat.UpdateRayMarch = lambda cur_step, _f=f: setattr(nat, "ray_march_fineness_", _f)
+    nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []
+
+    def train_iteration(step):
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        optimizers.zero_grad_all()
+        _, loss_dict, metrics_dict = pipe.get_train_loss_dict(step=step)
+        loss = sum(loss_dict.values())
+        loss.backward()
+        is_nan = False
+        if nan_check:  # trainer.py:415-423 (one host synchronisation per parameter that carries a .grad)
+            for tag, value in model.named_parameters():
+                if value.grad is not None and torch.isnan(value.grad).any():
+                    is_nan = True
+        if not is_nan:
+            optimizers.optimizer_step_all()
+            optimizers.scheduler_step_all(step)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        return loss
+
+    step = first
+    for _ in range(warmup):
+        train_iteration(step); step += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_iteration(step); step += 1
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(metric="train_rays_per_sec", value=n_rays / dt, unit="rays/s", ms_per_step=dt * 1e3, host_ms_per_step=host / steps * 1e3, steps=steps,
+                warmup=warmup, stage=stage, mean_samples_per_ray=mean, loss=float(loss.detach()),
+                optimizer="GfnAdam (HIP Adam kernels on the engine's gradient buffers)" if fused_optimizer else "torch.optim.Adam on dense f32 gradients",
+                prefetch_next_batch=prefetch, nan_check=nan_check,
+                surface="GFNerfPipeline.get_train_loss_dict -> backward -> Optimizers.optimizer_step_all -> scheduler_step_all (trainer.py:382-441)")
+
+
 # ------------------------------------------------------------------------------------------------ one timed training run
 class StageRun:
     """K timed training steps of one stage on this rank (the same code for the headline and the `global_stage` sub-record)."""

@@ -9,6 +9,7 @@ and the datamanager / scheduler / viewer configs are the tree's too; on a machin
 stand-ins and the datamanager is the HBM-resident one of gf_pipeline.py.  Either way the VALUES are the reference's."""
 from . import _host
 from ._host import AdamOptimizerConfig, MethodSpecification, TrainerConfig
+from .optim import GfnAdamOptimizerConfig
 from .gf_pipeline import GFNerfPipelineConfig, HbmDataManagerConfig
 from .nerfacto import GFNeRFModelConfig
 
@@ -85,7 +86,8 @@ gfnerf_config = MethodSpecification(
         max_num_iterations=STEPS_PERSSAMPLER_INIT + N_DATASET_CIRCLES * STEPS_PER_SPLIT_DATASET * N_SPLIT_DATASET,
         mixed_precision=False,
         pipeline=GFNerfPipelineConfig(datamanager=_datamanager_config(), model=_model_config()),
-        optimizers={"fields": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": _scheduler_config()}},
+        # torch.optim.Adam's update on the HIP Adam kernels, reading the gradients where the HIP backward leaves them (optim.py)
+        optimizers={"fields": {"optimizer": GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": _scheduler_config()}},
         **({"viewer": _viewer_config()} if _viewer_config() is not None else {}),
         vis="viewer",
     ),

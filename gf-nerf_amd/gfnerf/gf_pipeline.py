@@ -53,6 +53,8 @@ class _DataManagerBase:
         self.train_dataparser_outputs = SimpleNamespace(cameras=_Cameras(c2w_t, K))
         self.train_dataset = _TrainDataset(c2w_t.shape[0], scene_box=SimpleNamespace(aabb=torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])))
         self.eval_dataset = self.train_dataset
+        self.split_version = 0     # bumped whenever setup_train_split_oct changes what next_train draws from
+        self._split_idx = None
 
     def to(self, device):
         self.device = torch.device(device)
@@ -74,8 +76,13 @@ class SyntheticDataManager(_DataManagerBase):
         self.cams = None  # setup_train_split_oct: the active block's camera cluster
 
     def setup_train_split_oct(self, cameras_labels, split_idx, sample_tmp_dir=None):
-        """base_datamanager.py setup_train_split_oct: from now on rays are drawn from the cameras of cluster `split_idx` only."""
+        """base_datamanager.py setup_train_split_oct: from now on rays are drawn from the cameras of cluster `split_idx` only.
+        (The update_datamanager callback calls this after EVERY iteration, nerfacto.py:491-519: unchanged split, nothing to do.)"""
+        if self._split_idx == int(split_idx):
+            return
         self.cams = np.nonzero(cameras_labels.reshape(-1).cpu().numpy() == int(split_idx))[0]
+        self._split_idx = int(split_idx)
+        self.split_version += 1
 
     def next_train(self, step):
         o, d, cam = scene.make_rays(self.c2w, self.R, seed=self.seed + step, cams=self.cams)
@@ -83,6 +90,7 @@ class SyntheticDataManager(_DataManagerBase):
         t = lambda a: torch.from_numpy(a).to(self.device)  # noqa: E731
         steps = torch.full((self.R, 1), step, dtype=torch.int64, device=self.device)
         bundle = RayBundle(origins=t(o), directions=t(d), camera_indices=t(cam)[:, None], rel_camera_indices=t(cam)[:, None], steps=steps)
+        bundle._step_host = (steps, int(step))  # the step as a host integer too (GFNeRFModel._bundle: no read-back of `steps`)
         return bundle, {"image": t(gt)}, None
 
     def next_eval(self, step):
@@ -124,15 +132,21 @@ class ImageStackDataManager(_DataManagerBase):
     def setup_train_split_oct(self, cameras_labels, split_idx, sample_tmp_dir=None):
         """GFNerfDataManager.setup_train_split_oct: the cached batch becomes the images of camera cluster `split_idx` (their error
         maps with them) -- every focal block trains on its own cameras (perssampler.py:216-242)."""
+        if self._split_idx == int(split_idx):  # called after every iteration (nerfacto.py:491-519): unchanged split, nothing to do
+            return
         labels = cameras_labels.reshape(-1).to(self._all["image_idx"].device)
         keep = torch.nonzero(labels[self._all["image_idx"].long()] == int(split_idx)).reshape(-1)
         assert keep.numel() > 0, f"camera cluster {split_idx} holds no image of the stack"
         self._select(keep)
+        self._split_idx = int(split_idx)
+        self.split_version += 1
 
     def set_error_maps(self, maps):
         """render_init_error_maps (nerfacto.py:354-430) hands over one |gt - pred| map per training image."""
         self._all["error_maps"] = maps[..., None] if maps.dim() == 3 else maps
         self._select(None)
+        self._split_idx = None
+        self.split_version += 1
 
     def train_images_for_error_maps(self, down_scale_factor=8, step=None):
         """(gt image [H,W,3] in [0,1], RayBundle of every `down_scale_factor`-th pixel [h,w,.]) per training image (:383-391)."""
@@ -159,6 +173,7 @@ class ImageStackDataManager(_DataManagerBase):
         bundle = RayBundle(origins=rays["origins"], directions=rays["directions"], camera_indices=rays["camera_indices"][:, None],
                            rel_camera_indices=rays["rel_camera_indices"][:, None], steps=steps, pixel_area=rays["pixel_area"][:, None],
                            lookat_directions=rays["lookat"])
+        bundle._step_host = (steps, int(step))
         return bundle, batch, ray_indices
 
     def next_eval(self, step):
@@ -192,6 +207,7 @@ class HbmDataManagerConfig(InstantiateConfig):
     c2w: Any = None
     intrinsics: Any = None
     images: Any = None
+    image_idx: Any = None       # camera index of every image of the stack (default: image k is camera k)
     error_maps: Any = None
     train_num_rays_per_batch: int = 4096
     seed: int = 0
@@ -204,8 +220,9 @@ class HbmDataManagerConfig(InstantiateConfig):
         K = np.asarray(self.intrinsics)
         intr = torch.from_numpy(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32)).to(dev)
         gen = torch.Generator(device=dev).manual_seed(self.seed + 1000 * rank)
+        idx = None if self.image_idx is None else torch.as_tensor(np.asarray(self.image_idx)).to(dev)
         return ImageStackDataManager(self.images, torch.from_numpy(np.ascontiguousarray(self.c2w)).to(dev), intr, self.train_num_rays_per_batch,
-                                     error_maps=self.error_maps, generator=gen)
+                                     image_idx=idx, error_maps=self.error_maps, generator=gen)
 
 
 # ------------------------------------------------------------------------------------------------ the pipeline
@@ -215,6 +232,10 @@ class GFNerfPipelineConfig(InstantiateConfig):
     _target: Type = field(default_factory=lambda: GFNerfPipeline)
     datamanager: Any = field(default_factory=HbmDataManagerConfig)
     model: ModelConfig = field(default_factory=GFNeRFModelConfig)
+    prefetch_next_batch: bool = True
+    """(this build) get_train_loss_dict(step) also draws batch step + 1 -- after this step's forward and error-map write-back, so the
+    draw sees exactly the state it would see one call later -- and starts its ray sampler on the engine's second stream, beside this
+    step's backward.  False: every batch is drawn and sampled when its own step begins, like the reference (:146-148)."""
 
 
 class GFNerfPipeline(Pipeline):
@@ -237,6 +258,7 @@ class GFNerfPipeline(Pipeline):
                                          device=device)
         self.model.to(device)
         self.world_size, self.local_rank = world_size, local_rank
+        self._next_batch = None   # (step, datamanager split version, next_train(step) result) drawn one call early
         if world_size > 1:
             # no DDP wrapper (see the module docstring): the engine exchanges octree statistics and gradients itself
             assert self.model.hot.sync.world == world_size, "torch.distributed must be initialised before the pipeline is built (scripts/train.py:124)"
@@ -248,7 +270,11 @@ class GFNerfPipeline(Pipeline):
 
     def get_train_loss_dict(self, step: int):
         """:146-192."""
-        nxt = self.datamanager.next_train(step)
+        pre, self._next_batch = self._next_batch, None
+        if pre is not None and pre[0] == step and pre[1] == getattr(self.datamanager, "split_version", 0):
+            nxt = pre[2]
+        else:  # nothing drawn ahead, or the callbacks changed the camera split since (update_datamanager, nerfacto.py:491-519)
+            nxt = self.datamanager.next_train(step)
         ray_bundle, batch, ray_indices = nxt if len(nxt) == 3 else (nxt[0], nxt[1], None)
         model_outputs = self.model(ray_bundle)
         metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
@@ -262,6 +288,10 @@ class GFNerfPipeline(Pipeline):
                 loader.update_error_map(slots, pred_color, gt_color)
             else:
                 loader._update_error_map(ray_indices, torch.sum(torch.abs(gt_color - pred_color), dim=-1))
+        if getattr(self.config, "prefetch_next_batch", False) and self.model.training and hasattr(self.model, "prefetch_samples"):
+            nxt = self.datamanager.next_train(step + 1)
+            self._next_batch = (step + 1, getattr(self.datamanager, "split_version", 0), nxt)
+            self.model.prefetch_samples(nxt[0])
         return model_outputs, loss_dict, metrics_dict
 
     def forward(self):

@@ -93,34 +93,85 @@ class GFNeRFModelConfig(ModelConfig):
 
 
 class _RenderFn(torch.autograd.Function):
-    """forward: HotPath.forward_train; backward: HotPath.backward (+ the data-parallel exchange) -> autograd gradients of the
-    aliased parameters, in the order (table, block table, embedding weight, 10 decoder tensors)."""
+    """forward: HotPath.forward_train; backward: HotPath.backward (+ the data-parallel exchange).  The aliased parameters
+    arrive in the order (table, block table, embedding weight, 10 decoder tensors).  A parameter that a GfnAdam steps
+    (gfnerf/optim.py) gets NO autograd gradient: its gradient stays where the HIP backward wrote it (the f16 x128 table pool,
+    the flat decoder / embedding vectors) and the optimiser reads it there; for any other optimiser the dense f32 gradient is
+    materialised like Hash3DAnchoredFunction::backward does (Hash3DAnchored_cuda.cu:238: `pool.float() / 128`).  No host
+    synchronisation either way."""
 
     @staticmethod
     def forward(ctx, model, stage, block, o, d, cam, noise, table, block_table, emb, *decoder):
         hot = model.hot
         comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block)
-        ctx.model, ctx.hctx, ctx.stage, ctx.n_dec = model, hctx, stage, len(decoder)
+        ctx.model, ctx.hctx, ctx.stage, ctx.block = model, hctx, stage, block
+        ctx.params = (table, block_table, emb) + tuple(decoder)
+        ctx.set_materialize_grads(False)  # an output the loss does not use arrives as None, not as zeros to be tested on the host
         depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], hot.cfg.scale_factor)
         ctx.mark_non_differentiable(depth)
-        return comp["rgb"], comp["acc"], depth
+        # fresh tensor objects on the same storage: the outputs get this node as grad_fn, and the node reaches hctx -- handing out
+        # hctx's own tensors would close a reference cycle through the autograd graph that no collector can see (a step's samples
+        # and activations, ~1 GB at 4096 x 192, would never be freed)
+        return comp["rgb"].detach(), comp["acc"].detach(), depth
 
     @staticmethod
     def backward(ctx, g_rgb, g_acc, _g_depth):
         hot = ctx.model.hot
-        g_acc = None if g_acc is None or not bool(g_acc.any()) else g_acc.contiguous()
-        hot.backward(ctx.hctx, g_rgb.contiguous(), g_acc)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(ctx.hctx["comp"]["rgb"])
+        hot.backward(ctx.hctx, g_rgb.contiguous(), None if g_acc is None else g_acc.contiguous())
         hot.sync_grads(ctx.stage, ctx.hctx)  # ray data parallelism: averaged over the ranks before any optimiser sees them
-        tg = hot.table_grad
-        tg = tg.float() / 128.0 if tg.dtype == torch.float16 else tg.clone()
-        none7 = (None,) * 7
+        table, block_table, emb = ctx.params[:3]
+        decoder = ctx.params[3:]
+        wants = ctx.needs_input_grad[7:]
+
+        def dense_table_grad():
+            tg = hot.table_grad
+            return tg.float() / 128.0 if tg.dtype == torch.float16 else tg.clone()
+
+        out = [None] * len(ctx.params)
+        hot.grad_ready.clear()
         if ctx.stage == hp_mod.STAGE_GLOBAL:
-            emb_g = hot.emb_grad.clone() if hot.cfg.use_appearance_embedding else None
-            dec = []
-            for gW, gB in hot.layer_grads:
-                dec += [gW.clone(), gB.clone()]
-            return none7 + (tg, None, emb_g) + tuple(dec)
-        return none7 + (None, tg, None) + (None,) * ctx.n_dec
+            if wants[0]:
+                if hot.fused_claims(table):
+                    hot.grad_ready.add("table")
+                else:
+                    out[0] = dense_table_grad()
+            if wants[2] and hot.cfg.use_appearance_embedding:
+                if hot.fused_claims(emb):
+                    hot.grad_ready.add("emb")
+                else:
+                    out[2] = hot.emb_grad.clone()
+            if any(wants[3:]):
+                if all(hot.fused_claims(p) for p in decoder):
+                    hot.grad_ready.add("mlp")
+                else:
+                    k = 3
+                    for gW, gB in hot.layer_grads:
+                        out[k], out[k + 1] = (gW.clone() if wants[k] else None), (gB.clone() if wants[k + 1] else None)
+                        k += 2
+        elif wants[1]:
+            if hot.fused_claims(block_table):
+                hot.grad_ready.add(f"block{ctx.block}")
+            else:
+                out[1] = dense_table_grad()
+        ctx.params = ctx.hctx = ctx.model = None  # the step's buffers go back to the allocator now, not when the graph dies
+        return (None,) * 7 + tuple(out)
+
+
+class _CharbonnierFn(torch.autograd.Function):
+    """CharbonnierLoss (losses.py:73-84): sum(sqrt((x - y)^2 + eps^2)) / x.shape[0], value and gradient from one kernel."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        loss, g = ops.charbonnier(pred.contiguous(), gt.contiguous())
+        ctx.save_for_backward(g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (g,) = ctx.saved_tensors
+        return g * g_out, None
 
 
 class _S3IMFn(torch.autograd.Function):
@@ -209,6 +260,8 @@ class GFNeRFModel(Model):
             keep_blocks_resident=c.keep_blocks_resident)
         self._params_version = None
         self._tile_renderer = None
+        self._trainer_step = None
+        self._prefetched = None
         self._s3im_gen = torch.Generator(device=dev)
         self._s3im_gen.manual_seed(77 + c.engine_seed)
 
@@ -234,6 +287,7 @@ class GFNeRFModel(Model):
 
         def update_field_stage(step, *args, **kwargs):
             self.field.cur_stage = "init_stage" if (c.steps_perssampler_init > 0 and 0 <= step < c.steps_perssampler_init) else "block_stage"
+            self._trainer_step = step  # the Trainer's step as a host integer: get_outputs need not read ray_bundle.steps back
 
         def train_cameras_clustering(step, *args, **kwargs):
             if self.field.cur_stage == "block_stage" and self.persampler.cameras_labels is None:
@@ -320,16 +374,45 @@ class GFNeRFModel(Model):
             self._params_version = vers
 
     def _bundle(self, ray_bundle: RayBundle):
+        """(origins [R,3], directions [R,3], training step or -1).  The reference reads the step back from the device tensor
+        (`steps[0][0].item()`, perssampler.py:363: a host synchronisation per step); here it comes, in this order, from the host
+        integer this build's datamanagers stamp on the bundle, from the Trainer's step recorded by the update_field_stage
+        callback (trainer.py:212: callbacks run with the same `step` get_train_loss_dict receives), and only then from the tensor."""
         o = ray_bundle.origins.reshape(-1, 3).contiguous().float()
         d = ray_bundle.directions.reshape(-1, 3).contiguous().float()
-        step = -1 if ray_bundle.steps is None else int(ray_bundle.steps.reshape(-1)[0])
+        stamp = getattr(ray_bundle, "_step_host", None)  # (the steps tensor it describes, its value)
+        if ray_bundle.steps is None:
+            step = -1
+        elif stamp is not None and stamp[0] is ray_bundle.steps:
+            step = int(stamp[1])
+        elif self.training and self._trainer_step is not None:
+            step = int(self._trainer_step)
+        else:
+            step = int(ray_bundle.steps.reshape(-1)[0])
         return o, d, step
+
+    def prefetch_samples(self, ray_bundle: RayBundle):
+        """Start the sampler (K3 + K4) of the NEXT training batch now, on the engine's second stream, beside this iteration's
+        backward; get_outputs(ray_bundle) -- the very same object -- collects it.  Called by GFNerfPipeline.get_train_loss_dict after
+        this iteration's forward, i.e. after update_ray_march / update_mode / UpdateOctNodes (nerfacto.py:598-616) left the sampler
+        in the state the next GetSamples sees: same noise stream, same fineness, same tree as without the prefetch."""
+        if not (self.training and self.hot._fused_ok(None)):
+            return
+        o, d, _ = self._bundle(ray_bundle)
+        noise = self.persampler.sampler.make_noise(o.shape[0])
+        self._relink_tree()
+        self.hot.prefetch_sample(o, d, noise)
+        self._prefetched = (ray_bundle, o, d, noise)
 
     def get_outputs(self, ray_bundle: RayBundle):
         """nerfacto.py:522-619."""
         if self.field.persampler is None:
             object.__setattr__(self.field, "persampler", self.persampler)  # for trans_query_frame speed up (:532-533); not re-registered
+        pre, self._prefetched = self._prefetched, None
         o, d, step = self._bundle(ray_bundle)
+        noise = None
+        if pre is not None and pre[0] is ray_bundle:  # sampled already (prefetch_samples): the same tensors collect it
+            _, o, d, noise = pre
         R = o.shape[0]
         nat = self.persampler.sampler
         stage, blk = self.stage_of(step)
@@ -344,7 +427,8 @@ class GFNeRFModel(Model):
         cam = cam.reshape(-1).to(torch.int32).contiguous()
         self.field.cur_stage = "block_stage" if stage == hp_mod.STAGE_FOCAL else "init_stage"
         self.field.cur_split_dataset_idx = -1 if blk is None else blk
-        noise = nat.make_noise(R)
+        if noise is None:
+            noise = nat.make_noise(R)
         if self.training and torch.is_grad_enabled():
             if stage == hp_mod.STAGE_FOCAL:
                 self.field.update_active_blocks(blk)                   # nerfacto_field.py:470
@@ -437,7 +521,10 @@ class GFNeRFModel(Model):
         x, y = image, outputs["rgb"]
         loss_dict = {}
         if c.use_ch_loss:
-            loss_dict["rgb_loss"] = torch.sum(torch.sqrt((x - y).pow(2) + 1e-6 ** 2)) / x.shape[0]
+            if y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.shape[1] == 3 and x.shape == y.shape and x.dtype == y.dtype:
+                loss_dict["rgb_loss"] = _CharbonnierFn.apply(y, x)
+            else:
+                loss_dict["rgb_loss"] = torch.sum(torch.sqrt((x - y).pow(2) + 1e-6 ** 2)) / x.shape[0]
         else:
             loss_dict["rgb_loss"] = torch.mean((x - y) ** 2)
         if c.s3im_loss_mult > 0:

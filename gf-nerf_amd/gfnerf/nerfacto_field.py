@@ -126,6 +126,7 @@ class GFNeRFField(Field):
         add / delete / save / load then act on exactly what the fused kernels read."""
         nat = self.base_encoding_init.hash_3d
         nat.feat_pool_ = hp.table.requires_grad_(True)
+        nat.feat_pool_._gfn_link = ("table", hp)   # gfnerf.optim.GfnAdam: which gradient buffer of the engine belongs to this tensor
         nat.prim_pool_, nat.bias_pool_, nat.n_volumes_ = hp.prim, hp.bias, hp.n_volumes
         layers = list(self.base_network.layers) + list(self.mlp_head.layers)
         assert len(layers) == len(hp.layers)
@@ -133,7 +134,9 @@ class GFNeRFField(Field):
             assert tuple(layer.weight.shape) == tuple(W.shape), "decoder shapes of field and engine differ"
             layer.weight = nn.Parameter(W)
             layer.bias = nn.Parameter(B)
+            layer.weight._gfn_link = layer.bias._gfn_link = ("mlp", hp)
         self.embedding_appearance.embedding.weight = nn.Parameter(hp.emb)
+        self.embedding_appearance.embedding.weight._gfn_link = ("emb", hp)
         for i, b in enumerate(hp.blocks):  # block tables the engine already holds
             if b is not None and not hasattr(self, f"base_encoding_{i}"):
                 self.add_table(i)
@@ -188,6 +191,7 @@ class GFNeRFField(Field):
                 hp.add_block(table_idx)
             nat = enc.hash_3d
             nat.feat_pool_ = hp.blocks[table_idx].requires_grad_(True)
+            nat.feat_pool_._gfn_link = (f"block{table_idx}", hp)
             nat.prim_pool_, nat.bias_pool_, nat.n_volumes_ = hp.block_prims[table_idx], hp.bias, hp.n_volumes
         else:
             enc.zero()

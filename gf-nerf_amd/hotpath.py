@@ -10,6 +10,7 @@ live sample count stays on the device (no host synchronisation inside a step).
 """
 import contextlib
 import math
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -151,6 +152,10 @@ class HotPath:
         self.timed_ops = set()  # stage names to bracket with events on the launch stream (bench.py)
         self.timings = {}
         self._last_train_ctx = None
+        # the plugin surface (gfnerf.optim.GfnAdam): optimisers that step engine-aliased parameters from the engine's own gradient
+        # buffers, and the groups whose buffers hold this iteration's gradients ("table", "block<i>", "mlp", "emb")
+        self.fused_optimizers = weakref.WeakSet()
+        self.grad_ready = set()
 
     def add_block(self, i, table=None, prims=None):
         """GFNeRFField.add_table (nerfacto_field.py:336-347): make residual block table i resident -- zeros and fresh primes
@@ -757,6 +762,46 @@ class HotPath:
                 self._opt_pending = True
             else:
                 run()
+
+    # ------------------------------------------------------- optimiser state owned by the caller (the plugin surface)
+    def fused_claims(self, p):
+        """True when a live gfnerf.optim.GfnAdam steps parameter tensor `p` (it reads the engine's gradient buffers: no dense
+        autograd gradient is wanted for p)."""
+        return any(opt.owns(p) for opt in list(self.fused_optimizers))
+
+    def layer_grad_of(self, p):
+        """The engine's gradient view of decoder tensor `p` (a view of mlp_flat)."""
+        off = (p.data_ptr() - self.mlp_flat.data_ptr()) // 4
+        return self.mlp_grad[off:off + p.numel()].view(p.shape)
+
+    def decoder_changed(self):
+        self._x3_stale = True
+
+    def external_adam(self, name, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-15, grad=None):
+        """One torch.optim.Adam step of parameter group `name` ("table", "block<i>", "mlp", "emb") whose state (m, v, step count
+        t) lives with the caller -- the Trainer's torch.optim.Optimizer (engine/optimizers.py:73-133; gfnerf.optim.GfnAdam).
+        grad: None = the buffer the last backward filled (a table: the f16 x128 pool); a tensor = a dense gradient like `p`."""
+        c = self.cfg
+        self._sync_opt()
+        if name == "table" or name.startswith("block"):
+            i = None if name == "table" else int(name[5:])
+            p = self.table if i is None else self.blocks[i]
+            shadow = None
+            if c.table_f16_shadow:
+                shadow = self.table16 if i is None else self.blocks16[i]
+            g = self.table_grad if grad is None else grad.view(p.shape)
+            self._timed("adam", ops.adam_step_table, p, g, m, v, t, lr=lr, beta1=beta1, beta2=beta2, eps=eps, shadow_f16=shadow,
+                        n=17 * (1 << c.log2_T))
+            self.step += 1  # one per training step of either stage (forward_train reads it: level_major_global_after)
+            if i is None and c.share_block_primes:
+                self._pairs_stale = True
+        elif name == "mlp":
+            self._timed("adam", ops.adam_step, self.mlp_flat, self.mlp_grad if grad is None else grad, m, v, t, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
+            self._x3_stale = True
+        elif name == "emb":
+            self._timed("adam", ops.adam_step, self.emb, self.emb_grad if grad is None else grad, m, v, t, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
+        else:
+            raise _lib.GfnError(f"external_adam: unknown parameter group {name!r}")
 
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
