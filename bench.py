@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--stage-times", action="store_true", help="print per-stage event timings to stderr (adds event overhead)")
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the bounded cpu_baseline sample")
     ap.add_argument("--early-T", type=float, default=1e-4, help="early-termination transmittance (0 = none, the reference)")
+    ap.add_argument("--one-phase", action="store_true",
+                    help="level-major forward over every sample (no termination-aware split into phases; HotPathConfig.two_phase = False)")
     ap.add_argument("--no-oct-update", action="store_true", help="global stage: skip the per-step UpdateOctNodes (K5/K6)")
     ap.add_argument("--render-frames", type=int, default=2,
                     help="also time N full 1920x1080 frames (per rank) through the hipGraph tile renderer (BASELINE configs[4]); 0 = skip")
@@ -71,7 +73,11 @@ def parse():
                     help="experiment: ONE fixed batch every step, eagerly launched or as one captured hipGraph replayed per step "
                          "(isolates launch overhead; the captured step's optimiser scalars are frozen, so not a training run)")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
-                    help="torch.distributed backend at N > 1 (auto: RCCL, probed with one collective; gloo if that fails or ranks share a card)")
+                    help="torch.distributed backend at N > 1 (auto: RCCL whenever every rank has its own GPU -- a failure there is an error, "
+                         "never a silent fall-back --, gloo only with --share-gpu; gloo: explicitly, for rehearsals)")
+    ap.add_argument("--job-timeout", type=float, default=1500.0, help="N > 1, self-spawned ranks: seconds after which the ranks are killed and the exit code is 124")
+    ap.add_argument("--plugin-steps", type=int, default=100,
+                    help="timed iterations of the `plugin_step` sub-records (the step through GFNerfPipeline + Optimizers, N = 1 only); 0 = skip")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one address part at a time")
@@ -137,8 +143,13 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
+    t_end = time.monotonic() + args.job_timeout
     try:
         while procs:
+            if time.monotonic() > t_end:  # a rank that hangs (in a collective, in a rendezvous) must not hang the job
+                print(f"bench.py: ranks still running after {args.job_timeout:.0f} s: killed", file=sys.stderr)
+                rc = 124
+                break
             for p in list(procs):
                 code = p.poll()
                 if code is None:
@@ -157,7 +168,8 @@ def launch_ranks(args):
 
 class Deadline:
     """Safety net around a sub-record that talks to other ranks: if it has not finished after `seconds`, `on_expire` runs
-    on a helper thread (rank 0 prints the line without the sub-record) and the process leaves with os._exit."""
+    on a helper thread (rank 0 prints the line with an "error" entry for the sub-record) and the process leaves with exit code 3
+    (os._exit: the main thread sits in a collective that will never return)."""
 
     def __init__(self, seconds, on_expire):
         self.seconds, self.on_expire, self._done = seconds, on_expire, threading.Event()
@@ -169,7 +181,7 @@ class Deadline:
                     self.on_expire()
                 finally:
                     _OUT.flush()
-                    os._exit(0)
+                    os._exit(3)
 
         threading.Thread(target=watch, daemon=True).start()
         return self
@@ -200,27 +212,39 @@ def pick_fineness(hp, o, d, target, scene, torch):
     return best
 
 
-def lm_issued_gathers(samples, n_live, halves_from, torch):
+def lm_issued_gathers(samples, n_live, halves_from, torch, mask=None):
     """Gathers one lm_lookup_kernel launch issues for this batch: 8 per (sample, level), except that below level `halves_from`
     only the first lane of a run of consecutive samples in one cell of one volume gathers when a wave holds <= 40 such runs
     (csrc/lm_lookup.hip).  Waves are taken as aligned groups of 64 samples (the kernel's start at its workgroup's run)."""
     pts = samples["warped_pts"][:n_live]
     vol = samples["anchors"][:n_live, 0]
+    want = torch.ones(n_live, dtype=torch.bool, device=pts.device) if mask is None else mask[:n_live] != 0  # phased forward: the launch's share
     total = 0
     lane0 = (torch.arange(n_live, device=pts.device) % 64) == 0
     pad = (-n_live) % 64
     for level in range(16):
         if level >= halves_from:
-            total += 8 * n_live
+            total += 8 * int(want.sum().item())
             continue
         cell = torch.floor(pts * float(np.float32(2.0 ** (7.0 * level / 15.0 + 3.0)))).to(torch.int32)
         head = torch.ones(n_live, dtype=torch.bool, device=pts.device)
-        head[1:] = (vol[1:] != vol[:-1]) | (cell[1:] != cell[:-1]).any(1)
+        head[1:] = (vol[1:] != vol[:-1]) | (cell[1:] != cell[:-1]).any(1) | ~want[:-1]
         head |= lane0
+        head &= want
         per_wave = torch.nn.functional.pad(head.to(torch.int32), (0, pad)).view(-1, 64).sum(1)
         shared = torch.repeat_interleave(per_wave <= 40, 64)[:n_live]
-        total += 8 * int(torch.where(shared, head, torch.ones_like(head)).sum().item())
+        total += 8 * int(torch.where(shared, head, want).sum().item())
     return total
+
+
+def _sha256(path):
+    import hashlib
+
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
 
 
 def _cores():
@@ -497,6 +521,7 @@ class StageRun:
         ga = args.lm_global_after
         self.cfg = cfg = hotpath.HotPathConfig(
             log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
+            two_phase=not args.one_phase,
             prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, table_branch=args.table_branch,
             level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, adam_pipeline_chunks=args.adam_chunks, loss_before_fork=not args.fork_first,
@@ -621,7 +646,8 @@ class StageRun:
             sg.prime(o, d)
             sg.p = self.i % sg.cycle  # the block rotation goes on where the eager steps stopped
             sg.capture()
-            return sg, f"hipGraph replay ({sg.cycle} captured graphs: sample-buffer parity x block rotation)"
+            return sg, (f"hipGraph replay ({sg.cycle} captured graphs: sample-buffer parity x block rotation; forward {hp.last_forward}" +
+                        ("" if sg.phased is None else ", phased" if sg.phased else ", one phase: the plan at capture found no split worth its launches") + ")")
         except Exception as e:  # noqa: BLE001 -- the eager path is always there
             hp._pre = None
             return None, f"eager (capture failed: {type(e).__name__}: {e})"
@@ -686,6 +712,11 @@ class StageRun:
         # fused forward: only samples in front of each ray's termination point are looked up (sigma > 0 marks them); per such
         # sample 512 B of gathers per table + 16 B point/anchor + 8 B dt/t in, sigma 4 + rgb 12 + h0 4 + masks 48 + weight/alpha 8 out
         n_eval = int((aux["field"]["sigma"][:n_live] > 0).sum().item())
+        self.phase = None
+        if getattr(hp, "last_forward", "") == "lm2" and hp._phase is not None:  # the phased forward counts what it looks up and decodes itself
+            nA, nB_rays, nB_samples, K = (int(v) for v in hp._phase.stats_last.tolist())
+            n_eval = nA + nB_samples
+            self.phase = dict(K=K, phase_a_samples=nA, phase_b_rays=nB_rays, phase_b_samples=nB_samples, next_K=int(hp._phase.k.item()))
         # hash lookup per table and sample = 512 B gathered + 12 B point + 8 B anchor + 128 B features written = 660 B
         # (unfused); hash scatter = 16 x 8 x 4 B packed-f16 adds + point/anchor (+ 56 B of decoder state in the fused kernel)
         alg = {"fused_fwd": n_eval * (512 * n_tables + 24 + 76), "hash_fwd": n_live * 660 * n_tables,
@@ -696,29 +727,40 @@ class StageRun:
         kern_ms, alg_bytes = kern[dom], alg[dom]
         kernel_name, launches = {"bwd_scatter": "field_bwd_dx_x3_kernel<planes, records>", "hash_fwd": "hash_fwd_kernel",
                                  "hash_bwd": "hash_bwd_kernel"}.get(dom, dom + "_kernel"), 1
-        lm = getattr(hp, "last_forward", "") == "lm" and dom == "hash_fwd"
+        lm = getattr(hp, "last_forward", "").startswith("lm") and dom == "hash_fwd"
         if lm:  # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region
             kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
             kern_ms = kern_ms / launches
-            alg_bytes = n_live * 660
+            # the samples this launch looked up (all of them, or phase A's share: the first K of every ray)
+            alg_bytes = (self.phase["phase_a_samples"] if self.phase else n_live) * 660
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # measured separately with rocprofv3 --pmc (see profiles/README.md)
         traffic, req = None, None
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
+            # the counters describe the kernel sources they were collected on: a figure measured on another version of the dominant
+            # kernel is not reported (tools/sync_profiles.py records the hashes with the counters)
+            stale = [f for f, h in pmc.get("source_sha256", {"csrc/lm_lookup.hip": None}).items() if _sha256(os.path.join(ROOT, "gf-nerf_amd", f)) != h]
+            if stale:
+                print(f"bench.py: profiles/pmc_traffic.json predates {stale}: roofline.traffic not reported", file=sys.stderr)
+                pmc = {k: v for k, v in pmc.items() if k in ("l2_gather_ceiling_per_s", "gather_request_ceiling_per_s", "n_side")}
             # the PMC passes were taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21)
             default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
             traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
             n_req = pmc.get(f"{dom}:{self.stage}:fetch_requests") if default_cfg else None
             if lm:  # the level-major kernel is bound by the L2 -> L1 line fills of its gathers (86 % of them hit the L2), not by the fabric
-                n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch)
+                looked_up = None
+                if self.phase:  # the phased forward: the launch's share of the samples
+                    looked_up = torch.zeros(n_live, dtype=torch.uint8, device="cuda")
+                    looked_up[hp._phase.list_a[: self.phase["phase_a_samples"]].long()] = 1
+                n_g = lm_issued_gathers(aux["samples"], n_live, cfg.lm_halves_from, torch, mask=looked_up)
                 req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
                            frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
                            nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
                            l2_to_l1=(dict(line_fills_per_launch=pmc["lm_lookup:focal:l1_miss_requests"], bytes_per_fill=128,
                                           achieved_TBps=pmc["lm_lookup:focal:l1_miss_requests"] * 128 / (kern_ms * 1e-3) / 1e12, peak_TBps=34.5,
                                           l2_hit_rate=pmc["lm_lookup:focal:l2_hit_rate"],
-                                          source="TCP_TCC_READ_REQ_sum, TCC_HIT / TCC_MISS (profiles/r02_pmc_focal_per_kernel.csv); peak: MI355X guide, L2")
-                                     if default_cfg and self.stage == "focal" else None),
+                                          source="TCP_TCC_READ_REQ_sum, TCC_HIT / TCC_MISS (profiles/*_pmc_focal_per_kernel.csv); peak: MI355X guide, L2")
+                                     if default_cfg and self.stage == "focal" and "lm_lookup:focal:l1_miss_requests" in pmc else None),
                            source="gathers the kernel issues per launch (16 levels x 8 corners per sample, minus the corners that runs of samples in one "
                                   "cell share below level lm_halves_from: counted from this batch) over the live kernel time; peak = tools/gather_bench.hip on a 4 MB table")
             elif n_req:  # what actually bounds a random 4-byte gather: 64-byte L2-miss requests per second
@@ -739,6 +781,62 @@ class StageRun:
             tot += t
             print(f"[stage] {self.stage:6s} {name:16s} {t:8.3f} ms/step ({len(ev) // res['event_steps']} launches)", file=sys.stderr)
         print(f"[stage] {self.stage:6s} {'sum':16s} {tot:8.3f} ms/step", file=sys.stderr)
+
+
+def _r(v, n=5):
+    """Floats to n significant digits (the line must stay short)."""
+    return float(f"{v:.{n}g}") if isinstance(v, float) else v
+
+
+def compact_line(out):
+    """The line the driver parses: the contract's keys, `config` (which the driver keeps whole) with the headline numbers of every
+    sub-record hoisted into it, a short `roofline` and `cpu_baseline`.  < 2,000 characters."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "samples_per_sec", "ranks_seen")
+    line = {k: _r(out[k], 6) for k in keep if k in out}
+    c = out["config"]
+    cfg = {k: _r(c[k]) for k in ("workload", "rays_per_batch", "mean_samples_per_ray", "log2_table_size", "n_cameras", "n_tree_nodes", "stage", "early_T",
+                                  "alive_sample_frac", "evaluated_sample_frac", "backend", "loss") if c.get(k) is not None}
+    cfg["launch"] = "graph" if str(c.get("launch", "")).startswith("hipGraph") else "eager"
+    cfg["parallelism"] = c["parallelism"].split(":")[0].split(",")[0]
+    if c.get("two_phase"):
+        cfg["two_phase_K"] = c["two_phase"]["K"]
+    if c.get("allreduce_selfcheck"):
+        cfg["allreduce_selfcheck_ok"] = c["allreduce_selfcheck"]["ok"]
+    errors = {}
+
+    def hoist(sub, pairs):
+        r = out.get(sub)
+        if not isinstance(r, dict):
+            return
+        if "error" in r:
+            errors[sub] = r["error"][:120]
+            return
+        for src, dst in pairs:
+            if r.get(src) is not None:
+                cfg[dst] = _r(r[src])
+
+    hoist("global_stage", (("ms_per_step", "global_ms_per_step"), ("value", "global_rays_per_sec"), ("launch_short", "global_launch"),
+                           ("replicas_bit_identical", "replicas_bit_identical")))
+    hoist("render", (("value", "render_ms_per_mpix"),))
+    hoist("plugin_step_focal", (("value", "plugin_rays_per_sec"), ("ms_per_step", "plugin_ms_per_step")))
+    hoist("plugin_step_global", (("value", "plugin_global_rays_per_sec"), ("ms_per_step", "plugin_global_ms_per_step")))
+    hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
+    hoist("psnr", (("psnr_x3", "psnr"), ("psnr_f32", "psnr_f32_decoder"), ("steps", "psnr_train_steps")))
+    hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
+    for k in ("mfma_busy_frac", "mfma_tflops_issued"):
+        if out["roofline"].get(k) is not None:
+            cfg[k] = _r(out["roofline"][k])
+    line["config"] = cfg
+    ro = out["roofline"]
+    line["roofline"] = {k: _r(ro[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "alg_bytes_per_launch", "launches_per_step")
+                        if k in ro}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(value=_r(cb["value"]), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=cb["sample"].split(",")[0][:80])
+    if errors:
+        line["errors"] = errors
+    return line
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -770,6 +868,7 @@ def run_rank(args):
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     n_dev = torch.cuda.device_count()
     backend = "nccl"
+    selfcheck = None
     global CTL_DEV
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -780,27 +879,20 @@ def run_rank(args):
         torch.cuda.set_device(local_rank)
         if args.backend != "auto":
             backend = args.backend
-        backend_note = None
         if backend == "nccl":
-            try:  # RCCL over xGMI; probed with one real collective before anything depends on it
-                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
-                assert int(probe.item()) == world
-            except Exception as e:  # noqa: BLE001 -- every rank sees the same failure: fall back together
-                if args.backend == "nccl":
-                    raise
-                backend_note = f"gloo (RCCL could not be used: {type(e).__name__}: {str(e)[:120]})"
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = "gloo"
-        if backend == "gloo":
+            # RCCL over xGMI.  Every rank has its own GPU here: if RCCL cannot be brought up that is an ERROR (non-zero exit), never
+            # a quiet fall-back to gloo -- a line that says n_gpus = 8 must have exchanged its gradients over RCCL.
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise SystemExit(f"bench.py: RCCL all_reduce of ones over {world} ranks gave {probe.item()}")
+            selfcheck = gdist.allreduce_selfcheck(device="cuda")
+            if not selfcheck["ok"]:
+                raise SystemExit(f"bench.py: the direct all-reduce (all-to-all + shard mean + all-gather) disagrees with dist.all_reduce: {selfcheck}")
+        else:
             CTL_DEV = "cpu"
             dist.init_process_group("gloo")
-        if backend_note:
-            backend = backend_note
     else:
         torch.cuda.set_device(0)
     _lib.require_device()  # the HIP extension + a gfx950 device, or fail loudly
@@ -864,13 +956,22 @@ def run_rank(args):
                                graph_warmup_steps=GRAPH_WARMUP if run.launch.startswith("hipGraph") else 0,
                                host_enqueue_ms_per_step=res["host_enqueue"] / args.steps * 1e3,
                                async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step",
-                               loss=res["loss"]),
+                               two_phase=run.phase, allreduce_selfcheck=selfcheck, loss=res["loss"]),
                    roofline=roofline)
 
-    def emit():
-        if rank == 0 and out is not None:
-            print(json.dumps(out), file=_OUT)
-            _OUT.flush()
+    state = dict(pending=None)
+
+    def emit(expired=False):
+        """The ONE line on stdout: the contract's keys + `config` with every headline number of the sub-records hoisted into it
+        (short enough for a log tail); the sub-records in full go to stderr (`[bench-details] {...}`)."""
+        if not (rank == 0 and out is not None):
+            return
+        if expired and state["pending"]:
+            out[state["pending"]] = dict(error=f"timed out after {args.sub_timeout:.0f} s")
+        print("[bench-details] " + json.dumps(out), file=sys.stderr)
+        sys.stderr.flush()
+        print(json.dumps(compact_line(out)), file=_OUT)
+        _OUT.flush()
 
     # ---- configs[4]: render (every rank renders the frames of the block it owns)
     if args.render_frames > 0:
@@ -886,13 +987,15 @@ def run_rank(args):
                     path.append(int(cb[(37 * (f + 1)) % cb.size]))
             owners = gdist.frame_owner(labels[np.asarray(path)], world)
             rblock = 0 if (headline_stage == "focal" and hp.blocks) else None
+        state["pending"] = "render"
         try:
-            with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
+            with Deadline(args.sub_timeout if world > 1 else 1e9, lambda: emit(expired=True)):
                 r = render_bench(hp, sc, args, run.fineness, torch, path, rblock, world, rank, owners, dist)
-        except Exception as e:  # noqa: BLE001 -- the headline stands on its own
+        except Exception as e:  # noqa: BLE001 -- the headline stands on its own; the failure is in the line and in the exit code
             if world == 1:
                 raise
             r = dict(error=f"{type(e).__name__}: {e}")
+        state["pending"] = None
         if out is not None:
             out["render"] = r
     if world == 1 and args.render_frames > 0:
@@ -920,27 +1023,48 @@ def run_rank(args):
                     steps=args.global_steps, warmup=args.global_warmup, samples_per_sec=gv * g_live / N_RAYS,
                     workload="GF-NeRF global stage, single Hash3DAnchored encoder + tiny MLP, 4096 rays x 128 samples (BASELINE configs[1]); all parameters "
                              "train, UpdateOctNodes (K5/K6) every step", mean_samples_per_ray=g_live / N_RAYS, evaluated_sample_frac=g_eval / max(g_live, 1),
-                    forward=grun.hp.last_forward, fineness=grun.fineness, launch=grun.launch,
+                    forward=grun.hp.last_forward, fineness=grun.fineness, launch=grun.launch, two_phase=grun.phase,
+                    launch_short="graph" if grun.launch.startswith("hipGraph") else "eager",
                     host_enqueue_ms_per_step=gres["host_enqueue"] / args.global_steps * 1e3,
                     parallelism="single GPU" if world == 1 else f"dp{world}: octree statistics MAX-reduced, gradients averaged (direct all-reduce) inside HotPath.train_step",
                     replicas_bit_identical=identical, sync=dict(sync.stats) if world > 1 else None, loss=gres["loss"], roofline=groof)
 
+        state["pending"] = "global_stage"
         try:
-            with Deadline(args.sub_timeout if world > 1 else 1e9, emit):
+            with Deadline(args.sub_timeout if world > 1 else 1e9, lambda: emit(expired=True)):
                 global_record()
-        except Exception as e:  # the headline stands on its own
+        except Exception as e:  # the headline stands on its own; the failure is in the line and in the exit code
             if out is not None:
                 out["global_stage"] = dict(error=f"{type(e).__name__}: {e}")
+            print(f"bench.py: global_stage sub-record failed: {type(e).__name__}: {e}", file=sys.stderr)
+        state["pending"] = None
+    # ---- the same steps THROUGH the plugin surface (pipeline + Optimizers, the reference Trainer's call sequence), N = 1
+    if out is not None and world == 1 and args.plugin_steps > 0:
+        if grun is not None:
+            P_global, fine_global, batches_global = grun.hp.export_params(), grun.fineness, grun.batches_np
+        del grun
+        grun = None
+        torch.cuda.empty_cache()
+        for stage_name in ("focal", "global"):
+            try:
+                out[f"plugin_step_{stage_name}"] = plugin_step_bench(sc, torch, stage_name, steps=args.plugin_steps, warmup=30 if stage_name == "focal" else 60)
+            except Exception as e:  # noqa: BLE001
+                out[f"plugin_step_{stage_name}"] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
     if out is not None and not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
         out["cpu_reference_field"] = cpu_reference_field()
         out["cpu_baseline"] = cpu_baseline(P_focal, batches_focal[0], args.log2_T, fine_focal, args.cpu_rays,
                                            0 if headline_stage == "focal" else None, scene)
-        if grun is not None:
-            out["cpu_baseline_global"] = cpu_baseline_global(grun.hp.export_params(), grun.batches_np[0], args.log2_T, grun.fineness, scene)
+        if "P_global" in locals():
+            out["cpu_baseline_global"] = cpu_baseline_global(P_global, batches_global[0], args.log2_T, fine_global, scene)
     emit()
+    failed = [k for k, v in (out or {}).items() if isinstance(v, dict) and "error" in v]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:  # a sub-record that failed is a failed run, whatever the headline says
+        print(f"bench.py: failed sub-records: {failed}", file=sys.stderr)
+        sys.exit(4)
 
 
 def main():

@@ -101,21 +101,28 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
     const u32x4* __restrict__ image, float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ h0_out,
     unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo,
-    int64_t cap, int64_t feat_stride /* 0: feat is [n,32]; else level-major float2 [16][feat_stride] (gfn_hash_fwd_lm) */) {
+    int64_t cap, int64_t feat_stride /* 0: feat is [n,32]; else level-major float2 [16][feat_stride] (gfn_hash_fwd_lm) */,
+    const int32_t* __restrict__ list /* phased forward: decode only the samples list[0 .. *list_n) (ascending); the others' outputs and */,
+    const int32_t* __restrict__ list_n /* plane rows are not touched; the launch does nothing when *list_n == 0 */) {
+  if (list && *list_n == 0) return;  // grid-uniform
+  if (list && *list_n < 0) list = nullptr;  // "every sample": no list was written
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   __syncthreads();
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + FWD_CHUNKS * 64;
   const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
-  const int64_t n = gfn_live_n(n_max, n_dev);
+  // n = samples to decode: the live ones, or the entries of the list (tiles are then 32 consecutive ENTRIES: every tile full)
+  int64_t n = list ? (int64_t)*list_n : gfn_live_n(n_max, n_dev);
+  if (list && n > n_max) n = n_max;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t n_tiles = (n + 31) / 32;
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
-    const int64_t s = tile * 32 + j;
-    const bool valid = s < n;
-    const int64_t q = valid ? s : n - 1;
+    const int64_t e = tile * 32 + j;
+    const bool valid = e < n;
+    const int64_t s = list ? (int64_t)list[valid ? e : n - 1] : e;  // the lane's sample
+    const int64_t q = list ? s : (valid ? s : n - 1);
     // ---- k-step u of the feature row: columns 16u + 8h + i (invalid lanes rewrite the last live row with the same values)
     u32x4 xh[2], xl[2];
 #pragma unroll
@@ -525,8 +532,10 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
                      const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
-                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, void* stream) {
+                     uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride,
+                     const int32_t* list, const int32_t* list_n, void* stream) {
   if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr), "gfn_field_fwd_x3: a sample list needs its count");
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
   GFN_CHECK_ARG(feat_stride == 0 || feat_stride >= n_max, "gfn_field_fwd_x3: feat_stride=%lld must be 0 or >= n_max", (long long)feat_stride);
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 32 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 32", (long long)plane_cap);
@@ -554,7 +563,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
 #define GFN_LAUNCH(S, P, L)                                                                                                         \
   if (save == S && planes == P && planar == L)                                                                                       \
     field_fwd_x3_kernel<S, P, L><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk, \
-                                                                           planes_hi, planes_lo, plane_cap, feat_stride);
+                                                                           planes_hi, planes_lo, plane_cap, feat_stride, list, list_n);
   GFN_FWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_FWD_ALL

@@ -31,6 +31,9 @@ struct LmArgs {
   int split_log2;                                   // ... of 2^split_log2 parts per level (1: halves, 2: quarters)
   int cap;  // samples of one workgroup per round (LDS capacity)
   float* out;  // f32 [n,32] row-major, or level-major float2 [16][n_max]
+  // phased (termination-aware) forward: look up only the samples named by list[0 .. *list_n) (ascending sample indices; the other
+  // samples' feature slots are left as they are); the whole launch does nothing when *list_n == 0 -- decided on the device
+  const int32_t* list; const int32_t* list_n;
   LevelScales sc;
 };
 
@@ -51,7 +54,12 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
   __shared__ float s_scale[GFN_N_LEVELS];
   const int tid = threadIdx.x;
   if (tid < GFN_N_LEVELS) s_scale[tid] = A.sc.s[tid];
-  const int64_t n = gfn_live_n(A.n_max, A.n_dev);
+  // n = entries to look up: the live samples, or the entries of the list (every workgroup then owns a run of the LIST: the same
+  // number of wanted samples each, every wave of every pass full)
+  const int32_t* list = A.list;  // (a local: writing to the argument struct would move all of it out of the kernel-argument segment)
+  int64_t n = list ? (int64_t)*A.list_n : gfn_live_n(A.n_max, A.n_dev);
+  if (list && n < 0) { list = nullptr; n = gfn_live_n(A.n_max, A.n_dev); }  // "every sample": no list was written
+  if (list && n > A.n_max) n = A.n_max;
   const int64_t per_round = (int64_t)A.cap * gridDim.x;
   const uint32_t mask = (1u << A.log2_T) - 1u;
   for (int64_t r0 = 0; r0 < n; r0 += per_round) {
@@ -63,10 +71,13 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
     const int cnt = (int)(cnt64 < 0 ? 0 : (cnt64 > per ? per : cnt64));
     float px[kLmK], py[kLmK], pz[kLmK];
     int vol[kLmK];
+    int smp[kLmK];  // the sample in the slot
 #pragma unroll
     for (int k = 0; k < kLmK; k++) {
       const int s = tid + k * kLmThreads;
-      const int64_t i = s < cnt ? b0 + s : r0;  // idle slots read a valid sample (r0 < n): b0 itself may lie beyond the buffers
+      const int64_t e = s < cnt ? b0 + s : r0;  // idle slots read a valid entry (r0 < n): b0 itself may lie beyond the buffers
+      const int64_t i = list ? (int64_t)list[e] : e;
+      smp[k] = (int)i;
       px[k] = A.pts[3 * i]; py[k] = A.pts[3 * i + 1]; pz[k] = A.pts[3 * i + 2];
       vol[k] = A.anchors[i * A.anchor_stride];
     }
@@ -113,8 +124,8 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
               for (int d = 0; d < 8; d++) v[d] = ld_pair(base, c.pos[d]);
             }
             if (valid) {
-              float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + b0 + s
-                                   : reinterpret_cast<float2*>(A.out + (b0 + s) * 32 + 2 * level);
+              float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + smp[k]
+                                   : reinterpret_cast<float2*>(A.out + (int64_t)smp[k] * 32 + 2 * level);
               float a0 = 0.f, a1 = 0.f;
 #pragma unroll
               for (int d = 0; d < 8; d++) {
@@ -147,8 +158,8 @@ __global__ __launch_bounds__(kLmThreads) void lm_lookup_kernel(LmArgs A) {
                 for (int d = 0; d < 8; d++)
                   if ((int)(c.pos[d] >> pshift) == h) s_val[d * A.cap + s] = __builtin_bit_cast(uint32_t, ld_pair(base, c.pos[d]));
               } else {
-                float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + b0 + s
-                                     : reinterpret_cast<float2*>(A.out + (b0 + s) * 32 + 2 * level);
+                float2* dst = PLANAR ? reinterpret_cast<float2*>(A.out) + (int64_t)level * A.n_max + smp[k]
+                                     : reinterpret_cast<float2*>(A.out + (int64_t)smp[k] * 32 + 2 * level);
                 float2 prev = make_float2(0.f, 0.f);
                 if (ACC) prev = *dst;
                 half2_t v[8];
@@ -182,13 +193,15 @@ extern "C" {
 
 int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2,
                     const float* bias_pool, const float* pts, const int32_t* anchors, int anchor_stride, int64_t n_max, const int32_t* n_dev,
-                    int64_t n_volumes, int log2_T, int halves_from, int split_log2, int planar, int accumulate, float* out, void* stream) {
+                    int64_t n_volumes, int log2_T, int halves_from, int split_log2, int planar, int accumulate, float* out,
+                    const int32_t* list, const int32_t* list_n, void* stream) {
   if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr), "gfn_hash_fwd_lm: a sample list needs its count");
   GFN_CHECK_ARG(table_f16 && prim_pool && pts && anchors && out, "gfn_hash_fwd_lm: null pointer");
   GFN_CHECK_ARG(n_max > 0 && n_volumes > 0 && log2_T >= 4 && log2_T <= 24 && split_log2 >= 0 && split_log2 <= 3, "gfn_hash_fwd_lm: bad sizes");
   LmArgs A;
   A.n_max = n_max; A.n_dev = n_dev; A.pts = pts; A.anchors = anchors; A.anchor_stride = anchor_stride;
-  A.bias = bias_pool; A.n_volumes = n_volumes; A.log2_T = log2_T;
+  A.bias = bias_pool; A.n_volumes = n_volumes; A.log2_T = log2_T; A.list = list; A.list_n = list_n;
   A.halves_from = halves_from < 0 ? 0 : halves_from;
   // 0: halves.  Quarters (2 MB parts at T = 2^21) win 4 % when the lookup runs back to back on an otherwise idle chip (0.371
   // vs 0.385 ms: the table then sits in the memory-side cache and the cold parts come from there) and lose 2-5 % inside the

@@ -125,18 +125,33 @@ __global__ void tminmax_init_kernel(float* t_minmax) {
   t_minmax[1] = 0.f;  // t >= 0 always (global_near = 0.01)
 }
 
+// The termination-aware (phased) training forward: phase A looks up and decodes only the first K samples of every ray, composites
+// them, and finds the rays that are still transparent behind sample K; phase B evaluates the rest of those rays only (nothing, as a
+// rule); a planning kernel then picks the next step's K from where this batch's rays ended.  Everything is decided on the device.
+struct PhaseArgs {
+  const uint8_t* ray_gate;  // second pass: composite only the rays with a non-zero byte here (the others keep their results)
+  const int* gate;          // ... and nothing at all when *gate == 0
+  const int* k_split;       // first pass (non-null): K
+  uint8_t* need_more;       // [R] out (first pass): the ray is longer than K samples and not yet terminated behind them
+  int* term;                // [R] out (either pass): samples in front of the ray's termination point (all of them if it never ends)
+};
+
 // one wave per ray; lanes sweep the ray's samples 64 at a time (front to back)
+template <bool PHASED>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const int* __restrict__ pts_offsets, int n_rays, const float* __restrict__ sigma,
     const float* __restrict__ dt, const float* __restrict__ t, const float* __restrict__ rgb,
     float early_T, float* __restrict__ weights, float* __restrict__ alphas,
     float* __restrict__ out_rgb, float* __restrict__ out_acc, float* __restrict__ out_depth,
-    float* __restrict__ t_minmax) {
+    float* __restrict__ t_minmax, PhaseArgs P) {
   __shared__ float s_tmin[4], s_tmax[4];
+  if (PHASED && P.gate && *P.gate == 0) return;  // grid-uniform
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wave;
-  const bool has_ray = ray < n_rays;  // wave-uniform; idle waves still join the workgroup's min / max
+  bool has_ray = ray < n_rays;  // wave-uniform; idle waves still join the workgroup's min / max
+  if (PHASED && P.ray_gate && has_ray && P.ray_gate[ray] == 0) has_ray = false;
   const int s = has_ray ? pts_offsets[ray] : 0, e = has_ray ? pts_offsets[ray + 1] : 0;
+  int n_front = 0;    // samples in front of the termination point
   float carry = 0.f;  // sum of dt*sigma of all earlier chunks
   float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
   float tmin = INFINITY, tmax = 0.f;
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float alpha = 1.f - expf(-ds);
     float w = nan_to_num(alpha * T);
     if (early_T > 0.f && T < early_T) w = 0.f;
+    if (PHASED) n_front += __popcll(__ballot(v && !(early_T > 0.f && T < early_T)));
     if (v) {
       if (weights) weights[i] = w;
       if (alphas) alphas[i] = alpha;
@@ -203,6 +219,179 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     out_rgb[3 * ray] = cr; out_rgb[3 * ray + 1] = cg; out_rgb[3 * ray + 2] = cb;
     if (out_acc) out_acc[ray] = ca;
     if (out_depth) out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
+  }
+  if (PHASED && has_ray) {
+    if (P.term && lane == 0) P.term[ray] = n_front;
+    if (P.k_split) {
+      const int K = *P.k_split;
+      const bool need = !dead && (e - s) > K;  // wave-uniform: still transparent behind its first K samples, and there are more
+      if (lane == 0) P.need_more[ray] = need ? 1 : 0;
+    }
+  }
+}
+
+// The sample list of a phase: ray r contributes c_r consecutive samples from its sample `first` on --
+//   phase A (need_more == null): first = 0, c_r = min(K, n_r);   phase B: first = K, c_r = need_more[r] ? n_r - K : 0.
+// scan: one workgroup, exclusive prefix sum of c_r over the rays -> coff i32 [R + 1]; stats[base] = entries, stats[base + 1] = rays
+// with c_r > 0 (base 0 for phase A, 2 for phase B: stats = {A samples, A rays, B samples, B rays}).  fill: one wave per ray.
+__global__ __launch_bounds__(1024) void phase_scan_kernel(const int* __restrict__ pts_offsets, int n_rays, const int* __restrict__ k_split,
+                                                          const uint8_t* __restrict__ need_more, int* __restrict__ coff, int* __restrict__ stats) {
+  __shared__ int s_wave[16], s_rays[16];
+  __shared__ int s_carry, s_nr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = *k_split;
+  if (tid == 0) { s_carry = 0; s_nr = 0; }
+  __syncthreads();
+  for (int r0 = 0; r0 < n_rays; r0 += 1024) {
+    const int r = r0 + tid;
+    int c = 0;
+    if (r < n_rays) {
+      const int n = pts_offsets[r + 1] - pts_offsets[r];
+      c = need_more ? ((need_more[r] && n > K) ? n - K : 0) : (n < K ? n : K);
+      c = c < 0 ? 0 : c;
+    }
+    int v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    const int nz = __popcll(__ballot(c > 0));
+    if (lane == 63) { s_wave[wave] = v; s_rays[wave] = nz; }
+    __syncthreads();
+    int before = s_carry;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    if (r < n_rays) coff[r] = before + v - c;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0, nr = 0;
+      for (int w = 0; w < 16; w++) { tot += s_wave[w]; nr += s_rays[w]; }
+      s_carry += tot; s_nr += nr;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool all = !need_more && K >= 1024;  // phase A of a one-phase step: every sample -- no list is needed (entries = -1)
+    coff[n_rays] = all ? 0 : s_carry;
+    const int base = need_more ? 2 : 0;
+    stats[base] = all ? -1 : s_carry; stats[base + 1] = s_nr;
+  }
+}
+
+// zero_sigma / zero_rgb (phase A, optional): the samples of the ray that are NOT listed get sigma = 0 and rgb = 0 -- empty space
+// with a finite colour for the compositing and the backward, which read every sample of a ray
+__global__ __launch_bounds__(256) void phase_fill_kernel(const int* __restrict__ pts_offsets, int n_rays, const int* __restrict__ k_split,
+                                                         int phase_b, const int* __restrict__ coff, int* __restrict__ list,
+                                                         float* __restrict__ zero_sigma, float* __restrict__ zero_rgb) {
+  if (coff[n_rays] == 0) return;  // grid-uniform: an empty phase, or phase A of a one-phase step (nothing to list, nothing to clear)
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int c = coff[ray + 1] - coff[ray];
+  const int s0 = pts_offsets[ray], n = pts_offsets[ray + 1] - s0;
+  const int first = s0 + (phase_b ? *k_split : 0);
+  int* dst = list + coff[ray];
+  for (int i = lane; i < c; i += 64) dst[i] = first + i;
+  if (zero_sigma && !phase_b) {
+    for (int i = c + lane; i < n; i += 64) {
+      zero_sigma[s0 + i] = 0.f;
+      zero_rgb[3 * (s0 + i)] = 0.f; zero_rgb[3 * (s0 + i) + 1] = 0.f; zero_rgb[3 * (s0 + i) + 2] = 0.f;
+    }
+  }
+}
+
+// The next step's K from this batch: with n_r = samples of ray r and f_r = samples in front of its termination point,
+//     cost(K) = sum_r min(K, n_r)  +  [some f_r > K] * (fixed + sum_{r: f_r > K} (n_r - K))        (in samples)
+// (phase A evaluates the first K samples of every ray; phase B, if any ray needs it, costs its fixed sweeps of the tables plus the
+// rest of those rays).  K = argmin + a margin for the batch-to-batch scatter of the longest ray; one workgroup, three histograms.
+__global__ __launch_bounds__(1024) void two_phase_plan_kernel(const int* __restrict__ pts_offsets, int n_rays, const int* __restrict__ term,
+                                                              int* __restrict__ k_split, int* __restrict__ stats, int* __restrict__ stats_last,
+                                                              float fixed_cost, float save_enter, float save_stay, int enabled) {
+  // bins 0 .. 1024 (a ray has at most 1024 samples); thread k owns bin k, thread 1023 also carries bin 1024 into the totals
+  __shared__ int hN[1025], hC[1025], hS[1025];
+  __shared__ int pN[1024], pKN[1024], pC[1024], pS[1024];  // inclusive prefix sums over bins 0 .. k
+  __shared__ int s_wave[16][4];
+  __shared__ float s_best[2];
+  __shared__ int s_arg[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 1025; k += 1024) { hN[k] = 0; hC[k] = 0; hS[k] = 0; }
+  const int k_used = *k_split;
+  __syncthreads();
+  for (int r = tid; r < n_rays; r += 1024) {
+    int n = pts_offsets[r + 1] - pts_offsets[r];
+    n = n < 0 ? 0 : (n > 1024 ? 1024 : n);
+    int f = term[r];
+    f = f < 0 ? 0 : (f > n ? n : f);
+    atomicAdd(&hN[n], 1); atomicAdd(&hC[f], 1); atomicAdd(&hS[f], n);
+  }
+  __syncthreads();
+  int v[4] = {hN[tid], tid * hN[tid], hC[tid], hS[tid]};
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int u = __shfl_up(v[c], off, 64);
+      if (lane >= off) v[c] += u;
+    }
+  }
+  if (lane == 63) { s_wave[wave][0] = v[0]; s_wave[wave][1] = v[1]; s_wave[wave][2] = v[2]; s_wave[wave][3] = v[3]; }
+  __syncthreads();
+  for (int w = 0; w < wave; w++) { v[0] += s_wave[w][0]; v[1] += s_wave[w][1]; v[2] += s_wave[w][2]; v[3] += s_wave[w][3]; }
+  pN[tid] = v[0]; pKN[tid] = v[1]; pC[tid] = v[2]; pS[tid] = v[3];
+  __syncthreads();
+  const int totN = pN[1023] + hN[1024], totC = pC[1023] + hC[1024], totS = pS[1023] + hS[1024];
+  const int totKN = pKN[1023] + 1024 * hN[1024];
+  // candidates K = 8 * (tid + 1), tid < 128:  A(K) = sum_r min(K, n_r);  rays / samples of phase B = those with f_r > K
+  float cost = 3.0e38f;
+  const int K = 8 * (tid + 1);
+  if (tid < 128) {
+    float a, b;
+    int nb;
+    if (K >= 1024) { a = (float)totKN; nb = 0; b = 0.f; }
+    else {
+      a = (float)pKN[K] + (float)K * (float)(totN - pN[K]);
+      nb = totC - pC[K];
+      b = (float)(totS - pS[K]) - (float)K * (float)nb;
+    }
+    cost = a + (nb > 0 ? fixed_cost + b : 0.f);
+  }
+  int arg = K;
+  if (tid < 128) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float oc = __shfl_xor(cost, off, 64);
+      const int oa = __shfl_xor(arg, off, 64);
+      if (oc < cost || (oc == cost && oa < arg)) { cost = oc; arg = oa; }
+    }
+    if (lane == 0) { s_best[wave] = cost; s_arg[wave] = arg; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_best[1] < cost || (s_best[1] == cost && s_arg[1] < arg)) { cost = s_best[1]; arg = s_arg[1]; }
+    // one phase expected (the cheapest K covers every ray of this batch): K = the latest termination point + a margin as wide as
+    // the tail of this batch's distribution (latest - 99th percentile), for the next batch's rays are not this batch's;
+    // two phases expected: the cheapest K as it is
+    int next = arg;
+    if (arg >= 1024 || totC - pC[arg] == 0) {
+      int fmax = 0, f99 = 0;
+      const int want99 = totC - totC / 100;
+      for (int k = 1024; k >= 0; k--) if (hC[k] > 0) { fmax = k; break; }
+      for (int k = 0; k < 1024; k++) if (pC[k] >= want99) { f99 = k; break; }
+      if (f99 == 0 || f99 > fmax) f99 = fmax;
+      const int margin = fmax - f99 > 2 ? fmax - f99 : 2;
+      next = fmax + margin;
+    }
+    if (!enabled || next > 1024) next = 1024;
+    // a split has to save samples to pay for itself (list indirection, the extra small launches; with activation planes also their
+    // unaligned rows): a new one at least save_enter of them, a running one save_stay (no flip-flopping around the break-even
+    // point: a captured step is captured again when the mode changes)
+    if (next < 1024) {
+      const float kept = ((float)pKN[next] + (float)next * (float)(totN - pN[next])) / fmaxf((float)totKN, 1.f);
+      if (1.f - kept < (k_used >= 1024 ? save_enter : save_stay)) next = 1024;
+    }
+    // this step's counters (samples of phase A; rays, samples of phase B; the K used) for whoever wants to look
+    stats_last[0] = stats[0] < 0 ? totKN : stats[0]; stats_last[1] = stats[3]; stats_last[2] = stats[2]; stats_last[3] = k_used;
+    *k_split = next;
   }
 }
 
@@ -500,8 +689,50 @@ int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
     tminmax_init_kernel<<<1, 1, 0, st>>>(t_minmax);
     GFN_CHECK_LAUNCH();
   }
-  composite_fwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, sigma, dt, t, rgb, early_T,
-                                                                    weights, alphas, out_rgb, out_acc, out_depth, t_minmax);
+  composite_fwd_kernel<false><<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, sigma, dt, t, rgb, early_T,
+                                                                           weights, alphas, out_rgb, out_acc, out_depth, t_minmax, PhaseArgs{});
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_composite_fwd_phased(const int32_t* pts_offsets, int64_t n_rays, const float* sigma, const float* dt, const float* t,
+                             const float* rgb, float early_T, float* weights, float* alphas, float* out_rgb, float* out_acc,
+                             float* out_depth, float* t_minmax, const uint8_t* ray_gate, const int32_t* gate, const int32_t* k_split,
+                             uint8_t* need_more, int32_t* term, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && out_rgb && term, "gfn_composite_fwd_phased: null pointer");
+  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_composite_fwd_phased: n_rays=%lld", (long long)n_rays);
+  GFN_CHECK_ARG(!k_split || need_more, "gfn_composite_fwd_phased: the first pass needs need_more");
+  GFN_CHECK_ARG(!(ray_gate && t_minmax), "gfn_composite_fwd_phased: the t range belongs to the pass over all rays");
+  hipStream_t st = gfn_stream(stream);
+  if (t_minmax) {
+    tminmax_init_kernel<<<1, 1, 0, st>>>(t_minmax);
+    GFN_CHECK_LAUNCH();
+  }
+  PhaseArgs P{ray_gate, gate, k_split, need_more, term};
+  composite_fwd_kernel<true><<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, sigma, dt, t, rgb, early_T,
+                                                                          weights, alphas, out_rgb, out_acc, out_depth, t_minmax, P);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_split, const uint8_t* need_more, int32_t* coff,
+                   int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && k_split && coff && list && stats && n_rays > 0 && n_rays < (1ll << 24), "gfn_phase_list: bad arguments");
+  GFN_CHECK_ARG((zero_sigma == nullptr) == (zero_rgb == nullptr) && !(zero_sigma && need_more), "gfn_phase_list: sigma and rgb are cleared together, in phase A");
+  hipStream_t st = gfn_stream(stream);
+  phase_scan_kernel<<<1, 1024, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more, coff, stats);
+  GFN_CHECK_LAUNCH();
+  phase_fill_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more ? 1 : 0, coff, list, zero_sigma, zero_rgb);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_two_phase_plan(const int32_t* pts_offsets, int64_t n_rays, const int32_t* term, int32_t* k_split, int32_t* stats,
+                       int32_t* stats_last, float fixed_cost_samples, float save_enter, float save_stay, int enabled, void* stream) {
+  GFN_CHECK_ARG(pts_offsets && term && k_split && stats && stats_last && n_rays >= 0 && n_rays < (1ll << 20), "gfn_two_phase_plan: bad arguments");
+  two_phase_plan_kernel<<<1, 1024, 0, gfn_stream(stream)>>>(pts_offsets, (int)n_rays, term, k_split, stats, stats_last, fixed_cost_samples, save_enter, save_stay, enabled);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -31,14 +31,24 @@ def rank(group=None):
 
 
 def allreduce_mean(tensors, group=None):
-    """In-place average over ranks of a list of gradient tensors.  Every tensor is scaled by 1/world BEFORE the sum, so
-    the f16 x128-scaled table pool cannot overflow in the reduction however many ranks add up."""
+    """In-place average over ranks of a list of gradient tensors.  f16 tensors (the x128-scaled table-gradient pool) are summed in
+    f32, chunk by chunk, and rounded to f16 once -- like the direct path (gfn_reduce_shards): no overflow however many ranks add
+    up, no bits lost to a pre-scaled f16 sum; everything else is scaled by 1/world and summed in its own type."""
     w = world(group)
     if w == 1:
         return tensors
     for t in tensors:
-        t.mul_(1.0 / w)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.dtype == torch.float16:
+            flat = t.view(-1) if t.is_contiguous() else None
+            if flat is None:
+                raise ValueError("allreduce_mean: f16 gradients must be contiguous")
+            for chunk in flat.split(1 << 24):
+                f = chunk.float()
+                dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
+                chunk.copy_(f.mul_(1.0 / w))
+        else:
+            t.mul_(1.0 / w)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return tensors
 
 
@@ -73,6 +83,32 @@ def allreduce_mean_direct(t, group=None, recv=None, shard_mean=None):
     (shard_mean or _hip_shard_mean)(recv, w, mine)     # written in place into my slice of t ...
     dist.all_gather_into_tensor(t, mine.clone(), group=group)  # ... and published to everyone (same bits on every rank)
     return t
+
+
+def allreduce_selfcheck(n=1 << 20, device="cuda", group=None, shard_mean=None):
+    """Start-up check of the gradient exchange on the live communicator: allreduce_mean_direct (all_to_all_single + gfn_reduce_shards
+    + all_gather_into_tensor) of a seeded f16 buffer of n elements -- at the x128 scale of the table-gradient pool, with entries a
+    plain f16 SUM over the ranks would overflow -- against dist.all_reduce of the same values in f32.  -> dict(ok, max_abs_err,
+    n, dtype) (identical on every rank)."""
+    w, r = world(group), rank(group)
+    if w == 1:
+        return dict(ok=True, max_abs_err=0.0, n=0, world=1)
+    n = n // (8 * w) * (8 * w)
+    g = torch.Generator(device="cpu").manual_seed(1234 + r)
+    x32 = (torch.randn(n, generator=g) * 64.0)
+    x32[:: 97] = 40000.0  # w of these would overflow an f16 sum (65504)
+    x16 = x32.to(torch.float16).to(device)
+    want = x16.float()
+    dist.all_reduce(want, op=dist.ReduceOp.SUM, group=group)
+    want = (want / w).to(torch.float16)
+    got = allreduce_mean_direct(x16.clone(), group, shard_mean=shard_mean)
+    err = (got.float() - want.float()).abs().max()
+    worst = err.clone()
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
+    finite = torch.isfinite(got.float()).all().to(torch.float32)
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN, group=group)
+    tol = 32.0  # one f16 ulp at 40000 (the mean is rounded to f16 once on either side)
+    return dict(ok=bool(worst.item() <= tol and finite.item() == 1.0), max_abs_err=float(worst.item()), n=int(n), world=w, dtype="f16")
 
 
 def block_owner(block, world_size):

@@ -70,6 +70,12 @@ class HotPathConfig:
     record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
     prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
+    two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
+                                     # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
+                                     # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
+    two_phase_fixed_cost: float = 150e3  # what starting phase B costs, in samples (two table sweeps + small kernels ~ 0.15 ms)
+    two_phase_min_saving: tuple = (0.12, 0.06)  # samples a split must save to be started / to be kept (break-even ~ 9 %: measured);
+    two_phase_min_saving_planes: tuple = (0.30, 0.20)  # ... in the global stage: compacted samples write unaligned activation-plane rows
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
                                       # one-gather-per-corner image; False: own primes per table, like the reference
@@ -156,6 +162,8 @@ class HotPath:
         # buffers, and the groups whose buffers hold this iteration's gradients ("table", "block<i>", "mlp", "emb")
         self.fused_optimizers = weakref.WeakSet()
         self.grad_ready = set()
+        self._phase = None  # ops.PhaseState of the phased training forward (made for one batch size)
+        self.phase_override = None  # False: one-phase forward whatever cfg.two_phase says (StepGraph: the plan said a split does not pay)
 
     def add_block(self, i, table=None, prims=None):
         """GFNeRFField.add_table (nerfacto_field.py:336-347): make residual block table i resident -- zeros and fresh primes
@@ -359,6 +367,55 @@ class HotPath:
         rgb = self._timed("head_fwd", ops.linear_fwd, c2, hW2, hb2, "sigmoid", n_dev=n_dev)
         return dict(feat=feat, a1=a1, h=h, xh=xh, c1=c1, c2=c2, rgb=rgb, sigma=sigma)
 
+    def phase_state(self, n_rays, cap):
+        if self._phase is None or self._phase.n_rays != n_rays or self._phase.cap < cap:
+            self._phase = ops.PhaseState(n_rays, cap, self.dev)
+        return self._phase
+
+    def _forward_phased(self, s, cam_idx, block, save, planes, want_depth):
+        """The termination-aware level-major training forward (include/gfnerf_amd.h, gfn_composite_fwd_phased): phase A = the first K
+        samples of every ray through lookup(s) + decoder + compositing; phase B = the rest of the rays that are still transparent
+        behind them (its launches return at once when there is none); then the next step's K.  -> (field dict, comp dict)."""
+        c = self.cfg
+        n_dev = s["n_dev"]
+        T, V = c.log2_T, self.n_volumes
+        R = s["pts_offsets"].numel() - 1
+        st = self.phase_state(R, s["ts"].shape[0])
+        emb = self.emb if c.use_appearance_embedding else None
+        sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
+        lm_kw = dict(n_dev=n_dev, halves_from=c.lm_halves_from, split_log2=c.lm_split_log2, planar=True)
+        tables = [(self.table16, self.prim)] + ([(self.blocks16[block], self.block_prims[block])] if block is not None else [])
+
+        def lookups(name, samples, feat, first):
+            for i, (tab, prim) in enumerate(tables):
+                if i == 1 and first:
+                    self._sync_opt()  # the block table's lookup waits for the previous step's (asynchronous) Adam; the frozen global table's does not
+                feat = self._timed(name, ops.hash_fwd_lm, tab, prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T, out=feat,
+                                   accumulate=i > 0, sample_list=samples, **lm_kw)
+            return feat
+
+        if block is None:
+            self._sync_opt()
+        f = ops.field_outputs(s["ts"].shape[0], self.dev, save=save)
+        sa = self._timed("phase_list", ops.phase_list, s["pts_offsets"], st, zero=(f["sigma"], f["rgb"]))
+        feat = lookups("hash_fwd", sa, None, True)
+        if self.after_lookup is not None:
+            self.after_lookup()
+        self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save, precision="x3",
+                    image=self._x3()[0], planes=planes, sample_list=sa, out=f)
+        comp = self._timed("composite_fwd", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
+                           want_t_range=want_depth)
+        sb = self._timed("phase_list_b", ops.phase_list, s["pts_offsets"], st, phase_b=True)
+        lookups("hash_fwd_b", sb, feat, False)
+        self._timed("field_fwd_b", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save, precision="x3",
+                    image=self._x3()[0], planes=planes, sample_list=sb, out=f)
+        self._timed("composite_fwd_b", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
+                    second=True, out=comp)
+        enter, stay = c.two_phase_min_saving_planes if planes is not None else c.two_phase_min_saving
+        self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
+        f["feat"] = feat
+        return f, comp
+
     def _fused_ok(self, block):
         c = self.cfg
         return c.fused_forward and c.fused_field and c.hidden == 128 and c.mlp_precision == "x3" and c.table_f16_shadow
@@ -552,8 +609,11 @@ class HotPath:
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
         lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
               and not c.keep_features and not (blk is not None and c.share_block_primes))
-        self.last_forward = "lm" if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
-        if fused and self._fused_ok(blk) and not lm:
+        phased = lm and c.two_phase and c.early_T > 0 and self.phase_override is not False
+        self.last_forward = ("lm2" if phased else "lm") if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
+        if phased:
+            f, comp = self._forward_phased(s, cam_idx, blk, True, planes, want_depth)
+        elif fused and self._fused_ok(blk) and not lm:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
         else:
             f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes, lm=lm)

@@ -82,10 +82,14 @@ _part_ws = {}
 
 
 def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
-                halves_from=6, planar=False, accumulate=False, split_log2=0):
+                halves_from=6, planar=False, accumulate=False, split_log2=0, sample_list=None):
     """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time
     (levels >= halves_from in 2^split_log2 parts; 0 = halves).
-    planar: out is float2 [16, n] (level-major) instead of f32 [n, 32]."""
+    planar: out is float2 [16, n] (level-major) instead of f32 [n, 32].
+    sample_list = (list i32 [>= count] of ascending sample indices, count i32 [1]): only those samples are looked up (nothing at all
+    when the count is 0)."""
+    lst, lst_n = sample_list if sample_list is not None else (None, None)
+    _chk(lst, torch.int32, "sample_list"); _chk(lst_n, torch.int32, "sample_list count")
     _chk(table_f16, torch.float16, "table_f16"); _chk(table2_f16, torch.float16, "table2_f16"); _chk(prim_pool, torch.int32, "prim_pool")
     _chk(prim_pool2, torch.int32, "prim_pool2"); _chk(bias_pool, torch.float32, "bias_pool"); _chk(pts, torch.float32, "pts", 3)
     _chk(anchors, torch.int32, "anchors")
@@ -96,7 +100,8 @@ def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T
     if out.numel() != n * 32:
         raise _lib.GfnError("hash_fwd_lm: out must hold 32 features per sample")
     rc = _lib.lib().gfn_hash_fwd_lm(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
-                                    _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(split_log2), int(bool(planar)), int(bool(accumulate)), _ptr(out), _stream())
+                                    _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(split_log2), int(bool(planar)), int(bool(accumulate)), _ptr(out),
+                                    _ptr(lst), _ptr(lst_n), _stream())
     _lib.check(rc, "gfn_hash_fwd_lm")
     return out
 
@@ -676,11 +681,25 @@ def field_pack_x3(layers, fwd_image=None, bwd_image=None, want_fwd=True, want_bw
     return fwd_image, bwd_image
 
 
-def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None, planes=None):
+def field_outputs(n, device, save=True):
+    """Uninitialised outputs of field_fwd for n sample slots (to be passed as `out`)."""
+    return dict(sigma=torch.empty(n, dtype=torch.float32, device=device), rgb=torch.empty((n, 3), dtype=torch.float32, device=device),
+                h0=torch.empty(n, dtype=torch.float32, device=device) if save else None,
+                masks=torch.empty((n, 6), dtype=torch.int64, device=device) if save else None)
+
+
+def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None, planes=None, sample_list=None,
+              out=None):
     """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None).
     precision "x3": split-f16 MFMA (f32 accuracy, ~5x the f32 matrix rate; `image` = a current forward image from
     field_pack_x3, built here when absent); "f32": exact f32 MFMA.
-    feat: f32 [n,32], or the level-major [16,n,2] of hash_fwd_lm(planar=True) (x3 only)."""
+    feat: f32 [n,32], or the level-major [16,n,2] of hash_fwd_lm(planar=True) (x3 only).
+    sample_list (x3 only) = (list i32, count i32 [1]): decode only those samples; the others keep what `out` (the dict an earlier
+    call returned, or field_outputs(), written again) holds."""
+    lst, lst_n = sample_list if sample_list is not None else (None, None)
+    _chk(lst, torch.int32, "sample_list"); _chk(lst_n, torch.int32, "sample_list count")
+    if (lst is not None or out is not None) and precision != "x3":
+        raise _lib.GfnError("field_fwd: sample lists need the x3 decoder")
     planar = feat.dim() == 3
     _chk(feat, torch.float32, "feat", 2 if planar else 32); _chk(ray_id, torch.int32, "ray_id"); _chk(sh, torch.float32, "sh", 16)
     _chk(emb, torch.float32, "emb", 32); _chk(cam_idx, torch.int32, "cam_idx")
@@ -688,17 +707,23 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
         raise _lib.GfnError("field_fwd: level-major features are [16,n,2] and need the x3 decoder")
     n = feat.shape[1] if planar else feat.shape[0]
     dev = feat.device
-    sigma = torch.empty(n, dtype=torch.float32, device=dev)
-    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    h0 = torch.empty(n, dtype=torch.float32, device=dev) if save else None
-    masks = torch.empty((n, 6), dtype=torch.int64, device=dev) if save else None
+    if out is not None:
+        sigma, rgb, h0, masks = out["sigma"], out["rgb"], out["h0"], out["masks"]
+        if sigma.numel() != n or (save and masks is None):
+            raise _lib.GfnError("field_fwd: `out` was made for another batch / option set")
+    else:
+        sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        h0 = torch.empty(n, dtype=torch.float32, device=dev) if save else None
+        masks = torch.empty((n, 6), dtype=torch.int64, device=dev) if save else None
     if precision == "x3":
         if image is None:
             image, _ = field_pack_x3(layers, want_bwd=False)
         ph, pl = planes if planes is not None else (None, None)
         cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)  # split-f16 activation planes for the weight gradients (global stage)
         rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
-                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, n if planar else 0, _stream())
+                                         _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, n if planar else 0,
+                                         _ptr(lst), _ptr(lst_n), _stream())
         _lib.check(rc, "gfn_field_fwd_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)
@@ -1026,6 +1051,72 @@ def composite_fwd(pts_offsets, sigma, dt, t, rgb, early_T=0.0, want_weights=True
                                       _ptr(t_minmax), _stream())
     _lib.check(rc, "gfn_composite_fwd")
     return dict(weights=weights, alphas=alphas, rgb=out_rgb, acc=out_acc, depth_raw=out_depth, t_minmax=t_minmax)
+
+
+class PhaseState:
+    """Device-side state of the phased (termination-aware) training forward for batches of n_rays rays / cap sample slots."""
+
+    def __init__(self, n_rays, cap, device):
+        i32 = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=device)  # noqa: E731
+        self.n_rays, self.cap = int(n_rays), int(cap)
+        self.k = i32(1, 1024)        # K of the next forward (1024 = one phase); gfn_two_phase_plan rewrites it every step
+        self.stats = i32(4)          # [samples, rays of phase A, samples, rays of phase B] of the step in flight
+        self.stats_last = i32(4)     # [samples of phase A, rays of phase B, samples of phase B, K] of the last finished step
+        self.list_a, self.list_b = i32(cap), i32(cap)
+        self.coff = i32(n_rays + 1)
+        self.need_more = torch.zeros(n_rays, dtype=torch.uint8, device=device)
+        self.term = i32(n_rays)
+
+    def samples(self, phase_b=False):
+        """(list, count) of a phase for hash_fwd_lm / field_fwd."""
+        return (self.list_b, self.stats[2:3]) if phase_b else (self.list_a, self.stats[0:1])
+
+
+def phase_list(pts_offsets, st, phase_b=False, zero=None):
+    """Build the sample list of phase A (the first K samples of every ray) or phase B (samples K.. of the rays with need_more).
+    zero = (sigma [n], rgb [n,3]) (phase A): the samples that are NOT listed get sigma = rgb = 0."""
+    _chk(pts_offsets, torch.int32, "pts_offsets")
+    zs, zr = zero if zero is not None else (None, None)
+    _chk(zs, torch.float32, "sigma"); _chk(zr, torch.float32, "rgb", 3)
+    if st.n_rays != pts_offsets.numel() - 1:
+        raise _lib.GfnError("phase_list: the PhaseState was made for another batch size")
+    rc = _lib.lib().gfn_phase_list(_ptr(pts_offsets), st.n_rays, _ptr(st.k), _ptr(st.need_more) if phase_b else None, _ptr(st.coff),
+                                   _ptr(st.list_b if phase_b else st.list_a), _ptr(st.stats), _ptr(zs), _ptr(zr), _stream())
+    _lib.check(rc, "gfn_phase_list")
+    return st.samples(phase_b)
+
+
+def composite_fwd_phased(pts_offsets, sigma, dt, t, rgb, st, early_T, second=False, want_t_range=True, out=None):
+    """composite_fwd inside the phased forward.  First pass (second=False): every ray, + which rays still need their samples behind K
+    (st.need_more) and where every ray ends (st.term).  Second pass: only the rays with need_more, into the tensors of `out` (the
+    first pass's result); nothing when phase B is empty."""
+    _chk(pts_offsets, torch.int32, "pts_offsets"); _chk(sigma, torch.float32, "sigma"); _chk(dt, torch.float32, "dt")
+    _chk(t, torch.float32, "t"); _chk(rgb, torch.float32, "rgb", 3)
+    R = pts_offsets.numel() - 1
+    dev = sigma.device
+    n = sigma.shape[0]
+    if st.n_rays != R or st.cap < n:
+        raise _lib.GfnError("composite_fwd_phased: the PhaseState was made for another batch size")
+    if second:
+        if out is None:
+            raise _lib.GfnError("composite_fwd_phased: the second pass writes into the first pass's outputs")
+        o = out
+        t_minmax = None
+    else:
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        o = dict(weights=f32(n), alphas=f32(n), rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2) if want_t_range else None)
+        t_minmax = o["t_minmax"]
+    rc = _lib.lib().gfn_composite_fwd_phased(_ptr(pts_offsets), R, _ptr(sigma), _ptr(dt), _ptr(t), _ptr(rgb), float(early_T), _ptr(o["weights"]),
+                                             _ptr(o["alphas"]), _ptr(o["rgb"]), _ptr(o["acc"]), _ptr(o["depth_raw"]), _ptr(t_minmax),
+                                             _ptr(st.need_more) if second else None, _ptr(st.stats[2:3]) if second else None,
+                                             None if second else _ptr(st.k), None if second else _ptr(st.need_more), _ptr(st.term), _stream())
+    _lib.check(rc, "gfn_composite_fwd_phased")
+    return o
+
+
+def two_phase_plan(pts_offsets, st, fixed_cost_samples, save_enter=0.12, save_stay=0.06, enabled=True):
+    _lib.check(_lib.lib().gfn_two_phase_plan(_ptr(pts_offsets), pts_offsets.numel() - 1, _ptr(st.term), _ptr(st.k), _ptr(st.stats), _ptr(st.stats_last),
+                                            float(fixed_cost_samples), float(save_enter), float(save_stay), int(bool(enabled)), _stream()), "gfn_two_phase_plan")
 
 
 def depth_finalize(depth_raw, t_minmax, scale_factor):

@@ -27,8 +27,13 @@ from . import _lib, hotpath as hp_mod, ops
 
 
 class StepGraph:
-    def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None, draws_after_lookup=True):
-        """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant)."""
+    def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None, draws_after_lookup=True,
+                 replan_every=2048):
+        """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant).
+        replan_every: the phased (termination-aware) forward costs a handful of small launches even when its plan is "one phase, every
+        sample" (an empty scene: nothing terminates).  At capture the plan is read back once (a forward of the batch at hand, no
+        training step) and the step is captured WITHOUT the phase machinery when it says so; after this many replays the step is
+        captured again, so that the choice follows the scene as it fills."""
         if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL:
             raise _lib.GfnError("StepGraph: the data-parallel global stage exchanges gradients with eager collectives; not captured")
         self.hp, self.stage, self.R = hp, stage, int(n_rays)
@@ -59,6 +64,9 @@ class StepGraph:
         self.p = 0  # position in the cycle of the next replay
         self.primed = False
         self._tree = None
+        self.replan_every, self._since_capture, self.phased = int(replan_every), 0, None
+        self._k_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()  # the plan's K as the replays leave it (copied inside the graph)
+        self._idle = 0
 
     # ------------------------------------------------------------------ set-up
     def _noise(self, out=None):
@@ -101,6 +109,8 @@ class StepGraph:
                                       prefetch_out=self.S[1 - p], hyper=self.hyper)
         finally:
             hp.after_lookup = None
+        if hp.last_forward == "lm2":  # the planned K travels to the host with every replay (no synchronisation: step() reads it late)
+            self._k_host.copy_(hp._phase.k, non_blocking=True)
         assert hp._pre is not None and hp._pre[4]["pts_offsets"] is self.S[1 - p]["pts_offsets"], "the prefetch must fill the other sample buffer"
         self.S[1 - p] = hp._pre[4]
         hp._pre = None  # collected: the next replay reads it as its `samples`
@@ -119,6 +129,19 @@ class StepGraph:
             hp._adam_state(name, self._param_of(name))
         hp.tree_depth()  # (synchronises when the tree is new: not under capture)
         self._refresh_hyper(advance=False)
+        # does a termination-aware split pay on this scene right now?  Plan it from the batch at hand (forward only), read the plan back
+        hp.phase_override = None
+        self.phased = None
+        if hp.cfg.two_phase and hp.cfg.early_T > 0:
+            j0 = self.p
+            stale = hp._x3_stale  # (the forward repacks stale decoder weight images: the captured step must still do that itself)
+            hp.forward_train(None, None, self.cam, None, stage=self.stage, block=self.blocks[j0 % len(self.blocks)], want_depth=False, samples=self.S[j0 % 2])
+            hp._x3_stale = stale
+            if hp.last_forward == "lm2":
+                self.phased = int(hp._phase.k.item()) < 1024
+                hp.phase_override = None if self.phased else False
+        self._since_capture, self._idle = 0, 0
+        self._k_host.fill_(-1)
         torch.cuda.synchronize()
         steps_before, ticks_before = hp.step, dict(hp._adam_t)
         pool = None
@@ -171,6 +194,11 @@ class StepGraph:
         """One training step on the batch whose rays the previous step (or prime) sampled; next_rays_*: the rays of the batch
         the NEXT call will train on.  -> (loss [1] device tensor of this step, aux) -- static buffers, overwritten by the next call."""
         hp = self.hp
+        self._since_capture += 1
+        if self.phased:  # captured with the phase machinery: still worth it?  (the plan of a few replays ago, read without waiting)
+            self._idle = self._idle + 1 if int(self._k_host[0]) >= 1024 else 0
+        if hp.cfg.two_phase and (self._since_capture > self.replan_every or self._idle >= 16):
+            self.invalidate()  # plan the phases (and choose the forward kernels) again: the scene has moved on
         if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
             self.capture()
         ops.copy_list([(self.cam, cam_idx.contiguous()), (self.gt, gt_rgb.contiguous()), (self.nxt_o, next_rays_o.contiguous()),

@@ -119,11 +119,15 @@ int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const 
  * at a time, so that the slots being gathered fit the XCDs' L2 instead of missing to the
  * fabric.  Bit-identical features.  anchors i32, element i at anchors[i*anchor_stride].  planar != 0: out is
  * level-major, float2 [16][n_max] (coalesced stores; what gfn_field_fwd_x3 reads with feat_stride = n_max).
- * accumulate != 0: out += features.  One launch per table. */
+ * accumulate != 0: out += features.  One launch per table.
+ * list / list_n (device i32 [*list_n] ascending sample indices + its length, both or neither): only those samples are looked
+ * up -- every workgroup takes an equal run of the LIST --, the others' feature slots are left untouched, and the launch does
+ * nothing when *list_n == 0: the phased (termination-aware) training forward, see gfn_composite_fwd_phased. */
 int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const int32_t* anchors,
                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
-                    int halves_from, int split_log2, int planar, int accumulate, float* out, void* stream);
+                    int halves_from, int split_log2, int planar, int accumulate, float* out,
+                    const int32_t* list, const int32_t* list_n, void* stream);
 /* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
 int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
 
@@ -282,7 +286,9 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * gfn_grad_scale_host(*gmax_dev) (gmax_dev: device f32 = largest |gradient| entering the decoder,
  * from gfn_grad_max into a zeroed word), and accumulates the appearance-embedding gradient into
  * demb f32 [n_cams,32] (may be NULL).  gfn_wgrad_x3 turns pairs of planes into weight gradients.
- * feat_stride: 0 = feat is f32 [n,32]; else feat is level-major float2 [16][feat_stride] (gfn_hash_fwd_lm, planar). */
+ * feat_stride: 0 = feat is f32 [n,32]; else feat is level-major float2 [16][feat_stride] (gfn_hash_fwd_lm, planar).
+ * gfn_field_fwd_x3 with list / list_n (as in gfn_hash_fwd_lm) decodes only the listed samples, 32 consecutive ENTRIES per tile;
+ * outputs and plane rows of the other samples are not touched; nothing is done when *list_n == 0. */
 #define GFN_FIELD_X3_FWD_BYTES 149248
 #define GFN_FIELD_X3_BWD_BYTES 131072
 #define GFN_FIELD_X3_FWD_PLANE_LD 480
@@ -291,7 +297,8 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
                      float* sigma, float* rgb, float* h0, uint64_t* masks, uint16_t* planes_hi,
-                     uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, void* stream);
+                     uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, const int32_t* list,
+                     const int32_t* list_n, void* stream);
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                         float* dfeat, void* stream);
@@ -459,6 +466,40 @@ int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
                       const float* dt, const float* t, const float* rgb, float early_T,
                       float* weights, float* alphas, float* out_rgb, float* out_acc,
                       float* out_depth, float* t_minmax, void* stream);
+/* The termination-aware ("phased") training forward.  The reference evaluates every sample of every ray (1024 padded ones,
+ * PersSampler_cuda.cu:437-444, nerfacto_field.py:443); with early_T > 0 the samples behind a ray's termination point
+ * (transmittance < early_T) cannot change the image by more than early_T, and here they are not even looked up:
+ *   gfn_phase_list (need_more = NULL)   list_a = the first min(K, n_r) samples of every ray, K = *k_split, compacted by a prefix
+ *                           sum over the rays (coff i32 [n_rays + 1] workspace); stats[0] = entries, stats[1] = rays.  K >= 1024
+ *                           (one phase): no list is written and stats[0] = -1, which the two kernels below read as "every
+ *                           live sample"
+ *   gfn_hash_fwd_lm / gfn_field_fwd_x3 (list = list_a, list_n = stats)                       -- phase A
+ *                           (sigma and rgb of every other sample must be zero: gfn_phase_list clears them when given
+ *                           zero_sigma f32 [n] / zero_rgb f32 [n,3], phase A only)
+ *   gfn_composite_fwd_phased(k_split = K)   composites all rays (samples behind K count as empty) and marks the rays that are
+ *                           longer than K and not yet terminated: need_more u8 [n_rays]; term i32 [n_rays] = samples in front
+ *                           of each ray's termination point
+ *   gfn_phase_list (need_more)          list_b = samples K.. of those rays; stats[2] = entries, stats[3] = rays
+ *   the same two kernels with list = list_b, list_n = stats + 2                              -- phase B (nothing, as a rule)
+ *   gfn_composite_fwd_phased(ray_gate = need_more, gate = stats + 2)   composites those rays again, all samples now known
+ *   gfn_two_phase_plan      picks the next step's K from this batch's (ray length, termination point) pairs: the K that
+ *                           minimises samples(phase A) + [phase B needed] * (fixed_cost_samples + samples(phase B)); when that
+ *                           K covers every ray: the latest termination point + the width of the distribution's tail; 1024 when
+ *                           the split would save too little (a new split has to save the fraction save_enter of the samples, a running one save_stay); stats_last = (samples of phase A, rays of phase B, samples of phase B, the K just used).
+ *                           enabled == 0: K = 1024 (one phase: every sample, the reference's semantics with early_T = 0).
+ *                           n_rays < 2^20.
+ * All of it is decided on the device: no host round trip, capturable in a hipGraph.  The backward needs no change: samples
+ * that were never evaluated hold zero sigma / rgb and receive zero gradients. */
+int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_split, const uint8_t* need_more,
+                   int32_t* coff, int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb, void* stream);
+int gfn_composite_fwd_phased(const int32_t* pts_offsets, int64_t n_rays, const float* sigma, const float* dt,
+                             const float* t, const float* rgb, float early_T, float* weights, float* alphas,
+                             float* out_rgb, float* out_acc, float* out_depth, float* t_minmax,
+                             const uint8_t* ray_gate, const int32_t* gate, const int32_t* k_split,
+                             uint8_t* need_more, int32_t* term, void* stream);
+int gfn_two_phase_plan(const int32_t* pts_offsets, int64_t n_rays, const int32_t* term, int32_t* k_split,
+                       int32_t* stats, int32_t* stats_last, float fixed_cost_samples, float save_enter, float save_stay,
+                       int enabled, void* stream);
 int gfn_depth_finalize(float* depth, int64_t n_rays, const float* t_minmax, float scale_factor,
                        void* stream);
 int gfn_composite_bwd(const int32_t* pts_offsets, int64_t n_rays, const float* sigma,

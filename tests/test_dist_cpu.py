@@ -81,6 +81,10 @@ def _worker(rank, world, port, q):
         hotpath.HotPath.sync_grads(fake2, hotpath.STAGE_GLOBAL, {})
         t3 = g_mine[0].clone()
         hotpath.HotPath.sync_grads(types.SimpleNamespace(sync=sync, grads=lambda stage: [t3]), hotpath.STAGE_FOCAL, {})
+        # the f16 pool through the plain path (sizes the direct path cannot split, gloo rehearsals): summed in f32, rounded once
+        t4 = g_mine[0].clone()
+        gd.allreduce_mean([t4])
+        check = gd.allreduce_selfcheck(n=1 << 16, device="cpu", shard_mean=torch_shard_mean)
         same = sync.replicas_identical([table_grad, mlp_grad])
         differ = sync.replicas_identical([torch.full((9,), float(rank))])
         q.put(dict(rank=rank, mine=[m.numpy() for m in mine], avg=[t.numpy() for t in grads], stats=stats[0].numpy(), blocks=blocks,
@@ -89,6 +93,7 @@ def _worker(rank, world, port, q):
                    oct_mine=[t.numpy() for t in oct_mine], oct=[scratch.numpy(), visit.numpy()],
                    g_mine=[t.float().numpy() for t in g_mine], first=[t.float().numpy() for t in first],
                    second=[t.float().numpy() for t in (t2, m2, e2)], focal_untouched=bool(torch.equal(t3, g_mine[0])),
+                   plain_f16=t4.float().numpy(), selfcheck=check,
                    same=same, differ=differ, ranks_seen=sync.ranks_seen(), stats_sync=dict(sync.stats)))
     finally:
         dist.destroy_process_group()
@@ -130,6 +135,8 @@ def test_two_rank_collectives_and_hotpath_hooks():
             np.testing.assert_allclose(r0[key][k], want, rtol=2e-6 if k else 0, atol=0)
             assert np.array_equal(r0[key][k], r1[key][k])
         assert np.isfinite(r0[key][0]).all() and r0[key][0][5] == np.float32(np.float16(54976.0))  # (59968 + 49984) / 2
+    assert np.array_equal(r0["plain_f16"], r0["first"][0]) and np.array_equal(r1["plain_f16"], r0["first"][0])  # same bits as the direct path
+    assert r0["selfcheck"]["ok"] and r0["selfcheck"] == r1["selfcheck"] and r0["selfcheck"]["world"] == 2
     assert r0["focal_untouched"] and r1["focal_untouched"]
     assert r0["same"] and r1["same"] and not r0["differ"] and not r1["differ"]
     assert r0["ranks_seen"] == 2 and r1["ranks_seen"] == 2

@@ -73,12 +73,31 @@ def test_bench_self_spawns_two_ranks():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(lines[0]) < 2000, len(lines[0])  # the driver keeps the tail of the log: the line must fit
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "errors" not in d
+    assert d["config"]["global_ms_per_step"] > 0 and d["config"]["global_rays_per_sec"] > 0 and d["config"]["render_ms_per_mpix"] > 0
+    assert d["config"]["replicas_bit_identical"] is True and d["config"]["backend"] == "gloo"
+    # the sub-records in full are on stderr
+    det = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench-details] ")]
+    assert len(det) == 1
+    d = json.loads(det[0][len("[bench-details] "):])
     assert "1 block per GPU" in d["config"]["workload"] and "no data-path collective" in d["config"]["parallelism"]
     g = d["global_stage"]
     assert "error" not in g, g
     assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and g["sync"]["grad_reduces"] >= 3
     assert d["render"]["frames"] == 2 and "routed" in d["render"]["routing"]
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_bench_does_not_fall_back_when_rccl_cannot_be_used():
+    """`--backend nccl` with two ranks on ONE card (RCCL refuses that): the job must end with a non-zero exit code and no result
+    line -- never a line that claims N GPUs after a quiet switch to gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "nccl", "--n-side", "6", "--log2-T", "16",
+           "--steps", "2", "--warmup", "0", "--global-steps", "0", "--render-frames", "0", "--no-cpu-baseline", "--job-timeout", "150"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode != 0, p.stdout
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
