@@ -76,6 +76,9 @@ def parse():
                     help="torch.distributed backend at N > 1 (auto: RCCL whenever every rank has its own GPU -- a failure there is an error, "
                          "never a silent fall-back --, gloo only with --share-gpu; gloo: explicitly, for rehearsals)")
     ap.add_argument("--job-timeout", type=float, default=1500.0, help="N > 1, self-spawned ranks: seconds after which the ranks are killed and the exit code is 124")
+    ap.add_argument("--psnr-steps", type=str, default="2000,1000",
+                    help="`psnr` sub-record (N = 1): global,focal training steps on the procedural scene per run, 2 seeds x {x3, f32 decoder}; "
+                         "0,0 = skip")
     ap.add_argument("--plugin-steps", type=int, default=100,
                     help="timed iterations of the `plugin_step` sub-records (the step through GFNerfPipeline + Optimizers, N = 1 only); 0 = skip")
     ap.add_argument("--share-gpu", action="store_true",
@@ -822,7 +825,7 @@ def compact_line(out):
     hoist("plugin_step_focal", (("value", "plugin_rays_per_sec"), ("ms_per_step", "plugin_ms_per_step")))
     hoist("plugin_step_global", (("value", "plugin_global_rays_per_sec"), ("ms_per_step", "plugin_global_ms_per_step")))
     hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
-    hoist("psnr", (("psnr_x3", "psnr"), ("psnr_f32", "psnr_f32_decoder"), ("steps", "psnr_train_steps")))
+    hoist("psnr", (("psnr_x3", "psnr"), ("psnr_f32", "psnr_f32_decoder"), ("delta_sigma", "psnr_delta_sigma"), ("steps", "psnr_train_steps")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
     for k in ("mfma_busy_frac", "mfma_tflops_issued"):
         if out["roofline"].get(k) is not None:
@@ -1051,6 +1054,17 @@ def run_rank(args):
             except Exception as e:  # noqa: BLE001
                 out[f"plugin_step_{stage_name}"] = dict(error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
+    # ---- PSNR: the engine trained on a procedural scene, split-f16 decoder beside the exact-f32 one (the reference's arithmetic)
+    pg, pf = (int(v) for v in args.psnr_steps.split(","))
+    if out is not None and world == 1 and pg + pf > 0:
+        from gfnerf_amd import procedural
+
+        try:
+            out["psnr"] = procedural.psnr_study(sc, steps_global=pg, steps_focal=pf, log2_T=args.log2_T,
+                                                progress=lambda m: print(f"[bench] {m}", file=sys.stderr))
+        except Exception as e:  # noqa: BLE001
+            out["psnr"] = dict(error=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
     if out is not None and not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
         out["cpu_reference_field"] = cpu_reference_field()
         out["cpu_baseline"] = cpu_baseline(P_focal, batches_focal[0], args.log2_T, fine_focal, args.cpu_rays,
