@@ -86,14 +86,10 @@ def parse():
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one address part at a time")
     ap.add_argument("--lm-split-log2", type=int, default=0, help="level-major lookup: 2^this address parts per level (0 / 1: halves; 2: quarters)")
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
-    ap.add_argument("--render-lm", action="store_true", help="render: level-major lookups + decoder + compositing kernels instead of the fused forward")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
-    ap.add_argument("--adam-chunks", type=int, default=1, help="the table's Adam runs this many chunks of slot ranges behind their accumulation on a second stream (1: one after the other)")
     ap.add_argument("--fork-first", action="store_true", help="forward_backward forks the octree update / next sampler before it enqueues the loss kernels (round-2 order)")
     ap.add_argument("--draws-first", action="store_true",
                     help="graph launch: start the next step's random draws at the top of the step (beside the lookups) instead of behind them")
-    ap.add_argument("--table-branch", action="store_true",
-                    help="global stage: table-gradient accumulation + table Adam on a second stream beside the weight-gradient kernels (no gain measured)")
     ap.add_argument("--async-adam", action="store_true",
                     help="focal stage: Adam of step i on a third stream beside the frozen global table's lookup of step i + 1 (about "
                          "-1.5 percent per step; off by default so that the roofline kernel is timed running alone)")
@@ -111,9 +107,6 @@ def parse():
     ap.add_argument("--render-tile-width", type=int, default=128, help="with --render-tile-rays: render tiles are blocks of this width (0 = raster runs)")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
-    ap.add_argument("--share-block-primes", action="store_true",
-                    help="block tables reuse the global table's primes (enables the interleaved one-gather-per-corner image); "
-                         "default: own primes per table like the reference")
     return ap.parse_args()
 
 
@@ -352,7 +345,6 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     zoom = W / 1152.0  # the synthetic capture's 1152-wide intrinsics scaled to the output width
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
-    hp.cfg.level_major_render = bool(args.render_lm)
     hp.cfg.render_patch_width = int(args.render_patch_width)
     tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=True,
                            tile_width=args.render_tile_width if args.render_tile_rays else None, pipeline=args.render_pipeline or None,
@@ -382,7 +374,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=True,
                 tiles_per_replay=tr.P,
                 kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep" % (args.render_patch_width, 32 // args.render_patch_width)
-                        if args.render_patch_width > 0 and not args.render_lm and tr.patch_tw is not None else "fused_fwd_kernel: a wave per ray" if not args.render_lm else "level-major kernels"),
+                        if args.render_patch_width > 0 and tr.patch_tw is not None else "fused_fwd_kernel: a wave per ray"),
                 tile=(f"{tr.tw}x{tr.T // tr.tw} pixel blocks" if tr.tw else "raster runs"),
                 table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
                 routing=("single GPU" if world == 1 else f"{n_frames} frames routed to the rank owning each frame's block "
@@ -523,11 +515,11 @@ class StageRun:
         self.ops = ops
         ga = args.lm_global_after
         self.cfg = cfg = hotpath.HotPathConfig(
-            log2_T=args.log2_T, early_T=args.early_T, share_block_primes=args.share_block_primes, mlp_precision=args.mlp_precision,
+            log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision,
             two_phase=not args.one_phase,
             prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
-            fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam, table_branch=args.table_branch,
-            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, adam_pipeline_chunks=args.adam_chunks, loss_before_fork=not args.fork_first,
+            fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
+            level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, loss_before_fork=not args.fork_first,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
             **({"level_major_global_after": ga} if ga is not None else {}))
         self.n_blocks = n_blocks
@@ -747,7 +739,7 @@ class StageRun:
                 print(f"bench.py: profiles/pmc_traffic.json predates {stale}: roofline.traffic not reported", file=sys.stderr)
                 pmc = {k: v for k, v in pmc.items() if k in ("l2_gather_ceiling_per_s", "gather_request_ceiling_per_s", "n_side")}
             # the PMC passes were taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21)
-            default_cfg = (not args.share_block_primes) and args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
+            default_cfg = args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
             traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
             n_req = pmc.get(f"{dom}:{self.stage}:fetch_requests") if default_cfg else None
             if lm:  # the level-major kernel is bound by the L2 -> L1 line fills of its gathers (86 % of them hit the L2), not by the fabric
@@ -949,7 +941,7 @@ def run_rank(args):
                                n_cameras=n_cams, n_cameras_spec=1600, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
                                fineness=run.fineness, stage=headline_stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
                                evaluated_sample_frac=n_eval / max(n_live, 1), fused_forward=bool(cfg.fused_forward),
-                               block_primes="shared with global table" if cfg.share_block_primes else "own per table (reference)",
+                               block_primes="own per table (reference)",
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("single GPU" if world == 1 else
                                             f"{world} focal blocks, 1 per GPU, {len(my_cams)} cameras per block, no data-path collective" if headline_stage == "focal"

@@ -24,8 +24,6 @@ SIGNATURES = {
     "gfn_hash_level_scales_host": (None, [_vp]),
     "gfn_hash_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "gfn_hash_fwd_f16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
-    "gfn_table_pair_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
-    "gfn_hash_fwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp]),
     "gfn_table_to_f16": (_i32, [_vp, _vp, _i64, _vp]),
     "gfn_hash_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "gfn_normalize_dirs": (_i32, [_vp, _vp, _i64, _vp]),
@@ -65,9 +63,9 @@ SIGNATURES = {
     "gfn_wgrad_x3_layers": (_i32, [C.POINTER(WgradLayer), _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "gfn_wgrad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
+    "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
                          _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
+    "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -90,7 +88,7 @@ SIGNATURES = {
     "gfn_s3im": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "gfn_adam_hyper_host": (None, [_i32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),
-    "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp]),
+    "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "gfn_copy_list": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
     "gfn_reduce_shards": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),

@@ -25,7 +25,7 @@ struct FusedArgs {
   const int* pts_offsets; int n_rays;
   const float* pts; const int* anchors; const float* dt; const float* ts;
   const void* table_a; const void* table_b; const int* prim_a; const int* prim_b; const float* bias_pool;
-  int64_t n_volumes; int log2_T; int pair;  // pair: table_a is the interleaved {global, block} image (shared primes)
+  int64_t n_volumes; int log2_T;
   const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
   float early_T;
   float* sigma; float* rgb; float* h0; unsigned long long* masks; float* weights; float* alphas; float* feat;
@@ -75,25 +75,9 @@ __device__ __forceinline__ float2 gather_pairs_u32(const half2_t* __restrict__ t
   return make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
 }
 
-// gather_level_pair likewise (interleaved {global, block} image: one 8-byte gather per corner)
-__device__ __forceinline__ float2 gather_quads_u32(const half4_t* __restrict__ table, uint32_t slot0, const Corners& c) {
-  half4_t v[8];
-#pragma unroll
-  for (int d = 0; d < 8; d++) v[d] = table[slot0 + c.pos[d]];
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-  for (int d = 0; d < 8; d++) {
-    const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];
-    const float u0 = c.w[d] * (float)v[d][2], u1 = c.w[d] * (float)v[d][3];
-    a0 = (d == 0) ? t0 : a0 + t0; a1 = (d == 0) ? t1 : a1 + t1;
-    b0 = (d == 0) ? u0 : b0 + u0; b1 = (d == 0) ? u1 : b1 + u1;
-  }
-  return make_float2(gfn_round_f16(a0) + gfn_round_f16(b0), gfn_round_f16(a1) + gfn_round_f16(b1));
-}
-
-// TAB: 0 one table, 1 two tables with their own primes (DUAL), 2 one interleaved {global, block} image (shared primes).
-// A compile-time choice on purpose: with `if (A.pair)` inside the unrolled level loop the 512-thread build returned wrong
-// values for whole 16-lane groups of the upper half-wave now and then (hipcc 7.2; the same source is fine at 256 threads).
+// TAB: 0 one table, 1 two tables with their own primes (the focal stage: global + residual block table).
+// A compile-time choice on purpose: with a run-time `if` on the table mode inside the unrolled level loop the 512-thread build
+// returned wrong values for whole 16-lane groups of the upper half-wave now and then (hipcc 7.2; the same source is fine at 256 threads).
 template <int TAB, bool SAVE, bool PLANES>
 __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
@@ -154,9 +138,7 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
           Corners c;
           uint32_t cell[3];
           hash_corners<(TAB != 1 || SAVE)>(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
-          float2 r;
-          if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);  // one 8-byte gather per corner for both tables
-          else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
+          float2 r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
           if (TAB == 1) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486), through the block table's own primes
             if (A.prim_b) rehash_corners(cell, A.prim_b + tr3, T - 1u, c);  // same cell, same weights: only the slots change
             const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
@@ -317,9 +299,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
             Corners c;
             uint32_t cell[3];
             hash_corners(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
-            float2 r;
-            if (TAB == 2) r = gather_quads_u32(reinterpret_cast<const half4_t*>(A.table_a), slot0, c);
-            else r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
+            float2 r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
             if (TAB == 1) {
               if (A.prim_b) rehash_corners(cell, A.prim_b + tr3, T - 1u, c);  // same cell, same weights: only the slots change
               const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
@@ -380,7 +360,7 @@ extern "C" {
 
 int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
                       const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                      const int32_t* prim_pool2, int pair_table, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                      const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
                       const float* sh, const float* emb, const int32_t* cam_idx, float early_T, float* sigma, float* rgb,
                       float* h0, uint64_t* masks, float* weights, float* alphas, float* feat, uint16_t* planes_hi,
                       uint16_t* planes_lo, int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth,
@@ -391,7 +371,6 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_fused_forward: n_rays=%lld", (long long)n_rays);
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");  // 3 * 16 * n_volumes and 16 * T / 2 are 32-bit offsets in the kernel
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
-  GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_forward: an interleaved pair image already holds the second table");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
   GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 32 == 0)),
                 "gfn_fused_forward: planes need both halves, the masks and a capacity that is a multiple of 8");
@@ -401,7 +380,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   FusedArgs A;
   A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
   A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
-  A.n_volumes = n_volumes; A.log2_T = log2_T; A.pair = pair_table;
+  A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.sigma = sigma; A.rgb = rgb; A.h0 = h0; A.masks = reinterpret_cast<unsigned long long*>(masks); A.weights = weights; A.alphas = alphas;
   A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap;
@@ -410,8 +389,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_FUSED_ALL(X) X(0, false, false) X(0, true, false) X(0, true, true) X(1, false, false) X(1, true, false) X(1, true, true) \
-                         X(2, false, false) X(2, true, false) X(2, true, true)
+#define GFN_FUSED_ALL(X) X(0, false, false) X(0, true, false) X(0, true, true) X(1, false, false) X(1, true, false) X(1, true, true)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(D, S, P) \
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<D, S, P>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
@@ -421,7 +399,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t waves = n_rays;  // one ray at a time per wave
-  const int tab = table2_f16 ? 1 : (pair_table ? 2 : 0);
+  const int tab = table2_f16 ? 1 : 0;
   const bool save = masks != nullptr, planes = planes_hi != nullptr;
   const int threads = save ? FUSED_THREADS : FUSED_THREADS_LEAN;
   int64_t blocks = (waves + threads / 64 - 1) / (threads / 64);
@@ -438,7 +416,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
 
 int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
                      const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                     const int32_t* prim_pool2, int pair_table, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                     const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
                      const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
                      float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream) {
   if (n_rays == 0) return GFN_OK;
@@ -447,7 +425,6 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30) && n_rays % 32 == 0, "gfn_fused_render: n_rays=%lld must be a positive multiple of 32", (long long)n_rays);
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_render: n_volumes / log2_T out of range");
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_render: emb given without cam_idx");
-  GFN_CHECK_ARG(!pair_table || !table2_f16, "gfn_fused_render: an interleaved pair image already holds the second table");
   GFN_CHECK_ARG(tile_width == 0 || (tile_width > 0 && patch_width > 0 && 32 % patch_width == 0 && tile_width % patch_width == 0 &&
                                     n_rays % tile_width == 0 && (n_rays / tile_width) % (32 / patch_width) == 0),
                 "gfn_fused_render: a %d-wide tile of %lld rays does not divide into %d x %d patches", tile_width, (long long)n_rays, patch_width,
@@ -457,7 +434,7 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   FusedArgs A{};
   A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
   A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
-  A.n_volumes = n_volumes; A.log2_T = log2_T; A.pair = pair_table;
+  A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
   LevelScales sc;
@@ -467,7 +444,6 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   if (gfn_first_call_on_device(attr_seen)) {
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
   }
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
@@ -475,7 +451,6 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   const int cu_cap = gfn_decoder_cu_cap();
   if (blocks > cu_cap) blocks = cu_cap;
   if (table2_f16) fused_render_patch_kernel<1><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-  else if (pair_table) fused_render_patch_kernel<2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   else fused_render_patch_kernel<0><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_CHECK_LAUNCH();
   return GFN_OK;

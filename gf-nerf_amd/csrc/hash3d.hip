@@ -24,7 +24,7 @@
 
 namespace {
 
-template <typename AnchorT, bool F16, bool DUAL, bool PAIR = false>
+template <typename AnchorT, bool F16, bool DUAL>
 __global__ __launch_bounds__(256) void hash_fwd_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, int64_t n_volumes, int log2_T, LevelScales sc,
     const void* __restrict__ table_a, const void* __restrict__ table_b, const int* __restrict__ prim_pool,
@@ -46,10 +46,8 @@ __global__ __launch_bounds__(256) void hash_fwd_kernel(
       Corners c;
       uint32_t cell[3];
       hash_corners(px, py, pz, sc.s[level], prim_pool + 3 * tr, bias_pool ? bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
-      float2 r;
-      if (PAIR) r = gather_level_pair(table_a, (int64_t)level * T, c);
-      else r = gather_level<F16>(table_a, (int64_t)level * T, c);
-      if (DUAL && !PAIR) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486): f32 add of two f16-valued terms
+      float2 r = gather_level<F16>(table_a, (int64_t)level * T, c);
+      if (DUAL) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486): f32 add of two f16-valued terms
         // every Hash3DAnchored draws its own primes (Hash3DAnchored.cpp:43-50): same cell and weights, other slots
         if (prim_pool_b) hash_corners(px, py, pz, sc.s[level], prim_pool_b + 3 * tr, bias_pool ? bias_pool + 3 * tr : nullptr, T - 1u, c, cell);
         const float2 r2 = gather_level<F16>(table_b, (int64_t)level * T, c);
@@ -214,52 +212,9 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (_Float16)src[i];
 }
 
-__global__ __launch_bounds__(256) void pair_build_kernel(const float* __restrict__ g, const float* __restrict__ b,
-                                                         half4_t* __restrict__ pair, int64_t n_pairs) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * 256) {
-    const float2 gv = reinterpret_cast<const float2*>(g)[i], bv = reinterpret_cast<const float2*>(b)[i];
-    const half4_t v = {(_Float16)gv.x, (_Float16)gv.y, (_Float16)bv.x, (_Float16)bv.y};
-    pair[i] = v;
-  }
-}
-
 }  // namespace
 
 extern "C" {
-
-int gfn_table_pair_f16(const float* global_pool, const float* block_pool, uint16_t* pair_f16, int64_t n_elems,
-                       void* stream) {
-  if (n_elems == 0) return GFN_OK;
-  GFN_CHECK_ARG(global_pool && block_pool && pair_f16 && n_elems > 0 && n_elems % 2 == 0, "gfn_table_pair_f16: bad arguments");
-  int64_t blocks = (n_elems / 2 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  pair_build_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(global_pool, block_pool, reinterpret_cast<half4_t*>(pair_f16),
-                                                                     n_elems / 2);
-  GFN_CHECK_LAUNCH();
-  return GFN_OK;
-}
-
-int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const float* bias_pool, const float* pts,
-                      const void* anchors, int anchors_i64, int anchor_stride, int64_t n_max, const int32_t* n_dev,
-                      int64_t n_volumes, int log2_T, float* out, void* stream) {
-  if (n_max == 0) return GFN_OK;
-  GFN_CHECK_ARG(pair_f16 && prim_pool && pts && anchors && out, "gfn_hash_fwd_pair: null pointer");
-  if (int rc = check_common("gfn_hash_fwd_pair", n_max, n_volumes, log2_T, anchor_stride)) return rc;
-  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(pair_f16) & 7) == 0,
-                "gfn_hash_fwd_pair: misaligned pointer");
-  LevelScales sc;
-  gfn_hash_level_scales_host(sc.s);
-  const unsigned grid = point_grid(n_max);
-  hipStream_t st = gfn_stream(stream);
-  if (anchors_i64)
-    hash_fwd_kernel<int64_t, true, true, true><<<grid, 256, 0, st>>>(n_max, n_dev, n_volumes, log2_T, sc, pair_f16, nullptr, prim_pool,
-                                                                    nullptr, bias_pool, pts, (const int64_t*)anchors, anchor_stride, 0, out);
-  else
-    hash_fwd_kernel<int32_t, true, true, true><<<grid, 256, 0, st>>>(n_max, n_dev, n_volumes, log2_T, sc, pair_f16, nullptr, prim_pool,
-                                                                    nullptr, bias_pool, pts, (const int32_t*)anchors, anchor_stride, 0, out);
-  GFN_CHECK_LAUNCH();
-  return GFN_OK;
-}
 
 void gfn_hash_level_scales_host(float out_host[GFN_N_LEVELS]) {
   // Hash3DAnchored_cuda.cu:28; exact exp2 (double) of the f32 argument, as the oracle.

@@ -105,24 +105,4 @@ __device__ __forceinline__ float2 gather_level(const void* __restrict__ table, i
   return make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
 }
 
-// Focal stage, tables INTERLEAVED per slot: pair[(l*T)/2 + pos] = {global.ch0, global.ch1, block.ch0, block.ch1}
-// (f16 x4 = one 8-byte gather for what the two-table form fetches with two 4-byte gathers from arrays
-// 64 MiB apart).  Each table is blended and rounded separately, then added in f32 -- same values as DUAL.
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float2 gather_level_pair(const void* __restrict__ table, int64_t level_base, const Corners& c) {
-  const half4_t* base = reinterpret_cast<const half4_t*>(table) + (level_base >> 1);
-  half4_t v[8];
-#pragma unroll
-  for (int d = 0; d < 8; d++) v[d] = base[c.pos[d]];
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-  for (int d = 0; d < 8; d++) {
-    const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];
-    const float u0 = c.w[d] * (float)v[d][2], u1 = c.w[d] * (float)v[d][3];
-    a0 = (d == 0) ? t0 : a0 + t0; a1 = (d == 0) ? t1 : a1 + t1;
-    b0 = (d == 0) ? u0 : b0 + u0; b1 = (d == 0) ? u1 : b1 + u1;
-  }
-  return make_float2(gfn_round_f16(a0) + gfn_round_f16(b0), gfn_round_f16(a1) + gfn_round_f16(b1));
-}
-
 }  // namespace

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void adam_ex_kernel(float* __restrict__ p, con
                                                       float g_scale, float* __restrict__ m, float* __restrict__ v,
                                                       int64_t n, float one_m_b1, float beta2, float one_m_b2,
                                                       float step_size, float bc2_sqrt, float eps,
-                                                      _Float16* __restrict__ shadow, int shadow_pair, const float* __restrict__ hyper) {
+                                                      _Float16* __restrict__ shadow, const float* __restrict__ hyper) {
   if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
   // non-temporal accesses: 1 GB streams through once per step and must not evict what the level-major lookup of the next
   // step keeps in L2 when this kernel runs beside it (HotPathConfig.async_adam)
@@ -514,8 +514,7 @@ __global__ __launch_bounds__(256) void adam_ex_kernel(float* __restrict__ p, con
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     const float pi = p0 - step_size * (mi / denom);
     __builtin_nontemporal_store(pi, p + i);
-    // plain shadow: element i; pair layout {g0,g1,b0,b1} per slot: the block half of slot i/2
-    if (shadow) shadow[shadow_pair ? ((i >> 1) * 4 + 2 + (i & 1)) : i] = (_Float16)pi;
+    if (shadow) shadow[i] = (_Float16)pi;
   }
 }
 
@@ -793,7 +792,7 @@ int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
 
 int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
-                     int shadow_pair, const float* hyper_dev, void* stream) {
+                     const float* hyper_dev, void* stream) {
   if (n == 0) return GFN_OK;
   GFN_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "gfn_adam_step_ex: bad arguments");
   const double bc1 = 1.0 - pow((double)beta1, step);
@@ -803,10 +802,10 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
   _Float16* sh = reinterpret_cast<_Float16*>(shadow_f16);
   if (g_f16)
     adam_ex_kernel<true><<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, g_scale, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                                                                          (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair, hyper_dev);
+                                                                          (float)(lr / bc1), (float)sqrt(bc2), eps, sh, hyper_dev);
   else
     adam_ex_kernel<false><<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(p, g, g_scale, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                                                                           (float)(lr / bc1), (float)sqrt(bc2), eps, sh, shadow_pair, hyper_dev);
+                                                                           (float)(lr / bc1), (float)sqrt(bc2), eps, sh, hyper_dev);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -11,9 +11,11 @@ runs that keep everything in HBM and for the tests: `SyntheticDataManager` (seed
 ErrorPixelSampler data policy of the block stage, and `setup_train_split_oct`: each block trains on its own camera cluster).
 
 Multi-GPU: the reference wraps the model in DDP (:136-138), which never all-reduces the hash table (it is not a registered
-parameter: hash_3d_anchored.py:26,73-78).  Here nothing is wrapped: with world_size > 1 the engine's TrainSync MAX-reduces
-the octree statistics and averages every gradient inside the backward (gfnerf_amd.dist), so the Trainer's own
-optimizer.step() sees the reduced gradients."""
+parameter: hash_3d_anchored.py:26,73-78).  Here nothing is wrapped.  Global stage, world_size > 1: the engine's TrainSync
+MAX-reduces the octree statistics and averages every gradient inside the backward (gfnerf_amd.dist), so the Trainer's own
+optimizer.step() sees the reduced gradients.  Focal stage: nothing is exchanged -- every rank trains a block of its own
+(GFNeRFModel.stage_of: block (period * world + rank) mod n_split) on that block's camera cluster and writes that block's
+checkpoint alone (GFNeRFField.save_table: private file, os.replace)."""
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional, Type

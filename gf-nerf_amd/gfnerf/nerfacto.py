@@ -92,6 +92,13 @@ class GFNeRFModelConfig(ModelConfig):
                                         # ~128 Ki rays that divides the image (gfnerf_amd.render.choose_tile)
 
 
+def focal_block(step, steps_init, steps_per_split, n_split, world=1, rank=0):
+    """The focal block rank `rank` of `world` trains at `step` (None: the global stage): block (period * world + rank) mod n_split."""
+    if step < 0 or (steps_init > 0 and step < steps_init):
+        return None
+    return (((step - steps_init) // steps_per_split) * world + rank) % n_split
+
+
 class _RenderFn(torch.autograd.Function):
     """forward: HotPath.forward_train; backward: HotPath.backward (+ the data-parallel exchange).  The aliased parameters
     arrive in the order (table, block table, embedding weight, 10 decoder tensors).  A parameter that a GfnAdam steps
@@ -246,6 +253,9 @@ class GFNeRFModel(Model):
                                    s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time)
         self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg, device=dev,
                                   seed=c.engine_seed, n_blocks=0, sync=self.kwargs.get("sync", None))
+        if self.hot.sync.world > 1 and c.n_split_dataset % self.hot.sync.world != 0:
+            raise ValueError(f"focal stage on {self.hot.sync.world} ranks: n_split_dataset = {c.n_split_dataset} must be a multiple of the number of "
+                             "ranks (one block per rank and period; two ranks on one block would train diverging copies of its table)")
         self.hot.nodes, self.hot.transes, self.hot.nodes_compact = nat.tree_nodes_gpu_, nat.pers_trans_gpu_, nat.nodes_compact_
         if self.hot.sync.world > 1:  # K5's per-node maxima are MAX-reduced over the ranks before K6 (every replica keeps the same tree)
             nat.reduce_max = self.hot.sync.reduce_octree_stats
@@ -274,10 +284,14 @@ class GFNeRFModel(Model):
         return {"fields": params[0:n_named], "base_encoding_init": [params[n_named]]}
 
     def stage_of(self, step: int):
+        """(stage, focal block) of a training step.  One process: the reference's schedule -- the blocks one after the other,
+        steps_per_split_dataset steps each (nerfacto_field.py:248-330, perssampler.py:316-317).  W ranks: one block per rank:
+        in period p = (step - init) // steps_per_split_dataset rank r trains block (p W + r) mod n_split on rays of that block's camera
+        cluster (update_datamanager hands every rank's datamanager its own split), against the frozen global table and decoder every
+        rank holds -- nothing is exchanged, no two ranks ever write one table, and a round over all blocks takes n_split / W periods."""
         c = self.config
-        if step < 0 or (c.steps_perssampler_init > 0 and step < c.steps_perssampler_init):
-            return hp_mod.STAGE_GLOBAL, None
-        return hp_mod.STAGE_FOCAL, ((step - c.steps_perssampler_init) // c.steps_per_split_dataset) % c.n_split_dataset
+        blk = focal_block(step, c.steps_perssampler_init, c.steps_per_split_dataset, c.n_split_dataset, self.hot.sync.world, self.hot.sync.rank)
+        return (hp_mod.STAGE_GLOBAL, None) if blk is None else (hp_mod.STAGE_FOCAL, blk)
 
     def get_training_callbacks(self, training_callback_attributes: TrainingCallbackAttributes) -> List[TrainingCallback]:
         """nerfacto.py:323-520.  update_optimizer / render_init_error_maps / train_cameras_clustering / update_datamanager as the

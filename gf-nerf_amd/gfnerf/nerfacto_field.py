@@ -211,7 +211,10 @@ class GFNeRFField(Field):
     def save_table(self, table_idx):
         assert hasattr(self, f"base_encoding_{table_idx}")
         os.makedirs(self.encodings_ckpt_dir, exist_ok=True)
-        torch.save(getattr(self, f"base_encoding_{table_idx}").state_dict(), self.encodings_ckpt_dir / f"base_encoding_{table_idx}.ckpt")
+        path = self.encodings_ckpt_dir / f"base_encoding_{table_idx}.ckpt"
+        tmp = self.encodings_ckpt_dir / f".base_encoding_{table_idx}.ckpt.{os.getpid()}.tmp"  # written privately, published atomically
+        torch.save(getattr(self, f"base_encoding_{table_idx}").state_dict(), tmp)
+        os.replace(tmp, path)
 
     def load_table(self, table_idx, strict=False):
         assert hasattr(self, f"base_encoding_{table_idx}")

@@ -377,6 +377,9 @@ class PersSampler(nn.Module):
         from .. import cluster
 
         assert self.cameras_labels is None
+        # the reference clusters on get_distance_matrix_oct()'s matrix (:218), which as a side effect fills the buffers
+        # cameras_rays_nodes_centers / cameras_valid_mask (:196-197: they travel in its checkpoints and feed get_oct_split_dataset)
+        self.get_distance_matrix_oct()
         pos = self.c2w[:, 0:3, -1].detach().cpu().numpy()
         labels = cluster.equal_size_clusters(pos, int(k), seed=1234)
         self.cameras_labels = torch.from_numpy(labels).view(-1, 1).to(torch.int64)

@@ -49,7 +49,6 @@ class HotPathConfig:
     level_major: bool = True         # training forward: level-major lookup (L2-resident address ranges) + decoder + compositing
                                      # as three kernels instead of the one fused kernel (which stays the inference path)
     lds_accumulate_exact: bool = True  # exact fixed-point LDS sums (rounded to f16 once) where they provably fit; False: the reference's f16 adds
-    level_major_render: bool = False # inference with two tables: level-major lookups + decoder + compositing kernels instead of the fused forward
     level_major_global: bool = False # also in the global stage (one table), from the first step on
     level_major_global_after: int = 50  # ... or from this optimiser step on (-1: never): while the scene is empty the fused forward's
                                      # early termination wins (2.40 vs 2.69 ms/step); once nearly every sample is alive (a few dozen
@@ -58,15 +57,10 @@ class HotPathConfig:
     lm_split_log2: int = 0           # ... of 2^this parts per level (0 = 1: halves; 2: quarters, no gain inside the step)
     render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
-    table_branch: bool = False       # global stage, one rank: table-gradient accumulation + table Adam on a second stream beside the
-                                     # decoder's weight-gradient kernels.  Measured: no gain (2.10-2.17 vs 2.16 ms/step) -- both sides
-                                     # live on LDS (ds_read_tr staging / ds_add_u64), each takes twice as long beside the other
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
     loss_before_fork: bool = True    # forward_backward enqueues the loss kernels before it forks the octree update / next sampler
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
-    adam_pipeline_chunks: int = 1    # > 1: the table's Adam runs that many chunks of slot ranges behind their accumulation, on a second
-                                     # stream (measured: no gain -- both are bound by memory, and the sampler on the side stream is as long)
     record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
     prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
@@ -77,8 +71,6 @@ class HotPathConfig:
     two_phase_min_saving: tuple = (0.12, 0.06)  # samples a split must save to be started / to be kept (break-even ~ 9 %: measured);
     two_phase_min_saving_planes: tuple = (0.30, 0.20)  # ... in the global stage: compacted samples write unaligned activation-plane rows
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
-    share_block_primes: bool = False  # True: block tables reuse the global table's primes, which allows the interleaved
-                                      # one-gather-per-corner image; False: own primes per table, like the reference
 
 
 class HotPath:
@@ -109,8 +101,6 @@ class HotPath:
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
-        self._acc_chunks = None     # [(range_begin, range_end, event)] of the last backward's chunked record accumulation
-        self._table_branch = False  # backward forked the table-gradient branch onto _opt_stream; optimizer_step continues and joins it
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
@@ -122,8 +112,7 @@ class HotPath:
         # would hide nothing in training but zeros would hide kernel bugs in tests -> caller may overwrite
         self.blocks = [torch.zeros((16 * (1 << T), 2), dtype=torch.float32, device=self.dev) for _ in range(n_blocks)]
         # every Hash3DAnchored draws its own primes (Hash3DAnchored.cpp:43-50; add_table, nerfacto_field.py:341-347)
-        self.block_prims = [self.prim if self.cfg.share_block_primes else t(scene.make_primes(self.n_volumes, seed=seed + 100 + i))
-                            for i in range(n_blocks)]
+        self.block_prims = [t(scene.make_primes(self.n_volumes, seed=seed + 100 + i)) for i in range(n_blocks)]
         base, head = scene.make_mlps(seed=seed + 4, hidden=self.cfg.hidden)
         shapes = [w.shape for w, _ in base + head]
         sizes = [w.size + b.size for w, b in base + head]
@@ -145,7 +134,6 @@ class HotPath:
         self.record_counts_seen = None  # int32 like _records[1]: receives the stream counters each accumulate consumes (diagnostics, tests)
         self.table16 = None
         self.blocks16 = []
-        self._pairs_stale = False
         self._plane_bufs = None
         self._x3_images = [None, None]   # split-f16 weight images of the fused decoder (forward, backward)
         self._x3_stale = True
@@ -174,7 +162,7 @@ class HotPath:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
         self.blocks[i] = torch.zeros((16 * (1 << T), 2), dtype=torch.float32, device=self.dev) if table is None else table
         if prims is None:
-            prims = self.prim if self.cfg.share_block_primes else t(scene.make_primes(self.n_volumes, seed=self._seed + 100 + i))
+            prims = t(scene.make_primes(self.n_volumes, seed=self._seed + 100 + i))
         self.block_prims[i] = prims
         self.refresh_shadows()
         return self.blocks[i]
@@ -194,11 +182,7 @@ class HotPath:
             self.table16 = ops.table_to_f16(self.table, self.table16)
             if len(self.blocks16) != len(self.blocks):
                 self.blocks16 = (self.blocks16 + [None] * len(self.blocks))[: len(self.blocks)]
-            if self.cfg.share_block_primes:  # global + block interleaved per slot (one 8-byte gather per corner)
-                self.blocks16 = [None if b is None else ops.table_pair_f16(self.table, b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
-            else:
-                self.blocks16 = [None if b is None else ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
-        self._pairs_stale = False
+            self.blocks16 = [None if b is None else ops.table_to_f16(b, b16) for b, b16 in zip(self.blocks, self.blocks16)]
         self._x3_stale = True  # callers use this hook after writing parameters from outside the optimiser
 
     def _planes(self, cap):
@@ -318,12 +302,7 @@ class HotPath:
         lm = lm and fused and self.cfg.mlp_precision == "x3"  # the x3 decoder reads level-major features
         if not (lm and block is not None):
             self._sync_opt()
-        if block is not None and self._pairs_stale:  # the global table moved since the interleaved images were built
-            self.refresh_shadows()
-        if self.cfg.table_f16_shadow and block is not None and self.cfg.share_block_primes:
-            feat = self._timed("hash_fwd", ops.hash_fwd_pair, self.blocks16[block], self.prim, self.bias_arg, s["warped_pts"],
-                               s["anchors"], V, T, n_dev=n_dev)
-        elif self.cfg.table_f16_shadow and lm and block is not None and self._opt_pending:
+        if self.cfg.table_f16_shadow and lm and block is not None and self._opt_pending:
             # the frozen global table first, beside the previous step's Adam on the block table; then wait for that Adam
             feat = self._timed("hash_fwd", ops.hash_fwd_lm, self.table16, self.prim, self.bias_arg, s["warped_pts"], s["anchors"], V, T,
                                n_dev=n_dev, halves_from=self.cfg.lm_halves_from, split_log2=self.cfg.lm_split_log2, planar=True)
@@ -423,19 +402,15 @@ class HotPath:
     def _forward_fused(self, s, cam_idx, block, early_T, save=False, planes=None, want_weights=True):
         """Hash lookup + decoder + compositing in one launch (csrc/fused_fwd.hip) -> (field dict, comp dict)."""
         self._sync_opt()
-        if block is not None and self._pairs_stale:
-            self.refresh_shadows()
         if self.after_lookup is not None:
             self.after_lookup()
         sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
         emb = self.emb if self.cfg.use_appearance_embedding else None
-        pair = block is not None and self.cfg.share_block_primes  # blocks16[block] is then the interleaved {global, block} image
-        out = self._timed("fused_fwd", ops.fused_forward, s, self.blocks16[block] if pair else self.table16, self.prim, self.n_volumes,
+        out = self._timed("fused_fwd", ops.fused_forward, s, self.table16, self.prim, self.n_volumes,
                           self.cfg.log2_T, self._x3()[0], sh, emb, cam_idx,
-                          table2_f16=self.blocks16[block] if (block is not None and not pair) else None,
-                          prim_pool2=self.block_prims[block] if (block is not None and not pair) else None, bias_pool=self.bias_arg,
-                          early_T=early_T, save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes,
-                          pair_table=pair)
+                          table2_f16=self.blocks16[block] if block is not None else None,
+                          prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg,
+                          early_T=early_T, save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes)
         f = dict(sigma=out["sigma"], rgb=out["rgb_samples"], h0=out["h0"], masks=out["masks"], feat=out["feat"])
         comp = dict(weights=out["weights"], alphas=out["alphas"], rgb=out["rgb"], acc=out["acc"], depth_raw=out["depth_raw"],
                     t_minmax=out["t_minmax"])
@@ -452,26 +427,20 @@ class HotPath:
         s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
         R = s["pts_offsets"].numel() - 1
         pw = c.render_patch_width
-        if (tile_width is not None and pw > 0 and self._fused_ok(block) and not c.level_major_render and R % 32 == 0 and
+        if (tile_width is not None and pw > 0 and self._fused_ok(block) and R % 32 == 0 and
                 (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0))):
             self._sync_opt()
-            if block is not None and self._pairs_stale:
-                self.refresh_shadows()
             sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
-            pair = block is not None and c.share_block_primes
-            comp = self._timed("fused_render", ops.fused_render, s, self.blocks16[block] if pair else self.table16, self.prim, self.n_volumes, c.log2_T,
+            comp = self._timed("fused_render", ops.fused_render, s, self.table16, self.prim, self.n_volumes, c.log2_T,
                                self._x3()[0], sh, self.emb if c.use_appearance_embedding else None, cam_idx,
-                               table2_f16=self.blocks16[block] if (block is not None and not pair) else None,
-                               prim_pool2=self.block_prims[block] if (block is not None and not pair) else None, bias_pool=self.bias_arg,
-                               early_T=early, pair_table=pair, tile_width=tile_width, patch_width=pw)
+                               table2_f16=self.blocks16[block] if block is not None else None,
+                               prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg,
+                               early_T=early, tile_width=tile_width, patch_width=pw)
             depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
             rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)
             return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
                         oct_depth=s["first_oct_dis"][:, None] / c.scale_factor, samples=s, field=None, weights=None)
-        if c.level_major_render and block is not None and self._fused_ok(block) and not c.share_block_primes:
-            f = self._field_forward(s, cam_idx, block, fused=True, lm=True)
-            comp = ops.composite_fwd(s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], early_T=early)
-        elif self._fused_ok(block):
+        if self._fused_ok(block):
             f, comp = self._forward_fused(s, cam_idx, block, early)
         else:
             f = self._field_forward(s, cam_idx, block)
@@ -519,60 +488,17 @@ class HotPath:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
             self._opt_pending = False
 
-    def _join_table_branch(self):
-        if self._table_branch:
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
-            self._table_branch = False
-
-    def _reduce_records(self, rec, pipelined, state=None):
-        """gfn_grad_records_reduce over every slot range -- in adam_pipeline_chunks launches with an event behind each when the
-        table's optimiser step may follow chunk by chunk (optimizer_step picks the events up)."""
+    def _reduce_records(self, rec):
+        """gfn_grad_records_reduce over every slot range: the record streams of the last backward -> the f16 x128 gradient pool."""
         c = self.cfg
-        kw = dict(counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
-        n_chunks = c.adam_pipeline_chunks if pipelined else 1
-        self._acc_chunks = None
-        if n_chunks <= 1:
-            self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, **kw)
-            return
-        if state is not None:
-            self._adam_state(*state)  # created (zero-filled on THIS stream) in front of the first chunk's event, not behind the fork
-        n_ranges = ops.grad_record_ranges(c.log2_T)
-        bounds = [n_ranges * i // n_chunks for i in range(n_chunks + 1)]
-        chunks = []
-        for r0, r1 in zip(bounds[:-1], bounds[1:]):
-            if r1 <= r0:  # fewer ranges than chunks ((0, 0) would mean all of them)
-                continue
-            self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, ranges=(r0, r1), **kw)
-            ev = torch.cuda.Event()
-            ev.record()
-            chunks.append((r0, r1, ev))
-        self._acc_chunks = chunks
+        self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen,
+                    f16_accumulate=not c.lds_accumulate_exact)
 
-    def _adam_table(self, name, p, m, v, lr, shadow, shadow_pair, hyper):
-        """Adam on the live elements of a table; behind a chunked accumulation: chunk by chunk on the optimiser stream, each
-        as soon as its ranges' gradients are final, joined before returning."""
+    def _adam_table(self, name, p, m, v, lr, shadow, hyper):
+        """Adam on the live elements of a table (elements [0, 17T): the rest can never receive a gradient)."""
         c = self.cfg
-        n_live = 17 * (1 << c.log2_T)
-        t = self._adam_tick(name)
-        chunks, self._acc_chunks = self._acc_chunks, None
-        if not chunks or shadow_pair:
-            self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, t, lr=lr, eps=c.adam_eps, shadow_f16=shadow, n=n_live,
-                        shadow_pair=shadow_pair, hyper=hyper)
-            return
-        if self._opt_stream is None:
-            self._opt_stream = torch.cuda.Stream(device=self.dev)
-        flat = [x.view(-1) for x in (p, self.table_grad, m, v)]
-        sh = shadow.view(-1) if shadow is not None else None
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(self._opt_stream):  # ordered behind the chunks' events only: not behind whatever else this stream holds
-            for r0, r1, ev in chunks:
-                e0, e1 = r0 << (ops.GRAD_RANGE_LOG2 + 1), min(r1 << (ops.GRAD_RANGE_LOG2 + 1), n_live)
-                if e1 <= e0:
-                    continue
-                self._opt_stream.wait_event(ev)
-                self._timed("adam", ops.adam_step_table, flat[0][e0:e1], flat[1][e0:e1], flat[2][e0:e1], flat[3][e0:e1], t, lr=lr,
-                            eps=c.adam_eps, shadow_f16=sh[e0:e1] if sh is not None else None, hyper=hyper)
-        main.wait_stream(self._opt_stream)
+        self._timed("adam", ops.adam_step_table, p, self.table_grad, m, v, self._adam_tick(name), lr=lr, eps=c.adam_eps, shadow_f16=shadow,
+                    n=17 * (1 << c.log2_T), hyper=hyper)
 
     def _grad_live(self):
         """Elements [0, 17T) of the gradient pool: the only ones a backward can write (level-overlap quirk), so the only ones to
@@ -608,7 +534,7 @@ class HotPath:
         # cfg.level_major_global / level_major_global_after)
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
         lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
-              and not c.keep_features and not (blk is not None and c.share_block_primes))
+              and not c.keep_features)
         phased = lm and c.two_phase and c.early_T > 0 and self.phase_override is not False
         self.last_forward = ("lm2" if phased else "lm") if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
         if phased:
@@ -644,20 +570,11 @@ class HotPath:
             if cap:
                 _lib.lib().gfn_set_decoder_cus(prev)
 
-    def backward(self, ctx, g_rgb, g_acc=None, keep_branch=False):
-        """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]).
-        keep_branch (train_step only): leave the table-gradient branch (cfg.table_branch) open for optimizer_step to continue;
-        otherwise every gradient is final on the current stream when this returns."""
-        try:
-            self._backward(ctx, g_rgb, g_acc)
-        finally:
-            if not keep_branch:
-                self._join_table_branch()
-
-    def _backward(self, ctx, g_rgb, g_acc):
+    def backward(self, ctx, g_rgb, g_acc=None):
+        """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]): final on the
+        current stream when this returns (data parallel: the table gradient's exchange may still be in flight, see sync_grads)."""
         c = self.cfg
         self._sync_opt()  # the gradient pool is zeroed behind the asynchronous Adam
-        self._acc_chunks = None
         s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
         train_mlp = ctx["stage"] == STAGE_GLOBAL
         n_dev = s["n_dev"]
@@ -675,17 +592,8 @@ class HotPath:
                     self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
-                branch = rec is not None and c.table_branch and self.sync.world == 1
-                if branch:  # the records are complete: accumulate them (and later step the table) beside the weight gradients
-                    if self._opt_stream is None:
-                        self._opt_stream = torch.cuda.Stream(device=self.dev)
-                    self._adam_state("table", self.table)  # created (zero-filled on THIS stream) before the fork, not behind it
-                    self._opt_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self._opt_stream):
-                        self._timed("grad_reduce", ops.grad_records_reduce, rec, self.table_grad, c.log2_T, counts_seen=self.record_counts_seen, f16_accumulate=not c.lds_accumulate_exact)
-                    self._table_branch = True
-                elif rec is not None:
-                    self._reduce_records(rec, pipelined=self.sync.world == 1, state=("table", self.table))
+                if rec is not None:
+                    self._reduce_records(rec)
                 dfeat = None
                 # data parallel: the table gradient is final here -- its exchange runs beside the weight-gradient kernels below
                 self.sync.start_grads([self._grad_live()])
@@ -712,8 +620,7 @@ class HotPath:
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                             self.table_grad, n_dev=n_dev, records=rec)
             if rec is not None:
-                blk = ctx["block"]
-                self._reduce_records(rec, pipelined=not (c.async_adam or c.share_block_primes), state=(f"block{blk}", self.blocks[blk]))
+                self._reduce_records(rec)
             dfeat = None
         elif ctx["fused"]:
             prec = c.mlp_precision
@@ -738,7 +645,7 @@ class HotPath:
                     c.log2_T, grad_pool=self.table_grad, n_dev=n_dev, grad_f16=c.grad_f16)
 
     def forward_backward(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None, prefetch=None,
-                         update_oct=False, samples=None, prefetch_out=None, keep_branch=False):
+                         update_oct=False, samples=None, prefetch_out=None):
         """One loss evaluation + all parameter gradients (no optimiser step).  Returns (loss[1], aux).
         s3im_index: the arange + randperm index vector of S3IM.forward (losses.py:780-789); drawn here when absent.
         prefetch: (rays_o, rays_d_raw, noise) of the NEXT step -- its sampler runs beside this step's backward (focal stage; global
@@ -772,7 +679,7 @@ class HotPath:
                         loss=loss, g_pred=g_rgb)
         if c.loss_before_fork:
             fork()
-        self.backward(ctx, g_rgb, keep_branch=keep_branch)
+        self.backward(ctx, g_rgb)
         return loss, ctx
 
     def adam_groups(self, stage, block=None):
@@ -793,26 +700,19 @@ class HotPath:
         n_live = 17 * (1 << c.log2_T)
         if stage == STAGE_GLOBAL:
             m, v = self._adam_state("table", self.table)
-            step_table = lambda: self._adam_table("table", self.table, m, v, c.lr, self.table16, False, hy("table"))  # noqa: E731
-            if self._table_branch:
-                with torch.cuda.stream(self._opt_stream):
-                    step_table()
-            else:
-                step_table()
-            self._pairs_stale = True  # the global halves of the interleaved focal images are now out of date
+            self._adam_table("table", self.table, m, v, c.lr, self.table16, hy("table"))
             self._x3_stale = True
             for name, p, gr in (("mlp", self.mlp_flat, self.mlp_grad), ("emb", self.emb, self.emb_grad)):
                 if name == "emb" and not c.use_appearance_embedding:
                     continue
                 mm, vv = self._adam_state(name, p)
                 self._timed("adam", ops.adam_step, p, gr, mm, vv, self._adam_tick(name), lr=c.lr, eps=c.adam_eps, hyper=hy(name))
-            self._join_table_branch()  # the next forward reads the stepped table
         else:
             p = self.blocks[block]
             m, v = self._adam_state(f"block{block}", p)
             run = lambda: self._adam_table(f"block{block}", p, m, v, c.lr_block, self.blocks16[block] if c.table_f16_shadow else None,  # noqa: E731
-                                           c.share_block_primes, hy(f"block{block}"))
-            if c.async_adam and c.level_major and not c.share_block_primes:
+                                           hy(f"block{block}"))
+            if c.async_adam and c.level_major:
                 if self._opt_stream is None:
                     self._opt_stream = torch.cuda.Stream(device=self.dev)
                 self._opt_stream.wait_stream(torch.cuda.current_stream())
@@ -853,8 +753,6 @@ class HotPath:
             self._timed("adam", ops.adam_step_table, p, g, m, v, t, lr=lr, beta1=beta1, beta2=beta2, eps=eps, shadow_f16=shadow,
                         n=17 * (1 << c.log2_T))
             self.step += 1  # one per training step of either stage (forward_train reads it: level_major_global_after)
-            if i is None and c.share_block_primes:
-                self._pairs_stale = True
         elif name == "mlp":
             self._timed("adam", ops.adam_step, self.mlp_flat, self.mlp_grad if grad is None else grad, m, v, t, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
             self._x3_stale = True
@@ -866,7 +764,6 @@ class HotPath:
     def grads(self, stage=STAGE_GLOBAL):
         """Gradient tensors that data-parallel training must all-reduce before optimizer_step."""
         self._sync_opt()
-        self._join_table_branch()
         # only elements [0, 17T) of a table can receive a gradient (level-overlap quirk): reduce 71 MB, not 134 MB
         live = self._grad_live()
         if stage == STAGE_GLOBAL:
@@ -895,7 +792,7 @@ class HotPath:
         """Trainer.train_iteration (trainer.py:382-441) restricted to the hot path.  samples / prefetch_out / hyper: see
         gfnerf_amd.stepgraph (the step captured in a hipGraph)."""
         loss, aux = self.forward_backward(rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage, block, s3im_index=s3im_index, prefetch=prefetch,
-                                          update_oct=update_oct, samples=samples, prefetch_out=prefetch_out, keep_branch=True)
+                                          update_oct=update_oct, samples=samples, prefetch_out=prefetch_out)
         self.sync_grads(stage, aux)
         self.optimizer_step(stage, block, hyper=hyper)
         return loss, aux

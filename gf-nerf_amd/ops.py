@@ -141,36 +141,6 @@ def hash_fwd_f16(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_
     return out
 
 
-def table_pair_f16(global_pool, block_pool, out=None):
-    """Interleaved f16 image {global.ch0, global.ch1, block.ch0, block.ch1} per slot for hash_fwd_pair."""
-    _chk(global_pool, torch.float32, "global_pool"); _chk(block_pool, torch.float32, "block_pool")
-    if global_pool.numel() != block_pool.numel():
-        raise _lib.GfnError("tables differ in size")
-    if out is None:
-        out = torch.empty(global_pool.numel() * 2, dtype=torch.float16, device=global_pool.device)
-    _chk(out, torch.float16, "out")
-    _lib.check(_lib.lib().gfn_table_pair_f16(_ptr(global_pool), _ptr(block_pool), _ptr(out), global_pool.numel(), _stream()),
-               "gfn_table_pair_f16")
-    return out
-
-
-def hash_fwd_pair(pair_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, out=None, n_dev=None):
-    _chk(pair_f16, torch.float16, "pair_f16"); _chk(prim_pool, torch.int32, "prim_pool"); _chk(bias_pool, torch.float32, "bias_pool")
-    _chk(pts, torch.float32, "pts", 3); _chk(anchors, anchors.dtype, "anchors")
-    n = pts.shape[0]
-    if pair_f16.numel() != 16 * (1 << log2_T) * 4:
-        raise _lib.GfnError("pair table has the wrong size")
-    stride = _anchor_stride(anchors, n)
-    if out is None:
-        out = torch.empty((n, 32), dtype=torch.float32, device=pts.device)
-    _chk(out, torch.float32, "out", 32)
-    rc = _lib.lib().gfn_hash_fwd_pair(_ptr(pair_f16), _ptr(prim_pool), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
-                                      int(anchors.dtype == torch.int64), stride, n, _ptr(n_dev), n_volumes, log2_T, _ptr(out),
-                                      _stream())
-    _lib.check(rc, "gfn_hash_fwd_pair")
-    return out
-
-
 def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, grad_pool=None, n_dev=None, grad_f16=False):
     """Scatter grad_out [n,32] into grad_pool [16*T,2] (accumulating; allocated zeroed if None).
     grad_f16: pool is float16 and keeps the reference's x128 scale (packed f16 atomics)."""
@@ -443,7 +413,9 @@ def octree_proc(nodes, weight_stats, alpha_stats, visit_cnt, subdivide=False, br
         raise _lib.GfnError("gfn_octree_proc: node blob is not a tree rooted at node 0 (parent / child links disagree)")
     if status != 0 or m < 1:
         raise _lib.GfnError(f"gfn_octree_proc: status {status}, {m} nodes")
-    return out[: m * TREE_NODE_BYTES], w_out[:m], a_out[:m]
+    # exact-size tensors of their own (the buffers above hold room for the worst case -- 9 n nodes with subdivision -- and what lies
+    # behind the new tree is uninitialised: a view would carry all of it into every checkpoint and keep it resident)
+    return out[: m * TREE_NODE_BYTES].clone(), w_out[:m].clone(), a_out[:m].clone()
 
 
 def generate_rays(c2w, intr, cam_idx=None, coords=None, cam0=0, first_pixel=0, width=0, n=None, out=None, want_extras=True):
@@ -865,7 +837,7 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
 
 
 def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None, pair_table=False):
+                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None):
     """gfn_fused_forward on the packed sampler outputs `s` (dict of ops.sample_rays with table_space=True).
     -> dict(sigma, rgb_samples, h0, masks, weights, alphas, feat, rgb [R,3], acc [R], depth_raw [R], t_minmax [2])."""
     po = s["pts_offsets"]
@@ -879,8 +851,8 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
                              ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
                              ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
         _chk(t, dt_, nm, last)
-    for t, mult in ((table_f16, 2 if pair_table else 1), (table2_f16, 1)):
-        if t is not None and t.numel() != 16 * (1 << log2_T) * 2 * mult:
+    for t in (table_f16, table2_f16):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2:
             raise _lib.GfnError("f16 table has the wrong size")
     if prim_pool.numel() != 16 * n_volumes * 3 or (prim_pool2 is not None and prim_pool2.numel() != prim_pool.numel()):
         raise _lib.GfnError("prim_pool does not match n_volumes")
@@ -895,7 +867,7 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
     cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)
     counter = torch.empty(8, dtype=torch.int32, device=dev)
     rc = _lib.lib().gfn_fused_forward(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
-                                      _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), int(bool(pair_table)), _ptr(bias_pool), n_volumes, log2_T,
+                                      _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
                                       _ptr(image),
                                       _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), _ptr(out["sigma"]), _ptr(out["rgb_samples"]),
                                       _ptr(out["h0"]), _ptr(out["masks"]), _ptr(out["weights"]), _ptr(out["alphas"]), _ptr(out["feat"]),
@@ -906,7 +878,7 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
 
 
 def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                 early_T=0.0, pair_table=False, tile_width=0, patch_width=8):
+                 early_T=0.0, tile_width=0, patch_width=8):
     """gfn_fused_render: inference through patches of 32 neighbouring rays walked in lockstep (no per-sample outputs).
     -> dict(rgb [R,3], acc [R], depth_raw [R], t_minmax [2]).  R must be a multiple of 32; tile_width: the rays are a block of
     pixels this wide, row major (0: a run of rays)."""
@@ -920,8 +892,8 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
                              ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
                              ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
         _chk(t, dt_, nm, last)
-    for t, mult in ((table_f16, 2 if pair_table else 1), (table2_f16, 1)):
-        if t is not None and t.numel() != 16 * (1 << log2_T) * 2 * mult:
+    for t in (table_f16, table2_f16):
+        if t is not None and t.numel() != 16 * (1 << log2_T) * 2:
             raise _lib.GfnError("f16 table has the wrong size")
     if prim_pool.numel() != 16 * n_volumes * 3 or (prim_pool2 is not None and prim_pool2.numel() != prim_pool.numel()):
         raise _lib.GfnError("prim_pool does not match n_volumes")
@@ -931,7 +903,7 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
     out = dict(rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
     counter = torch.empty(8, dtype=torch.int32, device=dev)
     rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
-                                     _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), int(bool(pair_table)), _ptr(bias_pool), n_volumes, log2_T,
+                                     _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
                                      _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
                                      _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
     _lib.check(rc, "gfn_fused_render")
@@ -1211,7 +1183,7 @@ def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, hype
                                         float(beta2), float(eps), _ptr(hyper), _stream()), "gfn_adam_step")
 
 
-def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None, shadow_pair=False, hyper=None):
+def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15, shadow_f16=None, n=None, hyper=None):
     """Adam on (the first n elements of) a hash table; g float32, or float16 carrying the x128 loss scale."""
     _chk(p, torch.float32, "p"); _chk(m, torch.float32, "m"); _chk(v, torch.float32, "v"); _chk(shadow_f16, torch.float16, "shadow")
     if g.dtype not in (torch.float32, torch.float16):
@@ -1223,7 +1195,7 @@ def adam_step_table(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-15
     g16 = g.dtype == torch.float16
     _lib.check(_lib.lib().gfn_adam_step_ex(_ptr(p), _ptr(g), int(g16), (1.0 / 128.0) if g16 else 1.0, _ptr(m), _ptr(v), n,
                                            int(step), float(lr), float(beta1), float(beta2), float(eps), _ptr(shadow_f16),
-                                           int(bool(shadow_pair)), _ptr(hyper), _stream()), "gfn_adam_step_ex")
+                                           _ptr(hyper), _stream()), "gfn_adam_step_ex")
 
 
 def copy_list(pairs):

@@ -102,17 +102,6 @@ int gfn_hash_fwd_f16(const uint16_t* table_f16, const uint16_t* table2_f16, cons
                      const int32_t* prim_pool2, const float* bias_pool, const float* pts, const void* anchors, int anchors_i64,
                      int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                      float* out, void* stream);
-/* Focal stage with the two tables INTERLEAVED per slot (u16 [16*T*4]: {global.ch0, global.ch1,
- * block.ch0, block.ch1} as f16): one 8-byte gather per corner instead of two 4-byte gathers;
- * out = feat(global) + feat(block), bit-identical to the two-table forms.  ONLY valid when the
- * block table was created with the global table's primes (an option of this framework; tables
- * from a reference checkpoint carry their own primes and need gfn_hash_fwd_f16).  Built by
- * gfn_table_pair_f16; the block half is kept current by gfn_adam_step_ex (shadow_pair = 1). */
-int gfn_table_pair_f16(const float* global_pool, const float* block_pool, uint16_t* pair_f16, int64_t n_elems,
-                       void* stream);
-int gfn_hash_fwd_pair(const uint16_t* pair_f16, const int32_t* prim_pool, const float* bias_pool, const float* pts,
-                      const void* anchors, int anchors_i64, int anchor_stride, int64_t n_max, const int32_t* n_dev,
-                      int64_t n_volumes, int log2_T, float* out, void* stream);
 /* The same lookup as gfn_hash_fwd_f16 in LEVEL-MAJOR order (csrc/lm_lookup.hip): every workgroup owns a run of
  * samples and all workgroups sweep level by level, table by table, and -- for levels >= halves_from -- one
  * address part (1 / 2^split_log2 of the level's slots; split_log2 = 0: halves, 4 MB each at T = 2^21)
@@ -388,8 +377,7 @@ int gfn_wgrad_x3_layers(const gfn_wgrad_layer* layers, int n_layers, int64_t n_m
 int gfn_wgrad_reduce(const float* parts, int n_parts, int64_t part_stride, int64_t n, float* out, void* stream);
 
 /* Everything after the sampler in ONE persistent kernel (csrc/fused_fwd.hip): f16-shadow hash lookup
- * (+ residual table2 with its own primes, or NULL; or pair_table != 0: table_f16 is the interleaved
- * gfn_table_pair_f16 image of both tables) -> x3 decoder -> front-to-back compositing with early
+ * (+ residual table2 with its own primes, or NULL) -> x3 decoder -> front-to-back compositing with early
  * termination.  A wave walks one ray in 32-sample tiles and leaves it once the transmittance is below
  * early_T (early_T <= 0: every sample, the reference's semantics); samples behind that point are never
  * looked up and get sigma = rgb = weight = alpha = 0.  Inputs: the packed sampler outputs (pts in table
@@ -400,7 +388,7 @@ int gfn_wgrad_reduce(const float* parts, int n_parts, int64_t part_stride, int64
  * eighth of the batch, drained first by the workgroups of one XCD: neighbouring rays share an L2). */
 int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
                       const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
-                      const int32_t* prim_pool, const int32_t* prim_pool2, int pair_table, const float* bias_pool,
+                      const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                       int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                       const int32_t* cam_idx, float early_T, float* sigma, float* rgb, float* h0, uint64_t* masks,
                       float* weights, float* alphas, float* feat, uint16_t* planes_hi, uint16_t* planes_lo,
@@ -416,7 +404,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
  * Replaces GFNeRFModel.get_outputs under get_outputs_for_camera_ray_bundle (nerfacto.py:531-566, base_model.py:163-186). */
 int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
                      const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
-                     const int32_t* prim_pool, const int32_t* prim_pool2, int pair_table, const float* bias_pool,
+                     const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                      int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                      const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
                      float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
@@ -572,11 +560,10 @@ int gfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
                   float beta1, float beta2, float eps, const float* hyper_dev, void* stream);
 /* Adam for a hash table: g is f32 (g_f16 == 0) or f16 (g_f16 != 0) and is multiplied by
  * g_scale first (1/128 for gfn_hash_bwd's f16 pool); shadow_f16 (may be NULL) receives
- * f16(p) of every updated element so gfn_hash_fwd_f16 stays current (shadow_pair != 0: the
- * shadow is the block half of a gfn_table_pair_f16 image). */
+ * f16(p) of every updated element so the f16 lookups stay current. */
 int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m, float* v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
-                     int shadow_pair, const float* hyper_dev, void* stream);
+                     const float* hyper_dev, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
 /* n <= 8 small device-to-device copies (src[i] -> dst[i], bytes[i] a multiple of 4, 4-byte aligned) in ONE launch: the batch
  * hand-over in front of a captured training step (gfnerf_amd.stepgraph).  src / dst / bytes are HOST arrays. */

@@ -182,3 +182,20 @@ def test_frame_routing_follows_block_ownership():
         assert owners == [int(labels[c]) % k for c in path]
         shards = [gd.frame_shard_by_block(labels[path], k, r) for r in range(k)]
         assert sorted(f for s in shards for f in s) == list(range(25))
+
+
+def test_focal_blocks_are_routed_one_per_rank():
+    """GFNeRFModel.stage_of: one process follows the reference's schedule (block = period mod n_split, perssampler.py:316-317); W ranks
+    train W different blocks in every period and cover all blocks in n_split / W periods."""
+    from gfnerf_amd.gfnerf.nerfacto import focal_block
+
+    S, P, N = 30000, 10000, 8
+    assert focal_block(0, S, P, N) is None and focal_block(S - 1, S, P, N, 8, 3) is None and focal_block(-1, S, P, N) is None
+    assert [focal_block(S + p * P, S, P, N) for p in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    for world in (2, 4, 8):
+        seen = []
+        for period in range(N // world):
+            blocks = [focal_block(S + period * P + 17, S, P, N, world, r) for r in range(world)]
+            assert len(set(blocks)) == world  # no two ranks on one table
+            seen += blocks
+        assert sorted(seen) == list(range(N))

@@ -146,8 +146,6 @@ def test_hash_forward_f16_shadow_and_fused_dual(oracle, ops, dev):
     wb2 = oracle.hash_fwd(pb, prim2, bias, pts, anchors3[:, 0], n_vol, log2_T)
     dual2 = ops.hash_fwd_f16(a16, *common, table2_f16=b16, prim_pool2=_t(prim2, dev)).cpu().numpy()
     assert np.array_equal(dual2, wa + wb2) and not np.array_equal(dual2, dual)
-    pair = ops.table_pair_f16(_t(pa, dev), _t(pb, dev))
-    assert np.array_equal(ops.hash_fwd_pair(pair, *common).cpu().numpy(), dual)  # interleaved 8-byte gathers
     # unfused two-call form of the boundary (accumulate) agrees bit for bit
     two = ops.hash_fwd(_t(pa, dev), _t(prim, dev), _t(bias, dev), _t(pts, dev), _t(anchors3, dev), n_vol, log2_T)
     ops.hash_fwd(_t(pb, dev), _t(prim, dev), _t(bias, dev), _t(pts, dev), _t(anchors3, dev), n_vol, log2_T, out=two, accumulate=True)
@@ -199,12 +197,6 @@ def test_adam_table_f16_grad_and_shadow(oracle, ops, dev):
     np.testing.assert_allclose(got[:4000], p_ref[:4000], rtol=1e-6, atol=1e-8)
     assert np.array_equal(got[4000:], p0[4000:])  # elements beyond n untouched
     assert np.array_equal(shadow.cpu().numpy()[:4000], got[:4000].astype(np.float16))
-    # interleaved (pair) shadow: element i lands in the block half of slot i/2
-    pair = torch.zeros(2 * n, dtype=torch.float16, device=dev)
-    p2 = _t(p0.copy(), dev); m2, v2 = torch.zeros_like(p2), torch.zeros_like(p2)
-    ops.adam_step_table(p2, _t(g16, dev), m2, v2, 1, shadow_f16=pair, shadow_pair=True)
-    pr = pair.cpu().numpy().reshape(-1, 4)
-    assert np.all(pr[:, :2] == 0) and np.array_equal(pr[:, 2:].reshape(-1), p2.cpu().numpy().astype(np.float16))
 
 
 # --------------------------------------------------------------------------- sampler

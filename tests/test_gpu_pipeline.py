@@ -312,39 +312,6 @@ def test_fused_forward_matches_separate_kernels(setup, block):
     assert np.array_equal(ce["t_minmax"].cpu().numpy(), csep["t_minmax"].cpu().numpy())
 
 
-def test_fused_forward_pair_table(setup):
-    """share_block_primes: the fused forward gathers the interleaved {global, block} image; same features as the
-    two-table lookup through the global primes, same decoder outputs as the separate kernels."""
-    import torch
-
-    from gfnerf_amd import hotpath, ops
-
-    S = setup
-    sc, t = S["sc"], S["t"]
-    cfg = hotpath.HotPathConfig(log2_T=14, early_T=0.0, keep_features=True, share_block_primes=True)
-    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
-    hp.blocks[0].uniform_(-1e-2, 1e-2)
-    hp.table.mul_(100.0)
-    hp.refresh_shadows()
-    cam = t(S["cam"])
-    s = hp.sample(t(S["o"]), t(S["d"]), t(S["noise"]))
-    N = int(s["pts_offsets"][-1].item())
-    f, comp = hp._forward_fused(s, cam, 0, 0.0, save=True)
-    two = ops.hash_fwd_f16(hp.table16, hp.prim, None, s["warped_pts"], s["anchors"], hp.n_volumes, cfg.log2_T,
-                           table2_f16=ops.table_to_f16(hp.blocks[0]), prim_pool2=None, n_dev=s["n_dev"])
-    assert np.array_equal(f["feat"].cpu().numpy()[:N], two.cpu().numpy()[:N])
-    sep = hp._field_forward(s, cam, block=0, fused=True, save=True)
-    assert np.array_equal(f["sigma"].cpu().numpy()[:N], sep["sigma"].cpu().numpy()[:N])
-    assert np.array_equal(f["rgb"].cpu().numpy()[:N], sep["rgb"].cpu().numpy()[:N])
-    # and a training step runs through the pair path (Adam keeps the block half of the image current)
-    gt = t(S["gt"])
-    s3 = ops.s3im_index(cam.numel(), cfg.s3im_repeat_time, device="cuda")  # one permutation set: the losses are comparable
-    l0, _ = hp.train_step(t(S["o"]), t(S["d"]), cam, gt, t(S["noise"]), stage="focal", block=0, s3im_index=s3)
-    for _ in range(4):
-        l1, _ = hp.train_step(t(S["o"]), t(S["d"]), cam, gt, t(S["noise"]), stage="focal", block=0, s3im_index=s3)
-    assert l1.item() < l0.item()
-
-
 def test_fused_paths_edge_cases(setup):
     """Rays that miss the scene (no samples), rays that hit the 1024-sample cap, an all-miss batch and an empty batch
     through the fused forward / backward; every output stays finite and rays without samples render black."""
@@ -696,25 +663,6 @@ def test_exact_lds_accumulation_makes_the_table_gradient_reproducible(setup):
     assert float((f1.float() - a.float()).abs().max()) <= 5e-2 * float(a.float().abs().max())  # the f16 image: close, not identical
 
 
-def test_render_with_level_major_lookups_matches_fused_forward(setup):
-    """HotPathConfig.level_major_render: inference through the level-major lookups + decoder + compositing kernels gives the
-    fused forward's image (same features bit for bit, same decoder tile; the compositing scans differ in summation order)."""
-    S = setup
-    hp, t = S["hp"], S["t"]
-    args = (t(S["o"]), t(S["d"]), t(S["cam"]), t(S["noise"]))
-    ref = hp.render(*args, block=0)
-    hp.cfg.level_major_render = True
-    try:
-        got = hp.render(*args, block=0)
-        assert hp.render(*args, block=None)["rgb"].shape == ref["rgb"].shape  # one table: falls back to the fused forward
-    finally:
-        hp.cfg.level_major_render = False
-    n = int(ref["samples"]["pts_offsets"][-1].item())
-    assert np.array_equal(got["field"]["sigma"][:n].cpu().numpy(), ref["field"]["sigma"][:n].cpu().numpy())
-    for k in ("rgb", "accumulation", "depth"):
-        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].cpu().numpy(), atol=2e-6, rtol=1e-5)
-
-
 def test_async_adam_is_the_same_training_run(setup):
     """HotPathConfig.async_adam: Adam + pool zeroing on a third stream beside the next step's global-table lookup gives the
     same losses and (up to the f16 gradient noise) the same block table as the synchronous order."""
@@ -801,10 +749,10 @@ def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_wi
     assert odd["field"] is not None
 
 
-def test_pipelined_adam_is_the_same_step(setup):
-    """HotPathConfig.adam_pipeline_chunks = 4: the record accumulation in four launches over slot ranges, the block table's Adam a
-    chunk behind on the optimiser stream -- the same table, moments and f16 shadow, bit for bit, as the one-after-the-other order,
-    eagerly and as hipGraph replays."""
+def test_step_graph_replays_without_host_sync_use_each_steps_own_adam_factors(setup):
+    """StepGraph replays enqueued back to back, the host several steps ahead of the device (nothing is read back in between): Adam's
+    step-dependent factors -- they travel through a ring of pinned blocks, one per replay -- must still be those of the step being
+    replayed.  The same table, moments and f16 shadow, bit for bit, as the eager steps."""
     import torch
 
     from gfnerf_amd import hotpath, scene, stepgraph
@@ -820,8 +768,8 @@ def test_pipelined_adam_is_the_same_step(setup):
     fin = 5.0
     noise = t(scene.make_noise(R, False, fin))
 
-    def run(chunks, graph):
-        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, adam_pipeline_chunks=chunks)
+    def run(graph):
+        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.table.mul_(100.0); hp.refresh_shadows()
         o, d, cam, gt = batches[0]
@@ -839,14 +787,10 @@ def test_pipelined_adam_is_the_same_step(setup):
         m, v = hp._adam["block0"][:2]
         return hp.blocks[0].clone(), m.clone(), v.clone(), hp.blocks16[0].clone()
 
-    ref = run(1, False)
+    ref, got = run(False), run(True)
     assert float((ref[0]).abs().max()) > 0 and float(ref[1].abs().max()) > 0  # the block table did train
-    # (1, True): the replays run without a host synchronisation in between, i.e. with the host several steps ahead -- Adam's
-    # step-dependent factors must still be those of the step being replayed (they travel through a pinned block per step)
-    for chunks, graph in ((1, True), (4, False), (4, True), (3, False)):
-        got = run(chunks, graph)
-        for a, b, name in zip(got, ref, ("table", "m", "v", "f16 shadow")):
-            assert torch.equal(a, b), (chunks, graph, name)
+    for a, b, name in zip(got, ref, ("table", "m", "v", "f16 shadow")):
+        assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize("stage", ["focal", "global"])
