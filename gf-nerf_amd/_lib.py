@@ -52,7 +52,7 @@ SIGNATURES = {
     "gfn_field_fwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "gfn_field_bwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_field_bwd_scatter_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64,
-                                        _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+                                        _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_grad_record_ranges": (_i32, [_i32]),
     "gfn_grad_records_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "gfn_grad_max": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -80,7 +80,7 @@ SIGNATURES = {
     "gfn_errmap_sample": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_composite_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_depth_finalize": (_i32, [_vp, _i64, _vp, _f32, _vp]),
-    "gfn_phase_list": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gfn_phase_list": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_composite_fwd_phased": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_two_phase_plan": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i32, _vp]),
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),

@@ -278,7 +278,9 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
     const u32x4* __restrict__ image, float* __restrict__ dfeat, const float* __restrict__ gmax_dev,
     uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, int64_t cap, const int* __restrict__ ray_id,
-    const int* __restrict__ cam_idx, float* __restrict__ demb, ScatterArgs S) {
+    const int* __restrict__ cam_idx, float* __restrict__ demb, ScatterArgs S,
+    const int32_t* __restrict__ list /* (no planes) only the samples list[0 .. *list_n): the samples in front of their rays' */,
+    const int32_t* __restrict__ list_n /* termination points -- every other sample's incoming gradient is zero */) {
 #define BPL(half, C) (planes_##half + cap * (C))
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
@@ -290,7 +292,9 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
   __syncthreads();
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + BWD_CHUNKS * 64;
-  const int64_t n = gfn_live_n(n_max, n_dev);
+  const bool listed = !PLANES && list != nullptr && *list_n >= 0;  // (a negative count: "every sample", no list was written)
+  int64_t n = listed ? (int64_t)*list_n : gfn_live_n(n_max, n_dev);
+  if (n > n_max) n = n_max;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, j = lane & 31;
   const int64_t n_tiles = (n + 31) / 32;
@@ -298,9 +302,10 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
   if (PLANES) { g_sc = gfn_grad_scale_of(gmax_dev[0]); g_inv = 1.0f / g_sc; }
   constexpr int kWaves = bwd_threads<PLANES, SCATTER>() / 64;
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWaves) {
-    const int64_t s = tile * 32 + j;
-    const bool valid = s < n;
-    const int64_t q = valid ? s : n - 1;
+    const int64_t e = tile * 32 + j;
+    const bool valid = e < n;
+    const int64_t s = listed ? (int64_t)list[valid ? e : n - 1] : e;  // the lane's sample
+    const int64_t q = listed ? s : (valid ? s : n - 1);
     const float ds = valid ? d_sigma[q] : 0.f;
     float dz3[3];
     bool any_grad = ds != 0.f;
@@ -580,8 +585,11 @@ struct ScatterHost {  // optional: scatter d feat into a table gradient pool ins
 static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                              const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
-                             const int32_t* cam_idx, float* demb, const ScatterHost& sh, void* stream) {
+                             const int32_t* cam_idx, float* demb, const ScatterHost& sh, void* stream, const int32_t* list = nullptr,
+                             const int32_t* list_n = nullptr) {
   if (n_max == 0) return GFN_OK;
+  GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr) && !(list && planes_hi), "%s: a sample list needs its count and excludes the planes", fn);
+  GFN_CHECK_ARG(!list || sh.grad_pool, "%s: the sample list belongs to the scattering form", fn);
   const bool scatter = sh.grad_pool != nullptr;
   GFN_CHECK_ARG(d_sigma && d_rgb && rgb && h0 && masks && bwd_image && (dfeat || scatter), "%s: null pointer", fn);
   GFN_CHECK_ARG(!scatter || (sh.pts && sh.anchors && sh.prim_pool && sh.n_volumes > 0 && sh.n_volumes < (1ll << 26) && sh.log2_T >= 4 && sh.log2_T <= 26),
@@ -623,7 +631,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
 #define GFN_LAUNCH(P, SC)                                                                                                        \
   if (planes == P && mode == SC)                                                                                                 \
     field_bwd_dx_x3_kernel<P, SC><<<grid, bwd_threads<P, SC>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi, \
-                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S);
+                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n);
   GFN_BWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_BWD_ALL
@@ -642,7 +650,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const int32_t* prim_pool, const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
                              const int32_t* cam_idx, float* demb, void* records, uint32_t* record_counts, int64_t record_capacity,
-                             void* stream) {
+                             const int32_t* list, const int32_t* list_n, void* stream) {
   GFN_CHECK_ARG(n_max == 0 || grad_pool, "gfn_field_bwd_scatter_x3: null gradient pool");
   GFN_CHECK_ARG(n_max == 0 || (planes_hi == nullptr) == (planes_lo == nullptr), "gfn_field_bwd_scatter_x3: planes need both halves");
   GFN_CHECK_ARG(n_max == 0 || !planes_hi || gmax_dev, "gfn_field_bwd_scatter_x3: planes need gmax");
@@ -652,7 +660,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
   sh.grad_pool = grad_pool; sh.grad_f16 = grad_f16;
   sh.rec = records; sh.rec_count = record_counts; sh.rec_cap_total = record_capacity;
   return field_bwd_x3_impl("gfn_field_bwd_scatter_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, nullptr, gmax_dev, planes_hi, planes_lo,
-                           plane_cap, ray_id, cam_idx, demb, sh, stream);
+                           plane_cap, ray_id, cam_idx, demb, sh, stream, list, list_n);
 }
 
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,

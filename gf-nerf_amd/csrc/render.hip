@@ -231,11 +231,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 }
 
 // The sample list of a phase: ray r contributes c_r consecutive samples from its sample `first` on --
-//   phase A (need_more == null): first = 0, c_r = min(K, n_r);   phase B: first = K, c_r = need_more[r] ? n_r - K : 0.
+//   phase A (need_more == null): first = 0, c_r = min(K, n_r);   phase B: first = K, c_r = need_more[r] ? n_r - K : 0;
+//   the samples in front of the termination points (term != null; the backward's list): first = 0, c_r = min(term[r], n_r).
 // scan: one workgroup, exclusive prefix sum of c_r over the rays -> coff i32 [R + 1]; stats[base] = entries, stats[base + 1] = rays
-// with c_r > 0 (base 0 for phase A, 2 for phase B: stats = {A samples, A rays, B samples, B rays}).  fill: one wave per ray.
+// with c_r > 0 (base 0 / 2 / 4: stats = {A samples, A rays, B samples, B rays, front samples, front rays}).  fill: one wave per ray.
 __global__ __launch_bounds__(1024) void phase_scan_kernel(const int* __restrict__ pts_offsets, int n_rays, const int* __restrict__ k_split,
-                                                          const uint8_t* __restrict__ need_more, int* __restrict__ coff, int* __restrict__ stats) {
+                                                          const uint8_t* __restrict__ need_more, const int* __restrict__ term,
+                                                          int* __restrict__ coff, int* __restrict__ stats) {
   __shared__ int s_wave[16], s_rays[16];
   __shared__ int s_carry, s_nr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(1024) void phase_scan_kernel(const int* __restrict_
     int c = 0;
     if (r < n_rays) {
       const int n = pts_offsets[r + 1] - pts_offsets[r];
-      c = need_more ? ((need_more[r] && n > K) ? n - K : 0) : (n < K ? n : K);
+      if (term) c = term[r] < n ? term[r] : n;
+      else c = need_more ? ((need_more[r] && n > K) ? n - K : 0) : (n < K ? n : K);
       c = c < 0 ? 0 : c;
     }
     int v = c;
@@ -271,9 +274,9 @@ __global__ __launch_bounds__(1024) void phase_scan_kernel(const int* __restrict_
     __syncthreads();
   }
   if (tid == 0) {
-    const bool all = !need_more && K >= 1024;  // phase A of a one-phase step: every sample -- no list is needed (entries = -1)
+    const bool all = !need_more && !term && K >= 1024;  // phase A of a one-phase step: every sample -- no list is needed (entries = -1)
     coff[n_rays] = all ? 0 : s_carry;
-    const int base = need_more ? 2 : 0;
+    const int base = term ? 4 : (need_more ? 2 : 0);
     stats[base] = all ? -1 : s_carry; stats[base + 1] = s_nr;
   }
 }
@@ -313,7 +316,9 @@ __global__ __launch_bounds__(1024) void two_phase_plan_kernel(const int* __restr
   __shared__ int s_wave[16][4];
   __shared__ float s_best[2];
   __shared__ int s_arg[2];
+  __shared__ int s_fmax, s_f99;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { s_fmax = 0; s_f99 = 1024; }
   for (int k = tid; k < 1025; k += 1024) { hN[k] = 0; hC[k] = 0; hS[k] = 0; }
   const int k_used = *k_split;
   __syncthreads();
@@ -341,6 +346,10 @@ __global__ __launch_bounds__(1024) void two_phase_plan_kernel(const int* __restr
   __syncthreads();
   const int totN = pN[1023] + hN[1024], totC = pC[1023] + hC[1024], totS = pS[1023] + hS[1024];
   const int totKN = pKN[1023] + 1024 * hN[1024];
+  // the latest termination point of the batch and the 99th percentile (every thread looks at its own bin: no serial scan)
+  if (hC[tid] > 0) atomicMax(&s_fmax, tid);
+  if (tid == 1023 && hC[1024] > 0) atomicMax(&s_fmax, 1024);
+  if (pC[tid] >= totC - totC / 100) atomicMin(&s_f99, tid);
   // candidates K = 8 * (tid + 1), tid < 128:  A(K) = sum_r min(K, n_r);  rays / samples of phase B = those with f_r > K
   float cost = 3.0e38f;
   const int K = 8 * (tid + 1);
@@ -373,11 +382,9 @@ __global__ __launch_bounds__(1024) void two_phase_plan_kernel(const int* __restr
     // two phases expected: the cheapest K as it is
     int next = arg;
     if (arg >= 1024 || totC - pC[arg] == 0) {
-      int fmax = 0, f99 = 0;
-      const int want99 = totC - totC / 100;
-      for (int k = 1024; k >= 0; k--) if (hC[k] > 0) { fmax = k; break; }
-      for (int k = 0; k < 1024; k++) if (pC[k] >= want99) { f99 = k; break; }
-      if (f99 == 0 || f99 > fmax) f99 = fmax;
+      const int fmax = s_fmax;
+      int f99 = s_f99;
+      if (f99 > fmax) f99 = fmax;
       const int margin = fmax - f99 > 2 ? fmax - f99 : 2;
       next = fmax + margin;
     }
@@ -715,13 +722,14 @@ int gfn_composite_fwd_phased(const int32_t* pts_offsets, int64_t n_rays, const f
   return GFN_OK;
 }
 
-int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_split, const uint8_t* need_more, int32_t* coff,
-                   int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb, void* stream) {
+int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_split, const uint8_t* need_more, const int32_t* term,
+                   int32_t* coff, int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb, void* stream) {
   if (n_rays == 0) return GFN_OK;
   GFN_CHECK_ARG(pts_offsets && k_split && coff && list && stats && n_rays > 0 && n_rays < (1ll << 24), "gfn_phase_list: bad arguments");
-  GFN_CHECK_ARG((zero_sigma == nullptr) == (zero_rgb == nullptr) && !(zero_sigma && need_more), "gfn_phase_list: sigma and rgb are cleared together, in phase A");
+  GFN_CHECK_ARG((zero_sigma == nullptr) == (zero_rgb == nullptr) && !(zero_sigma && (need_more || term)), "gfn_phase_list: sigma and rgb are cleared together, in phase A");
+  GFN_CHECK_ARG(!(need_more && term), "gfn_phase_list: one kind of list per call");
   hipStream_t st = gfn_stream(stream);
-  phase_scan_kernel<<<1, 1024, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more, coff, stats);
+  phase_scan_kernel<<<1, 1024, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more, term, coff, stats);
   GFN_CHECK_LAUNCH();
   phase_fill_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more ? 1 : 0, coff, list, zero_sigma, zero_rgb);
   GFN_CHECK_LAUNCH();

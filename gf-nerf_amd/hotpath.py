@@ -390,6 +390,8 @@ class HotPath:
                     image=self._x3()[0], planes=planes, sample_list=sb, out=f)
         self._timed("composite_fwd_b", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
                     second=True, out=comp)
+        if planes is None:  # (focal stage) the backward walks exactly the samples in front of the termination points
+            f["front"] = self._timed("phase_list_front", ops.phase_list, s["pts_offsets"], st, front=True)
         enter, stay = c.two_phase_min_saving_planes if planes is not None else c.two_phase_min_saving
         self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
         f["feat"] = feat
@@ -618,7 +620,7 @@ class HotPath:
             with self._cu_cap():
                 self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
-                            self.table_grad, n_dev=n_dev, records=rec)
+                            self.table_grad, n_dev=n_dev, records=rec, sample_list=f.get("front"))
             if rec is not None:
                 self._reduce_records(rec)
             dfeat = None

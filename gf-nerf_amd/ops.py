@@ -911,7 +911,7 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
 
 
 def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, prim_pool, bias_pool, n_volumes, log2_T, grad_pool,
-                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None):
+                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None, sample_list=None):
     """Decoder backward + hash scatter in one kernel: accumulates into grad_pool (f16 x128-scaled or f32, like hash_bwd); with
     planes / gmax (global stage) it also writes the dz planes for wgrad_x3 and the appearance-embedding gradient."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
@@ -927,6 +927,10 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
     ph, pl = planes if planes is not None else (None, None)
     cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
     rec, cnt = (records[0], records[1]) if records is not None else (None, None)
+    lst, lst_n = sample_list if sample_list is not None else (None, None)  # (no planes) walk only these samples: the others' gradients are zero
+    _chk(lst, torch.int32, "sample_list"); _chk(lst_n, torch.int32, "sample_list count")
+    if lst is not None and planes is not None:
+        raise _lib.GfnError("field_bwd_scatter_x3: a sample list excludes the gradient planes (their unlisted rows would keep stale values)")
     if rec is not None:
         _chk(rec, torch.int64, "records"); _chk(cnt, torch.int32, "counts")
         if cnt.numel() != _lib.lib().gfn_grad_record_ranges(int(log2_T)) * 256 or grad_pool.dtype != torch.float16:
@@ -934,7 +938,8 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
     rc = _lib.lib().gfn_field_bwd_scatter_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev), _ptr(pts),
                                              _ptr(anchors), _ptr(prim_pool), _ptr(bias_pool), n_volumes, log2_T, _ptr(grad_pool),
                                              int(grad_pool.dtype == torch.float16), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id),
-                                             _ptr(cam_idx), _ptr(demb), _ptr(rec), _ptr(cnt), rec.numel() if rec is not None else 0, _stream())
+                                             _ptr(cam_idx), _ptr(demb), _ptr(rec), _ptr(cnt), rec.numel() if rec is not None else 0,
+                                             _ptr(lst), _ptr(lst_n), _stream())
     _lib.check(rc, "gfn_field_bwd_scatter_x3")
     return grad_pool
 
@@ -1032,30 +1037,34 @@ class PhaseState:
         i32 = lambda n, v=0: torch.full((n,), v, dtype=torch.int32, device=device)  # noqa: E731
         self.n_rays, self.cap = int(n_rays), int(cap)
         self.k = i32(1, 1024)        # K of the next forward (1024 = one phase); gfn_two_phase_plan rewrites it every step
-        self.stats = i32(4)          # [samples, rays of phase A, samples, rays of phase B] of the step in flight
+        self.stats = i32(8)          # [samples, rays of phase A, of phase B, in front of the termination points] of the step in flight
         self.stats_last = i32(4)     # [samples of phase A, rays of phase B, samples of phase B, K] of the last finished step
-        self.list_a, self.list_b = i32(cap), i32(cap)
+        self.list_a, self.list_b, self.list_front = i32(cap), i32(cap), i32(cap)
         self.coff = i32(n_rays + 1)
         self.need_more = torch.zeros(n_rays, dtype=torch.uint8, device=device)
         self.term = i32(n_rays)
 
-    def samples(self, phase_b=False):
-        """(list, count) of a phase for hash_fwd_lm / field_fwd."""
+    def samples(self, phase_b=False, front=False):
+        """(list, count) of a phase for hash_fwd_lm / field_fwd, or of the samples in front of the termination points for the backward."""
+        if front:
+            return (self.list_front, self.stats[4:5])
         return (self.list_b, self.stats[2:3]) if phase_b else (self.list_a, self.stats[0:1])
 
 
-def phase_list(pts_offsets, st, phase_b=False, zero=None):
-    """Build the sample list of phase A (the first K samples of every ray) or phase B (samples K.. of the rays with need_more).
+def phase_list(pts_offsets, st, phase_b=False, zero=None, front=False):
+    """Build the sample list of phase A (the first K samples of every ray), of phase B (samples K.. of the rays with need_more), or
+    (front) of the samples in front of the termination points (the first st.term[r] of every ray: what the backward has to walk).
     zero = (sigma [n], rgb [n,3]) (phase A): the samples that are NOT listed get sigma = rgb = 0."""
     _chk(pts_offsets, torch.int32, "pts_offsets")
     zs, zr = zero if zero is not None else (None, None)
     _chk(zs, torch.float32, "sigma"); _chk(zr, torch.float32, "rgb", 3)
     if st.n_rays != pts_offsets.numel() - 1:
         raise _lib.GfnError("phase_list: the PhaseState was made for another batch size")
-    rc = _lib.lib().gfn_phase_list(_ptr(pts_offsets), st.n_rays, _ptr(st.k), _ptr(st.need_more) if phase_b else None, _ptr(st.coff),
-                                   _ptr(st.list_b if phase_b else st.list_a), _ptr(st.stats), _ptr(zs), _ptr(zr), _stream())
+    rc = _lib.lib().gfn_phase_list(_ptr(pts_offsets), st.n_rays, _ptr(st.k), _ptr(st.need_more) if phase_b else None, _ptr(st.term) if front else None,
+                                   _ptr(st.coff), _ptr(st.list_front if front else (st.list_b if phase_b else st.list_a)), _ptr(st.stats), _ptr(zs), _ptr(zr),
+                                   _stream())
     _lib.check(rc, "gfn_phase_list")
-    return st.samples(phase_b)
+    return st.samples(phase_b, front)
 
 
 def composite_fwd_phased(pts_offsets, sigma, dt, t, rgb, st, early_T, second=False, want_t_range=True, out=None):

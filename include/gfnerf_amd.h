@@ -306,7 +306,8 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap,
                              const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* records,
-                             uint32_t* record_counts, int64_t record_capacity, void* stream);
+                             uint32_t* record_counts, int64_t record_capacity, const int32_t* list,
+                             const int32_t* list_n, void* stream);
 /* records != NULL (f16 pool only) DEFERS the atomics of gfn_field_bwd_scatter_x3: the pool's live slots (f16
  * pairs [0, 17T/2)) are cut into ranges of 2^GFN_GRAD_RANGE_LOG2 slots, and every add becomes a record (slot u32,
  * packed f16x2 value) in the stream of (range, workgroup): records[(range * 256 + workgroup) * cap + i] with
@@ -470,6 +471,9 @@ int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
  *   gfn_phase_list (need_more)          list_b = samples K.. of those rays; stats[2] = entries, stats[3] = rays
  *   the same two kernels with list = list_b, list_n = stats + 2                              -- phase B (nothing, as a rule)
  *   gfn_composite_fwd_phased(ray_gate = need_more, gate = stats + 2)   composites those rays again, all samples now known
+ *   gfn_phase_list (term)               the samples in front of every ray's termination point (the first term[r]); stats[4] =
+ *                           entries, stats[5] = rays: the list gfn_field_bwd_scatter_x3 walks (every other sample's incoming
+ *                           gradient is zero)
  *   gfn_two_phase_plan      picks the next step's K from this batch's (ray length, termination point) pairs: the K that
  *                           minimises samples(phase A) + [phase B needed] * (fixed_cost_samples + samples(phase B)); when that
  *                           K covers every ray: the latest termination point + the width of the distribution's tail; 1024 when
@@ -479,7 +483,8 @@ int gfn_composite_fwd(const int32_t* pts_offsets, int64_t n_rays, const float* s
  * All of it is decided on the device: no host round trip, capturable in a hipGraph.  The backward needs no change: samples
  * that were never evaluated hold zero sigma / rgb and receive zero gradients. */
 int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_split, const uint8_t* need_more,
-                   int32_t* coff, int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb, void* stream);
+                   const int32_t* term, int32_t* coff, int32_t* list, int32_t* stats, float* zero_sigma, float* zero_rgb,
+                   void* stream);
 int gfn_composite_fwd_phased(const int32_t* pts_offsets, int64_t n_rays, const float* sigma, const float* dt,
                              const float* t, const float* rgb, float early_T, float* weights, float* alphas,
                              float* out_rgb, float* out_acc, float* out_depth, float* t_minmax,

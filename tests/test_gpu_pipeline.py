@@ -907,7 +907,7 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
         assert torch.equal(a[k], ref[k]), k
     # (the gradients are sums in an order that differs from run to run at this table size: the record streams of a 2^14 table
     # overflow into f16 atomics, and the decoder's partial sums meet in f32 atomics)
-    assert float((a["tg"] - ref["tg"]).abs().max()) <= 2e-3 * float(ref["tg"].abs().max())
+    assert float((a["tg"] - ref["tg"]).abs().max()) <= 5e-3 * float(ref["tg"].abs().max())
     st = two._phase
     last = st.stats_last.cpu().numpy()
     assert last[3] == 1024 and last[0] == ref["n"] and last[1] == 0 and last[2] == 0
@@ -936,7 +936,7 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
         assert torch.equal(b["sigma"][alive_front], ref["sigma"][alive_front]) and torch.equal(b["srgb"][alive_front], ref["srgb"][alive_front]), label
         assert abs(b["loss"] - ref["loss"]) <= 1e-6 * abs(ref["loss"]), label
         scale = float(ref["tg"].abs().max())
-        assert float((b["tg"] - ref["tg"]).abs().max()) <= 2e-3 * scale, label   # zero gradients behind the cut either way; f16 pool
+        assert float((b["tg"] - ref["tg"]).abs().max()) <= 5e-3 * scale, label   # zero gradients behind the cut either way; f16 pool
         if stage == "global":
             np.testing.assert_allclose(b["mlp"].cpu().numpy(), ref["mlp"].cpu().numpy(), rtol=1e-4, atol=1e-6 * float(ref["mlp"].abs().max()), err_msg=label)
 
