@@ -732,16 +732,28 @@ class StageRun:
         traffic, req = None, None
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            # the counters describe the kernel sources they were collected on: a figure measured on another version of the dominant
-            # kernel is not reported (tools/sync_profiles.py records the hashes with the counters)
-            stale = [f for f, h in pmc.get("source_sha256", {"csrc/lm_lookup.hip": None}).items() if _sha256(os.path.join(ROOT, "gf-nerf_amd", f)) != h]
-            if stale:
-                print(f"bench.py: profiles/pmc_traffic.json predates {stale}: roofline.traffic not reported", file=sys.stderr)
-                pmc = {k: v for k, v in pmc.items() if k in ("l2_gather_ceiling_per_s", "gather_request_ceiling_per_s", "n_side")}
+            # the counters describe the kernel sources they were collected on: a figure measured on another version of a kernel is not
+            # reported (tools/sync_profiles.py records the hashes with the counters)
+            def fresh(group):
+                files = pmc.get("source_sha256", {}).get(group)
+                ok = bool(files) and all(_sha256(os.path.join(ROOT, "gf-nerf_amd", f)) == h for f, h in files.items())
+                if not ok:
+                    print(f"bench.py: profiles/pmc_traffic.json predates the {group} kernel sources: its counters are not reported", file=sys.stderr)
+                return ok
+
+            if not fresh("lm_lookup"):
+                pmc = {k: v for k, v in pmc.items() if not k.startswith("lm_lookup") and not k.startswith("hash_fwd")}
+            if not fresh("decoder"):
+                pmc = {k: v for k, v in pmc.items() if not k.startswith("mfma_busy") and not k.startswith("field_fwd") and not k.startswith("bwd_scatter")}
             # the PMC passes were taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21)
-            default_cfg = args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20)
+            default_cfg = args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20) and not args.one_phase
             traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
+            # the counter table holds the mean over ALL launches of an instantiation: phase A's and phase B's, which returned at once
+            mix = 2 if (lm and self.phase) else 1
+            if traffic is not None:
+                traffic *= mix
             n_req = pmc.get(f"{dom}:{self.stage}:fetch_requests") if default_cfg else None
+            n_req = n_req * mix if n_req is not None else None
             if lm:  # the level-major kernel is bound by the L2 -> L1 line fills of its gathers (86 % of them hit the L2), not by the fabric
                 looked_up = None
                 if self.phase:  # the phased forward: the launch's share of the samples
@@ -751,8 +763,8 @@ class StageRun:
                 req = dict(unit="G gathers/s (4-byte, L2-resident range)", achieved=n_g / (kern_ms * 1e-3) / 1e9, peak=pmc["l2_gather_ceiling_per_s"] / 1e9,
                            frac=n_g / (kern_ms * 1e-3) / pmc["l2_gather_ceiling_per_s"], fabric_requests_per_launch=n_req,
                            nominal_gathers_per_launch=n_live * 128, issued_gathers_per_launch=n_g,
-                           l2_to_l1=(dict(line_fills_per_launch=pmc["lm_lookup:focal:l1_miss_requests"], bytes_per_fill=128,
-                                          achieved_TBps=pmc["lm_lookup:focal:l1_miss_requests"] * 128 / (kern_ms * 1e-3) / 1e12, peak_TBps=34.5,
+                           l2_to_l1=(dict(line_fills_per_launch=pmc["lm_lookup:focal:l1_miss_requests"] * mix, bytes_per_fill=128,
+                                          achieved_TBps=pmc["lm_lookup:focal:l1_miss_requests"] * mix * 128 / (kern_ms * 1e-3) / 1e12, peak_TBps=34.5,
                                           l2_hit_rate=pmc["lm_lookup:focal:l2_hit_rate"],
                                           source="TCP_TCC_READ_REQ_sum, TCC_HIT / TCC_MISS (profiles/*_pmc_focal_per_kernel.csv); peak: MI355X guide, L2")
                                      if default_cfg and self.stage == "focal" and "lm_lookup:focal:l1_miss_requests" in pmc else None),
@@ -762,8 +774,16 @@ class StageRun:
                 req = dict(unit="G L2-miss requests/s", achieved=n_req / (kern_ms * 1e-3) / 1e9, peak=pmc["gather_request_ceiling_per_s"] / 1e9,
                            frac=n_req / (kern_ms * 1e-3) / pmc["gather_request_ceiling_per_s"],
                            source="FETCH_SIZE/64 (profiles/pmc_traffic.json) over the live kernel time; peak = tools/gather_bench.hip")
+        # MFMA utilisation of the decoder (north_star: "MFMA utilisation on the MLP against gfx950 peak"): SQ_VALU_MFMA_BUSY_CYCLES over SIMD
+        # cycles from the --pmc pass, and the rate of issued / useful matrix FLOP over the live kernel time against the 2.5 PFLOP/s dense f16 peak
+        mfma = {}
+        if os.path.exists(pmc_path) and "field_fwd" in kern:
+            busy = pmc.get(f"mfma_busy:field_fwd:{self.stage}") if default_cfg else None
+            useful = n_eval * 61952.0 / (kern["field_fwd"] * 1e-3) / 1e12  # 61,952 FLOP per decoded sample; x3 issues 3 MFMAs per product
+            mfma = dict(mfma_busy_frac=busy, mfma_tflops_useful=useful, mfma_tflops_issued=3.0 * useful, mfma_peak_tflops=2500.0,
+                        mfma_kernel="field_fwd_x3_kernel", mfma_kernel_ms=kern["field_fwd"])
         return dict(bound="hbm", kernel=kernel_name, launches_per_step=launches, achieved=alg_bytes / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms,
+                    frac=alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic, avg_kernel_ms=kern_ms, **mfma,
                     timing=("HIP events on the launch stream around every launch of the timed region" if res["event_steps"] == res["steps"] and self.launch.startswith("eager")
                             else f"HIP events on the launch stream in {res['event_steps']} eager steps run right after the timed region (the timed steps are hipGraph replays, "
                                  "which hide individual launches from events)"),

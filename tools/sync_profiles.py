@@ -65,7 +65,8 @@ j["mfma_busy:field_fwd:global"] = busy(one(g, "field_fwd_x3"))
 j["mfma_busy:bwd_scatter:global"] = busy(one(g, "field_bwd_dx"))
 j["mfma_busy:wgrad:global"] = busy(one(g, "wgrad_x3_layers"))
 sha = lambda q: hashlib.sha256(open(os.path.join("gf-nerf_amd", q), "rb").read()).hexdigest()
-j["source_sha256"] = {q: sha(q) for q in ("csrc/lm_lookup.hip", "csrc/hash_device.h", "csrc/field_x3.hip", "csrc/x3_device.h")}
+j["source_sha256"] = {"lm_lookup": {q: sha(q) for q in ("csrc/lm_lookup.hip", "csrc/hash_device.h")},
+                      "decoder": {q: sha(q) for q in ("csrc/field_x3.hip", "csrc/x3_device.h")}}
 json.dump(j, open(p, "w"), indent=1)
 for k in sorted(j):
     if ":" in k and not isinstance(j[k], dict):
