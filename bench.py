@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--lm-global-after", type=int, default=None, help="global stage: level-major forward from this optimiser step on (-1: never; default: HotPathConfig)")
     ap.add_argument("--record-capacity", type=int, default=0, help="gradient record buffer in records (0: HotPathConfig default)")
     ap.add_argument("--fork-first", action="store_true", help="forward_backward forks the octree update / next sampler before it enqueues the loss kernels (round-2 order)")
+    ap.add_argument("--segmented", action="store_true",
+                    help="experiment: capture the global step in the segments of the data-parallel step (exchange points eager, identities on one rank)")
     ap.add_argument("--draws-first", action="store_true",
                     help="graph launch: start the next step's random draws at the top of the step (beside the lookups) instead of behind them")
     ap.add_argument("--async-adam", action="store_true",
@@ -630,17 +632,22 @@ class StageRun:
         from gfnerf_amd import stepgraph
 
         hp, args = self.hp, self.args
-        if args.launch != "graph" or (self.world > 1 and self.stage == "global") or args.no_prefetch:
-            return None, "eager (requested)" if args.launch != "graph" else "eager (data-parallel step: collectives)"
+        if args.launch != "graph" or args.no_prefetch or (self.world > 1 and self.stage == "global" and args.no_oct_update):
+            return None, "eager (requested)"
         try:
             hp._drop_stale_samples()  # the last eager step prefetched a sample nobody will collect
             blocks = list(range(self.n_blocks)) if self.stage == "focal" else None
             sg = stepgraph.StepGraph(hp, self.stage, N_RAYS, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update,
-                                     draws_after_lookup=not args.draws_first)
+                                     draws_after_lookup=not args.draws_first,
+                                     segmented=True if (args.segmented and self.stage == "global") else None)
             o, d, _, _ = self.batches[self.i % 4]
             sg.prime(o, d)
             sg.p = self.i % sg.cycle  # the block rotation goes on where the eager steps stopped
             sg.capture()
+            if sg.segmented:
+                n_seg = sum(isinstance(x, self.torch.cuda.CUDAGraph) for x in sg.G[0])
+                return sg, (f"hipGraph replay in {n_seg} segments per step, the data-parallel exchanges (octree MAX, table gradient, decoder gradients) "
+                            f"eager between them; forward {hp.last_forward}")
             return sg, (f"hipGraph replay ({sg.cycle} captured graphs: sample-buffer parity x block rotation; forward {hp.last_forward}" +
                         ("" if sg.phased is None else ", phased" if sg.phased else ", one phase: the plan at capture found no split worth its launches") + ")")
         except Exception as e:  # noqa: BLE001 -- the eager path is always there

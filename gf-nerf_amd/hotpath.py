@@ -102,6 +102,8 @@ class HotPath:
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
+        self.seg = None             # set by a segmented StepGraph capture: seg(fn) ends the graph segment being captured, notes fn as the
+                                    # eager call between segments (a collective) and begins the next segment
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
         T = self.cfg.log2_T
         self.prim = t(scene.make_primes(self.n_volumes, seed=seed + 2))
@@ -598,7 +600,8 @@ class HotPath:
                     self._reduce_records(rec)
                 dfeat = None
                 # data parallel: the table gradient is final here -- its exchange runs beside the weight-gradient kernels below
-                self.sync.start_grads([self._grad_live()])
+                live = self._grad_live()
+                self._eager(lambda: self.sync.start_grads([live]))
                 ctx["table_exchange_started"] = True
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
@@ -656,18 +659,23 @@ class HotPath:
         c = self.cfg
         comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False, samples=samples)
         fwd_done = None
-        if c.loss_before_fork and prefetch is not None:
+        segmented = self.seg is not None
+        if c.loss_before_fork and prefetch is not None and not segmented:
             fwd_done = torch.cuda.Event()
             fwd_done.record()  # the side branch (octree update, next sampler) starts behind the forward, whatever is enqueued first
+        if segmented and stage == STAGE_GLOBAL and update_oct:
+            # a segmented capture cannot end a segment while a branch is open: K5 -> MAX exchange -> K6 run on THIS stream, between the
+            # forward and the loss; the side branch keeps the next batch's sampler
+            self._timed("oct_update", self.update_oct_nodes, ctx)
 
         def fork():
-            if stage == STAGE_GLOBAL and update_oct:
+            if stage == STAGE_GLOBAL and update_oct and not segmented:
                 if prefetch is not None:
                     self.prefetch_sample(*prefetch, first=lambda: self._timed("oct_update", self.update_oct_nodes, ctx), out=prefetch_out,
                                          after=fwd_done)
                 else:
                     self._timed("oct_update", self.update_oct_nodes, ctx)
-            elif prefetch is not None and stage == STAGE_FOCAL:
+            elif prefetch is not None and (stage == STAGE_FOCAL or (segmented and update_oct)):
                 self.prefetch_sample(*prefetch, out=prefetch_out, after=fwd_done)
 
         if not c.loss_before_fork:
@@ -775,19 +783,26 @@ class HotPath:
             return out
         return [live]
 
+    def _eager(self, fn):
+        """An exchange point of the data-parallel step: a collective, which is never captured.  Eager step: run it.  Segmented
+        capture (gfnerf_amd.stepgraph): the graph segment ends here, fn is replayed between this segment and the next."""
+        if self.seg is None:
+            fn()
+        else:
+            self.seg(fn)
+
     def sync_grads(self, stage, ctx=None):
         """Data-parallel global stage (scripts/train.py:124-137, gf_pipeline.py:136-138 -- DDP there, which misses the hash
         table): average this step's gradients over the ranks before Adam.  The table exchange may already be in flight
         (backward starts it as soon as the table gradient is final); the decoder / embedding gradients follow here.  The focal
         stage trains one block table per rank with everything shared frozen: nothing to exchange."""
-        if self.sync.world == 1 or stage != STAGE_GLOBAL:
+        if stage != STAGE_GLOBAL or (self.sync.world == 1 and self.seg is None):
             return
         g = self.grads(stage)
         if ctx is not None and ctx.pop("table_exchange_started", False):
-            self.sync.finish_grads(g[1:])
+            self._eager(lambda: self.sync.finish_grads(g[1:]))
         else:
-            self.sync.start_grads(g[:1])
-            self.sync.finish_grads(g[1:])
+            self._eager(lambda: (self.sync.start_grads(g[:1]), self.sync.finish_grads(g[1:])))
 
     def train_step(self, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, stage=STAGE_GLOBAL, block=None, s3im_index=None,
                    prefetch=None, update_oct=False, samples=None, prefetch_out=None, hyper=None):
@@ -803,9 +818,11 @@ class HotPath:
         """persampler.update_oct_nodes (nerfacto.py:606-613) on the packed samples of the last step.  Data parallel: the
         per-node maxima K5 produced from this rank's rays are MAX-reduced over the ranks before the statistics update and K6."""
         s, comp = aux["samples"], aux["comp"]
+        exchange = None
+        if self.sync.world > 1 or self.seg is not None:
+            exchange = lambda ts: self._eager(lambda: self.sync.reduce_octree_stats(ts))  # noqa: E731
         ops.update_nodes(s["pts_offsets"], s["anchors"], comp["weights"], comp["alphas"], self.weight_stats,
-                         self.alpha_stats, self.visit_cnt, self.nodes,
-                         reduce_max=self.sync.reduce_octree_stats if self.sync.world > 1 else None)
+                         self.alpha_stats, self.visit_cnt, self.nodes, reduce_max=exchange)
         ops.tree_compact(self.nodes, self.nodes_compact)  # K6 may have invalidated leaves
 
     def _drop_stale_samples(self):

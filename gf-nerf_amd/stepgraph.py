@@ -18,8 +18,15 @@ caller refills between replays (`cam / gt` of this batch, `o / d` of the next); 
 a device vector the host refreshes before every replay (gfn_adam_hyper_host), so bias correction and learning-rate schedule
 advance although the launches are frozen.
 
-Not capturable, and refused: data-parallel steps (collectives run eagerly); a tree that changes size (ProcOctree every
-compact_freq steps: re-capture afterwards -- `StepGraph.invalidate`)."""
+The data-parallel global step (world > 1) is captured in SEGMENTS: collectives are not captured (gloo cannot be, and an RCCL call
+inside a graph would be this stack's first), so the capture ends at each of the step's three exchange points, notes the collective as
+an eager call, and begins the next segment:
+    graph 1: hand-over, forward, K5        | MAX all-reduce of the octree statistics
+    graph 2: K6, loss, backward + gradient accumulation (side branch: the next batch's sampler)   | table-gradient exchange starts (own stream)
+    graph 3: decoder weight gradients      | small all-reduce of the decoder / embedding gradients, wait for the table exchange
+    graph 4: Adam (side branch: nothing left)
+A replay is 4 graph launches + the collectives instead of ~60 launches.  `segmented=True` with one rank breaks at the same points
+with identity exchanges (tests).  A tree that changes size (ProcOctree every compact_freq steps) needs a re-capture -- `StepGraph.invalidate`."""
 import numpy as np
 import torch
 
@@ -28,14 +35,15 @@ from . import _lib, hotpath as hp_mod, ops
 
 class StepGraph:
     def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None, draws_after_lookup=True,
-                 replan_every=2048):
+                 replan_every=2048, segmented=None):
         """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant).
         replan_every: the phased (termination-aware) forward costs a handful of small launches even when its plan is "one phase, every
         sample" (an empty scene: nothing terminates).  At capture the plan is read back once (a forward of the batch at hand, no
         training step) and the step is captured WITHOUT the phase machinery when it says so; after this many replays the step is
         captured again, so that the choice follows the scene as it fills."""
-        if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL:
-            raise _lib.GfnError("StepGraph: the data-parallel global stage exchanges gradients with eager collectives; not captured")
+        self.segmented = (hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL) if segmented is None else bool(segmented)
+        if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL and not self.segmented:
+            raise _lib.GfnError("StepGraph: the data-parallel global step exchanges gradients with collectives; capture it segmented")
         self.hp, self.stage, self.R = hp, stage, int(n_rays)
         self.blocks = list(block) if isinstance(block, (list, tuple)) else [block]
         self.cycle = len(self.blocks) if len(self.blocks) % 2 == 0 else 2 * len(self.blocks)  # lcm(2, number of blocks)
@@ -114,7 +122,8 @@ class StepGraph:
         assert hp._pre is not None and hp._pre[4]["pts_offsets"] is self.S[1 - p]["pts_offsets"], "the prefetch must fill the other sample buffer"
         self.S[1 - p] = hp._pre[4]
         hp._pre = None  # collected: the next replay reads it as its `samples`
-        main.wait_stream(side)
+        if not self.segmented:
+            main.wait_stream(side)  # (segmented: the capture joins whatever branch is open when a segment ends)
         return loss, aux
 
     def capture(self):
@@ -146,13 +155,57 @@ class StepGraph:
         steps_before, ticks_before = hp.step, dict(hp._adam_t)
         pool = None
         for j in range(self.cycle):
+            if self.segmented:
+                self.G[j], pool = self._capture_segments(j, pool)
+                continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):  # (a communicator's watchdog thread may poll events meanwhile)
                 self.loss[j], self.aux[j] = self._step_eager_or_captured(j)
             pool = g.pool()
             self.G[j] = g
         hp.step, hp._adam_t = steps_before, ticks_before  # capturing executes nothing: the counters must not move
         self._tree = (hp.nodes.data_ptr(), hp.n_nodes)
+
+    def _capture_segments(self, j, pool):
+        """Step j as [graph, eager call, graph, ...]: hp.seg (called by HotPath at every exchange point) closes the segment being
+        captured -- open branches joined first -- and opens the next one in the same memory pool."""
+        hp = self.hp
+        segs, state = [], {}
+        cur = torch.cuda.current_stream()
+        cap = torch.cuda.Stream(device=hp.dev)
+        cap.wait_stream(cur)
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=state.get("pool"), capture_error_mode="thread_local")
+            state["g"] = g
+
+        def end():
+            if hp._side is not None:
+                with torch.cuda.stream(hp._side):
+                    forked = torch.cuda.is_current_stream_capturing()
+                if forked:
+                    cap.wait_stream(hp._side)
+            state["g"].capture_end()
+            state["pool"] = state["g"].pool()
+            segs.append(state["g"])
+
+        def seg(fn):
+            end()
+            segs.append(fn)
+            begin()
+
+        state["pool"] = pool
+        with torch.cuda.stream(cap):
+            begin()
+            hp.seg = seg
+            try:
+                self.loss[j], self.aux[j] = self._step_eager_or_captured(j)
+            finally:
+                hp.seg = None
+                end()
+        cur.wait_stream(cap)
+        return segs, state["pool"]
 
     def invalidate(self):
         """The tree (or anything else baked into the launches) changed: capture again at the next step."""
@@ -205,6 +258,13 @@ class StepGraph:
                        (self.nxt_d, next_rays_d.contiguous())])  # one launch, not four memcpy nodes in front of every replay
         self._refresh_hyper(advance=True)
         j = self.p
-        self.G[j].replay()
+        if self.segmented:
+            for x in self.G[j]:
+                if isinstance(x, torch.cuda.CUDAGraph):
+                    x.replay()
+                else:
+                    x()  # a collective between two segments
+        else:
+            self.G[j].replay()
         self.p = (j + 1) % self.cycle
         return self.loss[j], self.aux[j]

@@ -104,6 +104,44 @@ def main():
         res["drift_detected"] = not sync.replicas_identical([mixed])
         res["sync_stats"] = dict(sync.stats)
         res["loss"] = float(loss.item())
+
+        # ---- the same data-parallel step captured in segments (gfnerf_amd.stepgraph: graphs between the three exchange points, the
+        # collectives eager) against the eager data-parallel step, from one state, without random draws
+        from gfnerf_amd import stepgraph
+
+        cfg0 = hotpath.HotPathConfig(log2_T=16, early_T=1e-4, s3im_loss_mult=0.0)
+
+        def fresh0(sync_):
+            h = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg0, seed=0, sync=sync_)
+            h.table.mul_(50.0)
+            h.refresh_shadows()
+            return h
+
+        se, sg_sync = gd.TrainSync(direct=True if direct else None), gd.TrainSync(direct=True if direct else None)
+        he, hg = fresh0(se), fresh0(sg_sync)
+        K = 3
+        for h in (he, hg):  # step 0 eagerly on both (the capture needs the lazily created buffers)
+            h.train_step(*mine[0][:4], noise, stage="global", update_oct=True)
+        for k in range(1, K + 1):
+            nxt = mine[(k + 1) % 4]
+            he.train_step(*mine[k % 4][:4], noise, stage="global", prefetch=(nxt[0], nxt[1], noise), update_oct=True)
+        g = stepgraph.StepGraph(hg, "global", R, 6.0, update_oct=True, train_noise=False)
+        assert g.segmented
+        g.prime(mine[1][0], mine[1][1])
+        for k in range(1, K + 1):
+            nxt = mine[(k + 1) % 4]
+            g.step(mine[k % 4][2], mine[k % 4][3], nxt[0], nxt[1])
+        torch.cuda.synchronize()
+        res["segments"] = ["graph" if isinstance(x, torch.cuda.CUDAGraph) else "eager" for x in g.G[0]]
+        res["graph_replicas_identical"] = sg_sync.replicas_identical([hg.table, hg.table16, hg.mlp_flat, hg.emb, hg.nodes, hg.weight_stats,
+                                                                     hg.alpha_stats, hg.visit_cnt])
+        res["graph_sync_stats"] = dict(sg_sync.stats)
+        res["graph_tree_equal_eager"] = bool(torch.equal(hg.nodes, he.nodes) and torch.equal(hg.visit_cnt, he.visit_cnt)
+                                            and torch.equal(hg.weight_stats, he.weight_stats) and torch.equal(hg.alpha_stats, he.alpha_stats))
+        far = (hg.table - he.table).abs() > 2e-3 * float(he.table.abs().max())
+        res["graph_table_far_frac"] = float(far.float().mean())
+        res["graph_mlp_rel"] = float((hg.mlp_flat - he.mlp_flat).abs().max() / he.mlp_flat.abs().max())
+        res["graph_steps"] = [hg.step, he.step]
         res["ranks_seen"] = sync.ranks_seen()
         res["ok"] = True
     except Exception as e:  # noqa: BLE001 -- reported through OUT, the test prints it

@@ -70,17 +70,22 @@ def _worker(rank, world, port, q):
         table_grad[5] = 60000.0 if rank == 0 else 50000.0  # a plain f16 SUM of these overflows to inf
         mlp_grad, emb_grad = torch.randn(31251, generator=g), torch.randn(40, 32, generator=g)
         g_mine = (table_grad.clone(), mlp_grad.clone(), emb_grad.clone())
-        fake = types.SimpleNamespace(sync=sync, grads=lambda stage: [table_grad, mlp_grad, emb_grad])
+        def fake_hp(grads):  # what HotPath.sync_grads touches: the exchange points run eagerly (seg is set only under a segmented capture)
+            ns = types.SimpleNamespace(sync=sync, grads=grads, seg=None)
+            ns._eager = lambda fn: hotpath.HotPath._eager(ns, fn)
+            return ns
+
+        fake = fake_hp(lambda stage: [table_grad, mlp_grad, emb_grad])
         # 1) the fused backward started the table exchange itself (ctx flag), sync_grads sends the late ones and waits
         sync.start_grads([table_grad])
         hotpath.HotPath.sync_grads(fake, hotpath.STAGE_GLOBAL, {"table_exchange_started": True})
         first = (table_grad.clone(), mlp_grad.clone(), emb_grad.clone())
         # 2) nothing started yet (unfused paths): sync_grads does everything; the focal stage exchanges nothing
         t2, m2, e2 = g_mine[0].clone(), g_mine[1].clone(), g_mine[2].clone()
-        fake2 = types.SimpleNamespace(sync=sync, grads=lambda stage: [t2, m2, e2])
+        fake2 = fake_hp(lambda stage: [t2, m2, e2])
         hotpath.HotPath.sync_grads(fake2, hotpath.STAGE_GLOBAL, {})
         t3 = g_mine[0].clone()
-        hotpath.HotPath.sync_grads(types.SimpleNamespace(sync=sync, grads=lambda stage: [t3]), hotpath.STAGE_FOCAL, {})
+        hotpath.HotPath.sync_grads(fake_hp(lambda stage: [t3]), hotpath.STAGE_FOCAL, {})
         # the f16 pool through the plain path (sizes the direct path cannot split, gloo rehearsals): summed in f32, rounded once
         t4 = g_mine[0].clone()
         gd.allreduce_mean([t4])

@@ -61,6 +61,11 @@ def test_two_rank_global_stage_replicas_stay_identical(tmp_path, mode):
     assert res["sync_stats"]["octree_max_reduces"] == 3 and res["sync_stats"]["grad_reduces"] >= 6
     if mode == "direct":
         assert res["sync_stats"]["direct_reduces"] == 3
+    # the step captured in segments: four graphs, three eager exchanges; the replicas stay identical and it is the eager run
+    assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
+    assert res["graph_replicas_identical"] and res["graph_tree_equal_eager"] and res["graph_steps"] == [4, 4]
+    assert res["graph_sync_stats"]["octree_max_reduces"] == 4 and res["graph_sync_stats"]["grad_reduces"] >= 8
+    assert res["graph_table_far_frac"] < 1e-3 and res["graph_mlp_rel"] < 2e-2, (res["graph_table_far_frac"], res["graph_mlp_rel"])
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
@@ -85,6 +90,7 @@ def test_bench_self_spawns_two_ranks():
     g = d["global_stage"]
     assert "error" not in g, g
     assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and g["sync"]["grad_reduces"] >= 3
+    assert g["launch_short"] == "graph" and "4 segments" in g["launch"], g["launch"]  # the data-parallel step replays graph segments
     assert d["render"]["frames"] == 2 and "routed" in d["render"]["routing"]
 
 

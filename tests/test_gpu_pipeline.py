@@ -793,17 +793,20 @@ def test_step_graph_replays_without_host_sync_use_each_steps_own_adam_factors(se
         assert torch.equal(a, b), name
 
 
-@pytest.mark.parametrize("stage", ["focal", "global"])
+@pytest.mark.parametrize("stage", ["focal", "global", "global_segmented"])
 def test_step_graph_is_the_same_training_run(setup, stage):
     """gfnerf_amd.stepgraph.StepGraph: K training steps as hipGraph replays (sampler of the next batch on a captured side branch,
     Adam's step-dependent factors read from the device) against the same K steps launched eagerly -- with the random draws
     switched off (eval-mode march noise, no S3IM) the two runs must agree: bit for bit in the focal stage (exact LDS
     accumulation makes the step reproducible), to f16 gradient rounding in the global stage (its weight-gradient atomics are
-    not ordered)."""
+    not ordered).  global_segmented: the form the data-parallel global step is captured in -- four graph segments with the three
+    exchange points (identities on one rank) called eagerly between them."""
     import torch
 
     from gfnerf_amd import hotpath, ops, scene, stepgraph
 
+    segmented = stage == "global_segmented"
+    stage = "global" if segmented else stage
     S = setup
     t, sc = S["t"], S["sc"]
     R, K = 256, 6
@@ -835,7 +838,7 @@ def test_step_graph_is_the_same_training_run(setup, stage):
     hg = make()
     o, d, cam, gt = batches[0]
     hg.train_step(o, d, cam, gt, noise, stage=stage, block=blk, update_oct=upd)
-    sg = stepgraph.StepGraph(hg, stage, R, fin, block=blk, update_oct=upd, train_noise=False)
+    sg = stepgraph.StepGraph(hg, stage, R, fin, block=blk, update_oct=upd, train_noise=False, segmented=segmented or None)
     sg.prime(batches[1][0], batches[1][1])
     losses_g = []
     for k in range(1, K + 1):
@@ -843,6 +846,10 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         l, _ = sg.step(batches[k][2], batches[k][3], nxt[0], nxt[1])
         losses_g.append(float(l.item()))
     torch.cuda.synchronize()
+    if segmented:
+        kinds = ["graph" if isinstance(x, torch.cuda.CUDAGraph) else "eager" for x in sg.G[0]]
+        assert kinds == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], kinds
+        assert hg.seg is None
     assert hg.step == he.step == K + 1 and hg._adam_t == he._adam_t
     pe = he.blocks[0] if stage == "focal" else he.table
     pg = hg.blocks[0] if stage == "focal" else hg.table
