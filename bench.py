@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--atomic-backward", action="store_true", help="backward issues its table adds as global atomics instead of records accumulated in LDS")
     ap.add_argument("--unfused-backward", action="store_true", help="decoder backward and hash scatter as two kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not run the next batch's sampler beside this step's backward")
-    ap.add_argument("--prefetch-cus", type=int, default=192, help="CUs left to the fused backward while the prefetched sampler runs beside it")
+    ap.add_argument("--prefetch-cus", type=int, default=0, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=0,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
     ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
@@ -519,7 +519,7 @@ class StageRun:
         self.cfg = cfg = hotpath.HotPathConfig(
             log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision,
             two_phase=not args.one_phase,
-            prefetch_cus=args.prefetch_cus, prefetch_cus_global=args.prefetch_cus if args.prefetch_cus != 192 else 224,
+            **({"prefetch_cus": args.prefetch_cus, "prefetch_cus_global": args.prefetch_cus} if args.prefetch_cus else {}),
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
             level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, loss_before_fork=not args.fork_first,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),

@@ -62,8 +62,9 @@ class HotPathConfig:
     loss_before_fork: bool = True    # forward_backward enqueues the loss kernels before it forks the octree update / next sampler
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
     record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
-    prefetch_cus: int = 192          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage)
-    prefetch_cus_global: int = 224   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
+    prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
+                                     # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
+    prefetch_cus_global: int = 208   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
     two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
                                      # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
                                      # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
