@@ -303,6 +303,70 @@ __global__ __launch_bounds__(256) void phase_fill_kernel(const int* __restrict__
   }
 }
 
+// Both steps in ONE launch for batches of up to kPhaseOneLaunchRays rays (a training batch: 4096): every workgroup of 16 waves = 16 rays
+// sums the entries of the rays in front of its own by itself (the 16 KB of offsets come from L2; ~2 us) instead of waiting for a
+// one-workgroup scan kernel -- these lists are built three times per step on the critical path, between launches that are empty as a rule.
+constexpr int kPhaseOneLaunchRays = 16384;
+__device__ __forceinline__ int phase_entries(const int* __restrict__ pts_offsets, int r, int K, const uint8_t* __restrict__ need_more,
+                                             const int* __restrict__ term) {
+  const int n = pts_offsets[r + 1] - pts_offsets[r];
+  int c;
+  if (term) c = term[r] < n ? term[r] : n;
+  else c = need_more ? ((need_more[r] && n > K) ? n - K : 0) : (n < K ? n : K);
+  return c < 0 ? 0 : c;
+}
+
+__global__ __launch_bounds__(1024) void phase_list_kernel(const int* __restrict__ pts_offsets, int n_rays, const int* __restrict__ k_split,
+                                                          const uint8_t* __restrict__ need_more, const int* __restrict__ term,
+                                                          int* __restrict__ coff, int* __restrict__ list, int* __restrict__ stats,
+                                                          float* __restrict__ zero_sigma, float* __restrict__ zero_rgb) {
+  __shared__ int s_before[16], s_total[16], s_rays[16], s_c[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = *k_split;
+  const int base = blockIdx.x * 16;  // this workgroup's rays: base .. base + 15, one per wave
+  int before = 0, total = 0, rays = 0;
+  for (int r = tid; r < n_rays; r += 1024) {
+    const int c = phase_entries(pts_offsets, r, K, need_more, term);
+    total += c;
+    rays += c > 0;
+    if (r < base) before += c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    before += __shfl_down(before, off, 64);
+    total += __shfl_down(total, off, 64);
+    rays += __shfl_down(rays, off, 64);
+  }
+  if (lane == 0) { s_before[wave] = before; s_total[wave] = total; s_rays[wave] = rays; }
+  if (lane == 1) s_c[wave] = base + wave < n_rays ? phase_entries(pts_offsets, base + wave, K, need_more, term) : 0;
+  __syncthreads();
+  before = 0; total = 0; rays = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { before += s_before[w]; total += s_total[w]; rays += s_rays[w]; }
+  for (int w = 0; w < wave; w++) before += s_c[w];
+  const bool all = !need_more && !term && K >= 1024;  // phase A of a one-phase step: every sample -- no list is needed (entries = -1)
+  if (blockIdx.x == 0 && tid == 0) {
+    coff[n_rays] = all ? 0 : total;
+    const int sb = term ? 4 : (need_more ? 2 : 0);
+    stats[sb] = all ? -1 : total; stats[sb + 1] = rays;
+  }
+  const int ray = base + wave;
+  if (ray >= n_rays) return;
+  if (lane == 0) coff[ray] = before;
+  if (all || total == 0) return;  // an empty phase, or phase A of a one-phase step (nothing to list, nothing to clear)
+  const int c = s_c[wave];
+  const int s0 = pts_offsets[ray], n = pts_offsets[ray + 1] - s0;
+  const int first = s0 + (need_more ? K : 0);
+  int* dst = list + before;
+  for (int i = lane; i < c; i += 64) dst[i] = first + i;
+  if (zero_sigma && !need_more) {
+    for (int i = c + lane; i < n; i += 64) {
+      zero_sigma[s0 + i] = 0.f;
+      zero_rgb[3 * (s0 + i)] = 0.f; zero_rgb[3 * (s0 + i) + 1] = 0.f; zero_rgb[3 * (s0 + i) + 2] = 0.f;
+    }
+  }
+}
+
 // The next step's K from this batch: with n_r = samples of ray r and f_r = samples in front of its termination point,
 //     cost(K) = sum_r min(K, n_r)  +  [some f_r > K] * (fixed + sum_{r: f_r > K} (n_r - K))        (in samples)
 // (phase A evaluates the first K samples of every ray; phase B, if any ray needs it, costs its fixed sweeps of the tables plus the
@@ -729,6 +793,11 @@ int gfn_phase_list(const int32_t* pts_offsets, int64_t n_rays, const int32_t* k_
   GFN_CHECK_ARG((zero_sigma == nullptr) == (zero_rgb == nullptr) && !(zero_sigma && (need_more || term)), "gfn_phase_list: sigma and rgb are cleared together, in phase A");
   GFN_CHECK_ARG(!(need_more && term), "gfn_phase_list: one kind of list per call");
   hipStream_t st = gfn_stream(stream);
+  if (n_rays <= kPhaseOneLaunchRays) {
+    phase_list_kernel<<<(unsigned)((n_rays + 15) / 16), 1024, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more, term, coff, list, stats, zero_sigma, zero_rgb);
+    GFN_CHECK_LAUNCH();
+    return GFN_OK;
+  }
   phase_scan_kernel<<<1, 1024, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more, term, coff, stats);
   GFN_CHECK_LAUNCH();
   phase_fill_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(pts_offsets, (int)n_rays, k_split, need_more ? 1 : 0, coff, list, zero_sigma, zero_rgb);

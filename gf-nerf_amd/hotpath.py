@@ -99,6 +99,7 @@ class HotPath:
         self._depth_key, self._depth_val = None, 0
         self._records = None
         self._opt_stream, self._opt_pending = None, False
+        self._aux_stream, self._aux_pending = None, False  # branch of the phased forward: front list + plan beside the loss
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
@@ -153,7 +154,7 @@ class HotPath:
         # buffers, and the groups whose buffers hold this iteration's gradients ("table", "block<i>", "mlp", "emb")
         self.fused_optimizers = weakref.WeakSet()
         self.grad_ready = set()
-        self._phase = None  # ops.PhaseState of the phased training forward (made for one batch size)
+        self._phase_state = None  # ops.PhaseState of the phased training forward (made for one batch size)
         self.phase_override = None  # False: one-phase forward whatever cfg.two_phase says (StepGraph: the plan said a split does not pay)
 
     def add_block(self, i, table=None, prims=None):
@@ -350,15 +351,22 @@ class HotPath:
         return dict(feat=feat, a1=a1, h=h, xh=xh, c1=c1, c2=c2, rgb=rgb, sigma=sigma)
 
     def phase_state(self, n_rays, cap):
-        if self._phase is None or self._phase.n_rays != n_rays or self._phase.cap < cap:
-            self._phase = ops.PhaseState(n_rays, cap, self.dev)
-        return self._phase
+        if self._phase_state is None or self._phase_state.n_rays != n_rays or self._phase_state.cap < cap:
+            self._phase_state = ops.PhaseState(n_rays, cap, self.dev)
+        return self._phase_state
+
+    @property
+    def _phase(self):
+        """The phase state as the last forward's plan left it (its branch joined into the current stream first)."""
+        self._join_aux()
+        return self._phase_state
 
     def _forward_phased(self, s, cam_idx, block, save, planes, want_depth):
         """The termination-aware level-major training forward (include/gfnerf_amd.h, gfn_composite_fwd_phased): phase A = the first K
         samples of every ray through lookup(s) + decoder + compositing; phase B = the rest of the rays that are still transparent
         behind them (its launches return at once when there is none); then the next step's K.  -> (field dict, comp dict)."""
         c = self.cfg
+        self._join_aux()  # (a forward whose backward never ran: its plan must have written K before this one reads it)
         n_dev = s["n_dev"]
         T, V = c.log2_T, self.n_volumes
         R = s["pts_offsets"].numel() - 1
@@ -393,12 +401,26 @@ class HotPath:
                     image=self._x3()[0], planes=planes, sample_list=sb, out=f)
         self._timed("composite_fwd_b", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
                     second=True, out=comp)
-        if planes is None:  # (focal stage) the backward walks exactly the samples in front of the termination points
-            f["front"] = self._timed("phase_list_front", ops.phase_list, s["pts_offsets"], st, front=True)
-        enter, stay = c.two_phase_min_saving_planes if planes is not None else c.two_phase_min_saving
-        self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
+        # the backward's list and the next step's K are not the loss's business: a branch of their own, beside the loss kernels
+        # (two dependent small launches less between the compositing and the backward); joined by backward() / the next forward
+        main = torch.cuda.current_stream()
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device=self.dev)
+        self._aux_stream.wait_stream(main)
+        with torch.cuda.stream(self._aux_stream):
+            if planes is None:  # (focal stage) the backward walks exactly the samples in front of the termination points
+                f["front"] = self._timed("phase_list_front", ops.phase_list, s["pts_offsets"], st, front=True)
+            enter, stay = c.two_phase_min_saving_planes if planes is not None else c.two_phase_min_saving
+            self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
+        self._aux_pending = True
         f["feat"] = feat
         return f, comp
+
+    def _join_aux(self):
+        """The branch that builds the backward's sample list and plans the next K (_forward_phased) -> this stream."""
+        if self._aux_pending:
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+            self._aux_pending = False
 
     def _fused_ok(self, block):
         c = self.cfg
@@ -580,6 +602,7 @@ class HotPath:
         current stream when this returns (data parallel: the table gradient's exchange may still be in flight, see sync_grads)."""
         c = self.cfg
         self._sync_opt()  # the gradient pool is zeroed behind the asynchronous Adam
+        self._join_aux()
         s, f, cam_idx = ctx["samples"], ctx["field"], ctx["cam_idx"]
         train_mlp = ctx["stage"] == STAGE_GLOBAL
         n_dev = s["n_dev"]

@@ -151,6 +151,7 @@ class StepGraph:
                 hp.phase_override = None if self.phased else False
         self._since_capture, self._idle = 0, 0
         self._k_host.fill_(-1)
+        hp._join_aux()  # (a branch left open by an eager forward must not be joined under capture)
         torch.cuda.synchronize()
         steps_before, ticks_before = hp.step, dict(hp._adam_t)
         pool = None
@@ -181,6 +182,7 @@ class StepGraph:
             state["g"] = g
 
         def end():
+            hp._join_aux()
             if hp._side is not None:
                 with torch.cuda.stream(hp._side):
                     forked = torch.cuda.is_current_stream_capturing()

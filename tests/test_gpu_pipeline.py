@@ -867,6 +867,54 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
 
 
+@pytest.mark.parametrize("n_rays", [1, 37, 4096, 16384, 20011])
+def test_phase_lists_against_numpy(n_rays):
+    """gfn_phase_list on synthetic ray lengths -- one launch up to 16,384 rays (every workgroup sums the entries in front of its rays by
+    itself), scan + fill beyond: list A (first K of every ray; the others get sigma = rgb = 0), list B (samples K.. of the rays with
+    need_more), the front list (first term[r]), their counts and ray counts; K = 1024 lists nothing (count -1)."""
+    import torch
+
+    from gfnerf_amd import ops
+
+    rng = np.random.default_rng(n_rays)
+    cnt = rng.integers(0, 300, n_rays).astype(np.int32)
+    cnt[rng.random(n_rays) < 0.1] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    n = int(off[-1])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    st = ops.PhaseState(n_rays, max(n, 1), "cuda")
+    K = 100
+    st.k.fill_(K)
+    need = (rng.random(n_rays) < 0.3).astype(np.uint8)
+    term = np.minimum(rng.integers(0, 320, n_rays), 400).astype(np.int32)
+    st.need_more.copy_(t(need)); st.term.copy_(t(term))
+    sigma, rgb = torch.ones(max(n, 1), device="cuda"), torch.ones((max(n, 1), 3), device="cuda")
+    po = t(off)
+
+    def want(c, first):
+        return np.concatenate([np.arange(off[r] + first[r], off[r] + first[r] + c[r]) for r in range(n_rays)] + [np.zeros(0, np.int64)]).astype(np.int32)
+
+    zero_r = np.zeros(n_rays, np.int32)
+    cases = [("a", dict(zero=(sigma, rgb)), np.minimum(cnt, K), zero_r, 0),
+             ("b", dict(phase_b=True), np.where((need > 0) & (cnt > K), cnt - K, 0), np.full(n_rays, K, np.int32), 2),
+             ("front", dict(front=True), np.minimum(term, cnt), zero_r, 4)]
+    for name, kw, c, first, sb in cases:
+        lst, count = ops.phase_list(po, st, **kw)
+        w = want(c, first)
+        stats = st.stats.cpu().numpy()
+        assert int(count.item()) == w.size == stats[sb] and stats[sb + 1] == int((c > 0).sum()), (name, int(count.item()), w.size)
+        assert np.array_equal(lst[: w.size].cpu().numpy(), w), name
+        assert np.array_equal(st.coff.cpu().numpy(), np.concatenate([[0], np.cumsum(c)]).astype(np.int32)), name
+    listed = np.zeros(max(n, 1), bool)
+    listed[want(np.minimum(cnt, K), zero_r)] = True
+    listed[n:] = True  # (padding when the batch is empty)
+    assert np.array_equal(sigma.cpu().numpy() != 0, listed) and np.array_equal((rgb.cpu().numpy() != 0).all(1), listed)
+    st.k.fill_(1024)  # one phase: no list, nothing cleared
+    sigma.fill_(1.0)
+    _, count = ops.phase_list(po, st, zero=(sigma, rgb))
+    assert int(count.item()) == -1 and bool((sigma == 1).all())
+
+
 @pytest.mark.parametrize("stage", ["focal", "global"])
 def test_phased_forward_is_the_one_phase_forward(setup, stage):
     """The termination-aware level-major forward (HotPathConfig.two_phase; gfn_phase_mask / gfn_composite_fwd_phased /
