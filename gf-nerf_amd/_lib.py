@@ -89,6 +89,7 @@ SIGNATURES = {
     "gfn_adam_hyper_host": (None, [_i32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "gfn_step_draws": (_i32, [_u64, _vp, _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
     "gfn_copy_list": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "gfn_fill_zero": (_i32, [_vp, _i64, _vp]),
     "gfn_reduce_shards": (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),

@@ -42,6 +42,48 @@ __global__ __launch_bounds__(256) void copy_list_kernel(CopyList L) {
   if (which >= L.n) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L.words[which]; i += (int64_t)gridDim.x * 256) L.dst[which][i] = L.src[which][i];
 }
+
+// Philox4x32-10 (Salmon et al., SC'11): counter (index lo, index hi, call, stream), key from the seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// The random draws of one training step in one launch: march noise (u + add) * mul, u in [0, 1) with 24 random bits like torch.rand
+// (PersSampler_cuda.cu:380-389), and 63-bit sort keys whose argsort is a uniform random permutation (S3IM's randperm, losses.py:780-789).
+// state[0] = number of calls so far, advanced by the last workgroup to finish (every workgroup has read it by then); state[1] = the
+// workgroups that have finished.  A captured step replays this launch: the call number, read from memory, is what moves on.
+__global__ __launch_bounds__(256) void step_draws_kernel(uint64_t seed, unsigned long long* __restrict__ state, float* __restrict__ noise,
+                                                         int64_t n_noise, float add, float mul, long long* __restrict__ keys, int64_t n_keys) {
+  const unsigned long long call = state[0];
+  const int64_t quads = (n_noise + 3) / 4, pairs = (n_keys + 1) / 2;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads + pairs; q += (int64_t)gridDim.x * 256) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)call, (uint32_t)(call >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if (q < quads) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (4 * q + k < n_noise) noise[4 * q + k] = ((float)(c[k] >> 8) * (1.0f / 16777216.0f) + add) * mul;
+    } else {
+      const int64_t j = 2 * (q - quads);
+      keys[j] = (long long)((((uint64_t)c[0] << 32) | c[1]) >> 1);
+      if (j + 1 < n_keys) keys[j + 1] = (long long)((((uint64_t)c[2] << 32) | c[3]) >> 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&state[1], 1ull) == (unsigned long long)gridDim.x - 1) { state[0] = call + 1; state[1] = 0; }
+  }
+}
 }
 
 void gfn_set_error(const char* fmt, ...) {
@@ -84,6 +126,18 @@ int gfn_reduce_shards(const void* recv, int n_shards, int64_t shard_elems, int i
   else
     reduce_shards_kernel<float><<<grid, 256, 0, gfn_stream(stream)>>>(reinterpret_cast<const float*>(recv), n_shards, shard_elems, scale,
                                                                       reinterpret_cast<float*>(out));
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_step_draws(uint64_t seed, uint64_t* state, float* noise, int64_t n_noise, float add, float mul, int64_t* keys, int64_t n_keys, void* stream) {
+  GFN_CHECK_ARG(state && n_noise >= 0 && n_keys >= 0 && (noise || n_noise == 0) && (keys || n_keys == 0), "gfn_step_draws: bad arguments");
+  const int64_t work = (n_noise + 3) / 4 + (n_keys + 1) / 2;
+  if (work == 0) return GFN_OK;
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  step_draws_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(seed, reinterpret_cast<unsigned long long*>(state), noise, n_noise, add, mul,
+                                                                    reinterpret_cast<long long*>(keys), n_keys);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

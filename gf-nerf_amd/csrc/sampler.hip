@@ -175,8 +175,40 @@ __global__ __launch_bounds__(1024) void scan_add_kernel(int n, int* __restrict__
   const int i = blockIdx.x * 1024 + threadIdx.x;
   if (i < n) offsets[i] += s_base;
 }
+// A training batch (n <= 8192 rays): one workgroup, one launch -- the scan sits between the march and the fill on the sampler's
+// branch, which ends the step since the backward got shorter; coalesced loads, 1,024 counts per round with a running carry.
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int* __restrict__ counts, int n, int* __restrict__ offsets) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const int c = i < n ? counts[i] : 0;
+    int v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    int base = s_carry;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    if (i < n) offsets[i] = base + v - c;
+    __syncthreads();
+    if (tid == 1023) s_carry = base + v;
+    __syncthreads();
+  }
+  if (tid == 0) offsets[n] = s_carry;
+}
 // block_sums: scratch of ceil(n / 1024) ints
 inline void launch_scan(const int* counts, int n, int* offsets, int* block_sums, hipStream_t st) {
+  if (n <= 8192) {
+    scan_small_kernel<<<1, 1024, 0, st>>>(counts, n, offsets);
+    return;
+  }
   const int blocks = (n + 1023) / 1024;
   scan_local_kernel<<<blocks, 1024, 0, st>>>(counts, n, offsets, block_sums);
   scan_add_kernel<<<blocks, 1024, 0, st>>>(n, offsets, block_sums);

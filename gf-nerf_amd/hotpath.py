@@ -257,6 +257,11 @@ class HotPath:
             torch.cuda.current_stream().wait_stream(self._side)  # a prefetch nobody collects still owns the workspace
         d = ops.normalize_dirs(rays_d_raw, out=None if out is None else out["dirs_unit"])
         R = rays_o.shape[0]
+        # per-ray leftovers of the step that only depend on the rays: computed here so that a prefetched sampler takes them off the
+        # main stream too (SH basis of the unit directions, nerfacto_field.py:519-521; the zero the loss kernels add to) -- and ahead
+        # of the traversal, not behind the fill: the sampler's branch is what a replayed focal step waits for last
+        sh = ops.sh4(d, out=None if out is None else out["sh"])
+        loss0 = torch.zeros(1, dtype=torch.float32, device=self.dev) if out is None else out["loss0_buf"].zero_()
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
                         c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
                         pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world, want_dirs=need_world,
@@ -264,13 +269,7 @@ class HotPath:
         self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
-        # per-ray leftovers of the step that only depend on the rays: computed here so that a prefetched sampler takes them off the
-        # main stream too (SH basis of the unit directions, nerfacto_field.py:519-521; the zero the loss kernels add to)
-        s["sh"] = ops.sh4(d, out=None if out is None else out["sh"])
-        if out is None:
-            s["loss0"] = torch.zeros(1, dtype=torch.float32, device=self.dev)
-        else:
-            s["loss0"] = out["loss0_buf"].zero_()
+        s["sh"], s["loss0"] = sh, loss0
         s["loss0_buf"] = s["loss0"]  # forward_backward pops "loss0"; the buffer stays for the next in-place refill
         return s
 

@@ -1143,6 +1143,35 @@ def s3im_index(n_rays, repeat_time=10, generator=None, device=None, out=None):
     return out.view(-1)
 
 
+class StepDraws:
+    """The per-step random draws of a training step from the device's own Philox stream (gfn_step_draws): march noise of the NEXT
+    batch and S3IM's index vector, without torch's generator (which a captured step pays for with two fills per replay)."""
+
+    def __init__(self, n_rays, repeat_time=10, seed=None, device="cuda"):
+        self.R, self.repeat = int(n_rays), int(repeat_time)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
+        self.state = torch.zeros(2, dtype=torch.int64, device=device)
+        self.keys = torch.empty((max(self.repeat - 1, 0), self.R), dtype=torch.int64, device=device)
+
+    def draw(self, noise_out=None, fineness=1.0, s3im_out=None, write_arange=True):
+        """noise_out f32 [1024 + R + 10] <- (U[0,1) + 0.5) * fineness (sampler_noise, training mode); s3im_out i32 [repeat * R] <- arange
+        followed by repeat - 1 random permutations (s3im_index)."""
+        _chk(noise_out, torch.float32, "noise_out"); _chk(s3im_out, torch.int32, "s3im_out")
+        nk = self.keys.numel() if s3im_out is not None else 0
+        if s3im_out is not None and s3im_out.numel() != self.repeat * self.R:
+            raise _lib.GfnError("StepDraws: s3im_out must hold repeat_time * n_rays indices")
+        rc = _lib.lib().gfn_step_draws(self.seed, _ptr(self.state), _ptr(noise_out), 0 if noise_out is None else noise_out.numel(), 0.5, float(fineness),
+                                       _ptr(self.keys) if nk else None, nk, _stream())
+        _lib.check(rc, "gfn_step_draws")
+        if s3im_out is not None:
+            o = s3im_out.view(self.repeat, self.R)
+            if write_arange:  # (a buffer s3im_index has filled once keeps its first row)
+                o[0] = torch.arange(self.R, device=o.device, dtype=torch.int32)
+            if nk:
+                o[1:] = torch.argsort(self.keys, dim=1)
+        return noise_out, s3im_out
+
+
 def sampler_noise(n_rays, fineness, train=True, generator=None, device=None, out=None):
     """rays_noise of GetSamples (PersSampler_cuda.cu:380-389): (U[0,1) + 0.5) * fineness in training, fineness in eval mode,
     1024 + R + 10 values (the march reads a sliding window of it, :204,270)."""

@@ -35,7 +35,7 @@ from . import _lib, hotpath as hp_mod, ops
 
 class StepGraph:
     def __init__(self, hp, stage, n_rays, fineness, block=None, update_oct=False, train_noise=True, lr_schedule=None, draws_after_lookup=True,
-                 replan_every=2048, segmented=None):
+                 replan_every=2048, segmented=None, seed=None):
         """lr_schedule: step -> learning-rate multiplier of the stage's groups (None: constant).
         replan_every: the phased (termination-aware) forward costs a handful of small launches even when its plan is "one phase, every
         sample" (an empty scene: nothing terminates).  At capture the plan is read back once (a forward of the batch at hand, no
@@ -64,6 +64,8 @@ class StepGraph:
         self._ring = [torch.zeros((len(self.groups), 2), dtype=torch.float32).pin_memory() for _ in range(256)]
         self._ring_ev, self._ring_pos = [None] * len(self._ring), 0
         self.noise = torch.zeros(1024 + self.R + 10, dtype=torch.float32, device=dev)  # the NEXT batch's march noise
+        self.rng = ops.StepDraws(self.R, hp.cfg.s3im_repeat_time, seed=seed, device=dev)  # the device's own Philox stream: torch's generator
+        # costs a captured step two fills in front of every replay
         self.S = [None, None]
         self.s3 = [None, None]  # S3IM permutations of the step that reads S[p], drawn one step ahead like the samples
         self.G = [None] * self.cycle
@@ -88,6 +90,7 @@ class StepGraph:
             self.S[k] = hp.sample(self.nxt_o, self.nxt_d, self._noise(), out=self.S[k])
             if hp.cfg.s3im_loss_mult > 0:
                 self.s3[k] = ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[k])
+        self._noise(out=self.noise)  # (eval mode: the constant the replays read; training mode: rewritten by every replay's draws)
         self.p, self.primed = 0, True  # the first replay reads S[0]
 
     def _step_eager_or_captured(self, j):
@@ -103,9 +106,9 @@ class StepGraph:
         def draws():  # the NEXT step's random draws, on the device: started behind this step's lookups (a sort beside them
             side.wait_stream(main)  # costs the gathers 10 %), beside the decoder, ahead of the next batch's sampler
             with torch.cuda.stream(side):
-                if hp.cfg.s3im_loss_mult > 0:
-                    ops.s3im_index(self.R, hp.cfg.s3im_repeat_time, device=hp.dev, out=self.s3[1 - p])
-                self._noise(out=self.noise)
+                s3 = self.s3[1 - p] if hp.cfg.s3im_loss_mult > 0 else None
+                if self.train_noise or s3 is not None:  # (eval-mode noise is the constant prime() wrote)
+                    self.rng.draw(noise_out=self.noise if self.train_noise else None, fineness=self.fineness, s3im_out=s3, write_arange=False)
 
         if self.draws_after_lookup:
             hp.after_lookup = draws

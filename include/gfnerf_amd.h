@@ -570,6 +570,15 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
                      int step, float lr, float beta1, float beta2, float eps, uint16_t* shadow_f16,
                      const float* hyper_dev, void* stream);
 int gfn_fill_zero(void* p, int64_t bytes, void* stream);
+/* The random draws of one training step, on the device, in one launch (replaces torch.rand's Philox stream, which a captured step
+ * can only use at the price of two extra fills in front of every replay): noise[i] = (u + add) * mul with u uniform in [0, 1) -- the
+ * march noise of GetSamples, PersSampler_cuda.cu:380-389: (rand + 0.5) * fineness -- and keys[j] = 63 random bits, whose argsort
+ * per row is a uniform random permutation (S3IM's torch.randperm, losses.py:780-789).  Philox4x32-10 keyed by `seed`, counter =
+ * (element, state[0]); state = device u64[2] {calls so far, scratch}, zero-initialised by the caller and advanced by the launch
+ * itself, so a hipGraph replay of this launch draws fresh numbers.  The reference's random streams cannot be reproduced (they are
+ * the CUDA generator's); the distribution is what the tests hold. */
+int gfn_step_draws(uint64_t seed, uint64_t* state, float* noise, int64_t n_noise, float add, float mul, int64_t* keys, int64_t n_keys,
+                   void* stream);
 /* n <= 8 small device-to-device copies (src[i] -> dst[i], bytes[i] a multiple of 4, 4-byte aligned) in ONE launch: the batch
  * hand-over in front of a captured training step (gfnerf_amd.stepgraph).  src / dst / bytes are HOST arrays. */
 int gfn_copy_list(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);

@@ -867,6 +867,53 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
 
 
+def test_step_draws_are_uniform_fresh_per_call_and_replayable():
+    """gfn_step_draws (the device's own Philox4x32-10 stream for a captured step's random draws): march noise (u + 0.5) * fineness with u
+    uniform in [0, 1) (PersSampler_cuda.cu:380-389), S3IM's index vector = arange + 9 uniform random permutations (losses.py:780-789);
+    every call -- and every hipGraph replay of one captured call -- draws fresh numbers; the same seed gives the same stream."""
+    import torch
+
+    from gfnerf_amd import ops
+
+    R, rep, fin = 4096, 10, 3.0
+    d = ops.StepDraws(R, rep, seed=1234)
+    noise = torch.empty(1024 + R + 10, device="cuda")
+    idx = torch.empty(rep * R, dtype=torch.int32, device="cuda")
+    d.draw(noise, fin, idx)
+    n1, i1 = noise.cpu().numpy().copy(), idx.cpu().numpy().reshape(rep, R).copy()
+    u = n1 / fin - 0.5
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.005
+    hist = np.histogram(u, bins=16, range=(0, 1))[0]
+    assert hist.min() > 0.75 * u.size / 16 and hist.max() < 1.25 * u.size / 16
+    assert np.array_equal(i1[0], np.arange(R))
+    for row in i1[1:]:
+        assert np.array_equal(np.sort(row), np.arange(R))
+    assert len({row.tobytes() for row in i1}) == rep  # all different
+    fixed = np.mean([np.mean(row == np.arange(R)) for row in i1[1:]])
+    assert fixed < 5.0 / R * 3  # a uniform permutation has one fixed point on average
+    # a position's images over the 9 permutations are spread over the whole range
+    assert abs(i1[1:, :64].mean() - (R - 1) / 2) < 0.1 * R
+    d.draw(noise, fin, idx)
+    n2 = noise.cpu().numpy().copy()
+    assert not np.array_equal(n1, n2) and abs(np.corrcoef(n1, n2)[0, 1]) < 0.05
+    assert int(d.state[0].item()) == 2 and int(d.state[1].item()) == 0
+    # the same seed: the same stream
+    e = ops.StepDraws(R, rep, seed=1234)
+    e.draw(noise, fin, idx)
+    assert np.array_equal(noise.cpu().numpy(), n1) and np.array_equal(idx.cpu().numpy().reshape(rep, R), i1)
+    # replays of ONE captured call move on
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        e.draw(noise, fin, idx, write_arange=False)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        seen.append(noise.cpu().numpy().copy())
+    assert np.array_equal(seen[0], n2) and not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    assert int(e.state[0].item()) == 4
+
+
 @pytest.mark.parametrize("n_rays", [1, 37, 4096, 16384, 20011])
 def test_phase_lists_against_numpy(n_rays):
     """gfn_phase_list on synthetic ray lengths -- one launch up to 16,384 rays (every workgroup sums the entries in front of its rays by
