@@ -83,6 +83,7 @@ class GfnAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._stepped = set()
         for group in self.param_groups:
             lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
             decoder = {}
@@ -94,6 +95,8 @@ class GfnAdam(torch.optim.Optimizer):
                 self._step_one(p, link, lr, b1, b2, eps)
             for hot, ps in decoder.values():
                 self._step_decoder(hot, ps, lr, b1, b2, eps)
+        for hot in self._stepped:  # this iteration's launches are all enqueued: room for the host work the pipeline put off (the next batch)
+            hot.run_deferred()
         return loss
 
     def _step_one(self, p, link, lr, b1, b2, eps):
@@ -107,6 +110,7 @@ class GfnAdam(torch.optim.Optimizer):
         if hot is not None:
             hot.external_adam(name, st["exp_avg"], st["exp_avg_sq"], t, lr, b1, b2, eps, grad=None if ready else p.grad.contiguous())
             hot.grad_ready.discard(name)
+            self._stepped.add(hot)
         else:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise NotImplementedError("GfnAdam steps contiguous float32 device parameters")
@@ -123,6 +127,7 @@ class GfnAdam(torch.optim.Optimizer):
                 self.state[p]["step"] += 1
             hot.external_adam("mlp", m_flat, v_flat, int(self.state[ps[0]]["step"]), lr, b1, b2, eps)
             hot.grad_ready.discard("mlp")
+            self._stepped.add(hot)
             return
         for p in ps:  # a subset of the decoder, or dense .grad tensors: tensor by tensor
             g = hot.layer_grad_of(p) if ready else p.grad

@@ -104,6 +104,7 @@ class HotPath:
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
+        self._deferred = []
         self.seg = None             # set by a segmented StepGraph capture: seg(fn) ends the graph segment being captured, notes fn as the
                                     # eager call between segments (a collective) and begins the next segment
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
@@ -272,6 +273,22 @@ class HotPath:
         s["sh"], s["loss0"] = sh, loss0
         s["loss0_buf"] = s["loss0"]  # forward_backward pops "loss0"; the buffer stays for the next in-place refill
         return s
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    def defer(self, fn):
+        """Host work the caller wants done once this iteration's backward and optimiser launches are enqueued (the plugin surface draws
+        and samples the NEXT batch there: between the forward and the backward the host is what the GPU waits for).  Run by the fused
+        optimiser after its launches (gfnerf/optim.py), or by whoever calls run_deferred() first."""
+        self._deferred.append(fn)
+
+    def run_deferred(self):
+        todo, self._deferred = self._deferred, []
+        for fn in todo:
+            fn()
 
     def prefetch_sample(self, rays_o, rays_d_raw, noise, need_world=False, first=None, out=None, after=None):
         """Run the sampler of the NEXT batch on a second stream now; the next self.sample(...) with the very same tensors
