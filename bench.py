@@ -493,10 +493,22 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     for _ in range(warmup):
         train_iteration(step); step += 1
     torch.cuda.synchronize()
+    prof = None
+    if os.environ.get("GFN_PLUGIN_PROFILE"):  # where the host spends the iteration (tools/README.md)
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = train_iteration(step); step += 1
     host = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(60)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return dict(metric="train_rays_per_sec", value=n_rays / dt, unit="rays/s", ms_per_step=dt * 1e3, host_ms_per_step=host / steps * 1e3, steps=steps,

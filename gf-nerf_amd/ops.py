@@ -17,7 +17,14 @@ TREE_NODE_BYTES = 128
 TRANS_INFO_BYTES = 576
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a void*.  (torch.cuda.current_stream() builds a Stream object through three
+    layers of Python -- 10 us a call, 0.3 ms per training iteration of the plugin surface; the raw getter is one C call.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
