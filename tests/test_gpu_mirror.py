@@ -603,6 +603,64 @@ def _trainer_loop(pipe, optimizers, callbacks, steps, fixed=True):
     return hist
 
 
+def test_drawing_the_next_batch_ahead_is_the_same_training_run(dev, tmp_path):
+    """GFNerfPipelineConfig.prefetch_next_batch: batch k + 1 is drawn after iteration k's forward and error-map write-back -- in the block
+    stage its host part runs behind the optimiser's launches (HotPath.defer), its kernels and the ray sampler on the engine's second
+    stream -- and must be the batch next_train(k + 1) would have returned one call later: the same pixels (uniform in the init stage,
+    error-map importance sampling in the block stage), the same march noise, hence the same parameters after every iteration.
+    The drawn pixels and rays are compared bit for bit over the init and the block stage (the error-map sampler included), the
+    parameters to the tolerance two runs of one schedule agree to."""
+    import torch
+
+    from gfnerf_amd import scene
+    from gfnerf_amd.gfnerf._host import Optimizers, TrainingCallbackAttributes
+    from gfnerf_amd.gfnerf.optim import GfnAdamOptimizerConfig
+    from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
+
+    c2w, intri, _ = scene.make_cameras(n_side=5, seed=3)
+    n, H, W = c2w.shape[0], 36, 48
+    K = intri.copy()
+    K[:, 0, 0] *= W / 1152.0; K[:, 1, 1] *= W / 1152.0; K[:, 0, 2] = W / 2; K[:, 1, 2] = H / 2
+    images = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    runs = {}
+    for name, prefetch in (("plain", False), ("ahead", True)):
+        torch.manual_seed(1234)
+        pipe, _, _ = _small_pipeline(dev, n_blocks=2, images=images, error_maps=torch.full((n, H, W, 1), 0.5, device=dev), intrinsics=K,
+                                     steps_perssampler_init=3, use_appearance_embedding=False, base_dir=str(tmp_path / name))
+        pipe.config.prefetch_next_batch = prefetch
+        model, dm = pipe.model, pipe.datamanager
+        drawn, inner = {}, dm.next_train
+
+        def logged(step, _inner=inner, _drawn=drawn):
+            out = _inner(step)
+            _drawn[step] = (out[2].clone(), out[0].origins.clone())
+            return out
+
+        dm.next_train = logged
+        sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=3, n_split_dataset=2, n_dataset_circles=1, steps_per_split_dataset=4,
+                                                      steps_perssampler_init=3)
+        optimizers = Optimizers({"fields": {"optimizer": GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": sched}}, pipe.get_param_groups())
+        callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
+        model.train(); model.persampler.update_mode(0)
+        hist = _trainer_loop(pipe, optimizers, callbacks, range(9), fixed=False)
+        torch.cuda.synchronize()
+        runs[name] = dict(hist=hist, drawn=drawn, table=model.hot.table.clone(), block0=model.hot.blocks[0].clone(), mlp=model.hot.mlp_flat.clone(),
+                          errmap=dm.error_map.map.clone(), deferred=len(model.hot._deferred))
+    a, b = runs["plain"], runs["ahead"]
+    assert set(range(9)) <= set(a["drawn"]) and set(range(9)) <= set(b["drawn"])
+    for step in range(9):
+        assert torch.equal(a["drawn"][step][0], b["drawn"][step][0]), f"pixels of step {step}"
+        assert torch.equal(a["drawn"][step][1], b["drawn"][step][1]), f"rays of step {step}"
+    # the parameters: the same up to what two runs of ONE schedule differ by (at T = 2^13 record streams overflow into unordered f16
+    # atomics, and Adam at eps = 1e-15 turns a last-bit difference of a near-zero gradient into a step of lr: test_gfn_adam_... above)
+    np.testing.assert_allclose(a["hist"], b["hist"], rtol=1e-4)
+    for k, tol, share in (("table", 2e-5, 1e-2), ("mlp", 2e-4, 1e-2), ("block0", 2e-5, 3e-2)):
+        diff = (b[k] - a[k]).abs()
+        assert float((diff > tol).float().mean()) < share and float(diff.max()) < 0.05, (k, float((diff > tol).float().mean()), float(diff.max()))
+    assert float((b["errmap"] - a["errmap"]).abs().max()) < 1e-3
+    assert float((b["block0"]).abs().max()) > 0 and b["deferred"] <= 1  # the block stage was reached; at most the last draw is still put off
+
+
 @pytest.mark.parametrize("prefetch", [False, True])
 def test_gfn_adam_is_the_same_training_run_as_torch_adam(dev, tmp_path, prefetch):
     """The `gf-nerf` config's optimiser (gfnerf/optim.py GfnAdam: the HIP Adam kernels on the engine's own gradient buffers, no
