@@ -830,7 +830,7 @@ def compact_line(out):
     line = {k: _r(out[k], 6) for k in keep if k in out}
     c = out["config"]
     cfg = {k: _r(c[k]) for k in ("workload", "rays_per_batch", "mean_samples_per_ray", "log2_table_size", "n_cameras", "n_tree_nodes", "stage", "early_T",
-                                  "alive_sample_frac", "evaluated_sample_frac", "backend", "loss") if c.get(k) is not None}
+                                  "alive_sample_frac", "evaluated_sample_frac", "evaluated_samples_per_sec", "backend", "loss") if c.get(k) is not None}
     cfg["launch"] = "graph" if str(c.get("launch", "")).startswith("hipGraph") else "eager"
     cfg["parallelism"] = c["parallelism"].split(":")[0].split(",")[0]
     if c.get("two_phase"):
@@ -979,7 +979,8 @@ def run_rank(args):
                                rays_per_batch=N_RAYS, mean_samples_per_ray=n_live / N_RAYS, log2_table_size=args.log2_T,
                                n_cameras=n_cams, n_cameras_spec=1600, n_tree_nodes=int(sc["n_nodes"]), n_warp_transforms=int(sc["n_trans"]),
                                fineness=run.fineness, stage=headline_stage, early_T=cfg.early_T, alive_sample_frac=alive_frac,
-                               evaluated_sample_frac=n_eval / max(n_live, 1), fused_forward=bool(cfg.fused_forward),
+                               evaluated_sample_frac=n_eval / max(n_live, 1), evaluated_samples_per_sec=value * n_eval / N_RAYS,
+                               fused_forward=bool(cfg.fused_forward),
                                block_primes="own per table (reference)",
                                mlp=("split-f16 x3 MFMA 32x32x16 (f32 accuracy)" if cfg.mlp_precision == "x3" else "f32 MFMA 32x32x2"),
                                parallelism=("single GPU" if world == 1 else
