@@ -417,7 +417,7 @@ def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
                 includes="index draw, pixel gather, ray generation, error-map write-back + CDF upkeep", duplicates_left=int(sampler.last_status[1].item()))
 
 
-def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True):
+def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True, graph_forward=True):
     """The training iteration THROUGH the plugin surface, the way the reference's Trainer drives it (engine/trainer.py:195-231,
     382-441): callbacks before -> optimizers.zero_grad_all -> pipeline.get_train_loss_dict(step) (incl. datamanager.next_train)
     -> sum(loss_dict) -> backward -> the NaN check over model.named_parameters() -> optimizers.optimizer_step_all ->
@@ -447,6 +447,7 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
                                 model=GFNeRFModelConfig(**mk), prefetch_next_batch=prefetch)
     pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfn_plugin_bench"))
     model = pipe.model
+    model.hot.cfg.graph_forward = bool(graph_forward)
     sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=S_INIT, n_split_dataset=N_SPLIT, n_dataset_circles=1,
                                                   steps_per_split_dataset=S_SPLIT, steps_perssampler_init=S_INIT)
     ocfg = (GfnAdamOptimizerConfig if fused_optimizer else AdamOptimizerConfig)(lr=1e-2, eps=1e-15)

@@ -336,7 +336,8 @@ class GFNerfPipeline(Pipeline):
 
         # (global stage: the backward is followed by the weight-gradient kernels, whose LDS the sampler's traversal cannot share -- started
         # late it ends late: 2.23 against 2.04 ms per iteration; there the host draws at once)
-        if hot.fused_optimizers and self.model.field.cur_stage == "block_stage":
+        # (a forward that was one graph replay leaves the host ahead of the device: nothing to gain, and the sampler would start late)
+        if hot.fused_optimizers and self.model.field.cur_stage == "block_stage" and not hot.last_forward_replayed:
             hot.defer(draw)
         else:
             draw()

@@ -110,7 +110,13 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, stage, block, o, d, cam, noise, table, block_table, emb, *decoder):
         hot = model.hot
-        comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block)
+        s = hot.sample(o, d, noise)  # (collects the prefetched sampler, if these are its tensors)
+        # static buffers (prefetch_samples): the focal stage's forward as a graph replay (global stage, measured: 2.07 against 2.02 ms per
+        # iteration -- its iteration is not bound by the host)
+        if stage == hp_mod.STAGE_FOCAL and any(s is st for st in model._static_samples):
+            comp, hctx = hot.forward_train_graphed(cam, stage, block, s)
+        else:
+            comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block, samples=s)
         ctx.model, ctx.hctx, ctx.stage, ctx.block = model, hctx, stage, block
         ctx.params = (table, block_table, emb) + tuple(decoder)
         ctx.set_materialize_grads(False)  # an output the loss does not use arrives as None, not as zeros to be tested on the host
@@ -272,6 +278,7 @@ class GFNeRFModel(Model):
         self._tile_renderer = None
         self._trainer_step = None
         self._prefetched = None
+        self._static_samples, self._static_turn = [None, None], 0  # prefetch_samples' two sets of sample buffers
         self._s3im_gen = torch.Generator(device=dev)
         self._s3im_gen.manual_seed(77 + c.engine_seed)
 
@@ -415,7 +422,15 @@ class GFNeRFModel(Model):
         o, d, _ = self._bundle(ray_bundle)
         noise = self.persampler.sampler.make_noise(o.shape[0])
         self._relink_tree()
-        self.hot.prefetch_sample(o, d, noise)
+        # two sets of sample buffers, written alternately: static addresses let the engine replay the forward that reads them as a
+        # hipGraph (HotPath.forward_train_graphed); a set made for another batch size is dropped
+        st, k = self._static_samples, self._static_turn
+        if st[k] is not None and st[k]["pts_offsets"].numel() != o.shape[0] + 1:
+            st[0] = st[1] = None
+            self.hot.forget_graphs()
+        self.hot.prefetch_sample(o, d, noise, out=st[k])
+        st[k] = self.hot._pre[4]
+        self._static_turn = 1 - k
         self._prefetched = (ray_bundle, o, d, noise)
 
     def get_outputs(self, ray_bundle: RayBundle):

@@ -127,9 +127,12 @@ if "plugin" in what:
     import bench
 
     res = {}
-    variants = [("fused+prefetch", dict()), ("fused", dict(prefetch=False)), ("torch_adam", dict(fused_optimizer=False, prefetch=False))]
+    variants = [("fused+prefetch", dict()), ("fused+prefetch, eager forward", dict(graph_forward=False)), ("fused", dict(prefetch=False)),
+                ("torch_adam", dict(fused_optimizer=False, prefetch=False))]
     if "quick" in what:
         variants = variants[:1]
+    if "ab" in what:
+        variants = variants[:2] * 2
     import gc
     if "profile" in what:
         import cProfile, pstats
