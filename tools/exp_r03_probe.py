@@ -36,7 +36,7 @@ def timed(fn, iters=20, warm=3):
 
 
 sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir="/tmp/gfnerf_amd_scene")
-if what & {"lm", "term", "mask"}:
+if what & {"lm", "term"}:
     cfg = hotpath.HotPathConfig(log2_T=21)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
     g = torch.Generator(device="cuda").manual_seed(100)
@@ -69,27 +69,6 @@ if "lm" in what:
         rows.append(dict(frac=frac, n=n, lm_ms_per_table=round(ms, 4), direct_two_tables_ms=round(ms_d, 4)))
         print(rows[-1], flush=True)
     out["lm_scaling"] = rows
-
-if "mask" in what:
-    T, V = cfg.log2_T, hp.n_volumes
-    cap = s["ts"].shape[0]
-    st = ops.PhaseState(N_RAYS, cap, "cuda")
-    feat = torch.empty((16, cap, 2), dtype=torch.float32, device="cuda")
-    sh = ops.sh4(s["dirs_unit"])
-    rows = []
-    for K in (1024, 160, 136, 128, 96, 64):
-        st.k.fill_(K)
-        ops.phase_mask(s["pts_offsets"], s["ray_id"], s["n_dev"], st)
-        nA = int(st.mask_a[:n_live].sum().item())
-        nd = torch.tensor([nA], dtype=torch.int32, device="cuda")
-        ms_mask = timed(lambda: ops.hash_fwd_lm(hp.table16, hp.prim, None, s["warped_pts"], s["anchors"], V, T, n_dev=s["n_dev"], planar=True, out=feat, mask=st.mask_a))
-        ms_pref = timed(lambda: ops.hash_fwd_lm(hp.table16, hp.prim, None, s["warped_pts"], s["anchors"], V, T, n_dev=nd, planar=True, out=feat))
-        ops.hash_fwd_lm(hp.table16, hp.prim, None, s["warped_pts"], s["anchors"], V, T, n_dev=s["n_dev"], planar=True, out=feat)
-        d_mask = timed(lambda: ops.field_fwd(feat, s["ray_id"], sh, hp.emb, cam, hp.layers, n_dev=s["n_dev"], save=True, image=hp._x3()[0], mask=st.mask_a))
-        d_pref = timed(lambda: ops.field_fwd(feat, s["ray_id"], sh, hp.emb, cam, hp.layers, n_dev=nd, save=True, image=hp._x3()[0]))
-        rows.append(dict(K=K, frac=round(nA / n_live, 3), lm_masked=round(ms_mask, 4), lm_prefix_same_count=round(ms_pref, 4), dec_masked=round(d_mask, 4), dec_prefix=round(d_pref, 4)))
-        print(rows[-1], flush=True)
-    out["mask_vs_prefix"] = rows
 
 if "term" in what:
     gt = torch.rand((N_RAYS, 3), device="cuda")
