@@ -66,7 +66,7 @@ class HotPathConfig:
     record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
-    prefetch_cus_global: int = 208   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
+    prefetch_cus_global: int = 192   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
     two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
                                      # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
                                      # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
