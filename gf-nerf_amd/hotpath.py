@@ -636,6 +636,8 @@ class HotPath:
         ent["cam"].copy_(cam_idx)
         self._join_aux()
         self._sync_opt()
+        if stage != STAGE_GLOBAL and self._x3_stale:
+            self._x3()  # the decoder was written from outside (a checkpoint): repacked in place, the replay reads the same images
         ent["graph"].replay()
         self.last_forward_replayed = True
         self.last_forward, self._last_train_ctx = ent["last_forward"], ent["ctx"]

@@ -867,6 +867,54 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
 
 
+def test_graphed_forward_is_the_eager_forward(setup):
+    """HotPath.forward_train_graphed (the plugin surface's focal forward over two static sets of sample buffers): three eager runs per
+    set, then one hipGraph replay per call -- the same training run as forward_train, bit for bit (focal stage, T = 2^18: exact record
+    accumulation): losses, the block table and its Adam moments after eight iterations, phased forward included; and a decoder
+    written from outside between two replays (a checkpoint) is repacked before the next one."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops, scene
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    R, K = 256, 8
+    noise = t(scene.make_noise(R, False, 5.0))
+    batches = []
+    for k in range(K):
+        o, d, cam = scene.make_rays(sc["c2w"], R, seed=340 + k)
+        gt = np.random.default_rng(390 + k).random((R, 3)).astype(np.float32)
+        batches.append(tuple(t(a) for a in (o, d, cam, gt)))
+
+    def run(graphed):
+        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=graphed)
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
+        hp.table.mul_(100.0); hp.refresh_shadows()
+        bufs, losses, kinds = [None, None], [], []
+        for k, (o, d, cam, gt) in enumerate(batches):
+            if k == 6:  # parameters written from outside the optimiser: the frozen decoder and the global table
+                hp.layers[1][0].mul_(1.25); hp.table.mul_(0.9); hp.refresh_shadows()
+            s = hp.sample(o, d, noise, out=bufs[k % 2])
+            bufs[k % 2] = s
+            comp, ctx = hp.forward_train_graphed(cam, "focal", 0, s, want_depth=False)
+            kinds.append(hp.last_forward_replayed)
+            loss, g = ops.charbonnier(comp["rgb"], gt)
+            hp.backward(ctx, g)
+            hp.optimizer_step("focal", 0)
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        return dict(losses=losses, kinds=kinds, table=hp.blocks[0].clone(), m=hp._adam["block0"][0].clone(), v=hp._adam["block0"][1].clone(),
+                    k=int(hp._phase.k.item()))
+
+    a, b = run(False), run(True)
+    assert a["kinds"] == [False] * K and b["kinds"] == [False] * 6 + [True] * 2, (a["kinds"], b["kinds"])  # three eager runs per buffer set first
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-6)  # (the loss scalar is summed with atomics)
+    assert a["k"] == b["k"] and a["losses"][6] != a["losses"][5]
+    for key in ("table", "m", "v"):
+        assert torch.equal(a[key], b[key]), key
+    assert float(b["table"].abs().max()) > 0
+
+
 def test_step_draws_are_uniform_fresh_per_call_and_replayable():
     """gfn_step_draws (the device's own Philox4x32-10 stream for a captured step's random draws): march noise (u + 0.5) * fineness with u
     uniform in [0, 1) (PersSampler_cuda.cu:380-389), S3IM's index vector = arange + 9 uniform random permutations (losses.py:780-789);
