@@ -1247,9 +1247,9 @@ def copy_list(pairs):
     """[(dst, src)]: up to 8 small same-dtype, same-size contiguous device tensors copied in ONE launch (gfn_copy_list)."""
     import ctypes as C
 
-    for d, s in pairs:
-        if d.dtype != s.dtype or d.numel() != s.numel() or not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous()):
-            raise _lib.GfnError("copy_list: pairs of contiguous device tensors of one dtype and size")
+    for d, s in pairs:  # (a source may also be PINNED host memory: the device reads it in place -- small per-step scalars ride along)
+        if d.dtype != s.dtype or d.numel() != s.numel() or not (d.is_cuda and (s.is_cuda or s.is_pinned()) and d.is_contiguous() and s.is_contiguous()):
+            raise _lib.GfnError("copy_list: pairs of contiguous tensors of one dtype and size, device destinations, device or pinned host sources")
     pairs = [(d, s) for d, s in pairs if d.numel()]  # nothing to do for empty tensors (they have no address)
     n = len(pairs)
     if n == 0:

@@ -217,8 +217,10 @@ class StepGraph:
         self.G = [None] * self.cycle
 
     # ------------------------------------------------------------------ per step
-    def _refresh_hyper(self, advance=True):
-        """Adam's factors of the NEXT step of every group; advance: the groups of the step about to be replayed take it."""
+    def _refresh_hyper(self, advance=True, ride_with=None):
+        """Adam's factors of the NEXT step of every group; advance: the groups of the step about to be replayed take it.
+        ride_with: (dst, src) pairs of the batch hand-over -- the factors then travel in the same launch (gfn_copy_list reads the pinned
+        block in place) instead of a host-to-device copy of their own in front of the replay."""
         hp = self.hp
         step_for_lr = hp.step
         active = {n for n, _ in hp.adam_groups(self.stage, self.blocks[self.p % len(self.blocks)])}
@@ -238,7 +240,10 @@ class StepGraph:
                 hp._adam_t[name] = t
             mult = 1.0 if self.lr_schedule is None else float(self.lr_schedule(step_for_lr))
             host[i] = torch.from_numpy(ops.adam_hyper(t, lr * mult))
-        self.hyper_dev.copy_(host, non_blocking=True)
+        if ride_with is not None:
+            ops.copy_list(list(ride_with) + [(self.hyper_dev, host)])
+        else:
+            self.hyper_dev.copy_(host, non_blocking=True)
         self._ring_ev[k] = torch.cuda.Event()
         self._ring_ev[k].record()
         if advance:
@@ -259,9 +264,9 @@ class StepGraph:
             self.invalidate()  # plan the phases (and choose the forward kernels) again: the scene has moved on
         if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
             self.capture()
-        ops.copy_list([(self.cam, cam_idx.contiguous()), (self.gt, gt_rgb.contiguous()), (self.nxt_o, next_rays_o.contiguous()),
-                       (self.nxt_d, next_rays_d.contiguous())])  # one launch, not four memcpy nodes in front of every replay
-        self._refresh_hyper(advance=True)
+        # one launch in front of every replay (not four memcpy nodes and a host-to-device copy): the batch and Adam's factors
+        self._refresh_hyper(advance=True, ride_with=[(self.cam, cam_idx.contiguous()), (self.gt, gt_rgb.contiguous()), (self.nxt_o, next_rays_o.contiguous()),
+                                                     (self.nxt_d, next_rays_d.contiguous())])
         j = self.p
         if self.segmented:
             for x in self.G[j]:
