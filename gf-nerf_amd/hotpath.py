@@ -101,6 +101,7 @@ class HotPath:
         self._depth_key, self._depth_val = None, 0
         self._records = None
         self._opt_stream, self._opt_pending = None, False
+        self.k_host = None          # see _forward_phased
         self._aux_stream, self._aux_pending = None, False  # branch of the phased forward: front list + plan beside the loss
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
@@ -433,6 +434,8 @@ class HotPath:
                 f["front"] = self._timed("phase_list_front", ops.phase_list, s["pts_offsets"], st, front=True)
             enter, stay = c.two_phase_min_saving_planes if planes is not None else c.two_phase_min_saving
             self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
+            if self.k_host is not None:  # a pinned int32 [1]: the planned K travels to the host from this branch (read late, never waited for)
+                self.k_host.copy_(st.k, non_blocking=True)
         self._aux_pending = True
         f["feat"] = feat
         return f, comp

@@ -114,14 +114,13 @@ class StepGraph:
             hp.after_lookup = draws
         else:
             draws()
+        hp.k_host = self._k_host  # the planned K travels to the host with every replay (no synchronisation: step() reads it late)
         try:
             loss, aux = hp.train_step(None, None, self.cam, self.gt, None, stage=self.stage, block=block, s3im_index=self.s3[p],
                                       prefetch=(self.nxt_o, self.nxt_d, self.noise), update_oct=self.update_oct, samples=self.S[p],
                                       prefetch_out=self.S[1 - p], hyper=self.hyper)
         finally:
-            hp.after_lookup = None
-        if hp.last_forward == "lm2":  # the planned K travels to the host with every replay (no synchronisation: step() reads it late)
-            self._k_host.copy_(hp._phase.k, non_blocking=True)
+            hp.after_lookup, hp.k_host = None, None
         assert hp._pre is not None and hp._pre[4]["pts_offsets"] is self.S[1 - p]["pts_offsets"], "the prefetch must fill the other sample buffer"
         self.S[1 - p] = hp._pre[4]
         hp._pre = None  # collected: the next replay reads it as its `samples`
