@@ -258,12 +258,12 @@ def cpu_baseline(P, batch, log2_T, fineness, n_rays, block, scene):
     o, d, cam, gt = (a[:n_rays] for a in batch)
     noise = scene.make_noise(n_rays, True, fineness, seed=1)
     t0 = time.perf_counter()
-    loss, grads, aux = opipe.loss_and_grads(P, o, d, cam, gt, noise, log2_T, block=block)
+    loss, grads, aux = opipe.loss_and_grads(P, o, d, cam, gt, noise, log2_T, block=block, bwd_threads=0)
     dt = time.perf_counter() - t0
     n_samples = int(aux["samples"]["pts_offsets"][-1])
     return dict(value=n_rays / dt, unit="rays/s", cores=_cores(), kind="port",
                 sample=f"{n_rays} rays ({n_samples} samples) of the same batch, oracle fwd+bwd (no Adam), {dt:.1f} s; "
-                       "trace/march/hash-fwd/linear-fwd/composite run OpenMP on all cores, the backward pieces are scalar")
+                       "all stages OpenMP on all cores (trace, march, hash fwd/bwd, decoder fwd/bwd, compositing fwd/bwd)")
 
 
 def cpu_baseline_global(P, batch, log2_T, fineness, scene, n_packed=1024, n_dense=48):

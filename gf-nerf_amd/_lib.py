@@ -16,6 +16,8 @@ class WgradLayer(C.Structure):
                 ("m_valid", C.c_int32), ("k_valid", C.c_int32), ("col_map", _vp), ("dW", _vp), ("ldw", C.c_int32), ("db", _vp)]
 
 
+ABI_VERSION = 102  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
+
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {
     "gfn_last_error": (C.c_char_p, []),
@@ -136,6 +138,11 @@ def lib():
         handle = C.CDLL(LIB_PATH)
     except OSError as e:  # no fallback
         raise GfnError(f"cannot load the HIP extension {LIB_PATH}: {e}") from e
+    handle.gfn_version.restype, handle.gfn_version.argtypes = _i32, []
+    got = handle.gfn_version()
+    if got != ABI_VERSION:  # a .so and a binding from different revisions: calls would go through with shifted arguments
+        raise GfnError(f"{LIB_PATH} implements ABI revision {got}, this binding was written for {ABI_VERSION} (include/gfnerf_amd.h GFN_ABI_VERSION): "
+                       "rebuild the extension (python gf-nerf_amd/build.py) or use the _lib.py that ships with it")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res

@@ -97,7 +97,7 @@ extern "C" {
 
 const char* gfn_last_error(void) { return g_err; }
 
-int gfn_version(void) { return 100; /* 0.1.0 */ }
+int gfn_version(void) { return GFN_ABI_VERSION; }
 
 int gfn_device_count(void) {
   int n = 0;

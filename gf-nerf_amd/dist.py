@@ -30,12 +30,12 @@ def rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
-def allreduce_mean(tensors, group=None):
-    """In-place average over ranks of a list of gradient tensors.  f16 tensors (the x128-scaled table-gradient pool) are summed in
+def allreduce_mean(tensors, group=None, force=False):
+    """In-place average over ranks of a list of gradient tensors (force: issue the collectives on a one-rank group too).  f16 tensors (the x128-scaled table-gradient pool) are summed in
     f32, chunk by chunk, and rounded to f16 once -- like the direct path (gfn_reduce_shards): no overflow however many ranks add
     up, no bits lost to a pre-scaled f16 sum; everything else is scaled by 1/world and summed in its own type."""
     w = world(group)
-    if w == 1:
+    if w == 1 and not force:
         return tensors
     for t in tensors:
         if t.dtype == torch.float16:
@@ -52,9 +52,9 @@ def allreduce_mean(tensors, group=None):
     return tensors
 
 
-def allreduce_max_(tensors, group=None):
+def allreduce_max_(tensors, group=None, force=False):
     """In-place elementwise max over ranks (octree node statistics / visit counts)."""
-    if world(group) == 1:
+    if world(group) == 1 and not force:
         return tensors
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -67,12 +67,13 @@ def _hip_shard_mean(recv, n_shards, out):
     ops.reduce_shards(recv, n_shards, out, scale=1.0 / n_shards)
 
 
-def allreduce_mean_direct(t, group=None, recv=None, shard_mean=None):
+def allreduce_mean_direct(t, group=None, recv=None, shard_mean=None, force=False):
     """Average the flat contiguous tensor `t` over ranks in place: all-to-all of shards, local f32 sum x 1/world of this
     rank's shard (shard_mean(recv, world, out_shard): the HIP kernel by default), all-gather of the reduced shards.
-    t.numel() must be a multiple of 8 x world (callers fall back to allreduce_mean otherwise).  recv: scratch like t."""
+    t.numel() must be a multiple of 8 x world (callers fall back to allreduce_mean otherwise).  recv: scratch like t.
+    force: run the three steps on a one-rank group too (the all-to-all and the all-gather are then copies through the communicator)."""
     w = world(group)
-    if w == 1:
+    if w == 1 and not force:
         return t
     n = t.numel()
     assert t.dim() == 1 and t.is_contiguous() and n % (8 * w) == 0, "allreduce_mean_direct: flat tensor of 8*world*k elements"
@@ -85,13 +86,13 @@ def allreduce_mean_direct(t, group=None, recv=None, shard_mean=None):
     return t
 
 
-def allreduce_selfcheck(n=1 << 20, device="cuda", group=None, shard_mean=None):
+def allreduce_selfcheck(n=1 << 20, device="cuda", group=None, shard_mean=None, force=False):
     """Start-up check of the gradient exchange on the live communicator: allreduce_mean_direct (all_to_all_single + gfn_reduce_shards
     + all_gather_into_tensor) of a seeded f16 buffer of n elements -- at the x128 scale of the table-gradient pool, with entries a
     plain f16 SUM over the ranks would overflow -- against dist.all_reduce of the same values in f32.  -> dict(ok, max_abs_err,
     n, dtype) (identical on every rank)."""
     w, r = world(group), rank(group)
-    if w == 1:
+    if w == 1 and not force:
         return dict(ok=True, max_abs_err=0.0, n=0, world=1)
     n = n // (8 * w) * (8 * w)
     g = torch.Generator(device="cpu").manual_seed(1234 + r)
@@ -101,7 +102,7 @@ def allreduce_selfcheck(n=1 << 20, device="cuda", group=None, shard_mean=None):
     want = x16.float()
     dist.all_reduce(want, op=dist.ReduceOp.SUM, group=group)
     want = (want / w).to(torch.float16)
-    got = allreduce_mean_direct(x16.clone(), group, shard_mean=shard_mean)
+    got = allreduce_mean_direct(x16.clone(), group, shard_mean=shard_mean, force=force)
     err = (got.float() - want.float()).abs().max()
     worst = err.clone()
     dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
@@ -184,10 +185,14 @@ class TrainSync:
 
     DIRECT_MIN_ELEMS = 1 << 20
 
-    def __init__(self, group=None, overlap=True, direct=None, shard_mean=None, single=False):
-        """single: behave as a one-rank job whatever the process group says (a rank's purely local step, e.g. in tests)."""
+    def __init__(self, group=None, overlap=True, direct=None, shard_mean=None, single=False, force_exchange=False):
+        """single: behave as a one-rank job whatever the process group says (a rank's purely local step, e.g. in tests).
+        force_exchange: issue every collective of the step even when the group has ONE rank (the world-1 shortcuts off): the
+        communicator, the communication stream's ordering and the segmented replay then run exactly as with N ranks -- how a
+        one-GPU box exercises the RCCL path (tests/test_gpu_dist.py)."""
         self.group = group
         self.world, self.rank = (1, 0) if single else (world(group), rank(group))
+        self.exchanges = (self.world > 1 or bool(force_exchange)) and not single  # does a step talk to the group at all?
         self.overlap = overlap
         self.direct = direct
         self.shard_mean = shard_mean
@@ -199,8 +204,8 @@ class TrainSync:
     # ---------------------------------------------------------------- octree statistics (between K5 and K6)
     def reduce_octree_stats(self, tensors):
         """tensors: [scratch (w_adder | a_adder | mark) i64 [3 n_nodes], visit_cnt i64 [n_nodes]] -> elementwise MAX over ranks."""
-        if self.world > 1:
-            allreduce_max_(tensors, self.group)
+        if self.exchanges:
+            allreduce_max_(tensors, self.group, force=True)
             self.stats["octree_max_reduces"] += 1
         return tensors
 
@@ -218,16 +223,16 @@ class TrainSync:
             if self._use_direct(t):
                 if self._recv is None or self._recv.numel() != t.numel() or self._recv.dtype != t.dtype or self._recv.device != t.device:
                     self._recv = torch.empty_like(t)
-                allreduce_mean_direct(t, self.group, recv=self._recv, shard_mean=self.shard_mean)
+                allreduce_mean_direct(t, self.group, recv=self._recv, shard_mean=self.shard_mean, force=True)
                 self.stats["direct_reduces"] += 1
             else:
-                allreduce_mean([t], self.group)
+                allreduce_mean([t], self.group, force=True)
         self.stats["grad_reduces"] += 1
 
     def start_grads(self, tensors):
         """Begin averaging `tensors` (final as of the current stream) over the ranks; returns at once.  On the device the
         exchange runs on the communication stream, so kernels launched next on the current stream overlap it."""
-        if self.world == 1:
+        if not self.exchanges:
             return
         assert self._pending is None, "start_grads: the previous exchange was not finished"
         if self.overlap and tensors and tensors[0].is_cuda:
@@ -246,7 +251,7 @@ class TrainSync:
 
     def finish_grads(self, tensors=()):
         """Average `tensors` (the small late gradients: decoder, embedding) now and wait for what start_grads began."""
-        if self.world == 1:
+        if not self.exchanges:
             return
         if tensors:
             self._reduce(list(tensors))

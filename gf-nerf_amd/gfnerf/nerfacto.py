@@ -116,7 +116,8 @@ class _RenderFn(torch.autograd.Function):
         if stage == hp_mod.STAGE_FOCAL and any(s is st for st in model._static_samples):
             comp, hctx = hot.forward_train_graphed(cam, stage, block, s)
         else:
-            comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block, samples=s)
+            # (init stage: update_oct_nodes follows every training forward, nerfacto.py:605-613, and reads every sample's alpha)
+            comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block, samples=s, all_alphas=stage == hp_mod.STAGE_GLOBAL)
         ctx.model, ctx.hctx, ctx.stage, ctx.block = model, hctx, stage, block
         ctx.params = (table, block_table, emb) + tuple(decoder)
         ctx.set_materialize_grads(False)  # an output the loss does not use arrives as None, not as zeros to be tested on the host

@@ -162,6 +162,43 @@ class _NativePersSampler:
         ops.mark_invisible_nodes(self.tree_nodes_gpu_, self.intri_, self.w2c_, self.bound_)
         ops.tree_compact(self.tree_nodes_gpu_, self.nodes_compact_)
 
+    def VisOctree(self, base_exp_dir_):
+        """PersSampler::VisOctree (PersSampler.cpp:478-514, bindings.cpp:53,363): the eight corners of every node as `v` lines and the
+        twelve edges of every LEAF as `l` lines of <base_exp_dir_>/octree.obj (a debugging aid: host file output, no kernel)."""
+        import os
+
+        nd = self._nodes_np()
+        with open(os.path.join(base_exp_dir_, "octree.obj"), "w") as f:
+            for n in nd:
+                c, side = n["center"].astype(np.float32), np.float32(n["side_len"])
+                for st in range(8):
+                    x, y, z = (c + np.array([(st >> 2 & 1) - 0.5, (st >> 1 & 1) - 0.5, (st & 1) - 0.5], np.float32) * side).tolist()
+                    f.write(f"v {x:g} {y:g} {z:g}\n")  # (std::ofstream's default float format: 6 significant digits)
+            for i, n in enumerate(nd):
+                if not n["is_leaf_node"]:
+                    continue
+                for a in range(8):
+                    for b in range(a + 1, 8):
+                        if (a ^ b) in (1, 2, 4):
+                            f.write(f"l {i * 8 + a + 1} {i * 8 + b + 1}\n")
+
+    def GetEdgeSamples(self, n_pts):
+        """bindings.cpp:84-87,370 -> K9 GetEdgeSamplesKernel (PersSampler_cuda.cu:479-516): random points on the edges shared by neighbouring
+        warps, the input of F2-NeRF's total-variation loss.  Its only Python caller, PersSampler.get_edge_samples (perssampler.py:495-497),
+        is itself never called anywhere in gfnerf/ (no TV loss in GFNeRFModel.get_loss_dict, nerfacto.py:628-689), and the edge pool it reads
+        is never built by GF-NeRF's tree construction: outside the hot path -- refused loudly rather than returning made-up points."""
+        raise NotImplementedError("my_classes.PersSampler.GetEdgeSamples (K9, F2-NeRF's TV-loss edge samples) has no caller in gfnerf/ and no edge pool "
+                                  "to read: not part of the GF-NeRF hot path (SURVEY.md 2b K9)")
+
+    def get_points_anchors(self, rays_o, rays_d, t_starts, t_ends):
+        """bindings.cpp:391 -> K10 GetRaysTreeNodesIntersects / GetTreeNodeIdxFromTs: serves the proposal sampler, which gfnerf/ never creates."""
+        raise NotImplementedError("my_classes.PersSampler.get_points_anchors (K10) serves the proposal sampler, which the reference never creates "
+                                  "(no `proposal_sampler` assignment anywhere in gfnerf/): dead code, not built (SURVEY.md 2b)")
+
+    def trans_query_frame(self, world_positions_flat, anchors_flat):
+        """bindings.cpp:392 -> K11 TransQueryFrameKernel: the same dead proposal-sampler path; samples leave GetSamples warped already."""
+        raise NotImplementedError("my_classes.PersSampler.trans_query_frame (K11) serves the dead proposal-sampler path (SURVEY.md 2b)")
+
     def UpdateRayMarch(self, cur_step):
         if cur_step >= self.ray_march_fineness_decay_end_iter_:  # PersSampler.cpp:958-967
             self.ray_march_fineness_ = 1.0
@@ -454,20 +491,7 @@ class PersSampler(nn.Module):
         with open(os.path.join(base_exp_dir, "cam_pos.obj"), "w") as f:
             for pos in self.c2w[:, :, 3].cpu().tolist():
                 f.write(f"v {pos[0]} {pos[1]} {pos[2]}\n")
-        nd = self.sampler._nodes_np()
-        with open(os.path.join(base_exp_dir, "octree.obj"), "w") as f:
-            for n in nd:
-                for st in range(8):
-                    off = np.array([(st >> 2 & 1) - 0.5, (st >> 1 & 1) - 0.5, (st & 1) - 0.5]) * float(n["side_len"])
-                    x, y, z = (n["center"] + off).tolist()
-                    f.write(f"v {x} {y} {z}\n")
-            for i, n in enumerate(nd):
-                if n["trans_idx"] < 0:
-                    continue
-                for a in range(8):
-                    for b in range(a + 1, 8):
-                        if (a ^ b) in (1, 2, 4):
-                            f.write(f"l {i * 8 + a + 1} {i * 8 + b + 1}\n")
+        self.sampler.VisOctree(base_exp_dir)  # perssampler.py:455
 
     def visualize_split_cameras(self, output_dir):
         """perssampler.py:262-283 writes one .ply per camera cluster with plyfile; here the same points as ASCII .ply (positions +
@@ -486,14 +510,14 @@ class PersSampler(nn.Module):
                     f.write(" ".join(repr(float(v)) for v in list(p_) + list(d_)) + "\n")
 
     def get_points_anchors(self, rays_o, rays_d, t_starts, t_ends):
-        raise NotImplementedError("K10 GetRaysTreeNodesIntersects / GetTreeNodeIdxFromTs serve the proposal sampler, which the reference never "
-                                  "creates (no `proposal_sampler` assignment anywhere in gfnerf/): dead code, not built (SURVEY 2b)")
+        return self.sampler.get_points_anchors(rays_o, rays_d, t_starts, t_ends)  # refuses: dead proposal-sampler path
 
     def trans_query_frame(self, world_positions_flat, anchors_flat):
-        raise NotImplementedError("K11 TransQueryFrameKernel serves the dead proposal-sampler path (SURVEY 2b); samples leave GetSamples warped already")
+        return self.sampler.trans_query_frame(world_positions_flat, anchors_flat)  # refuses: dead proposal-sampler path
 
     def get_edge_samples(self, n_pts: int):
-        raise NotImplementedError("K9 GetEdgeSamples (F2-NeRF's TV loss) has no caller in gfnerf/ (SURVEY 2b): not built")
+        """perssampler.py:495-497: forwards to the native GetEdgeSamples, which refuses (no caller in gfnerf/)."""
+        return self.sampler.GetEdgeSamples(n_pts)
 
     def to_proposal_sampler_oct_tree_nodes(self):
         """perssampler.py:552-581: one record per tree node (the model only takes its length: n_volumes, nerfacto.py:268)."""

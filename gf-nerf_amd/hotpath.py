@@ -8,6 +8,7 @@ and for training the matching backward, the Charbonnier loss and Adam.  Every st
 call through the C ABI into hand-written HIP kernels (ops.py); samples stay PACKED and the
 live sample count stays on the device (no host synchronisation inside a step).
 """
+import collections
 import contextlib
 import math
 import weakref
@@ -59,6 +60,8 @@ class HotPathConfig:
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
                                      # hipGraph replay per (stage, block, buffer) after three eager runs: ~25 launches less for the host
+    graph_forward_keep: int = 4      # captured forwards kept (least recently used go first): each holds a full set of forward activations
+                                     # (150-200 MB at 4096 x 192); 4 = two sample buffers x (the active block + the one before it)
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
                                      # frozen global table (HBM-bound beside address-path-bound)
     loss_before_fork: bool = True    # forward_backward enqueues the loss kernels before it forks the octree update / next sampler
@@ -109,7 +112,8 @@ class HotPath:
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self._deferred = []
         self.last_forward_replayed = False
-        self._fwd_graphs = {}       # forward_train_graphed: key -> dict(n, graph, cam, comp, ctx, last_forward)
+        self._fwd_graphs = collections.OrderedDict()  # forward_train_graphed: key -> dict(n, graph, cam, comp, ctx, last_forward), least recently used first
+        self._fwd_pool = None       # one memory pool for every captured forward (their transient buffers share it; replays are sequential)
         self.seg = None             # set by a segmented StepGraph capture: seg(fn) ends the graph segment being captured, notes fn as the
                                     # eager call between segments (a collective) and begins the next segment
         self.n_volumes = self.n_nodes  # nerfacto.py:268: one hash "volume" slot per tree node
@@ -566,11 +570,17 @@ class HotPath:
             ops.fill_zero(self.mlp_grad)
             ops.fill_zero(self.emb_grad)
 
-    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None, want_depth=True, samples=None):
+    def forward_train(self, rays_o, rays_d_raw, cam_idx, noise, stage=STAGE_GLOBAL, block=None, want_depth=True, samples=None, all_alphas=False):
         """Training forward of get_outputs.  Returns (comp, ctx): comp holds rgb [R,3], acc, depth_raw, weights,
         alphas; ctx is what backward() needs (the reference keeps the whole autograd graph alive instead).
         want_depth=False (the native train step, whose losses do not read depth) skips the batch-global t range that
-        DepthRenderer's clip needs (renderers.py:281): comp["t_minmax"] is then None."""
+        DepthRenderer's clip needs (renderers.py:281): comp["t_minmax"] is then None.
+        all_alphas: comp["alphas"] must be the TRUE alpha of every sample, also behind a ray's termination point -- what UpdateOctNodes
+        reads (K5 compares each node's largest alpha with its thresholds, PersSampler_cuda.cu:21-75: a dense node that the rays of one
+        batch only reach behind their cuts must still count as occupied, or its alpha statistic decays 16x faster than the
+        reference's weight statistic lets it).  The density of every sample is then evaluated: no ray leaves the fused forward
+        kernel early, no phased forward; the cut at early_T still applies to the colour (< 1e-4), the weights (0 instead of < 1e-4,
+        below every threshold K5 can form for a ray that has a cut) and the backward."""
         c = self.cfg
         train_mlp = stage == STAGE_GLOBAL
         self.last_forward_replayed = False
@@ -584,14 +594,16 @@ class HotPath:
         # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
         # (with one table the fused kernel's early termination makes it a tie at first and a loss once the scene has density:
         # cfg.level_major_global / level_major_global_after)
-        lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
+        all_alphas = bool(all_alphas) and c.early_T > 0
+        lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after) or all_alphas
         lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
               and not c.keep_features)
-        phased = lm and c.two_phase and c.early_T > 0 and self.phase_override is not False
-        self.last_forward = ("lm2" if phased else "lm") if lm else ("fused" if (fused and self._fused_ok(blk)) else "unfused")
+        phased = lm and c.two_phase and c.early_T > 0 and self.phase_override is not False and not all_alphas
+        use_fused_kernel = fused and self._fused_ok(blk) and not lm and not all_alphas
+        self.last_forward = ("lm2" if phased else "lm") if lm else ("fused" if use_fused_kernel else "unfused")
         if phased:
             f, comp = self._forward_phased(s, cam_idx, blk, True, planes, want_depth)
-        elif fused and self._fused_ok(blk) and not lm:
+        elif use_fused_kernel:
             f, comp = self._forward_fused(s, cam_idx, blk, c.early_T, save=True, planes=planes)
         else:
             f = self._field_forward(s, cam_idx, blk, fused=fused, save=fused, planes=planes, lm=lm)
@@ -617,6 +629,7 @@ class HotPath:
                self.table16.data_ptr() if self.table16 is not None else 0,
                0 if blk is None else (self.blocks16[blk].data_ptr() if c.table_f16_shadow else self.blocks[blk].data_ptr(), self.block_prims[blk].data_ptr()))
         ent = self._fwd_graphs.setdefault(key, dict(n=0, samples=samples))  # (holds the buffers: their id stays theirs)
+        self._fwd_graphs.move_to_end(key)
         usable = (c.graph_forward and self.seg is None and self.after_lookup is None and not self.timed_ops
                   and not torch.cuda.is_current_stream_capturing())
         if not usable or ("graph" not in ent and (ent["n"] < 3 or self.table_grad is None)):
@@ -631,8 +644,17 @@ class HotPath:
             else:
                 self._x3()             # frozen decoder: packed now, not under capture
             torch.cuda.synchronize()
+            # a new key (another block became active, the plan changed the forward kind, ...): the graphs of keys not used for longest
+            # go, with the activations they hold, and so do the counters of keys that never reached a capture
+            captured = [k for k, e in self._fwd_graphs.items() if "graph" in e]
+            for k in captured[: max(len(captured) - (c.graph_forward_keep - 1), 0)]:
+                del self._fwd_graphs[k]
+            for k in [k for k, e in self._fwd_graphs.items() if "graph" not in e and k != key][:-8]:
+                del self._fwd_graphs[k]
+            if self._fwd_pool is None:
+                self._fwd_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self._fwd_pool, capture_error_mode="thread_local"):
                 comp, ctx = self.forward_train(None, None, cam, None, stage, block, want_depth=want_depth, samples=samples)
                 self._join_aux()  # (the branch that builds the backward's list: inside the graph)
             ent.update(graph=g, cam=cam, comp=comp, ctx=ctx, last_forward=self.last_forward)
@@ -753,7 +775,9 @@ class HotPath:
         stage only together with update_oct).  update_oct (global stage): run UpdateOctNodes on this step's samples right after
         the forward, like GFNeRFModel.get_outputs does."""
         c = self.cfg
-        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False, samples=samples)
+        # (UpdateOctNodes reads every sample's alpha: see forward_train)
+        comp, ctx = self.forward_train(rays_o, rays_d_raw, cam_idx, noise, stage, block, want_depth=False, samples=samples,
+                                       all_alphas=update_oct and stage == STAGE_GLOBAL)
         fwd_done = None
         segmented = self.seg is not None
         if c.loss_before_fork and prefetch is not None and not segmented:
@@ -892,7 +916,7 @@ class HotPath:
         table): average this step's gradients over the ranks before Adam.  The table exchange may already be in flight
         (backward starts it as soon as the table gradient is final); the decoder / embedding gradients follow here.  The focal
         stage trains one block table per rank with everything shared frozen: nothing to exchange."""
-        if stage != STAGE_GLOBAL or (self.sync.world == 1 and self.seg is None):
+        if stage != STAGE_GLOBAL or (not self.sync.exchanges and self.seg is None):
             return
         g = self.grads(stage)
         if ctx is not None and ctx.pop("table_exchange_started", False):
@@ -915,7 +939,7 @@ class HotPath:
         per-node maxima K5 produced from this rank's rays are MAX-reduced over the ranks before the statistics update and K6."""
         s, comp = aux["samples"], aux["comp"]
         exchange = None
-        if self.sync.world > 1 or self.seg is not None:
+        if self.sync.exchanges or self.seg is not None:
             exchange = lambda ts: self._eager(lambda: self.sync.reduce_octree_stats(ts))  # noqa: E731
         ops.update_nodes(s["pts_offsets"], s["anchors"], comp["weights"], comp["alphas"], self.weight_stats,
                          self.alpha_stats, self.visit_cnt, self.nodes, reduce_max=exchange)

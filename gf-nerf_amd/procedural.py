@@ -27,16 +27,36 @@ def height(x, y):
     return 1.5 * torch.sin(0.35 * x) * torch.cos(0.27 * y) + 0.8 * torch.sin(0.9 * x + 1.3) * torch.sin(0.7 * y + 0.4)
 
 
-def field(xyz):
+TEX_WAVELENGTHS = (1.6, 0.8, 0.4, 0.2, 0.1)  # world units; a pixel of the capture covers ~0.012 units of ground
+
+
+def texture(x, y, z, c):
+    """Fine detail of colour channel c in [-1, 1]: five octaves of oriented ripples (wavelengths TEX_WAVELENGTHS, amplitude ~ sqrt(wavelength),
+    directions and phases fixed per octave and channel) -- the rubble on the terrain: detail a 3,000-step run resolves only in part,
+    which is what bounds PSNR on a real capture (Mega-NeRF's Rubble: 24-26 dB), not optimiser noise."""
+    v, norm = 0.0, 0.0
+    for k, lam in enumerate(TEX_WAVELENGTHS):
+        f = 2.0 * math.pi / lam
+        th, ph, ps = 0.7 + 2.399963 * (3 * k + c), 1.3 * (k + 1) * (c + 1), 0.9 * (k + 2) * (c + 1)
+        a = math.sqrt(lam / TEX_WAVELENGTHS[0])
+        v = v + a * torch.sin(f * (x * math.cos(th) + y * math.sin(th)) + ph) * torch.cos(0.5 * f * z + ps)
+        norm += a
+    return v / norm
+
+
+def field(xyz, detail=0.0):
     """xyz [..., 3] world coordinates -> (sigma [...], rgb [..., 3]): opaque below the terrain surface (optical depth 6 per unit),
-    coloured in smooth bands of position and height."""
+    coloured in smooth bands of position and height; detail > 0 adds detail * texture() to every channel (clamped to [0, 1])."""
     x, y, z = xyz[..., 0], xyz[..., 1], xyz[..., 2]
     h = height(x, y)
     sigma = 6.0 * torch.sigmoid(4.0 * (h - z))
     r = 0.5 + 0.5 * torch.sin(0.8 * x + 0.3 * h)
     g = 0.5 + 0.5 * torch.sin(0.6 * y + 1.0 + 0.5 * h)
     b = 0.5 + 0.5 * torch.cos(0.4 * (x + y)) * torch.cos(1.1 * h)
-    return sigma, torch.stack([r, g, b], -1)
+    rgb = torch.stack([r, g, b], -1)
+    if detail > 0:
+        rgb = (rgb + detail * torch.stack([texture(x, y, z, c) for c in range(3)], -1)).clamp(0.0, 1.0)
+    return sigma, rgb
 
 
 def quadrature_points(o, d):
@@ -52,10 +72,10 @@ def quadrature_points(o, d):
     return o[:, None, :] + t[..., None] * dn[:, None, :], step[:, None].expand(-1, N_QUAD)
 
 
-def gt_colors(o, d):
+def gt_colors(o, d, detail=0.0):
     """Ground-truth colour [R,3] of rays (o, d): front-to-back compositing of `field` over `quadrature_points`, black background."""
     xyz, dt = quadrature_points(o, d)
-    sigma, rgb = field(xyz)
+    sigma, rgb = field(xyz, detail)
     ds = sigma * dt
     T = torch.exp(-(torch.cumsum(ds, 1) - ds))
     w = (1.0 - torch.exp(-ds)) * T
@@ -66,55 +86,204 @@ def psnr(pred, gt):
     return float(-10.0 * torch.log10(torch.mean((pred - gt) ** 2)))
 
 
+LEGS = {
+    # the product as shipped: split-f16 x3 MFMA decoder, early termination at T < 1e-4, phased forward, LDS fixed-point gradient accumulation, GfnAdam's kernel
+    "fast": dict(precision="x3"),
+    "x3": dict(precision="x3"),
+    # the product with the exact-f32 decoder (isolates the decoder arithmetic inside the product's own training semantics)
+    "f32": dict(precision="f32"),
+    # the reference's training semantics (engine/trainer.py:382-441 + gfnerf/nerfacto.py:522-619,628-689): every sample evaluated and composited
+    # (no transmittance cut), exact-f32 nn.Linear decoder (gfnerf/mlp.py:35-57), table gradient through f16 x128 atomic adds
+    # (Hash3DAnchored_cuda.cu:151,209,222), torch.optim.Adam per parameter group (engine/optimizers.py:100-133)
+    "reference": dict(precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, torch_adam=True),
+}
+
+
+def device_rays(c2w, n, gen, cams=None):
+    """scene.make_rays on the device: uniformly random (camera, pixel) rays of the capture, fresh every step (a training set of
+    1,600 x 1 Mpixel is never cycled inside a few thousand steps).  c2w f32 [n_cams,3,4] on the device; cams: int64 indices to draw from."""
+    dev = c2w.device
+    if cams is None:
+        cam = torch.randint(0, c2w.shape[0], (n,), generator=gen, device=dev)
+    else:
+        cam = cams[torch.randint(0, cams.numel(), (n,), generator=gen, device=dev)]
+    uv = torch.rand((n, 2), generator=gen, device=dev, dtype=torch.float32)
+    px, py = uv[:, 0] * scene.WIDTH, uv[:, 1] * scene.HEIGHT
+    d_cam = torch.stack([(px - scene.WIDTH / 2) / scene.FOCAL, -(py - scene.HEIGHT / 2) / scene.FOCAL, -torch.ones_like(px)], -1)
+    d = torch.einsum("nij,nj->ni", c2w[cam, :, :3], d_cam)
+    d = d / d.norm(dim=-1, keepdim=True)
+    return c2w[cam, :, 3].contiguous(), d.contiguous(), cam.to(torch.int32)
+
+
+class TorchAdam:
+    """torch.optim.Adam per parameter group on the engine's parameters -- Optimizers.optimizer_scaler_step_all (engine/optimizers.py:100-133) --
+    fed the dense f32 gradients the reference's autograd would hold: the table's = the f16 x128 pool / 128 (Hash3DAnchoredFunction::backward,
+    Hash3DAnchored_cuda.cu:209-240)."""
+
+    def __init__(self, hp):
+        self.hp, self.opt = hp, {}
+
+    def _group(self, name):
+        hp = self.hp
+        if name not in self.opt:
+            n_live = 17 * (1 << hp.cfg.log2_T)
+            if name == "table" or name.startswith("block"):
+                p = (hp.table if name == "table" else hp.blocks[int(name[5:])]).view(-1)[:n_live]
+                grad = lambda: hp.table_grad.view(-1)[:n_live].float() / (128.0 if hp.table_grad.dtype == torch.float16 else 1.0)  # noqa: E731
+            elif name == "mlp":
+                p, grad = hp.mlp_flat, lambda: hp.mlp_grad
+            else:
+                p, grad = hp.emb, lambda: hp.emb_grad
+            p = torch.nn.Parameter(p, requires_grad=False)  # a leaf that aliases the engine's storage
+            self.opt[name] = (p, grad, torch.optim.Adam([p], lr=1e-2, eps=hp.cfg.adam_eps))
+        return self.opt[name]
+
+    def step(self, groups):
+        """groups: [(name, lr)] (HotPath.adam_groups with the schedule's rate)."""
+        hp = self.hp
+        hp._sync_opt()
+        for name, lr in groups:
+            p, grad, opt = self._group(name)
+            p.grad = grad()
+            opt.param_groups[0]["lr"] = lr
+            opt.step()
+        hp.step += 1
+        hp.refresh_shadows()  # f16 shadows of the tables + the decoder's weight images follow the new values
+
+
+def grad_cosine(hp, batch, noise, s3, stage, block):
+    """One forward + backward of `batch` from the engine's current state with the exact-f32 decoder and with the split-f16 x3 decoder:
+    cosine and relative difference of the two gradients per parameter group (no optimiser step, no octree update)."""
+    o, d, cam, gt = batch
+    saved, got = hp.cfg.mlp_precision, {}
+    n_live = 17 * (1 << hp.cfg.log2_T)
+    for prec in ("f32", "x3"):
+        hp.cfg.mlp_precision = prec
+        hp._x3_stale = True
+        hp.forward_backward(o, d, cam, gt, noise, stage=stage, block=block, s3im_index=s3, update_oct=False)
+        hp._sync_opt()
+        g = dict(table=hp.table_grad.view(-1)[:n_live].double())
+        if stage == hotpath.STAGE_GLOBAL:
+            g.update(mlp=hp.mlp_grad.double().clone(), emb=hp.emb_grad.double().clone())
+        got[prec] = {k: v.clone() for k, v in g.items()}
+    hp.cfg.mlp_precision = saved
+    hp._x3_stale = True
+    out = {}
+    for k in got["f32"]:
+        a, b = got["f32"][k], got["x3"][k]
+        na, nb = float(a.norm()), float(b.norm())
+        out[k] = dict(cos=float((a * b).sum()) / max(na * nb, 1e-300), rel_diff=float((a - b).norm()) / max(na, 1e-300))
+    return out
+
+
 def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_rays=4096, log2_T=21, seed=0, n_pool=64, eval_rays=16384, target_samples=128,
-                   early_T=1e-4, progress=None, update_oct=True, **cfg_kw):
+                   early_T=1e-4, progress=None, update_oct=True, torch_adam=False, fresh_rays=True, data_seed=None, eval_seed=0, lr_final=1e-2,
+                   holdout_every=0, cosine_every=0, keep_engine=False, detail=0.0, **cfg_kw):
     """Train on the procedural scene with the product's native step (HotPath.train_step: sampler -> lookup -> decoder -> compositing ->
-    Charbonnier + S3IM -> backward -> Adam; UpdateOctNodes every global step like GFNeRFModel.get_outputs), lr 1e-2 -> 1e-4 over the global
-    stage and 5e-3 -> 5e-5 over the focal stage (GFNerfExponentialDecayScheduler's shape, schedulers.py:113-184), then render held-out rays
-    of the training cameras.  -> dict(psnr_global, psnr, loss, ...)."""
+    Charbonnier + S3IM -> backward -> Adam; UpdateOctNodes every global step like GFNeRFModel.get_outputs), lr 1e-2 -> 1e-2 * lr_final over the
+    global stage and 5e-3 -> 5e-3 * lr_final over the focal stage (GFNerfExponentialDecayScheduler's shape, schedulers.py:113-184), then render
+    held-out rays.  -> dict(psnr_global, psnr, loss, ...).
+
+    detail: amplitude of the fine colour texture (procedural.texture) in the ground truth.
+    seed: the model's initialisation (tables, primes, decoder, embedding) and the march noise; data_seed (default: seed): the training rays;
+    eval_seed: the held-out rays -- ONE fixed set for every seed by default, so that runs are compared on the same pixels.
+    fresh_rays: new random rays every step (device_rays); False: a resident pool of n_pool batches, cycled (rounds 2-3).
+    torch_adam: step the parameters with torch.optim.Adam on dense gradients (TorchAdam) instead of the engine's Adam kernel.
+    holdout_every = k > 0: cameras k-1, 2k-1, ... give no training ray; `psnr_heldout` renders their pixels with the nearest training
+    camera's appearance embedding (nerfacto_field.py:533: "test mode use nearest rel camera indices").
+    cosine_every = n > 0: every n steps, grad_cosine of the batch at hand (res["grad_cosine"] = [(stage, step, {group: {cos, rel_diff}})]).
+    After training the SAME state is also rendered with the other decoder arithmetic (psnr_eval_x3 / psnr_eval_f32): the inference-only
+    difference, free of training chaos."""
     dev = torch.device("cuda", torch.cuda.current_device())
     cfg = hotpath.HotPathConfig(log2_T=log2_T, mlp_precision=precision, early_T=early_T, **cfg_kw)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=seed, n_blocks=1)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    data_seed = seed if data_seed is None else data_seed
+    c2w = t(sc["c2w"])
+    n_cams = c2w.shape[0]
+    all_cams = torch.arange(n_cams, device=dev)
+    if holdout_every > 0:
+        held = all_cams[holdout_every - 1:: holdout_every]
+        train_cams = all_cams[(all_cams + 1) % holdout_every != 0]
+    else:
+        held, train_cams = None, None
+    dgen = torch.Generator(device=dev).manual_seed(data_seed * 100003 + 17)
     pool = []
-    for k in range(n_pool):  # a resident pool of training batches (rays + ground truth), cycled
-        o, d, cam = scene.make_rays(sc["c2w"], n_rays, seed=seed * 100003 + k)
-        o, d, cam = t(o), t(d), t(cam)
-        pool.append((o, d, cam, gt_colors(o, d)))
-    eo, ed, ecam = scene.make_rays(sc["c2w"], eval_rays, seed=seed * 100003 + 7_000_000)
-    eo, ed, ecam = t(eo), t(ed), t(ecam)
-    egt = gt_colors(eo, ed)
+    if not fresh_rays:
+        for k in range(n_pool):  # a resident pool of training batches (rays + ground truth), cycled
+            o, d, cam = scene.make_rays(sc["c2w"], n_rays, seed=data_seed * 100003 + k, cams=None if train_cams is None else train_cams.cpu().numpy())
+            o, d, cam = t(o), t(d), t(cam)
+            pool.append((o, d, cam, gt_colors(o, d, detail)))
+
+    def batch(i):
+        if not fresh_rays:
+            return pool[i % n_pool]
+        o, d, cam = device_rays(c2w, n_rays, dgen, cams=train_cams)
+        return o, d, cam, gt_colors(o, d, detail)
+
+    egen = torch.Generator(device=dev).manual_seed(eval_seed * 100003 + 7_000_000)
+    eo, ed, ecam = device_rays(c2w, eval_rays, egen, cams=train_cams)
+    egt = gt_colors(eo, ed, detail)
+    if held is not None:
+        ho, hd, hcam = device_rays(c2w, eval_rays, egen, cams=held)
+        hgt = gt_colors(ho, hd, detail)
+        pos = c2w[:, :, 3]
+        near = torch.cdist(pos[held], pos[train_cams]).argmin(1)  # nearest training camera of every held-out camera
+        lut = torch.zeros(n_cams, dtype=torch.int64, device=dev)
+        lut[held] = train_cams[near]
+        hemb = lut[hcam.long()].to(torch.int32)
     # ray-march fineness for the sample budget, held (UpdateRayMarch anneals 16 -> 1 over 10,000 steps, PersSampler.cpp:958-967)
     lo, hi = 0.5, 64.0
+    fo, fd = eo[:n_rays].contiguous(), ed[:n_rays].contiguous()
     for _ in range(14):
         fin = (lo * hi) ** 0.5
-        mean = hp.sample(pool[0][0], pool[0][1], ops.sampler_noise(n_rays, fin, train=False, device=dev))["pts_offsets"][-1].item() / n_rays
+        mean = hp.sample(fo, fd, ops.sampler_noise(n_rays, fin, train=False, device=dev))["pts_offsets"][-1].item() / n_rays
         if abs(mean - target_samples) / target_samples < 0.01:
             break
         lo, hi = (fin, hi) if mean > target_samples else (lo, fin)
     gen = torch.Generator(device=dev).manual_seed(seed + 11)
 
-    def evaluate(block):
+    def evaluate(block, rays=None, prec=None):
+        o_, d_, cam_, gt_ = (eo, ed, ecam, egt) if rays is None else rays
+        saved = hp.cfg.mlp_precision
+        if prec is not None and prec != saved:
+            hp.cfg.mlp_precision = prec
+            hp._x3_stale = True
         out = []
-        for a in range(0, eval_rays, n_rays):
+        for a in range(0, o_.shape[0], n_rays):
             sl = slice(a, a + n_rays)
             noise = ops.sampler_noise(n_rays, fin, train=False, device=dev)
-            out.append(hp.render(eo[sl].contiguous(), ed[sl].contiguous(), ecam[sl].contiguous(), noise, block=block)["rgb"])
-        return psnr(torch.cat(out), egt)
+            out.append(hp.render(o_[sl].contiguous(), d_[sl].contiguous(), cam_[sl].contiguous(), noise, block=block)["rgb"])
+        hp.cfg.mlp_precision = saved
+        img = torch.cat(out)
+        if rays is None and prec is None:  # how the error is spread over the rays: a few broken rays (holes) or the texture everywhere?
+            e = ((img - gt_) ** 2).mean(1).sort(descending=True).values
+            res["eval_sqerr_top1pct_share"] = float(e[: max(e.numel() // 100, 1)].sum() / e.sum().clamp(min=1e-30))
+        return psnr(img, gt_)
 
-    res = dict(precision=precision, fineness=fin, mean_samples_per_ray=mean, steps_global=steps_global, steps_focal=steps_focal)
+    res = dict(precision=precision, fineness=fin, mean_samples_per_ray=mean, steps_global=steps_global, steps_focal=steps_focal, seed=seed,
+               early_T=early_T, torch_adam=bool(torch_adam), fresh_rays=bool(fresh_rays), detail=detail)
+    adam = TorchAdam(hp) if torch_adam else None
+    cosines = []
     loss = None
     for stage, steps, lr0, block in (("global", steps_global, cfg.lr, None), ("focal", steps_focal, cfg.lr_block, 0)):
         for i in range(steps):
-            o, d, cam, gt = pool[i % n_pool]
-            mult = math.exp(math.log(1e-2) * i / max(steps, 1))  # lr_init -> lr_init / 100 over the stage
-            if stage == "global":
-                hp.cfg.lr = lr0 * mult
-            else:
-                hp.cfg.lr_block = lr0 * mult
+            b = batch(i)
+            mult = math.exp(math.log(lr_final) * i / max(steps, 1))  # lr_init -> lr_init * lr_final over the stage
             noise = ops.sampler_noise(n_rays, fin, train=True, generator=gen, device=dev)
             s3 = ops.s3im_index(n_rays, cfg.s3im_repeat_time, generator=gen, device=dev)
-            loss, _ = hp.train_step(o, d, cam, gt, noise, stage=stage, block=block, s3im_index=s3, update_oct=update_oct and stage == "global")
+            if cosine_every > 0 and (i + 1) % cosine_every == 0:
+                cosines.append((stage, i + 1, grad_cosine(hp, b, noise, s3, stage, block)))
+            oct_now = update_oct and stage == "global"
+            if adam is not None:
+                loss, _ = hp.forward_backward(*b, noise, stage=stage, block=block, s3im_index=s3, update_oct=oct_now)
+                adam.step([(name, lr * mult) for name, lr in hp.adam_groups(stage, block)])
+            else:
+                if stage == "global":
+                    hp.cfg.lr = lr0 * mult
+                else:
+                    hp.cfg.lr_block = lr0 * mult
+                loss, _ = hp.train_step(*b, noise, stage=stage, block=block, s3im_index=s3, update_oct=oct_now)
             if progress is not None and (i + 1) % 500 == 0:
                 progress(f"{precision} {stage} step {i + 1}/{steps} loss {float(loss):.4f}")
         if stage == "global":
@@ -123,42 +292,65 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
             res["leaves_pruned"] = int((hp.nodes.view(-1, 128)[:, 96:104].contiguous().view(torch.int64) < 0).sum().item())
         else:
             hp.cfg.lr_block = lr0
-    res["psnr"] = evaluate(0) if steps_focal > 0 else res["psnr_global"]
+    blk = 0 if steps_focal > 0 else None
+    res["psnr"] = evaluate(blk) if steps_focal > 0 else res["psnr_global"]
+    # the trained state under both decoder arithmetics (inference only): what the x3 split costs once training chaos is taken out
+    res["psnr_eval_x3"] = res["psnr"] if precision == "x3" else evaluate(blk, prec="x3")
+    res["psnr_eval_f32"] = res["psnr"] if precision == "f32" else evaluate(blk, prec="f32")
+    if held is not None:
+        res["psnr_heldout"] = evaluate(blk, rays=(ho, hd, hemb, hgt))
     res["loss"] = None if loss is None else float(loss)
-    n = None
-    comp, ctx = hp.forward_train(pool[0][0], pool[0][1], pool[0][2], ops.sampler_noise(n_rays, fin, train=False, device=dev), stage="focal" if steps_focal > 0 else "global",
-                                 block=0 if steps_focal > 0 else None)
+    if cosines:
+        res["grad_cosine"] = cosines
+    b0 = batch(0)
+    comp, ctx = hp.forward_train(b0[0], b0[1], b0[2], ops.sampler_noise(n_rays, fin, train=False, device=dev), stage="focal" if steps_focal > 0 else "global", block=blk)
     n = int(ctx["samples"]["pts_offsets"][-1].item())
     res["alive_sample_frac_trained"] = float((comp["weights"][:n] > 0).float().mean())
-    if hp._phase is not None:
+    if hp.last_forward == "lm2" and hp._phase is not None:
         res["planned_K_trained"] = int(hp._phase.k.item())
+    if keep_engine:
+        res["engine"], res["fineness"] = hp, fin
     return res
 
 
-def psnr_study(sc, seeds=(0, 1), precisions=("x3", "f32"), progress=None, **kw):
-    """train_and_eval per (decoder arithmetic, seed) -> dict(psnr_<p> = mean, psnr_<p>_runs = [...], psnr_<p>_std, delta_x3_minus_f32 = mean over
-    the seeds of PSNR(x3) - PSNR(f32), delta_runs, delta_sigma = the standard error of that mean)."""
-    out = dict(seeds=list(seeds), workload="procedural terrain seen by the synthetic capture's cameras (gfnerf_amd.procedural); PSNR on 16,384 held-out rays")
+def _paired(a, b):
+    """Mean, standard error and runs of the paired differences a[i] - b[i]."""
+    dl = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    se = float(dl.std(ddof=1) / math.sqrt(len(dl))) if len(dl) > 1 else None
+    return float(dl.mean()), se, [round(float(v), 3) for v in dl]
+
+
+def psnr_study(sc, seeds=(0, 1), legs=("fast", "reference"), progress=None, precisions=None, **kw):
+    """train_and_eval per (leg of LEGS, seed), paired by seed (the same initialisation, training rays, random draws and held-out rays for
+    every leg) -> dict(psnr_<leg> = mean, psnr_<leg>_runs, psnr_<leg>_std; delta / se / n_seeds = mean, standard error and count of the paired
+    differences PSNR(legs[0]) - PSNR(legs[1]); decoder_delta / decoder_se = the same trained states (legs[0]'s) rendered with the x3 and with the
+    exact-f32 decoder, inference only)."""
+    if precisions is not None:  # rounds 2-3 spelling: ("x3", "f32")
+        legs = tuple(precisions)
+    out = dict(seeds=list(seeds), legs=list(legs), workload="procedural terrain seen by the synthetic capture's cameras (gfnerf_amd.procedural); PSNR on "
+               f"{kw.get('eval_rays', 16384):,} held-out rays, one fixed set for every seed and leg; fresh training rays every step")
     runs = {}
-    for p in precisions:
-        runs[p] = []
+    for leg in legs:
+        runs[leg] = []
         for sd in seeds:
-            r = train_and_eval(sc, precision=p, seed=sd, **kw)
-            runs[p].append(r)
+            r = train_and_eval(sc, seed=sd, **{**kw, **LEGS[leg]})
+            runs[leg].append(r)
             if progress is not None:
-                progress(f"psnr {p} seed {sd}: global {r['psnr_global']:.3f} final {r['psnr']:.3f}")
-        vals = np.array([r["psnr"] for r in runs[p]])
-        out[f"psnr_{p}"] = float(vals.mean())
-        out[f"psnr_{p}_runs"] = [round(float(v), 3) for v in vals]
-        out[f"psnr_{p}_std"] = float(vals.std(ddof=1)) if len(vals) > 1 else None
-        out[f"psnr_global_{p}"] = float(np.mean([r["psnr_global"] for r in runs[p]]))
-    r0 = runs[precisions[0]][0]
-    out.update(steps=[r0["steps_global"], r0["steps_focal"]], mean_samples_per_ray=r0["mean_samples_per_ray"],
+                progress(f"psnr {leg} seed {sd}: global {r['psnr_global']:.3f} final {r['psnr']:.3f} (same state: x3 {r['psnr_eval_x3']:.3f} f32 {r['psnr_eval_f32']:.3f})")
+        vals = np.array([r["psnr"] for r in runs[leg]])
+        out[f"psnr_{leg}"] = float(vals.mean())
+        out[f"psnr_{leg}_runs"] = [round(float(v), 3) for v in vals]
+        out[f"psnr_{leg}_std"] = float(vals.std(ddof=1)) if len(vals) > 1 else None
+        out[f"psnr_global_{leg}"] = float(np.mean([r["psnr_global"] for r in runs[leg]]))
+        if "psnr_heldout" in runs[leg][0]:
+            out[f"psnr_heldout_{leg}"] = float(np.mean([r["psnr_heldout"] for r in runs[leg]]))
+    r0 = runs[legs[0]][0]
+    out.update(steps=[r0["steps_global"], r0["steps_focal"]], mean_samples_per_ray=r0["mean_samples_per_ray"], n_seeds=len(seeds),
                alive_sample_frac_trained=r0.get("alive_sample_frac_trained"), planned_K_trained=r0.get("planned_K_trained"))
-    if "x3" in runs and "f32" in runs:  # paired by seed: the same initialisation, batches and random draws for both decoders
-        dl = np.array([a["psnr"] - b["psnr"] for a, b in zip(runs["x3"], runs["f32"])])
-        out["delta_x3_minus_f32"] = float(dl.mean())
-        out["delta_runs"] = [round(float(v), 3) for v in dl]
-        if len(seeds) > 1:
-            out["delta_sigma"] = float(dl.std(ddof=1) / math.sqrt(len(dl)))  # standard error of the mean paired difference
+    if len(legs) > 1:
+        out["delta"], out["se"], out["delta_runs"] = _paired([r["psnr"] for r in runs[legs[0]]], [r["psnr"] for r in runs[legs[1]]])
+        out["delta_of"] = f"PSNR({legs[0]}) - PSNR({legs[1]}), paired by seed"
+    first = runs[legs[0]]
+    out["decoder_delta"], out["decoder_se"], out["decoder_delta_runs"] = _paired([r["psnr_eval_x3"] for r in first], [r["psnr_eval_f32"] for r in first])
+    out["decoder_delta_of"] = f"the states trained by the '{legs[0]}' leg rendered with the x3 decoder - with the exact-f32 decoder (inference only)"
     return out

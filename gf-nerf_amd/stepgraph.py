@@ -41,8 +41,8 @@ class StepGraph:
         sample" (an empty scene: nothing terminates).  At capture the plan is read back once (a forward of the batch at hand, no
         training step) and the step is captured WITHOUT the phase machinery when it says so; after this many replays the step is
         captured again, so that the choice follows the scene as it fills."""
-        self.segmented = (hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL) if segmented is None else bool(segmented)
-        if hp.sync.world > 1 and stage == hp_mod.STAGE_GLOBAL and not self.segmented:
+        self.segmented = (hp.sync.exchanges and stage == hp_mod.STAGE_GLOBAL) if segmented is None else bool(segmented)
+        if hp.sync.exchanges and stage == hp_mod.STAGE_GLOBAL and not self.segmented:
             raise _lib.GfnError("StepGraph: the data-parallel global step exchanges gradients with collectives; capture it segmented")
         self.hp, self.stage, self.R = hp, stage, int(n_rays)
         self.blocks = list(block) if isinstance(block, (list, tuple)) else [block]
@@ -140,33 +140,41 @@ class StepGraph:
             hp._adam_state(name, self._param_of(name))
         hp.tree_depth()  # (synchronises when the tree is new: not under capture)
         self._refresh_hyper(advance=False)
-        # does a termination-aware split pay on this scene right now?  Plan it from the batch at hand (forward only), read the plan back
-        hp.phase_override = None
-        self.phased = None
-        if hp.cfg.two_phase and hp.cfg.early_T > 0:
-            j0 = self.p
-            stale = hp._x3_stale  # (the forward repacks stale decoder weight images: the captured step must still do that itself)
-            hp.forward_train(None, None, self.cam, None, stage=self.stage, block=self.blocks[j0 % len(self.blocks)], want_depth=False, samples=self.S[j0 % 2])
-            hp._x3_stale = stale
-            if hp.last_forward == "lm2":
-                self.phased = int(hp._phase.k.item()) < 1024
-                hp.phase_override = None if self.phased else False
-        self._since_capture, self._idle = 0, 0
-        self._k_host.fill_(-1)
-        hp._join_aux()  # (a branch left open by an eager forward must not be joined under capture)
-        torch.cuda.synchronize()
-        steps_before, ticks_before = hp.step, dict(hp._adam_t)
-        pool = None
-        for j in range(self.cycle):
-            if self.segmented:
-                self.G[j], pool = self._capture_segments(j, pool)
-                continue
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):  # (a communicator's watchdog thread may poll events meanwhile)
-                self.loss[j], self.aux[j] = self._step_eager_or_captured(j)
-            pool = g.pool()
-            self.G[j] = g
-        hp.step, hp._adam_t = steps_before, ticks_before  # capturing executes nothing: the counters must not move
+        # does a termination-aware split pay on this scene right now?  Plan it from the batch at hand (forward only), read the plan back.
+        # The verdict ("one phase") is this capture's business only: hp.phase_override is set around the capture and put back, so that
+        # other users of the engine (an eager forward_train, the plugin's forward_train_graphed, procedural.train_and_eval) keep the
+        # termination-aware forward; the replays have it baked in.
+        outer_override = hp.phase_override
+        try:
+            hp.phase_override = None
+            self.phased = None
+            if hp.cfg.two_phase and hp.cfg.early_T > 0:
+                j0 = self.p
+                stale = hp._x3_stale  # (the forward repacks stale decoder weight images: the captured step must still do that itself)
+                hp.forward_train(None, None, self.cam, None, stage=self.stage, block=self.blocks[j0 % len(self.blocks)], want_depth=False, samples=self.S[j0 % 2],
+                                 all_alphas=self.update_oct)  # (the forward the captured step will run)
+                hp._x3_stale = stale
+                if hp.last_forward == "lm2":
+                    self.phased = int(hp._phase.k.item()) < 1024
+                    hp.phase_override = None if self.phased else False
+            self._since_capture, self._idle = 0, 0
+            self._k_host.fill_(-1)
+            hp._join_aux()  # (a branch left open by an eager forward must not be joined under capture)
+            torch.cuda.synchronize()
+            steps_before, ticks_before = hp.step, dict(hp._adam_t)
+            pool = None
+            for j in range(self.cycle):
+                if self.segmented:
+                    self.G[j], pool = self._capture_segments(j, pool)
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):  # (a communicator's watchdog thread may poll events meanwhile)
+                    self.loss[j], self.aux[j] = self._step_eager_or_captured(j)
+                pool = g.pool()
+                self.G[j] = g
+            hp.step, hp._adam_t = steps_before, ticks_before  # capturing executes nothing: the counters must not move
+        finally:
+            hp.phase_override = outer_override
         self._tree = (hp.nodes.data_ptr(), hp.n_nodes)
 
     def _capture_segments(self, j, pool):
@@ -259,7 +267,9 @@ class StepGraph:
         self._since_capture += 1
         if self.phased:  # captured with the phase machinery: still worth it?  (the plan of a few replays ago, read without waiting)
             self._idle = self._idle + 1 if int(self._k_host[0]) >= 1024 else 0
-        if hp.cfg.two_phase and (self._since_capture > self.replan_every or self._idle >= 16):
+        # (self.phased is None: the phased forward cannot apply here -- early_T = 0, or not the level-major forward -- and a re-capture
+        # would cost a full synchronisation and capture for the same graph)
+        if self.phased is not None and hp.cfg.two_phase and hp.cfg.early_T > 0 and (self._since_capture > self.replan_every or self._idle >= 16):
             self.invalidate()  # plan the phases (and choose the forward kernels) again: the scene has moved on
         if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
             self.capture()

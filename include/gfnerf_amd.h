@@ -44,6 +44,14 @@ typedef enum {
   GFN_ERR_NO_DEVICE = -3 /* no gfx950 device visible */
 } gfn_status;
 
+/* ABI revision of this header: bumped whenever an exported signature changes, is added or removed.  gfn_version() returns
+ * the revision the loaded library was built from; a binding written for another revision must refuse to call it (the
+ * ctypes loader gf-nerf_amd/_lib.py does: arguments of a changed signature would otherwise shift silently).
+ *   100: rounds 1-2.   101: round 3 (gfn_adam_step_ex / gfn_fused_forward / gfn_fused_render lost an int, gfn_hash_fwd_lm /
+ *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
+ *   102: round 4. */
+#define GFN_ABI_VERSION 102
+
 const char* gfn_last_error(void);
 int gfn_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only host). */

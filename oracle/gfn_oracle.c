@@ -209,13 +209,17 @@ void gfn_o_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const floa
 
 void gfn_o_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const float* pts,
                     const int64_t* anchors, const float* grad_out, int64_t n_pts, int64_t n_volumes,
-                    int log2_T, float* grad_pool) {
+                    int log2_T, float* grad_pool, int threads) {
   float scales[GFN_N_LEVELS];
   gfn_o_level_scales(scales);
   const uint32_t T = 1u << log2_T;
   const uint32_t local_size = (T >> 4) << 4;
   const int64_t pool_elems = (int64_t)GFN_N_LEVELS * T * 2;
   double* acc = (double*)calloc((size_t)pool_elems, sizeof(double));
+  threads = use_threads(threads);
+  /* Every addend is an f16 value (a multiple of 2^-24 below 2^16): their sum in double is EXACT whatever the order, so the
+   * points may be scattered by any number of threads (atomic adds) and the pool is the same bits as the serial loop's. */
+#pragma omp parallel for num_threads(threads) schedule(static)
   for (int64_t i = 0; i < n_pts; i++) {
     int64_t vol = anchors[i];
     for (int l = 0; l < GFN_N_LEVELS; l++) {
@@ -231,12 +235,15 @@ void gfn_o_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const floa
           float c0 = gfn_o_f16_to_f32(gfn_o_f32_to_f16(g0 * c.w[d]));
           float c1 = gfn_o_f16_to_f32(gfn_o_f32_to_f16(g1 * c.w[d]));
           int64_t e = (int64_t)l * T + (int64_t)c.pos[d] * 2; /* :109 + :151 */
+#pragma omp atomic
           acc[e] += (double)c0;
+#pragma omp atomic
           acc[e + 1] += (double)c1;
         }
       }
     }
   }
+#pragma omp parallel for num_threads(threads) schedule(static)
   for (int64_t e = 0; e < pool_elems; e++) grad_pool[e] = (float)(acc[e] / 128.0); /* :238 */
   free(acc);
 }
@@ -541,38 +548,57 @@ void gfn_o_linear_fwd(const float* x, const float* W, const float* b, int64_t n,
 }
 
 void gfn_o_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int64_t n,
-                      int in_dim, int out_dim, int act, float* dx, float* dW, float* db) {
-  double* aW = (double*)calloc((size_t)in_dim * out_dim, sizeof(double));
-  double* ab = (double*)calloc((size_t)out_dim, sizeof(double));
-  float* dz = (float*)malloc(sizeof(float) * (size_t)out_dim);
-  for (int64_t i = 0; i < n; i++) {
-    for (int o = 0; o < out_dim; o++) {
-      float g = dy[i * out_dim + o];
-      float yo = y[i * out_dim + o];
-      if (act == 1) g = yo > 0.f ? g : 0.f;
-      else if (act == 2) g = g * yo * (1.f - yo);
-      dz[o] = g;
-      ab[o] += g;
-      for (int k = 0; k < in_dim; k++) aW[(int64_t)o * in_dim + k] += (double)g * x[i * in_dim + k];
-    }
-    if (dx) {
-      for (int k = 0; k < in_dim; k++) {
-        float acc = 0.f;
-        for (int o = 0; o < out_dim; o++) acc += dz[o] * W[(int64_t)o * in_dim + k];
-        dx[i * in_dim + k] = acc;
+                      int in_dim, int out_dim, int act, float* dx, float* dW, float* db, int threads) {
+  /* threads == 1: one pass in sample order (the form the parity tests were pinned with).  More: every thread owns a contiguous
+   * run of samples and its own double accumulators, added up in thread order at the end (deterministic for a thread count). */
+  threads = use_threads(threads);
+  if (threads > n) threads = n > 0 ? (int)n : 1;
+  const size_t nW = (size_t)in_dim * out_dim;
+  double* aW = (double*)calloc(nW * (size_t)threads, sizeof(double));
+  double* ab = (double*)calloc((size_t)out_dim * (size_t)threads, sizeof(double));
+#pragma omp parallel num_threads(threads)
+  {
+    const int tid = omp_get_thread_num();
+    const int64_t lo = n * tid / threads, hi = n * (tid + 1) / threads;
+    double* tW = aW + nW * (size_t)tid;
+    double* tb = ab + (size_t)out_dim * (size_t)tid;
+    float* dz = (float*)malloc(sizeof(float) * (size_t)out_dim);
+    for (int64_t i = lo; i < hi; i++) {
+      for (int o = 0; o < out_dim; o++) {
+        float g = dy[i * out_dim + o];
+        float yo = y[i * out_dim + o];
+        if (act == 1) g = yo > 0.f ? g : 0.f;
+        else if (act == 2) g = g * yo * (1.f - yo);
+        dz[o] = g;
+        tb[o] += g;
+        for (int k = 0; k < in_dim; k++) tW[(int64_t)o * in_dim + k] += (double)g * x[i * in_dim + k];
+      }
+      if (dx) {
+        for (int k = 0; k < in_dim; k++) {
+          float acc = 0.f;
+          for (int o = 0; o < out_dim; o++) acc += dz[o] * W[(int64_t)o * in_dim + k];
+          dx[i * in_dim + k] = acc;
+        }
       }
     }
+    free(dz);
   }
-  if (dW) for (int64_t e = 0; e < (int64_t)in_dim * out_dim; e++) dW[e] = (float)aW[e];
+  for (int t = 1; t < threads; t++) {
+    for (size_t e = 0; e < nW; e++) aW[e] += aW[nW * (size_t)t + e];
+    for (int o = 0; o < out_dim; o++) ab[o] += ab[(size_t)out_dim * (size_t)t + o];
+  }
+  if (dW) for (int64_t e = 0; e < (int64_t)nW; e++) dW[e] = (float)aW[e];
   if (db) for (int o = 0; o < out_dim; o++) db[o] = (float)ab[o];
-  free(aW); free(ab); free(dz);
+  free(aW); free(ab);
 }
 
 /* a11 activations.py:24-42 + nerfacto_field.py:499  sigma = trunc_exp(h0 + 1) */
 void gfn_o_density_fwd(const float* h, int64_t n, int stride, float* sigma) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) sigma[i] = expf(h[i * stride] + 1.0f);
 }
 void gfn_o_density_bwd(const float* h, const float* dsigma, int64_t n, int stride, float* dh0) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
     float x = h[i * stride] + 1.0f;
     x = x < -15.f ? -15.f : (x > 15.f ? 15.f : x);
@@ -647,7 +673,9 @@ void gfn_o_depth_finalize(float* depth, const int64_t* offsets, int64_t n_rays, 
  *   dw_i/dsigma_i = dt_i T_{i+1};  dw_k/dsigma_i = -dt_i w_k (k > i). */
 void gfn_o_composite_bwd(const int64_t* offsets, int64_t n_rays, const float* sigma,
                          const float* dt, const float* rgb, const float* g_rgb,
-                         const float* g_acc, float* d_sigma, float* d_rgb) {
+                         const float* g_acc, float* d_sigma, float* d_rgb, int threads) {
+  threads = use_threads(threads);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16) /* rays are independent: the same bits for any thread count */
   for (int64_t r = 0; r < n_rays; r++) {
     int64_t s = offsets[r], e = offsets[r + 1];
     int64_t n = e - s;

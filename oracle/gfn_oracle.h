@@ -79,7 +79,7 @@ void gfn_o_hash_fwd(const float* feat_pool, const int32_t* prim_pool, const floa
  * (g*128 -> f16, g16*w -> f16) but SUMMED in double, then /128. */
 void gfn_o_hash_bwd(const int32_t* prim_pool, const float* bias_pool, const float* pts,
                     const int64_t* anchors, const float* grad_out, int64_t n_pts, int64_t n_volumes,
-                    int log2_T, float* grad_pool);
+                    int log2_T, float* grad_pool, int threads);
 
 /* ---- a2: K3 ray/octree traversal (PersSampler_cuda.cu:21-152) ---------- */
 /* Two-call protocol like the reference's two passes: call with hit_idx==NULL to
@@ -116,7 +116,7 @@ void gfn_o_linear_fwd(const float* x, const float* W, const float* b, int64_t n,
                       int out_dim, int act, float* y, int threads);
 /* given y (post-activation) and dy -> dx (may be NULL), dW, db (accumulated in double) */
 void gfn_o_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int64_t n,
-                      int in_dim, int out_dim, int act, float* dx, float* dW, float* db);
+                      int in_dim, int out_dim, int act, float* dx, float* dW, float* db, int threads);
 
 /* ---- a11 + a5: density activation  sigma = trunc_exp(h0 + 1) ------------- */
 void gfn_o_density_fwd(const float* h, int64_t n, int stride, float* sigma);
@@ -140,7 +140,7 @@ void gfn_o_depth_finalize(float* depth, const int64_t* offsets, int64_t n_rays, 
 /* backward of rgb/acc w.r.t. sigma and rgb. g_rgb [R,3], g_acc [R] (may be NULL) */
 void gfn_o_composite_bwd(const int64_t* offsets, int64_t n_rays, const float* sigma,
                          const float* dt, const float* rgb, const float* g_rgb,
-                         const float* g_acc, float* d_sigma, float* d_rgb);
+                         const float* g_acc, float* d_sigma, float* d_rgb, int threads);
 
 /* ---- a15: UpdateOctNodes K5/K6 (PersSampler_cuda.cu:518-665) ------------ */
 /* packed weights/alphas/oct_idx; stats i64 [n_nodes] updated in place; nodes'

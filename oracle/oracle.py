@@ -107,13 +107,14 @@ def hash_fwd(feat_pool, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, t
     return out
 
 
-def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T):
+def hash_bwd(prim_pool, bias_pool, pts, anchors, grad_out, n_volumes, log2_T, threads=0):
+    """threads: any number gives the same bits (the double sums of f16 addends are exact, gfn_oracle.c)."""
     bias_pool, pts, grad_out = _f32(bias_pool), _f32(pts), _f32(grad_out)
     prim_pool, anchors = _i32(prim_pool), _i64(anchors)
     n = pts.shape[0]
     grad_pool = np.zeros((16 * (1 << log2_T), 2), np.float32)
     lib().gfn_o_hash_bwd(_p(prim_pool), _p(bias_pool), _p(pts), _p(anchors), _p(grad_out), C.c_int64(n),
-                         C.c_int64(n_volumes), C.c_int(log2_T), _p(grad_pool))
+                         C.c_int64(n_volumes), C.c_int(log2_T), _p(grad_pool), C.c_int(threads))
     return grad_pool
 
 
@@ -196,7 +197,8 @@ def linear_fwd(x, W, b, act="none", threads=0):
     return y
 
 
-def linear_bwd(x, W, y, dy, act="none", need_dx=True):
+def linear_bwd(x, W, y, dy, act="none", need_dx=True, threads=1):
+    """threads = 1: the serial accumulation the parity tests are pinned with; 0 = all cores (per-thread double partial sums)."""
     x, W, y, dy = _f32(x), _f32(W), _f32(y), _f32(dy)
     n, k = x.shape
     o = W.shape[0]
@@ -204,7 +206,7 @@ def linear_bwd(x, W, y, dy, act="none", need_dx=True):
     dW = np.zeros((o, k), np.float32)
     db = np.zeros(o, np.float32)
     lib().gfn_o_linear_bwd(_p(x), _p(W), _p(y), _p(dy), C.c_int64(n), C.c_int(k), C.c_int(o), C.c_int(ACT[act]),
-                           _p(dx), _p(dW), _p(db))
+                           _p(dx), _p(dW), _p(db), C.c_int(threads))
     return dx, dW, db
 
 
@@ -243,14 +245,14 @@ def depth_finalize(depth_raw, offsets, t, scale_factor):
     return d
 
 
-def composite_bwd(offsets, sigma, dt, rgb, g_rgb, g_acc=None):
+def composite_bwd(offsets, sigma, dt, rgb, g_rgb, g_acc=None, threads=0):
     offsets, sigma, dt, rgb, g_rgb = _i64(offsets), _f32(sigma), _f32(dt), _f32(rgb), _f32(g_rgb)
     g_acc = None if g_acc is None else _f32(g_acc)
     N = max(sigma.shape[0], 1)
     d_sigma = np.zeros(N, np.float32)
     d_rgb = np.zeros((N, 3), np.float32)
     lib().gfn_o_composite_bwd(_p(offsets), C.c_int64(offsets.shape[0] - 1), _p(sigma), _p(dt), _p(rgb), _p(g_rgb),
-                              _p(g_acc), _p(d_sigma), _p(d_rgb))
+                              _p(g_acc), _p(d_sigma), _p(d_rgb), C.c_int(threads))
     n = sigma.shape[0]
     return d_sigma[:n], d_rgb[:n]
 

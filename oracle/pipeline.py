@@ -64,9 +64,11 @@ def render(P, rays_o, rays_d_raw, cam_idx, noise, log2_T, block=None, early_T=0.
 
 
 def loss_and_grads(P, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, log2_T, block=None, train_mlp=True, use_emb=True,
-                   s3im_index=None, s3im_mult=1.0, **sampler_kw):
+                   s3im_index=None, s3im_mult=1.0, bwd_threads=1, **sampler_kw):
     """Charbonnier loss (nerfacto.py:636) and every parameter gradient, by hand-written backward
-    of the same pieces (reference: autograd + Hash3DAnchoredFunction::backward)."""
+    of the same pieces (reference: autograd + Hash3DAnchoredFunction::backward).
+    bwd_threads: OpenMP threads of the decoder's backward (1: the serial sums the parity tests use; 0: all cores -- bench.py's
+    cpu_baseline); every other piece runs on all cores either way with thread-count-independent results."""
     m = sample(P, rays_o, rays_d_raw, noise, **sampler_kw)
     f = field_forward(P, m, cam_idx, log2_T, block, use_emb=use_emb)
     comp = O.composite_fwd(m["pts_offsets"], f["sigma"], m["dists"], m["ts"], f["rgb"])
@@ -78,9 +80,9 @@ def loss_and_grads(P, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, log2_T, block=
     d_sigma, d_rgb = O.composite_bwd(m["pts_offsets"], f["sigma"], m["dists"], f["rgb"], g_rgb, None)
     (bW0, _), (bW1, _), (hW0, _), (hW1, _), (hW2, _) = P["layers"]
     grads = {}
-    dc2, grads["hW2"], grads["hb2"] = O.linear_bwd(f["c2"], hW2, f["rgb"], d_rgb, "sigmoid")
-    dc1, grads["hW1"], grads["hb1"] = O.linear_bwd(f["c1"], hW1, f["c2"], dc2, "relu")
-    dxh, grads["hW0"], grads["hb0"] = O.linear_bwd(f["xh"], hW0, f["c1"], dc1, "relu")
+    dc2, grads["hW2"], grads["hb2"] = O.linear_bwd(f["c2"], hW2, f["rgb"], d_rgb, "sigmoid", threads=bwd_threads)
+    dc1, grads["hW1"], grads["hb1"] = O.linear_bwd(f["c1"], hW1, f["c2"], dc2, "relu", threads=bwd_threads)
+    dxh, grads["hW0"], grads["hb0"] = O.linear_bwd(f["xh"], hW0, f["c1"], dc1, "relu", threads=bwd_threads)
     dh = np.zeros_like(f["h"])
     dh[:, 0] = O.density_bwd(f["h"], d_sigma)
     dh[:, 1:16] = dxh[:, 16:31]
@@ -88,8 +90,8 @@ def loss_and_grads(P, rays_o, rays_d_raw, cam_idx, gt_rgb, noise, log2_T, block=
     if use_emb:
         np.add.at(demb, np.asarray(cam_idx)[m["ray_id"]], dxh[:, 31:63].astype(np.float64))
     grads["emb"] = demb.astype(np.float32)
-    da1, grads["bW1"], grads["bb1"] = O.linear_bwd(f["a1"], bW1, f["h"], dh, "none")
-    dfeat, grads["bW0"], grads["bb0"] = O.linear_bwd(f["feat"], bW0, f["a1"], da1, "relu")
+    da1, grads["bW1"], grads["bb1"] = O.linear_bwd(f["a1"], bW1, f["h"], dh, "none", threads=bwd_threads)
+    dfeat, grads["bW0"], grads["bb0"] = O.linear_bwd(f["feat"], bW0, f["a1"], da1, "relu", threads=bwd_threads)
     V = P["prim"].shape[1]
     # focal stage (block given): the gradient belongs to the block table and scatters through ITS primes
     gprim = P["prim"] if block is None else P.get("block_prims", [P["prim"]] * (block + 1))[block]

@@ -63,14 +63,31 @@ def parse(path):
     return mod
 
 
+BINDINGS = "gfnerf/bindings/hashanchored/bindings.cpp"
+
+
+def torchscript_classes(path):
+    """Names only: the TorchScript classes TORCH_LIBRARY(my_classes, ...) registers and the method names each `.def("name", ...)` exposes
+    (bindings.cpp:343-399) -> {class: [method names in order]}."""
+    import re
+
+    text = open(os.path.join(REF, path)).read()
+    text = re.sub(r"//[^\n]*", "", text[text.index("TORCH_LIBRARY("):])
+    out = {}
+    for m in re.finditer(r'm\.class_<\w+>\("(\w+)"\)(.*?);', text, re.S):
+        out[m.group(1)] = re.findall(r'\.def\("(\w+)"', m.group(2))
+    return out
+
+
 def main():
     assert os.path.isdir(REF), "reference tree not mounted; the signature file can only be regenerated in the build container"
     out = {p: parse(p) for p in FILES}
+    out[BINDINGS] = dict(torchscript_classes=torchscript_classes(BINDINGS))
     path = os.path.join(HERE, "api_signatures.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    n_cls = sum(len(m["classes"]) for m in out.values())
-    n_meth = sum(len(c["methods"]) for m in out.values() for c in m["classes"].values())
+    n_cls = sum(len(m.get("classes", {})) for m in out.values())
+    n_meth = sum(len(c["methods"]) for m in out.values() for c in m.get("classes", {}).values())
     print(f"wrote {path}: {len(out)} modules, {n_cls} classes, {n_meth} methods")
 
 

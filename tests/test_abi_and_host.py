@@ -27,7 +27,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), f"{n} declared in include/gfnerf_amd.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert handle.gfn_version() >= 100
+    # the library, the header and the binding agree on the ABI revision (a mismatch is refused at load time, see below)
+    header = open(os.path.join(ROOT, "include", "gfnerf_amd.h")).read()
+    abi = int(re.search(r"#define\s+GFN_ABI_VERSION\s+(\d+)", header).group(1))
+    assert handle.gfn_version() == abi == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_revision(monkeypatch):
+    """exported signatures changed while gfn_version() stood still.  Now the loader compares gfn_version() with the revision
+    _lib.py was written for and raises instead of calling through shifted arguments."""
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import _lib
+
+    _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    monkeypatch.setenv("GFN_NO_REBUILD", "1")
+    with pytest.raises(_lib.GfnError, match="ABI revision"):
+        _lib.lib()
 
 
 def test_no_cpu_fallback():

@@ -3,7 +3,9 @@ on one device; the collectives' meaning is the backend's contract, their use is 
   * test_two_rank_global_stage_replicas_stay_identical: HotPath.train_step under two ranks (tests/dp_worker.py);
   * test_bench_self_spawns_two_ranks: `python bench.py --gpus 2` started as the driver starts it, from a process that has
     no torchrun environment;
-  * test_reduce_shards_matches_torch: the local shard sum of the direct all-reduce against torch.
+  * test_reduce_shards_matches_torch: the local shard sum of the direct all-reduce against torch;
+  * test_rccl_world_one_runs_every_exchange_of_the_step: the same step on the REAL backend -- a one-rank "nccl" (= RCCL) group with the
+    world-1 shortcuts disabled (tests/rccl_worker.py): the first time the exchange code meets the communicator without an 8-GPU node.
 Child processes are started with subprocess (never exec'd over this process) and ended by their exact pids."""
 import json
 import os
@@ -66,6 +68,36 @@ def test_two_rank_global_stage_replicas_stay_identical(tmp_path, mode):
     assert res["graph_replicas_identical"] and res["graph_tree_equal_eager"] and res["graph_steps"] == [4, 4]
     assert res["graph_sync_stats"]["octree_max_reduces"] == 4 and res["graph_sync_stats"]["grad_reduces"] >= 8
     assert res["graph_table_far_frac"] < 1e-3 and res["graph_mlp_rel"] < 2e-2, (res["graph_table_far_frac"], res["graph_mlp_rel"])
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
+    """init_process_group("nccl", world_size=1) on the card; TrainSync(force_exchange=True): allreduce_mean_direct (all_to_all_single ->
+    gfn_reduce_shards -> all_gather_into_tensor), TrainSync.start_grads / finish_grads on the communication stream, reduce_octree_stats
+    (MAX) and the four-segment StepGraph with its three eager exchanges all run on RCCL.  One rank: the mean of one is the value, so the
+    result must be the single-process step bit for bit."""
+    port, out = str(_free_port()), str(tmp_path / "rccl.json")
+    worker = os.path.join(ROOT, "tests", "rccl_worker.py")
+    codes, outs = _run_ranks(lambda r: [sys.executable, worker, port, out], 1, timeout=420)
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    assert codes == [0] and res.get("ok"), (codes, res.get("error"), outs)
+    assert res["backend"] == "nccl" and res["allreduce_of_ones"] == [1.0] * 4
+    assert res["selfcheck"]["ok"] and res["selfcheck"]["n"] > 0 and res["selfcheck"]["max_abs_err"] == 0.0, res["selfcheck"]
+    assert res["direct_71MB_identity"]
+    # eager: three steps, every exchange through the communicator == the plain single-process run, bit for bit (as far as the plain run
+    # repeats itself: the control)
+    assert res["uses_direct"] and res["comm_stream_used"]
+    assert res["eager_sync_stats"] == dict(octree_max_reduces=3, grad_reduces=6, direct_reduces=3), res["eager_sync_stats"]
+    assert res["eager_forced_identical"] == res["eager_control_identical"], (res["eager_forced_identical"], res["eager_control_identical"], res["eager_forced_rel"])
+    assert all(res["eager_forced_identical"][i] for i in (0, 1, 4, 5, 6, 7)), res["eager_forced_identical"]  # tables and tree: deterministic kernels
+    assert max(res["eager_forced_rel"]) < 1e-5, res["eager_forced_rel"]
+    # segmented replay: four graphs, three eager RCCL exchanges, four replays
+    assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
+    assert res["graph_sync_stats"]["octree_max_reduces"] == 5 and res["graph_sync_stats"]["direct_reduces"] == 5, res["graph_sync_stats"]
+    assert res["graph_steps"] == [5, 5, 5] and res["finite"]
+    assert all(res["graph_forced_vs_segmented_identical"][i] for i in (0, 1, 4, 5, 6, 7)), (res["graph_forced_vs_segmented_identical"], res["graph_forced_vs_segmented_rel"])
+    assert max(res["graph_forced_vs_segmented_rel"]) < 1e-5, res["graph_forced_vs_segmented_rel"]
+    assert res["graph_forced_vs_onegraph_rel"][0] < 2e-2 and res["graph_forced_vs_onegraph_rel"][2] < 2e-2, res["graph_forced_vs_onegraph_rel"]
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")

@@ -21,6 +21,13 @@ def test_ground_truth_colours_match_the_oracle_composited_fixture():
     sigma, col = procedural.field(torch.from_numpy(g["xyz_probe"]))
     np.testing.assert_allclose(sigma.numpy(), g["sigma_probe"], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(col.numpy(), g["rgb_probe"], atol=2e-5)
+    # the detailed variant (fine colour texture: what the PSNR study trains on)
+    dt = float(g["detail"])
+    rgb_d = procedural.gt_colors(o, d, dt).numpy()
+    np.testing.assert_allclose(rgb_d, g["rgb_detail"], atol=3e-4)  # (f32 sines of arguments up to ~3,000: 2e-4 of phase)
+    _, col_d = procedural.field(torch.from_numpy(g["xyz_probe"]), dt)
+    np.testing.assert_allclose(col_d.numpy(), g["rgb_detail_probe"], atol=3e-4)
+    assert float(np.abs(rgb_d - rgb).mean()) > 0.02  # and it is a different picture
     # PSNR as torchmetrics defines it for data_range 1 (nerfacto.py:300): -10 log10(mse)
     a = torch.rand(100, 3)
     assert abs(procedural.psnr(a, a + 0.01) - 40.0) < 1e-3
