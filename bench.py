@@ -76,6 +76,13 @@ def parse():
                     help="torch.distributed backend at N > 1 (auto: RCCL whenever every rank has its own GPU -- a failure there is an error, "
                          "never a silent fall-back --, gloo only with --share-gpu; gloo: explicitly, for rehearsals)")
     ap.add_argument("--job-timeout", type=float, default=1500.0, help="N > 1, self-spawned ranks: seconds after which the ranks are killed and the exit code is 124")
+    ap.add_argument("--psnr-seeds", type=int, default=3,
+                    help="`psnr` sub-record: seeds per leg (the product's training leg against the reference-semantics leg, paired by seed); the many-seed "
+                         "record is profiles/r04_psnr_study.json (tools/psnr_study.py)")
+    ap.add_argument("--trained-seeds", type=str, default="0,1",
+                    help="`trained_state` sub-records (N = 1): engine seeds whose procedurally TRAINED state (global stage, then 4 focal blocks in rotation) the same "
+                         "steps are timed on; empty = none")
+    ap.add_argument("--trained-steps", type=int, default=100, help="timed steps of a trained-state record")
     ap.add_argument("--psnr-steps", type=str, default="2000,1000",
                     help="`psnr` sub-record (N = 1): global,focal training steps on the procedural scene per run, 2 seeds x {x3, f32 decoder}; "
                          "0,0 = skip")
@@ -519,15 +526,107 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
                 surface="GFNerfPipeline.get_train_loss_dict -> backward -> Optimizers.optimizer_step_all -> scheduler_step_all (trainer.py:382-441)")
 
 
+def psnr_study_record(steps_global, steps_focal):
+    """The many-seed PSNR record of the round (profiles/r04_psnr_study.json, written by tools/psnr_study.py on an MI355X): reported beside this run's few
+    seeds ONLY when it was made with the same protocol (gfnerf_amd.procedural.PROTOCOL, steps)."""
+    from gfnerf_amd import procedural
+
+    path = os.path.join(ROOT, "profiles", "r04_psnr_study.json")
+    try:
+        rec = json.load(open(path))
+        st = rec["psnr_study"]
+        if st["steps"] != [steps_global, steps_focal] or rec.get("protocol") != procedural.PROTOCOL:
+            return dict(study_note="profiles/r04_psnr_study.json was made with another protocol: not reported")
+        return dict(study_delta=st["delta"], study_se=st["se"], study_n_seeds=st["n_seeds"], study_decoder_delta=st["decoder_delta"],
+                    study_source="profiles/r04_psnr_study.json (tools/psnr_study.py; same protocol)")
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_focal):
+    """The headline step (and the global-stage step) timed on TRAINED engines: gfnerf_amd.procedural trains the global stage on the procedural terrain
+    (the PSNR study's scene and schedule), the global step is timed there (learning rate held at the schedule's end), then four focal blocks train in
+    rotation and the focal step is timed -- same StageRun / StepGraph / roofline code as the random-init records, batches = rays of the capture with
+    their ground-truth colours.  -> dict with one record per seed; value / ms_per_step = the SLOWEST seed's focal step (the number DESIGN.md leads with
+    when it is slower than the random-init headline)."""
+    from gfnerf_amd import procedural
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c2w = torch.from_numpy(sc["c2w"]).to(dev)
+    recs = []
+
+    def timed(hp, stage, seed):
+        gen = torch.Generator(device=dev).manual_seed(9000 + seed)
+        batches = []
+        for _ in range(4):
+            o, d, cam = procedural.device_rays(c2w, N_RAYS, gen)
+            batches.append((o, d, cam, procedural.gt_colors(o, d, procedural.STUDY_DETAIL)))
+        hp._drop_stale_samples()
+        run = StageRun(args, stage, sc, 1, 0, sync, torch, engine=dict(hp=hp, batches=batches))
+        res = run.run(args.trained_steps, 10)
+        roof, n_live, n_eval = run.roofline(res)
+        w = res["aux"]["comp"]["weights"][:n_live]
+        ms = res["elapsed"] / args.trained_steps * 1e3
+        hp._drop_stale_samples()
+        hp.phase_override = None
+        return dict(ms_per_step=ms, rays_per_sec=N_RAYS / (ms * 1e-3), mean_samples_per_ray=n_live / N_RAYS, alive_sample_frac=float((w > 0).float().mean().item()),
+                    evaluated_sample_frac=n_eval / max(n_live, 1), evaluated_samples_per_sec=n_eval / (ms * 1e-3), two_phase=run.phase, forward=hp.last_forward,
+                    launch=run.launch, fineness=run.fineness, loss=res["loss"],
+                    roofline={k: roof[k] for k in ("kernel", "launches_per_step", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "alg_bytes_per_launch", "kernel_ms")})
+
+    for sd in seeds:
+        rec = dict(seed=sd)
+
+        def after_global(hp, lr_end):
+            hp.cfg.lr = lr_end
+            rec["global"] = timed(hp, "global", sd)
+
+        r = procedural.train_and_eval(sc, seed=sd, steps_global=steps_global, steps_focal=steps_focal, log2_T=args.log2_T, detail=procedural.STUDY_DETAIL, n_blocks=4,
+                                      keep_engine=True, after_global=after_global, progress=None, **procedural.LEGS["fast"])
+        hp = r.pop("engine")
+        hp.cfg.lr_block = hp.cfg.lr_block * 1e-2  # the schedule's end
+        rec["focal"] = timed(hp, "focal", sd)
+        rec.update(psnr_global=r["psnr_global"], psnr=r["psnr"], leaves_pruned=r["leaves_pruned"], train_steps=[steps_global, steps_focal])
+        recs.append(rec)
+        del hp, r
+        torch.cuda.empty_cache()
+        print(f"[bench] trained state seed {sd}: focal {rec['focal']['ms_per_step']:.3f} ms (alive {rec['focal']['alive_sample_frac']:.2f}, evaluated "
+              f"{rec['focal']['evaluated_sample_frac']:.2f}), global {rec['global']['ms_per_step']:.3f} ms", file=sys.stderr)
+    slow = max(recs, key=lambda x: x["focal"]["ms_per_step"])
+    slow_g = max(recs, key=lambda x: x["global"]["ms_per_step"])
+    return dict(metric="train_rays_per_sec", unit="rays/s", value=slow["focal"]["rays_per_sec"], ms_per_step=slow["focal"]["ms_per_step"], seed=slow["seed"],
+                alive_sample_frac=slow["focal"]["alive_sample_frac"], evaluated_sample_frac=slow["focal"]["evaluated_sample_frac"],
+                two_phase_K=(slow["focal"]["two_phase"] or {}).get("K"), roofline_frac=slow["focal"]["roofline"]["frac"],
+                global_ms_per_step=slow_g["global"]["ms_per_step"], global_rays_per_sec=slow_g["global"]["rays_per_sec"],
+                workload="the headline step (4 focal blocks resident, 1 active / step, 4096 x 192) and the global step (4096 x 128) on engines TRAINED on the procedural "
+                         f"terrain ({steps_global} global + {steps_focal} focal steps, texture {procedural.STUDY_DETAIL}); headline keys = the slowest seed",
+                seeds=recs)
+
+
 # ------------------------------------------------------------------------------------------------ one timed training run
 class StageRun:
     """K timed training steps of one stage on this rank (the same code for the headline and the `global_stage` sub-record)."""
 
-    def __init__(self, args, stage, sc, world, rank, sync, torch, cams=None, n_blocks=0, block_seed=0):
+    def __init__(self, args, stage, sc, world, rank, sync, torch, cams=None, n_blocks=0, block_seed=0, engine=None):
+        """engine: dict(hp=HotPath, batches=[(o, d, cam, gt) device tensors] x 4) -- time the steps on an engine that exists already (the
+        `trained_state` sub-records: tables, decoder, embedding and pruned octree as gfnerf_amd.procedural left them) instead of a fresh
+        random-init one."""
         from gfnerf_amd import hotpath, ops, scene
 
         self.args, self.stage, self.world, self.rank, self.torch, self.scene = args, stage, world, rank, torch, scene
         self.ops = ops
+        self.trained = engine is not None
+        if engine is not None:
+            self.hp = hp = engine["hp"]
+            self.cfg, self.n_blocks = hp.cfg, (len(hp.blocks) if stage == "focal" else 0)
+            hp._record_buffers()
+            self.batches, self.batches_np = list(engine["batches"]), None
+            self.target = TARGET_SAMPLES[stage]
+            self.fineness, self.mean_samples = pick_fineness(hp, self.batches[0][0], self.batches[0][1], self.target, scene, torch)
+            self.draw_stream = torch.cuda.Stream()
+            self.drawn = {}
+            self.i = 0
+            return
         ga = args.lm_global_after
         self.cfg = cfg = hotpath.HotPathConfig(
             log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision,
@@ -708,6 +807,7 @@ class StageRun:
         if sg is not None:  # per-kernel event timings: eager steps right after the timed region
             hp._pre = None
             hp.timed_ops = events
+            hp.phase_override = False if sg.phased is False else None  # ... with the forward the replays ran (StepGraph keeps its verdict to itself)
             probe = max(self.args.probe_steps, 1)
             for _ in range(probe):
                 # the stream spins for a few ms first, so that every launch of the step is queued behind it: the events then
@@ -740,11 +840,12 @@ class StageRun:
         kern = {name: float(sum(a.elapsed_time(b) for a, b in ev)) / steps for name, ev in hp.timings.items()}
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k])
         kern_ms, alg_bytes = kern[dom], alg[dom]
-        kernel_name, launches = {"bwd_scatter": "field_bwd_dx_x3_kernel<planes, records>", "hash_fwd": "hash_fwd_kernel",
-                                 "hash_bwd": "hash_bwd_kernel"}.get(dom, dom + "_kernel"), 1
+        # the symbols as rocprofv3's kernel trace prints them (profiles/*_kernel_stats.csv)
+        kernel_name, launches = {"bwd_scatter": "field_bwd_dx_x3_kernel<true, 3>" if self.stage == "global" else "field_bwd_dx_x3_kernel<false, 3>",
+                                 "hash_fwd": "hash_fwd_kernel", "hash_bwd": "hash_bwd_kernel", "fused_fwd": "fused_fwd_kernel<0, true, true>"}.get(dom, dom + "_kernel"), 1
         lm = getattr(hp, "last_forward", "").startswith("lm") and dom == "hash_fwd"
         if lm:  # level-major lookup: one launch of lm_lookup_kernel per table inside the timed "hash_fwd" region
-            kernel_name, launches, dom = "lm_lookup_kernel", n_tables, "lm_lookup"
+            kernel_name, launches, dom = "lm_lookup_kernel<true, false> (+ <true, true>: the second table accumulates)" if n_tables == 2 else "lm_lookup_kernel<true, false>", n_tables, "lm_lookup"
             kern_ms = kern_ms / launches
             # the samples this launch looked up (all of them, or phase A's share: the first K of every ray)
             alg_bytes = (self.phase["phase_a_samples"] if self.phase else n_live) * 660
@@ -766,7 +867,7 @@ class StageRun:
             if not fresh("decoder"):
                 pmc = {k: v for k, v in pmc.items() if not k.startswith("mfma_busy") and not k.startswith("field_fwd") and not k.startswith("bwd_scatter")}
             # the PMC passes were taken on the default configuration only (own primes per table, early_T 1e-4, T = 2^21)
-            default_cfg = args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20) and not args.one_phase
+            default_cfg = args.early_T == 1e-4 and args.log2_T == 21 and args.n_side == pmc.get("n_side", 20) and not args.one_phase and not self.trained
             traffic = pmc.get(f"{dom}:{self.stage}") if default_cfg else None
             # the counter table holds the mean over ALL launches of an instantiation: phase A's and phase B's, which returned at once
             mix = 2 if (lm and self.phase) else 1
@@ -827,7 +928,7 @@ def compact_line(out):
     """The line the driver parses: the contract's keys, `config` (which the driver keeps whole) with the headline numbers of every
     sub-record hoisted into it, a short `roofline` and `cpu_baseline`.  < 2,000 characters."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "samples_per_sec", "ranks_seen")
+            "samples_per_sec", "batch_samples_per_sec", "ranks_seen")
     line = {k: _r(out[k], 6) for k in keep if k in out}
     c = out["config"]
     cfg = {k: _r(c[k]) for k in ("workload", "rays_per_batch", "mean_samples_per_ray", "log2_table_size", "n_cameras", "n_tree_nodes", "stage", "early_T",
@@ -857,7 +958,12 @@ def compact_line(out):
     hoist("plugin_step_focal", (("value", "plugin_rays_per_sec"), ("ms_per_step", "plugin_ms_per_step")))
     hoist("plugin_step_global", (("value", "plugin_global_rays_per_sec"), ("ms_per_step", "plugin_global_ms_per_step")))
     hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
-    hoist("psnr", (("psnr_x3", "psnr"), ("psnr_f32", "psnr_f32_decoder"), ("delta_sigma", "psnr_delta_sigma"), ("steps", "psnr_train_steps")))
+    hoist("psnr", (("psnr_fast", "psnr"), ("psnr_reference", "psnr_reference"), ("delta", "psnr_delta"), ("se", "psnr_se"), ("n_seeds", "psnr_n_seeds"),
+                   ("decoder_delta", "psnr_decoder_delta"), ("study_delta", "psnr_study_delta"), ("study_se", "psnr_study_se"), ("study_n_seeds", "psnr_study_n_seeds")))
+    hoist("trained_state", (("value", "trained_rays_per_sec"), ("ms_per_step", "trained_ms_per_step"), ("alive_sample_frac", "trained_alive_sample_frac"),
+                            ("evaluated_sample_frac", "trained_evaluated_sample_frac"), ("two_phase_K", "trained_two_phase_K"),
+                            ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step"),
+                            ("global_rays_per_sec", "trained_global_rays_per_sec")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
     for k in ("mfma_busy_frac", "mfma_tflops_issued"):
         if out["roofline"].get(k) is not None:
@@ -970,8 +1076,10 @@ def run_rank(args):
         w = res["aux"]["comp"]["weights"][:n_live]
         alive_frac = float((w > 0).float().mean().item()) if w is not None else None
         out = dict(metric="train_rays_per_sec", value=value, unit="rays/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   samples_per_sec=value * n_live / N_RAYS, ranks_seen=ranks_seen,
+                   ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32 (split-f16 x3 MFMA decoder, f16 table)" if cfg.mlp_precision == "x3" else "f32 (f16 table)", data="synthetic",
+                   samples_per_sec=value * n_eval / N_RAYS,  # the samples the forward looked up and decoded (the batch holds n_live: batch_samples_per_sec)
+                   batch_samples_per_sec=value * n_live / N_RAYS, ranks_seen=ranks_seen,
                    config=dict(workload=("GF-NeRF global+focal train step, 4 focal blocks resident (1 active/step), "
                                          if headline_stage == "focal" and world == 1 else
                                          "GF-NeRF focal stage, 1 block per GPU, rays from the block's camera cluster, " if headline_stage == "focal" else
@@ -1089,12 +1197,24 @@ def run_rank(args):
             torch.cuda.empty_cache()
     # ---- PSNR: the engine trained on a procedural scene, split-f16 decoder beside the exact-f32 one (the reference's arithmetic)
     pg, pf = (int(v) for v in args.psnr_steps.split(","))
-    if out is not None and world == 1 and pg + pf > 0:
+    # ---- the same steps on a TRAINED state: the random-init scene is a uniform fog in which 43 % of the samples lie behind their
+    # ray's termination point; a trained scene has surfaces and free space
+    trained_seeds = [int(v) for v in args.trained_seeds.split(",") if v.strip() != ""]
+    if out is not None and world == 1 and trained_seeds and pg > 0 and args.stage == "focal":
+        try:
+            out["trained_state"] = trained_state_records(sc, args, torch, sync, trained_seeds, pg, pf)
+        except Exception as e:  # noqa: BLE001
+            out["trained_state"] = dict(error=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
+    # ---- PSNR: the engine trained on the procedural scene by the product's leg and by the reference-semantics leg, paired by seed
+    if out is not None and world == 1 and pg + pf > 0 and args.psnr_seeds > 0:
         from gfnerf_amd import procedural
 
         try:
-            out["psnr"] = procedural.psnr_study(sc, steps_global=pg, steps_focal=pf, log2_T=args.log2_T,
-                                                progress=lambda m: print(f"[bench] {m}", file=sys.stderr))
+            ps = procedural.psnr_study(sc, seeds=tuple(range(args.psnr_seeds)), legs=("fast", "reference"), steps_global=pg, steps_focal=pf, log2_T=args.log2_T,
+                                       detail=procedural.STUDY_DETAIL, holdout_every=8, progress=lambda m: print(f"[bench] {m}", file=sys.stderr))
+            ps.update(psnr_study_record(pg, pf))
+            out["psnr"] = ps
         except Exception as e:  # noqa: BLE001
             out["psnr"] = dict(error=f"{type(e).__name__}: {e}")
         torch.cuda.empty_cache()

@@ -152,5 +152,21 @@ class GfnAdam(torch.optim.Optimizer):
 @dataclass
 class GfnAdamOptimizerConfig(AdamOptimizerConfig):
     """AdamOptimizerConfig (engine/optimizers.py:38-57) whose `_target` is GfnAdam: same fields (lr, eps, max_norm,
-    weight_decay), same `setup(params)`."""
+    weight_decay), same `setup(params)`.
+
+    Limits, refused rather than silently ignored: for engine-linked parameters the gradient stays in the engine's buffers and
+    `p.grad` is None, so `Optimizers.optimizer_scaler_step_all`'s `clip_grad_norm_` (engine/optimizers.py:131-136) would clip nothing:
+    `max_norm` must stay None (the gf-nerf method config's value, gfnerf/config.py:130).  For the same reason gradient accumulation over
+    several forwards is not supported (the engine zeroes its buffers in every training forward: `gradient_accumulation_steps` must be 1) and
+    neither is an enabled GradScaler (`mixed_precision` off: the HIP backward carries its own x128 / power-of-two loss scales)."""
     _target: Type = field(default_factory=lambda: GfnAdam)
+
+    def setup(self, params):
+        params = list(params)
+        if self.max_norm is not None and any(getattr(p, "_gfn_link", None) is not None for g in params
+                                             for p in (g["params"] if isinstance(g, dict) else [g])):
+            raise NotImplementedError(
+                "GfnAdamOptimizerConfig: max_norm is set, but engine-linked parameters (hash tables, decoder, appearance embedding) keep their "
+                "gradients in the engine's buffers (p.grad is None), so Optimizers' clip_grad_norm_ would silently clip nothing.  Leave max_norm = None "
+                "(gfnerf/config.py:130) or use torch.optim.Adam (AdamOptimizerConfig), which gets dense gradients.")
+        return super().setup(params)

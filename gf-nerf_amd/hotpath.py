@@ -77,6 +77,9 @@ class HotPathConfig:
     two_phase_min_saving: tuple = (0.12, 0.06)  # samples a split must save to be started / to be kept (break-even ~ 9 %: measured);
     two_phase_min_saving_planes: tuple = (0.30, 0.20)  # ... in the global stage: compacted samples write unaligned activation-plane rows
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
+    exact_oct_alphas: bool = True    # a training forward that UpdateOctNodes follows evaluates the density of EVERY sample, so that K5 reads true alphas
+                                     # behind the rays' termination points like the reference does (forward_train's all_alphas); False: rounds 2-3
+                                     # (alpha = 0 where the forward skipped a sample: a node's alpha statistic then decays whenever only occluded rays reach it)
 
 
 class HotPath:
@@ -594,7 +597,7 @@ class HotPath:
         # level-major lookup (own primes per table): three kernels beat the fused one because the gathers then hit L2
         # (with one table the fused kernel's early termination makes it a tie at first and a loss once the scene has density:
         # cfg.level_major_global / level_major_global_after)
-        all_alphas = bool(all_alphas) and c.early_T > 0
+        all_alphas = bool(all_alphas) and c.early_T > 0 and c.exact_oct_alphas
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after) or all_alphas
         lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
               and not c.keep_features)

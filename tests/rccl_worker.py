@@ -73,20 +73,35 @@ def main():
         s3 = ops.s3im_index(R, 10, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
 
         # ---- the eager data-parallel step: one process (shortcuts, no group) | the same again (control) | every exchange through RCCL
-        def eager_run(sync):
-            hp = fresh(sync)
+        def eager_run(sync, **kw):
+            hp = fresh(sync, **kw)
+            first = None
             for k in range(3):
                 nxt = batches[(k + 1) % 4]
                 hp.train_step(*batches[k], noise, stage="global", s3im_index=s3, prefetch=(nxt[0], nxt[1], noise) if k else None, update_oct=True)
+                if k == 0:
+                    first = [x.clone() for x in state(hp)]
             torch.cuda.synchronize()
-            return hp
+            return hp, first
 
-        plain, control = eager_run(gd.TrainSync(single=True)), eager_run(gd.TrainSync(single=True))
+        def far(a, b):  # fraction of table entries further apart than 2e-3 of the largest (a last-bit difference of a near-zero gradient is a
+            return float(((a.table - b.table).abs() > 2e-3 * float(b.table.abs().max())).float().mean())  # full Adam step at eps = 1e-15)
+
+        (plain, plain1), (control, control1) = eager_run(gd.TrainSync(single=True)), eager_run(gd.TrainSync(single=True))
         forced_sync = gd.TrainSync(force_exchange=True)
-        forced = eager_run(forced_sync)
+        forced, forced1 = eager_run(forced_sync)
+        res["eager_control_identical_step1"] = [bool(torch.equal(x, y)) for x, y in zip(plain1, control1)]
+        res["eager_forced_identical_step1"] = [bool(torch.equal(x, y)) for x, y in zip(plain1, forced1)]
         res["eager_control_identical"] = same(plain, control)
         res["eager_forced_identical"] = same(plain, forced)
         res["eager_forced_rel"] = close(plain, forced)
+        res["eager_control_rel"] = close(plain, control)
+        res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"] = far(plain, forced), far(plain, control)
+        # without the appearance embedding (its gradient is the step's only float-atomic sum): is the step then repeatable bit for bit?
+        (p2, _), (c2, _) = eager_run(gd.TrainSync(single=True), use_appearance_embedding=False), eager_run(gd.TrainSync(single=True), use_appearance_embedding=False)
+        f2, _ = eager_run(gd.TrainSync(force_exchange=True), use_appearance_embedding=False)
+        res["noemb_control_identical"], res["noemb_forced_identical"] = same(p2, c2), same(p2, f2)
+        del p2, c2, f2
         res["eager_sync_stats"] = dict(forced_sync.stats)
         res["uses_direct"] = bool(forced_sync._use_direct(forced._grad_live()))
         res["comm_stream_used"] = forced_sync._stream is not None

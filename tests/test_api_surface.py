@@ -181,6 +181,24 @@ def test_method_config_carries_the_reference_values(api):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_gfn_adam_config_refuses_what_it_cannot_honour():
+    """engine-linked parameters keep their gradients in the engine (p.grad is None), so Optimizers' clip_grad_norm_ would clip
+    nothing: GfnAdamOptimizerConfig.setup raises when max_norm is set for such parameters instead of skipping the clip silently."""
+    import torch
+
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd.gfnerf.optim import GfnAdam, GfnAdamOptimizerConfig
+
+    linked, plain = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
+    linked._gfn_link = ("emb", type("E", (), dict(fused_optimizers=set()))())
+    with pytest.raises(NotImplementedError, match="max_norm"):
+        GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15, max_norm=1.0).setup([linked])
+    with pytest.raises(NotImplementedError, match="max_norm"):
+        GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15, max_norm=1.0).setup([dict(params=[plain, linked])])
+    assert isinstance(GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15, max_norm=1.0).setup([plain]), GfnAdam)   # dense .grad: clipping works
+    assert isinstance(GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15).setup([linked]), GfnAdam)               # the shipped config: max_norm None
+
+
 def test_reference_registry_accepts_the_spec():
     """The reference's OWN registry code (nerfstudio/plugins/registry.py:34-51, with its isinstance check) run on this
     package's `gfnerf_config`, in a child interpreter where the reference's Nerfstudio tree is importable (third-party

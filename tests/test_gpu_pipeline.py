@@ -1107,23 +1107,83 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
     assert np.array_equal(two._phase.term.cpu().numpy(), term)  # the termination points do not depend on the split
 
 
-def test_psnr_of_the_split_f16_decoder_against_the_exact_f32_decoder():
-    """BASELINE.json: "PSNR vs ref ... within 0.1 dB".  The engine is trained on the procedural scene (gfnerf_amd.procedural; ground truth
-    pinned by tests/test_procedural.py) with the split-f16 x3 decoder and with the exact-f32 decoder -- the reference's arithmetic,
-    gfnerf/mlp.py:35-57 -- at reduced length (500 + 150 steps; the 1,600-camera scene needs its T = 2^21 slots), four seeds, the two
-    decoders paired by seed (same initialisation, batches, random draws).  PSNR scatters by +-2 dB from seed to seed, and training is
-    chaotic in the last bits (Adam's eps = 1e-15: gfnerf_amd/procedural.py), so the statement that can be tested is about the paired
-    differences: every pair within 0.6 dB at this length, their mean within 0.1 dB + three standard errors; and every run learns the
-    scene (PSNR > 18 dB on held-out rays from ~7 dB at the start; the 3,000-step runs of bench.py reach 35 dB)."""
+def test_octree_statistics_do_not_depend_on_the_cut(setup):
+    """with early termination (early_T = 1e-4) samples behind a ray's termination point are cut from the colour and the
+    backward -- but UpdateOctNodes (K5, PersSampler_cuda.cu:21-75) compares each visited node's largest ALPHA with its thresholds, and a dense
+    node that a batch only reaches behind its rays' cuts must still count as occupied, like in the reference (which has no cut).  A training
+    forward that K5 follows therefore evaluates every sample's density (HotPath.forward_train(all_alphas=True)): from the same state and
+    batches, node statistics, visit counts and the node blob (K6's invalidations) are the early_T = 0 ones bit for bit over repeated updates --
+    while the rounds 2-3 behaviour (alpha = 0 where the forward skipped the sample; HotPathConfig.exact_oct_alphas = False) is not."""
+    import torch
+
+    from gfnerf_amd import hotpath
+
+    S = setup
+    sc, t = S["sc"], S["t"]
+    batches = [tuple(t(a) for a in rays_for(sc, 384, seed=s)) for s in (3, 4, 5)]
+    noise = t(S["noise"])
+
+    def run(**kw):
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14, **kw), seed=1)
+        hp.table.mul_(100.0); hp.layers[1][0].mul_(4.0); hp.refresh_shadows()   # dense enough that rays terminate inside the volume
+        hp.weight_stats.fill_(3); hp.alpha_stats.fill_(3)                        # so that K6 prunes within a few updates (INIT_NODE_STAT is 1000)
+        alphas, kinds = [], []
+        for k in range(8):
+            o, d, cam = batches[k % 3]
+            comp, ctx = hp.forward_train(o, d, cam, noise, stage="global", all_alphas=True)
+            kinds.append(hp.last_forward)
+            n = int(ctx["samples"]["pts_offsets"][-1].item())
+            alphas.append((comp["alphas"][:n].clone(), comp["weights"][:n].clone()))
+            hp.update_oct_nodes(ctx)
+        return hp, alphas, kinds
+
+    cut, a_cut, k_cut = run(early_T=1e-4)
+    ref, a_ref, k_ref = run(early_T=0.0)
+    old, a_old, k_old = run(early_T=1e-4, exact_oct_alphas=False)
+    assert set(k_cut) == {"lm"} and set(k_old) == {"fused"}, (k_cut, k_old)  # every density evaluated | rays leave the fused kernel once opaque
+    behind = 0
+    for (a, w), (ar, wr) in zip(a_cut, a_ref):
+        assert a.shape == ar.shape and float((a - ar).abs().max()) <= 1e-6          # the true alpha of every sample
+        cutoff = (w == 0) & (wr > 0)
+        behind += int(cutoff.sum())
+        assert float(wr[cutoff].max() if cutoff.any() else 0.0) < 1e-4             # the weights the cut drops are below 1e-4 ...
+        assert float((w - wr)[~cutoff].abs().max()) <= 1e-6
+    assert behind > 1000                                                            # ... and there are many such samples in this scene
+    for name in ("weight_stats", "alpha_stats", "visit_cnt", "nodes"):
+        assert torch.equal(getattr(cut, name), getattr(ref, name)), name
+    pruned = int((ref.weight_stats < 0).sum() + (ref.alpha_stats < 0).sum())
+    assert pruned > 0                                                               # K6 did invalidate leaves on the way
+    assert not torch.equal(old.alpha_stats, ref.alpha_stats)                        # the test can tell: rounds 2-3 fed K5 alpha = 0 behind the cut
+
+
+def test_psnr_of_the_product_against_the_reference_semantics():
+    """BASELINE.json: "PSNR vs ref ... within 0.1 dB".  Three statements, tightest first (gfnerf_amd.procedural; ground truth pinned by
+    tests/test_procedural.py; the record over many seeds at full length is profiles/r04_psnr_study.json, made by tools/psnr_study.py):
+      1. the decoder arithmetic alone: every trained state rendered with the split-f16 x3 decoder and with the exact-f32 decoder (the
+         reference's nn.Linear, gfnerf/mlp.py:35-57) gives the same PSNR to 0.01 dB -- no training chaos involved;
+      2. along a training run the gradient of a batch computed with either decoder has cosine >= 0.9999 in every parameter group;
+      3. trained end to end (reduced length: 1,200 + 400 steps, four seeds), the product's leg ("fast") against the reference-semantics leg
+         ("reference": early_T = 0, every sample, exact-f32 decoder, f16 atomics, torch.optim.Adam; engine/trainer.py:382-441,
+         gfnerf/nerfacto.py:522-619,628-689), paired by seed: |mean difference| <= 0.1 dB + 2 standard errors.  One training run is one draw
+         (Adam at eps = 1e-15 amplifies last-bit differences), so the standard error of four pairs is what bounds this statement; the
+         many-seed record narrows it."""
     import torch
 
     import gfnerf_amd  # noqa: F401
     from gfnerf_amd import procedural, scene
 
     sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir=__import__("os").path.join(__import__("os").environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene"))
-    r = procedural.psnr_study(sc, seeds=(0, 1, 2, 3), steps_global=500, steps_focal=150, n_pool=64, eval_rays=8192)
-    print({k: v for k, v in r.items() if k.startswith("psnr") or k.startswith("delta")})
-    assert min(r["psnr_x3_runs"] + r["psnr_f32_runs"]) > 18.0, r
-    assert max(abs(v) for v in r["delta_runs"]) < 0.6 and r["delta_sigma"] < 0.25, r
-    assert abs(r["delta_x3_minus_f32"]) <= 3.0 * r["delta_sigma"] + 0.1, r
+    kw = dict(steps_global=1200, steps_focal=400, eval_rays=8192, detail=procedural.STUDY_DETAIL)
+    r = procedural.psnr_study(sc, seeds=(0, 1, 2, 3), legs=("fast", "reference"), **kw)
+    print({k: v for k, v in r.items() if k.startswith("psnr") or k.startswith("delta") or k.startswith("decoder") or k in ("se", "n_seeds")})
+    assert min(r["psnr_fast_runs"] + r["psnr_reference_runs"]) > 24.0, r                 # every run learns the scene (~7 dB at the start)
+    assert max(abs(v) for v in r["decoder_delta_runs"]) <= 0.01, r["decoder_delta_runs"]   # 1.
+    assert r["n_seeds"] == 4 and r["se"] is not None
+    assert abs(r["delta"]) <= 0.1 + 2.0 * r["se"], (r["delta"], r["se"], r["delta_runs"])  # 3.
+    c = procedural.train_and_eval(sc, seed=0, steps_global=400, steps_focal=200, eval_rays=4096, detail=procedural.STUDY_DETAIL, cosine_every=100,
+                                  **procedural.LEGS["fast"])["grad_cosine"]
+    assert len(c) == 6
+    for stage, step, groups in c:                                                           # 2.
+        for g, v in groups.items():
+            assert v["cos"] >= 0.9999, (stage, step, g, v)
     torch.cuda.empty_cache()
