@@ -83,9 +83,9 @@ def parse():
                     help="`trained_state` sub-records (N = 1): engine seeds whose procedurally TRAINED state (global stage, then 4 focal blocks in rotation) the same "
                          "steps are timed on; empty = none")
     ap.add_argument("--trained-steps", type=int, default=100, help="timed steps of a trained-state record")
-    ap.add_argument("--psnr-steps", type=str, default="2000,1000",
-                    help="`psnr` sub-record (N = 1): global,focal training steps on the procedural scene per run, 2 seeds x {x3, f32 decoder}; "
-                         "0,0 = skip")
+    ap.add_argument("--psnr-steps", type=str, default="3000,1000",
+                    help="`psnr` and `trained_state` sub-records (N = 1): global,focal training steps on the procedural scene per run "
+                         "(gfnerf_amd.procedural.STUDY_STEPS); 0,0 = skip")
     ap.add_argument("--plugin-steps", type=int, default=100,
                     help="timed iterations of the `plugin_step` sub-records (the step through GFNerfPipeline + Optimizers, N = 1 only); 0 = skip")
     ap.add_argument("--share-gpu", action="store_true",
@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--prefetch-cus", type=int, default=0, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=0,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
+    ap.add_argument("--render-eager", action="store_true", help="render tiles as eager launches, one tile at a time (counter collection: rocprofv3 --pmc serialises "
+                    "dispatches anyway and sees eager launches reliably); the kernels are the graph's")
     ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
     ap.add_argument("--render-patch-width", type=int, default=8,
                     help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
@@ -355,7 +357,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1)
                             .astype(np.float32)).cuda()
     hp.cfg.render_patch_width = int(args.render_patch_width)
-    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=True,
+    tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=not args.render_eager,
                            tile_width=args.render_tile_width if args.render_tile_rays else None, pipeline=args.render_pipeline or None,
                            decoder_cus=args.render_decoder_cus)
     mine = [f for f in range(len(cams)) if owners is None or owners[f] == rank]
@@ -379,8 +381,11 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     n_frames = len(cams)
     mpix = n_frames * H * W / 1e6
     acc = float(local[mine[-1]]["accumulation"].mean().item()) if mine else None
-    return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}",
-                ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=True,
+    roof = None
+    if world == 1 and mine:
+        roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
+    return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
+                ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,
                 kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep" % (args.render_patch_width, 32 // args.render_patch_width)
                         if args.render_patch_width > 0 and tr.patch_tw is not None else "fused_fwd_kernel: a wave per ray"),
@@ -388,6 +393,46 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
                 table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
                 routing=("single GPU" if world == 1 else f"{n_frames} frames routed to the rank owning each frame's block "
                          f"({len(mine)} on rank 0), images gathered on rank 0 inside the timed region"))
+
+
+def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, torch):
+    """What a frame's inference kernel evaluates, against the rates that bound it.  The samples in front of each ray's termination
+    point are counted by the wave-per-ray forward (HotPath.render without a tile width: it returns the weights) over the same frame's rays in raster
+    chunks; per such sample the kernel issues 16 levels x 8 corners gathers per table and 61,952 useful decoder FLOP (x 3 MFMAs issued).  Rates are
+    over the WHOLE frame time (samplers, copies and the 32 CUs left to the samplers included): lower bounds of what the kernel itself sustains;
+    its own duration and counters are profiles/r04_render_kernel_stats.csv / r04_pmc_render_per_kernel.csv."""
+    from gfnerf_amd import ops
+
+    rays = ops.generate_rays(c2w, intr, cam0=cam, first_pixel=0, width=W, n=H * W, want_extras=False)
+    O, D = rays["origins"], rays["directions"]
+    n_tables = 2 if block is not None else 1
+    chunk, n_eval, n_all = 65536, 0, 0
+    for a in range(0, H * W, chunk):
+        o, d = O[a:a + chunk].contiguous(), D[a:a + chunk].contiguous()
+        n = o.shape[0]
+        noise = torch.full((1024 + n + 10,), float(fineness), device="cuda")
+        out = hp.render(o, d, torch.full((n,), cam, dtype=torch.int32, device="cuda"), noise, block=block)
+        m = int(out["samples"]["pts_offsets"][-1].item())
+        n_all += m
+        n_eval += int((out["weights"][:m] > 0).sum().item())
+        del out
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    fresh = bool(pmc.get("source_sha256", {}).get("render")) and all(
+        _sha256(os.path.join(ROOT, "gf-nerf_amd", f)) == h for f, h in pmc["source_sha256"]["render"].items())
+    gathers = n_eval * 128.0 * n_tables
+    ceiling = pmc.get("l2_gather_ceiling_per_s")
+    tiles_per_frame = -(-H * W // tr.T)
+    return dict(evaluated_samples_per_frame=n_eval, sampled_per_frame=n_all, evaluated_frac=n_eval / max(n_all, 1),
+                samples_per_sec=n_eval / s_per_frame, gathers_per_sec=gathers / s_per_frame, gather_ceiling_per_s=ceiling,
+                gather_frac=(gathers / s_per_frame / ceiling) if ceiling else None,
+                mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_tflops_issued=3.0 * n_eval * 61952.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
+                mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
+                lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * tiles_per_frame)
+                                     if fresh and pmc.get("decoded_samples_per_launch:render") else None),  # useful samples / samples the lockstep patches decode
+                kernel="fused_render_patch_kernel<1, 2>" if block is not None else "fused_render_patch_kernel<0, 2>",
+                kernel_ms_per_tile=pmc.get("kernel_ms:render") if fresh else None,
+                note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 
 
 def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
@@ -581,10 +626,10 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
             hp.cfg.lr = lr_end
             rec["global"] = timed(hp, "global", sd)
 
-        r = procedural.train_and_eval(sc, seed=sd, steps_global=steps_global, steps_focal=steps_focal, log2_T=args.log2_T, detail=procedural.STUDY_DETAIL, n_blocks=4,
+        r = procedural.train_and_eval(sc, seed=sd, steps_global=steps_global, steps_focal=steps_focal, log2_T=args.log2_T, detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL, n_blocks=4,
                                       keep_engine=True, after_global=after_global, progress=None, **procedural.LEGS["fast"])
         hp = r.pop("engine")
-        hp.cfg.lr_block = hp.cfg.lr_block * 1e-2  # the schedule's end
+        hp.cfg.lr_block = hp.cfg.lr_block * procedural.STUDY_LR_FINAL  # the schedule's end
         rec["focal"] = timed(hp, "focal", sd)
         rec.update(psnr_global=r["psnr_global"], psnr=r["psnr"], leaves_pruned=r["leaves_pruned"], train_steps=[steps_global, steps_focal])
         recs.append(rec)
@@ -955,6 +1000,11 @@ def compact_line(out):
     hoist("global_stage", (("ms_per_step", "global_ms_per_step"), ("value", "global_rays_per_sec"), ("launch_short", "global_launch"),
                            ("replicas_bit_identical", "replicas_bit_identical")))
     hoist("render", (("value", "render_ms_per_mpix"),))
+    if isinstance(out.get("render"), dict) and isinstance(out["render"].get("roofline"), dict):
+        rr = out["render"]["roofline"]
+        cfg["render_samples_per_sec"] = _r(rr["samples_per_sec"])
+        if rr.get("mfma_busy_frac") is not None:
+            cfg["render_mfma_busy_frac"] = _r(rr["mfma_busy_frac"])
     hoist("plugin_step_focal", (("value", "plugin_rays_per_sec"), ("ms_per_step", "plugin_ms_per_step")))
     hoist("plugin_step_global", (("value", "plugin_global_rays_per_sec"), ("ms_per_step", "plugin_global_ms_per_step")))
     hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
@@ -1212,7 +1262,7 @@ def run_rank(args):
 
         try:
             ps = procedural.psnr_study(sc, seeds=tuple(range(args.psnr_seeds)), legs=("fast", "reference"), steps_global=pg, steps_focal=pf, log2_T=args.log2_T,
-                                       detail=procedural.STUDY_DETAIL, holdout_every=8, progress=lambda m: print(f"[bench] {m}", file=sys.stderr))
+                                       detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL, holdout_every=8, progress=lambda m: print(f"[bench] {m}", file=sys.stderr))
             ps.update(psnr_study_record(pg, pf))
             out["psnr"] = ps
         except Exception as e:  # noqa: BLE001

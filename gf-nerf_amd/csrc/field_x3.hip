@@ -367,75 +367,125 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = zl;
       }
     }
-    Frag g2[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      Acc2 a;
-      acc_init_zero(a);
-      mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
-      grad_tile_to_frag<true>(a, g2[it], m_c2, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZ2), BPL(lo, BP_DZ2), 128, s, 32 * it, g2[it], h);
-    }
-    // ---- d c1 = hW1^T dz2
-    Frag g1[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      Acc2 a;
-      acc_init_zero(a);
-#pragma unroll
-      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
-      grad_tile_to_frag<true>(a, g1[it], m_c1, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZ1), BPL(lo, BP_DZ1), 128, s, 32 * it, g1[it], h);
-    }
-    // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
-    u32x4 dh_h, dh_l;
-    {
-      Acc2 a;
-      acc_init_zero(a);
-#pragma unroll
-      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G1 + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
-      if (h == 0) v[0] = dh0 * sc;
-      split8(v, dh_h, dh_l);
-      if (PLANES && valid) store_half_tile(BPL(hi, BP_DH), BPL(lo, BP_DH), 16, s, 0, dh_h, dh_l, h);
-    }
-    if (PLANES && demb) {
-      // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
-      Acc2 a;
-      acc_init_zero(a);
-#pragma unroll
-      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_GE + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
-      const int ray = valid ? ray_id[q] : -1;
-      const int prev = __shfl_up(ray, 1, 32);
-      const bool head = (j == 0) || prev != ray;
-      const unsigned long long heads64 = __ballot(head);
-      const uint32_t heads = (uint32_t)(heads64 >> (32 * h));
-      const uint32_t later = (j == 31) ? 0u : (heads >> (j + 1));
-      const int run_end = later ? j + __builtin_ctz(later) : 31;
-      float* erow = (head && valid) ? demb + (int64_t)cam_idx[ray] * 32 : nullptr;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float v = half_run_sum(valid ? acc_get(a, r) : 0.f, j, run_end);
-        if (erow && v != 0.f) atomicAdd(erow + (r & 3) + 8 * (r >> 2) + 4 * h, v * inv);
-      }
-    }
-    // ---- d a1 = bW1^T dh
-    Frag ga[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      Acc2 a;
-      acc_init_zero(a);
-      mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
-      grad_tile_to_frag<true>(a, ga[it], m_a1, it);
-      if (PLANES && valid) store_tile(BPL(hi, BP_DZA1), BPL(lo, BP_DZA1), 128, s, 32 * it, ga[it], h);
-    }
-    // ---- d feat = bW0^T dz
     Acc2 gf;
-    acc_init_zero(gf);
+    if (!PLANES) {
+      // Focal stage: weight fragments are read one chunk ahead of their MFMAs (mma3p, x3_device.h), and the narrow products (d h, d feat) consume
+      // each 32-row tile of their input as soon as it exists -- the same k-steps in the same order, the same bits -- so that three tiles of
+      // fragments are never alive at once (what pays for the prefetch's registers).  The global stage's form (below) also keeps every tile for
+      // the planes and d appearance; it is bound by its plane stores, not by the matrix pipe, and stays as it was.
+      WFrag w = wfrag_load(Ihi, Ilo, D_G3, lane);
+      Frag g2[4];
 #pragma unroll
-    for (int u = 0; u < 8; u++) mma3(gf, Ihi, Ilo, D_GB0 + u, lane, ga[u >> 1].hi[u & 1], ga[u >> 1].lo[u & 1]);
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+        mma3p(a, w, Ihi, Ilo, it < 3 ? D_G3 + it + 1 : D_G2, lane, zh, zl);
+        grad_tile_to_frag<true>(a, g2[it], m_c2, it);
+      }
+      // ---- d c1 = hW1^T dz2, feeding d h: rows 1..15 = hW0[:, 16:31]^T dz1 (row 0 = d h0)
+      Acc2 adh;
+      acc_init_zero(adh);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+#pragma unroll
+        for (int u = 0; u < 8; u++) mma3p(a, w, Ihi, Ilo, u < 7 ? D_G2 + (u + 1) * 4 + it : D_G1 + 2 * it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
+        Frag g1;
+        grad_tile_to_frag<true>(a, g1, m_c1, it);
+        mma3p(adh, w, Ihi, Ilo, D_G1 + 2 * it + 1, lane, g1.hi[0], g1.lo[0]);
+        mma3p(adh, w, Ihi, Ilo, it < 3 ? D_G2 + it + 1 : D_GB1, lane, g1.hi[1], g1.lo[1]);
+      }
+      u32x4 dh_h, dh_l;
+      {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = acc_get(adh, r);
+        if (h == 0) v[0] = dh0 * sc;
+        split8(v, dh_h, dh_l);
+      }
+      // ---- d a1 = bW1^T dh, feeding d feat = bW0^T dz
+      acc_init_zero(gf);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+        mma3p(a, w, Ihi, Ilo, D_GB0 + 2 * it, lane, dh_h, dh_l);
+        Frag ga;
+        grad_tile_to_frag<true>(a, ga, m_a1, it);
+        mma3p(gf, w, Ihi, Ilo, D_GB0 + 2 * it + 1, lane, ga.hi[0], ga.lo[0]);
+        mma3p(gf, w, Ihi, Ilo, it < 3 ? D_GB1 + it + 1 : -1, lane, ga.hi[1], ga.lo[1]);
+      }
+    } else {
+      Frag g2[4];
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+        mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
+        grad_tile_to_frag<true>(a, g2[it], m_c2, it);
+        if (PLANES && valid) store_tile(BPL(hi, BP_DZ2), BPL(lo, BP_DZ2), 128, s, 32 * it, g2[it], h);
+      }
+      // ---- d c1 = hW1^T dz2
+      Frag g1[4];
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+#pragma unroll
+        for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
+        grad_tile_to_frag<true>(a, g1[it], m_c1, it);
+        if (PLANES && valid) store_tile(BPL(hi, BP_DZ1), BPL(lo, BP_DZ1), 128, s, 32 * it, g1[it], h);
+      }
+      // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
+      u32x4 dh_h, dh_l;
+      {
+        Acc2 a;
+        acc_init_zero(a);
+#pragma unroll
+        for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G1 + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
+        if (h == 0) v[0] = dh0 * sc;
+        split8(v, dh_h, dh_l);
+        if (PLANES && valid) store_half_tile(BPL(hi, BP_DH), BPL(lo, BP_DH), 16, s, 0, dh_h, dh_l, h);
+      }
+      if (PLANES && demb) {
+        // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
+        Acc2 a;
+        acc_init_zero(a);
+#pragma unroll
+        for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_GE + u, lane, g1[u >> 1].hi[u & 1], g1[u >> 1].lo[u & 1]);
+        const int ray = valid ? ray_id[q] : -1;
+        const int prev = __shfl_up(ray, 1, 32);
+        const bool head = (j == 0) || prev != ray;
+        const unsigned long long heads64 = __ballot(head);
+        const uint32_t heads = (uint32_t)(heads64 >> (32 * h));
+        const uint32_t later = (j == 31) ? 0u : (heads >> (j + 1));
+        const int run_end = later ? j + __builtin_ctz(later) : 31;
+        float* erow = (head && valid) ? demb + (int64_t)cam_idx[ray] * 32 : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = half_run_sum(valid ? acc_get(a, r) : 0.f, j, run_end);
+          if (erow && v != 0.f) atomicAdd(erow + (r & 3) + 8 * (r >> 2) + 4 * h, v * inv);
+        }
+      }
+      // ---- d a1 = bW1^T dh
+      Frag ga[4];
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        Acc2 a;
+        acc_init_zero(a);
+        mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
+        grad_tile_to_frag<true>(a, ga[it], m_a1, it);
+        if (PLANES && valid) store_tile(BPL(hi, BP_DZA1), BPL(lo, BP_DZA1), 128, s, 32 * it, ga[it], h);
+      }
+      // ---- d feat = bW0^T dz
+      acc_init_zero(gf);
+#pragma unroll
+      for (int u = 0; u < 8; u++) mma3(gf, Ihi, Ilo, D_GB0 + u, lane, ga[u >> 1].hi[u & 1], ga[u >> 1].lo[u & 1]);
+    }
     if (SCATTER) {
       // registers (2a, 2a+1) of the tile = channels (0, 1) of level 2h + (a & 1) + 4 (a >> 1) of sample j
       const uint32_t T = 1u << S.log2_T;

@@ -15,6 +15,8 @@
 // levels 8u + 4h + i/2) -- then runs decoder_tile (x3_device.h), then the lower half composites the 32 samples with a
 // wave scan.  Rays are handed out through an atomic counter (rays differ 100x in length).  Samples behind the
 // termination point get sigma = rgb = weight = alpha = 0 so that the unchanged backward kernels see no gradient there.
+#include <stdlib.h>
+
 #include "gfn_common.h"
 #include "hash_device.h"
 #include "x3_device.h"
@@ -60,19 +62,50 @@ constexpr int FUSED_THREADS_LEAN = 512;  // forms that keep nothing for a backwa
 template <bool SAVE>
 constexpr int fused_threads() { return SAVE ? FUSED_THREADS : FUSED_THREADS_LEAN; }
 
-// gather_level<true> with the level's base as a 32-bit pair index (same gathers, same left-to-right blend, same bits)
+// gather_level<true> with the level's base as a 32-bit pair index (same gathers, same left-to-right blend, same values).
+// Shaped for the instruction count (the inference kernel is bound by VALU issue, profiles/r04_pmc_render_per_kernel.csv):
+//  * the address is a 32-bit BYTE offset from the (uniform) table base: `global_load_dword v, v_off, s[base]` -- no 64-bit address arithmetic per gather;
+//  * w * float(f16) is ONE v_fma_mix_f32 reading the f16 half in place (w * f + 0: the product rounded once, exactly what v_cvt_f32_f16 + v_mul_f32
+//    give; only the sign of a zero product can differ, and zeros add and round alike) -- the compiler folds the builtin form back into cvt + mul;
+//  * both channels are added with one packed add.  Products and sums stay separately rounded, in the reference's order (Hash3DAnchored_cuda.cu:73-77).
 __device__ __forceinline__ float2 gather_pairs_u32(const half2_t* __restrict__ table, uint32_t slot0, const Corners& c) {
-  half2_t v[8];
-#pragma unroll
-  for (int d = 0; d < 8; d++) v[d] = table[slot0 + c.pos[d]];
-  float a0 = 0.f, a1 = 0.f;
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  uint32_t v[8];
 #pragma unroll
   for (int d = 0; d < 8; d++) {
-    const float t0 = c.w[d] * (float)v[d][0], t1 = c.w[d] * (float)v[d][1];
-    a0 = (d == 0) ? t0 : a0 + t0;
-    a1 = (d == 0) ? t1 : a1 + t1;
+    const uint32_t off = (slot0 + c.pos[d]) << 2;  // < 2^31: 17 T slots of 4 bytes, log2_T <= 26 checked by the host
+    v[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(table) + off);
   }
-  return make_float2(gfn_round_f16(a0), gfn_round_f16(a1));
+  f2 a;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    float t0, t1;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t0) : "v"(c.w[d]), "v"(v[d]));
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(t1) : "v"(c.w[d]), "v"(v[d]));
+    a = (d == 0) ? f2{t0, t1} : a + f2{t0, t1};
+  }
+  return make_float2(gfn_round_f16(a[0]), gfn_round_f16(a[1]));
+}
+
+// the same in two steps, for callers that keep several levels' gathers in flight before they blend any (fused_render_patch_kernel)
+__device__ __forceinline__ void gather_issue_u32(const half2_t* __restrict__ table, uint32_t slot0, const uint32_t (&pos)[8], uint32_t (&v)[8]) {
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const uint32_t off = (slot0 + pos[d]) << 2;
+    v[d] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(table) + off);
+  }
+}
+__device__ __forceinline__ float2 blend_pairs(const uint32_t (&v)[8], const float (&w)[8]) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  f2 a;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    float t0, t1;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(t0) : "v"(w[d]), "v"(v[d]));
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(t1) : "v"(w[d]), "v"(v[d]));
+    a = (d == 0) ? f2{t0, t1} : a + f2{t0, t1};
+  }
+  return make_float2(gfn_round_f16(a[0]), gfn_round_f16(a[1]));
 }
 
 // TAB: 0 one table, 1 two tables with their own primes (the focal stage: global + residual block table).
@@ -229,8 +262,9 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
 // tile_w > 0: the rays are a tile_w-wide block of pixels, row major, and a patch is patch_w x (32 / patch_w) pixels;
 // tile_w == 0: a patch is 32 consecutive rays.
 constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / prime offsets the kernel needs 254 registers, no spills
-
-template <int TAB>
+// RENDER_LEVELS: levels whose gathers (16 each with two tables) a lane keeps in flight together (2 or 4; GFN_RENDER_LEVELS in the environment
+// picks the instantiation -- measured: tools/README.md, round 4)
+template <int TAB, int RENDER_LEVELS>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -246,6 +280,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
   const int n_vol = (int)A.n_volumes;    // 16 * n_volumes * 3 < 2^31 (checked by the host)
   const int n_patches = A.n_rays / 32;  // the host guarantees whole patches
   const int patches_per_row = tile_w > 0 ? tile_w / patch_w : 1, patch_h = tile_w > 0 ? 32 / patch_w : 1;
+  const int pw_shift = 31 - __builtin_clz((unsigned)(patch_w > 0 ? patch_w : 1));  // patch_w divides 32: a power of two (checked by the host)
   // patches are handed out like fused_fwd_kernel's rays: 8 counters, a workgroup starts on the eighth of its XCD group
   const int seg_len = (n_patches + 7) / 8;
   int seg_k = 0, fetches = 0;
@@ -262,21 +297,26 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     idx = __shfl(idx, 0, 64);
     fetches++;
     if (seg_n <= 0 || idx >= seg_n) { seg_k++; continue; }  // wave-uniform
-    const int patch = seg_lo + idx;
-    const int ray = tile_w > 0 ? ((patch / patches_per_row) * patch_h + j / patch_w) * tile_w + (patch % patches_per_row) * patch_w + j % patch_w
-                               : patch * 32 + j;
+    const int patch = __builtin_amdgcn_readfirstlane(seg_lo + idx);  // wave-uniform: its row / column arithmetic stays on the scalar unit
+    const int prow = patch / patches_per_row, pcol = patch - prow * patches_per_row;
+    const int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
     const int s = A.pts_offsets[ray], cnt = A.pts_offsets[ray + 1] - s;
     int kmax = cnt;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
-    const float* sh_row = A.sh + (int64_t)ray * 16;
-    const float* emb_row = A.emb ? A.emb + (int64_t)A.cam_idx[ray] * 32 : nullptr;
+    const int cam = A.emb ? A.cam_idx[ray] : 0;
     float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
     bool done = false;
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
       if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
       const int64_t q = (int64_t)s + k;
+      // (rebuilt every sample from two 32-bit values the compiler cannot see through: as 64-bit pointers -- or their hoisted parts -- kept
+      // across the loops they were what spilled)
+      int ray_k = ray, cam_k = cam;
+      asm volatile("" : "+v"(ray_k), "+v"(cam_k));
+      const float* sh_row = A.sh + (int64_t)ray_k * 16;
+      const float* emb_row = A.emb ? A.emb + (int64_t)cam_k * 32 : nullptr;
       // ---- lookup: this lane's 8 levels of its ray's k-th sample (rays that have left gather nothing)
       u32x4 xh[2], xl[2];
       float x[2][8];
@@ -287,26 +327,55 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       if (act) {
         const float px = A.pts[3 * q], py = A.pts[3 * q + 1], pz = A.pts[3 * q + 2];
         const int vol = A.anchors[3 * q];
-        // 32-bit offsets throughout: the lane's 8 levels are per-lane values, and 64-bit per-level bases (table base, prime row)
-        // hoisted out of the loops cost 2 x 8 x 4 registers -- the difference between one and two waves per SIMD
+        // The lookup of a lane's 8 levels is a chain of round trips (point -> primes -> slots) with a handful of instructions between them,
+        // and with two waves per SIMD there is little else to run meanwhile: taken level by level it was 1 + 2 x 8 x 2 dependent trips per
+        // sample.  So, per half of the lane's levels: its 8 prime triples first (one trip), then the levels in groups of RENDER_LEVELS -- hash every
+        // level of the group for both tables, issue ALL its gathers (16 per level), then blend -- 1 + 2 + 8 / RENDER_LEVELS trips.  Registers are there: the
+        // decoder's fragments are dead during the lookup.  32-bit offsets throughout (64-bit per-level bases cost 2 x 8 x 4 registers).
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int uu = 0; uu < 2; uu++) {
+        int pra[4][3], prb[4][3];  // the prime triples of this half's 4 levels, both tables: one trip
 #pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int level = 8 * u + 4 * h + m;
-            const int tr3 = 3 * (level * n_vol + vol);
-            const uint32_t slot0 = (uint32_t)level << (A.log2_T - 1);  // level * T halfs = level * T / 2 pairs
-            Corners c;
+        for (int m = 0; m < 4; m++) {
+          const int level = 8 * uu + 4 * h + m;
+          const int tr3 = 3 * (level * n_vol + vol);
+          pra[m][0] = A.prim_a[tr3]; pra[m][1] = A.prim_a[tr3 + 1]; pra[m][2] = A.prim_a[tr3 + 2];
+          if (TAB == 1 && A.prim_b) { prb[m][0] = A.prim_b[tr3]; prb[m][1] = A.prim_b[tr3 + 1]; prb[m][2] = A.prim_b[tr3 + 2]; }
+        }
+#pragma unroll
+        for (int g0 = 4 * uu; g0 < 4 * uu + 4; g0 += RENDER_LEVELS) {
+          Corners c[RENDER_LEVELS];
+          uint32_t posb[RENDER_LEVELS][8], va[RENDER_LEVELS][8], vb[RENDER_LEVELS][8];
+#pragma unroll
+          for (int l = 0; l < RENDER_LEVELS; l++) {
+            const int g = g0 + l, level = 8 * (g >> 2) + 4 * h + (g & 3);
             uint32_t cell[3];
-            hash_corners(px, py, pz, s_scale[level], A.prim_a + tr3, A.bias_pool ? A.bias_pool + tr3 : nullptr, T - 1u, c, cell);
-            float2 r = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c);
+            hash_corners(px, py, pz, s_scale[level], pra[g & 3], A.bias_pool ? A.bias_pool + 3 * (level * n_vol + vol) : nullptr, T - 1u, c[l], cell);
             if (TAB == 1) {
-              if (A.prim_b) rehash_corners(cell, A.prim_b + tr3, T - 1u, c);  // same cell, same weights: only the slots change
-              const float2 r2 = gather_pairs_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, c);
+              Corners cb;
+              if (A.prim_b) rehash_corners(cell, prb[g & 3], T - 1u, cb);  // same cell, same weights: only the slots change
+#pragma unroll
+              for (int d = 0; d < 8; d++) posb[l][d] = A.prim_b ? cb.pos[d] : c[l].pos[d];
+            }
+          }
+#pragma unroll
+          for (int l = 0; l < RENDER_LEVELS; l++) {
+            const int g = g0 + l, level = 8 * (g >> 2) + 4 * h + (g & 3);
+            const uint32_t slot0 = (uint32_t)level << (A.log2_T - 1);  // level * T halfs = level * T / 2 pairs
+            gather_issue_u32(reinterpret_cast<const half2_t*>(A.table_a), slot0, c[l].pos, va[l]);
+            if (TAB == 1) gather_issue_u32(reinterpret_cast<const half2_t*>(A.table_b), slot0, posb[l], vb[l]);
+          }
+#pragma unroll
+          for (int l = 0; l < RENDER_LEVELS; l++) {
+            const int g = g0 + l;
+            float2 r = blend_pairs(va[l], c[l].w);
+            if (TAB == 1) {  // hash_feats += residual_hash_feats (nerfacto_field.py:486)
+              const float2 r2 = blend_pairs(vb[l], c[l].w);
               r.x = r.x + r2.x; r.y = r.y + r2.y;
             }
-            x[u][2 * m] = r.x; x[u][2 * m + 1] = r.y;
+            x[g >> 2][2 * (g & 3)] = r.x; x[g >> 2][2 * (g & 3) + 1] = r.y;
           }
+        }
         }
       }
 #pragma unroll
@@ -442,16 +511,21 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;
   if (gfn_first_call_on_device(attr_seen)) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
   }
+  static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave
   const int cu_cap = gfn_decoder_cu_cap();
   if (blocks > cu_cap) blocks = cu_cap;
-  if (table2_f16) fused_render_patch_kernel<1><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-  else fused_render_patch_kernel<0><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  if (table2_f16 && levels == 4) fused_render_patch_kernel<1, 4><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  else if (table2_f16) fused_render_patch_kernel<1, 2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  else if (levels == 4) fused_render_patch_kernel<0, 4><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  else fused_render_patch_kernel<0, 2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -47,7 +47,12 @@ __host__ __device__ __forceinline__ int64_t plane_off(int64_t q, int W, int octe
 
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   const auto hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // round toward zero: saturates at 65504, never rounds to inf
-  const float r0 = (x0 - (float)hv[0]) * 2048.f, r1 = (x1 - (float)hv[1]) * 2048.f;  // exact
+  // (x - hi) * 2048, exact: x - hi has at most 13 significant bits and 2048 is a power of two.  Written as fma(hi, -2048, x * 2048) -- the same
+  // exact value, rounded (not at all) once -- because that form is ONE v_fma_mix_f32 per element (the f16 operand is read in place) behind one
+  // packed multiply per pair, where (x - float(hi)) * 2048 costs a conversion, a subtraction and a multiplication per element.
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  const f2 t = f2{x0, x1} * 2048.f;
+  const float r0 = __builtin_fmaf((float)hv[0], -2048.f, t[0]), r1 = __builtin_fmaf((float)hv[1], -2048.f, t[1]);
   hi = __builtin_bit_cast(uint32_t, hv);
   lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
@@ -68,10 +73,39 @@ __device__ __forceinline__ void mma3(Acc2& a, const u32x4* __restrict__ Ihi, con
   __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting every later operand read (register blow-up)
 }
 
-__device__ __forceinline__ void acc_init_bias(Acc2& a, const float* __restrict__ bias, int ot, int h) {
+// The same with the weight fragments of the NEXT chunk requested before this chunk's MFMAs are issued: read one chunk ahead, the LDS round trip
+// (ds_read_b128 x 2, ~100 cycles; issued behind the second MFMA, where the current `hi` fragment's registers are free again) runs under the
+// matrix pipe's work instead of in front of every triple --
+// mma3 alone leaves the pipe idle for most of a round trip per chunk, because the barrier that keeps the operand reads from all being hoisted
+// (register blow-up) also keeps the next read behind the MFMAs.  `w` carries the fragments from call to call; chunk_next < 0: nothing to prefetch.
+struct WFrag {
+  h8 hi, lo;
+};
+__device__ __forceinline__ WFrag wfrag_load(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, int chunk, int lane) {
+  WFrag w;
+  w.hi = __builtin_bit_cast(h8, Ihi[chunk * 64 + lane]);
+  w.lo = __builtin_bit_cast(h8, Ilo[chunk * 64 + lane]);
+  return w;
+}
+__device__ __forceinline__ void mma3p(Acc2& a, WFrag& w, const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, int chunk_next, int lane,
+                                      const u32x4& bhi, const u32x4& blo) {
+  const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
+  a.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, bh, a.m, 0, 0, 0);
+  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, bl, a.c, 0, 0, 0);
+  h8 nh = w.hi, nl = w.lo;
+  if (chunk_next >= 0) { nh = __builtin_bit_cast(h8, Ihi[chunk_next * 64 + lane]); }
+  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, bh, a.c, 0, 0, 0);
+  if (chunk_next >= 0) { nl = __builtin_bit_cast(h8, Ilo[chunk_next * 64 + lane]); }
+  __builtin_amdgcn_sched_barrier(0);
+  w.hi = nh; w.lo = nl;
+}
+
+// bias_h = the layer biases' LDS block + 4 * h (ONE lane-dependent address for all five layers: every load below is it + a compile-time offset;
+// a pointer per layer cost the register-tight inference kernels five address registers), off = the layer's offset in floats
+__device__ __forceinline__ void acc_init_bias(Acc2& a, const float* __restrict__ bias_h, int off, int ot) {
 #pragma unroll
   for (int g = 0; g < 4; g++) {  // registers 4g..4g+3 = rows 32ot + 8g + 4h + 0..3
-    const float4 b = *reinterpret_cast<const float4*>(bias + 32 * ot + 8 * g + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(bias_h + (off + 32 * ot + 8 * g));
     a.m[4 * g] = b.x; a.m[4 * g + 1] = b.y; a.m[4 * g + 2] = b.z; a.m[4 * g + 3] = b.w;
   }
 #pragma unroll
@@ -82,6 +116,15 @@ __device__ __forceinline__ void acc_init_zero(Acc2& a) {
   for (int r = 0; r < 16; r++) { a.m[r] = 0.f; a.c[r] = 0.f; }
 }
 __device__ __forceinline__ float acc_get(const Acc2& a, int r) { return __builtin_fmaf(a.c[r], 0x1p-11f, a.m[r]); }
+// the same for all 16 registers of a tile: register pairs (2p, 2p + 1) through one v_pk_fma_f32 each (the same fma per element)
+__device__ __forceinline__ void acc_get16(const Acc2& a, float (&v)[16]) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    const f2 r = __builtin_elementwise_fma(f2{a.c[2 * p], a.c[2 * p + 1]}, f2{0x1p-11f, 0x1p-11f}, f2{a.m[2 * p], a.m[2 * p + 1]});
+    v[2 * p] = r[0]; v[2 * p + 1] = r[1];
+  }
+}
 
 // a finished tile -> (ReLU, mask bits,) the two k-step fragments of the next layer
 struct Frag {
@@ -90,13 +133,13 @@ struct Frag {
 template <bool RELU>
 __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t) {
   float v[16];
+  acc_get16(a, v);
   uint32_t bits = 0;  // this tile's 16 ReLU bits.  A C++ compare leaves a 64-bit lane mask in an SGPR pair, and with 16 of them per
                       // tile alive at once the compiler spilled SGPRs through v_writelane / v_readlane (724 of the forward kernel's
                       // ~2,700 vector instructions per tile).  Here every compare lands in VCC and is shifted into `bits` by the
                       // next instruction (bits = 2 * bits + carry), registers 15 .. 0 so that bit r ends up as register r's.
 #pragma unroll
   for (int r = 15; r >= 0; r--) {
-    v[r] = acc_get(a, r);
     if (RELU) {
       asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[r]) : "vcc");  // not volatile: dropped where nobody reads the masks (inference)
       v[r] = fmaxf(v[r], 0.f);  // = v > 0 ? v : 0 (NaN -> 0 either way)
@@ -169,27 +212,32 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
                                                    uint16_t* __restrict__ planes_lo, int64_t cap, int64_t q) {
   const int h = lane >> 5;
-  const float* Bb0 = bias; const float* Bb1 = bias + 128; const float* Bh0 = bias + 160; const float* Bh1 = bias + 288; const float* Bh2 = bias + 416;
+  const float* bias_h = bias + 4 * h;
+  constexpr int Bb0 = 0, Bb1 = 128, Bh0 = 160, Bh1 = 288, Bh2 = 416;  // offsets of the five layers' biases (floats)
   DecoderOut out;
 #define FPL(half, C) (planes_##half + cap * (C))
   {
-    // ---- base layer 1: 32 -> 128, ReLU.  k-step u of the feature row: columns 16u + 8h + i
-    Frag a1[4];
+    // Weight fragments are read one chunk ahead of their MFMAs throughout (mma3p; `w` holds the chunk about to be used).  The two narrow layers
+    // (base L2: 128 -> 16, head L3: 128 -> 3) consume each 32-row tile of their input as soon as it exists -- the same k-steps in the same order on
+    // their accumulator, so the same bits -- instead of after all four: three tiles of fragments (48 registers) are never alive at once, which is
+    // what pays for the prefetch in the register-tight kernels.
+    WFrag w = wfrag_load(Ihi, Ilo, C_B0, lane);
+    // ---- base layer 1: 32 -> 128, ReLU (k-step u of the feature row: columns 16u + 8h + i), feeding base layer 2: 128 -> 16 (padded to one tile)
     unsigned long long m_a1 = 0;
+    Acc2 hh;
+    acc_init_bias(hh, bias_h, Bb1, 0);
 #pragma unroll
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
-      acc_init_bias(a, Bb0, ot, h);
-#pragma unroll
-      for (int u = 0; u < 2; u++) mma3(a, Ihi, Ilo, C_B0 + u * 4 + ot, lane, xh[u], xl[u]);
-      tile_to_frag<true>(a, a1[ot], m_a1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1[ot], h);
+      acc_init_bias(a, bias_h, Bb0, ot);
+      mma3p(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
+      mma3p(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
+      Frag a1;
+      tile_to_frag<true>(a, a1, m_a1, ot);
+      if (PLANES) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1, h);
+      mma3p(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
+      mma3p(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
     }
-    // ---- base layer 2: 128 -> 16 (padded to one 32-row tile)
-    Acc2 hh;
-    acc_init_bias(hh, Bb1, 0, h);
-#pragma unroll
-    for (int u = 0; u < 8; u++) mma3(hh, Ihi, Ilo, C_B1 + u, lane, a1[u >> 1].hi[u & 1], a1[u >> 1].lo[u & 1]);
     out.h0 = acc_get(hh, 0);            // row 0 = density channel: register 0 of the h=0 lanes
     out.sigma = expf(out.h0 + 1.0f);    // trunc_exp(h0 + 1), nerfacto_field.py:499
     u32x4 gh, gl;  // rows 0..15 of the tile = k-step 0 (row 0 meets zero weights)
@@ -227,31 +275,30 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
-      acc_init_bias(a, Bh0, ot, h);
-      mma3(a, Ihi, Ilo, C_H0 + 0 * 4 + ot, lane, gh, gl);
-      mma3(a, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, sh_h, sh_l);
-      mma3(a, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, e_h[0], e_l[0]);
-      mma3(a, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[1], e_l[1]);
+      acc_init_bias(a, bias_h, Bh0, ot);
+      mma3p(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
+      mma3p(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
+      mma3p(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
+      mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
       tile_to_frag<true>(a, c1[ot], m_c1, ot);
       if (PLANES) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
     }
-    // ---- head layer 2: 128 -> 128, ReLU
-    Frag c2[4];
+    // ---- head layer 2: 128 -> 128, ReLU, feeding head layer 3: 128 -> 3 (padded), sigmoid
     unsigned long long m_c2 = 0;
+    Acc2 o3;
+    acc_init_bias(o3, bias_h, Bh2, 0);
 #pragma unroll
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
-      acc_init_bias(a, Bh1, ot, h);
+      acc_init_bias(a, bias_h, Bh1, ot);
 #pragma unroll
-      for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, C_H1 + u * 4 + ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
-      tile_to_frag<true>(a, c2[ot], m_c2, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2[ot], h);
+      for (int u = 0; u < 8; u++) mma3p(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
+      Frag c2;
+      tile_to_frag<true>(a, c2, m_c2, ot);
+      if (PLANES) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2, h);
+      mma3p(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
+      mma3p(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
     }
-    // ---- head layer 3: 128 -> 3 (padded), sigmoid
-    Acc2 o3;
-    acc_init_bias(o3, Bh2, 0, h);
-#pragma unroll
-    for (int u = 0; u < 8; u++) mma3(o3, Ihi, Ilo, C_H2 + u, lane, c2[u >> 1].hi[u & 1], c2[u >> 1].lo[u & 1]);
     out.r = 1.f / (1.f + expf(-acc_get(o3, 0)));  // rows 0..2 = registers 0..2 of the h=0 lanes
     out.g = 1.f / (1.f + expf(-acc_get(o3, 1)));
     out.b = 1.f / (1.f + expf(-acc_get(o3, 2)));
@@ -264,10 +311,10 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 template <bool RELU_MASK>
 __device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t) {
   float v[16];
+  acc_get16(a, v);
   const int bits = (int)(uint32_t)(mask >> (t * 16));  // this tile's 16 ReLU bits
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    v[r] = acc_get(a, r);
     // ReLU': and with the bit stretched to a word (v_bfe_i32 + v_and instead of shift / and / compare / select on 64 bits)
     if (RELU_MASK) v[r] = __int_as_float(__float_as_int(v[r]) & ((bits << (31 - r)) >> 31));
   }

@@ -624,7 +624,10 @@ class HotPath:
         """forward_train(samples=...) for a caller whose sample buffers are static (HotPath.sample(out=...): the same dict every other
         step) -- after three eager runs per (stage, block, buffer, forward kind) the launches are captured once and replayed: the
         training iteration of the plugin surface is bound by the host, and the forward is a third of its launches.  Outputs (comp,
-        ctx) of a replay are the capture's tensors, written again: valid until the second next call with the same buffers."""
+        ctx) of a replay are the capture's tensors, written again: valid until the NEXT replay of any captured forward (the captures share one
+        memory pool, so a later forward's transient buffers may reuse an earlier one's; a training iteration consumes them in its own backward,
+        before the next forward).  At most cfg.graph_forward_keep captures are kept, the least recently used go first (each holds a full set
+        of forward activations)."""
         c = self.cfg
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
         blk = block if stage == STAGE_FOCAL else None

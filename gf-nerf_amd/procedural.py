@@ -20,7 +20,12 @@ import torch
 from . import hotpath, ops, scene
 
 Z_TOP, Z_BOTTOM, N_QUAD = 4.0, -4.0, 384
-PROTOCOL = "r04: fresh rays every step, one fixed held-out set, texture 0.5, lr x1e-2 per stage, legs fast | reference"  # bumped when the study's meaning changes
+PROTOCOL = "r04b: fresh rays every step, one fixed held-out set, texture 0.5, 3000 + 1000 steps, lr x0.1 per stage, legs fast | reference"  # bumped when the study's meaning changes
+STUDY_STEPS = (3000, 1000)  # global, focal steps of a study run
+STUDY_LR_FINAL = 0.1        # learning-rate decay over each stage (1e-2 -> 1e-3, 5e-3 -> 5e-4).  With the rounds 2-3 schedule (2,000 steps, x0.01) the rate
+                            # collapsed before the initial fog had cleared in some runs: a bimodal outcome (crisp ~32 dB | foggy 27-29 dB, chosen by
+                            # the seed and by chaos) whose pair-to-pair scatter of 1.1 dB no affordable number of seeds averages out; this schedule
+                            # brings every seed to 33-34 dB (tools/README.md, round 4)
 STUDY_DETAIL = 0.5  # texture amplitude of the PSNR study: 3,000-step runs plateau at ~32 dB (without it: 45-52 dB, where PSNR is optimiser noise)
 
 
@@ -153,26 +158,40 @@ class TorchAdam:
         hp.refresh_shadows()  # f16 shadows of the tables + the decoder's weight images follow the new values
 
 
-def grad_cosine(hp, batch, noise, s3, stage, block):
-    """One forward + backward of `batch` from the engine's current state with the exact-f32 decoder and with the split-f16 x3 decoder:
-    cosine and relative difference of the two gradients per parameter group (no optimiser step, no octree update)."""
+GRADIENT_LEGS = {  # HotPathConfig fields of the two gradient semantics grad_cosine compares from one state
+    "fast": dict(mlp_precision="x3", early_T=1e-4, two_phase=True, lds_accumulate=True),       # the product: x3 decoder, cut at T < 1e-4, exact LDS sums
+    "reference": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False),  # every sample, exact-f32 decoder, f16 atomics
+    "f32": dict(mlp_precision="f32"),                                                           # the product with the exact-f32 decoder only
+}
+
+
+def grad_cosine(hp, batch, noise, s3, stage, block, legs=("reference", "fast")):
+    """One forward + backward of `batch` from the engine's current state under each of two gradient semantics (GRADIENT_LEGS; default: the
+    reference's -- every sample, exact-f32 decoder, f16 atomic adds -- and the product's -- x3 decoder, early termination, phased forward,
+    exact LDS accumulation): cosine and relative difference of the two gradients per parameter group (no optimiser step, no octree update)."""
     o, d, cam, gt = batch
-    saved, got = hp.cfg.mlp_precision, {}
-    n_live = 17 * (1 << hp.cfg.log2_T)
-    for prec in ("f32", "x3"):
-        hp.cfg.mlp_precision = prec
+    c = hp.cfg
+    saved = {k: getattr(c, k) for k in ("mlp_precision", "early_T", "two_phase", "lds_accumulate")}
+    got = {}
+    n_live = 17 * (1 << c.log2_T)
+    try:
+        for leg in legs:
+            for k, v in GRADIENT_LEGS[leg].items():
+                setattr(c, k, v)
+            hp._x3_stale = True
+            hp.forward_backward(o, d, cam, gt, noise, stage=stage, block=block, s3im_index=s3, update_oct=False)
+            hp._sync_opt()
+            g = dict(table=hp.table_grad.view(-1)[:n_live].double())
+            if stage == hotpath.STAGE_GLOBAL:
+                g.update(mlp=hp.mlp_grad.double(), emb=hp.emb_grad.double())
+            got[leg] = {k: v.clone() for k, v in g.items()}
+    finally:
+        for k, v in saved.items():
+            setattr(c, k, v)
         hp._x3_stale = True
-        hp.forward_backward(o, d, cam, gt, noise, stage=stage, block=block, s3im_index=s3, update_oct=False)
-        hp._sync_opt()
-        g = dict(table=hp.table_grad.view(-1)[:n_live].double())
-        if stage == hotpath.STAGE_GLOBAL:
-            g.update(mlp=hp.mlp_grad.double().clone(), emb=hp.emb_grad.double().clone())
-        got[prec] = {k: v.clone() for k, v in g.items()}
-    hp.cfg.mlp_precision = saved
-    hp._x3_stale = True
     out = {}
-    for k in got["f32"]:
-        a, b = got["f32"][k], got["x3"][k]
+    for k in got[legs[0]]:
+        a, b = got[legs[0]][k], got[legs[1]][k]
         na, nb = float(a.norm()), float(b.norm())
         out[k] = dict(cos=float((a * b).sum()) / max(na * nb, 1e-300), rel_diff=float((a - b).norm()) / max(na, 1e-300))
     return out
@@ -180,12 +199,14 @@ def grad_cosine(hp, batch, noise, s3, stage, block):
 
 def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_rays=4096, log2_T=21, seed=0, n_pool=64, eval_rays=16384, target_samples=128,
                    early_T=1e-4, progress=None, update_oct=True, torch_adam=False, fresh_rays=True, data_seed=None, eval_seed=0, lr_final=1e-2,
-                   holdout_every=0, cosine_every=0, keep_engine=False, detail=0.0, n_blocks=1, after_global=None, **cfg_kw):
+                   holdout_every=0, cosine_every=0, cosine_legs=("reference", "fast"), keep_engine=False, detail=0.0, n_blocks=1, after_global=None, lr_hold=0,
+                   **cfg_kw):
     """Train on the procedural scene with the product's native step (HotPath.train_step: sampler -> lookup -> decoder -> compositing ->
     Charbonnier + S3IM -> backward -> Adam; UpdateOctNodes every global step like GFNeRFModel.get_outputs), lr 1e-2 -> 1e-2 * lr_final over the
     global stage and 5e-3 -> 5e-3 * lr_final over the focal stage (GFNerfExponentialDecayScheduler's shape, schedulers.py:113-184), then render
     held-out rays.  -> dict(psnr_global, psnr, loss, ...).
 
+    lr_hold: global-stage steps at the initial learning rate before the decay starts.
     n_blocks: focal blocks resident; the focal stage trains them in rotation (step k: block k mod n_blocks), PSNR is block 0's.
     after_global(hp, lr_end): called between the stages (bench.py times the global step on the trained state there).
     detail: amplitude of the fine colour texture (procedural.texture) in the ground truth.
@@ -195,7 +216,8 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
     torch_adam: step the parameters with torch.optim.Adam on dense gradients (TorchAdam) instead of the engine's Adam kernel.
     holdout_every = k > 0: cameras k-1, 2k-1, ... give no training ray; `psnr_heldout` renders their pixels with the nearest training
     camera's appearance embedding (nerfacto_field.py:533: "test mode use nearest rel camera indices").
-    cosine_every = n > 0: every n steps, grad_cosine of the batch at hand (res["grad_cosine"] = [(stage, step, {group: {cos, rel_diff}})]).
+    cosine_every = n > 0: every n steps, grad_cosine of the batch at hand under the two gradient semantics `cosine_legs` (GRADIENT_LEGS)
+    (res["grad_cosine"] = [(stage, step, {group: {cos, rel_diff}})]).
     After training the SAME state is also rendered with the other decoder arithmetic (psnr_eval_x3 / psnr_eval_f32): the inference-only
     difference, free of training chaos."""
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -275,11 +297,12 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
             b = batch(i)
             if stage == "focal":
                 block = i % n_blocks
-            mult = math.exp(math.log(lr_final) * i / max(steps, 1))  # lr_init -> lr_init * lr_final over the stage
+            hold = lr_hold if stage == "global" else 0  # (the global stage may keep lr_init for its first lr_hold steps)
+            mult = math.exp(math.log(lr_final) * max(i - hold, 0) / max(steps - hold, 1))  # lr_init -> lr_init * lr_final over the stage
             noise = ops.sampler_noise(n_rays, fin, train=True, generator=gen, device=dev)
             s3 = ops.s3im_index(n_rays, cfg.s3im_repeat_time, generator=gen, device=dev)
             if cosine_every > 0 and (i + 1) % cosine_every == 0:
-                cosines.append((stage, i + 1, grad_cosine(hp, b, noise, s3, stage, block)))
+                cosines.append((stage, i + 1, grad_cosine(hp, b, noise, s3, stage, block, legs=cosine_legs)))
             oct_now = update_oct and stage == "global"
             if adam is not None:
                 loss, _ = hp.forward_backward(*b, noise, stage=stage, block=block, s3im_index=s3, update_oct=oct_now)

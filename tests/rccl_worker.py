@@ -3,8 +3,10 @@
 (the MAX all-reduce of the octree statistics between K5 and K6, all_to_all_single -> gfn_reduce_shards -> all_gather_into_tensor of
 the f16 table gradient on the communication stream, the small all-reduce of the decoder / embedding gradients) goes through the
 communicator, eagerly and between the four graph segments of a segmented StepGraph.  With one rank the mean of one is the value
-itself, so the run must be the single-process run bit for bit (scripts/train.py:124-137, gf_pipeline.py:136-138 are the reference's
-counterpart: DDP over NCCL).  Not collected by pytest; started by tests/test_gpu_dist.py as `python rccl_worker.py PORT OUT`."""
+itself, so the run must be the single-process run -- bit for bit in everything integer (tree, node statistics), and as close in the
+floating-point state as a second single-process run is to the first (the control: at this table size some gradient-record streams
+overflow into f16 atomics, so the plain step does not repeat itself bit for bit).  scripts/train.py:124-137, gf_pipeline.py:136-138
+are the reference's counterpart: DDP over NCCL.  Not collected by pytest; started by tests/test_gpu_dist.py as `python rccl_worker.py PORT OUT`."""
 import json
 import os
 import sys

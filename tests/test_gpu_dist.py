@@ -75,7 +75,7 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     """init_process_group("nccl", world_size=1) on the card; TrainSync(force_exchange=True): allreduce_mean_direct (all_to_all_single ->
     gfn_reduce_shards -> all_gather_into_tensor), TrainSync.start_grads / finish_grads on the communication stream, reduce_octree_stats
     (MAX) and the four-segment StepGraph with its three eager exchanges all run on RCCL.  One rank: the mean of one is the value, so the
-    result must be the single-process step bit for bit."""
+    result must be the single-process step -- bit for bit where the step itself is deterministic (see below)."""
     port, out = str(_free_port()), str(tmp_path / "rccl.json")
     worker = os.path.join(ROOT, "tests", "rccl_worker.py")
     codes, outs = _run_ranks(lambda r: [sys.executable, worker, port, out], 1, timeout=420)
@@ -89,19 +89,21 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     assert res["uses_direct"] and res["comm_stream_used"]
     assert res["eager_sync_stats"] == dict(octree_max_reduces=3, grad_reduces=6, direct_reduces=3), res["eager_sync_stats"]
     print(json.dumps({k: v for k, v in res.items() if k != "error"}))
-    # after ONE step the state is a function of deterministic kernels only (table gradient: exact LDS sums; decoder dW: fixed-order partial sums)
-    assert res["eager_forced_identical_step1"] == res["eager_control_identical_step1"], (res["eager_forced_identical_step1"], res["eager_control_identical_step1"])
-    assert all(res["eager_forced_identical_step1"][i] for i in (0, 1, 4, 5, 6, 7)), res["eager_forced_identical_step1"]  # tables and tree, bit for bit
-    # three steps: as identical to the plain run as the plain run is to itself (the appearance embedding's gradient is a float-atomic sum)
-    assert res["eager_forced_identical"] == res["eager_control_identical"], (res["eager_forced_identical"], res["eager_control_identical"], res["eager_forced_rel"])
-    assert all(res["eager_forced_identical"][i] for i in (4, 5, 6, 7)), res["eager_forced_identical"]  # the tree and its statistics
-    assert res["eager_forced_table_far_frac"] <= max(2.0 * res["eager_control_table_far_frac"], 1e-3), (res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"])
-    assert res["noemb_forced_identical"] == res["noemb_control_identical"], (res["noemb_forced_identical"], res["noemb_control_identical"])
+    # "Bit for bit" has a ceiling: the plain single-process run does not repeat ITSELF bit for bit (the control: two identical runs differ in the
+    # last bits of the table after one step -- at T = 2^16 some gradient-record streams overflow into f16 atomics, whose order is the hardware's,
+    # and Adam at eps = 1e-15 turns a last-bit difference of a near-zero gradient into a full step).  So: everything integer -- the tree and its
+    # statistics, what the MAX exchange carries -- is identical, and the floating-point state is as close to the plain run as a second plain run is.
+    for key in ("eager_forced_identical_step1", "eager_forced_identical", "noemb_forced_identical"):
+        assert all(res[key][i] for i in (4, 5, 6, 7)), (key, res[key])  # nodes, weight / alpha statistics, visit counts
+    assert res["eager_forced_table_far_frac"] <= max(2.0 * res["eager_control_table_far_frac"], 1e-4), (res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"])
+    assert res["eager_forced_rel"][2] < 1e-4 and res["eager_forced_rel"][3] < 1e-5, res["eager_forced_rel"]  # decoder, embedding (the table: far_frac above -- its
+    # largest single difference is one flipped Adam step, 2 lr, in either comparison)
     # segmented replay: four graphs, three eager RCCL exchanges, four replays
     assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
     assert res["graph_sync_stats"]["octree_max_reduces"] == 5 and res["graph_sync_stats"]["direct_reduces"] == 5, res["graph_sync_stats"]
     assert res["graph_steps"] == [5, 5, 5] and res["finite"]
     assert all(res["graph_forced_vs_segmented_identical"][i] for i in (4, 5, 6, 7)), (res["graph_forced_vs_segmented_identical"], res["graph_forced_vs_segmented_rel"])
+    assert res["graph_forced_vs_segmented_rel"][0] < 2e-2 and res["graph_forced_vs_segmented_rel"][2] < 1e-4, res["graph_forced_vs_segmented_rel"]
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")

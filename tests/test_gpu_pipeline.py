@@ -915,6 +915,49 @@ def test_graphed_forward_is_the_eager_forward(setup):
     assert float(b["table"].abs().max()) > 0
 
 
+def test_captured_forwards_are_bounded_and_evicted_least_recently_used(setup):
+    """forward_train_graphed kept every capture (a full set of forward activations each) until drop_block / proc_octree.  Now the
+    captures share one memory pool and at most cfg.graph_forward_keep stay (least recently used first out): three blocks x two sample-buffer
+    sets with keep = 4 -- never more than 4 captured forwards alive, the oldest block's graphs gone when the third block's are captured, a
+    block that comes back is captured again, and every replay still is the eager forward (outputs compared on the spot)."""
+    import torch
+
+    from gfnerf_amd import hotpath, scene
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    R = 256
+    noise = t(scene.make_noise(R, False, 5.0))
+    cfg = hotpath.HotPathConfig(log2_T=14, s3im_loss_mult=0.0, early_T=1e-2, graph_forward_keep=4)
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=3)
+    hp.table.mul_(100.0); hp.refresh_shadows()
+    for b in hp.blocks:
+        b.uniform_(-1e-2, 1e-2, generator=torch.Generator(device="cuda").manual_seed(5))
+    hp.refresh_shadows()
+    hp.zero_grads("focal", 0)
+    bufs = [None, None]
+    seen_max, k = 0, 0
+    for block in (0, 1, 2, 0):
+        for it in range(8):  # 3 eager runs per buffer set, then replays
+            o, d, cam = (t(a) for a in scene.make_rays(sc["c2w"], R, seed=500 + k))
+            s = hp.sample(o, d, noise, out=bufs[k % 2])
+            bufs[k % 2] = s
+            comp, ctx = hp.forward_train_graphed(cam, "focal", block, s, want_depth=False)
+            replayed = hp.last_forward_replayed
+            got = comp["rgb"].clone()
+            want, _ = hp.forward_train(None, None, cam, None, "focal", block, want_depth=False, samples=s)
+            assert float((got - want["rgb"]).abs().max()) <= 1e-6, (block, it, replayed)
+            captured = [key for key, e in hp._fwd_graphs.items() if "graph" in e]
+            seen_max = max(seen_max, len(captured))
+            k += 1
+        assert replayed                                     # every block reaches replays
+        assert {key[2] for key in captured} <= {block, (block - 1) % 3 if block else 2}, [key[2] for key in captured]  # this block's + the one before
+    assert seen_max == 4 and len(hp._fwd_graphs) <= 12
+    hp.forget_graphs()
+    assert len(hp._fwd_graphs) == 0
+    torch.cuda.empty_cache()
+
+
 def test_step_draws_are_uniform_fresh_per_call_and_replayable():
     """gfn_step_draws (the device's own Philox4x32-10 stream for a captured step's random draws): march noise (u + 0.5) * fineness with u
     uniform in [0, 1) (PersSampler_cuda.cu:380-389), S3IM's index vector = arange + 9 uniform random permutations (losses.py:780-789);
@@ -1127,7 +1170,7 @@ def test_octree_statistics_do_not_depend_on_the_cut(setup):
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=14, **kw), seed=1)
         hp.table.mul_(100.0); hp.layers[1][0].mul_(4.0); hp.refresh_shadows()   # dense enough that rays terminate inside the volume
         hp.weight_stats.fill_(3); hp.alpha_stats.fill_(3)                        # so that K6 prunes within a few updates (INIT_NODE_STAT is 1000)
-        alphas, kinds = [], []
+        alphas, kinds, hist = [], [], []
         for k in range(8):
             o, d, cam = batches[k % 3]
             comp, ctx = hp.forward_train(o, d, cam, noise, stage="global", all_alphas=True)
@@ -1135,11 +1178,12 @@ def test_octree_statistics_do_not_depend_on_the_cut(setup):
             n = int(ctx["samples"]["pts_offsets"][-1].item())
             alphas.append((comp["alphas"][:n].clone(), comp["weights"][:n].clone()))
             hp.update_oct_nodes(ctx)
-        return hp, alphas, kinds
+            hist.append((hp.weight_stats.clone(), hp.alpha_stats.clone(), hp.visit_cnt.clone(), hp.nodes.clone()))
+        return hp, alphas, kinds, hist
 
-    cut, a_cut, k_cut = run(early_T=1e-4)
-    ref, a_ref, k_ref = run(early_T=0.0)
-    old, a_old, k_old = run(early_T=1e-4, exact_oct_alphas=False)
+    cut, a_cut, k_cut, h_cut = run(early_T=1e-4)
+    ref, a_ref, k_ref, h_ref = run(early_T=0.0)
+    old, a_old, k_old, h_old = run(early_T=1e-4, exact_oct_alphas=False)
     assert set(k_cut) == {"lm"} and set(k_old) == {"fused"}, (k_cut, k_old)  # every density evaluated | rays leave the fused kernel once opaque
     behind = 0
     for (a, w), (ar, wr) in zip(a_cut, a_ref):
@@ -1148,12 +1192,14 @@ def test_octree_statistics_do_not_depend_on_the_cut(setup):
         behind += int(cutoff.sum())
         assert float(wr[cutoff].max() if cutoff.any() else 0.0) < 1e-4             # the weights the cut drops are below 1e-4 ...
         assert float((w - wr)[~cutoff].abs().max()) <= 1e-6
-    assert behind > 1000                                                            # ... and there are many such samples in this scene
-    for name in ("weight_stats", "alpha_stats", "visit_cnt", "nodes"):
-        assert torch.equal(getattr(cut, name), getattr(ref, name)), name
-    pruned = int((ref.weight_stats < 0).sum() + (ref.alpha_stats < 0).sum())
-    assert pruned > 0                                                               # K6 did invalidate leaves on the way
-    assert not torch.equal(old.alpha_stats, ref.alpha_stats)                        # the test can tell: rounds 2-3 fed K5 alpha = 0 behind the cut
+    assert behind > 100                                                             # ... and such samples exist in this scene
+    for step, (c_, r_) in enumerate(zip(h_cut, h_ref)):       # after EVERY update: weight / alpha statistics, visit counts, node blob
+        for name, x, y in zip(("weight_stats", "alpha_stats", "visit_cnt", "nodes"), c_, r_):
+            assert torch.equal(x, y), (step, name)
+    moved = int((h_ref[-1][0] != 3).sum() + (h_ref[-1][1] != 3).sum())
+    assert moved > 10                                                               # the updates did touch the statistics
+    # and the test can tell: rounds 2-3 fed K5 alpha = 0 behind the cut -- some node's alpha statistic was decremented where the reference's was kept
+    assert any(not torch.equal(o_[1], r_[1]) for o_, r_ in zip(h_old, h_ref))
 
 
 def test_psnr_of_the_product_against_the_reference_semantics():
@@ -1162,7 +1208,7 @@ def test_psnr_of_the_product_against_the_reference_semantics():
       1. the decoder arithmetic alone: every trained state rendered with the split-f16 x3 decoder and with the exact-f32 decoder (the
          reference's nn.Linear, gfnerf/mlp.py:35-57) gives the same PSNR to 0.01 dB -- no training chaos involved;
       2. along a training run the gradient of a batch computed with either decoder has cosine >= 0.9999 in every parameter group;
-      3. trained end to end (reduced length: 1,200 + 400 steps, four seeds), the product's leg ("fast") against the reference-semantics leg
+      3. trained end to end (reduced length: 1,500 + 400 steps, four seeds), the product's leg ("fast") against the reference-semantics leg
          ("reference": early_T = 0, every sample, exact-f32 decoder, f16 atomics, torch.optim.Adam; engine/trainer.py:382-441,
          gfnerf/nerfacto.py:522-619,628-689), paired by seed: |mean difference| <= 0.1 dB + 2 standard errors.  One training run is one draw
          (Adam at eps = 1e-15 amplifies last-bit differences), so the standard error of four pairs is what bounds this statement; the
@@ -1173,14 +1219,14 @@ def test_psnr_of_the_product_against_the_reference_semantics():
     from gfnerf_amd import procedural, scene
 
     sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir=__import__("os").path.join(__import__("os").environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene"))
-    kw = dict(steps_global=1200, steps_focal=400, eval_rays=8192, detail=procedural.STUDY_DETAIL)
+    kw = dict(steps_global=1500, steps_focal=400, eval_rays=8192, detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL)
     r = procedural.psnr_study(sc, seeds=(0, 1, 2, 3), legs=("fast", "reference"), **kw)
     print({k: v for k, v in r.items() if k.startswith("psnr") or k.startswith("delta") or k.startswith("decoder") or k in ("se", "n_seeds")})
     assert min(r["psnr_fast_runs"] + r["psnr_reference_runs"]) > 24.0, r                 # every run learns the scene (~7 dB at the start)
     assert max(abs(v) for v in r["decoder_delta_runs"]) <= 0.01, r["decoder_delta_runs"]   # 1.
     assert r["n_seeds"] == 4 and r["se"] is not None
     assert abs(r["delta"]) <= 0.1 + 2.0 * r["se"], (r["delta"], r["se"], r["delta_runs"])  # 3.
-    c = procedural.train_and_eval(sc, seed=0, steps_global=400, steps_focal=200, eval_rays=4096, detail=procedural.STUDY_DETAIL, cosine_every=100,
+    c = procedural.train_and_eval(sc, seed=0, steps_global=400, steps_focal=200, eval_rays=4096, detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL, cosine_every=100,
                                   **procedural.LEGS["fast"])["grad_cosine"]
     assert len(c) == 6
     for stage, step, groups in c:                                                           # 2.

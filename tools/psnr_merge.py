@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Merge the outputs of several tools/psnr_study.py calls (disjoint seed ranges, one protocol) into the round's record:
+    python tools/psnr_merge.py OUT.json PART0.json PART1.json ..."""
+import json, math, sys
+import numpy as np
+
+parts = [json.load(open(p)) for p in sys.argv[2:]]
+assert len({p["protocol"] for p in parts}) == 1, "parts were made with different protocols"
+out = {k: v for k, v in parts[0].items() if k != "psnr_study"}
+out["parts"] = [dict(seed0=p.get("seed0", 0), argv=p["argv"]) for p in parts]
+st0 = parts[0]["psnr_study"]
+legs = st0["legs"]
+st = {k: st0[k] for k in ("legs", "workload", "steps", "mean_samples_per_ray", "delta_of", "decoder_delta_of")}
+st["seeds"] = sum((p["psnr_study"]["seeds"] for p in parts), [])
+assert len(set(st["seeds"])) == len(st["seeds"]), "overlapping seeds"
+for leg in legs:
+    runs = sum((p["psnr_study"][f"psnr_{leg}_runs"] for p in parts), [])
+    st[f"psnr_{leg}_runs"] = runs
+    st[f"psnr_{leg}"] = float(np.mean(runs))
+    st[f"psnr_{leg}_std"] = float(np.std(runs, ddof=1))
+    for key in (f"psnr_global_{leg}", f"psnr_heldout_{leg}"):
+        if key in st0:
+            st[key] = float(np.average([p["psnr_study"][key] for p in parts], weights=[len(p["psnr_study"]["seeds"]) for p in parts]))
+for name in ("delta", "decoder_delta"):
+    runs = sum((p["psnr_study"][f"{name}_runs"] for p in parts), [])
+    st[f"{name}_runs"] = runs
+    st[name] = float(np.mean(runs))
+    st["se" if name == "delta" else "decoder_se"] = float(np.std(runs, ddof=1) / math.sqrt(len(runs)))
+st["n_seeds"] = len(st["seeds"])
+st["seconds"] = sum(p["psnr_study"].get("seconds", 0.0) for p in parts)
+out["psnr_study"] = st
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(f"{st['n_seeds']} seeds: delta {st['delta']:+.3f} +- {st['se']:.3f} dB; same-state decoder delta {st['decoder_delta']:+.6f} +- {st['decoder_se']:.1e}; "
+      f"{legs[0]} {st['psnr_' + legs[0]]:.2f} +- {st['psnr_' + legs[0] + '_std']:.2f}, {legs[1]} {st['psnr_' + legs[1]]:.2f} +- {st['psnr_' + legs[1] + '_std']:.2f}")

@@ -3,7 +3,9 @@
 early termination, phased forward, LDS gradient accumulation, GfnAdam's kernel) against the reference-semantics leg ("reference": every sample
 evaluated, exact-f32 decoder, f16 atomics, torch.optim.Adam), paired by seed -- over N seeds, plus the gradient-cosine trajectory of one run and the
 octree study (early_T 1e-4 vs 0: leaf sets after the global stage).
-    python tools/psnr_study.py OUT.json [n_seeds [steps_global steps_focal [detail]]]"""
+    python tools/psnr_study.py OUT.json [n_seeds [steps_global steps_focal [detail]]]
+GFN_STUDY_SEED0=k: seeds k .. k + n_seeds - 1 and only the paired study (a call on the GPU box lasts 20 minutes at most: the record of a round is
+several calls' outputs merged by tools/psnr_merge.py)."""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +15,14 @@ from gfnerf_amd import procedural, scene  # noqa: E402
 
 out_path = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-sg = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-sf = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+sg = int(sys.argv[3]) if len(sys.argv) > 3 else procedural.STUDY_STEPS[0]
+sf = int(sys.argv[4]) if len(sys.argv) > 4 else procedural.STUDY_STEPS[1]
 detail = float(sys.argv[5]) if len(sys.argv) > 5 else procedural.STUDY_DETAIL
+LRF = procedural.STUDY_LR_FINAL
 sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene"))
 say = lambda m: print(f"[{time.strftime('%H:%M:%S')}] {m}", flush=True)  # noqa: E731
-res = dict(argv=sys.argv[1:], protocol=procedural.PROTOCOL)
+seed0 = int(os.environ.get("GFN_STUDY_SEED0", "0"))
+res = dict(argv=sys.argv[1:], protocol=procedural.PROTOCOL, seed0=seed0)
 
 
 def save():
@@ -27,51 +31,58 @@ def save():
     os.replace(out_path + ".tmp", out_path)
 
 
-# ---- 1. one trajectory: x3-vs-f32 gradient cosine every 100 steps
-t0 = time.perf_counter()
-r = procedural.train_and_eval(sc, seed=0, steps_global=sg, steps_focal=sf, detail=detail, cosine_every=100, **procedural.LEGS["fast"])
-cos = r.pop("grad_cosine")
-res["grad_cosine"] = dict(every=100, seed=0, min_cos={g: min(c[g]["cos"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
-                          max_rel_diff={g: max(c[g]["rel_diff"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
-                          trajectory=[(st, i, {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c.items()}) for st, i, c in cos],
-                          note="cos / relative L2 difference of the gradient of one batch from one state computed with the exact-f32 decoder and with the split-f16 x3 "
-                               "decoder (table: both legs' f16 x128 pools, i.e. including the pool's own rounding)")
-say(f"gradient cosine: min {res['grad_cosine']['min_cos']} ({time.perf_counter() - t0:.0f} s)")
-save()
+def aux_sections():
+    # ---- 1. one trajectory: gradient cosine every 100 steps
+    t0 = time.perf_counter()
+    r = procedural.train_and_eval(sc, seed=0, steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, cosine_every=100, **procedural.LEGS["fast"])
+    cos = r.pop("grad_cosine")
+    res["grad_cosine"] = dict(every=100, seed=0, min_cos={g: min(c[g]["cos"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
+                              max_rel_diff={g: max(c[g]["rel_diff"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
+                              trajectory=[(st, i, {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c.items()}) for st, i, c in cos],
+                              note="cos / relative L2 difference of the gradient of one batch from one state under the reference's gradient semantics (every sample, exact-f32 "
+                                   "decoder, f16 atomic adds) and under the product's (x3 decoder, early termination, phased forward, exact LDS sums); table: the f16 x128 "
+                                   "pools, i.e. including the pool's own rounding")
+    say(f"gradient cosine: min {res['grad_cosine']['min_cos']} ({time.perf_counter() - t0:.0f} s)")
+    save()
 
-# ---- 2. octree study: the global stage from one seed with early_T = 1e-4 (exact alphas for K5) | early_T = 0 | early_T = 1e-4 the rounds 2-3 way
-def valid_leaf_mask(hp):
-    from gfnerf_amd.gfnerf.perssampler import _NODE_DT
-    a = hp.nodes.cpu().numpy().view(_NODE_DT)
-    return (a["is_leaf_node"] != 0) & (a["trans_idx"] >= 0), (a["is_leaf_node"] != 0)
+    # ---- 2. octree study: the global stage from one seed with early_T = 1e-4 (exact alphas for K5) | early_T = 0 | early_T = 1e-4 the rounds 2-3 way
+    def valid_leaf_mask(hp):
+        from gfnerf_amd.gfnerf.perssampler import _NODE_DT
+        a = hp.nodes.cpu().numpy().view(_NODE_DT)
+        return (a["is_leaf_node"] != 0) & (a["trans_idx"] >= 0), (a["is_leaf_node"] != 0)
 
 
-oct_rows = []
-for sd in range(min(n, 4)):
-    row = dict(seed=sd)
-    masks = {}
-    for name, kw in (("early_T_1e-4", dict()), ("early_T_0", dict(early_T=0.0)), ("early_T_1e-4_r03_alphas", dict(exact_oct_alphas=False))):
-        rr = procedural.train_and_eval(sc, seed=sd, steps_global=sg, steps_focal=0, detail=detail, holdout_every=8, keep_engine=True, **{**procedural.LEGS["fast"], **kw})
-        hp = rr.pop("engine")
-        m, is_leaf = valid_leaf_mask(hp)
-        masks[name] = m
-        row[name] = dict(valid_leaves=int(m.sum()), leaves=int(is_leaf.sum()), psnr=round(rr["psnr"], 3), psnr_heldout_cams=round(rr["psnr_heldout"], 3))
-        del hp, rr
-        torch.cuda.empty_cache()
-    ref = masks["early_T_0"]
-    for name in ("early_T_1e-4", "early_T_1e-4_r03_alphas"):
-        row[name]["leaf_jaccard_vs_early_T_0"] = round(float((masks[name] & ref).sum() / max((masks[name] | ref).sum(), 1)), 5)
-        row[name]["valid_only_here"], row[name]["valid_only_in_early_T_0"] = int((masks[name] & ~ref).sum()), int((~masks[name] & ref).sum())
-    oct_rows.append(row)
-    say(f"octree seed {sd}: {row}")
-res["octree_study"] = dict(rows=oct_rows, steps_global=sg, note="UpdateOctNodes (K5/K6) every global step, no ProcOctree: node indices are stable, a leaf is 'valid' while "
-                           "trans_idx >= 0 (MarkInvalidNodes, PersSampler_cuda.cu:577-583).  Training is chaotic, so two runs differ in a few leaves whatever the semantics; "
-                           "the same-state statement is tests/test_gpu_pipeline.py::test_octree_statistics_do_not_depend_on_the_cut")
-save()
+    oct_rows = []
+    for sd in range(min(n, 4)):
+        row = dict(seed=sd)
+        masks = {}
+        for name, kw in (("early_T_1e-4", dict()), ("early_T_0", dict(early_T=0.0)), ("early_T_1e-4_r03_alphas", dict(exact_oct_alphas=False))):
+            rr = procedural.train_and_eval(sc, seed=sd, steps_global=sg, steps_focal=0, detail=detail, lr_final=LRF, holdout_every=8, keep_engine=True, **{**procedural.LEGS["fast"], **kw})
+            hp = rr.pop("engine")
+            m, is_leaf = valid_leaf_mask(hp)
+            masks[name] = m
+            row[name] = dict(valid_leaves=int(m.sum()), leaves=int(is_leaf.sum()), psnr=round(rr["psnr"], 3), psnr_heldout_cams=round(rr["psnr_heldout"], 3))
+            del hp, rr
+            torch.cuda.empty_cache()
+        ref = masks["early_T_0"]
+        for name in ("early_T_1e-4", "early_T_1e-4_r03_alphas"):
+            row[name]["leaf_jaccard_vs_early_T_0"] = round(float((masks[name] & ref).sum() / max((masks[name] | ref).sum(), 1)), 5)
+            row[name]["valid_only_here"], row[name]["valid_only_in_early_T_0"] = int((masks[name] & ~ref).sum()), int((~masks[name] & ref).sum())
+        oct_rows.append(row)
+        say(f"octree seed {sd}: {row}")
+    res["octree_study"] = dict(rows=oct_rows, steps_global=sg, note="UpdateOctNodes (K5/K6) every global step, no ProcOctree: node indices are stable, a leaf is 'valid' while "
+                               "trans_idx >= 0 (MarkInvalidNodes, PersSampler_cuda.cu:577-583).  Training is chaotic, so two runs differ in a few leaves whatever the semantics; "
+                               "the same-state statement is tests/test_gpu_pipeline.py::test_octree_statistics_do_not_depend_on_the_cut")
+    save()
+
+
+
+if seed0 == 0:
+    aux_sections()
 
 # ---- 3. the paired study
 t0 = time.perf_counter()
-st = procedural.psnr_study(sc, seeds=tuple(range(n)), legs=("fast", "reference"), steps_global=sg, steps_focal=sf, detail=detail, holdout_every=8, progress=say)
+st = procedural.psnr_study(sc, seeds=tuple(range(seed0, seed0 + n)), legs=("fast", "reference"), steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, holdout_every=8, progress=say)
 st["seconds"] = time.perf_counter() - t0
 res["psnr_study"] = st
 say(f"delta {st['delta']:+.3f} +- {st['se']:.3f} dB over {n} seeds; same-state decoder delta {st['decoder_delta']:+.4f} +- {st['decoder_se']}")

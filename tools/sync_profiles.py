@@ -1,9 +1,9 @@
-"""Copy the summaries of a tools/r03_profiles.sh run (gpurun_out/r03p) into profiles/r03_* and refresh profiles/pmc_traffic.json
+"""Copy the summaries of a tools/r04_profiles.sh run (gpurun_out/r04p: both modes) into profiles/r04_* and refresh profiles/pmc_traffic.json
 (what bench.py reads for roofline.traffic / request_rate / mfma_busy_frac; the hashes of the kernel sources the counters were
 collected on are recorded beside them, and bench.py reports none of it for other sources)."""
 import csv, glob, hashlib, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03p"
-TAG = "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04p"
+TAG = "r04"
 py = sys.executable
 for t in ("focal_graph", "global_graph"):
     subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_{t}", f"profiles/{TAG}_{t}_kernel_stats.csv"])
@@ -16,14 +16,17 @@ shutil.copy(f"{R}/bench.json", f"profiles/{TAG}_bench.json")
 shutil.copy(f"{R}/bench_details.json", f"profiles/{TAG}_bench_details.json")
 subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_*/")))
 subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_global_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_global_*/")))
+subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_render_eager", f"profiles/{TAG}_render_eager_kernel_stats.csv"])
+shutil.copy(f"{R}/render_eager_under_rocprof.json", f"profiles/{TAG}_render_eager_bench_under_rocprof.json")
+subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_render_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_render_*/")))
 p = "profiles/pmc_traffic.json"
 old = json.load(open(p))
 j = {k: old[k] for k in ("gather_request_ceiling_per_s", "l2_gather_ceiling_per_s")}
-if "r02" in old:
-    j["r02"], j["r01"] = old["r02"], old["r01"]
-else:
-    j["r02"] = {k: v for k, v in old.items() if k not in ("r01", "gather_request_ceiling_per_s", "l2_gather_ceiling_per_s")}
-    j["r01"] = old["r01"]
+for k in ("r01", "r02", "r03"):
+    if k in old:
+        j[k] = old[k]
+if "r03" not in old:  # the previous round's figures move under their key
+    j["r03"] = {k: v for k, v in old.items() if k not in ("r01", "r02", "gather_request_ceiling_per_s", "l2_gather_ceiling_per_s")}
 load = lambda pp: {r["kernel"]: r for r in csv.DictReader(open(pp))}
 f, g = load(f"profiles/{TAG}_pmc_focal_per_kernel.csv"), load(f"profiles/{TAG}_pmc_global_per_kernel.csv")
 tr = lambda r: int(round((2 * float(r["FETCH_SIZE_mean"]) + float(r["WRITE_SIZE_mean"])) * 1024))
@@ -36,8 +39,8 @@ busy = lambda r: round(float(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"]) / (float(r["GRB
 lm = sorted([r for k, r in f.items() if "lm_lookup" in k], key=lambda r: -float(r["FETCH_SIZE_mean"]))
 n_launch_rows = len(lm)
 j["n_side"] = 40
-j["_note"] = ("HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes of the r03 build on the default workload "
-              "(1,600 cameras, T = 2^21, own primes per table, early_T 1e-4, phased forward): profiles/r03_pmc_{focal,global}_per_kernel.csv.  2 x: a request moves a 128-byte "
+j["_note"] = ("HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes of the r04 build on the default workload "
+              "(1,600 cameras, T = 2^21, own primes per table, early_T 1e-4, phased forward): profiles/r04_pmc_{focal,global,render}_per_kernel.csv.  2 x: a request moves a 128-byte "
               "line and is tallied as 64 bytes (profiles/r02_pmc_fetch_calibration.csv).  lm_lookup rows are means over ALL launches of a kernel instantiation, "
               f"phase-B launches that return at once included ({n_launch_rows} instantiations): bench.py uses the per-launch figures of the instantiation with the larger FETCH.")
 # per-launch means include the gated phase-B launches (no traffic): scale to the launches that work.  launches column = per pass
@@ -64,9 +67,26 @@ j["mfma_busy:bwd_scatter:focal"] = busy(one(f, "field_bwd_dx"))
 j["mfma_busy:field_fwd:global"] = busy(one(g, "field_fwd_x3"))
 j["mfma_busy:bwd_scatter:global"] = busy(one(g, "field_bwd_dx"))
 j["mfma_busy:wgrad:global"] = busy(one(g, "wgrad_x3_layers"))
+# the inference kernel (one eager launch per 138,240-ray tile): matrix / vector pipe occupancy, what it decodes, its duration
+rd = load(f"profiles/{TAG}_pmc_render_per_kernel.csv")
+rk = one(rd, "fused_render_patch_kernel")
+fv = lambda key: float(rk[key + "_mean"])
+simd_cycles = fv("GRBM_GUI_ACTIVE") * 128.0  # GUI_ACTIVE sums the 8 XCDs; 1,024 SIMDs
+j["mfma_busy:render"] = round(fv("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles, 4)
+j["valu_busy:render"] = round(4.0 * fv("SQ_ACTIVE_INST_VALU") / simd_cycles, 4)  # SQ_ACTIVE_INST_* count quad-cycles
+j["wait_frac:render"] = round(fv("SQ_WAIT_INST_ANY") / fv("SQ_WAVE_CYCLES"), 4)
+j["mfma_valu_coexec_frac:render"] = round(fv("SQ_VALU_MFMA_COEXEC_CYCLES") / fv("SQ_VALU_MFMA_BUSY_CYCLES"), 4)
+j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / 216.0 * 32.0))  # 216 MFMAs per 32-sample tile of the decoder
+j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA") / 216.0), 1)
+j["l1_miss_requests:render"] = int(round(fv("TCP_TCC_READ_REQ_sum")))
+j["l2_hit_rate:render"] = round(fv("TCC_HIT") / (fv("TCC_HIT") + fv("TCC_MISS")), 3)
+j["traffic:render"] = tr(rk)
+ks = {r["kernel"]: r for r in csv.DictReader(open(f"profiles/{TAG}_render_eager_kernel_stats.csv"))}
+j["kernel_ms:render"] = round(float(one(ks, "fused_render_patch_kernel")["avg_ns"]) / 1e6, 4)
 sha = lambda q: hashlib.sha256(open(os.path.join("gf-nerf_amd", q), "rb").read()).hexdigest()
 j["source_sha256"] = {"lm_lookup": {q: sha(q) for q in ("csrc/lm_lookup.hip", "csrc/hash_device.h")},
-                      "decoder": {q: sha(q) for q in ("csrc/field_x3.hip", "csrc/x3_device.h")}}
+                      "decoder": {q: sha(q) for q in ("csrc/field_x3.hip", "csrc/x3_device.h")},
+                      "render": {q: sha(q) for q in ("csrc/fused_fwd.hip", "csrc/x3_device.h", "csrc/hash_device.h")}}
 json.dump(j, open(p, "w"), indent=1)
 for k in sorted(j):
     if ":" in k and not isinstance(j[k], dict):
