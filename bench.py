@@ -424,8 +424,10 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
     ceiling = pmc.get("l2_gather_ceiling_per_s")
     tiles_per_frame = -(-H * W // tr.T)
     return dict(evaluated_samples_per_frame=n_eval, sampled_per_frame=n_all, evaluated_frac=n_eval / max(n_all, 1),
-                samples_per_sec=n_eval / s_per_frame, gathers_per_sec=gathers / s_per_frame, gather_ceiling_per_s=ceiling,
-                gather_frac=(gathers / s_per_frame / ceiling) if ceiling else None,
+                samples_per_sec=n_eval / s_per_frame, nominal_gathers_per_sec=gathers / s_per_frame, distinct_address_gather_ceiling_per_s=ceiling,
+                gather_note="16 levels x 8 corners per table and evaluated sample; the lanes of a patch want 0.09 distinct cells per sample and level "
+                            "(tools/exp_patch_sharing.py) and a gather instruction costs its DISTINCT addresses (tools/gather_share.hip), so the nominal rate "
+                            "exceeds the ceiling measured for distinct addresses: the kernel is bound by instruction issue, not by the gather path",
                 mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_tflops_issued=3.0 * n_eval * 61952.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
                 mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
                 lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * tiles_per_frame)
@@ -973,11 +975,11 @@ def compact_line(out):
     """The line the driver parses: the contract's keys, `config` (which the driver keeps whole) with the headline numbers of every
     sub-record hoisted into it, a short `roofline` and `cpu_baseline`.  < 2,000 characters."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "samples_per_sec", "batch_samples_per_sec", "ranks_seen")
+            "samples_per_sec", "ranks_seen")
     line = {k: _r(out[k], 6) for k in keep if k in out}
     c = out["config"]
     cfg = {k: _r(c[k]) for k in ("workload", "rays_per_batch", "mean_samples_per_ray", "log2_table_size", "n_cameras", "n_tree_nodes", "stage", "early_T",
-                                  "alive_sample_frac", "evaluated_sample_frac", "evaluated_samples_per_sec", "backend", "loss") if c.get(k) is not None}
+                                  "alive_sample_frac", "evaluated_sample_frac", "backend", "loss") if c.get(k) is not None}
     cfg["launch"] = "graph" if str(c.get("launch", "")).startswith("hipGraph") else "eager"
     cfg["parallelism"] = c["parallelism"].split(":")[0].split(",")[0]
     if c.get("two_phase"):
@@ -999,34 +1001,41 @@ def compact_line(out):
 
     hoist("global_stage", (("ms_per_step", "global_ms_per_step"), ("value", "global_rays_per_sec"), ("launch_short", "global_launch"),
                            ("replicas_bit_identical", "replicas_bit_identical")))
+    if out.get("n_gpus", 1) == 1:
+        cfg.pop("global_launch", None)  # (the N > 1 line says whether the data-parallel step replays graph segments; at N = 1 it is "graph" like the headline)
     hoist("render", (("value", "render_ms_per_mpix"),))
     if isinstance(out.get("render"), dict) and isinstance(out["render"].get("roofline"), dict):
         rr = out["render"]["roofline"]
-        cfg["render_samples_per_sec"] = _r(rr["samples_per_sec"])
         if rr.get("mfma_busy_frac") is not None:
             cfg["render_mfma_busy_frac"] = _r(rr["mfma_busy_frac"])
-    hoist("plugin_step_focal", (("value", "plugin_rays_per_sec"), ("ms_per_step", "plugin_ms_per_step")))
-    hoist("plugin_step_global", (("value", "plugin_global_rays_per_sec"), ("ms_per_step", "plugin_global_ms_per_step")))
+    hoist("plugin_step_focal", (("ms_per_step", "plugin_ms_per_step"),))
+    hoist("plugin_step_global", (("ms_per_step", "plugin_global_ms_per_step"),))
     hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
     hoist("psnr", (("psnr_fast", "psnr"), ("psnr_reference", "psnr_reference"), ("delta", "psnr_delta"), ("se", "psnr_se"), ("n_seeds", "psnr_n_seeds"),
                    ("decoder_delta", "psnr_decoder_delta"), ("study_delta", "psnr_study_delta"), ("study_se", "psnr_study_se"), ("study_n_seeds", "psnr_study_n_seeds")))
     hoist("trained_state", (("value", "trained_rays_per_sec"), ("ms_per_step", "trained_ms_per_step"), ("alive_sample_frac", "trained_alive_sample_frac"),
                             ("evaluated_sample_frac", "trained_evaluated_sample_frac"), ("two_phase_K", "trained_two_phase_K"),
-                            ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step"),
-                            ("global_rays_per_sec", "trained_global_rays_per_sec")))
+                            ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
-    for k in ("mfma_busy_frac", "mfma_tflops_issued"):
+    for k in ("mfma_busy_frac",):
         if out["roofline"].get(k) is not None:
             cfg[k] = _r(out["roofline"][k])
     line["config"] = cfg
     ro = out["roofline"]
-    line["roofline"] = {k: _r(ro[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "alg_bytes_per_launch", "launches_per_step")
-                        if k in ro}
+    ro = line["roofline"] = {k: _r(ro[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "alg_bytes_per_launch", "launches_per_step")
+                             if k in ro}
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = dict(value=_r(cb["value"]), unit=cb["unit"], cores=cb["cores"], kind=cb["kind"], sample=cb["sample"].split(",")[0][:80])
     if errors:
         line["errors"] = errors
+    ro["kernel"] = str(ro.get("kernel", "")).split(" (")[0]
+    # the driver keeps the tail of the log: the line must stay under 2,000 characters whatever sub-records ran (everything is in [bench-details])
+    for k in ("cpu_torch_field_rays_per_sec", "batch_assembly_ms", "rays_per_batch", "loss", "global_rays_per_sec", "n_tree_nodes", "log2_table_size",
+              "trained_roofline_frac", "psnr_decoder_delta", "plugin_global_ms_per_step", "trained_two_phase_K"):
+        if len(json.dumps(line)) <= 1950:
+            break
+        cfg.pop(k, None)
     return line
 
 

@@ -60,6 +60,7 @@ class HotPathConfig:
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
                                      # hipGraph replay per (stage, block, buffer) after three eager runs: ~25 launches less for the host
+    graph_forward_shared_pool: bool = True  # the captured forwards share one memory pool (their transient buffers overlap; replays are sequential)
     graph_forward_keep: int = 4      # captured forwards kept (least recently used go first): each holds a full set of forward activations
                                      # (150-200 MB at 4096 x 192); 4 = two sample buffers x (the active block + the one before it)
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
@@ -657,10 +658,10 @@ class HotPath:
                 del self._fwd_graphs[k]
             for k in [k for k, e in self._fwd_graphs.items() if "graph" not in e and k != key][:-8]:
                 del self._fwd_graphs[k]
-            if self._fwd_pool is None:
+            if self._fwd_pool is None and c.graph_forward_shared_pool:
                 self._fwd_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._fwd_pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self._fwd_pool if c.graph_forward_shared_pool else None, capture_error_mode="thread_local"):
                 comp, ctx = self.forward_train(None, None, cam, None, stage, block, want_depth=want_depth, samples=samples)
                 self._join_aux()  # (the branch that builds the backward's list: inside the graph)
             ent.update(graph=g, cam=cam, comp=comp, ctx=ctx, last_forward=self.last_forward)

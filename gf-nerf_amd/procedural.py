@@ -158,42 +158,55 @@ class TorchAdam:
         hp.refresh_shadows()  # f16 shadows of the tables + the decoder's weight images follow the new values
 
 
-GRADIENT_LEGS = {  # HotPathConfig fields of the two gradient semantics grad_cosine compares from one state
-    "fast": dict(mlp_precision="x3", early_T=1e-4, two_phase=True, lds_accumulate=True),       # the product: x3 decoder, cut at T < 1e-4, exact LDS sums
-    "reference": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False),  # every sample, exact-f32 decoder, f16 atomics
-    "f32": dict(mlp_precision="f32"),                                                           # the product with the exact-f32 decoder only
+GRADIENT_LEGS = {  # HotPathConfig fields of the gradient semantics grad_cosine compares from one state
+    "fast": dict(mlp_precision="x3", early_T=1e-4, two_phase=True, lds_accumulate=True, grad_f16=True),         # the product: x3 decoder, cut at T < 1e-4, exact LDS sums
+    "reference": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, grad_f16=True),  # every sample, exact-f32 decoder, f16 x128 atomics
+    "exact": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, grad_f16=False),     # the same with an f32 gradient pool: the gradient both approximate
+    "f32": dict(mlp_precision="f32", early_T=1e-4, two_phase=True, lds_accumulate=True, grad_f16=True),         # the product with the exact-f32 decoder only
 }
 
 
 def grad_cosine(hp, batch, noise, s3, stage, block, legs=("reference", "fast")):
-    """One forward + backward of `batch` from the engine's current state under each of two gradient semantics (GRADIENT_LEGS; default: the
+    """One forward + backward of `batch` from the engine's current state under each of the gradient semantics `legs` (GRADIENT_LEGS; default: the
     reference's -- every sample, exact-f32 decoder, f16 atomic adds -- and the product's -- x3 decoder, early termination, phased forward,
-    exact LDS accumulation): cosine and relative difference of the two gradients per parameter group (no optimiser step, no octree update)."""
+    exact LDS accumulation): cosine and relative difference of the gradients per parameter group, for every pair of legs (no optimiser step,
+    no octree update).  -> {"a|b": {group: {cos, rel_diff (relative to a)}}}."""
     o, d, cam, gt = batch
     c = hp.cfg
-    saved = {k: getattr(c, k) for k in ("mlp_precision", "early_T", "two_phase", "lds_accumulate")}
+    keys = ("mlp_precision", "early_T", "two_phase", "lds_accumulate", "grad_f16")
+    saved = {k: getattr(c, k) for k in keys}
+    saved_pool = hp.table_grad
     got = {}
     n_live = 17 * (1 << c.log2_T)
     try:
         for leg in legs:
             for k, v in GRADIENT_LEGS[leg].items():
                 setattr(c, k, v)
+            if hp.table_grad is not None and (hp.table_grad.dtype == torch.float16) != c.grad_f16:
+                hp.table_grad = None  # (allocated again in this leg's pool type by the forward's zero_grads)
             hp._x3_stale = True
             hp.forward_backward(o, d, cam, gt, noise, stage=stage, block=block, s3im_index=s3, update_oct=False)
             hp._sync_opt()
-            g = dict(table=hp.table_grad.view(-1)[:n_live].double())
+            scale = 1.0 / 128.0 if hp.table_grad.dtype == torch.float16 else 1.0
+            g = dict(table=hp.table_grad.view(-1)[:n_live].double() * scale)
             if stage == hotpath.STAGE_GLOBAL:
                 g.update(mlp=hp.mlp_grad.double(), emb=hp.emb_grad.double())
             got[leg] = {k: v.clone() for k, v in g.items()}
     finally:
         for k, v in saved.items():
             setattr(c, k, v)
+        if saved_pool is not None and (hp.table_grad is None or hp.table_grad.dtype != saved_pool.dtype):
+            hp.table_grad = saved_pool
         hp._x3_stale = True
     out = {}
-    for k in got[legs[0]]:
-        a, b = got[legs[0]][k], got[legs[1]][k]
-        na, nb = float(a.norm()), float(b.norm())
-        out[k] = dict(cos=float((a * b).sum()) / max(na * nb, 1e-300), rel_diff=float((a - b).norm()) / max(na, 1e-300))
+    for i, la in enumerate(legs):
+        for lb in legs[i + 1:]:
+            pair = {}
+            for k in got[la]:
+                a, b = got[la][k], got[lb][k]
+                na, nb = float(a.norm()), float(b.norm())
+                pair[k] = dict(cos=float((a * b).sum()) / max(na * nb, 1e-300), rel_diff=float((a - b).norm()) / max(na, 1e-300))
+            out[f"{la}|{lb}"] = pair
     return out
 
 

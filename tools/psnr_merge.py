@@ -4,9 +4,14 @@
 import json, math, sys
 import numpy as np
 
-parts = [json.load(open(p)) for p in sys.argv[2:]]
-assert len({p["protocol"] for p in parts}) == 1, "parts were made with different protocols"
-out = {k: v for k, v in parts[0].items() if k != "psnr_study"}
+every = [json.load(open(p)) for p in sys.argv[2:]]
+assert len({p["protocol"] for p in every}) == 1, "parts were made with different protocols"
+parts = [p for p in every if "psnr_study" in p]
+out = dict(protocol=every[0]["protocol"])
+for p in every:  # gradient-cosine trajectory / octree study: the LAST file that carries them (an aux-only call, or part 0)
+    for k in ("grad_cosine", "octree_study"):
+        if k in p:
+            out[k] = p[k]
 out["parts"] = [dict(seed0=p.get("seed0", 0), argv=p["argv"]) for p in parts]
 st0 = parts[0]["psnr_study"]
 legs = st0["legs"]

@@ -34,15 +34,21 @@ def save():
 def aux_sections():
     # ---- 1. one trajectory: gradient cosine every 100 steps
     t0 = time.perf_counter()
-    r = procedural.train_and_eval(sc, seed=0, steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, cosine_every=100, **procedural.LEGS["fast"])
+    r = procedural.train_and_eval(sc, seed=0, steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, cosine_every=100,
+                                  cosine_legs=("exact", "reference", "fast", "f32"), **procedural.LEGS["fast"])
     cos = r.pop("grad_cosine")
-    res["grad_cosine"] = dict(every=100, seed=0, min_cos={g: min(c[g]["cos"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
-                              max_rel_diff={g: max(c[g]["rel_diff"] for _, _, c in cos if g in c) for g in ("table", "mlp", "emb")},
-                              trajectory=[(st, i, {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c.items()}) for st, i, c in cos],
-                              note="cos / relative L2 difference of the gradient of one batch from one state under the reference's gradient semantics (every sample, exact-f32 "
-                                   "decoder, f16 atomic adds) and under the product's (x3 decoder, early termination, phased forward, exact LDS sums); table: the f16 x128 "
-                                   "pools, i.e. including the pool's own rounding")
-    say(f"gradient cosine: min {res['grad_cosine']['min_cos']} ({time.perf_counter() - t0:.0f} s)")
+    pairs = sorted(cos[0][2])
+    groups = ("table", "mlp", "emb")
+    res["grad_cosine"] = dict(every=100, seed=0, legs={k: v for k, v in procedural.GRADIENT_LEGS.items()},
+                              min_cos={p: {g: min(c[p][g]["cos"] for _, _, c in cos if g in c[p]) for g in groups} for p in pairs},
+                              max_rel_diff={p: {g: max(c[p][g]["rel_diff"] for _, _, c in cos if g in c[p]) for g in groups} for p in pairs},
+                              mean_rel_diff={p: {g: float(np.mean([c[p][g]["rel_diff"] for _, _, c in cos if g in c[p]])) for g in groups} for p in pairs},
+                              trajectory=[(st, i, {p: {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c[p].items()} for p in ("exact|reference", "exact|fast", "fast|f32")})
+                                          for st, i, c in cos],
+                              note="cos / relative L2 difference of the gradient of one batch from one state under pairs of gradient semantics: exact = every sample, exact-f32 "
+                                   "decoder, f32 gradient pool; reference = the same with the reference's f16 x128 atomic adds; fast = the product (x3 decoder, cut at T < 1e-4, "
+                                   "phased forward, exact LDS sums rounded to f16 once); f32 = the product with the exact-f32 decoder")
+    say(f"gradient cosine: min {res['grad_cosine']['min_cos']} mean rel diff {res['grad_cosine']['mean_rel_diff']} ({time.perf_counter() - t0:.0f} s)")
     save()
 
     # ---- 2. octree study: the global stage from one seed with early_T = 1e-4 (exact alphas for K5) | early_T = 0 | early_T = 1e-4 the rounds 2-3 way
@@ -77,8 +83,10 @@ def aux_sections():
 
 
 
-if seed0 == 0:
+if seed0 == 0 or os.environ.get("GFN_STUDY_AUX_ONLY") == "1":
     aux_sections()
+if os.environ.get("GFN_STUDY_AUX_ONLY") == "1":  # the gradient-cosine trajectory and the octree study alone (merged with the seed ranges' parts)
+    sys.exit(0)
 
 # ---- 3. the paired study
 t0 = time.perf_counter()
