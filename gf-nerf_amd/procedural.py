@@ -163,6 +163,7 @@ GRADIENT_LEGS = {  # HotPathConfig fields of the gradient semantics grad_cosine 
     "reference": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, grad_f16=True),  # every sample, exact-f32 decoder, f16 x128 atomics
     "exact": dict(mlp_precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, grad_f16=False),     # the same with an f32 gradient pool: the gradient both approximate
     "f32": dict(mlp_precision="f32", early_T=1e-4, two_phase=True, lds_accumulate=True, grad_f16=True),         # the product with the exact-f32 decoder only
+    "fast0": dict(mlp_precision="x3", early_T=0.0, two_phase=True, lds_accumulate=True, grad_f16=True),         # the product without the cut (every sample)
 }
 
 

@@ -1207,8 +1207,10 @@ def test_psnr_of_the_product_against_the_reference_semantics():
     tests/test_procedural.py; the record over many seeds at full length is profiles/r04_psnr_study.json, made by tools/psnr_study.py):
       1. the decoder arithmetic alone: every trained state rendered with the split-f16 x3 decoder and with the exact-f32 decoder (the
          reference's nn.Linear, gfnerf/mlp.py:35-57) gives the same PSNR to 0.01 dB -- no training chaos involved;
-      2. along a training run the gradient of a batch computed with either decoder has cosine >= 0.9999 in every parameter group, and the
-         product's gradient (x3, cut at T < 1e-4, exact LDS sums) is at least as close to the f32-pool gradient as the reference's (f16 atomics);
+      2. along a training run the gradient of a batch computed with either decoder has cosine >= 0.9999 in every parameter group; the product
+         without the cut (x3, exact LDS sums, every sample) is within the f16 pool's rounding of the f32-pool gradient (cosine >= 0.99999); the cut
+         at T < 1e-4 is what moves the gradient (cosine >= 0.995): Charbonnier's gradient is sign-like, and a colour change of up to 1e-4 flips it
+         on the rays whose error is that small;
       3. trained end to end (reduced length: 1,500 + 400 steps, four seeds), the product's leg ("fast") against the reference-semantics leg
          ("reference": early_T = 0, every sample, exact-f32 decoder, f16 atomics, torch.optim.Adam; engine/trainer.py:382-441,
          gfnerf/nerfacto.py:522-619,628-689), paired by seed: |mean difference| <= 0.1 dB + 2 standard errors.  One training run is one draw
@@ -1228,12 +1230,13 @@ def test_psnr_of_the_product_against_the_reference_semantics():
     assert r["n_seeds"] == 4 and r["se"] is not None
     assert abs(r["delta"]) <= 0.1 + 2.0 * r["se"], (r["delta"], r["se"], r["delta_runs"])  # 3.
     c = procedural.train_and_eval(sc, seed=0, steps_global=400, steps_focal=200, eval_rays=4096, detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL, cosine_every=100,
-                                  cosine_legs=("exact", "reference", "fast", "f32"), **procedural.LEGS["fast"])["grad_cosine"]
+                                  cosine_legs=("exact", "reference", "fast", "f32", "fast0"), **procedural.LEGS["fast"])["grad_cosine"]
     assert len(c) == 6
     for stage, step, pairs in c:                                                            # 2.
         for g, v in pairs["fast|f32"].items():      # the decoder arithmetic alone (everything else the product's)
             assert v["cos"] >= 0.9999, (stage, step, g, v)
-        for g in pairs["exact|fast"]:               # against the gradient with an f32 pool: the product is at least as close as the reference's f16 atomics
-            assert pairs["exact|fast"][g]["cos"] >= 0.999 and pairs["exact|reference"][g]["cos"] >= 0.999, (stage, step, g, pairs)
-            assert pairs["exact|fast"][g]["rel_diff"] <= 1.5 * pairs["exact|reference"][g]["rel_diff"] + 1e-3, (stage, step, g, pairs)
+        for g, v in pairs["exact|fast0"].items():   # x3 decoder + exact LDS sums, every sample, against the f32-pool gradient: f16-pool rounding only
+            assert v["cos"] >= 0.99999 and v["rel_diff"] <= 3e-3, (stage, step, g, v)
+        for g, v in pairs["exact|fast"].items():    # with the cut: the <= 1e-4 colour change flips Charbonnier's sign-like gradient on the few rays at |error| < 1e-4
+            assert v["cos"] >= 0.995, (stage, step, g, v)
     torch.cuda.empty_cache()

@@ -35,7 +35,7 @@ def aux_sections():
     # ---- 1. one trajectory: gradient cosine every 100 steps
     t0 = time.perf_counter()
     r = procedural.train_and_eval(sc, seed=0, steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, cosine_every=100,
-                                  cosine_legs=("exact", "reference", "fast", "f32"), **procedural.LEGS["fast"])
+                                  cosine_legs=("exact", "reference", "fast", "f32", "fast0"), **procedural.LEGS["fast"])
     cos = r.pop("grad_cosine")
     pairs = sorted(cos[0][2])
     groups = ("table", "mlp", "emb")
@@ -43,11 +43,11 @@ def aux_sections():
                               min_cos={p: {g: min(c[p][g]["cos"] for _, _, c in cos if g in c[p]) for g in groups} for p in pairs},
                               max_rel_diff={p: {g: max(c[p][g]["rel_diff"] for _, _, c in cos if g in c[p]) for g in groups} for p in pairs},
                               mean_rel_diff={p: {g: float(np.mean([c[p][g]["rel_diff"] for _, _, c in cos if g in c[p]])) for g in groups} for p in pairs},
-                              trajectory=[(st, i, {p: {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c[p].items()} for p in ("exact|reference", "exact|fast", "fast|f32")})
+                              trajectory=[(st, i, {p: {g: [round(v["cos"], 9), round(v["rel_diff"], 6)] for g, v in c[p].items()} for p in ("exact|reference", "exact|fast", "exact|fast0", "fast|f32")})
                                           for st, i, c in cos],
                               note="cos / relative L2 difference of the gradient of one batch from one state under pairs of gradient semantics: exact = every sample, exact-f32 "
                                    "decoder, f32 gradient pool; reference = the same with the reference's f16 x128 atomic adds; fast = the product (x3 decoder, cut at T < 1e-4, "
-                                   "phased forward, exact LDS sums rounded to f16 once); f32 = the product with the exact-f32 decoder")
+                                   "phased forward, exact LDS sums rounded to f16 once); f32 = the product with the exact-f32 decoder; fast0 = the product without the cut (early_T = 0)")
     say(f"gradient cosine: min {res['grad_cosine']['min_cos']} mean rel diff {res['grad_cosine']['mean_rel_diff']} ({time.perf_counter() - t0:.0f} s)")
     save()
 
