@@ -288,9 +288,15 @@ class HotPath:
         s["loss0_buf"] = s["loss0"]  # forward_backward pops "loss0"; the buffer stays for the next in-place refill
         return s
 
+    def _new_side_stream(self):
+        """The second stream (next batch's draw + sampler, octree update).  (Round 4: a LOW-priority second stream, so that the backward's
+        workgroups are dispatched ahead of the sampler's when both become ready together, is not available -- this stack's priority range
+        is (0, -1): normal and high only.)"""
+        return torch.cuda.Stream(device=self.dev)
+
     def side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = self._new_side_stream()
         return self._side
 
     def defer(self, fn):
@@ -314,7 +320,7 @@ class HotPath:
         order."""
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = self._new_side_stream()
         if after is not None:  # an event of the current stream: what the side branch has to wait for (not everything enqueued since)
             self._side.wait_event(after)
         else:

@@ -100,7 +100,7 @@ class StepGraph:
         p, block = j % 2, self.blocks[j % len(self.blocks)]
         main = torch.cuda.current_stream()
         if hp._side is None:
-            hp._side = torch.cuda.Stream(device=hp.dev)
+            hp._side = hp._new_side_stream()
         side = hp._side
 
         def draws():  # the NEXT step's random draws, on the device: started behind this step's lookups (a sort beside them

@@ -201,3 +201,42 @@ def test_choose_tile_divides_the_frame():
         assert tw * th <= max(h * w, 1) and (tw * th >= 0.4 * min(131072, h * w))
     assert choose(1080, 1920) == (384, 360)
     assert choose(1080, 1917)[0] == 128  # no width divides 1917 into multiples of 8: fixed-width tiles with ragged borders
+
+
+def test_bench_line_stays_under_two_thousand_characters():
+    """The driver keeps the tail of the log: bench.compact_line must fit every sub-record's headline figures into < 2,000 characters (the
+    full records go to stderr as [bench-details])."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    f = 1234567.891234
+    out = dict(metric="train_rays_per_sec", value=f, unit="rays/s", n_gpus=1, steps=50, warmup=5, ms_per_step=1.35164321, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f32 (split-f16 x3 MFMA decoder, f16 table)", data="synthetic", samples_per_sec=f * 300, batch_samples_per_sec=f * 400, ranks_seen=1,
+               config=dict(workload="GF-NeRF global+focal train step, 4 focal blocks resident (1 active/step), 4096 rays x 192 samples, Rubble-scale synthetic cameras",
+                           rays_per_batch=4096, mean_samples_per_ray=192.51234, log2_table_size=21, n_cameras=1600, n_tree_nodes=10809, stage="focal", early_T=1e-4,
+                           alive_sample_frac=0.5681234, evaluated_sample_frac=0.6749412, backend=None, loss=1.683412, launch="hipGraph replay (8 captured graphs)",
+                           parallelism="single GPU", two_phase=dict(K=130), allreduce_selfcheck=None),
+               roofline=dict(bound="hbm", kernel="lm_lookup_kernel<true, false> (+ <true, true>: the second table accumulates)", achieved=1242.01234, peak=8000.0, unit="GB/s",
+                             frac=0.1552512, traffic=1033260646, avg_kernel_ms=0.2828112, alg_bytes_per_launch=351253980, launches_per_step=2, mfma_busy_frac=0.3612),
+               global_stage=dict(ms_per_step=1.926412, value=f, launch_short="graph", replicas_bit_identical=None),
+               render=dict(value=51.655123, roofline=dict(samples_per_sec=f * 1000, mfma_busy_frac=0.3039)),
+               plugin_step_focal=dict(value=f, ms_per_step=1.817712), plugin_step_global=dict(value=f, ms_per_step=2.028512), batch_assembly=dict(ms_per_batch=0.1041123),
+               psnr=dict(psnr_fast=33.668123, psnr_reference=33.565123, delta=0.1026612, se=0.1582212, n_seeds=3, decoder_delta=1.2716e-06, study_delta=0.012345, study_se=0.048712,
+                         study_n_seeds=148),
+               trained_state=dict(value=f, ms_per_step=1.583012, alive_sample_frac=0.8626212, evaluated_sample_frac=1.0, two_phase_K=1024, roofline_frac=0.2323312,
+                                  global_ms_per_step=1.782412, global_rays_per_sec=f),
+               cpu_reference_field=dict(train_rays_per_sec=4227.212), cpu_baseline=dict(value=712.0812, unit="rays/s", cores=256, kind="port",
+                                                                                        sample="2048 rays (392816 samples) of the same batch, oracle fwd+bwd (no Adam), 2.9 s; all stages OpenMP"))
+    line = bench.compact_line(out)
+    text = json.dumps(line)
+    assert len(text) < 2000, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    c = line["config"]
+    for key in ("workload", "trained_rays_per_sec", "trained_ms_per_step", "psnr", "psnr_reference", "psnr_delta", "psnr_se", "psnr_n_seeds", "psnr_study_delta", "psnr_study_se",
+                "psnr_study_n_seeds", "render_ms_per_mpix", "global_ms_per_step", "plugin_ms_per_step"):
+        assert key in c, key
+    assert line["roofline"]["kernel"] == "lm_lookup_kernel<true, false>" and set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}

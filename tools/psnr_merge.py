@@ -26,11 +26,16 @@ for leg in legs:
     for key in (f"psnr_global_{leg}", f"psnr_heldout_{leg}"):
         if key in st0:
             st[key] = float(np.average([p["psnr_study"][key] for p in parts], weights=[len(p["psnr_study"]["seeds"]) for p in parts]))
-for name in ("delta", "decoder_delta"):
-    runs = sum((p["psnr_study"][f"{name}_runs"] for p in parts), [])
-    st[f"{name}_runs"] = runs
-    st[name] = float(np.mean(runs))
-    st["se" if name == "delta" else "decoder_se"] = float(np.std(runs, ddof=1) / math.sqrt(len(runs)))
+runs = sum((p["psnr_study"]["delta_runs"] for p in parts), [])
+st["delta_runs"] = runs
+st["delta"] = float(np.mean(runs))
+st["se"] = float(np.std(runs, ddof=1) / math.sqrt(len(runs)))
+# the same-state decoder differences are ~1e-6 dB: the per-seed list is rounded to 1e-3, so the parts' own means / standard errors are combined
+ns = np.array([len(p["psnr_study"]["seeds"]) for p in parts], np.float64)
+st["decoder_delta_runs"] = sum((p["psnr_study"]["decoder_delta_runs"] for p in parts), [])
+st["decoder_delta"] = float(np.sum(ns * np.array([p["psnr_study"]["decoder_delta"] for p in parts])) / ns.sum())
+st["decoder_se"] = float(np.sqrt(np.sum((ns * np.array([p["psnr_study"]["decoder_se"] or 0.0 for p in parts])) ** 2)) / ns.sum())
+st["decoder_delta_max_abs_run"] = float(max(abs(v) for v in st["decoder_delta_runs"]))
 st["n_seeds"] = len(st["seeds"])
 st["seconds"] = sum(p["psnr_study"].get("seconds", 0.0) for p in parts)
 out["psnr_study"] = st
