@@ -670,7 +670,7 @@ class StageRun:
             self.batches, self.batches_np = list(engine["batches"]), None
             self.target = TARGET_SAMPLES[stage]
             self.fineness, self.mean_samples = pick_fineness(hp, self.batches[0][0], self.batches[0][1], self.target, scene, torch)
-            self.draw_stream = torch.cuda.Stream()
+            self.draw_stream = ops.concurrent_stream()
             self.drawn = {}
             self.i = 0
             return
@@ -715,7 +715,7 @@ class StageRun:
         # The march noise (PersSampler_cuda.cu:380-389) and S3IM's arange + 9 permutations (losses.py:780-789) are drawn on the
         # device EVERY step, inside the timed region like the reference does: step i draws them for step i + 1 on a third stream
         # (they depend on nothing), beside the step's own kernels.
-        self.draw_stream = torch.cuda.Stream()
+        self.draw_stream = ops.concurrent_stream()
         self.drawn = {}
         self.i = 0
 

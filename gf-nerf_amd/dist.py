@@ -238,7 +238,9 @@ class TrainSync:
         if self.overlap and tensors and tensors[0].is_cuda:
             cur = torch.cuda.current_stream()
             if self._stream is None:
-                self._stream = torch.cuda.Stream(device=tensors[0].device)
+                from . import ops
+
+                self._stream = ops.concurrent_stream(tensors[0].device)  # (a stream sharing the launch stream's hardware queue would not overlap)
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
                 self._reduce(tensors)

@@ -289,10 +289,8 @@ class HotPath:
         return s
 
     def _new_side_stream(self):
-        """The second stream (next batch's draw + sampler, octree update).  (Round 4: a LOW-priority second stream, so that the backward's
-        workgroups are dispatched ahead of the sampler's when both become ready together, is not available -- this stack's priority range
-        is (0, -1): normal and high only.)"""
-        return torch.cuda.Stream(device=self.dev)
+        """The second stream (next batch's draw + sampler, octree update): one that demonstrably runs BESIDE the current stream (ops.concurrent_stream)."""
+        return ops.concurrent_stream(self.dev)
 
     def side_stream(self):
         if self._side is None:
@@ -441,7 +439,7 @@ class HotPath:
         # (two dependent small launches less between the compositing and the backward); joined by backward() / the next forward
         main = torch.cuda.current_stream()
         if self._aux_stream is None:
-            self._aux_stream = torch.cuda.Stream(device=self.dev)
+            self._aux_stream = ops.concurrent_stream(self.dev)
         self._aux_stream.wait_stream(main)
         with torch.cuda.stream(self._aux_stream):
             if planes is None:  # (focal stage) the backward walks exactly the samples in front of the termination points
@@ -857,7 +855,7 @@ class HotPath:
                                            hy(f"block{block}"))
             if c.async_adam and c.level_major:
                 if self._opt_stream is None:
-                    self._opt_stream = torch.cuda.Stream(device=self.dev)
+                    self._opt_stream = ops.concurrent_stream(self.dev)
                 self._opt_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._opt_stream):
                     run()

@@ -1260,6 +1260,44 @@ def copy_list(pairs):
     _lib.check(_lib.lib().gfn_copy_list(src, dst, nb, n, _stream()), "gfn_copy_list")
 
 
+def concurrent_stream(device=None):
+    """A new stream that demonstrably runs BESIDE the current one.  HIP maps streams onto a few hardware queues in creation order, so whether a new
+    stream shares its queue with the stream the step is launched on -- and then runs behind it, not beside it -- depends on how many streams the
+    process made before (round 4: the plugin surface's focal iteration took 1.81 or 1.55 ms depending on whether bench.py had rendered first; with
+    this probe 1.55 either way).  Up to 8 candidates, each probed once: a ~2.5 ms spin on the current stream, a tiny kernel on the candidate -- does
+    the candidate's event complete while the spin still runs?  ~20 ms once per stream made; a plain stream under capture (graph branches are not
+    queues) or with GFN_SIDE_STREAM_PROBE=0."""
+    import os
+    import time
+
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if os.environ.get("GFN_SIDE_STREAM_PROBE", "1") != "1" or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    probe = torch.zeros(64, dtype=torch.float32, device=device)
+    kept = []  # (candidates that share the queue stay allocated until one is found: a fresh one would land on the same queue again)
+    for _ in range(8):
+        cand = torch.cuda.Stream(device=device)
+        kept.append(cand)
+        torch.cuda.synchronize(device)
+        done, spun = torch.cuda.Event(), torch.cuda.Event()
+        torch.cuda._sleep(6_000_000)
+        spun.record(main)
+        with torch.cuda.stream(cand):
+            probe.add_(1.0)
+            done.record(cand)
+        t0 = time.perf_counter()
+        beside = False
+        while time.perf_counter() - t0 < 2.0e-3:
+            if done.query():
+                beside = not spun.query()
+                break
+        torch.cuda.synchronize(device)
+        if beside:
+            return cand
+    return kept[0]
+
+
 def fill_zero(t):
     _lib.check(_lib.lib().gfn_fill_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "gfn_fill_zero")
 
