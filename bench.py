@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--trained-seeds", type=str, default="0,1",
                     help="`trained_state` sub-records (N = 1): engine seeds whose procedurally TRAINED state (global stage, then 4 focal blocks in rotation) the same "
                          "steps are timed on; empty = none")
-    ap.add_argument("--trained-steps", type=int, default=100, help="timed steps of a trained-state record")
+    ap.add_argument("--trained-steps", type=int, default=300, help="timed steps of a trained-state record")
     ap.add_argument("--psnr-steps", type=str, default="3000,1000",
                     help="`psnr` and `trained_state` sub-records (N = 1): global,focal training steps on the procedural scene per run "
                          "(gfnerf_amd.procedural.STUDY_STEPS); 0,0 = skip")
@@ -618,6 +618,7 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
         hp.phase_override = None
         return dict(ms_per_step=ms, rays_per_sec=N_RAYS / (ms * 1e-3), mean_samples_per_ray=n_live / N_RAYS, alive_sample_frac=float((w > 0).float().mean().item()),
                     evaluated_sample_frac=n_eval / max(n_live, 1), evaluated_samples_per_sec=n_eval / (ms * 1e-3), two_phase=run.phase, forward=hp.last_forward,
+                    recaptures_in_timed_region=res["recaptures"], timed_steps=args.trained_steps,
                     launch=run.launch, fineness=run.fineness, loss=res["loss"],
                     roofline={k: roof[k] for k in ("kernel", "launches_per_step", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "alg_bytes_per_launch", "kernel_ms")})
 
@@ -834,6 +835,7 @@ class StageRun:
         events = {"*"} if self.args.stage_times else {"fused_fwd", "bwd_scatter", "grad_reduce", "hash_fwd", "hash_bwd", "field_fwd", "field_bwd", "wgrad", "adam"}
         hp.timings = {}
         hp.timed_ops = set() if sg is not None else events
+        captures0 = sg.captures if sg is not None else 0
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -863,7 +865,10 @@ class StageRun:
                 loss, aux = self.step()
             torch.cuda.synchronize()
         hp.timed_ops = set()
-        return dict(elapsed=elapsed, host_enqueue=host_enqueue, loss=loss_value, aux=aux, steps=steps, event_steps=probe)
+        # (a re-plan of the phases inside the timed region -- StepGraph.step: K idle for 16 replays, or replan_every -- is a synchronisation + capture
+        # of every graph of the cycle, ~30 ms: it belongs to the product's step and stays in the time; the count says that it happened)
+        return dict(elapsed=elapsed, host_enqueue=host_enqueue, loss=loss_value, aux=aux, steps=steps, event_steps=probe,
+                    recaptures=(sg.captures - captures0) if sg is not None else 0)
 
     def roofline(self, res):
         """Dominant kernel by event time per step + its algorithmic bytes (DESIGN.md "Kernels")."""
@@ -1159,7 +1164,7 @@ def run_rank(args):
                                graph_warmup_steps=GRAPH_WARMUP if run.launch.startswith("hipGraph") else 0,
                                host_enqueue_ms_per_step=res["host_enqueue"] / args.steps * 1e3,
                                async_adam=bool(cfg.async_adam), per_step_draws="march noise + S3IM permutations drawn on the device every timed step",
-                               two_phase=run.phase, allreduce_selfcheck=selfcheck, loss=res["loss"]),
+                               two_phase=run.phase, allreduce_selfcheck=selfcheck, loss=res["loss"], recaptures_in_timed_region=res["recaptures"]),
                    roofline=roofline)
 
     state = dict(pending=None)

@@ -77,6 +77,7 @@ class StepGraph:
         self.replan_every, self._since_capture, self.phased = int(replan_every), 0, None
         self._k_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()  # the plan's K as the replays leave it (copied inside the graph)
         self._idle = 0
+        self.captures = 0  # how often the step was captured (the first time, tree changes, re-plans of the phases)
 
     # ------------------------------------------------------------------ set-up
     def _noise(self, out=None):
@@ -134,6 +135,7 @@ class StepGraph:
         the graph's pool and be re-initialised by every replay -- so at least one EAGER train_step of this stage comes first."""
         assert self.primed, "StepGraph.prime(first batch's rays) before the first step"
         hp = self.hp
+        self.captures += 1
         if hp.table_grad is None or (self.stage == hp_mod.STAGE_GLOBAL and hp._plane_bufs is None and hp.cfg.fused_field):
             raise _lib.GfnError("StepGraph: run one eager HotPath.train_step of this stage before capturing (lazily created buffers)")
         for name, _ in self.groups:
