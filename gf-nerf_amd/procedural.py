@@ -5,13 +5,15 @@ of a ray is the front-to-back quadrature of that field (rays.py:178-200's weight
 background, renderers.py:109-110), evaluated with plain torch ops on whatever device the rays live on -- the same closed form the
 CPU fixture tests/golden/procedural_gt.npz was made with through the oracle's compositing (tests/golden/make_procedural.py).
 
-`train_and_eval` trains the engine (global stage, then one focal block) on rays of this scene with the product's own step and
-reports PSNR on held-out rays; `psnr_study` (bench.py's `psnr` sub-record) runs it for the split-f16 `x3` decoder and for the exact-f32
-decoder -- the stand-in for the reference's f32 nn.Linear (gfnerf/mlp.py:35-57) -- over several seeds each.  Several, because one
-training run is one draw: Adam with eps = 1e-15 (gfnerf/config.py:130) turns the first last-bit difference of a near-zero table gradient
-into a step of the full learning rate, and from there the two arithmetics (or two seeds of one) follow different trajectories whose
-PSNR scatters by ~0.5 dB (measured: tools/exp_x3_vs_f32_traj.py trains both in lockstep -- single steps from a common state agree to
-1e-6 in every gradient, tools/exp_x3_vs_f32_step.py).  The two decoders are compared through their means."""
+`train_and_eval` trains the engine (global stage, then the focal block(s)) on rays of this scene with the product's own step and reports PSNR on
+held-out rays; `psnr_study` (bench.py's `psnr` sub-record, tools/psnr_study.py) runs it for two LEGS over several seeds, paired by seed: "fast" =
+the product as shipped, "reference" = the reference's training semantics (every sample, exact-f32 decoder, f16 atomic adds, torch.optim.Adam).
+Round 4's protocol (PROTOCOL, STUDY_*): fresh random rays every step, one fixed held-out set for every seed and leg, a five-octave colour texture in
+the ground truth, 3,000 + 1,000 steps with the rate decayed x 0.1 per stage.  Several seeds, because one training run is one draw: Adam with
+eps = 1e-15 (gfnerf/config.py:130) turns the first last-bit difference of a near-zero gradient into a step of the full learning rate, Charbonnier's
+gradient is sign-like, and from there two runs (or two arithmetics of one) follow different trajectories whose PSNR scatters by ~0.5 dB; single steps
+from a common state agree (grad_cosine; tools/exp_x3_vs_f32_step.py).  The legs are compared through their means over many seeds
+(profiles/r04_psnr_study.json) and, without any training chaos, through the same trained states rendered with either decoder."""
 import math
 
 import numpy as np
