@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r02p
 mkdir -p $O
 export TMPDIR=/tmp
-B=/root/repo/bench.py
+B=$GRAFT_REPO_ROOT/bench.py
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"
 cd /tmp
@@ -30,7 +30,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 for C in FETCH_SIZE "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B"; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d $O/calib_$T -- /root/repo/tools/fetch_calib.bin > $O/calib_$T.txt 2>$O/calib_$T.err || echo "calib $T failed"
+  rocprofv3 --pmc $C --output-format csv -d $O/calib_$T -- $GRAFT_REPO_ROOT/tools/fetch_calib.bin > $O/calib_$T.txt 2>$O/calib_$T.err || echo "calib $T failed"
 done
 echo "calibration done"
 # keep the merged output small: the raw traces are not needed, the stats and counter tables are

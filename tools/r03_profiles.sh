@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r03p
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-B=/root/repo/bench.py
+B=$GRAFT_REPO_ROOT/bench.py
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err
 grep "bench-details" $O/bench.err | sed 's/^\[bench-details\] //' > $O/bench_details.json
 echo "bench done"
@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_global_graph -- py
 echo "kt global graph done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
 echo "kt render done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_plugin_focal -- python3 /root/repo/tools/plugin_trace.py focal 100 > $O/plugin_focal_under_rocprof.txt 2>$O/kt_plugin_focal.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_plugin_focal -- python3 $GRAFT_REPO_ROOT/tools/plugin_trace.py focal 100 > $O/plugin_focal_under_rocprof.txt 2>$O/kt_plugin_focal.err
 echo "kt plugin done"
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B" "TCC_HIT TCC_MISS" "TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   T=$(echo $C | tr ' ' '_')
