@@ -494,31 +494,32 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
   if (in_range && k == 0) counts[ray] = cnt;
 }
 
-// tree sum of one value per lane over lanes 0..11 of each 16-lane row, association of sum12():
-// ((q0+(q1+q2)) + (q3+(q4+q5))) + ((q6+(q7+q8)) + (q9+(q10+q11))); the result is valid on lane 0 of the row.
-// lane i of a 16-lane row reads lane i+N of the same row (0 beyond the row): DPP row_shl, no LDS traffic
-template <int N>
-__device__ __forceinline__ float row_down(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+// lane i of a quad (4 neighbouring lanes) reads lane i ^ 1 / lane i ^ 2 of the same quad: DPP quad_perm, no LDS traffic
+__device__ __forceinline__ float quad_x1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
 }
-// lane i of a 16-lane row reads lane i-N of the same row (0 below the row): DPP row_shr
-template <int N>
-__device__ __forceinline__ float row_up(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xF, 0xF, true));
+__device__ __forceinline__ float quad_x2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float row_sum12(float q) {
-  const float a = q + row_down<1>(q);   // lanes 3k+1: q[3k+1] + q[3k+2]
-  const float b = q + row_down<1>(a);   // lanes 3k  : q[3k] + (q[3k+1] + q[3k+2])
-  const float c = b + row_down<3>(b);   // lanes 0, 6: s0 + s1, s2 + s3
-  return c + row_down<6>(c);            // lane 0
+// Sum over the 12 projections in the association of sum12(): ((q0+(q1+q2)) + (q3+(q4+q5))) + ((q6+(q7+q8)) + (q9+(q10+q11))).
+// Lane k of the quad brings q[3k], q[3k+1], q[3k+2]; its own triple is the innermost bracket, two exchanges finish the tree
+// (a + b and b + a are the same float), and EVERY lane of the quad ends with the result.
+__device__ __forceinline__ float quad_sum12(float q0, float q1, float q2) {
+  const float s = q0 + (q1 + q2);
+  const float t = s + quad_x1(s);
+  return t + quad_x2(t);
 }
 
-constexpr int kGroup = 16;                 // lanes per ray
-constexpr int kRaysPerBlock = 256 / kGroup;  // 16 rays per 256-thread workgroup
+constexpr int kGroup = 4;                            // lanes per ray: lane k owns projections 3k, 3k+1, 3k+2
+constexpr int kMarchThreads = 64;                    // one wave per workgroup: 4096 training rays spread over 256 CUs
+constexpr int kRaysPerBlock = kMarchThreads / kGroup;  // 16 rays per wave
 
-// K4 with a 16-lane row per ray.  Hits come from the dense slots of trace_dense_kernel.
+// K4 with a quad of lanes per ray.  Hits come from the dense slots of trace_group_kernel.  (Until round 4 a ray had a 16-lane row, one
+// projection per lane: the step's ~300 instructions served 4 rays of a wave -- 12 contractions x 4 DPP steps with 4 .. 1 useful lanes
+// each -- and a render tile's march cost a third of the CU time of the tile.  With three projections per lane the innermost bracket
+// of sum12() is lane-local, the same ~300 instructions serve 16 rays, and nothing about the arithmetic changes.)
 template <bool FILL>
-__global__ __launch_bounds__(256) void march_group_kernel(
+__global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
     int n_rays, float sample_l, int scale_by_dis, int table_space, int max_hits,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ noise_all,
     const int* __restrict__ hit_counts, const int* __restrict__ hit_idx, const float2* __restrict__ hit_nf,
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(256) void march_group_kernel(
     const int* __restrict__ pts_offsets, float* __restrict__ world_pts, float* __restrict__ warped_pts,
     float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
     int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow,
-    float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf} for fill_from_rec_kernel, or NULL */) {
-  const int g = threadIdx.x & (kGroup - 1);          // projection index owned by this lane (0..11 live)
+    float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf, warped point} for fill_from_rec_kernel, or NULL */) {
+  const int k = threadIdx.x & (kGroup - 1);
   const int ray = blockIdx.x * kRaysPerBlock + (threadIdx.x / kGroup);
   const bool in_range = ray < n_rays;
   const int r = in_range ? ray : 0;
@@ -537,82 +538,100 @@ __global__ __launch_bounds__(256) void march_group_kernel(
   const int n_oct = in_range ? hit_counts[r] : 0;
   hit_idx += (int64_t)r * max_hits;
   hit_nf += (int64_t)r * max_hits;
+  if (rec) rec += (int64_t)r * GFN_MAX_SAMPLE_PER_RAY * GFN_MARCH_REC_FLOATS;
   int max_n = GFN_MAX_SAMPLE_PER_RAY;
   int64_t base = 0;
   if (FILL) {
     base = pts_offsets[r];
     int64_t end = pts_offsets[r + 1];
-    if (end > pts_cap) { end = pts_cap; if (overflow && g == 0) atomicOr(overflow, 4); }
+    if (end > pts_cap) { end = pts_cap; if (overflow && k == 0) atomicOr(overflow, 4); }
     max_n = (int)(end > base ? end - base : 0);
     if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;
-    if (in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
+    if (in_range && k == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
   }
   bool active = in_range && max_n > 0 && n_oct > 0;
   int pts_ptr = 0, oct_ptr = 0;
   int nz_base = -1;
-  float nz = 0.f;
+  float nz[4] = {0.f, 0.f, 0.f, 0.f};
   int cur_oct_idx = active ? hit_idx[0] : 0;
   float2 nf = active ? hit_nf[0] : make_float2(0.f, 0.f);
   float cur_t = nf.x, cur_far = nf.y, cur_near = nf.x;
   float cur_march_step = 0.f, exp_march_step = 0.f;
   float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
   bool first = true;
-  // this lane's slice of the current leaf's TransInfo
+  // this lane's three projections of the current leaf's TransInfo (24 + 9 of its 144 floats)
   int loaded_oct = -1, trans_idx = 0, block_idx = 0;
-  float4 m0 = make_float4(0, 0, 0, 0), m1 = make_float4(0, 0, 0, 1);
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f, tcx = 0.f, tcy = 0.f, tcz = 0.f, tdis = 1.f, radius_clip = 1.f;
-  const int gi = g < GFN_N_PROS ? g : 0;
+  float4 m0[3], m1[3];
+  float w[3][3];  // [output row][projection of this lane]
+#pragma unroll
+  for (int p = 0; p < 3; p++) {
+    m0[p] = make_float4(0, 0, 0, 0); m1[p] = make_float4(0, 0, 0, 1);
+    w[0][p] = 0.f; w[1][p] = 0.f; w[2][p] = 0.f;
+  }
+  float radius_clip = 1.f;
   while (__any(active)) {
-    if (active && loaded_oct != cur_oct_idx) {  // row-uniform: reload on leaf change only
+    if (active && loaded_oct != cur_oct_idx) {  // quad-uniform: reload on leaf change only
       const CompactNode* nd = nodes + cur_oct_idx;
       trans_idx = nd->trans_idx;
       block_idx = nd->block_idx;
       const float* tp = transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4);
-      m0 = *reinterpret_cast<const float4*>(tp + gi * 8);
-      m1 = *reinterpret_cast<const float4*>(tp + gi * 8 + 4);
-      w0 = tp[96 + gi]; w1 = tp[96 + 12 + gi]; w2 = tp[96 + 24 + gi];
-      tcx = tp[132]; tcy = tp[133]; tcz = tp[134]; tdis = tp[136];
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        m0[p] = *reinterpret_cast<const float4*>(tp + (3 * k + p) * 8);
+        m1[p] = *reinterpret_cast<const float4*>(tp + (3 * k + p) * 8 + 4);
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) w[rr][p] = tp[96 + 12 * rr + 3 * k + p];
+      }
       loaded_oct = cur_oct_idx;
       // the ray's distance to the leaf's cameras, in units of their distance summary: constant while the ray stays in the leaf
-      const float dx = o[0] - tcx, dy = o[1] - tcy, dz = o[2] - tcz;
-      radius_clip = fmaxf(sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tdis, 1.f);
+      const float dx = o[0] - tp[132], dy = o[1] - tp[133], dz = o[2] - tp[134];
+      radius_clip = fmaxf(sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tp[136], 1.f);
     }
-    // per-lane projection i = g  (PersSampler_cuda.cu:155-188)
-    const float x0 = gfn_sum4(m0.x * xyz[0], m0.y * xyz[1], m0.z * xyz[2], m0.w * 1.f);
-    const float x1 = gfn_sum4(m1.x * xyz[0], m1.y * xyz[1], m1.z * xyz[2], m1.w * 1.f);
-    const float dv0 = 1.f / x1;
-    const float dv1 = -x0 / (x1 * x1);
-    const bool lv = g < GFN_N_PROS;
-    const float tj0 = lv ? dv0 * m0.x + dv1 * m1.x : 0.f;
-    const float tj1 = lv ? dv0 * m0.y + dv1 * m1.y : 0.f;
-    const float tj2 = lv ? dv0 * m0.z + dv1 * m1.z : 0.f;
-    float jac[9];
-    jac[0] = row_sum12(w0 * tj0); jac[1] = row_sum12(w0 * tj1); jac[2] = row_sum12(w0 * tj2);
-    jac[3] = row_sum12(w1 * tj0); jac[4] = row_sum12(w1 * tj1); jac[5] = row_sum12(w1 * tj2);
-    jac[6] = row_sum12(w2 * tj0); jac[7] = row_sum12(w2 * tj1); jac[8] = row_sum12(w2 * tj2);
+    // this lane's projections i = 3k + p  (PersSampler_cuda.cu:155-188)
+    float tj[3][3], v[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      const float x0 = gfn_sum4(m0[p].x * xyz[0], m0[p].y * xyz[1], m0[p].z * xyz[2], m0[p].w * 1.f);
+      const float x1 = gfn_sum4(m1[p].x * xyz[0], m1[p].y * xyz[1], m1[p].z * xyz[2], m1[p].w * 1.f);
+      const float dv0 = 1.f / x1;
+      const float dv1 = -x0 / (x1 * x1);
+      tj[p][0] = dv0 * m0[p].x + dv1 * m1[p].x;
+      tj[p][1] = dv0 * m0[p].y + dv1 * m1[p].y;
+      tj[p][2] = dv0 * m0[p].z + dv1 * m1[p].z;
+      v[p] = (FILL || rec) ? x0 / x1 : 0.f;
+    }
     float pj[3];
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) pj[rr] = gfn_sum3(jac[rr * 3] * d[0], jac[rr * 3 + 1] * d[1], jac[rr * 3 + 2] * d[2]);
-    float pnorm = sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
-    pnorm = __shfl(pnorm, 0, 16);  // lane 0 of the row holds the true reductions
+    for (int rr = 0; rr < 3; rr++) {
+      float jr[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) jr[c] = quad_sum12(w[rr][0] * tj[0][c], w[rr][1] * tj[1][c], w[rr][2] * tj[2][c]);
+      pj[rr] = gfn_sum3(jr[0] * d[0], jr[1] * d[1], jr[2] * d[2]);
+    }
+    const float pnorm = sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
     float wp[3] = {0.f, 0.f, 0.f};
     if (FILL || rec) {  // warped point (:155-170): v_i = x0/x1, out_r = sum12(weight[r][i] * v_i); the counting pass records it too
-      const float v = lv ? x0 / x1 : 0.f;
-      wp[0] = row_sum12(w0 * v); wp[1] = row_sum12(w1 * v); wp[2] = row_sum12(w2 * v);
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) wp[rr] = quad_sum12(w[rr][0] * v[0], w[rr][1] * v[1], w[rr][2] * v[2]);
     }
-    // (count pass) the warped point moved from lane 0 to the lanes that store it
-    const float wp3 = row_up<3>(wp[0]), wp4 = row_up<4>(wp[1]), wp5 = row_up<5>(wp[2]);
     if (active) {
-      // the step's noise: sixteen values per load, one in each lane of the row, handed out through the LDS crossbar -- a global load
-      // per step made every step wait for the memory system (and, loads and stores sharing one counter here, for the stores of
-      // the steps before it)
-      const int nb = pts_ptr & ~(kGroup - 1);
-      if (nb != nz_base) { nz = noise[nb + g]; nz_base = nb; }
-      const float warp_step = sample_l * __shfl(nz, pts_ptr & (kGroup - 1), kGroup);
+      // the step's noise: sixteen values per quad and visit of memory, four consecutive ones in each lane, handed out through the LDS
+      // crossbar -- a global load per step made every step wait for the memory system (and, loads and stores sharing one counter here,
+      // for the stores of the steps before it)
+      const int nb = pts_ptr & ~15;
+      if (nb != nz_base) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) nz[m] = noise[nb + 4 * k + m];
+        nz_base = nb;
+      }
+      const int sub = pts_ptr & 3;
+      float nzv = nz[0];
+      nzv = sub == 1 ? nz[1] : nzv; nzv = sub == 2 ? nz[2] : nzv; nzv = sub == 3 ? nz[3] : nzv;
+      const float warp_step = sample_l * __shfl(nzv, (pts_ptr >> 2) & 3, kGroup);
       exp_march_step = warp_step / (pnorm + 1e-6f);
       if (scale_by_dis) exp_march_step *= radius_clip;
       cur_march_step = exp_march_step;
-      if (FILL && !first && g == 0) {
+      if (FILL && !first && k == 0) {
         const int64_t p = base + pts_ptr;
         if (table_space) {
           const float inv3 = 1.0f / 3.0f;
@@ -628,16 +647,13 @@ __global__ __launch_bounds__(256) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
-      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE store of the row's lanes 0 .. 5
-        // (six stores from lane 0 were six memory instructions per step, and on this architecture a wave's next load waits for
+      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE 8-byte store from three lanes of the quad
+        // (six stores from one lane were six memory instructions per step, and on this architecture a wave's next load waits for
         // every store before it: beside a kernel that keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
-        float v = cur_t;
-        v = g == 1 ? exp_march_step * (pnorm + 1e-6f) : v;
-        v = g == 2 ? __int_as_float(cur_oct_idx) : v;
-        v = g == 3 ? wp3 : v;  // the projections are in this row's lanes anyway: 3 more DPP trees here save the fill pass
-        v = g == 4 ? wp4 : v;  // 12 projections, 12 divisions and the whole TransInfo per sample
-        v = g == 5 ? wp5 : v;
-        if (g < GFN_MARCH_REC_FLOATS) rec[((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + pts_ptr) * GFN_MARCH_REC_FLOATS + g] = v;
+        float2 v2;
+        v2.x = k == 0 ? cur_t : (k == 1 ? __int_as_float(cur_oct_idx) : wp[1]);
+        v2.y = k == 0 ? exp_march_step * (pnorm + 1e-6f) : (k == 1 ? wp[0] : wp[2]);
+        if (k < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + (int64_t)pts_ptr * GFN_MARCH_REC_FLOATS)[k] = v2;
       }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(256) void march_group_kernel(
       active = pts_ptr < max_n && oct_ptr < n_oct;
     }
   }
-  if (!FILL && in_range && g == 0) counts[ray] = pts_ptr;
+  if (!FILL && in_range && k == 0) counts[ray] = pts_ptr;
 }
 
 __device__ __forceinline__ float sum12_tree(const float* q) {  // the association of row_sum12 / Eigen's redux
@@ -1014,7 +1030,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
   GFN_CHECK_LAUNCH();
   const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   int* counts = anchors;  // scratch until the fill pass
-  march_group_kernel<false><<<grid, 256, 0, st>>>(
+  march_group_kernel<false><<<grid, kMarchThreads, 0, st>>>(
       (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
       reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts, nullptr, nullptr,
       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev, march_rec);
@@ -1027,7 +1043,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
         reinterpret_cast<const float*>(transes), march_rec, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
         first_oct_dis, pts_cap, overflow_dev);
   else
-    march_group_kernel<true><<<grid, 256, 0, st>>>(
+    march_group_kernel<true><<<grid, kMarchThreads, 0, st>>>(
         (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
         reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), nullptr, pts_offsets,
         world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev, nullptr);
