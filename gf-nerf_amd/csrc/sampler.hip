@@ -11,6 +11,9 @@
 // every f32 produced here are bit-exact against the oracle.
 #include "gfn_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 constexpr int kRayBlock = 64;   // one wave per workgroup: 4096 rays -> 64 WGs spread over CUs
@@ -494,32 +497,58 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
   if (in_range && k == 0) counts[ray] = cnt;
 }
 
-// lane i of a quad (4 neighbouring lanes) reads lane i ^ 1 / lane i ^ 2 of the same quad: DPP quad_perm, no LDS traffic
+// ---- the 12 projections of a step, shared by the L lanes of a ray --------------------------------------------------------------
+// Sum over the projections in the association of sum12(): ((q0+(q1+q2)) + (q3+(q4+q5))) + ((q6+(q7+q8)) + (q9+(q10+q11))).
+// lane i of a 16-lane row reads lane i+N / lane i-N of the same row (0 beyond the row): DPP row_shl / row_shr, no LDS traffic
+template <int N>
+__device__ __forceinline__ float row_down(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ float row_up(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xF, 0xF, true));
+}
+// lane i of a quad (4 neighbouring lanes) reads lane i ^ 1 / lane i ^ 2 of the same quad: DPP quad_perm
 __device__ __forceinline__ float quad_x1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_x2(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
 }
-// Sum over the 12 projections in the association of sum12(): ((q0+(q1+q2)) + (q3+(q4+q5))) + ((q6+(q7+q8)) + (q9+(q10+q11))).
-// Lane k of the quad brings q[3k], q[3k+1], q[3k+2]; its own triple is the innermost bracket, two exchanges finish the tree
-// (a + b and b + a are the same float), and EVERY lane of the quad ends with the result.
-__device__ __forceinline__ float quad_sum12(float q0, float q1, float q2) {
-  const float s = q0 + (q1 + q2);
-  const float t = s + quad_x1(s);
-  return t + quad_x2(t);
-}
 
-constexpr int kGroup = 4;                            // lanes per ray: lane k owns projections 3k, 3k+1, 3k+2
-constexpr int kMarchThreads = 64;                    // one wave per workgroup: 4096 training rays spread over 256 CUs
-constexpr int kRaysPerBlock = kMarchThreads / kGroup;  // 16 rays per wave
+// How the L lanes of a ray share the work of a step.
+//   L = 16: one projection per lane (lanes 0 .. 11), the tree is 4 DPP steps and its result lands on lane 0 -- a step's ~300 instructions serve
+//           the 4 rays of a wave, and 4096 training rays are 1024 waves, one per SIMD: the shortest serial chain, for batches that leave
+//           the machine empty anyway (a wave stalls on every leaf change of ANY of its rays: few rays per wave is what counts there);
+//   L = 4:  three projections per lane -- the innermost bracket of sum12() is lane-local, two quad exchanges finish the tree (a + b and
+//           b + a are the same float) and every lane of the quad holds the result -- the same ~300 instructions serve 16 rays: a quarter of
+//           the vector work per ray, for render tiles, where the march is bound by instruction issue (a 138 k-ray tile: 2.2 -> 0.76 ms).
+template <int L> struct MarchGroup;
+template <> struct MarchGroup<16> {
+  static constexpr int P = 1, NZ = 1, THREADS = 256;
+  static __device__ __forceinline__ float sum12(const float (&q)[1]) {
+    const float a = q[0] + row_down<1>(q[0]);  // lanes 3k+1: q[3k+1] + q[3k+2]
+    const float b = q[0] + row_down<1>(a);     // lanes 3k  : q[3k] + (q[3k+1] + q[3k+2])
+    const float c = b + row_down<3>(b);        // lanes 0, 6: s0 + s1, s2 + s3
+    return c + row_down<6>(c);                 // lane 0
+  }
+  static __device__ __forceinline__ float to_all(float v) { return __shfl(v, 0, 16); }         // lane 0's value in every lane of the row
+  template <int N> static __device__ __forceinline__ float to_lane(float v) { return row_up<N>(v); }  // lane 0's value in lane N
+};
+template <> struct MarchGroup<4> {
+  static constexpr int P = 3, NZ = 4, THREADS = 64;
+  static __device__ __forceinline__ float sum12(const float (&q)[3]) {
+    const float s = q[0] + (q[1] + q[2]);
+    const float t = s + quad_x1(s);
+    return t + quad_x2(t);                     // every lane of the quad
+  }
+  static __device__ __forceinline__ float to_all(float v) { return v; }
+  template <int N> static __device__ __forceinline__ float to_lane(float v) { return v; }
+};
 
-// K4 with a quad of lanes per ray.  Hits come from the dense slots of trace_group_kernel.  (Until round 4 a ray had a 16-lane row, one
-// projection per lane: the step's ~300 instructions served 4 rays of a wave -- 12 contractions x 4 DPP steps with 4 .. 1 useful lanes
-// each -- and a render tile's march cost a third of the CU time of the tile.  With three projections per lane the innermost bracket
-// of sum12() is lane-local, the same ~300 instructions serve 16 rays, and nothing about the arithmetic changes.)
-template <bool FILL>
-__global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
+// K4 with L lanes per ray.  Hits come from the dense slots of trace_group_kernel.
+template <int L, bool FILL>
+__global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
     int n_rays, float sample_l, int scale_by_dis, int table_space, int max_hits,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ noise_all,
     const int* __restrict__ hit_counts, const int* __restrict__ hit_idx, const float2* __restrict__ hit_nf,
@@ -528,8 +557,10 @@ __global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
     float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
     int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow,
     float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf, warped point} for fill_from_rec_kernel, or NULL */) {
-  const int k = threadIdx.x & (kGroup - 1);
-  const int ray = blockIdx.x * kRaysPerBlock + (threadIdx.x / kGroup);
+  using G = MarchGroup<L>;
+  constexpr int P = G::P, NZ = G::NZ;
+  const int g = threadIdx.x & (L - 1);
+  const int ray = blockIdx.x * (G::THREADS / L) + (threadIdx.x / L);
   const bool in_range = ray < n_rays;
   const int r = in_range ? ray : 0;
   const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
@@ -544,60 +575,63 @@ __global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
   if (FILL) {
     base = pts_offsets[r];
     int64_t end = pts_offsets[r + 1];
-    if (end > pts_cap) { end = pts_cap; if (overflow && k == 0) atomicOr(overflow, 4); }
+    if (end > pts_cap) { end = pts_cap; if (overflow && g == 0) atomicOr(overflow, 4); }
     max_n = (int)(end > base ? end - base : 0);
     if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;
-    if (in_range && k == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
+    if (in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
   }
   bool active = in_range && max_n > 0 && n_oct > 0;
   int pts_ptr = 0, oct_ptr = 0;
   int nz_base = -1;
-  float nz[4] = {0.f, 0.f, 0.f, 0.f};
+  float nz[NZ];
+#pragma unroll
+  for (int m = 0; m < NZ; m++) nz[m] = 0.f;
   int cur_oct_idx = active ? hit_idx[0] : 0;
   float2 nf = active ? hit_nf[0] : make_float2(0.f, 0.f);
   float cur_t = nf.x, cur_far = nf.y, cur_near = nf.x;
   float cur_march_step = 0.f, exp_march_step = 0.f;
   float xyz[3] = {o[0] + d[0] * cur_t, o[1] + d[1] * cur_t, o[2] + d[2] * cur_t};
   bool first = true;
-  // this lane's three projections of the current leaf's TransInfo (24 + 9 of its 144 floats)
+  // this lane's projections of the current leaf's TransInfo: rows proj0 .. proj0 + P - 1 of w2xz and the matching weight columns
+  const int proj0 = P * g < GFN_N_PROS ? P * g : 0;  // (L = 16: lanes 12 .. 15 repeat projection 0, nothing reads their sums)
   int loaded_oct = -1, trans_idx = 0, block_idx = 0;
-  float4 m0[3], m1[3];
-  float w[3][3];  // [output row][projection of this lane]
+  float4 m0[P], m1[P];
+  float w[3][P];  // [output row][projection of this lane]
 #pragma unroll
-  for (int p = 0; p < 3; p++) {
+  for (int p = 0; p < P; p++) {
     m0[p] = make_float4(0, 0, 0, 0); m1[p] = make_float4(0, 0, 0, 1);
     w[0][p] = 0.f; w[1][p] = 0.f; w[2][p] = 0.f;
   }
   float radius_clip = 1.f;
   while (__any(active)) {
-    if (active && loaded_oct != cur_oct_idx) {  // quad-uniform: reload on leaf change only
+    if (active && loaded_oct != cur_oct_idx) {  // uniform over the ray's lanes: reload on leaf change only
       const CompactNode* nd = nodes + cur_oct_idx;
       trans_idx = nd->trans_idx;
       block_idx = nd->block_idx;
       const float* tp = transes + (size_t)trans_idx * (GFN_TRANS_INFO_BYTES / 4);
 #pragma unroll
-      for (int p = 0; p < 3; p++) {
-        m0[p] = *reinterpret_cast<const float4*>(tp + (3 * k + p) * 8);
-        m1[p] = *reinterpret_cast<const float4*>(tp + (3 * k + p) * 8 + 4);
+      for (int p = 0; p < P; p++) {
+        m0[p] = *reinterpret_cast<const float4*>(tp + (proj0 + p) * 8);
+        m1[p] = *reinterpret_cast<const float4*>(tp + (proj0 + p) * 8 + 4);
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++) w[rr][p] = tp[96 + 12 * rr + 3 * k + p];
+        for (int rr = 0; rr < 3; rr++) w[rr][p] = tp[96 + 12 * rr + proj0 + p];
       }
       loaded_oct = cur_oct_idx;
       // the ray's distance to the leaf's cameras, in units of their distance summary: constant while the ray stays in the leaf
       const float dx = o[0] - tp[132], dy = o[1] - tp[133], dz = o[2] - tp[134];
       radius_clip = fmaxf(sqrtf(gfn_sum3(dx * dx, dy * dy, dz * dz)) / tp[136], 1.f);
     }
-    // this lane's projections i = 3k + p  (PersSampler_cuda.cu:155-188)
-    float tj[3][3], v[3];
+    // this lane's projections (PersSampler_cuda.cu:155-188)
+    float tj[3][P], v[P];  // [column][projection]
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
+    for (int p = 0; p < P; p++) {
       const float x0 = gfn_sum4(m0[p].x * xyz[0], m0[p].y * xyz[1], m0[p].z * xyz[2], m0[p].w * 1.f);
       const float x1 = gfn_sum4(m1[p].x * xyz[0], m1[p].y * xyz[1], m1[p].z * xyz[2], m1[p].w * 1.f);
       const float dv0 = 1.f / x1;
       const float dv1 = -x0 / (x1 * x1);
-      tj[p][0] = dv0 * m0[p].x + dv1 * m1[p].x;
-      tj[p][1] = dv0 * m0[p].y + dv1 * m1[p].y;
-      tj[p][2] = dv0 * m0[p].z + dv1 * m1[p].z;
+      tj[0][p] = dv0 * m0[p].x + dv1 * m1[p].x;
+      tj[1][p] = dv0 * m0[p].y + dv1 * m1[p].y;
+      tj[2][p] = dv0 * m0[p].z + dv1 * m1[p].z;
       v[p] = (FILL || rec) ? x0 / x1 : 0.f;
     }
     float pj[3];
@@ -605,33 +639,45 @@ __global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
     for (int rr = 0; rr < 3; rr++) {
       float jr[3];
 #pragma unroll
-      for (int c = 0; c < 3; c++) jr[c] = quad_sum12(w[rr][0] * tj[0][c], w[rr][1] * tj[1][c], w[rr][2] * tj[2][c]);
+      for (int c = 0; c < 3; c++) {
+        float q[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) q[p] = w[rr][p] * tj[c][p];
+        jr[c] = G::sum12(q);
+      }
       pj[rr] = gfn_sum3(jr[0] * d[0], jr[1] * d[1], jr[2] * d[2]);
     }
-    const float pnorm = sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2]));
+    const float pnorm = G::to_all(sqrtf(gfn_sum3(pj[0] * pj[0], pj[1] * pj[1], pj[2] * pj[2])));
     float wp[3] = {0.f, 0.f, 0.f};
     if (FILL || rec) {  // warped point (:155-170): v_i = x0/x1, out_r = sum12(weight[r][i] * v_i); the counting pass records it too
 #pragma unroll
-      for (int rr = 0; rr < 3; rr++) wp[rr] = quad_sum12(w[rr][0] * v[0], w[rr][1] * v[1], w[rr][2] * v[2]);
+      for (int rr = 0; rr < 3; rr++) {
+        float q[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) q[p] = w[rr][p] * v[p];
+        wp[rr] = G::sum12(q);
+      }
     }
+    // (count pass) the warped point where the record's store wants it: lane 1 (x), lane 2 (y, z)
+    const float wp_x1 = G::template to_lane<1>(wp[0]), wp_y2 = G::template to_lane<2>(wp[1]), wp_z2 = G::template to_lane<2>(wp[2]);
     if (active) {
-      // the step's noise: sixteen values per quad and visit of memory, four consecutive ones in each lane, handed out through the LDS
-      // crossbar -- a global load per step made every step wait for the memory system (and, loads and stores sharing one counter here,
-      // for the stores of the steps before it)
+      // the step's noise: sixteen values per ray and visit of memory, NZ consecutive ones in each lane, handed out through the LDS crossbar --
+      // a global load per step made every step wait for the memory system (and, loads and stores sharing one counter here, for the stores
+      // of the steps before it)
       const int nb = pts_ptr & ~15;
       if (nb != nz_base) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) nz[m] = noise[nb + 4 * k + m];
+        for (int m = 0; m < NZ; m++) nz[m] = noise[nb + NZ * g + m];
         nz_base = nb;
       }
-      const int sub = pts_ptr & 3;
       float nzv = nz[0];
-      nzv = sub == 1 ? nz[1] : nzv; nzv = sub == 2 ? nz[2] : nzv; nzv = sub == 3 ? nz[3] : nzv;
-      const float warp_step = sample_l * __shfl(nzv, (pts_ptr >> 2) & 3, kGroup);
+#pragma unroll
+      for (int m = 1; m < NZ; m++) nzv = (pts_ptr & (NZ - 1)) == m ? nz[m] : nzv;
+      const float warp_step = sample_l * __shfl(nzv, (pts_ptr & 15) / NZ, L);
       exp_march_step = warp_step / (pnorm + 1e-6f);
       if (scale_by_dis) exp_march_step *= radius_clip;
       cur_march_step = exp_march_step;
-      if (FILL && !first && k == 0) {
+      if (FILL && !first && g == 0) {
         const int64_t p = base + pts_ptr;
         if (table_space) {
           const float inv3 = 1.0f / 3.0f;
@@ -647,13 +693,13 @@ __global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
-      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE 8-byte store from three lanes of the quad
+      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE 8-byte store from lanes 0 .. 2 of the ray
         // (six stores from one lane were six memory instructions per step, and on this architecture a wave's next load waits for
         // every store before it: beside a kernel that keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
         float2 v2;
-        v2.x = k == 0 ? cur_t : (k == 1 ? __int_as_float(cur_oct_idx) : wp[1]);
-        v2.y = k == 0 ? exp_march_step * (pnorm + 1e-6f) : (k == 1 ? wp[0] : wp[2]);
-        if (k < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + (int64_t)pts_ptr * GFN_MARCH_REC_FLOATS)[k] = v2;
+        v2.x = g == 0 ? cur_t : (g == 1 ? __int_as_float(cur_oct_idx) : wp_y2);
+        v2.y = g == 0 ? exp_march_step * (pnorm + 1e-6f) : (g == 1 ? wp_x1 : wp_z2);
+        if (g < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + (int64_t)pts_ptr * GFN_MARCH_REC_FLOATS)[g] = v2;
       }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
@@ -672,7 +718,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_group_kernel(
       active = pts_ptr < max_n && oct_ptr < n_oct;
     }
   }
-  if (!FILL && in_range && k == 0) counts[ray] = pts_ptr;
+  if (!FILL && in_range && g == 0) counts[ray] = pts_ptr;
 }
 
 __device__ __forceinline__ float sum12_tree(const float* q) {  // the association of row_sum12 / Eigen's redux
@@ -1028,12 +1074,27 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
       (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
       reinterpret_cast<float2*>(hit_near_far), overflow_dev, stack);
   GFN_CHECK_LAUNCH();
-  const unsigned grid = (unsigned)((n_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   int* counts = anchors;  // scratch until the fill pass
-  march_group_kernel<false><<<grid, kMarchThreads, 0, st>>>(
-      (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
-      reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts, nullptr, nullptr,
-      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pts_cap, overflow_dev, march_rec);
+  // lanes per ray (MarchGroup): a row of 16 while the batch leaves the machine empty (the shortest chain per step), a quad from 32 Ki rays on
+  // (a quarter of the vector work per ray); GFN_MARCH_LANES = 4 | 16 in the environment overrides (tests run both on the same rays)
+  const char* lanes_env = getenv("GFN_MARCH_LANES");
+  const int forced_lanes = lanes_env ? atoi(lanes_env) : 0;
+  const bool quad = forced_lanes == 4 || (forced_lanes != 16 && n_rays >= 32768);
+  auto march = [&](auto lanes, auto fill, int* counts_out, const int* offsets, float* rec) {
+    constexpr int L = decltype(lanes)::value;
+    constexpr bool FILL = decltype(fill)::value;
+    const int rays_per_block = MarchGroup<L>::THREADS / L;
+    const unsigned grid = (unsigned)((n_rays + rays_per_block - 1) / rays_per_block);
+    march_group_kernel<L, FILL><<<grid, MarchGroup<L>::THREADS, 0, st>>>(
+        (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
+        reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts_out, offsets,
+        FILL ? world_pts : nullptr, FILL ? warped_pts : nullptr, FILL ? dirs : nullptr, FILL ? dists : nullptr, FILL ? ts : nullptr,
+        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, FILL ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec);
+  };
+  using Row = std::integral_constant<int, 16>;
+  using Quad = std::integral_constant<int, 4>;
+  if (quad) march(Quad{}, std::false_type{}, counts, nullptr, march_rec);
+  else march(Row{}, std::false_type{}, counts, nullptr, march_rec);
   GFN_CHECK_LAUNCH();
   launch_scan(counts, (int)n_rays, pts_offsets, counts + n_rays, st);  // anchors holds 3 x pts_cap >= 3 x n_rays words: counts, then the scan's scratch
   GFN_CHECK_LAUNCH();
@@ -1042,11 +1103,8 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
         (int)n_rays, table_space, max_hits, rays_o, rays_d, hit_counts, reinterpret_cast<const float2*>(hit_near_far), cn,
         reinterpret_cast<const float*>(transes), march_rec, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
         first_oct_dis, pts_cap, overflow_dev);
-  else
-    march_group_kernel<true><<<grid, kMarchThreads, 0, st>>>(
-        (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
-        reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), nullptr, pts_offsets,
-        world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev, nullptr);
+  else if (quad) march(Quad{}, std::true_type{}, nullptr, pts_offsets, nullptr);
+  else march(Row{}, std::true_type{}, nullptr, pts_offsets, nullptr);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

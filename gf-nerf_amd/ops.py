@@ -250,7 +250,7 @@ def tree_compact(nodes, out=None):
 def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8,
                 max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None, out=None,
                 tree_depth=0):
-    """Fast GetSamples: single-pass dense trace + 16-lane-per-ray march.  Same dict as march().  out: a dict an earlier call
+    """Fast GetSamples: single-pass dense trace + march with a group of lanes per ray (a 16-lane row below 32 Ki rays, a quad from there on).  Same dict as march().  out: a dict an earlier call
     returned (same R / pts_cap / options): its tensors are written again instead of allocating new ones (static buffers of a
     captured step).  tree_depth: depth of the deepest node (see tree_depth()) or 0 for the reference's bound of 24."""
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")

@@ -269,19 +269,30 @@ def test_march_bit_exact(oracle, ops, dev, train, fineness):
     assert int(g["overflow"].item()) == 0
 
 
+@pytest.mark.parametrize("lanes,with_rec", [(16, True), (16, False), (4, True), (4, False)])
 @pytest.mark.parametrize("train,fineness,n_rays", [(True, 6.0, 333), (False, 0.5, 70), (False, 16.0, 4)])
-def test_fast_sampler_bit_exact(oracle, ops, dev, train, fineness, n_rays):
-    """gfn_sample_rays (compact nodes, one-pass dense trace, 16-lane row per ray, DPP reductions) produces the
-    same bits as the oracle -- and therefore as the gfn_trace + gfn_march boundary functions."""
+def test_fast_sampler_bit_exact(oracle, ops, dev, monkeypatch, train, fineness, n_rays, lanes, with_rec):
+    """gfn_sample_rays (compact nodes, one-pass dense trace, a group of lanes per ray with DPP reductions) produces the same bits as
+    the oracle -- and therefore as the gfn_trace + gfn_march boundary functions -- in each of its forms: a 16-lane row per ray (what
+    batches below 32 Ki rays get) or a quad of lanes (render tiles), GFN_MARCH_LANES forcing either on these rays; the counting march
+    recording (t, dist, leaf, warped point) for the sample-parallel fill, or, without the record buffer, a second march writing the samples."""
+    import torch
+
     from gfnerf_amd import scene
 
+    monkeypatch.setenv("GFN_MARCH_LANES", str(lanes))
     sc, ref, gpu = _sample_both(oracle, ops, dev, n_rays=n_rays, train=train, fineness=fineness)
     m = ref["m"]
     noise = scene.make_noise(n_rays, train, fineness, seed=1)
     cn = ops.tree_compact(_t(sc["nodes"], dev))
+    ws = None
+    if not with_rec:  # a workspace without the record buffer: count pass, scan, fill pass (both marches)
+        ws = dict(hit_counts=torch.empty(n_rays, dtype=torch.int32, device=dev), hit_idx=torch.empty(n_rays * ops.MAX_OCT_PER_RAY, dtype=torch.int32, device=dev),
+                  hit_nf=torch.empty((n_rays * ops.MAX_OCT_PER_RAY, 2), dtype=torch.float32, device=dev))
     for table_space in (False, True):
         g = ops.sample_rays(_t(ref["o"], dev), _t(ref["d"], dev), _t(noise, dev), cn, _t(sc["transes"], dev), 1.0 / 256, True,
-                            want_world=True, want_dirs=True, table_space=table_space)
+                            want_world=True, want_dirs=True, table_space=table_space, workspace=ws)
+        assert ("march_rec" in g["workspace"]) == with_rec
         po = g["pts_offsets"].cpu().numpy()
         assert np.array_equal(po.astype(np.int64), m["pts_offsets"])
         N = int(po[-1])
