@@ -26,6 +26,7 @@ namespace {
 struct FusedArgs {
   const int* pts_offsets; int n_rays;
   const float* pts; const int* anchors; const float* dt; const float* ts;
+  const float* rec; const int* counts;  // gfn_fused_render_rec: the samples where the counting march recorded them (slot k of ray r at (r * 1024 + k) * 8)
   const void* table_a; const void* table_b; const int* prim_a; const int* prim_b; const float* bias_pool;
   int64_t n_volumes; int log2_T;
   const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
 constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / prime offsets the kernel needs 254 registers, no spills
 // RENDER_LEVELS: levels whose gathers (16 each with two tables) a lane keeps in flight together (2 or 4; GFN_RENDER_LEVELS in the environment
 // picks the instantiation -- measured: tools/README.md, round 4)
-template <int TAB, int RENDER_LEVELS>
+// REC: the samples come from the march's records (32 bytes each, gfn_sample_rays_record) instead of the packed arrays a fill pass made of them
+template <int TAB, int RENDER_LEVELS, bool REC>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     const int patch = __builtin_amdgcn_readfirstlane(seg_lo + idx);  // wave-uniform: its row / column arithmetic stays on the scalar unit
     const int prow = patch / patches_per_row, pcol = patch - prow * patches_per_row;
     const int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
-    const int s = A.pts_offsets[ray], cnt = A.pts_offsets[ray + 1] - s;
+    const int cnt = REC ? A.counts[ray] : A.pts_offsets[ray + 1] - A.pts_offsets[ray];
+    const int64_t s = REC ? (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY : (int64_t)A.pts_offsets[ray];
     int kmax = cnt;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
       if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
-      const int64_t q = (int64_t)s + k;
+      const int64_t q = s + k;
       // (rebuilt every sample from two 32-bit values the compiler cannot see through: as 64-bit pointers -- or their hoisted parts -- kept
       // across the loops they were what spilled)
       int ray_k = ray, cam_k = cam;
@@ -325,8 +328,17 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
 #pragma unroll
         for (int m = 0; m < 8; m++) x[u][m] = 0.f;
       if (act) {
-        const float px = A.pts[3 * q], py = A.pts[3 * q + 1], pz = A.pts[3 * q + 2];
-        const int vol = A.anchors[3 * q];
+        float px, py, pz;
+        int vol;
+        if (REC) {  // {t, dist, leaf, transform | warped x, y, z, block}: the table-space point as the fill pass makes it (sampler.hip)
+          const float4 r1 = *reinterpret_cast<const float4*>(A.rec + q * GFN_MARCH_REC_FLOATS + 4);
+          const float inv3 = 1.0f / 3.0f;
+          px = (r1.x + 1.5f) * inv3; py = (r1.y + 1.5f) * inv3; pz = (r1.z + 1.5f) * inv3;
+          vol = __float_as_int(A.rec[q * GFN_MARCH_REC_FLOATS + 3]);
+        } else {
+          px = A.pts[3 * q]; py = A.pts[3 * q + 1]; pz = A.pts[3 * q + 2];
+          vol = A.anchors[3 * q];
+        }
         // The lookup of a lane's 8 levels is a chain of round trips (point -> primes -> slots) with a handful of instructions between them,
         // and with two waves per SIMD there is little else to run meanwhile: taken level by level it was 1 + 2 x 8 x 2 dependent trips per
         // sample.  So, per half of the lane's levels: its 8 prime triples first (one trip), then the levels in groups of RENDER_LEVELS -- hash every
@@ -384,8 +396,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       const DecoderOut o = decoder_tile<false>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q);
       // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
       if (act && h == 0) {
-        const float ti = A.ts[q];
-        const float ds = A.dt[q] * o.sigma;
+        const float ti = REC ? A.rec[q * GFN_MARCH_REC_FLOATS] : A.ts[q];
+        const float ds = (REC ? A.rec[q * GFN_MARCH_REC_FLOATS + 1] : A.dt[q]) * o.sigma;
         const float Tr = expf(-carry);
         const float alpha = 1.f - expf(-ds);
         float w = nan_to_num_f(alpha * Tr);
@@ -402,7 +414,11 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       if (A.out_depth) A.out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
     }
     if (A.t_minmax) {  // t grows along a ray: its range is its first and its last sample, terminated or not
-      float tmin = cnt > 0 ? A.ts[s] : INFINITY, tmax = cnt > 0 ? A.ts[s + cnt - 1] : 0.f;
+      float tmin = INFINITY, tmax = 0.f;
+      if (cnt > 0) {
+        tmin = REC ? A.rec[s * GFN_MARCH_REC_FLOATS] : A.ts[s];
+        tmax = REC ? A.rec[(s + cnt - 1) * GFN_MARCH_REC_FLOATS] : A.ts[s + cnt - 1];
+      }
       if (cnt < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -483,25 +499,25 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   return GFN_OK;
 }
 
-int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
-                     const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
-                     const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
-                     const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
-                     float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream) {
-  if (n_rays == 0) return GFN_OK;
-  GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts && table_f16 && prim_pool && fwd_image && sh && out_rgb && work_counter,
-                "gfn_fused_render: null pointer");
-  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30) && n_rays % 32 == 0, "gfn_fused_render: n_rays=%lld must be a positive multiple of 32", (long long)n_rays);
-  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_render: n_volumes / log2_T out of range");
-  GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_render: emb given without cam_idx");
+}  // extern "C"
+
+// the launch of gfn_fused_render / gfn_fused_render_rec (A holds the sample source of either)
+static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, const uint16_t* table_f16, const uint16_t* table2_f16,
+                               const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
+                               const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
+                               int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
+                               void* stream) {
+  GFN_CHECK_ARG(table_f16 && prim_pool && fwd_image && sh && out_rgb && work_counter, "%s: null pointer", who);
+  GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30) && n_rays % 32 == 0, "%s: n_rays=%lld must be a positive multiple of 32", who, (long long)n_rays);
+  GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "%s: n_volumes / log2_T out of range", who);
+  GFN_CHECK_ARG(!emb || cam_idx, "%s: emb given without cam_idx", who);
   GFN_CHECK_ARG(tile_width == 0 || (tile_width > 0 && patch_width > 0 && 32 % patch_width == 0 && tile_width % patch_width == 0 &&
                                     n_rays % tile_width == 0 && (n_rays / tile_width) % (32 / patch_width) == 0),
-                "gfn_fused_render: a %d-wide tile of %lld rays does not divide into %d x %d patches", tile_width, (long long)n_rays, patch_width,
+                "%s: a %d-wide tile of %lld rays does not divide into %d x %d patches", who, tile_width, (long long)n_rays, patch_width,
                 patch_width > 0 ? 32 / patch_width : 0);
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(emb)) & 15) == 0,
-                "gfn_fused_render: image, sh and emb must be 16-byte aligned");
-  FusedArgs A{};
-  A.pts_offsets = pts_offsets; A.n_rays = (int)n_rays; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
+                "%s: image, sh and emb must be 16-byte aligned", who);
+  A.n_rays = (int)n_rays;
   A.table_a = table_f16; A.table_b = table2_f16; A.prim_a = prim_pool; A.prim_b = table2_f16 ? prim_pool2 : nullptr; A.bias_pool = bias_pool;
   A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
@@ -510,11 +526,12 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;
+#define GFN_RENDER_ALL(X) X(0, 2, false) X(1, 2, false) X(0, 4, false) X(1, 4, false) X(0, 2, true) X(1, 2, true) X(0, 4, true) X(1, 4, true)
   if (gfn_first_call_on_device(attr_seen)) {
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+#define GFN_SET(T, L, R) \
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<T, L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    GFN_RENDER_ALL(GFN_SET)
+#undef GFN_SET
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
@@ -522,12 +539,43 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave
   const int cu_cap = gfn_decoder_cu_cap();
   if (blocks > cu_cap) blocks = cu_cap;
-  if (table2_f16 && levels == 4) fused_render_patch_kernel<1, 4><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-  else if (table2_f16) fused_render_patch_kernel<1, 2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-  else if (levels == 4) fused_render_patch_kernel<0, 4><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-  else fused_render_patch_kernel<0, 2><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  const int tab = table2_f16 ? 1 : 0;
+  const bool rec = A.rec != nullptr;
+#define GFN_LAUNCH(T, L, R) \
+  if (tab == T && levels == L && rec == R) fused_render_patch_kernel<T, L, R><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  GFN_RENDER_ALL(GFN_LAUNCH)
+#undef GFN_LAUNCH
+#undef GFN_RENDER_ALL
   GFN_CHECK_LAUNCH();
   return GFN_OK;
+}
+
+extern "C" {
+
+int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
+                     const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
+                     const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
+                     const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
+                     float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts, "gfn_fused_render: null sample pointer");
+  FusedArgs A{};
+  A.pts_offsets = pts_offsets; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
+  return fused_render_launch(A, "gfn_fused_render", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image, sh,
+                             emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
+}
+
+int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const uint16_t* table_f16, const uint16_t* table2_f16,
+                         const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
+                         const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
+                         int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
+                         void* stream) {
+  if (n_rays == 0) return GFN_OK;
+  GFN_CHECK_ARG(counts && march_rec && (reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_fused_render_rec: counts / march_rec null or not 16-byte aligned");
+  FusedArgs A{};
+  A.counts = counts; A.rec = march_rec;
+  return fused_render_launch(A, "gfn_fused_render_rec", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image,
+                             sh, emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
 }
 
 }  // extern "C"

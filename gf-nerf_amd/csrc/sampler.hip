@@ -578,8 +578,8 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
     if (end > pts_cap) { end = pts_cap; if (overflow && g == 0) atomicOr(overflow, 4); }
     max_n = (int)(end > base ? end - base : 0);
     if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;
-    if (in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;
   }
+  if ((FILL || rec) && in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;  // (:229-234; the count pass of gfn_sample_rays_record)
   bool active = in_range && max_n > 0 && n_oct > 0;
   int pts_ptr = 0, oct_ptr = 0;
   int nz_base = -1;
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
         wp[rr] = G::sum12(q);
       }
     }
-    // (count pass) the warped point where the record's store wants it: lane 1 (x), lane 2 (y, z)
-    const float wp_x1 = G::template to_lane<1>(wp[0]), wp_y2 = G::template to_lane<2>(wp[1]), wp_z2 = G::template to_lane<2>(wp[2]);
+    // (count pass) the warped point where the record's store wants it: lane 2 (x, y), lane 3 (z)
+    const float wp_x2 = G::template to_lane<2>(wp[0]), wp_y2 = G::template to_lane<2>(wp[1]), wp_z3 = G::template to_lane<3>(wp[2]);
     if (active) {
       // the step's noise: sixteen values per ray and visit of memory, NZ consecutive ones in each lane, handed out through the LDS crossbar --
       // a global load per step made every step wait for the memory system (and, loads and stores sharing one counter here, for the stores
@@ -693,12 +693,13 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
-      if (!FILL && rec && !first) {  // what the sample-parallel fill needs to rebuild this sample: ONE 8-byte store from lanes 0 .. 2 of the ray
-        // (six stores from one lane were six memory instructions per step, and on this architecture a wave's next load waits for
-        // every store before it: beside a kernel that keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
+      if (!FILL && rec && !first) {  // the sample as a 32-byte record {t, dist, leaf, transform, warped x y z, block}: all the sample-parallel fill (or the
+        // inference kernel, gfn_fused_render_rec) needs -- ONE 8-byte store from lanes 0 .. 3 of the ray (one store per value from one lane were
+        // six memory instructions per step, and on this architecture a wave's next load waits for every store before it: beside a kernel that
+        // keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
         float2 v2;
-        v2.x = g == 0 ? cur_t : (g == 1 ? __int_as_float(cur_oct_idx) : wp_y2);
-        v2.y = g == 0 ? exp_march_step * (pnorm + 1e-6f) : (g == 1 ? wp_x1 : wp_z2);
+        v2.x = g == 0 ? cur_t : (g == 1 ? __int_as_float(cur_oct_idx) : (g == 2 ? wp_x2 : wp_z3));
+        v2.y = g == 0 ? exp_march_step * (pnorm + 1e-6f) : (g == 1 ? __int_as_float(trans_idx) : (g == 2 ? wp_y2 : __int_as_float(block_idx)));
         if (g < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + (int64_t)pts_ptr * GFN_MARCH_REC_FLOATS)[g] = v2;
       }
       if (!first) pts_ptr += 1;
@@ -725,14 +726,13 @@ __device__ __forceinline__ float sum12_tree(const float* q) {  // the associatio
   return ((q[0] + (q[1] + q[2])) + (q[3] + (q[4] + q[5]))) + ((q[6] + (q[7] + q[8])) + (q[9] + (q[10] + q[11])));
 }
 
-// Second half of K4 when the count pass has recorded (t, dist, leaf, warped point) per sample: with the offsets known every
-// sample is written where it belongs, one thread per sample, instead of re-running the serial march.  (Until round 2 the record
-// held (t, dist, leaf) and this kernel redid the 12 projections per sample: 0.86 ms on a 138 k-ray render tile, 60 loads and 12
-// divisions per sample.)
+// Second half of K4 when the count pass has recorded the samples (32 bytes each: t, dist, leaf, transform, warped point, block): with
+// the offsets known every sample is written where it belongs, one thread per sample, instead of re-running the serial march.  (Until
+// round 2 the record held (t, dist, leaf) and this kernel redid the 12 projections per sample: 0.86 ms on a 138 k-ray render tile, 60
+// loads and 12 divisions per sample; until round 4 it fetched the leaf's node for the two indices the march had in registers.)
 __global__ __launch_bounds__(256) void fill_from_rec_kernel(
     int n_rays, int table_space, int max_hits, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const int* __restrict__ hit_counts, const float2* __restrict__ hit_nf, const CompactNode* __restrict__ nodes,
-    const float* __restrict__ transes, const float* __restrict__ rec, const int* __restrict__ pts_offsets,
+    const int* __restrict__ hit_counts, const float2* __restrict__ hit_nf, const float* __restrict__ rec, const int* __restrict__ pts_offsets,
     float* __restrict__ world_pts, float* __restrict__ warped_pts, float* __restrict__ dirs, float* __restrict__ dists,
     float* __restrict__ ts, int* __restrict__ anchors, int* __restrict__ ray_id, float* __restrict__ first_oct_dis,
     int64_t pts_cap, int* __restrict__ overflow) {
@@ -746,13 +746,11 @@ __global__ __launch_bounds__(256) void fill_from_rec_kernel(
   const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
   const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
   for (int k = threadIdx.x; k < n; k += 256) {
-    const float* rp = rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + k) * GFN_MARCH_REC_FLOATS;
-    const float t = rp[0], dist = rp[1];
-    const int oct = __float_as_int(rp[2]);
-    const CompactNode* nd = nodes + oct;
-    const int trans_idx = nd->trans_idx, block_idx = nd->block_idx;
+    const float4* rp = reinterpret_cast<const float4*>(rec + ((int64_t)ray * GFN_MAX_SAMPLE_PER_RAY + k) * GFN_MARCH_REC_FLOATS);
+    const float4 r0 = rp[0], r1 = rp[1];
+    const float t = r0.x;
     const float xyz[3] = {o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t};
-    float wp[3] = {rp[3], rp[4], rp[5]};  // as march_group_kernel<true> computes it (same lanes, same DPP trees)
+    float wp[3] = {r1.x, r1.y, r1.z};  // as march_group_kernel<L, true> computes it (same lanes, same DPP trees)
     if (table_space) {
       const float inv3 = 1.0f / 3.0f;
       wp[0] = (wp[0] + 1.5f) * inv3; wp[1] = (wp[1] + 1.5f) * inv3; wp[2] = (wp[2] + 1.5f) * inv3;
@@ -762,8 +760,8 @@ __global__ __launch_bounds__(256) void fill_from_rec_kernel(
     if (dirs) { dirs[3 * p] = d[0]; dirs[3 * p + 1] = d[1]; dirs[3 * p + 2] = d[2]; }
     warped_pts[3 * p] = wp[0]; warped_pts[3 * p + 1] = wp[1]; warped_pts[3 * p + 2] = wp[2];
     ts[p] = t;
-    dists[p] = dist;
-    anchors[3 * p] = trans_idx; anchors[3 * p + 1] = oct; anchors[3 * p + 2] = block_idx;
+    dists[p] = r0.y;
+    anchors[3 * p] = __float_as_int(r0.w); anchors[3 * p + 1] = __float_as_int(r0.z); anchors[3 * p + 2] = __float_as_int(r1.w);
     if (ray_id) ray_id[p] = ray;
   }
 }
@@ -1046,27 +1044,33 @@ int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void
   return GFN_OK;
 }
 
-int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
-                    const void* compact_nodes, const void* transes, float near_bound, float far_bound,
-                    int max_hits, float sample_l, int scale_by_dis, int table_space,
-                    int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
-                    int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
-                    float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream) {
-  GFN_CHECK_ARG(pts_offsets, "gfn_sample_rays: null pts_offsets");
+}  // extern "C"
+
+// gfn_sample_rays (record_counts == NULL) and gfn_sample_rays_record (the traversal and the counting march only: the per-ray counts go to
+// record_counts, the samples stay in march_rec)
+static int sample_rays_core(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                            int max_hits, float sample_l, int scale_by_dis, int table_space,
+                            int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
+                            int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+                            float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+                            int32_t* overflow_dev, float* march_rec, int tree_depth, int32_t* record_counts, void* stream) {
+  const bool record_only = record_counts != nullptr;
+  GFN_CHECK_ARG(record_only || pts_offsets, "gfn_sample_rays: null pts_offsets");
   GFN_CHECK_ARG(tree_depth <= kMaxDepth, "gfn_sample_rays: tree_depth=%d (at most %d levels)", tree_depth, kMaxDepth);
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
-    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
+    if (!record_only) GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
     return GFN_OK;
   }
   GFN_CHECK_ARG(rays_o && rays_d && noise && compact_nodes && transes && hit_counts && hit_idx && hit_near_far,
                 "gfn_sample_rays: null input / workspace pointer");
-  GFN_CHECK_ARG(warped_pts && dists && ts && anchors, "gfn_sample_rays: null output pointer");
+  GFN_CHECK_ARG(record_only ? march_rec != nullptr : (warped_pts && dists && ts && anchors), "gfn_sample_rays: null output pointer");
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays: march_rec must be 16-byte aligned");
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30), "gfn_sample_rays: n_rays=%lld", (long long)n_rays);
   GFN_CHECK_ARG(max_hits > 0 && max_hits <= GFN_MAX_OCT_PER_RAY && n_rays * max_hits < (1ll << 31),
                 "gfn_sample_rays: max_hits=%d", max_hits);
-  GFN_CHECK_ARG(pts_cap >= n_rays && pts_cap * 3 < (1ll << 31), "gfn_sample_rays: pts_cap=%lld must be in [n_rays, 2^31/3)",
+  GFN_CHECK_ARG(record_only || (pts_cap >= n_rays && pts_cap * 3 < (1ll << 31)), "gfn_sample_rays: pts_cap=%lld must be in [n_rays, 2^31/3)",
                 (long long)pts_cap);
   const CompactNode* cn = reinterpret_cast<const CompactNode*>(compact_nodes);
   const int stack = 7 * (tree_depth > 0 ? tree_depth : kMaxDepth) + 2;  // every expansion nets at most +7 entries per level
@@ -1074,7 +1078,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
       (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
       reinterpret_cast<float2*>(hit_near_far), overflow_dev, stack);
   GFN_CHECK_LAUNCH();
-  int* counts = anchors;  // scratch until the fill pass
+  int* counts = record_only ? record_counts : anchors;  // (anchors: scratch until the fill pass)
   // lanes per ray (MarchGroup): a row of 16 while the batch leaves the machine empty (the shortest chain per step), a quad from 32 Ki rays on
   // (a quarter of the vector work per ray); GFN_MARCH_LANES = 4 | 16 in the environment overrides (tests run both on the same rays)
   const char* lanes_env = getenv("GFN_MARCH_LANES");
@@ -1089,24 +1093,51 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
         (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
         reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts_out, offsets,
         FILL ? world_pts : nullptr, FILL ? warped_pts : nullptr, FILL ? dirs : nullptr, FILL ? dists : nullptr, FILL ? ts : nullptr,
-        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, FILL ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec);
+        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, (FILL || record_only) ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec);
   };
   using Row = std::integral_constant<int, 16>;
   using Quad = std::integral_constant<int, 4>;
   if (quad) march(Quad{}, std::false_type{}, counts, nullptr, march_rec);
   else march(Row{}, std::false_type{}, counts, nullptr, march_rec);
   GFN_CHECK_LAUNCH();
+  if (record_only) return GFN_OK;
   launch_scan(counts, (int)n_rays, pts_offsets, counts + n_rays, st);  // anchors holds 3 x pts_cap >= 3 x n_rays words: counts, then the scan's scratch
   GFN_CHECK_LAUNCH();
   if (march_rec)
     fill_from_rec_kernel<<<(unsigned)n_rays, 256, 0, st>>>(
-        (int)n_rays, table_space, max_hits, rays_o, rays_d, hit_counts, reinterpret_cast<const float2*>(hit_near_far), cn,
-        reinterpret_cast<const float*>(transes), march_rec, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
-        first_oct_dis, pts_cap, overflow_dev);
+        (int)n_rays, table_space, max_hits, rays_o, rays_d, hit_counts, reinterpret_cast<const float2*>(hit_near_far), march_rec, pts_offsets,
+        world_pts, warped_pts, dirs, dists, ts, anchors, ray_id, first_oct_dis, pts_cap, overflow_dev);
   else if (quad) march(Quad{}, std::true_type{}, nullptr, pts_offsets, nullptr);
   else march(Row{}, std::true_type{}, nullptr, pts_offsets, nullptr);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
+}
+
+
+extern "C" {
+
+int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                    const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                    int max_hits, float sample_l, int scale_by_dis, int table_space,
+                    int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
+                    int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
+                    float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
+                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream) {
+  return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis,
+                          table_space, hit_counts, hit_idx, hit_near_far, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
+                          first_oct_dis, pts_cap, overflow_dev, march_rec, tree_depth, nullptr, stream);
+}
+
+int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                           const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                           int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
+                           float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
+                           float* march_rec, int tree_depth, void* stream) {
+  GFN_CHECK_ARG(counts && first_oct_dis && (n_rays == 0 || march_rec), "gfn_sample_rays_record: null output pointer");
+  GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays_record: march_rec must be 16-byte aligned");
+  return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis, 1,
+                          hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, stream);
 }
 
 int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float* world_pts,

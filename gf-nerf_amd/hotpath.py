@@ -105,6 +105,7 @@ class HotPath:
         self.n_nodes = self.nodes.numel() // ops.TREE_NODE_BYTES
         self.nodes_compact = ops.tree_compact(self.nodes)  # 64-byte lines for the fast sampler
         self._sampler_ws = None
+        self._record_ws = None  # hit lists of sample(record=True) when the packed form's workspace does not exist or is too small
         self._depth_key, self._depth_val = None, 0
         self._records = None
         self._opt_stream, self._opt_pending = None, False
@@ -256,12 +257,14 @@ class HotPath:
             self._depth_key = key
         return self._depth_val
 
-    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None):
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
-        returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph)."""
+        returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph).
+        record: traversal + counting march only (ops.sample_rays_record) -- the samples stay in the march's records, for
+        render(tile_width=...), whose patch kernel reads them there (no scan, no fill, no packed copy)."""
         c = self.cfg
         pre, self._pre = self._pre, None
-        if pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
+        if not record and pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
             main = torch.cuda.current_stream()
             main.wait_stream(self._side)
             for v in list(pre[4].values()) + list(pre[4]["workspace"].values()):
@@ -276,6 +279,15 @@ class HotPath:
         # main stream too (SH basis of the unit directions, nerfacto_field.py:519-521; the zero the loss kernels add to) -- and ahead
         # of the traversal, not behind the fill: the sampler's branch is what a replayed focal step waits for last
         sh = ops.sh4(d, out=None if out is None else out["sh"])
+        if record:
+            s = self._timed("sample", ops.sample_rays_record, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l, c.scale_by_dis,
+                            near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
+                            workspace=self._record_ws if self._record_ws is not None else self._sampler_ws,  # (the hit lists of the packed form will do)
+                            out=out, tree_depth=self.tree_depth())
+            if s["workspace"] is not self._sampler_ws:
+                self._record_ws = s["workspace"]
+            s["dirs_unit"], s["sh"] = d, sh
+            return s
         loss0 = torch.zeros(1, dtype=torch.float32, device=self.dev) if out is None else out["loss0_buf"].zero_()
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
                         c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
@@ -488,7 +500,8 @@ class HotPath:
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
-        R = s["pts_offsets"].numel() - 1
+        recorded = s.get("pts_offsets") is None  # sample(record=True): only the patch kernel reads that form
+        R = s["counts"].numel() if recorded else s["pts_offsets"].numel() - 1
         pw = c.render_patch_width
         if (tile_width is not None and pw > 0 and self._fused_ok(block) and R % 32 == 0 and
                 (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0))):
@@ -503,6 +516,8 @@ class HotPath:
             rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)
             return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
                         oct_depth=s["first_oct_dis"][:, None] / c.scale_factor, samples=s, field=None, weights=None)
+        if recorded:
+            raise _lib.GfnError("render: samples of sample(record=True) need tile_width and a ray count the patch kernel takes (whole patches of 32)")
         if self._fused_ok(block):
             f, comp = self._forward_fused(s, cam_idx, block, early)
         else:

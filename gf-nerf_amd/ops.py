@@ -13,6 +13,7 @@ from . import _lib
 
 MAX_SAMPLE_PER_RAY = 1024
 MAX_OCT_PER_RAY = 1024
+MARCH_REC_FLOATS = 8  # GFN_MARCH_REC_FLOATS: t, dist, leaf, transform, warped x y z, block per recorded sample
 TREE_NODE_BYTES = 128
 TRANS_INFO_BYTES = 576
 
@@ -266,7 +267,7 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
         workspace = dict(hit_counts=torch.empty(max(R, 1), dtype=torch.int32, device=dev),
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
                          hit_nf=f(max(R * max_hits, 1), 2),
-                         march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * 6))  # (t, dist, leaf, warped point) per sample slot of the counting march
+                         march_rec=f(max(R, 1) * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS))  # the counting march's record of every sample
     if out is not None:
         if out["pts_offsets"].numel() != R + 1 or out["ts"].numel() != pts_cap or (want_world and out["world_pts"] is None):
             raise _lib.GfnError("sample_rays: `out` was made for another batch size / capacity / option set")
@@ -288,6 +289,38 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
                                     _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _ptr(workspace.get("march_rec")), int(tree_depth),
                                     _stream())
     _lib.check(rc, "gfn_sample_rays")
+    return out
+
+
+def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8, max_hits=MAX_OCT_PER_RAY,
+                       workspace=None, out=None, tree_depth=0):
+    """gfn_sample_rays_record: traversal + counting march only -> dict(counts i32 [R], first_oct_dis [R], march_rec f32 [R * 1024 * 8],
+    overflow, workspace): the samples stay where the march recorded them (slot k of ray r at (r * 1024 + k) * MARCH_REC_FLOATS), for
+    fused_render's record form.  out: the dict of an earlier call with the same R, written again in place."""
+    _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
+    _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
+    R = rays_o.shape[0]
+    if noise.numel() < MAX_SAMPLE_PER_RAY + R:
+        raise _lib.GfnError(f"noise needs at least {MAX_SAMPLE_PER_RAY + R} entries")
+    dev = rays_o.device
+    if workspace is None or workspace["hit_idx"].numel() < R * max_hits:
+        workspace = dict(hit_counts=torch.empty(max(R, 1), dtype=torch.int32, device=dev),
+                         hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
+                         hit_nf=torch.empty((max(R * max_hits, 1), 2), dtype=torch.float32, device=dev))
+    if out is not None:
+        if out["counts"].numel() != R:
+            raise _lib.GfnError("sample_rays_record: `out` was made for another batch size")
+        out["overflow"].zero_()
+        out["workspace"] = workspace
+    else:
+        out = dict(counts=torch.empty(R, dtype=torch.int32, device=dev), first_oct_dis=torch.empty(R, dtype=torch.float32, device=dev),
+                   march_rec=torch.empty(max(R, 1) * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS, dtype=torch.float32, device=dev),
+                   overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace)
+    rc = _lib.lib().gfn_sample_rays_record(_ptr(rays_o), _ptr(rays_d), _ptr(noise), R, _ptr(compact_nodes), _ptr(transes), near, far, max_hits,
+                                           float(sample_l), int(bool(scale_by_dis)), _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]),
+                                           _ptr(workspace["hit_nf"]), _ptr(out["counts"]), _ptr(out["first_oct_dis"]), _ptr(out["overflow"]),
+                                           _ptr(out["march_rec"]), int(tree_depth), _stream())
+    _lib.check(rc, "gfn_sample_rays_record")
     return out
 
 
@@ -888,13 +921,24 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
                  early_T=0.0, tile_width=0, patch_width=8):
     """gfn_fused_render: inference through patches of 32 neighbouring rays walked in lockstep (no per-sample outputs).
     -> dict(rgb [R,3], acc [R], depth_raw [R], t_minmax [2]).  R must be a multiple of 32; tile_width: the rays are a block of
-    pixels this wide, row major (0: a run of rays)."""
-    po = s["pts_offsets"]
-    R = po.numel() - 1
-    dev = po.device
-    for nm, t, dt_, last in (("pts_offsets", po, torch.int32, None), ("warped_pts", s["warped_pts"], torch.float32, 3),
-                             ("anchors", s["anchors"], torch.int32, 3), ("dists", s["dists"], torch.float32, None), ("ts", s["ts"], torch.float32, None),
-                             ("table", table_f16, torch.float16, None), ("table2", table2_f16, torch.float16, None),
+    pixels this wide, row major (0: a run of rays).  s: the packed samples of sample_rays, or the records of sample_rays_record
+    (gfn_fused_render_rec: same images, no fill pass in between)."""
+    rec = s.get("pts_offsets") is None  # the record form: samples of sample_rays_record (counts + march_rec)
+    if rec:
+        po = None
+        R = s["counts"].numel()
+        dev = s["counts"].device
+        _chk(s["counts"], torch.int32, "counts"); _chk(s["march_rec"], torch.float32, "march_rec")
+        if s["march_rec"].numel() < R * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS:
+            raise _lib.GfnError("march_rec does not hold 1024 record slots per ray")
+    else:
+        po = s["pts_offsets"]
+        R = po.numel() - 1
+        dev = po.device
+        for nm, t, dt_, last in (("pts_offsets", po, torch.int32, None), ("warped_pts", s["warped_pts"], torch.float32, 3),
+                                 ("anchors", s["anchors"], torch.int32, 3), ("dists", s["dists"], torch.float32, None), ("ts", s["ts"], torch.float32, None)):
+            _chk(t, dt_, nm, last)
+    for nm, t, dt_, last in (("table", table_f16, torch.float16, None), ("table2", table2_f16, torch.float16, None),
                              ("prim_pool", prim_pool, torch.int32, None), ("prim_pool2", prim_pool2, torch.int32, None),
                              ("bias_pool", bias_pool, torch.float32, None), ("image", image, torch.uint8, None), ("sh", sh, torch.float32, 16),
                              ("emb", emb, torch.float32, 32), ("cam_idx", cam_idx, torch.int32, None)):
@@ -909,10 +953,13 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     out = dict(rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
     counter = torch.empty(8, dtype=torch.int32, device=dev)
-    rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), _ptr(table_f16),
-                                     _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
-                                     _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
-                                     _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
+    tail = (_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
+            _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
+            _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
+    if rec:
+        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), *tail)
+    else:
+        rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), *tail)
     _lib.check(rc, "gfn_fused_render")
     return out
 

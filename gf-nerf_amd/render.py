@@ -119,7 +119,9 @@ class TileRenderer:
                 with torch.cuda.stream(side):
                     if i >= self.SLOTS:
                         side.wait_event(used[i - self.SLOTS])
-                    samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None))
+                    # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
+                    samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
+                                             record=self.patch_tw is not None))
                     ev = torch.cuda.Event()
                     ev.record(side)
                     done.append(ev)

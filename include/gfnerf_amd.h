@@ -50,7 +50,7 @@ typedef enum {
  *   100: rounds 1-2.   101: round 3 (gfn_adam_step_ex / gfn_fused_forward / gfn_fused_render lost an int, gfn_hash_fwd_lm /
  *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
  *   102: round 4. */
-#define GFN_ABI_VERSION 102
+#define GFN_ABI_VERSION 103
 
 const char* gfn_last_error(void);
 int gfn_version(void);
@@ -171,12 +171,12 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
               int32_t* overflow_dev, void* stream);
 
 /* Fast path of GetSamples() for the training / render loop: K3 once into per-ray dense
- * slots + K4 with a 16-lane wave row per ray; bit-identical samples to gfn_trace + gfn_march.
+ * slots + K4 with a group of lanes per ray (a 16-lane row below 32 Ki rays, a quad from there on); bit-identical samples to gfn_trace + gfn_march.
  * compact_nodes: output of gfn_tree_compact (64 B per node, 64-byte aligned), to be refreshed
  * whenever the node blob changes (gfn_update_nodes).  Workspace: hit_counts i32 [R],
- * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2], and march_rec f32 [R*1024*GFN_MARCH_REC_FLOATS] (may be
- * NULL): with it the counting march records (t, dist, leaf) per sample and the outputs are rebuilt one
- * thread per sample instead of marching every ray a second time -- same bits, ~1/3 less time.  tree_depth: depth of
+ * hit_idx i32 [R*max_hits], hit_near_far f32 [R*max_hits,2], and march_rec f32 [R*1024*GFN_MARCH_REC_FLOATS], 16-byte aligned (may be
+ * NULL): with it the counting march records every sample (32 bytes: t, dist, leaf, transform, warped point, block) and the outputs are
+ * rebuilt one thread per sample instead of marching every ray a second time -- same bits, ~1/3 less time.  tree_depth: depth of
  * the deepest node (root = 0) or an upper bound of it, 0 = the reference's 24: the traversal's per-ray stack in LDS holds
  * 7 * tree_depth + 2 entries, and a shallower tree lets a CU traverse more rays at once. */
 int gfn_tree_compact(const void* nodes, int64_t n_nodes, void* compact_out, void* stream);
@@ -187,6 +187,15 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
                     int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream);
+/* The first half of the same only: traversal + counting march.  The samples stay where the march recorded them -- slot k of ray r at
+ * march_rec[(r * 1024 + k) * GFN_MARCH_REC_FLOATS], counts[r] of them (table_space does not apply: the record holds the warped point) --
+ * for a consumer that walks rays, not packed samples: gfn_fused_render_rec.  No scan, no fill, no second copy of the samples (a
+ * 138 k-ray render tile: 1.4 GB of the 2.8 GB its samples cost the memory system).  first_oct_dis f32 [R] as gfn_sample_rays. */
+int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                           const void* compact_nodes, const void* transes, float near_bound, float far_bound,
+                           int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
+                           float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
+                           float* march_rec, int tree_depth, void* stream);
 
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
@@ -334,7 +343,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
  * of them) -- a caller may step the slots of finished ranges (range r = f16 elements [r << 15, (r + 1) << 15) of
  * the pool) while later ranges still accumulate. */
 #define GFN_GRAD_RANGE_LOG2 14
-#define GFN_MARCH_REC_FLOATS 6 /* per sample slot of gfn_sample_rays' march_rec: t, dist, leaf, warped point */
+#define GFN_MARCH_REC_FLOATS 8 /* per sample slot of gfn_sample_rays' march_rec: t, dist, leaf (i32), transform (i32), warped x y z, block (i32) */
 #define GFN_GRAD_MAX_RANGES 1088
 int gfn_grad_record_ranges(int log2_T);
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T,
@@ -417,6 +426,14 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
                      int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                      const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
                      float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
+/* The same on the samples of gfn_sample_rays_record: counts i32 [R] and march_rec (16-byte aligned) instead of the packed arrays.  Slot k
+ * of ray r is read where the counting march left it; the table-space point is made from the recorded warped point as the fill pass
+ * makes it ((w + 1.5) * (1/3)), so the images are the bits of gfn_sample_rays(table_space = 1) + gfn_fused_render. */
+int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const uint16_t* table_f16,
+                         const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
+                         int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
+                         const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
+                         float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
 
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's

@@ -744,6 +744,16 @@ def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_wi
         assert np.isfinite(a).all()
         np.testing.assert_allclose(a, b, rtol=tol, atol=tol, err_msg=k)
     assert float(ref["accumulation"].max()) > 0.5  # the comparison is not between empty images
+    # the samples read where the counting march recorded them (sample(record=True) -> gfn_fused_render_rec: no scan, no fill, no packed
+    # copy) are the same samples: the same images, bit for bit
+    recd = hp.sample(o, d, noise, record=True)
+    assert recd.get("pts_offsets") is None and torch.equal(recd["counts"], ref["samples"]["pts_offsets"].diff())
+    assert torch.equal(recd["first_oct_dis"], ref["samples"]["first_oct_dis"])
+    again = hp.render(o, d, cam, noise, block=block, early_T=early_T, samples=recd, tile_width=tile_width)
+    for k in ("rgb", "accumulation", "depth", "oct_depth"):
+        assert torch.equal(again[k], got[k]), k
+    with pytest.raises(Exception, match="record"):
+        hp.render(o, d, cam, noise, block=block, early_T=early_T, samples=recd)  # only the patch kernel reads records
     # a ray count that does not divide into patches falls back to the wave-per-ray kernel
     odd = hp.render(o[:40], d[:40], cam[:40], noise, block=block, early_T=early_T, tile_width=0)
     assert odd["field"] is not None
