@@ -499,12 +499,15 @@ class HotPath:
         neighbouring rays in lockstep (field / weights are then not returned)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
-        s = self.sample(rays_o, rays_d_raw, noise) if samples is None else samples
-        recorded = s.get("pts_offsets") is None  # sample(record=True): only the patch kernel reads that form
-        R = s["counts"].numel() if recorded else s["pts_offsets"].numel() - 1
+        R = rays_o.shape[0]
         pw = c.render_patch_width
-        if (tile_width is not None and pw > 0 and self._fused_ok(block) and R % 32 == 0 and
-                (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0))):
+        patches = (tile_width is not None and pw > 0 and self._fused_ok(block) and R % 32 == 0 and
+                   (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0)))
+        s = self.sample(rays_o, rays_d_raw, noise, record=patches) if samples is None else samples  # (the patch kernel reads the march's records)
+        recorded = s.get("pts_offsets") is None  # sample(record=True): only the patch kernel reads that form
+        if (s["counts"].numel() if recorded else s["pts_offsets"].numel() - 1) != R:
+            raise _lib.GfnError("render: `samples` were made for another ray count")
+        if patches:
             self._sync_opt()
             sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
             comp = self._timed("fused_render", ops.fused_render, s, self.table16, self.prim, self.n_volumes, c.log2_T,

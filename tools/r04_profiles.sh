@@ -1,5 +1,6 @@
 # round-4 profile collection, two gpurun calls (a call lasts 20 minutes at most):
 #   bash tools/r04_profiles.sh traces   the bench line + kernel-trace stats (focal / global graph launch, render graph + eager, the plugin-surface step)
+#   bash tools/r04_profiles.sh pmc_render   only the inference kernel's passes of the next mode (after a change to csrc/fused_fwd.hip alone)
 #   bash tools/r04_profiles.sh pmc      separate --pmc passes (one counter group each; never together with a trace: MI355X guide) for the focal step,
 #                                       the global step and the inference kernel (tiles rendered eagerly: --render-eager)
 # Everything is addressed through $GRAFT_REPO_ROOT (the r03 script mixed it with /root/repo).
@@ -29,12 +30,12 @@ if [ "$MODE" = "traces" ]; then
   echo "kt plugin done"
 else
   cd /tmp
-  for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B" "TCC_HIT TCC_MISS" "TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  [ "$MODE" = "pmc_render" ] || for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B" "TCC_HIT TCC_MISS" "TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     T=$(echo $C | tr ' ' '_')
     rocprofv3 --pmc $C --output-format csv -d $O/pmc_focal_$T -- python3 $B --steps 3 --warmup 2 $COMMON --global-steps 0 --launch eager > $O/pmc_focal_$T.json 2>$O/pmc_focal_$T.err || echo "pmc $T failed"
     echo "pmc focal $T done"
   done
-  for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  [ "$MODE" = "pmc_render" ] || for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     T=$(echo $C | tr ' ' '_')
     rocprofv3 --pmc $C --output-format csv -d $O/pmc_global_$T -- python3 $B --steps 3 --warmup 58 $COMMON --stage global --launch eager > $O/pmc_global_$T.json 2>$O/pmc_global_$T.err || echo "pmc global $T failed"
     echo "pmc global $T done"
