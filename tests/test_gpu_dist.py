@@ -96,8 +96,9 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     for key in ("eager_forced_identical_step1", "eager_forced_identical", "noemb_forced_identical"):
         assert all(res[key][i] for i in (4, 5, 6, 7)), (key, res[key])  # nodes, weight / alpha statistics, visit counts
     assert res["eager_forced_table_far_frac"] <= max(2.0 * res["eager_control_table_far_frac"], 1e-4), (res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"])
-    assert res["eager_forced_rel"][2] < 1e-4 and res["eager_forced_rel"][3] < 1e-5, res["eager_forced_rel"]  # decoder, embedding (the table: far_frac above -- its
-    # largest single difference is one flipped Adam step, 2 lr, in either comparison)
+    for i, floor in ((2, 1e-4), (3, 1e-5)):  # decoder, embedding: as close to the plain run as the control run is (a flipped Adam step in a weight that both
+        # runs update from a near-zero gradient shows in either comparison: 6e-4 of the largest weight, once in ten runs); the table: far_frac above
+        assert res["eager_forced_rel"][i] <= max(2.0 * res["eager_control_rel"][i], floor), (i, res["eager_forced_rel"], res["eager_control_rel"])
     # segmented replay: four graphs, three eager RCCL exchanges, four replays
     assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
     assert res["graph_sync_stats"]["octree_max_reduces"] == 5 and res["graph_sync_stats"]["direct_reduces"] == 5, res["graph_sync_stats"]
