@@ -112,7 +112,7 @@ class TileRenderer:
             side.wait_stream(main)
             # producer branch: the P samplers back to back (they share one workspace), into a ring of SLOTS sample buffers -- tile i
             # is sampled into the buffer of tile i - SLOTS once that tile's fused forward has read it, so a whole frame can be one
-            # replay without one 5 GB sample buffer per tile; consumer branch: the fused forward of tile i beside the samplers
+            # replay without one 4.5 GB record buffer per tile; consumer branch: the fused forward of tile i beside the samplers
             # of the tiles after it
             done, used, samples, outs = [], [], [], []
             for i in range(self.P):
