@@ -387,7 +387,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,
-                kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep" % (args.render_patch_width, 32 // args.render_patch_width)
+                kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep, samples read from the counting march's records" % (args.render_patch_width, 32 // args.render_patch_width)
                         if args.render_patch_width > 0 and tr.patch_tw is not None else "fused_fwd_kernel: a wave per ray"),
                 tile=(f"{tr.tw}x{tr.T // tr.tw} pixel blocks" if tr.tw else "raster runs"),
                 table="global + focal block" if block is not None else "global", fineness=fineness, mean_accumulation=acc,
@@ -432,7 +432,7 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
                 mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
                 lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * tiles_per_frame)
                                      if fresh and pmc.get("decoded_samples_per_launch:render") else None),  # useful samples / samples the lockstep patches decode
-                kernel="fused_render_patch_kernel<1, 2>" if block is not None else "fused_render_patch_kernel<0, 2>",
+                kernel="fused_render_patch_kernel<1, 2, true>" if block is not None else "fused_render_patch_kernel<0, 2, true>",
                 kernel_ms_per_tile=pmc.get("kernel_ms:render") if fresh else None,
                 note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 
