@@ -96,15 +96,18 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     for key in ("eager_forced_identical_step1", "eager_forced_identical", "noemb_forced_identical"):
         assert all(res[key][i] for i in (4, 5, 6, 7)), (key, res[key])  # nodes, weight / alpha statistics, visit counts
     assert res["eager_forced_table_far_frac"] <= max(2.0 * res["eager_control_table_far_frac"], 1e-4), (res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"])
-    for i, floor in ((2, 1e-4), (3, 1e-5)):  # decoder, embedding: as close to the plain run as the control run is (a flipped Adam step in a weight that both
-        # runs update from a near-zero gradient shows in either comparison: 6e-4 of the largest weight, once in ten runs); the table: far_frac above
-        assert res["eager_forced_rel"][i] <= max(2.0 * res["eager_control_rel"][i], floor), (i, res["eager_forced_rel"], res["eager_control_rel"])
+    # decoder, embedding: as close to the plain run as the control run is, or within a few flipped Adam steps -- the table's last-bit differences reach the
+    # decoder's gradients, and a weight whose gradient is near zero then steps the other way: 3e-4 - 6e-4 of the largest weight per flip, seen in the
+    # control as often as in the forced run.  (An exchange that lost, doubled or mis-scaled a gradient moves every weight: 1e-2 and more.)  The table: far_frac above
+    FLIPS = 2e-3
+    for i in (2, 3):
+        assert res["eager_forced_rel"][i] <= max(2.0 * res["eager_control_rel"][i], FLIPS), (i, res["eager_forced_rel"], res["eager_control_rel"])
     # segmented replay: four graphs, three eager RCCL exchanges, four replays
     assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
     assert res["graph_sync_stats"]["octree_max_reduces"] == 5 and res["graph_sync_stats"]["direct_reduces"] == 5, res["graph_sync_stats"]
     assert res["graph_steps"] == [5, 5, 5] and res["finite"]
     assert all(res["graph_forced_vs_segmented_identical"][i] for i in (4, 5, 6, 7)), (res["graph_forced_vs_segmented_identical"], res["graph_forced_vs_segmented_rel"])
-    assert res["graph_forced_vs_segmented_rel"][0] < 2e-2 and res["graph_forced_vs_segmented_rel"][2] < 1e-4, res["graph_forced_vs_segmented_rel"]
+    assert res["graph_forced_vs_segmented_rel"][0] < 2e-2 and max(res["graph_forced_vs_segmented_rel"][2:4]) < FLIPS, res["graph_forced_vs_segmented_rel"]
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
