@@ -380,10 +380,11 @@ __global__ __launch_bounds__(kRayBlock) void march_kernel(
 //   * the traversal runs once, writing each ray's leaves to its own dense slot
 //     (R x max_hits is small) -- no count pass, no scan, no host sync -- with an 8-lane
 //     group per ray that tests all children of a node in one step;
-//   * the march gives every ray a 16-lane row of a wave: lanes 0..11 own one of the
-//     12 perspective projections, the 3x12 contractions are 4-step shuffle trees in
-//     exactly the association of sum12(), and the leaf's TransInfo stays in registers
-//     until the ray crosses into the next leaf.  4096 rays = 1024 waves instead of 64.
+//   * the march gives every ray a group of lanes of a wave (MarchGroup below): the 12
+//     perspective projections are shared among them, the 3x12 contractions are DPP
+//     trees in exactly the association of sum12(), and the leaf's TransInfo stays in
+//     registers until the ray crosses into the next leaf.  16 lanes per ray for small
+//     batches (4096 rays = 1024 waves instead of 64), 4 for render tiles.
 // ============================================================================
 struct __attribute__((aligned(64))) CompactNode {
   float cx, cy, cz, side;
