@@ -81,6 +81,10 @@ j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA
 j["l1_miss_requests:render"] = int(round(fv("TCP_TCC_READ_REQ_sum")))
 j["l2_hit_rate:render"] = round(fv("TCC_HIT") / (fv("TCC_HIT") + fv("TCC_MISS")), 3)
 j["traffic:render"] = tr(rk)
+# the march of a render tile (quad of lanes per ray; the same eager run): bound by vector-instruction issue
+mq = one(rd, "march_group_kernel<4")
+j["valu_busy:march_quad:render"] = round(4.0 * float(mq["SQ_ACTIVE_INST_VALU_mean"]) / (float(mq["GRBM_GUI_ACTIVE_mean"]) * 128.0), 4)
+j["valu_insts_per_launch:march_quad:render"] = int(round(float(mq["SQ_INSTS_VALU_mean"])))
 ks = {r["kernel"]: r for r in csv.DictReader(open(f"profiles/{TAG}_render_eager_kernel_stats.csv"))}
 j["kernel_ms:render"] = round(float(one(ks, "fused_render_patch_kernel")["avg_ns"]) / 1e6, 4)
 sha = lambda q: hashlib.sha256(open(os.path.join("gf-nerf_amd", q), "rb").read()).hexdigest()
