@@ -1134,7 +1134,8 @@ int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
                            float* march_rec, int tree_depth, void* stream) {
-  GFN_CHECK_ARG(counts && first_oct_dis && (n_rays == 0 || march_rec), "gfn_sample_rays_record: null output pointer");
+  if (n_rays == 0) return GFN_OK;  // (an empty batch has no outputs to point at)
+  GFN_CHECK_ARG(counts && first_oct_dis && march_rec, "gfn_sample_rays_record: null output pointer");
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays_record: march_rec must be 16-byte aligned");
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis, 1,
                           hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,

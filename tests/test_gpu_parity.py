@@ -307,6 +307,42 @@ def test_fast_sampler_bit_exact(oracle, ops, dev, monkeypatch, train, fineness, 
         assert int(g["overflow"].item()) == 0
 
 
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_sample_record_holds_the_packed_samples(oracle, ops, dev, monkeypatch, lanes):
+    """gfn_sample_rays_record (traversal + counting march only; what the inference kernel reads, gfn_fused_render_rec): slot k of ray r of
+    march_rec is sample pts_offsets[r] + k of gfn_sample_rays, field by field and bit for bit -- {t, dist, leaf, transform, warped point
+    (before the table-space map), block} -- and counts / first_oct_dis are the packed form's; slots beyond a ray's count are never read."""
+    import torch
+
+    from gfnerf_amd import scene
+
+    monkeypatch.setenv("GFN_MARCH_LANES", str(lanes))
+    n_rays = 160
+    sc, ref, _ = _sample_both(oracle, ops, dev, n_rays=n_rays, train=True, fineness=6.0)
+    noise = _t(scene.make_noise(n_rays, True, 6.0, seed=1), dev)
+    cn, tr = ops.tree_compact(_t(sc["nodes"], dev)), _t(sc["transes"], dev)
+    o, d = _t(ref["o"], dev), _t(ref["d"], dev)
+    packed = ops.sample_rays(o, d, noise, cn, tr, 1.0 / 256, True, table_space=False)
+    rec = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True)
+    po = packed["pts_offsets"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(rec["counts"].cpu().numpy(), np.diff(po)) and int(po[-1]) > 3000
+    assert torch.equal(rec["first_oct_dis"], packed["first_oct_dis"]) and int(rec["overflow"].item()) == 0
+    R = rec["march_rec"].view(n_rays, ops.MAX_SAMPLE_PER_RAY, ops.MARCH_REC_FLOATS).cpu().numpy()
+    Ri = R.view(np.int32)
+    ts, dists, wp, an = (packed[k].cpu().numpy() for k in ("ts", "dists", "warped_pts", "anchors"))
+    for r in range(n_rays):
+        a, b = po[r], po[r + 1]
+        m = R[r, :b - a]
+        assert np.array_equal(m[:, 0], ts[a:b]) and np.array_equal(m[:, 1], dists[a:b]) and np.array_equal(m[:, 4:7], wp[a:b]), r
+        mi = Ri[r, :b - a]
+        assert np.array_equal(mi[:, 2], an[a:b, 1]) and np.array_equal(mi[:, 3], an[a:b, 0]) and np.array_equal(mi[:, 7], an[a:b, 2]), r
+    # the same dict written again in place
+    again = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True, workspace=rec["workspace"], out=rec)
+    assert again is rec and np.array_equal(rec["counts"].cpu().numpy(), np.diff(po))
+    empty = torch.empty((0, 3), device=dev)
+    assert ops.sample_rays_record(empty, empty, noise, cn, tr, 1.0 / 256, True)["counts"].numel() == 0
+
+
 def test_traversal_stack_sized_by_tree_depth(oracle, ops, dev):
     """gfn_sample_rays with tree_depth = the blob's real depth (ops.tree_depth: parent links) gives the bits of the default
     (the reference's 24-level bound): 7 entries per level + 2 is what a depth-first traversal can stack.  A bound below the real
