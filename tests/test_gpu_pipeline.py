@@ -343,6 +343,11 @@ def test_fused_paths_edge_cases(setup):
         np.testing.assert_allclose(pr["rgb"].cpu().numpy(), rgb, atol=2e-6)
         np.testing.assert_allclose(pr["accumulation"].cpu().numpy(), out["accumulation"].cpu().numpy(), atol=2e-6)
         np.testing.assert_allclose(pr["depth"].cpu().numpy(), out["depth"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # ... and from the march's records (no samples given: render samples in the record form itself): the same bits
+        pr2 = hp.render(t(o), t(d), t(cam), noise, block=0, early_T=0.0, tile_width=tw)
+        assert pr2["samples"].get("pts_offsets") is None and np.array_equal(pr2["samples"]["counts"].cpu().numpy(), cnt)
+        for k in ("rgb", "accumulation", "depth", "oct_depth"):
+            assert torch.equal(pr2[k], pr[k]), (tw, k)
     # training step on the same batch (fused backward): finite loss and gradients
     gt = t(S["gt"][:R])
     loss, aux = hp.forward_backward(t(o), t(d), t(cam), gt, noise, stage="focal", block=0)
@@ -354,6 +359,8 @@ def test_fused_paths_edge_cases(setup):
     out2p = hp.render(t(o2), t(d2), t(cam), noise, block=None, samples=out2["samples"], tile_width=0)
     assert out2p["field"] is None and float(out2p["rgb"].abs().max()) == 0.0 and float(out2p["accumulation"].abs().max()) == 0.0
     assert torch.equal(out2p["depth"], out2["depth"])
+    out2r = hp.render(t(o2), t(d2), t(cam), noise, block=None, tile_width=0)  # the record form on rays without samples
+    assert int(out2r["samples"]["counts"].sum().item()) == 0 and float(out2r["rgb"].abs().max()) == 0.0 and torch.equal(out2r["depth"], out2["depth"])
     loss2, _ = hp.forward_backward(t(o2), t(d2), t(cam), gt, noise, stage="global")
     assert np.isfinite(loss2.item()) and float(hp.table_grad.float().abs().max()) == 0.0
     # empty batch
