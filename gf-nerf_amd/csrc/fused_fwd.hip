@@ -262,6 +262,7 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
 // its lane (no scan) and drops out once its transmittance is below early_T.  Per-sample outputs are not written (inference).
 // tile_w > 0: the rays are a tile_w-wide block of pixels, row major, and a patch is patch_w x (32 / patch_w) pixels;
 // tile_w == 0: a patch is 32 consecutive rays.
+constexpr int kRenderStrip = 4;      // patch columns per strip of the hand-out order (below)
 constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / prime offsets the kernel needs 254 registers, no spills
 // RENDER_LEVELS: levels whose gathers (16 each with two tables) a lane keeps in flight together (2 or 4; GFN_RENDER_LEVELS in the environment
 // picks the instantiation -- measured: tools/README.md, round 4)
@@ -300,7 +301,15 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     fetches++;
     if (seg_n <= 0 || idx >= seg_n) { seg_k++; continue; }  // wave-uniform
     const int patch = __builtin_amdgcn_readfirstlane(seg_lo + idx);  // wave-uniform: its row / column arithmetic stays on the scalar unit
-    const int prow = patch / patches_per_row, pcol = patch - prow * patches_per_row;
+    // the order patches are handed out in: vertical strips of kRenderStrip patch columns, row major inside a strip -- the ~220 patches an XCD has
+    // in flight are then a 32 x 220 pixel block instead of a 384 x 18 pixel band of the tile, their rays closer together in the volume and
+    // more of their table lines shared in the XCD's L2 (40.4 -> 39.7 ms/Mpix; strips of 2 ... 6 columns alike, 12 ... 24 less)
+    int prow = patch / patches_per_row, pcol = patch - prow * patches_per_row;
+    if (tile_w > 0 && patches_per_row % kRenderStrip == 0) {
+      const int per_strip = kRenderStrip * (n_patches / patches_per_row);
+      const int strip = patch / per_strip, rem = patch - strip * per_strip;
+      prow = rem / kRenderStrip; pcol = strip * kRenderStrip + rem % kRenderStrip;
+    }
     const int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
     const int cnt = REC ? A.counts[ray] : A.pts_offsets[ray + 1] - A.pts_offsets[ray];
     const int64_t s = REC ? (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY : (int64_t)A.pts_offsets[ray];
