@@ -49,7 +49,8 @@ typedef enum {
  * ctypes loader gf-nerf_amd/_lib.py does: arguments of a changed signature would otherwise shift silently).
  *   100: rounds 1-2.   101: round 3 (gfn_adam_step_ex / gfn_fused_forward / gfn_fused_render lost an int, gfn_hash_fwd_lm /
  *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
- *   102: round 4. */
+ *   102: round 4.   103: round 4 (gfn_sample_rays_record, gfn_fused_render_rec added; GFN_MARCH_REC_FLOATS 6 -> 8: a caller's march_rec
+ *   buffer grows by a third). */
 #define GFN_ABI_VERSION 103
 
 const char* gfn_last_error(void);
