@@ -18,10 +18,13 @@ import torch
 from . import ops
 
 
-def choose_tile(height, width, target_rays=131072, patch=(8, 4)):
+def choose_tile(height, width, target_rays=524288, patch=(8, 4)):
     """-> (tile_width, tile_height): a block of pixels that divides the frame exactly (no ragged border tiles), holds whole
-    patches, and is close to target_rays and to square (score: |log(rays / target)| + 0.1 |log(width / height)|).  The patch renderer wants ~4 patches
-    per SIMD in flight: 128 Ki rays; border tiles padded to full size cost a 1920 x 1080 frame 21 % with 512 x 256 tiles."""
+    patches, and is close to target_rays and to square (score: |log(rays / target)| + 0.1 |log(width / height)|).  Border tiles padded to full
+    size cost a 1920 x 1080 frame 21 % with 512 x 256 tiles.  512 Ki rays: every tile ends with the tail of its march and a hand-over between
+    the two branches, and a tile of 400 Ki - 700 Ki rays spreads that over four times the work of the 128 Ki-ray tile rounds 2 - 4 used (full HD:
+    960 x 540, 38.6 against 39.9 ms/Mpix; 1920 x 216 / 1920 x 360 / 640 x 1080: 38.1 / 38.1 / 38.4; the record form of the samples costs
+    32 KB per ray and buffer: 17 GB each here)."""
     best = None
     for tw in range(patch[0], width + 1, patch[0]):
         if width % tw:
@@ -51,9 +54,9 @@ class TileRenderer:
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
         tile_rays / tile_width: a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (tile_width 0: a raster run);
-        None = chosen per image size by choose_tile (~128 Ki rays, dividing the frame).  pipeline: tiles per graph replay
-        (their samplers run on a second graph branch, through a ring of three sample buffers); None = the largest divisor of the tile
-        count <= 16 (a full-HD frame: its 15 tiles in one replay)."""
+        None = chosen per image size by choose_tile (~512 Ki rays, dividing the frame).  pipeline: tiles per graph replay
+        (their samplers run on a second graph branch, through a ring of two sample buffers); None = the largest divisor of the tile
+        count <= 16 (a full-HD frame: its 4 tiles in one replay)."""
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
         self.block, self.early_T, self.fineness = block, early_T, float(fineness)
@@ -135,7 +138,7 @@ class TileRenderer:
             _lib.lib().gfn_set_decoder_cus(prev)
         return outs
 
-    SLOTS = 3  # sample buffers of the tile pipeline
+    SLOTS = 2  # sample buffers of the tile pipeline: the one the inference kernel reads and the one the next tile's sampler fills
 
     def _consume(self, i, main, done, used, samples, outs):
         hp = self.hp

@@ -187,7 +187,7 @@ def test_matrix_kernels_do_not_spill():
 
 
 def test_choose_tile_divides_the_frame():
-    """render.choose_tile: tiles that divide the image exactly and hold whole 8 x 4 patches, near 128 Ki rays."""
+    """render.choose_tile: tiles that divide the image exactly and hold whole 8 x 4 patches, near 512 Ki rays."""
     import importlib.util
     import math  # noqa: F401
 
@@ -198,8 +198,8 @@ def test_choose_tile_divides_the_frame():
     for (h, w) in ((1080, 1920), (864, 1152), (2160, 3840), (64, 128), (720, 1280), (480, 640)):
         tw, th = choose(h, w)
         assert w % tw == 0 and h % th == 0 and tw % 8 == 0 and th % 4 == 0, (h, w, tw, th)
-        assert tw * th <= max(h * w, 1) and (tw * th >= 0.4 * min(131072, h * w))
-    assert choose(1080, 1920) == (384, 360)
+        assert tw * th <= max(h * w, 1) and (tw * th >= 0.4 * min(524288, h * w))
+    assert choose(1080, 1920) == (960, 540) and choose(1080, 1920, target_rays=131072) == (384, 360)
     assert choose(1080, 1917)[0] == 128  # no width divides 1917 into multiples of 8: fixed-width tiles with ragged borders
 
 

@@ -393,13 +393,13 @@ def test_bench_step_phased_forward_is_the_one_phase_forward_at_full_size(world):
 
 def test_bench_scene_full_frame_tile_render(world, oracle):
     """BASELINE configs[4] at the size bench.py's `render` sub-record times (VERDICT r03 #2b): a 1920 x 1080 frame of the 1,600-camera scene,
-    T = 2^21, global + focal table, through render.TileRenderer exactly as bench.render_bench builds it -- choose_tile's 384 x 360 pixel
-    blocks, all 15 tiles in ONE hipGraph replay, samplers on the producer branch through the ring of three sample buffers,
-    gfn_fused_render (patches of 8 x 4 neighbouring pixels per wave) on the consumer branch.
+    T = 2^21, global + focal table, through render.TileRenderer exactly as bench.render_bench builds it -- choose_tile's 960 x 540 pixel
+    blocks, all 4 tiles in ONE hipGraph replay, samplers (traversal + counting march: the samples stay in the march's records) on the producer
+    branch through the ring of two record buffers, gfn_fused_render_rec (patches of 8 x 4 neighbouring pixels per wave) on the consumer branch.
       * the frame is finite, colours in [0, 1], accumulation in [0, 1];
-      * tiles are seamless: the 8 rows around the tile edge y = 360 and the 8 columns around x = 384 equal one direct HotPath.render of those
-        rays (the wave-per-ray fused forward: another kernel, another launch shape) to 2e-6;
-      * a run of 32 pixels across the corner (row 360, columns 368..399: two tiles, the first row of the second tile row) against the CPU
+      * tiles are seamless: the 8 rows around the tile edge y = 540 and the 8 columns around x = 960 equal one direct HotPath.render of those
+        rays (the wave-per-ray fused forward on packed samples: another kernel, another launch shape, another form of the samples) to 2e-6;
+      * a run of 32 pixels across the corner (row 540, columns 944..975: two tiles, the first row of the second tile row) against the CPU
         oracle pipeline: rgb within 1e-3 abs (north_star's bar), accumulation 1e-4;
       * a second camera through the same captured graph: the same run against a direct render.
     Reference: Model.get_outputs_for_camera_ray_bundle, nerfstudio/models/base_model.py:163-186."""
@@ -419,7 +419,8 @@ def test_bench_scene_full_frame_tile_render(world, oracle):
     tr = rmod.TileRenderer(hp, c2w, intr, block=0, fineness=fin, use_graph=True)
     cam0 = 37
     img = tr.render_camera(cam0, H, W)
-    assert (tr.tw, tr.T // tr.tw, tr.P, tr.SLOTS) == (384, 360, 15, 3) and tr.patch_tw == 384 and tr.graph is not None
+    tw, th = tr.tw, tr.T // tr.tw
+    assert (tw, th, tr.P, tr.SLOTS) == (960, 540, 4, 2) and tr.patch_tw == tw and tr.graph is not None
     rgb, acc, dep = img["rgb"], img["accumulation"], img["depth"]
     assert rgb.shape == (H, W, 3) and acc.shape == (H, W)
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(acc).all()) and bool(torch.isfinite(dep).all())
@@ -434,14 +435,14 @@ def test_bench_scene_full_frame_tile_render(world, oracle):
         noise = torch.full((1024 + n + 10,), float(fin), device="cuda")
         return hp.render(o.contiguous(), d.contiguous(), torch.full((n,), cam, dtype=torch.int32, device="cuda"), noise, block=0)
 
-    for name, sl in (("rows around y = 360", (slice(356, 364), slice(0, W))), ("columns around x = 384", (slice(0, H), slice(380, 388)))):
+    for name, sl in ((f"rows around y = {th}", (slice(th - 4, th + 4), slice(0, W))), (f"columns around x = {tw}", (slice(0, H), slice(tw - 4, tw + 4)))):
         ref = direct(O[sl].reshape(-1, 3), D[sl].reshape(-1, 3), cam0)
         got = rgb[sl].reshape(-1, 3)
         assert float((got - ref["rgb"]).abs().max()) <= 2e-6, name
         assert float((acc[sl].reshape(-1) - ref["accumulation"][:, 0]).abs().max()) <= 2e-6, name
 
     # the oracle on a run of 32 pixels across the tile corner
-    y, x0 = 360, 368
+    y, x0 = th, tw - 16
     o_np, d_np = O[y, x0:x0 + 32].cpu().numpy(), D[y, x0:x0 + 32].cpu().numpy()
     P = hp.export_params()
     ref = world["opipe"].render(P, o_np, d_np, np.full(32, cam0, np.int32), scene.make_noise(32, False, fin), LOG2_T, block=0, early_T=hp.cfg.early_T,
