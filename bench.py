@@ -422,7 +422,6 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
         _sha256(os.path.join(ROOT, "gf-nerf_amd", f)) == h for f, h in pmc["source_sha256"]["render"].items())
     gathers = n_eval * 128.0 * n_tables
     ceiling = pmc.get("l2_gather_ceiling_per_s")
-    tiles_per_frame = -(-H * W // tr.T)
     return dict(evaluated_samples_per_frame=n_eval, sampled_per_frame=n_all, evaluated_frac=n_eval / max(n_all, 1),
                 samples_per_sec=n_eval / s_per_frame, nominal_gathers_per_sec=gathers / s_per_frame, distinct_address_gather_ceiling_per_s=ceiling,
                 gather_note="16 levels x 8 corners per table and evaluated sample; the lanes of a patch want 0.09 distinct cells per sample and level "
@@ -430,10 +429,11 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
                             "exceeds the ceiling measured for distinct addresses: the kernel is bound by instruction issue, not by the gather path",
                 mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_tflops_issued=3.0 * n_eval * 61952.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
                 mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
-                lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * tiles_per_frame)
-                                     if fresh and pmc.get("decoded_samples_per_launch:render") else None),  # useful samples / samples the lockstep patches decode
+                lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * H * W / pmc["tile_rays:render"])
+                                     if fresh and pmc.get("decoded_samples_per_launch:render") and pmc.get("tile_rays:render") else None),  # useful samples /
+                # samples the lockstep patches decode (the counter run's launches are tiles of pmc["tile_rays:render"] rays)
                 kernel="fused_render_patch_kernel<1, 2, true>" if block is not None else "fused_render_patch_kernel<0, 2, true>",
-                kernel_ms_per_tile=pmc.get("kernel_ms:render") if fresh else None,
+                kernel_ms_per_tile=(pmc["kernel_ms:render"] * tr.T / pmc["tile_rays:render"] if fresh and pmc.get("kernel_ms:render") and pmc.get("tile_rays:render") else None),
                 note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 
 

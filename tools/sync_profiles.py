@@ -77,6 +77,12 @@ j["valu_busy:render"] = round(4.0 * fv("SQ_ACTIVE_INST_VALU") / simd_cycles, 4) 
 j["wait_frac:render"] = round(fv("SQ_WAIT_INST_ANY") / fv("SQ_WAVE_CYCLES"), 4)
 j["mfma_valu_coexec_frac:render"] = round(fv("SQ_VALU_MFMA_COEXEC_CYCLES") / fv("SQ_VALU_MFMA_BUSY_CYCLES"), 4)
 j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / 216.0 * 32.0))  # 216 MFMAs per 32-sample tile of the decoder
+# (per-launch figures belong to the tile the eager run rendered: the renderer's default for a full-HD frame, bench.py scales by its own tile)
+_src = open("gf-nerf_amd/render.py").read()
+_ns = {}
+exec("import math\n" + _src[_src.index("def choose_tile"):_src.index("def frame_shard")], _ns)
+_tw, _th = _ns["choose_tile"](1080, 1920)
+j["tile_rays:render"] = _tw * _th
 j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA") / 216.0), 1)
 j["l1_miss_requests:render"] = int(round(fv("TCP_TCC_READ_REQ_sum")))
 j["l2_hit_rate:render"] = round(fv("TCC_HIT") / (fv("TCC_HIT") + fv("TCC_MISS")), 3)
