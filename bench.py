@@ -116,6 +116,9 @@ def parse():
                     help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
     ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~128 Ki rays that divides the frame)")
     ap.add_argument("--render-tile-width", type=int, default=128, help="with --render-tile-rays: render tiles are blocks of this width (0 = raster runs)")
+    ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
+                    help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
+                         "nearest (default); x3 = hi + lo' planes (rounds 1-4); mixed = dz one plane, activations split")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     return ap.parse_args()
@@ -677,7 +680,7 @@ class StageRun:
             return
         ga = args.lm_global_after
         self.cfg = cfg = hotpath.HotPathConfig(
-            log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision,
+            log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision, wgrad_planes=args.wgrad_planes,
             two_phase=not args.one_phase,
             **({"prefetch_cus": args.prefetch_cus, "prefetch_cus_global": args.prefetch_cus} if args.prefetch_cus else {}),
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,

@@ -95,7 +95,7 @@ __global__ void field_pack_x3_kernel(FieldWeights w, u32x4* __restrict__ fwd, u3
   }
 }
 
-template <bool SAVE, bool PLANES, bool PLANAR>
+template <bool SAVE, int PLANES /* PL_* (x3_device.h) */, bool PLANAR>
 __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ feat, const int* __restrict__ ray_id,
     const float* __restrict__ sh, const float* __restrict__ emb, const int* __restrict__ cam_idx,
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     unsigned long long* __restrict__ masks /* [n][3][2] */, uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo,
     int64_t cap, int64_t feat_stride /* 0: feat is [n,32]; else level-major float2 [16][feat_stride] (gfn_hash_fwd_lm) */,
     const int32_t* __restrict__ list /* phased forward: decode only the samples list[0 .. *list_n) (ascending); the others' outputs and */,
-    const int32_t* __restrict__ list_n /* plane rows are not touched; the launch does nothing when *list_n == 0 */) {
+    const int32_t* __restrict__ list_n /* plane rows are not touched; the launch does nothing when *list_n == 0 */,
+    float dither /* PL_RNE: amplitude of the per-sample dither (plane_dither, x3_device.h) */) {
   if (list && *list_n == 0) return;  // grid-uniform
   if (list && *list_n < 0) list = nullptr;  // "every sample": no list was written
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
     const bool valid = e < n;
     const int64_t s = list ? (int64_t)list[valid ? e : n - 1] : e;  // the lane's sample
     const int64_t q = list ? s : (valid ? s : n - 1);
+    const float pc = PLANES == PL_RNE ? 1.f + plane_dither(q, dither) : 1.f;
     // ---- k-step u of the feature row: columns 16u + 8h + i (invalid lanes rewrite the last live row with the same values)
     u32x4 xh[2], xl[2];
 #pragma unroll
@@ -139,11 +141,12 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
         load8(feat + q * 32 + 16 * u + 8 * h, x);
       }
       split8(x, xh[u], xl[u]);
-      if (PLANES) store_nat(planes_hi + cap * FP_FEAT, planes_lo + cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
+      if (PLANES == PL_SPLIT) store_nat(planes_hi + cap * FP_FEAT, planes_lo + cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
+      if (PLANES == PL_RNE) { u32x4 r; rne8(x, r); store_nat_rne(planes_hi + cap * FP_FEAT, 32, q, 16 * u, r, h); }  // (f16 numbers already: exact, no dither)
     }
     const int ray = ray_id[q];
     const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh + (int64_t)ray * 16,
-                                              emb ? emb + (int64_t)cam_idx[ray] * 32 : nullptr, planes_hi, planes_lo, cap, q);
+                                              emb ? emb + (int64_t)cam_idx[ray] * 32 : nullptr, planes_hi, planes_lo, cap, q, pc);
     if (valid) {
       if (h == 0) {
         sigma[s] = o.sigma;
@@ -158,10 +161,12 @@ __global__ __launch_bounds__(512) void field_fwd_x3_kernel(
   }
 }
 
-// PLANES = false: the focal stage (decoder frozen): d feat only, per-sample gradient scale.
-// PLANES = true : the global stage: also writes dz of every layer as split-f16 planes (for gfn_wgrad_x3) under ONE
-//                 power-of-two scale for the whole batch (gfn_grad_scale_of(*gmax)), and reduces the appearance-embedding
-//                 gradient over each ray's samples into demb.
+// PLANES = 0: the focal stage (decoder frozen): d feat only, per-sample gradient scale.
+// PLANES = 1: the global stage: also writes dz of every layer as split-f16 planes (for gfn_wgrad_x3) under ONE
+//             power-of-two scale for the whole batch (gfn_grad_scale_of(*gmax)), and reduces the appearance-embedding
+//             gradient over each ray's samples into demb.
+// PLANES = 2: the same with ONE f16 plane per layer, dz rounded to nearest under the sample's dither (PL_RNE, x3_device.h), except
+//             dza1, which keeps both halves (lo' at column BP_DZA1_LO of planes_hi's buffer); planes_lo is not touched.
 // SCATTER: instead of writing d feat, scatter it straight into the hash table's gradient pool
 // (Hash3DAnchoredFunction::backward, Hash3DAnchored_cuda.cu:81-155,198-239): the accumulator tile of d feat holds, on
 // lane (h, j), sample j's gradient for the 8 levels {2h, 2h+1, 4+2h, 5+2h, 8+2h, 9+2h, 12+2h, 13+2h} -- each lane hashes
@@ -269,10 +274,10 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
 // Every form runs 512-thread workgroups = two waves per SIMD, so that one wave's hashing / record stores run beside the other's
 // MFMAs (the PLANES + SCATTER form used to run 256: 0.68 ms where the MFMA and the store phases add up; it fits 255 registers
 // when asked to) -- no build of these kernels may spill (tests/test_abi_and_host.py)
-template <bool PLANES, int SCATTER>
+template <int PLANES, int SCATTER>
 constexpr int bwd_threads() { return 512; }
 
-template <bool PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records */>
+template <int PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records */>
 __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
@@ -280,7 +285,8 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
     uint16_t* __restrict__ planes_hi, uint16_t* __restrict__ planes_lo, int64_t cap, const int* __restrict__ ray_id,
     const int* __restrict__ cam_idx, float* __restrict__ demb, ScatterArgs S,
     const int32_t* __restrict__ list /* (no planes) only the samples list[0 .. *list_n): the samples in front of their rays' */,
-    const int32_t* __restrict__ list_n /* termination points -- every other sample's incoming gradient is zero */) {
+    const int32_t* __restrict__ list_n /* termination points -- every other sample's incoming gradient is zero */,
+    float dither /* PL_RNE: amplitude of the per-sample dither (plane_dither, x3_device.h) */) {
 #define BPL(half, C) (planes_##half + cap * (C))
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
@@ -325,15 +331,20 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         }
         if (PLANES) {  // zero this sample's rows of the five gradient planes (lane half h: its half of each row)
           const u32x4 z = {0u, 0u, 0u, 0u};
+          constexpr bool LO = PLANES == PL_SPLIT;
+          if (PLANES == PL_RNE) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) *reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1_LO) + plane_off(s, 128, 8 * h + e)) = z;
+          }
 #pragma unroll
           for (int e = 0; e < 8; e++) {  // 128-wide rows = 16 octets, 8 per half
             const int64_t o = plane_off(s, 128, 8 * h + e);
-            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ2) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ2) + o) = z;
-            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ1) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ1) + o) = z;
-            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1) + o) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZA1) + o) = z;
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ2) + o) = z; if (LO) *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ2) + o) = z;
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ1) + o) = z; if (LO) *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ1) + o) = z;
+            *reinterpret_cast<u32x4*>(BPL(hi, BP_DZA1) + o) = z; if (LO) *reinterpret_cast<u32x4*>(BPL(lo, BP_DZA1) + o) = z;
           }
-          *reinterpret_cast<u32x4*>(BPL(hi, BP_DH) + plane_off(s, 16, h)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DH) + plane_off(s, 16, h)) = z;
-          if (h == 0) { *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = z; *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = z; }
+          *reinterpret_cast<u32x4*>(BPL(hi, BP_DH) + plane_off(s, 16, h)) = z; if (LO) *reinterpret_cast<u32x4*>(BPL(lo, BP_DH) + plane_off(s, 16, h)) = z;
+          if (h == 0) { *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = z; if (LO) *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = z; }
         }
       }
       continue;
@@ -355,17 +366,23 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       inv = __uint_as_float((uint32_t)e << 23);          // 2^(e-127)
     }
     const unsigned long long* mp = masks + q * 6 + h;
-    const unsigned long long m_a1 = mp[0], m_c1 = mp[2], m_c2 = mp[4];
+    // (with planes every mask is loaded in front of the layer that reads it: behind the plane stores the compiler may not move the
+    // loads there itself, and the four registers of the two masks not yet needed are what the record form of the one-plane kernel lacks)
+    unsigned long long m_a1 = 0, m_c1 = 0;
+    const unsigned long long m_c2 = mp[4];
+    if (!PLANES) { m_a1 = mp[0]; m_c1 = mp[2]; }
+    const float pc = PLANES == PL_RNE ? 1.f - plane_dither(q, dither) : 1.f;  // the inverse (to 2^-22) of the factor on this sample's activations
     // ---- d c2 = hW2^T dz3 : one k-step whose fragment is (dz3[0..2], 0...) on the h=0 lanes
     u32x4 zh, zl;
     {
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (h == 0) { v[0] = dz3[0] * sc; v[1] = dz3[1] * sc; v[2] = dz3[2] * sc; }
       split8(v, zh, zl);
-      if (PLANES && valid && h == 0) {
+      if (PLANES == PL_SPLIT && valid && h == 0) {
         *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = zh;
         *reinterpret_cast<u32x4*>(BPL(lo, BP_DZ3) + plane_off(s, 8, 0)) = zl;
       }
+      if (PLANES == PL_RNE && valid && h == 0) { u32x4 r; rne8(v, r, pc); *reinterpret_cast<u32x4*>(BPL(hi, BP_DZ3) + plane_off(s, 8, 0)) = r; }
     }
     Acc2 gf;
     if (!PLANES) {
@@ -423,19 +440,22 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         Acc2 a;
         acc_init_zero(a);
         mma3(a, Ihi, Ilo, D_G3 + it, lane, zh, zl);
-        grad_tile_to_frag<true>(a, g2[it], m_c2, it);
-        if (PLANES && valid) store_tile(BPL(hi, BP_DZ2), BPL(lo, BP_DZ2), 128, s, 32 * it, g2[it], h);
+        const PlaneDst pd{BPL(hi, BP_DZ2), 128, s, 32 * it, h, pc, valid};
+        grad_tile_to_frag<true, PLANES == PL_RNE>(a, g2[it], m_c2, it, &pd);
+        if (PLANES == PL_SPLIT && valid) store_tile(BPL(hi, BP_DZ2), BPL(lo, BP_DZ2), 128, s, 32 * it, g2[it], h);
       }
       // ---- d c1 = hW1^T dz2
       Frag g1[4];
+      m_c1 = mp[2];
 #pragma unroll
       for (int it = 0; it < 4; it++) {
         Acc2 a;
         acc_init_zero(a);
 #pragma unroll
         for (int u = 0; u < 8; u++) mma3(a, Ihi, Ilo, D_G2 + u * 4 + it, lane, g2[u >> 1].hi[u & 1], g2[u >> 1].lo[u & 1]);
-        grad_tile_to_frag<true>(a, g1[it], m_c1, it);
-        if (PLANES && valid) store_tile(BPL(hi, BP_DZ1), BPL(lo, BP_DZ1), 128, s, 32 * it, g1[it], h);
+        const PlaneDst pd{BPL(hi, BP_DZ1), 128, s, 32 * it, h, pc, valid};
+        grad_tile_to_frag<true, PLANES == PL_RNE>(a, g1[it], m_c1, it, &pd);
+        if (PLANES == PL_SPLIT && valid) store_tile(BPL(hi, BP_DZ1), BPL(lo, BP_DZ1), 128, s, 32 * it, g1[it], h);
       }
       // ---- d h: rows 1..15 = hW0[:, 16:31]^T dz1, row 0 = d h0
       u32x4 dh_h, dh_l;
@@ -449,7 +469,8 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
         for (int r = 0; r < 8; r++) v[r] = acc_get(a, r);
         if (h == 0) v[0] = dh0 * sc;
         split8(v, dh_h, dh_l);
-        if (PLANES && valid) store_half_tile(BPL(hi, BP_DH), BPL(lo, BP_DH), 16, s, 0, dh_h, dh_l, h);
+        if (PLANES == PL_SPLIT && valid) store_half_tile(BPL(hi, BP_DH), BPL(lo, BP_DH), 16, s, 0, dh_h, dh_l, h);
+        if (PLANES == PL_RNE && valid) { u32x4 r; rne8(v, r, pc); store_half_tile_rne(BPL(hi, BP_DH), 16, s, 0, r, h); }
       }
       if (PLANES && demb) {
         // ---- d appearance = hW0[:, 31:63]^T dz1, summed over each ray's samples (the embedding row is per ray)
@@ -473,13 +494,14 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
       }
       // ---- d a1 = bW1^T dh
       Frag ga[4];
+      m_a1 = mp[0];
 #pragma unroll
       for (int it = 0; it < 4; it++) {
         Acc2 a;
         acc_init_zero(a);
         mma3(a, Ihi, Ilo, D_GB1 + it, lane, dh_h, dh_l);
         grad_tile_to_frag<true>(a, ga[it], m_a1, it);
-        if (PLANES && valid) store_tile(BPL(hi, BP_DZA1), BPL(lo, BP_DZA1), 128, s, 32 * it, ga[it], h);
+        if (PLANES && valid) store_tile(BPL(hi, BP_DZA1), PLANES == PL_RNE ? BPL(hi, BP_DZA1_LO) : BPL(lo, BP_DZA1), 128, s, 32 * it, ga[it], h);
       }
       // ---- d feat = bW0^T dz
       acc_init_zero(gf);
@@ -489,8 +511,12 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
     if (SCATTER) {
       // registers (2a, 2a+1) of the tile = channels (0, 1) of level 2h + (a & 1) + 4 (a >> 1) of sample j
       const uint32_t T = 1u << S.log2_T;
-      const float px = S.pts[3 * q], py = S.pts[3 * q + 1], pz = S.pts[3 * q + 2];
-      const int64_t vol = (int64_t)S.anchors[3 * q];
+      int64_t qs = q;
+      if (PLANES) asm volatile("" : "+v"(qs));  // the point and its volume are loaded HERE: hoisted to the top of the tile (as the compiler
+                                                // does when it may) they sit in four registers through the whole decoder chain, which the
+                                                // one-plane record form then spills
+      const float px = S.pts[3 * qs], py = S.pts[3 * qs + 1], pz = S.pts[3 * qs + 2];
+      const int64_t vol = (int64_t)S.anchors[3 * qs];
       // a level's primes are loaded BEFORE the level before it stores its records: the stores may alias anything as far as the
       // compiler knows, so a load written behind them stays behind them -- and on this architecture then waits for their
       // acknowledgement (one counter for loads and stores): 0.34 -> 0.31 ms for the focal backward
@@ -508,7 +534,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
           nx[0] = pn[0]; nx[1] = pn[1]; nx[2] = pn[2];
         }
         const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
-        if (SCATTER == 3) scatter_level<true, true, PLANES>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr, s_rec_cursor);
+        if (SCATTER == 3) scatter_level<true, true, PLANES != 0>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr, s_rec_cursor);
         else if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
         else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
         pr[0] = nx[0]; pr[1] = nx[1]; pr[2] = nx[2];
@@ -557,9 +583,11 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
 }
 
 int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
+int g_plane_dither = 1;  // gfn_set_plane_dither
 
 }  // namespace
 int gfn_decoder_cu_cap() { return (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256; }
+float gfn_plane_dither_amp() { return g_plane_dither ? 0x1p-22f : 0.f; }
 namespace {
 
 unsigned persistent_grid8(int64_t n_max) {
@@ -596,14 +624,13 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   GFN_CHECK_ARG(!planes_hi || (plane_cap >= n_max && plane_cap % 32 == 0), "gfn_field_fwd_x3: plane_cap=%lld must be >= n_max and a multiple of 32", (long long)plane_cap);
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_field_fwd_x3: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_field_fwd_x3: h0 and masks must be given together");
-  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || masks),
-                "gfn_field_fwd_x3: planes need both halves and the masks");
+  GFN_CHECK_ARG((planes_hi || !planes_lo) && (!planes_hi || masks), "gfn_field_fwd_x3: planes need the hi half (alone: rounded to nearest) and the masks");
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31) / 32, "gfn_field_fwd_x3: n_max=%lld", (long long)n_max);
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(sh) |
                   reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
                 "gfn_field_fwd_x3: image, feat, sh, emb and planes must be 16-byte aligned");
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_FWD_ALL(X) X(true, true, false) X(true, false, false) X(false, false, false) X(true, false, true) X(false, false, true) X(true, true, true)
+#define GFN_FWD_ALL(X) X(true, 1, false) X(true, 0, false) X(false, 0, false) X(true, 0, true) X(false, 0, true) X(true, 1, true) X(true, 2, false) X(true, 2, true)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(S, P, L) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_fwd_x3_kernel<S, P, L>), hipFuncAttributeMaxDynamicSharedMemorySize, GFN_FIELD_X3_FWD_BYTES));
     GFN_FWD_ALL(GFN_SET)
@@ -613,12 +640,13 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
   const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
   hipStream_t st = gfn_stream(stream);
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
-  const bool save = masks != nullptr, planes = planes_hi != nullptr, planar = feat_stride != 0;
+  const bool save = masks != nullptr, planar = feat_stride != 0;
+  const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
   if (!save) h0 = nullptr;
 #define GFN_LAUNCH(S, P, L)                                                                                                         \
   if (save == S && planes == P && planar == L)                                                                                       \
     field_fwd_x3_kernel<S, P, L><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk, \
-                                                                           planes_hi, planes_lo, plane_cap, feat_stride, list, list_n);
+                                                                           planes_hi, planes_lo, plane_cap, feat_stride, list, list_n, gfn_plane_dither_amp());
   GFN_FWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_FWD_ALL
@@ -650,7 +678,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_BWD_ALL(X) X(false, 0) X(false, 1) X(false, 2) X(false, 3) X(true, 0) X(true, 1) X(true, 2) X(true, 3)
+#define GFN_BWD_ALL(X) X(0, 0) X(0, 1) X(0, 2) X(0, 3) X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(2, 0) X(2, 1) X(2, 2) X(2, 3)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(P, SC) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<P, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     GFN_BWD_ALL(GFN_SET)
@@ -675,13 +703,13 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
     S.n_ranges = (int)n_ranges;
   }
   gfn_hash_level_scales_host(S.sc.s);
-  const bool planes = planes_hi != nullptr;
+  const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
   const int mode = !scatter ? 0 : (sh.rec ? 3 : (sh.grad_f16 ? 1 : 2));
   if (!planes) { gmax_dev = nullptr; plane_cap = 0; ray_id = nullptr; cam_idx = nullptr; demb = nullptr; }
 #define GFN_LAUNCH(P, SC)                                                                                                        \
   if (planes == P && mode == SC)                                                                                                 \
     field_bwd_dx_x3_kernel<P, SC><<<grid, bwd_threads<P, SC>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi, \
-                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n);
+                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
   GFN_BWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_BWD_ALL
@@ -702,7 +730,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const int32_t* cam_idx, float* demb, void* records, uint32_t* record_counts, int64_t record_capacity,
                              const int32_t* list, const int32_t* list_n, void* stream) {
   GFN_CHECK_ARG(n_max == 0 || grad_pool, "gfn_field_bwd_scatter_x3: null gradient pool");
-  GFN_CHECK_ARG(n_max == 0 || (planes_hi == nullptr) == (planes_lo == nullptr), "gfn_field_bwd_scatter_x3: planes need both halves");
+  GFN_CHECK_ARG(n_max == 0 || planes_hi || !planes_lo, "gfn_field_bwd_scatter_x3: a lo' plane needs its hi plane");
   GFN_CHECK_ARG(n_max == 0 || !planes_hi || gmax_dev, "gfn_field_bwd_scatter_x3: planes need gmax");
   GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_scatter_x3: demb needs ray_id and cam_idx");
   ScatterHost sh;
@@ -717,7 +745,7 @@ int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb,
                      const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, const float* gmax_dev,
                      uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx,
                      float* demb, void* stream) {
-  GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi && planes_lo), "gfn_field_bwd_x3: gmax and both plane halves are required");
+  GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi), "gfn_field_bwd_x3: gmax and the planes (hi, or hi and lo') are required");
   GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_x3: demb needs ray_id and cam_idx");
   return field_bwd_x3_impl("gfn_field_bwd_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, gmax_dev, planes_hi, planes_lo,
                            plane_cap, ray_id, cam_idx, demb, ScatterHost{}, stream);
@@ -736,6 +764,12 @@ int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int6
 }
 
 float gfn_grad_scale_host(float gmax) { return gfn_grad_scale_of(gmax); }
+
+int gfn_set_plane_dither(int on) {
+  const int old = g_plane_dither;
+  g_plane_dither = on != 0;
+  return old;
+}
 
 int gfn_set_decoder_cus(int n_cus) {
   const int old = g_decoder_cus;

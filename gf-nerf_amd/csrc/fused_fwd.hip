@@ -32,7 +32,7 @@ struct FusedArgs {
   const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
   float early_T;
   float* sigma; float* rgb; float* h0; unsigned long long* masks; float* weights; float* alphas; float* feat;
-  uint16_t* planes_hi; uint16_t* planes_lo; int64_t cap;
+  uint16_t* planes_hi; uint16_t* planes_lo; int64_t cap; float dither;
   float* out_rgb; float* out_acc; float* out_depth; float* t_minmax;
   int* counter;
 };
@@ -112,7 +112,7 @@ __device__ __forceinline__ float2 blend_pairs(const uint32_t (&v)[8], const floa
 // TAB: 0 one table, 1 two tables with their own primes (the focal stage: global + residual block table).
 // A compile-time choice on purpose: with a run-time `if` on the table mode inside the unrolled level loop the 512-thread build
 // returned wrong values for whole 16-lane groups of the upper half-wave now and then (hipcc 7.2; the same source is fine at 256 threads).
-template <int TAB, bool SAVE, bool PLANES>
+template <int TAB, bool SAVE, int PLANES /* PL_* (x3_device.h) */>
 __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(FusedArgs A, LevelScales sc) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -185,10 +185,12 @@ __global__ __launch_bounds__((fused_threads<SAVE>())) void fused_fwd_kernel(Fuse
           fp[0] = make_float4(x[0], x[1], x[2], x[3]); fp[1] = make_float4(x[4], x[5], x[6], x[7]);
         }
         split8(x, xh[u], xl[u]);
-        if (PLANES) store_nat(A.planes_hi + A.cap * FP_FEAT, A.planes_lo + A.cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
+        if (PLANES == PL_SPLIT) store_nat(A.planes_hi + A.cap * FP_FEAT, A.planes_lo + A.cap * FP_FEAT, 32, q, 16 * u, xh[u], xl[u], h);
+        if (PLANES == PL_RNE) { u32x4 r; rne8(x, r); store_nat_rne(A.planes_hi + A.cap * FP_FEAT, 32, q, 16 * u, r, h); }  // (f16 numbers already: exact, no dither)
       }
       // ---- decoder
-      const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, A.planes_hi, A.planes_lo, A.cap, q);
+      const DecoderOut o = decoder_tile<PLANES>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, A.planes_hi, A.planes_lo, A.cap, q,
+                                                PLANES == PL_RNE ? 1.f + plane_dither(q, A.dither) : 1.f);
       if (valid) {
         if (h == 0) {
           A.sigma[i] = o.sigma;
@@ -466,8 +468,8 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "gfn_fused_forward: n_volumes / log2_T out of range");  // 3 * 16 * n_volumes and 16 * T / 2 are 32-bit offsets in the kernel
   GFN_CHECK_ARG(!emb || cam_idx, "gfn_fused_forward: emb given without cam_idx");
   GFN_CHECK_ARG((h0 == nullptr) == (masks == nullptr), "gfn_fused_forward: h0 and masks must be given together");
-  GFN_CHECK_ARG((planes_hi == nullptr) == (planes_lo == nullptr) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 32 == 0)),
-                "gfn_fused_forward: planes need both halves, the masks and a capacity that is a multiple of 8");
+  GFN_CHECK_ARG((planes_hi || !planes_lo) && (!planes_hi || (masks && plane_cap > 0 && plane_cap % 32 == 0)),
+                "gfn_fused_forward: planes need the hi half (alone: rounded to nearest), the masks and a capacity that is a multiple of 32");
   GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(fwd_image) | reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(emb) |
                   reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(planes_hi) | reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0,
                 "gfn_fused_forward: image, sh, emb, feat and planes must be 16-byte aligned");
@@ -477,13 +479,13 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.sigma = sigma; A.rgb = rgb; A.h0 = h0; A.masks = reinterpret_cast<unsigned long long*>(masks); A.weights = weights; A.alphas = alphas;
-  A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap;
+  A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap; A.dither = gfn_plane_dither_amp();
   A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
   LevelScales sc;
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_FUSED_ALL(X) X(0, false, false) X(0, true, false) X(0, true, true) X(1, false, false) X(1, true, false) X(1, true, true)
+#define GFN_FUSED_ALL(X) X(0, false, 0) X(0, true, 0) X(0, true, 1) X(0, true, 2) X(1, false, 0) X(1, true, 0) X(1, true, 1) X(1, true, 2)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(D, S, P) \
     GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel<D, S, P>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
@@ -494,7 +496,8 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   GFN_CHECK_LAUNCH();
   int64_t waves = n_rays;  // one ray at a time per wave
   const int tab = table2_f16 ? 1 : 0;
-  const bool save = masks != nullptr, planes = planes_hi != nullptr;
+  const bool save = masks != nullptr;
+  const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
   const int threads = save ? FUSED_THREADS : FUSED_THREADS_LEAN;
   int64_t blocks = (waves + threads / 64 - 1) / (threads / 64);
   const int cu_cap = gfn_decoder_cu_cap();  // gfn_set_decoder_cus: leave CUs to kernels of another stream

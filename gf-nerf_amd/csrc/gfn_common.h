@@ -33,6 +33,8 @@ void gfn_set_error(const char* fmt, ...);
 
 // cap on the workgroups (= CUs) of the persistent decoder kernels (gfn_set_decoder_cus), 256 = every CU; field_x3.hip
 int gfn_decoder_cu_cap();
+// amplitude of the one-plane (PL_RNE) producers' per-sample dither (gfn_set_plane_dither; x3_device.h), 0 = off; field_x3.hip
+float gfn_plane_dither_amp();
 
 static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -12,6 +12,10 @@
 //                           (global_load_lds_dwordx4, two buffers), bias sums from the MFMA fragments, per-workgroup partial
 //                           vectors + wgrad_reduce_kernel instead of final atomics.  1.85 GB of planes in 0.38 ms (4.9 TB/s);
 //                           the five register-staged launches with atomics it replaces took 0.47 ms
+//                           An operand may come as ONE plane (lo == NULL): its values rounded to f16 once, to nearest (the producers'
+//                           PL_RNE mode, x3_device.h) -- the per-term rounding is zero-mean and averages out over the 5e5 samples of the
+//                           sum; the term that needs the missing half is not computed (both operands so: one MFMA per fragment pair,
+//                           64-sample slabs, 0.93 GB of planes instead of 1.85)
 //   wgrad_x3_kernel         planes as plain rows [n][ld] (callers that build planes themselves; tests): 64-sample slabs
 //                           staged through registers, f32 atomics at the end
 #include "gfn_common.h"
@@ -201,9 +205,8 @@ int launch(int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a,
 // Two buffers: the loads of slab i + 1 are issued right after the barrier that retires slab i's and land under its MFMAs.
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-constexpr int SG = 32;  // samples per slab of the LDS-DMA kernel
 
-template <int FEAT>
+template <int FEAT, bool LO, int SG /* samples per slab */>
 __device__ __forceinline__ void glds_image(const Plane& p, _Float16* img_hi, _Float16* img_lo, int64_t s0, int64_t n) {
   constexpr int TILES = (FEAT + 31) / 32, PIECES = TILES * SG * 4;  // 16-byte pieces of one image
   const int lane = threadIdx.x & 63;
@@ -215,7 +218,7 @@ __device__ __forceinline__ void glds_image(const Plane& p, _Float16* img_hi, _Fl
       if (oct < FEAT / 8 && s0 + s < n) {  // the other pieces keep the zeros the kernel starts with (tail slab: zeroed below)
         const int64_t o = plane_off(s0 + s, p.ld, oct);
         __builtin_amdgcn_global_load_lds((gptr_t)(p.hi + o), (lptr_t)(img_hi + (e - lane) * 8), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p.lo + o), (lptr_t)(img_lo + (e - lane) * 8), 16, 0, 0);
+        if (LO) __builtin_amdgcn_global_load_lds((gptr_t)(p.lo + o), (lptr_t)(img_lo + (e - lane) * 8), 16, 0, 0);
       }
     }
   }
@@ -241,14 +244,18 @@ struct LayerArgs {
 // One layer's weight gradient from this workgroup's share of the slabs.  parts == nullptr: added to dW / db with f32 atomics;
 // else this workgroup's partial sums are STORED at parts + (dW - base) (every valid entry, zeros included) for wgrad_reduce_kernel:
 // 512 workgroups x 31 k atomics into the same 124 KB took 85 us of the 0.48 ms the five layers needed.
-template <int FD, int FA>
+// DLO / ALO: the dz / a operand has its lo' plane (else: one plane, rounded to nearest).  SG: samples per slab.
+template <int FD, int FA, bool DLO, bool ALO, int SG>
 __device__ __forceinline__ void wgrad_phase(const LayerArgs& L, int64_t n, const float* __restrict__ gmax_dev, float* parts_w,
                                             float* parts_b, _Float16* lds) {
   constexpr int MO = (FD + 31) / 32, NI = (FA + 31) / 32;
   constexpr bool WAVE_IS_NI = (NI == 4);
   static_assert(WAVE_IS_NI || MO == 4, "one of the tile counts must be 4 (one per wave)");
   constexpr int PPW = WAVE_IS_NI ? MO : NI;
-  constexpr int IMG_A = MO * SG * 32, IMG_B = NI * SG * 32, BUF = 2 * (IMG_A + IMG_B);  // halfs; lds: [2][Ahi | Alo | Bhi | Blo]
+  constexpr int IMG_A = MO * SG * 32, IMG_B = NI * SG * 32;                // halfs per image
+  constexpr int OFF_ALO = IMG_A, OFF_BHI = IMG_A * (DLO ? 2 : 1), OFF_BLO = OFF_BHI + IMG_B;
+  constexpr int BUF = OFF_BHI + IMG_B * (ALO ? 2 : 1);                     // lds: [2][Ahi | Alo? | Bhi | Blo?]
+  constexpr int ROWS = (MO * (DLO ? 2 : 1) + NI * (ALO ? 2 : 1)) * SG;     // 64-byte rows of one buffer
   __syncthreads();  // (several layers in one kernel) nobody still reads the previous layer's images
   for (int e = threadIdx.x; e < 2 * BUF / 8; e += blockDim.x) reinterpret_cast<u32x4*>(lds)[e] = u32x4{0u, 0u, 0u, 0u};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,49 +270,58 @@ __device__ __forceinline__ void wgrad_phase(const LayerArgs& L, int64_t n, const
   const int64_t n_slabs = (n + SG - 1) / SG;
   __syncthreads();  // the zeros are in place before the first DMA lands on them
   if ((int64_t)blockIdx.x < n_slabs) {
-    glds_image<FD>(L.dz, lds, lds + IMG_A, (int64_t)blockIdx.x * SG, n);
-    glds_image<FA>(L.a, lds + 2 * IMG_A, lds + 2 * IMG_A + IMG_B, (int64_t)blockIdx.x * SG, n);
+    glds_image<FD, DLO, SG>(L.dz, lds, lds + OFF_ALO, (int64_t)blockIdx.x * SG, n);
+    glds_image<FA, ALO, SG>(L.a, lds + OFF_BHI, lds + OFF_BLO, (int64_t)blockIdx.x * SG, n);
   }
   int cur = 0;
   for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x, cur ^= 1) {
     _Float16* Ahi = lds + cur * BUF;
-    _Float16* Alo = Ahi + IMG_A;
-    _Float16* Bhi = Alo + IMG_A;
-    _Float16* Blo = Bhi + IMG_B;
+    _Float16* Alo = Ahi + OFF_ALO;
+    _Float16* Bhi = Ahi + OFF_BHI;
+    _Float16* Blo = Ahi + OFF_BLO;
     __syncthreads();  // vmcnt(0) + barrier: this slab has landed, and every wave is done reading the other buffer
     if ((slab + 1) * SG > n) {  // the last, partial slab: rows beyond n still hold an earlier slab
       const int first = (int)(n - slab * SG);
-      for (int e = threadIdx.x; e < 2 * (MO + NI) * SG * 4; e += blockDim.x)
+      for (int e = threadIdx.x; e < ROWS * 4; e += blockDim.x)
         if (((e >> 2) % SG) >= first) reinterpret_cast<u32x4*>(Ahi)[e] = u32x4{0u, 0u, 0u, 0u};
       __syncthreads();
     }
     const int64_t next = slab + gridDim.x;
     if (next < n_slabs) {
       _Float16* N = lds + (cur ^ 1) * BUF;
-      glds_image<FD>(L.dz, N, N + IMG_A, next * SG, n);
-      glds_image<FA>(L.a, N + 2 * IMG_A, N + 2 * IMG_A + IMG_B, next * SG, n);
+      glds_image<FD, DLO, SG>(L.dz, N, N + OFF_ALO, next * SG, n);
+      glds_image<FA, ALO, SG>(L.a, N + OFF_BHI, N + OFF_BLO, next * SG, n);
     }
 #pragma unroll
     for (int ks = 0; ks < SG / 16; ks++) {
       if (WAVE_IS_NI) {
-        const h8 bh = tr_frag(Bhi + wave * SG * 32, ks, lane), bl = tr_frag(Blo + wave * SG * 32, ks, lane);
+        const h8 bh = tr_frag(Bhi + wave * SG * 32, ks, lane);
+        h8 bl = bh;
+        if (ALO) bl = tr_frag(Blo + wave * SG * 32, ks, lane);
 #pragma unroll
         for (int t = 0; t < PPW; t++) {
-          const h8 ah = tr_frag(Ahi + t * SG * 32, ks, lane), al = tr_frag(Alo + t * SG * 32, ks, lane);
-          if (t == wave) { bs_hi = frag_sum(ah, bs_hi); bs_lo = frag_sum(al, bs_lo); }  // MO <= 4: wave t sums out tile t
+          const h8 ah = tr_frag(Ahi + t * SG * 32, ks, lane);
+          h8 al = ah;
+          if (DLO) al = tr_frag(Alo + t * SG * 32, ks, lane);
+          if (t == wave) { bs_hi = frag_sum(ah, bs_hi); if (DLO) bs_lo = frag_sum(al, bs_lo); }  // MO <= 4: wave t sums out tile t
           accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[t], 0, 0, 0);
-          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
-          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
+          if (ALO) accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
+          if (DLO) accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
         }
       } else {
-        const h8 ah = tr_frag(Ahi + wave * SG * 32, ks, lane), al = tr_frag(Alo + wave * SG * 32, ks, lane);
-        bs_hi = frag_sum(ah, bs_hi); bs_lo = frag_sum(al, bs_lo);
+        const h8 ah = tr_frag(Ahi + wave * SG * 32, ks, lane);
+        h8 al = ah;
+        if (DLO) al = tr_frag(Alo + wave * SG * 32, ks, lane);
+        bs_hi = frag_sum(ah, bs_hi);
+        if (DLO) bs_lo = frag_sum(al, bs_lo);
 #pragma unroll
         for (int t = 0; t < PPW; t++) {
-          const h8 bh = tr_frag(Bhi + t * SG * 32, ks, lane), bl = tr_frag(Blo + t * SG * 32, ks, lane);
+          const h8 bh = tr_frag(Bhi + t * SG * 32, ks, lane);
+          h8 bl = bh;
+          if (ALO) bl = tr_frag(Blo + t * SG * 32, ks, lane);
           accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[t], 0, 0, 0);
-          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
-          accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
+          if (ALO) accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[t], 0, 0, 0);
+          if (DLO) accc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[t], 0, 0, 0);
         }
       }
     }
@@ -350,7 +366,13 @@ struct LayersArgs {
   const float* base;                  // dW / db point into the flat gradient vector starting here
 };
 
+__host__ __device__ constexpr int slab_of(bool dlo, bool alo) { return (dlo || alo) ? 32 : 64; }  // one plane per operand: half the bytes per sample, twice the samples in flight
+
 // All layers of the decoder in one launch: five kernels of 60-150 us each paid their ramp-up, first-slab latency and tail five times.
+// FORMS: the operand form per layer SHAPE, two bits each -- bit 2i: the dz plane of shape i has its lo' half, bit 2i + 1: the a plane
+// has.  A compile-time table (one kernel per combination in use: GFN_WGRAD_FORMS) rather than a run-time choice: with all twenty
+// (shape, form) bodies in one kernel the register allocator spills.
+template <uint32_t FORMS>
 __global__ __launch_bounds__(256, 2) void wgrad_x3_layers_kernel(int64_t n_max, const int32_t* __restrict__ n_dev,
                                                                  const float* __restrict__ gmax_dev, LayersArgs A) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -361,7 +383,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_layers_kernel(int64_t n_max, 
     float* pw = mine ? mine + (L.dW - A.base) : nullptr;
     float* pb = (mine && L.db) ? mine + (L.db - A.base) : nullptr;
     switch (L.shape) {
-#define GFN_CASE(ID, D, F) case ID: wgrad_phase<D, F>(L, n, gmax_dev, pw, pb, lds); break;
+#define GFN_CASE(ID, D, F)                                                                                                   \
+      case ID: {                                                                                                             \
+        constexpr bool dlo = (FORMS >> (2 * ID)) & 1u, alo = (FORMS >> (2 * ID + 1)) & 1u;                                  \
+        wgrad_phase<D, F, dlo, alo, slab_of(dlo, alo)>(L, n, gmax_dev, pw, pb, lds);                                         \
+      } break;
       GFN_WGRAD_SHAPES(GFN_CASE)
 #undef GFN_CASE
     }
@@ -387,7 +413,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 constexpr int kWgradBlocks = 512;  // two workgroups per CU; also the number of partial vectors
 
-inline size_t lds_bytes_of(int FD, int FA) { return (size_t)2 * 2 * ((FD + 31) / 32 + (FA + 31) / 32) * SG * 32 * sizeof(_Float16); }
+inline size_t lds_bytes_of(int FD, int FA, bool dlo, bool alo) {
+  return (size_t)2 * (((FD + 31) / 32) * (dlo ? 2 : 1) + ((FA + 31) / 32) * (alo ? 2 : 1)) * slab_of(dlo, alo) * 32 * sizeof(_Float16);
+}
 
 inline int shape_id(int fd, int fa) {
 #define GFN_ID(ID, D, F) if (fd == D && fa == F) return ID;
@@ -396,21 +424,45 @@ inline int shape_id(int fd, int fa) {
   return -1;
 }
 
+// The combinations of operand forms in use: every layer x3 (0x3ff); every operand one plane (0); every dz one plane, every a split
+// (0x2aa); the engine's one-plane form, where dza1 -- shape 4 -- keeps its lo' half (0x100), and its "mixed" form (0x3aa).
+#define GFN_WGRAD_FORMS(X) X(0x3ffu) X(0x000u) X(0x2aau) X(0x100u) X(0x3aau)
+
 int launch_layers(const LayersArgs& A, int64_t n_max, const int32_t* n_dev, const float* gmax_dev, hipStream_t st) {
   size_t lds = 0;
+  uint32_t forms = 0, seen = 0;
   for (int l = 0; l < A.n_layers; l++) {
-    const size_t b = lds_bytes_of(A.L[l].dz.feat, A.L[l].a.feat);
+    const bool dlo = A.L[l].dz.lo != nullptr, alo = A.L[l].a.lo != nullptr;
+    const size_t b = lds_bytes_of(A.L[l].dz.feat, A.L[l].a.feat, dlo, alo);
     if (b > lds) lds = b;
+    const uint32_t f = (dlo ? 1u : 0u) | (alo ? 2u : 0u), sh = 2 * A.L[l].shape;
+    GFN_CHECK_ARG(!((seen >> sh) & 1u) || ((forms >> sh) & 3u) == f, "gfn_wgrad_x3_layers: two layers of one shape differ in which lo' planes they have");
+    seen |= 1u << sh;
+    forms |= f << sh;
   }
-  static unsigned long long attr_seen = 0;
-  if (gfn_first_call_on_device(attr_seen))
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_layers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds_bytes_of(128, 128)));
-  int64_t blocks = (n_max + SG - 1) / SG;
+  // shapes no layer has: any form will do -- take them from the first instantiated table that agrees on the shapes present
+  uint32_t present = 0;
+  for (int i = 0; i < 5; i++)
+    if ((seen >> (2 * i)) & 1u) present |= 3u << (2 * i);
+  // the grid does not depend on the slab: workgroup b always owns partial vector b, and the caller's reduce reads the first
+  // min(ceil(n_max / 32), 512) of them (a workgroup without a slab stores zeros)
+  int64_t blocks = (n_max + 31) / 32;
   if (blocks > kWgradBlocks) blocks = kWgradBlocks;
-  wgrad_x3_layers_kernel<<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, gmax_dev, A);
-  GFN_CHECK_LAUNCH();
-  return GFN_OK;
+  static unsigned long long attr_seen = 0;
+  const bool first = gfn_first_call_on_device(attr_seen);
+#define GFN_SET(F) if (first) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_layers_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_of(128, 128, true, true)));
+  GFN_WGRAD_FORMS(GFN_SET)
+#undef GFN_SET
+#define GFN_TRY(F)                                                                                   \
+  if (((F ^ forms) & present) == 0) {                                                                \
+    wgrad_x3_layers_kernel<F><<<(unsigned)blocks, 256, lds, st>>>(n_max, n_dev, gmax_dev, A);        \
+    GFN_CHECK_LAUNCH();                                                                              \
+    return GFN_OK;                                                                                   \
+  }
+  GFN_WGRAD_FORMS(GFN_TRY)
+#undef GFN_TRY
+  gfn_set_error("gfn_wgrad_x3_layers: no kernel for this combination of one-plane / two-plane operands (forms 0x%x; see GFN_WGRAD_FORMS)", forms);
+  return GFN_ERR_ARG;
 }
 
 int one_layer(int shape, int64_t n_max, const int32_t* n_dev, const Plane& dz, const Plane& a, const float* gmax_dev, float* dW, int ldw,
@@ -429,7 +481,7 @@ int gfn_wgrad_x3(const uint16_t* dz_hi, const uint16_t* dz_lo, int ld_dz, int fe
                  int ld_a, int feat_a, int64_t n_max, const int32_t* n_dev, const float* gmax_dev, int m_valid, int k_valid,
                  const int32_t* col_map, float* dW, int ldw, float* db, int tiled, void* stream) {
   if (n_max == 0) return GFN_OK;
-  GFN_CHECK_ARG(dz_hi && dz_lo && a_hi && a_lo && dW, "gfn_wgrad_x3: null pointer");
+  GFN_CHECK_ARG(dz_hi && a_hi && dW && (tiled || (dz_lo && a_lo)), "gfn_wgrad_x3: null pointer (one-plane operands, lo == NULL, need the tile-major form)");
   GFN_CHECK_ARG(n_max > 0 && n_max < (1ll << 31), "gfn_wgrad_x3: n_max=%lld", (long long)n_max);
   GFN_CHECK_ARG(ld_dz % 8 == 0 && ld_a % 8 == 0 && feat_dz % 8 == 0 && feat_a % 8 == 0 && feat_dz >= 8 && feat_a >= 8 &&
                     feat_dz <= ld_dz && feat_a <= ld_a && feat_dz <= 128 && feat_a <= 128,
@@ -466,7 +518,7 @@ int gfn_wgrad_x3_layers(const gfn_wgrad_layer* layers, int n_layers, int64_t n_m
   A.n_layers = n_layers; A.parts = parts; A.part_stride = part_stride; A.base = grad_base;
   for (int l = 0; l < n_layers; l++) {
     const gfn_wgrad_layer& g = layers[l];
-    GFN_CHECK_ARG(g.dz_hi && g.dz_lo && g.a_hi && g.a_lo && g.dW, "gfn_wgrad_x3_layers: null pointer in layer %d", l);
+    GFN_CHECK_ARG(g.dz_hi && g.a_hi && g.dW, "gfn_wgrad_x3_layers: null pointer in layer %d", l);
     GFN_CHECK_ARG(((reinterpret_cast<uintptr_t>(g.dz_hi) | reinterpret_cast<uintptr_t>(g.dz_lo) | reinterpret_cast<uintptr_t>(g.a_hi) |
                     reinterpret_cast<uintptr_t>(g.a_lo)) & 15) == 0, "gfn_wgrad_x3_layers: planes must be 16-byte aligned");
     const int shape = shape_id(g.feat_dz, g.feat_a);

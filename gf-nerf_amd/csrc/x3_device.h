@@ -38,7 +38,30 @@ constexpr int FP_LD = GFN_FIELD_X3_FWD_PLANE_LD;   // feat 0..31 | a1 32..159 | 
 constexpr int FP_FEAT = 0, FP_A1 = 32, FP_XP = 160, FP_C1 = 224, FP_C2 = 352;
 constexpr int BP_LD = GFN_FIELD_X3_BWD_PLANE_LD;   // dz3 0..7 | dh 8..23 | dz2 24..151 | dz1 152..279 | dza1 280..407
 constexpr int BP_DZ3 = 0, BP_DH = 8, BP_DZ2 = 24, BP_DZ1 = 152, BP_DZA1 = 280;
-static_assert(FP_LD == 480 && BP_LD == 408, "plane row widths");
+constexpr int BP_DZA1_LO = GFN_FIELD_X3_BWD_PLANE_LD, BP_LD_RNE = GFN_FIELD_X3_BWD_PLANE_LD_RNE;  // one-plane form: dza1's lo' plane behind the five
+static_assert(FP_LD == 480 && BP_LD == 408 && BP_LD_RNE == BP_LD + 128, "plane row widths");
+// PLANES (template parameter of the producers): 0 none; 1 both halves (hi = rtz, lo' = the residual: wgrad at x3 accuracy);
+// 2 ONE plane per operand: x rounded to f16 once, to nearest even (v_cvt_pk_f16_f32), written where mode 1 writes hi.  The weight
+// gradient is a sum over every sample of the batch (dW = sum_s dz a, 5e5 terms): a rounding that is zero-mean per term averages
+// out in it (rtz would not: it shrinks every operand by 2^-12 on average), unlike in the per-sample chains d x = W^T dz, which stay
+// x3.  Half the plane bytes written, half read by gfn_wgrad_x3_layers, one MFMA per fragment pair instead of three.
+// One layer is kept out of it: base layer 1, dW = sum dza1 feat.  Its activations are the hash features -- f16 numbers already (one
+// table in the global stage: the plane holds them exactly) and on a young table signed noise, so that dW is a sum of random-sign
+// terms that is no larger than its own rounding noise times 2^12 (measured: 1.0e-4 of the largest |dW| from dz's rounding alone,
+// whatever the dither).  dza1 therefore keeps its lo' plane (column BP_DZA1_LO of the same buffer, 128 wide) and neither it nor
+// feat is dithered: that layer's gradient is the x3 one.
+// Dither (PL_RNE): rounding alone is zero-mean but not independent from sample to sample -- neighbouring samples of a ray have
+// nearly the same activations (the SH and appearance inputs are the SAME along a ray) and so nearly the same rounding error, which
+// then adds up along the ray instead of averaging out (measured on the bench's global step: the activations' rounding contributed
+// 3x what dz's did, 2e-4 of the largest |dW| in the head's first layer).  So sample q's activations are stored as
+// rne(a * (1 + u_q)) and its dz as rne(dz * (1 - u_q)), u_q a fixed low-discrepancy hash of q in +-2^-11 (about one f16 ulp): the
+// products dz a keep their value to 2^-22, every rounding meets its own position on the f16 grid, and db = sum dz (1 - u_q) gains
+// zero-mean noise of 3e-4 per term.  amp = 0 switches it off (gfn_set_plane_dither).
+constexpr int PL_NONE = 0, PL_SPLIT = 1, PL_RNE = 2;
+__device__ __forceinline__ float plane_dither(int64_t q, float amp) {
+  const uint32_t hq = (uint32_t)q * 2654435761u;  // golden-ratio sequence: consecutive samples spread evenly
+  return ((float)((int)(hq >> 20) - 2048) + 0.5f) * amp;  // amp = 2^-22: u in (-2^-11, 2^-11)
+}
 
 __device__ __forceinline__ int acc_row(int t, int s, int h, int i) { return 32 * t + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3); }
 
@@ -57,6 +80,16 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 
+// two f32 -> packed f16, round to nearest even: one v_cvt_pk_f16_f32
+__device__ __forceinline__ uint32_t rne2(float x0, float x1) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x0, x1}, h2));
+}
+__device__ __forceinline__ void rne8(const float* x, u32x4& r, float pc = 1.f) {  // pc: the sample's dither factor (plane_dither)
+#pragma unroll
+  for (int p = 0; p < 4; p++) r[p] = rne2(x[2 * p] * pc, x[2 * p + 1] * pc);
+}
 
 struct Acc2 {
   f32x16 m, c;
@@ -130,8 +163,26 @@ __device__ __forceinline__ void acc_get16(const Acc2& a, float (&v)[16]) {
 struct Frag {
   u32x4 hi[2], lo[2];
 };
-template <bool RELU>
-__device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t) {
+// where a tile's 32 columns go in a one-plane (PL_RNE) buffer: columns col0 .. col0+31 of sample q in the plane `base` of width W
+// (registers 8s+4g..+3 = rows 16s+8g+4h..+3: lane half h owns 4 of the 8 features of octet (col0 + 16s + 8g) / 8); pc = the
+// sample's dither factor.  Stored from inside the conversion, value by value: a tile's rounded copy never occupies registers
+struct PlaneDst {
+  uint16_t* base; int W; int64_t q; int col0; int h; float pc; bool on;
+};
+__device__ __forceinline__ void store_tile_rne(const PlaneDst& d, const float (&v)[16]) {
+  if (!d.on) return;
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const float* x = v + 8 * s + 4 * g;
+      *reinterpret_cast<uint2*>(d.base + plane_off(d.q, d.W, (d.col0 >> 3) + 2 * s + g) + 4 * d.h) =
+          make_uint2(rne2(x[0] * d.pc, x[1] * d.pc), rne2(x[2] * d.pc, x[3] * d.pc));
+    }
+}
+// RNE: the tile's 16 values also go, rounded to nearest, to the one-plane buffer row `dst` names
+template <bool RELU, bool RNE = false>
+__device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t, const PlaneDst* dst = nullptr) {
   float v[16];
   acc_get16(a, v);
   uint32_t bits = 0;  // this tile's 16 ReLU bits.  A C++ compare leaves a 64-bit lane mask in an SGPR pair, and with 16 of them per
@@ -146,6 +197,7 @@ __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned lo
     }
   }
   if (RELU) mask |= (unsigned long long)bits << (t * 16);
+  if (RNE) store_tile_rne(*dst, v);
 #pragma unroll
   for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -199,18 +251,27 @@ __device__ __forceinline__ void store_nat(uint16_t* __restrict__ base_hi, uint16
   *reinterpret_cast<u32x4*>(base_lo + o) = fl;
 }
 
+// the half tile and the natural-order fragment for a one-plane buffer (PL_RNE): r = the values rounded to nearest, in the fragment's order
+__device__ __forceinline__ void store_half_tile_rne(uint16_t* __restrict__ base, int W, int64_t q, int col0, const u32x4& r, int h) {
+#pragma unroll
+  for (int g = 0; g < 2; g++) *reinterpret_cast<uint2*>(base + plane_off(q, W, (col0 >> 3) + g) + 4 * h) = make_uint2(r[2 * g], r[2 * g + 1]);
+}
+__device__ __forceinline__ void store_nat_rne(uint16_t* __restrict__ base, int W, int64_t q, int col0, const u32x4& r, int h) {
+  *reinterpret_cast<u32x4*>(base + plane_off(q, W, (col0 >> 3) + h)) = r;
+}
+
 // One 32-sample tile of the decoder (nerfacto_field.py:455-555): split hash features (k-steps xh/xl) -> base_network ->
 // sigma, [geo | SH | appearance] -> mlp_head -> rgb.  sigma / h0 / rgb are meaningful on the h = 0 lanes; the ReLU masks
-// on both halves.  PLANES: every layer input is also written to the split-f16 planes at row q (global stage).
+// on both halves.  PLANES (PL_*): every layer input is also written to the f16 planes at row q (global stage).
 struct DecoderOut {
   float sigma, h0, r, g, b;
   unsigned long long m_a1, m_c1, m_c2;
 };
-template <bool PLANES>
+template <int PLANES>
 __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, const float* __restrict__ bias,
                                                    int lane, const u32x4 (&xh)[2], const u32x4 (&xl)[2], const float* __restrict__ sh_row,
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
-                                                   uint16_t* __restrict__ planes_lo, int64_t cap, int64_t q) {
+                                                   uint16_t* __restrict__ planes_lo, int64_t cap, int64_t q, float pc = 1.f) {
   const int h = lane >> 5;
   const float* bias_h = bias + 4 * h;
   constexpr int Bb0 = 0, Bb1 = 128, Bh0 = 160, Bh1 = 288, Bh2 = 416;  // offsets of the five layers' biases (floats)
@@ -233,8 +294,9 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       mma3p(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
       mma3p(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
       Frag a1;
-      tile_to_frag<true>(a, a1, m_a1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1, h);
+      const PlaneDst pd{FPL(hi, FP_A1), 128, q, 32 * ot, h, pc, true};
+      tile_to_frag<true, PLANES == PL_RNE>(a, a1, m_a1, ot, &pd);
+      if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1, h);
       mma3p(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
       mma3p(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
     }
@@ -246,7 +308,8 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
       split8(v, gh, gl);
-      if (PLANES) store_half_tile(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 0, gh, gl, h);
+      if (PLANES == PL_SPLIT) store_half_tile(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 0, gh, gl, h);
+      if (PLANES == PL_RNE) { u32x4 r; rne8(v, r, pc); store_half_tile_rne(FPL(hi, FP_XP), 64, q, 0, r, h); }
     }
     // ---- head layer 1: [geo | SH | appearance] -> 128, ReLU
     u32x4 sh_h, sh_l, e_h[2], e_l[2];
@@ -254,17 +317,23 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       float x[8];
       load8(sh_row + 8 * h, x);
       split8(x, sh_h, sh_l);
+      if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 16, r, h); }
       if (emb_row) {
         const float* ep = emb_row;
 #pragma unroll
-        for (int u = 0; u < 2; u++) { load8(ep + 16 * u + 8 * h, x); split8(x, e_h[u], e_l[u]); }
+        for (int u = 0; u < 2; u++) {
+          load8(ep + 16 * u + 8 * h, x); split8(x, e_h[u], e_l[u]);
+          if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 32 + 16 * u, r, h); }
+        }
       } else {
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < 2; u++) {
 #pragma unroll
           for (int p = 0; p < 4; p++) { e_h[u][p] = 0u; e_l[u][p] = 0u; }
+          if (PLANES == PL_RNE) store_nat_rne(FPL(hi, FP_XP), 64, q, 32 + 16 * u, e_h[u], h);
+        }
       }
-      if (PLANES) {
+      if (PLANES == PL_SPLIT) {
         store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 16, sh_h, sh_l, h);
         store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 32, e_h[0], e_l[0], h);
         store_nat(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 48, e_h[1], e_l[1], h);
@@ -280,8 +349,9 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       mma3p(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
       mma3p(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
       mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
-      tile_to_frag<true>(a, c1[ot], m_c1, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
+      const PlaneDst pd{FPL(hi, FP_C1), 128, q, 32 * ot, h, pc, true};
+      tile_to_frag<true, PLANES == PL_RNE>(a, c1[ot], m_c1, ot, &pd);
+      if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU, feeding head layer 3: 128 -> 3 (padded), sigmoid
     unsigned long long m_c2 = 0;
@@ -294,8 +364,9 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #pragma unroll
       for (int u = 0; u < 8; u++) mma3p(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       Frag c2;
-      tile_to_frag<true>(a, c2, m_c2, ot);
-      if (PLANES) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2, h);
+      const PlaneDst pd{FPL(hi, FP_C2), 128, q, 32 * ot, h, pc, true};
+      tile_to_frag<true, PLANES == PL_RNE>(a, c2, m_c2, ot, &pd);
+      if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2, h);
       mma3p(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
       mma3p(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
     }
@@ -308,8 +379,8 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
 #undef FPL
 }
 
-template <bool RELU_MASK>
-__device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t) {
+template <bool RELU_MASK, bool RNE = false>
+__device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsigned long long mask, int t, const PlaneDst* dst = nullptr) {
   float v[16];
   acc_get16(a, v);
   const int bits = (int)(uint32_t)(mask >> (t * 16));  // this tile's 16 ReLU bits
@@ -318,6 +389,7 @@ __device__ __forceinline__ void grad_tile_to_frag(const Acc2& a, Frag& f, unsign
     // ReLU': and with the bit stretched to a word (v_bfe_i32 + v_and instead of shift / and / compare / select on 64 bits)
     if (RELU_MASK) v[r] = __int_as_float(__float_as_int(v[r]) & ((bits << (31 - r)) >> 31));
   }
+  if (RNE) store_tile_rne(*dst, v);
 #pragma unroll
   for (int s = 0; s < 2; s++) split8(v + 8 * s, f.hi[s], f.lo[s]);
 }

@@ -78,6 +78,11 @@ class HotPathConfig:
     two_phase_min_saving: tuple = (0.12, 0.06)  # samples a split must save to be started / to be kept (break-even ~ 9 %: measured);
     two_phase_min_saving_planes: tuple = (0.30, 0.20)  # ... in the global stage: compacted samples write unaligned activation-plane rows
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
+    wgrad_planes: str = "rne"        # operands of the decoder's WEIGHT gradient (global stage; dW = sum over the batch's 5e5 samples of dz a):
+                                     # "rne" one f16 plane per operand, rounded to nearest (zero-mean per term, averages out in the sum;
+                                     # half the plane traffic, one MFMA per fragment pair); "x3" hi + lo' planes for both (rounds 1-4:
+                                     # f32-class per term); "mixed" dz one plane, activations hi + lo'.  The per-sample chains (forward,
+                                     # d x = W^T dz, the table gradient) are x3 whatever this says
     exact_oct_alphas: bool = True    # a training forward that UpdateOctNodes follows evaluates the density of EVERY sample, so that K5 reads true alphas
                                      # behind the rays' termination points like the reference does (forward_train's all_alphas); False: rounds 2-3
                                      # (alpha = 0 where the forward skipped a sample: a node's alpha statistic then decays whenever only occluded rays reach it)
@@ -206,15 +211,19 @@ class HotPath:
         self._x3_stale = True  # callers use this hook after writing parameters from outside the optimiser
 
     def _planes(self, cap):
-        """Split-f16 activation / gradient planes of the global stage (480 + 408 f16 columns, hi and lo' each), sized like
-        the packed sample buffers and kept across steps."""
+        """Activation / gradient planes of the global stage (480 + 408 f16 columns; hi and lo' each, or one plane rounded to
+        nearest: cfg.wgrad_planes), sized like the packed sample buffers and kept across steps."""
         if self._plane_bufs is None or self._plane_bufs[0][0].numel() < cap * ops.FIELD_X3_FWD_PLANE_LD:
             cap = (cap + 31) // 32 * 32  # whole 32-sample tiles (the planes are tile-major)
             # zero-initialised: rows of samples the fused forward skips (behind a ray's termination point) keep whatever finite
             # values they held, and meet zero gradients in gfn_wgrad_x3 -- garbage f16 could be NaN
-            mk = lambda ld: (torch.zeros(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
-                             torch.zeros(cap * ld, dtype=torch.float16, device=self.dev))
-            self._plane_bufs = (mk(ops.FIELD_X3_FWD_PLANE_LD), mk(ops.FIELD_X3_BWD_PLANE_LD))
+            if self.cfg.wgrad_planes not in ("rne", "x3", "mixed"):
+                raise _lib.GfnError(f"wgrad_planes must be 'rne', 'x3' or 'mixed', not {self.cfg.wgrad_planes!r}")
+            mk = lambda ld, lo: (torch.zeros(cap * ld, dtype=torch.float16, device=self.dev),  # noqa: E731
+                                 torch.zeros(cap * ld, dtype=torch.float16, device=self.dev) if lo else None)
+            bwd_one = self.cfg.wgrad_planes != "x3"  # (its buffer then also holds dza1's lo' plane: ops.BWD_PLANE)
+            self._plane_bufs = (mk(ops.FIELD_X3_FWD_PLANE_LD, self.cfg.wgrad_planes != "rne"),
+                                mk(ops.FIELD_X3_BWD_PLANE_LD_RNE if bwd_one else ops.FIELD_X3_BWD_PLANE_LD, not bwd_one))
             # xp plane column -> hW0 column: base rows 1..15 = geo (16..30), row 0 = density channel (none), SH, appearance
             cm = np.concatenate([[-1], 15 + np.arange(1, 16), np.arange(16), 31 + np.arange(32)]).astype(np.int32)
             self._xp_col_map = torch.from_numpy(cm).to(self.dev)
@@ -754,10 +763,17 @@ class HotPath:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
                                     bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
             g = self.layer_grads
-            fv = lambda k: (ops.plane_flat(fp[0], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE)[0],  # noqa: E731
-                            *ops.plane_flat(fp[1], ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE))
-            bv = lambda k: (ops.plane_flat(bp[0], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE)[0],  # noqa: E731
-                            *ops.plane_flat(bp[1], ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE))
+            def pv(bufs, ld, k, table):  # (hi_flat, lo_flat | None, width) of plane k
+                hi, w = ops.plane_flat(bufs[0], ld, k, table)
+                return hi, (None if bufs[1] is None else ops.plane_flat(bufs[1], ld, k, table)[0]), w
+            fv = lambda k: pv(fp, ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE)  # noqa: E731
+            bld = ops.FIELD_X3_BWD_PLANE_LD if bp[1] is not None else ops.FIELD_X3_BWD_PLANE_LD_RNE
+
+            def bv(k):
+                hi, lo, w = pv(bp, bld, k, ops.BWD_PLANE)
+                if k == "dza1" and lo is None:  # the one-plane form keeps this plane's lo' half, in the same buffer
+                    lo = ops.plane_flat(bp[0], bld, "dza1_lo", ops.BWD_PLANE)[0]
+                return hi, lo, w
             n_cap = s["ts"].shape[0]
             if self._wgrad_parts is None:
                 self._wgrad_parts = ops.wgrad_parts(self.mlp_grad.numel(), self.dev)

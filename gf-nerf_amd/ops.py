@@ -646,18 +646,22 @@ def _weight_ptrs(layers):
 
 FIELD_X3_FWD_BYTES, FIELD_X3_BWD_BYTES = 149248, 131072
 FIELD_X3_FWD_PLANE_LD, FIELD_X3_BWD_PLANE_LD = 480, 408
+FIELD_X3_BWD_PLANE_LD_RNE = 536  # the backward's one-plane buffer: + dza1's lo' plane (include/gfnerf_amd.h)
 # column ranges of the planes (include/gfnerf_amd.h)
 FWD_PLANE = dict(feat=(0, 32), a1=(32, 128), xp=(160, 64), c1=(224, 128), c2=(352, 128))
-BWD_PLANE = dict(dz3=(0, 8), dh=(8, 16), dz2=(24, 128), dz1=(152, 128), dza1=(280, 128))
+BWD_PLANE = dict(dz3=(0, 8), dh=(8, 16), dz2=(24, 128), dz1=(152, 128), dza1=(280, 128), dza1_lo=(408, 128))
 
 
 def _plane_cap(ph, pl, ld, n):
-    """Plane buffers are flat f16 tensors of cap * ld elements, plane-major (see include/gfnerf_amd.h)."""
+    """Plane buffers are flat f16 tensors of cap * ld elements, plane-major (see include/gfnerf_amd.h).  pl None: ONE plane per
+    operand, its values rounded to f16 once, to nearest (the weight gradient's operands only: csrc/x3_device.h, PL_RNE)."""
     if ph is None and pl is None:
         return 0
+    if ph is None:
+        raise _lib.GfnError("a lo' plane buffer needs its hi buffer")
     for t in (ph, pl):
         _chk(t, torch.float16, "planes")
-    if ph.numel() != pl.numel() or ph.numel() % ld:
+    if (pl is not None and ph.numel() != pl.numel()) or ph.numel() % ld:
         raise _lib.GfnError("plane halves differ in size or are not a multiple of the row width")
     cap = ph.numel() // ld
     if cap < n or cap % 32:
@@ -779,15 +783,18 @@ def split_f16(x):
 def wgrad_x3(dz, a, dW, db=None, n_dev=None, gmax=None, m_valid=None, k_valid=None, col_map=None, n=None, tiled=False):
     """dW[m, col(k)] += sum_s dz[s, m] a[s, k] / gfn_grad_scale(gmax) from split-f16 planes.  dz and a are
     (hi, lo') pairs of [n, width] tensors, or (hi, lo', col0, width) to address a column range of wider planes; with
-    tiled=True they are (hi_flat, lo_flat, width): whole tile-major planes as the fused kernels write them (plane_flat)."""
+    tiled=True they are (hi_flat, lo_flat, width): whole tile-major planes as the fused kernels write them (plane_flat), where
+    lo_flat may be None: one plane, its values rounded to nearest (csrc/x3_device.h, PL_RNE)."""
     def unpack(p):
         hi, lo = p[0], p[1]
         _chk(hi, torch.float16, "plane"); _chk(lo, torch.float16, "plane")
         if tiled:
             width = p[2]
-            if hi.numel() != lo.numel() or hi.numel() % (32 * width):
+            if (lo is not None and hi.numel() != lo.numel()) or hi.numel() % (32 * width):
                 raise _lib.GfnError("tile-major plane halves differ or do not hold a whole number of 32-sample tiles")
-            return hi.data_ptr(), lo.data_ptr(), width, width, hi.numel() // width
+            return hi.data_ptr(), (None if lo is None else lo.data_ptr()), width, width, hi.numel() // width
+        if lo is None:
+            raise _lib.GfnError("one-plane operands (lo None) need the tile-major form")
         col0, width = (p[2], p[3]) if len(p) == 4 else (0, hi.shape[1])
         if hi.shape != lo.shape or col0 + width > hi.shape[1]:
             raise _lib.GfnError("plane halves differ or the column range is out of bounds")
@@ -815,8 +822,8 @@ def wgrad_parts(grad_len, device):
 
 def wgrad_x3_layers(layers, grad, n, n_dev=None, gmax=None, parts=None):
     """Weight (and bias) gradients of several decoder layers from tile-major split-f16 planes in ONE launch, added to `grad`.
-    layers: [(dz, a, dW, db, m_valid, col_map)] with dz / a = (hi_flat, lo_flat, width) (plane_flat) and dW / db views INTO the
-    flat f32 vector grad.  parts (wgrad_parts): the workgroups store partial sums there and a second small kernel adds them up
+    layers: [(dz, a, dW, db, m_valid, col_map)] with dz / a = (hi_flat, lo_flat, width) (plane_flat; lo_flat None = one plane,
+    rounded to nearest: per layer and operand) and dW / db views INTO the flat f32 vector grad.  parts (wgrad_parts): the workgroups store partial sums there and a second small kernel adds them up
     (no atomics on the 31 k weights from 512 workgroups); None: f32 atomics straight into grad."""
     _chk(grad, torch.float32, "grad"); _chk(gmax, torch.float32, "gmax"); _chk(parts, torch.float32, "parts")
     arr = (_lib.WgradLayer * len(layers))()
@@ -824,7 +831,7 @@ def wgrad_x3_layers(layers, grad, n, n_dev=None, gmax=None, parts=None):
     for i, (dz, a, dW, db, m_valid, col_map) in enumerate(layers):
         for pl in (dz, a):
             _chk(pl[0], torch.float16, "plane"); _chk(pl[1], torch.float16, "plane")
-            if pl[0].numel() != pl[1].numel() or pl[0].numel() % (32 * pl[2]) or pl[0].numel() // pl[2] < n:
+            if (pl[1] is not None and pl[0].numel() != pl[1].numel()) or pl[0].numel() % (32 * pl[2]) or pl[0].numel() // pl[2] < n:
                 raise _lib.GfnError("wgrad_x3_layers: plane halves differ, are not whole 32-sample tiles, or hold fewer than n samples")
         _chk(dW, torch.float32, "dW"); _chk(db, torch.float32, "db"); _chk(col_map, torch.int32, "col_map")
         for t in (dW, db):
@@ -835,7 +842,7 @@ def wgrad_x3_layers(layers, grad, n, n_dev=None, gmax=None, parts=None):
             k_valid = min(k_valid, col_map.numel())
         if dW.shape[0] < m_valid or (col_map is None and dW.shape[1] < k_valid):
             raise _lib.GfnError("wgrad_x3_layers: dW too small for the requested rows and columns")
-        arr[i] = _lib.WgradLayer(dz[0].data_ptr(), dz[1].data_ptr(), a[0].data_ptr(), a[1].data_ptr(), dz[2], a[2], int(m_valid), int(k_valid),
+        arr[i] = _lib.WgradLayer(dz[0].data_ptr(), _ptr(dz[1]), a[0].data_ptr(), _ptr(a[1]), dz[2], a[2], int(m_valid), int(k_valid),
                                  _ptr(col_map), dW.data_ptr(), dW.stride(0), _ptr(db))
     if parts is not None and (parts.shape[0] != _lib.lib().gfn_wgrad_x3_parts() or parts.shape[1] < glen):
         raise _lib.GfnError("wgrad_x3_layers: parts must come from wgrad_parts(grad.numel(), ...)")
@@ -868,7 +875,7 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
     _chk(ray_id, torch.int32, "ray_id"); _chk(cam_idx, torch.int32, "cam_idx"); _chk(demb, torch.float32, "demb", 32)
     ph, pl = planes
     n = d_sigma.shape[0]
-    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
+    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD if (pl is not None or ph is None) else FIELD_X3_BWD_PLANE_LD_RNE, n)
     dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
     rc = _lib.lib().gfn_field_bwd_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
                                      _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _stream())
@@ -979,7 +986,7 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
         raise _lib.GfnError("weight image or prim_pool of the wrong size")
     n = d_sigma.shape[0]
     ph, pl = planes if planes is not None else (None, None)
-    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD, n)
+    cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD if (pl is not None or ph is None) else FIELD_X3_BWD_PLANE_LD_RNE, n)
     rec, cnt = (records[0], records[1]) if records is not None else (None, None)
     lst, lst_n = sample_list if sample_list is not None else (None, None)  # (no planes) walk only these samples: the others' gradients are zero
     _chk(lst, torch.int32, "sample_list"); _chk(lst_n, torch.int32, "sample_list count")

@@ -51,7 +51,7 @@ typedef enum {
  *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
  *   102: round 4.   103: round 4 (gfn_sample_rays_record, gfn_fused_render_rec added; GFN_MARCH_REC_FLOATS 6 -> 8: a caller's march_rec
  *   buffer grows by a third). */
-#define GFN_ABI_VERSION 103
+#define GFN_ABI_VERSION 104
 
 const char* gfn_last_error(void);
 int gfn_version(void);
@@ -284,7 +284,12 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * NULL) and are read-only to the kernels; buffers of GFN_FIELD_X3_{FWD,BWD}_BYTES, 16-byte aligned.
  *
  * Global stage (decoder trains): gfn_field_fwd_x3 with planes_{hi,lo} != NULL also keeps every layer
- * input as split-f16 planes.  A plane buffer holds plane_cap * LD u16 (plane_cap >= n_max, multiple of
+ * input as split-f16 planes.  planes_hi != NULL with planes_lo == NULL (the same in gfn_field_bwd_x3, gfn_field_bwd_scatter_x3,
+ * gfn_fused_forward; dz_lo / a_lo of gfn_wgrad_x3_layers): ONE plane per operand, its values rounded to f16 once, to nearest
+ * even, under a per-sample dither (gfn_set_plane_dither) -- for the weight gradient only, a sum over every sample of the batch
+ * in which zero-mean, sample-to-sample independent rounding averages out; half the plane traffic (csrc/x3_device.h, PL_RNE).
+ * The backward's one-plane buffer has GFN_FIELD_X3_BWD_PLANE_LD_RNE columns: dza1 -- whose layer contracts against the hash
+ * features, exact in f16 -- keeps its lo' plane there (C=408 W=128) and is not dithered, nor is feat.  A plane buffer holds plane_cap * LD u16 (plane_cap >= n_max, multiple of
  * 8) and is PLANE-MAJOR: the plane with first column C and width W is the contiguous array
  * [plane_cap][W] at element offset plane_cap * C.  Forward (LD = GFN_FIELD_X3_FWD_PLANE_LD): feat
  * C=0 W=32 | a1 C=32 W=128 | xp C=160 W=64 (base output rows 0..15, SH 16, appearance 32) | c1 C=224
@@ -300,6 +305,7 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
 #define GFN_FIELD_X3_BWD_BYTES 131072
 #define GFN_FIELD_X3_FWD_PLANE_LD 480
 #define GFN_FIELD_X3_BWD_PLANE_LD 408
+#define GFN_FIELD_X3_BWD_PLANE_LD_RNE 536 /* one-plane form (planes_lo == NULL): the backward's buffer also holds dza1's lo' plane, C=408 W=128 */
 int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_image, void* stream);
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb,
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
@@ -358,6 +364,10 @@ float gfn_grad_scale_host(float gmax);
  * gather / scatter kernels of another chunk running on a second stream (0 = every CU).  Returns the
  * previous value.  Process-wide. */
 int gfn_set_decoder_cus(int n_cus);
+/* One-plane (planes_lo == NULL) producers: sample q's activations are stored as rne(a * (1 + u_q)) and its dz as
+ * rne(dz * (1 - u_q)), u_q a fixed hash of q in +-2^-11, so that neighbouring samples' rounding errors are independent
+ * (csrc/x3_device.h).  on = 0 switches the dither off (plain rounding).  Returns the previous value.  Process-wide; default on. */
+int gfn_set_plane_dither(int on);
 
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]

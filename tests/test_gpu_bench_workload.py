@@ -241,25 +241,47 @@ def test_bench_step_forward_and_backward_against_oracle_on_a_run_of_rays(world, 
     assert abs(halves.sum() - full_pool.sum()) <= 1e-3 * mass
 
 
-def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world, oracle):
+@pytest.mark.parametrize("mode,forward", [("x3", "fused"), ("rne", "fused"), ("rne", "lm"), ("mixed", "lm"), ("rne-plain", "lm")])
+def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world, oracle, mode, forward):
     """The global stage at 4096 x 128 (524 k samples).  gfn_grad_max / gfn_grad_scale_of: the batch scale is the power of two
     that brings the largest incoming gradient into [8, 16).  The activation planes the forward keeps and the dz planes the
-    backward writes (split f16, tile-major) read back as the oracle's activations and pre-activation gradients on rays
-    [900, 916).  `wgrad_x3_layers`: dW / db of all five layers equal a float64 contraction dz^T a / scale over ALL samples of
-    the very planes it read (2e-6 of sum |dz||a|)."""
+    backward writes (tile-major; `mode` = HotPathConfig.wgrad_planes: "x3" hi + lo' for both operands, "rne" ONE plane per operand
+    rounded to nearest, "mixed" dz one plane / activations split; `forward`: the fused kernel or lookup + decoder kernels) read back
+    as the oracle's activations and pre-activation gradients on rays [900, 916).  `wgrad_x3_layers`: dW / db of all five layers
+    equal a float64 contraction dz^T a / scale over ALL samples of the very planes it read (2e-6 of sum |dz||a|: the kernel's own
+    arithmetic), and -- the one-plane modes' accuracy -- the float64 contraction of the x3 planes (22-bit
+    operands, taken as exact) to 1e-4 of each layer's largest |dW|: the achieved figure is printed.  "rne-plain": the one-plane
+    mode WITHOUT its per-sample dither (gfn_set_plane_dither(0)), reported for comparison and held to 3e-4 only."""
     import torch
 
-    from gfnerf_amd import ops
+    from gfnerf_amd import _lib, ops
 
     S = _stage(world, "global")
     hp = S["hp"]
+    prev = (hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override)
+    plain = mode == "rne-plain"
+    mode = "rne" if plain else mode
+    hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override = mode, forward == "lm", False  # (one phase: every plane row written)
+    hp._plane_bufs = None  # the planes are allocated for one mode
+    was = _lib.lib().gfn_set_plane_dither(0 if plain else 1)
+    try:
+        _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=3e-4 if plain else 1e-4)
+    finally:
+        _lib.lib().gfn_set_plane_dither(was)
+        hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override = prev
+        hp._plane_bufs = None
+
+
+def _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=1e-4):
     o, d, cam, noise = _t(S["o"]), _t(S["d"]), _t(S["cam"]), _t(S["noise"])
     comp, ctx = hp.forward_train(o, d, cam, noise, stage="global")
     s, f = ctx["samples"], ctx["field"]
     n = int(s["pts_offsets"][-1].item())
-    assert abs(n / R - 128) < 2 and hp.last_forward == "fused"
+    assert abs(n / R - 128) < 2 and hp.last_forward == forward, hp.last_forward
     loss, g_rgb = _g_rgb(S, comp["rgb"])
     d_sigma, d_rgb = ops.composite_bwd(s["pts_offsets"], f["sigma"], s["dists"], f["rgb"], g_rgb, None, early_T=hp.cfg.early_T)
+    for gW, gB in hp.layer_grads:
+        gW.zero_(); gB.zero_()
     hp.backward(ctx, g_rgb)
     # the batch scale
     gs = (d_sigma[:n] * torch.exp(torch.clamp(f["h0"][:n] + 1.0, -15.0, 15.0))).abs().max()
@@ -268,14 +290,18 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
     scale = ops.grad_scale(float(hp._gmax.item()))
     assert 8.0 <= gmax_want * scale < 16.0 and np.log2(scale) == round(np.log2(scale))
     fp, bp = hp._planes(s["ts"].shape[0])
+    assert (fp[1] is None) == (mode == "rne") and (bp[1] is None) == (mode != "x3")
 
     def plane(pair, ld, name, table):
-        hi, lo = (ops.plane_view(buf, ld, name, table)[:n].double() for buf in pair)
-        return hi + lo / 2048.0
+        hi = ops.plane_view(pair[0], ld, name, table)[:n].double()
+        return hi if pair[1] is None else hi + ops.plane_view(pair[1], ld, name, table)[:n].double() / 2048.0
 
     A = {k: plane(fp, ops.FIELD_X3_FWD_PLANE_LD, k, ops.FWD_PLANE) for k in ("feat", "a1", "xp", "c1", "c2")}
-    DZ = {k: plane(bp, ops.FIELD_X3_BWD_PLANE_LD, k, ops.BWD_PLANE) / scale for k in ("dz3", "dh", "dz2", "dz1", "dza1")}
-    # ---- the planes against the oracle on a run of rays
+    bld = ops.FIELD_X3_BWD_PLANE_LD if bp[1] is not None else ops.FIELD_X3_BWD_PLANE_LD_RNE
+    DZ = {k: plane(bp, bld, k, ops.BWD_PLANE) / scale for k in ("dz3", "dh", "dz2", "dz1", "dza1")}
+    if bp[1] is None:  # the one-plane form keeps dza1's lo' half (same buffer)
+        DZ["dza1"] = DZ["dza1"] + ops.plane_view(bp[0], bld, "dza1_lo", ops.BWD_PLANE)[:n].double() / 2048.0 / scale
+    # ---- the planes against the oracle on a run of rays (one-plane modes: the values rounded to f16, 2^-11 relative)
     P = hp.export_params()
     r0, k = 900, 16
     po = s["pts_offsets"].cpu().numpy().astype(np.int64)
@@ -284,9 +310,10 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
     assert np.array_equal(po[r0:r0 + k + 1] - a, m["pts_offsets"])
     alive = co["weights"] > 0
     cm = hp._xp_col_map.cpu().numpy()  # xp plane column -> column of the head's 63-wide input
+    rt_a = 1e-4 if fp[1] is not None else 1.2e-3  # one plane: rounding 2^-11 + the sample's dither factor 1 +- 2^-11
     for name, want in (("feat", fo["feat"]), ("a1", fo["a1"]), ("c1", fo["c1"]), ("c2", fo["c2"])):
         got = A[name][a:b].cpu().numpy()
-        np.testing.assert_allclose(got[alive], want[alive], rtol=1e-4, atol=2e-5 * np.abs(want).max(), err_msg=name)
+        np.testing.assert_allclose(got[alive], want[alive], rtol=rt_a, atol=2e-5 * np.abs(want).max(), err_msg=name)
     xp = A["xp"][a:b].cpu().numpy()
     for col in range(64):
         if cm[col] >= 0:
@@ -297,6 +324,8 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
         np.testing.assert_allclose(got, want, rtol=5e-3, atol=2e-3 * np.abs(want).max(), err_msg=name)
     # ---- weight gradients = dz^T a over all 524 k samples, in float64 on the device
     cmt = torch.from_numpy(cm).cuda()
+    exact = world["cache"].setdefault("wgrad_exact", {})  # the x3 run's contraction: 22-bit operands, "exact" for the one-plane modes
+    report = []
     for li, dzk, ak, mv in ((4, "dz3", "c2", 3), (3, "dz2", "c1", 128), (2, "dz1", "xp", 128), (1, "dh", "a1", 16), (0, "dza1", "feat", 128)):
         dz, act = DZ[dzk][:, :mv], A[ak]
         want = dz.T @ act
@@ -309,6 +338,20 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
             want = w2
         assert float((gW.double() - want).abs().max()) < 2e-6 * mag, (li, float((gW.double() - want).abs().max()), mag)
         np.testing.assert_allclose(gB.double().cpu().numpy(), dz.sum(0).cpu().numpy(), rtol=1e-4, atol=2e-6 * float(dz.abs().sum(0).max()))
+        if mode == "x3":
+            exact[li] = (want.clone(), dz.sum(0).clone())
+        elif li in exact:
+            wW, wB = exact[li]
+            eW = float((gW.double() - wW).abs().max()) / float(wW.abs().max())
+            eB = float((gB.double() - wB).abs().max()) / float(wB.abs().max())
+            cos = float((gW.double() * wW).sum() / (gW.double().norm() * wW.norm()))
+            report.append((li, eW, eB, cos))
+    if report:
+        print(f"\n[wgrad {mode}/{forward}] max |dW - exact| / max |dW| per layer (layer, dW, db, cosine): " +
+              ", ".join(f"({li}, {eW:.2e}, {eB:.2e}, {cos:.8f})" for li, eW, eB, cos in report))
+        assert len(report) == 5  # (the x3 case runs first: pytest keeps the parametrisation's order)
+        for li, eW, eB, cos in report:
+            assert eW <= bar and eB <= bar and cos >= 0.99999, (mode, li, eW, eB, cos)
 
 
 def test_bench_scene_octree_statistics_bit_exact_on_a_run_of_rays(world, oracle):

@@ -679,10 +679,13 @@ def test_wgrad_x3_matches_f64(ops, dev, m_feat, k_feat, m_valid, k_valid, tiled)
     np.testing.assert_allclose(db.cpu().numpy(), dz[:n, :m_valid].astype(np.float64).sum(0), rtol=1e-4, atol=2e-6 * np.abs(dz[:n]).sum(0).max())
 
 
+@pytest.mark.parametrize("form", ["x3", "rne", "mixed"])
 @pytest.mark.parametrize("with_parts", [True, False])
-def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts):
+def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts, form):
     """gfn_wgrad_x3_layers: the five decoder layers in one launch (slabs by LDS-DMA, bias sums from the MFMA fragments), partial
-    vectors + gfn_wgrad_reduce or atomics, against float64 dz^T a; ragged n, device count, scale, col_map, gaps in the flat vector."""
+    vectors + gfn_wgrad_reduce or atomics, against float64 dz^T a; ragged n, device count, scale, col_map, gaps in the flat vector.
+    form: both operands as hi + lo' planes ("x3"), both as ONE plane rounded to nearest ("rne": 64-sample slabs, one MFMA per
+    fragment pair) or dz one plane and the activations split ("mixed") -- the contraction of the values the planes hold."""
     import torch
 
     rng = np.random.default_rng(11)
@@ -699,7 +702,16 @@ def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts):
         dz = (rng.standard_normal((n_cap, m_feat)) * np.exp(rng.uniform(-6, 0, (n_cap, 1)))).astype(np.float32)
         a = np.maximum(rng.standard_normal((n_cap, k_feat)), 0).astype(np.float32) * 3.0
         dz[:, m_valid:] = 0
+        if form != "x3":  # one plane: the operand IS its f16 rounding
+            dz = ((dz * scale).astype(np.float16).astype(np.float32) / scale).astype(np.float32)
+        if form == "rne":
+            a = a.astype(np.float16).astype(np.float32)
         dzp, ap = ops.split_f16(t(dz * scale)), ops.split_f16(t(a))
+        if form != "x3":
+            assert float(dzp[1].abs().max()) == 0.0
+            dzp = (dzp[0], None)
+        if form == "rne":
+            ap = (ap[0], None)
         ldw = k_valid
         col_map = None
         want = dz[:n, :m_valid].astype(np.float64).T @ a[:n, :k_valid].astype(np.float64)
@@ -714,7 +726,8 @@ def test_wgrad_x3_layers_matches_f64(ops, dev, with_parts):
             want = w2
         dW = grad[off:off + m_valid * ldw].view(m_valid, ldw); off += m_valid * ldw
         db = grad[off:off + m_valid]; off += m_valid
-        layers.append(((tile(dzp[0]), tile(dzp[1]), m_feat), (tile(ap[0]), tile(ap[1]), k_feat), dW, db, m_valid, col_map))
+        tl = lambda x: None if x is None else tile(x)  # noqa: E731
+        layers.append(((tile(dzp[0]), tl(dzp[1]), m_feat), (tile(ap[0]), tl(ap[1]), k_feat), dW, db, m_valid, col_map))
         mag = (np.abs(dz[:n, :m_valid]).astype(np.float64).T @ np.abs(a[:n, :k_valid]).astype(np.float64)).max()
         wants.append((want, dz[:n, :m_valid].astype(np.float64).sum(0), mag, np.abs(dz[:n]).sum(0).max()))
     n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
