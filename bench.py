@@ -88,6 +88,9 @@ def parse():
                          "(gfnerf_amd.procedural.STUDY_STEPS); 0,0 = skip")
     ap.add_argument("--plugin-steps", type=int, default=100,
                     help="timed iterations of the `plugin_step` sub-records (the step through GFNerfPipeline + Optimizers, N = 1 only); 0 = skip")
+    ap.add_argument("--inject-divergence", action="store_true",
+                    help="test hook (N > 1): rank 1 changes one table entry after the global-stage steps -- the run must then report "
+                         "replicas_bit_identical false and end with exit code 5")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; gloo instead of RCCL)")
     ap.add_argument("--lm-halves-from", type=int, default=6, help="level-major lookup: levels >= this are gathered one address part at a time")
@@ -1215,6 +1218,7 @@ def run_rank(args):
     fine_focal, batches_focal = run.fineness, run.batches_np
     # ---- configs[1]: the global stage under the same clock (sub-record); data parallel at N > 1
     grun = None
+    identical_after_global = [None]
     if args.global_steps > 0 and headline_stage != "global":
         del run, hp, res
         torch.cuda.empty_cache()
@@ -1226,7 +1230,10 @@ def run_rank(args):
             if rank == 0 and args.stage_times:
                 grun.print_stage_times(gres)
             groof, g_live, g_eval = grun.roofline(gres)
+            if args.inject_divergence and world > 1 and rank == 1:
+                grun.hp.table.view(-1)[12345] += 1.0
             identical = sync.replicas_identical([grun.hp.table, grun.hp.mlp_flat, grun.hp.emb, grun.hp.nodes]) if world > 1 else None
+            identical_after_global[0] = identical
             if out is not None:
                 gv = N_RAYS * world * args.global_steps / gres["elapsed"]
                 out["global_stage"] = dict(
@@ -1299,6 +1306,11 @@ def run_rank(args):
     if failed:  # a sub-record that failed is a failed run, whatever the headline says
         print(f"bench.py: failed sub-records: {failed}", file=sys.stderr)
         sys.exit(4)
+    # data-parallel replicas that are not bit-identical after the timed steps: the exchanges lost or reordered something.  Every rank
+    # holds the same verdict (an all-reduced checksum comparison), so every rank leaves with the same code
+    if identical_after_global[0] is False:
+        print("bench.py: the data-parallel replicas DIVERGED (replicas_bit_identical false)", file=sys.stderr)
+        sys.exit(5)
 
 
 def main():

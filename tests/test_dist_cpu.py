@@ -1,4 +1,4 @@
-"""World-size-2 gloo tests (CPU) of the multi-GPU path: the exchanges HotPath.train_step drives through
+"""World-size-2 and world-size-8 gloo tests (CPU) of the multi-GPU path: the exchanges HotPath.train_step drives through
 gfnerf_amd.dist.TrainSync (MAX-reduce of the octree statistics between K5 and K6, the direct all-reduce of the table
 gradient started inside the backward, the late decoder / embedding gradients), one-block-per-rank ownership, block-owner
 frame routing and the checkpoint gather.  The ranks run the product's host code on CPU tensors; the one device kernel of
@@ -146,6 +146,126 @@ def test_two_rank_collectives_and_hotpath_hooks():
     assert r0["same"] and r1["same"] and not r0["differ"] and not r1["differ"]
     assert r0["ranks_seen"] == 2 and r1["ranks_seen"] == 2
     assert r0["stats_sync"]["octree_max_reduces"] == 1 and r0["stats_sync"]["direct_reduces"] == 2
+
+
+def _pattern(n, r, scale=1.0):
+    """Rank r's table-gradient pool for the world-8 rehearsal: f16-exact values every rank can rebuild for every other rank (a
+    multiplicative hash of the index, shifted per rank), x128-scale magnitudes, a few entries a plain f16 sum would overflow on."""
+    i = torch.arange(n, dtype=torch.int64)
+    v = (((i * 2654435761 + r * 40503) >> 7) % 4096 - 2048).to(torch.float32) * (scale / 16.0)
+    v[5::100003] = 50000.0 + 100.0 * r
+    return v.to(torch.float16)
+
+
+def _worker8(rank, world, port, q, n_tab):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import cluster, dist as gd
+    from gfnerf_amd import hotpath
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = dict(rank=rank)
+        sync = gd.TrainSync(direct=True, shard_mean=torch_shard_mean)
+        # ---- the table gradient at its REAL element count (17 * 2^21 f16 = 71 MB): shard = n / world
+        table_grad = _pattern(n_tab, rank)
+        assert sync._use_direct(table_grad) and n_tab % (8 * world) == 0
+        g = torch.Generator().manual_seed(100 + rank)
+        mlp_grad, emb_grad = torch.randn(31251, generator=g), torch.randn(40, 32, generator=g)
+        mlp_mine = mlp_grad.clone()
+
+        def fake_hp(grads):
+            ns = types.SimpleNamespace(sync=sync, grads=grads, seg=None)
+            ns._eager = lambda fn: hotpath.HotPath._eager(ns, fn)
+            return ns
+
+        sync.start_grads([table_grad])  # what the fused backward does once the table gradient is final
+        hotpath.HotPath.sync_grads(fake_hp(lambda stage: [table_grad, mlp_grad, emb_grad]), hotpath.STAGE_GLOBAL, {"table_exchange_started": True})
+        # expected: f32 sum of the ranks' pools in rank order x 1/world, rounded to f16 once (gfn_reduce_shards' contract), chunk by chunk
+        ok, finite = True, True
+        for c0 in range(0, n_tab, 1 << 22):
+            c1 = min(n_tab, c0 + (1 << 22))
+            acc = torch.zeros(c1 - c0, dtype=torch.float32)
+            i = torch.arange(c0, c1, dtype=torch.int64)
+            for r in range(world):
+                v = (((i * 2654435761 + r * 40503) >> 7) % 4096 - 2048).to(torch.float32) * (1.0 / 16.0)
+                first = (5 - c0) % 100003
+                v[first::100003] = 50000.0 + 100.0 * r
+                acc += v.to(torch.float16).float()
+            want = (acc * (1.0 / world)).to(torch.float16)
+            ok = ok and bool(torch.equal(table_grad[c0:c1], want))
+            finite = finite and bool(torch.isfinite(table_grad[c0:c1].float()).all())
+        res.update(table_mean_exact=ok, table_finite=finite, direct_reduces=sync.stats["direct_reduces"], shard=n_tab // world)
+        # the decoder gradient: mean of the eight (every rank can rebuild the others' draws)
+        want_mlp = torch.stack([torch.randn(31251, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).double().mean(0)
+        res["mlp_err"] = float((mlp_grad.double() - want_mlp).abs().max())
+        res["mlp_changed"] = not torch.equal(mlp_grad, mlp_mine)
+        # ---- octree statistics: elementwise MAX of the eight ranks' K5 results
+        n_nodes = 10809
+        mk = lambda r: (torch.randint(-1, 600, (3 * n_nodes,), generator=torch.Generator().manual_seed(7 + r), dtype=torch.int64),  # noqa: E731
+                        torch.randint(0, 50, (n_nodes,), generator=torch.Generator().manual_seed(70 + r), dtype=torch.int64))
+        scratch, visit = (t.clone() for t in mk(rank))
+        sync.reduce_octree_stats([scratch, visit])
+        alls = [mk(r) for r in range(world)]
+        res["oct_max_exact"] = bool(torch.equal(scratch, torch.stack([a[0] for a in alls]).max(0).values) and
+                                    torch.equal(visit, torch.stack([a[1] for a in alls]).max(0).values))
+        # ---- one block per rank: ownership, frame routing, the checkpoint gather, the stage-boundary broadcast
+        res["blocks8"], res["blocks16"] = gd.my_blocks(8), gd.my_blocks(16)
+        rng = np.random.default_rng(0)
+        pos = rng.uniform(-40, 40, (1600, 3))
+        labels = cluster.equal_size_clusters(pos, 8)
+        path = rng.integers(0, 1600, 40)
+        res["owners"] = gd.frame_owner(labels[path], world)
+        res["my_frames"] = gd.frame_shard_by_block(labels[path], world, rank)
+        res["path_labels"] = labels[path].tolist()
+        res["my_cams"] = int(cluster.cameras_of(labels, gd.my_blocks(8)[0]).size)
+        tables = {b: torch.full((64, 2), float(b)) for b in gd.my_blocks(8)}
+        gathered = gd.gather_block_tables(tables, 8, dst=0)
+        res["gathered"] = None if gathered is None else {int(b): float(t.mean()) for b, t in gathered.items()}
+        shared = [torch.full((3,), float(rank))]
+        gd.broadcast_from(shared, src=3)
+        res["broadcast"] = shared[0].tolist()
+        res["selfcheck"] = gd.allreduce_selfcheck(n=1 << 18, device="cpu", shard_mean=torch_shard_mean)
+        res["same"] = sync.replicas_identical([table_grad, mlp_grad, scratch])
+        res["differ"] = sync.replicas_identical([torch.full((9,), float(rank == 5))])  # ONE rank out of eight differs
+        res["ranks_seen"] = sync.ranks_seen()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal():
+    """the exchanges of the data-parallel step and the one-block-per-rank bookkeeping at the world size of the node
+    (BASELINE configs[3]: 8 x MI355X) -- TrainSync's direct path with shard = n / 8 on the table gradient's real element count
+    (17 * 2^21 f16), its result bit for bit the f32 mean rounded once; the K5 MAX exchange on a bench-sized tree; my_blocks /
+    frame_owner / frame_shard_by_block for 8 blocks and 1,600 cameras; gather_block_tables; replicas_identical telling one deviating
+    rank out of eight.  gloo on the CPU: what only RCCL over xGMI can still break is listed in DESIGN.md section 6."""
+    world, n_tab = 8, 17 << 21
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, n_tab)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r, x in enumerate(res):
+        assert x["table_mean_exact"] and x["table_finite"] and x["direct_reduces"] == 1 and x["shard"] == n_tab // 8, x
+        assert x["mlp_err"] < 1e-6 and x["mlp_changed"] and x["oct_max_exact"], x
+        assert x["blocks8"] == [r] and x["blocks16"] == [r, r + 8]
+        assert x["owners"] == [lb % 8 for lb in x["path_labels"]]
+        assert x["my_frames"] == [f for f, lb in enumerate(x["path_labels"]) if lb % 8 == r]
+        assert x["my_cams"] == 200  # 1,600 cameras in 8 equal clusters
+        assert x["broadcast"] == [3.0, 3.0, 3.0]
+        assert x["selfcheck"]["ok"] and x["selfcheck"]["world"] == 8
+        assert x["same"] and not x["differ"] and x["ranks_seen"] == 8
+    assert sorted(f for x in res for f in x["my_frames"]) == list(range(40))  # every frame of the path rendered exactly once
+    assert res[0]["gathered"] == {b: float(b) for b in range(8)} and all(x["gathered"] is None for x in res[1:])
 
 
 def test_single_process_is_identity():

@@ -137,6 +137,43 @@ def test_bench_self_spawns_two_ranks():
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_bench_six_ranks_share_the_card():
+    """VERDICT r04 #3(b), as far as one card goes: the GPU boxes allow at most 6 processes on a card, so the widest job that can run
+    here is `bench.py --gpus 6 --share-gpu` (gloo) -- shards of n/6, six blocks on six ranks, six-way frame routing, the four-segment
+    data-parallel StepGraph with six replicas.  (World 8 -- shard = n/8 at the table gradient's real size, 8 blocks, 8-way routing --
+    runs on the CPU: tests/test_dist_cpu.py::test_eight_rank_rehearsal.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--share-gpu", "--n-side", "6", "--log2-T", "16", "--steps", "3",
+           "--warmup", "0", "--global-steps", "3", "--global-warmup", "0", "--render-frames", "1", "--no-cpu-baseline", "--sub-timeout", "400"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 2000, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 6 and d["ranks_seen"] == 6 and d["scaling"] == "weak" and d["value"] > 0 and "errors" not in d
+    assert d["config"]["global_ms_per_step"] > 0 and d["config"]["global_rays_per_sec"] > 0 and d["config"]["replicas_bit_identical"] is True
+    det = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench-details] ")]
+    d = json.loads(det[0][len("[bench-details] "):])
+    g = d["global_stage"]
+    assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and "dp6" in g["parallelism"], g
+    assert d["render"]["frames"] == 6 and "routed" in d["render"]["routing"], d["render"]
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_bench_exit_code_says_when_replicas_diverge():
+    """`--inject-divergence` (rank 1 changes one table entry after the data-parallel steps): the line reports replicas_bit_identical
+    false and the job ends with exit code 5 on every rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--n-side", "6", "--log2-T", "16", "--steps", "2",
+           "--warmup", "0", "--global-steps", "2", "--global-warmup", "0", "--render-frames", "0", "--no-cpu-baseline", "--inject-divergence"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 5, (p.returncode, p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["config"]["replicas_bit_identical"] is False, p.stdout
+    assert "DIVERGED" in p.stderr
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
 def test_bench_does_not_fall_back_when_rccl_cannot_be_used():
     """`--backend nccl` with two ranks on ONE card (RCCL refuses that): the job must end with a non-zero exit code and no result
     line -- never a line that claims N GPUs after a quiet switch to gloo."""
