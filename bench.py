@@ -117,7 +117,7 @@ def parse():
     ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
     ap.add_argument("--render-patch-width", type=int, default=8,
                     help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
-    ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~128 Ki rays that divides the frame)")
+    ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~512 Ki rays that divides the frame, capped by the free device memory)")
     ap.add_argument("--render-tile-width", type=int, default=128, help="with --render-tile-rays: render tiles are blocks of this width (0 = raster runs)")
     ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
                     help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
@@ -677,7 +677,7 @@ class StageRun:
             self.batches, self.batches_np = list(engine["batches"]), None
             self.target = TARGET_SAMPLES[stage]
             self.fineness, self.mean_samples = pick_fineness(hp, self.batches[0][0], self.batches[0][1], self.target, scene, torch)
-            self.draw_stream = ops.concurrent_stream()
+            self.draw_stream = ops.concurrent_stream(role="draws")
             self.drawn = {}
             self.i = 0
             return
@@ -722,7 +722,7 @@ class StageRun:
         # The march noise (PersSampler_cuda.cu:380-389) and S3IM's arange + 9 permutations (losses.py:780-789) are drawn on the
         # device EVERY step, inside the timed region like the reference does: step i draws them for step i + 1 on a third stream
         # (they depend on nothing), beside the step's own kernels.
-        self.draw_stream = ops.concurrent_stream()
+        self.draw_stream = ops.concurrent_stream(role="draws")
         self.drawn = {}
         self.i = 0
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gfn_grad_scale_host": (_f32, [_f32]),
     "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_set_plane_dither": (_i32, [_i32]),
+    "gfn_set_march_lanes": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_wgrad_x3_parts": (_i32, []),
     "gfn_wgrad_x3_layers": (_i32, [C.POINTER(WgradLayer), _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -947,7 +947,18 @@ __global__ void query_centers_kernel(int64_t n_pts, int64_t n_nodes, const uint8
 
 }  // namespace
 
+namespace {
+int g_march_lanes = [] { const char* e = getenv("GFN_MARCH_LANES"); return e ? atoi(e) : 0; }();
+}  // namespace
+
 extern "C" {
+
+int gfn_set_march_lanes(int lanes) {
+  const int old = g_march_lanes;
+  g_march_lanes = (lanes == 4 || lanes == 16) ? lanes : 0;
+  return old;
+}
+
 
 int gfn_normalize_dirs(const float* rays_d_raw, float* rays_d, int64_t n_rays, void* stream) {
   if (n_rays == 0) return GFN_OK;
@@ -1082,8 +1093,7 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
   int* counts = record_only ? record_counts : anchors;  // (anchors: scratch until the fill pass)
   // lanes per ray (MarchGroup): a row of 16 while the batch leaves the machine empty (the shortest chain per step), a quad from 32 Ki rays on
   // (a quarter of the vector work per ray); GFN_MARCH_LANES = 4 | 16 in the environment overrides (tests run both on the same rays)
-  const char* lanes_env = getenv("GFN_MARCH_LANES");
-  const int forced_lanes = lanes_env ? atoi(lanes_env) : 0;
+  const int forced_lanes = g_march_lanes;  // gfn_set_march_lanes (GFN_MARCH_LANES in the environment is its start value, read once)
   const bool quad = forced_lanes == 4 || (forced_lanes != 16 && n_rays >= 32768);
   auto march = [&](auto lanes, auto fill, int* counts_out, const int* offsets, float* rec) {
     constexpr int L = decltype(lanes)::value;

@@ -240,7 +240,7 @@ class TrainSync:
             if self._stream is None:
                 from . import ops
 
-                self._stream = ops.concurrent_stream(tensors[0].device)  # (a stream sharing the launch stream's hardware queue would not overlap)
+                self._stream = ops.concurrent_stream(tensors[0].device, role="comm")  # (a stream sharing the launch stream's hardware queue would not overlap)
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
                 self._reduce(tensors)

@@ -311,7 +311,7 @@ class HotPath:
 
     def _new_side_stream(self):
         """The second stream (next batch's draw + sampler, octree update): one that demonstrably runs BESIDE the current stream (ops.concurrent_stream)."""
-        return ops.concurrent_stream(self.dev)
+        return ops.concurrent_stream(self.dev, role="sampler")
 
     def side_stream(self):
         if self._side is None:
@@ -460,7 +460,7 @@ class HotPath:
         # (two dependent small launches less between the compositing and the backward); joined by backward() / the next forward
         main = torch.cuda.current_stream()
         if self._aux_stream is None:
-            self._aux_stream = ops.concurrent_stream(self.dev)
+            self._aux_stream = ops.concurrent_stream(self.dev, role="aux")
         self._aux_stream.wait_stream(main)
         with torch.cuda.stream(self._aux_stream):
             if planes is None:  # (focal stage) the backward walks exactly the samples in front of the termination points
@@ -500,6 +500,14 @@ class HotPath:
                     t_minmax=out["t_minmax"])
         return f, comp
 
+    def uses_patch_kernel(self, n_rays, tile_width, block=None):
+        """Will render(tile_width=...) of n_rays rays go through the patch kernel (gfn_fused_render: lookup + decoder + compositing,
+        32 neighbouring rays in lockstep)?  Then -- and only then -- the samples may be in the record form (sample(record=True)): callers
+        that sample ahead of render (the tile pipeline) decide the form with this one predicate."""
+        pw = self.cfg.render_patch_width
+        return bool(tile_width is not None and pw > 0 and self._fused_ok(block) and n_rays % 32 == 0 and
+                    (tile_width == 0 or (tile_width % pw == 0 and n_rays % tile_width == 0 and (n_rays // tile_width) % (32 // pw) == 0)))
+
     def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None):
         """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566).
         samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles).
@@ -510,8 +518,7 @@ class HotPath:
         early = c.early_T if early_T is None else early_T
         R = rays_o.shape[0]
         pw = c.render_patch_width
-        patches = (tile_width is not None and pw > 0 and self._fused_ok(block) and R % 32 == 0 and
-                   (tile_width == 0 or (tile_width % pw == 0 and R % tile_width == 0 and (R // tile_width) % (32 // pw) == 0)))
+        patches = self.uses_patch_kernel(R, tile_width, block)
         s = self.sample(rays_o, rays_d_raw, noise, record=patches) if samples is None else samples  # (the patch kernel reads the march's records)
         recorded = s.get("pts_offsets") is None  # sample(record=True): only the patch kernel reads that form
         if (s["counts"].numel() if recorded else s["pts_offsets"].numel() - 1) != R:
@@ -630,7 +637,7 @@ class HotPath:
         # (with one table the fused kernel's early termination makes it a tie at first and a loss once the scene has density:
         # cfg.level_major_global / level_major_global_after)
         all_alphas = bool(all_alphas) and c.early_T > 0 and c.exact_oct_alphas
-        lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after) or all_alphas
+        lm_global = self.level_major_global_now(all_alphas)
         lm = (c.level_major and (blk is not None or lm_global) and fused and c.mlp_precision == "x3" and c.table_f16_shadow
               and not c.keep_features)
         phased = lm and c.two_phase and c.early_T > 0 and self.phase_override is not False and not all_alphas
@@ -647,6 +654,14 @@ class HotPath:
         ctx = dict(samples=s, field=f, comp=comp, cam_idx=cam_idx, stage=stage, fused=fused, block=block)
         self._last_train_ctx = ctx
         return comp, ctx
+
+    def level_major_global_now(self, all_alphas=False):
+        """Global stage: would forward_train take the level-major forward at THIS optimiser step?  (cfg.level_major_global, or from step
+        cfg.level_major_global_after on, or whenever UpdateOctNodes needs every sample's alpha.)  A captured step has the answer of its
+        capture baked in: StepGraph compares and captures again when it changes."""
+        c = self.cfg
+        return bool(c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after) or
+                    (all_alphas and c.early_T > 0 and c.exact_oct_alphas))
 
     def forget_graphs(self):
         """Whatever a captured forward has baked in (tree blob, table addresses) is about to change."""
@@ -889,7 +904,7 @@ class HotPath:
                                            hy(f"block{block}"))
             if c.async_adam and c.level_major:
                 if self._opt_stream is None:
-                    self._opt_stream = ops.concurrent_stream(self.dev)
+                    self._opt_stream = ops.concurrent_stream(self.dev, role="adam")
                 self._opt_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._opt_stream):
                     run()

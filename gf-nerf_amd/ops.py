@@ -1314,8 +1314,14 @@ def copy_list(pairs):
     _lib.check(_lib.lib().gfn_copy_list(src, dst, nb, n, _stream()), "gfn_copy_list")
 
 
-def concurrent_stream(device=None):
-    """A new stream that demonstrably runs BESIDE the current one.  HIP maps streams onto a few hardware queues in creation order, so whether a new
+_SIDE_STREAMS = {}  # (device index, role) -> the probed stream of that role
+
+
+def concurrent_stream(device=None, role=None):
+    """A stream that demonstrably runs BESIDE the current one.  role (a name: "sampler", "aux", "adam", "comm", "draws" ...): ONE stream per
+    device and role for the whole process, probed once and handed out again afterwards -- torch takes its streams from a round-robin pool of 32 per
+    device, so engines that each made their own would soon be handed streams already in use by another role (safe, but the overlap the probe is for
+    would be lost silently): a candidate whose handle another role already holds is skipped.  role None: a fresh probed stream every call.  HIP maps streams onto a few hardware queues in creation order, so whether a new
     stream shares its queue with the stream the step is launched on -- and then runs behind it, not beside it -- depends on how many streams the
     process made before (round 4: the plugin surface's focal iteration took 1.81 or 1.55 ms depending on whether bench.py had rendered first; with
     this probe 1.55 either way).  Up to 8 candidates, each probed once: a ~2.5 ms spin on the current stream, a tiny kernel on the candidate -- does
@@ -1325,14 +1331,20 @@ def concurrent_stream(device=None):
     import time
 
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    if role is not None and key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
     if os.environ.get("GFN_SIDE_STREAM_PROBE", "1") != "1" or torch.cuda.is_current_stream_capturing():
-        return torch.cuda.Stream(device=device)
+        return torch.cuda.Stream(device=device)  # (not remembered: made without a probe)
     main = torch.cuda.current_stream(device)
+    taken = {s.cuda_stream for (d, _), s in _SIDE_STREAMS.items() if d == key[0]} | {main.cuda_stream}
     probe = torch.zeros(64, dtype=torch.float32, device=device)
     kept = []  # (candidates that share the queue stay allocated until one is found: a fresh one would land on the same queue again)
     for _ in range(8):
         cand = torch.cuda.Stream(device=device)
         kept.append(cand)
+        if cand.cuda_stream in taken:  # the pool has wrapped onto a stream in use
+            continue
         torch.cuda.synchronize(device)
         done, spun = torch.cuda.Event(), torch.cuda.Event()
         torch.cuda._sleep(6_000_000)
@@ -1348,8 +1360,14 @@ def concurrent_stream(device=None):
                 break
         torch.cuda.synchronize(device)
         if beside:
+            if role is not None:
+                _SIDE_STREAMS[key] = cand
             return cand
-    return kept[0]
+    free = [c for c in kept if c.cuda_stream not in taken]
+    cand = free[0] if free else kept[0]
+    if role is not None:
+        _SIDE_STREAMS[key] = cand
+    return cand
 
 
 def fill_zero(t):

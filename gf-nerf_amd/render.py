@@ -18,19 +18,24 @@ import torch
 from . import ops
 
 
-def choose_tile(height, width, target_rays=524288, patch=(8, 4)):
+MAX_TILE_RAYS = (1 << 31) // 1024 - 32  # the sampler indexes n_rays * max_hits (1024) in 32 bits
+
+
+def choose_tile(height, width, target_rays=524288, patch=(8, 4), max_rays=MAX_TILE_RAYS):
     """-> (tile_width, tile_height): a block of pixels that divides the frame exactly (no ragged border tiles), holds whole
     patches, and is close to target_rays and to square (score: |log(rays / target)| + 0.1 |log(width / height)|).  Border tiles padded to full
     size cost a 1920 x 1080 frame 21 % with 512 x 256 tiles.  512 Ki rays: every tile ends with the tail of its march and a hand-over between
     the two branches, and a tile of 400 Ki - 700 Ki rays spreads that over four times the work of the 128 Ki-ray tile rounds 2 - 4 used (full HD:
     960 x 540, 38.6 against 39.9 ms/Mpix; 1920 x 216 / 1920 x 360 / 640 x 1080: 38.1 / 38.1 / 38.4; the record form of the samples costs
-    32 KB per ray and buffer: 17 GB each here)."""
+    32 KB per ray and buffer: 17 GB each here).  max_rays: no tile above it (the sampler's 32-bit indexing; the caller's memory cap):
+    a frame with few divisors (2008 x 1052: 8 x 263) would otherwise get ONE tile of 2.1 M rays."""
     best = None
+    target_rays = min(target_rays, max_rays)
     for tw in range(patch[0], width + 1, patch[0]):
         if width % tw:
             continue
         for th in range(patch[1], height + 1, patch[1]):
-            if height % th:
+            if height % th or tw * th > max_rays:
                 continue
             key = abs(math.log(tw * th / target_rays)) + 0.1 * abs(math.log(tw / th))
             if best is None or key < best[0]:
@@ -47,6 +52,7 @@ def frame_shard(n_frames, world_size, rank):
 
 class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
+    BYTES_PER_RAY = 1024 * 32 + 6144  # record form: 1024 sample slots of 32 bytes + the traversal's hit lists
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
                  pipeline=None, decoder_cus=224):
@@ -72,7 +78,11 @@ class TileRenderer:
         """Tile shape, tiles per replay and the static input buffers for images of this size."""
         tile_rays, tile_width, pipeline = self._want
         if tile_rays is None:
-            tw, th = choose_tile(height, width)
+            # the record form costs 32 KB per ray and ring buffer + 6 KB of hit lists: a tile may take a quarter of what is free now
+            # (two ring buffers, and the eager warm-ups' cached blocks beside the graph's private pool)
+            free = torch.cuda.mem_get_info(self.hp.dev)[0] if self.hp.dev.type == "cuda" else 1 << 40
+            cap = max(int(free // 4 // self.BYTES_PER_RAY) // 32 * 32, 8192)
+            tw, th = choose_tile(height, width, max_rays=min(cap, MAX_TILE_RAYS))
             T = tw * th
         else:
             T = int(tile_rays)
@@ -91,6 +101,11 @@ class TileRenderer:
         # neighbouring rays cross the same table cells: gfn_fused_render walks patches of them in lockstep (tile_width passed
         # on); the wave-per-ray fused forward keeps each eighth of a small tile (a strip of rows) on one XCD's L2
         self.patch_tw = tw if T >= self.PATCH_MIN_RAYS else None
+        # the samples' form follows the kernel that will read them (ONE predicate, HotPath.uses_patch_kernel: render_patch_width = 0,
+        # an exact-f32 decoder or a tile that does not hold whole patches fall back to the wave-per-ray kernel on PACKED samples)
+        self.record = self.patch_tw is not None and self.hp.uses_patch_kernel(T, self.patch_tw, self.block)
+        if not self.record:
+            self.patch_tw = None
         self.noise = torch.full((ops.MAX_SAMPLE_PER_RAY + T + 10,), self.fineness, dtype=torch.float32, device=dev)
         self.P = P if self.use_graph else 1
         self.o = torch.zeros((self.P, T, 3), dtype=torch.float32, device=dev)
@@ -124,7 +139,7 @@ class TileRenderer:
                         side.wait_event(used[i - self.SLOTS])
                     # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
                     samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
-                                             record=self.patch_tw is not None))
+                                             record=self.record))
                     ev = torch.cuda.Event()
                     ev.record(side)
                     done.append(ev)

@@ -77,6 +77,7 @@ class StepGraph:
         self.replan_every, self._since_capture, self.phased = int(replan_every), 0, None
         self._k_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()  # the plan's K as the replays leave it (copied inside the graph)
         self._idle = 0
+        self._lm_captured = None  # global stage: did the captured forward take the level-major kernels (HotPath.level_major_global_now)?
         self.captures = 0  # how often the step was captured (the first time, tree changes, re-plans of the phases)
 
     # ------------------------------------------------------------------ set-up
@@ -160,6 +161,7 @@ class StepGraph:
                     self.phased = int(hp._phase.k.item()) < 1024
                     hp.phase_override = None if self.phased else False
             self._since_capture, self._idle = 0, 0
+            self._lm_captured = hp.level_major_global_now(self.update_oct) if self.stage == hp_mod.STAGE_GLOBAL else None
             self._k_host.fill_(-1)
             hp._join_aux()  # (a branch left open by an eager forward must not be joined under capture)
             torch.cuda.synchronize()
@@ -273,6 +275,8 @@ class StepGraph:
         # would cost a full synchronisation and capture for the same graph)
         if self.phased is not None and hp.cfg.two_phase and hp.cfg.early_T > 0 and (self._since_capture > self.replan_every or self._idle >= 16):
             self.invalidate()  # plan the phases (and choose the forward kernels) again: the scene has moved on
+        if self.stage == hp_mod.STAGE_GLOBAL and self._lm_captured is not None and hp.level_major_global_now(self.update_oct) != self._lm_captured:
+            self.invalidate()  # the step crossed cfg.level_major_global_after: the capture has the fused forward baked in
         if self.G[0] is None or self._tree != (hp.nodes.data_ptr(), hp.n_nodes):
             self.capture()
         # one launch in front of every replay (not four memcpy nodes and a host-to-device copy): the batch and Adam's factors

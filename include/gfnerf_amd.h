@@ -368,6 +368,10 @@ int gfn_set_decoder_cus(int n_cus);
  * rne(dz * (1 - u_q)), u_q a fixed hash of q in +-2^-11, so that neighbouring samples' rounding errors are independent
  * (csrc/x3_device.h).  on = 0 switches the dither off (plain rounding).  Returns the previous value.  Process-wide; default on. */
 int gfn_set_plane_dither(int on);
+/* Lanes per ray of gfn_sample_rays' march: 16 (a row per ray: batches that leave the machine empty) or 4 (a quad: a quarter of the
+ * vector work per ray), 0 = by batch size (a quad from 32 Ki rays on).  Both give the same bits (tests run both on the same rays).
+ * Starts at GFN_MARCH_LANES from the environment, read once.  Returns the previous value.  Process-wide. */
+int gfn_set_march_lanes(int lanes);
 
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]

@@ -193,7 +193,7 @@ def test_choose_tile_divides_the_frame():
 
     src = open(os.path.join(ROOT, "gf-nerf_amd", "render.py")).read()
     ns = {}
-    exec("import math\n" + src[src.index("def choose_tile"):src.index("def frame_shard")], ns)  # the module itself imports the HIP library
+    exec("import math\n" + src[src.index("MAX_TILE_RAYS ="):src.index("def frame_shard")], ns)  # the module itself imports the HIP library
     choose = ns["choose_tile"]
     for (h, w) in ((1080, 1920), (864, 1152), (2160, 3840), (64, 128), (720, 1280), (480, 640)):
         tw, th = choose(h, w)
@@ -201,6 +201,12 @@ def test_choose_tile_divides_the_frame():
         assert tw * th <= max(h * w, 1) and (tw * th >= 0.4 * min(524288, h * w))
     assert choose(1080, 1920) == (960, 540) and choose(1080, 1920, target_rays=131072) == (384, 360)
     assert choose(1080, 1917)[0] == 128  # no width divides 1917 into multiples of 8: fixed-width tiles with ragged borders
+    # a frame with few divisors must not become ONE tile beyond the sampler's 32-bit indexing (n_rays * 1024 < 2^31), and a caller's
+    # memory cap is respected
+    tw, th = choose(1052, 2008)
+    assert tw * th <= ns["MAX_TILE_RAYS"] and 2008 % tw == 0 and 1052 % th == 0, (tw, th)
+    tw, th = choose(1080, 1920, max_rays=150000)
+    assert tw * th <= 150000 and 1920 % tw == 0 and 1080 % th == 0
 
 
 def test_bench_line_stays_under_two_thousand_characters():

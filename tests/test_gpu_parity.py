@@ -33,6 +33,22 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def set_march_lanes():
+    """gfn_set_march_lanes for one test (the library's process-wide setting is put back afterwards)."""
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import _lib
+
+    before = []
+
+    def _set(lanes):
+        before.append(_lib.lib().gfn_set_march_lanes(int(lanes)))
+
+    yield _set
+    if before:
+        _lib.lib().gfn_set_march_lanes(before[0])
+
+
 def _t(a, dev):
     import torch
 
@@ -271,16 +287,16 @@ def test_march_bit_exact(oracle, ops, dev, train, fineness):
 
 @pytest.mark.parametrize("lanes,with_rec", [(16, True), (16, False), (4, True), (4, False)])
 @pytest.mark.parametrize("train,fineness,n_rays", [(True, 6.0, 333), (False, 0.5, 70), (False, 16.0, 4)])
-def test_fast_sampler_bit_exact(oracle, ops, dev, monkeypatch, train, fineness, n_rays, lanes, with_rec):
+def test_fast_sampler_bit_exact(oracle, ops, dev, set_march_lanes, train, fineness, n_rays, lanes, with_rec):
     """gfn_sample_rays (compact nodes, one-pass dense trace, a group of lanes per ray with DPP reductions) produces the same bits as
     the oracle -- and therefore as the gfn_trace + gfn_march boundary functions -- in each of its forms: a 16-lane row per ray (what
-    batches below 32 Ki rays get) or a quad of lanes (render tiles), GFN_MARCH_LANES forcing either on these rays; the counting march
+    batches below 32 Ki rays get) or a quad of lanes (render tiles), gfn_set_march_lanes forcing either on these rays; the counting march
     recording (t, dist, leaf, warped point) for the sample-parallel fill, or, without the record buffer, a second march writing the samples."""
     import torch
 
     from gfnerf_amd import scene
 
-    monkeypatch.setenv("GFN_MARCH_LANES", str(lanes))
+    set_march_lanes(lanes)
     sc, ref, gpu = _sample_both(oracle, ops, dev, n_rays=n_rays, train=train, fineness=fineness)
     m = ref["m"]
     noise = scene.make_noise(n_rays, train, fineness, seed=1)
@@ -308,7 +324,7 @@ def test_fast_sampler_bit_exact(oracle, ops, dev, monkeypatch, train, fineness, 
 
 
 @pytest.mark.parametrize("lanes", [16, 4])
-def test_sample_record_holds_the_packed_samples(oracle, ops, dev, monkeypatch, lanes):
+def test_sample_record_holds_the_packed_samples(oracle, ops, dev, set_march_lanes, lanes):
     """gfn_sample_rays_record (traversal + counting march only; what the inference kernel reads, gfn_fused_render_rec): slot k of ray r of
     march_rec is sample pts_offsets[r] + k of gfn_sample_rays, field by field and bit for bit -- {t, dist, leaf, transform, warped point
     (before the table-space map), block} -- and counts / first_oct_dis are the packed form's; slots beyond a ray's count are never read."""
@@ -316,7 +332,7 @@ def test_sample_record_holds_the_packed_samples(oracle, ops, dev, monkeypatch, l
 
     from gfnerf_amd import scene
 
-    monkeypatch.setenv("GFN_MARCH_LANES", str(lanes))
+    set_march_lanes(lanes)
     n_rays = 160
     sc, ref, _ = _sample_both(oracle, ops, dev, n_rays=n_rays, train=True, fineness=6.0)
     noise = _t(scene.make_noise(n_rays, True, 6.0, seed=1), dev)
