@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgfn_oracle.so")
+_LIB_PATH = os.environ.get("GFN_ORACLE_LIB") or os.path.join(_HERE, "libgfn_oracle.so")  # (GFN_ORACLE_LIB: the sanitizer build, tests/test_sanitizers.py)
 
 TREE_NODE_DTYPE = np.dtype(
     {

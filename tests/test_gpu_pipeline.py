@@ -777,6 +777,42 @@ def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_wi
     assert odd["field"] is not None
 
 
+@pytest.mark.parametrize("variant", ["patch_width_0", "f32_decoder", "unfused_forward"])
+def test_tile_pipeline_without_the_patch_kernel(setup, variant):
+    """the pipelined TileRenderer (several tiles per replay, tiles of >= 32 Ki rays) sampled in the record form whenever the
+    tile was large enough for the patch kernel -- also for configurations HotPath.render does not send there (render_patch_width = 0,
+    the exact-f32 decoder, fused_forward off), which then failed on the first multi-tile frame.  Now the sample form follows
+    HotPath.uses_patch_kernel: those configurations render the same image through the wave-per-ray kernel on packed samples."""
+    import dataclasses
+
+    import torch
+
+    from gfnerf_amd import hotpath
+    from gfnerf_amd import render as rmod
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    c2w = t(sc["c2w"])
+    K = sc["intri"]
+    intr = t(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32))
+    H, W = 256, 256  # two tiles of 128 x 256 = 32,768 rays in one replay
+    intr2 = intr.clone(); intr2[:, 2] = W / 2; intr2[:, 3] = H / 2; intr2[:, 0] *= 0.25; intr2[:, 1] *= 0.25
+    over = dict(patch_width_0=dict(render_patch_width=0), f32_decoder=dict(mlp_precision="f32"), unfused_forward=dict(fused_forward=False))[variant]
+    imgs = {}
+    for name, kw in (("default", {}), (variant, over)):
+        cfg = dataclasses.replace(S["cfg"], **kw)
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
+        hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3); hp.refresh_shadows()
+        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=2)
+        assert tr.T == 32768 and tr.P == 2 and tr.record == (name == "default") and (tr.patch_tw is not None) == (name == "default")
+        imgs[name] = tr.render_camera(3, H, W)["rgb"]
+        del tr, hp
+        torch.cuda.empty_cache()
+    assert float(imgs["default"].std()) > 0.01
+    tol = 1e-3 if variant == "f32_decoder" else 2e-5
+    np.testing.assert_allclose(imgs[variant].cpu().numpy(), imgs["default"].cpu().numpy(), atol=tol)
+
+
 def test_step_graph_replays_without_host_sync_use_each_steps_own_adam_factors(setup):
     """StepGraph replays enqueued back to back, the host several steps ahead of the device (nothing is read back in between): Adam's
     step-dependent factors -- they travel through a ring of pinned blocks, one per replay -- must still be those of the step being
