@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--psnr-steps", type=str, default="3000,1000",
                     help="`psnr` and `trained_state` sub-records (N = 1): global,focal training steps on the procedural scene per run "
                          "(gfnerf_amd.procedural.STUDY_STEPS); 0,0 = skip")
+    ap.add_argument("--rays8192-steps", type=int, default=100,
+                    help="timed steps of the `rays8192` sub-records (the reference's default batch, gfnerf/config.py:75: focal and global step on 8192 rays, N = 1); 0 = skip")
     ap.add_argument("--plugin-steps", type=int, default=100,
                     help="timed iterations of the `plugin_step` sub-records (the step through GFNerfPipeline + Optimizers, N = 1 only); 0 = skip")
     ap.add_argument("--inject-divergence", action="store_true",
@@ -390,7 +392,9 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     roof = None
     if world == 1 and mine:
         roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
+    fp = tr.footprint_bytes()
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
+                hbm_footprint_gb=None if fp is None else fp / 1e9,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,
                 kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep, samples read from the counting march's records" % (args.render_patch_width, 32 // args.render_patch_width)
@@ -477,21 +481,49 @@ def batch_assembly_bench(sc, torch, iters=50, n_images=64, H=864, W=1152):
                 includes="index draw, pixel gather, ray generation, error-map write-back + CDF upkeep", duplicates_left=int(sampler.last_status[1].item()))
 
 
-def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True, graph_forward=True):
+def procedural_image_stack(sc, torch, image_idx, H, W, chunk=1 << 17):
+    """Renderings [n,H,W,3] u8 of the procedural terrain (gfnerf_amd.procedural, the PSNR study's ground truth) from the cameras `image_idx` of the
+    capture at H x W pixels, through the datamanager's own ray generator (pixel centres as the pipeline will draw them) -> (images, intrinsics [n_cams,3,3])."""
+    from gfnerf_amd import data, procedural
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    K = np.array(sc["intri"], np.float32, copy=True)
+    K[:, 0, :] *= W / 1152.0
+    K[:, 1, :] *= H / 864.0
+    intr = torch.from_numpy(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32)).to(dev)
+    rg = data.RayGenerator(torch.from_numpy(np.ascontiguousarray(sc["c2w"])).to(dev), intr)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    images = torch.empty((len(image_idx), H, W, 3), dtype=torch.uint8, device=dev)
+    for k, cam in enumerate(image_idx):
+        idx = torch.stack([torch.full_like(yy, int(cam)), yy, xx], -1).reshape(-1, 3)
+        out = images[k].view(-1, 3)
+        for a in range(0, H * W, chunk):
+            r = rg(idx[a:a + chunk])
+            out[a:a + chunk] = (procedural.gt_colors(r["origins"], r["directions"], procedural.STUDY_DETAIL).clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
+    return images, K
+
+
+def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True, graph_forward=True, trained=None):
     """The training iteration THROUGH the plugin surface, the way the reference's Trainer drives it (engine/trainer.py:195-231,
     382-441): callbacks before -> optimizers.zero_grad_all -> pipeline.get_train_loss_dict(step) (incl. datamanager.next_train)
     -> sum(loss_dict) -> backward -> the NaN check over model.named_parameters() -> optimizers.optimizer_step_all ->
     scheduler_step_all -> callbacks after; rays/s = rays per batch / iteration wall time (trainer.py:225-231).
     The pipeline, model, field, sampler, optimizers, scheduler and callbacks are the mirror classes of gfnerf_amd.gfnerf with
     the `gf-nerf` method config's values (gfnerf/config.py) on the bench scene; the datamanager is the HBM-resident synthetic
-    one (image loading is out of scope).  stage "global": steps 100.., 4096 x 128; "focal": steps 30100.., 4096 x 192, block 0."""
+    one (image loading is out of scope).  stage "global": steps 100.., 4096 x 128; "focal": steps 30100.., 4096 x 192, block 0.
+    trained = (steps_global, steps_focal) (stage "focal"): the image stack holds renderings of the procedural terrain (the PSNR
+    study's ground truth) instead of noise, the schedule is the study's (steps_global global iterations, then block 0's period), and the pipeline
+    TRAINS through this very surface from step 0 -- stage switch, camera clustering, octree upkeep and all -- before the last `steps` iterations of
+    block 0's period are timed: the reference's own definition of rays/s (trainer.py:225-231) on a trained scene."""
     from gfnerf_amd.gfnerf._host import AdamOptimizerConfig, Optimizers, TrainingCallbackAttributes, TrainingCallbackLocation
     from gfnerf_amd.gfnerf.gf_pipeline import GFNerfPipelineConfig, HbmDataManagerConfig
     from gfnerf_amd.gfnerf.nerfacto import GFNeRFModelConfig
     from gfnerf_amd.gfnerf.optim import GfnAdamOptimizerConfig
     from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
 
-    S_INIT, S_SPLIT, N_SPLIT = 30000, 10000, 4
+    S_INIT, S_SPLIT, N_SPLIT = (30000, 10000, 4) if trained is None else (int(trained[0]), int(trained[1]), 4)
+    if trained is not None and (stage != "focal" or S_SPLIT < steps + 100):
+        raise ValueError("plugin_step_bench(trained=...): the focal stage, with a block period longer than the timed window")
     mk = dict(log2_hashmap_size=21, hidden_dim=128, hidden_dim_color=128, steps_perssampler_init=S_INIT, steps_per_split_dataset=S_SPLIT,
               n_split_dataset=N_SPLIT, n_blocks=N_SPLIT, scale_factor=10.0, use_appearance_embedding=True, use_ch_loss=True, s3im_loss_mult=1.0,
               eval_num_rays_per_chunk=2048)
@@ -500,9 +532,12 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     # rays on the device (gfnerf_amd.data)
     n_img = 64
     gen = torch.Generator(device="cuda").manual_seed(11)
-    images = torch.randint(0, 256, (n_img, 864, 1152, 3), dtype=torch.uint8, device="cuda", generator=gen)
     image_idx = (np.arange(n_img) * (sc["c2w"].shape[0] // n_img)).astype(np.int32)
-    pcfg = GFNerfPipelineConfig(datamanager=HbmDataManagerConfig(c2w=sc["c2w"], intrinsics=sc["intri"], images=images, image_idx=image_idx,
+    if trained is None:
+        images, intri = torch.randint(0, 256, (n_img, 864, 1152, 3), dtype=torch.uint8, device="cuda", generator=gen), sc["intri"]
+    else:
+        images, intri = procedural_image_stack(sc, torch, image_idx, 432, 576)
+    pcfg = GFNerfPipelineConfig(datamanager=HbmDataManagerConfig(c2w=sc["c2w"], intrinsics=intri, images=images, image_idx=image_idx,
                                                                  train_num_rays_per_batch=n_rays),
                                 model=GFNeRFModelConfig(**mk), prefetch_next_batch=prefetch)
     pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfn_plugin_bench"))
@@ -515,21 +550,26 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
     pipe.train()
     nat = model.persampler.sampler
-    first = 100 if stage == "global" else S_INIT + 100
-    target = TARGET_SAMPLES[stage]
-    # the ray-march fineness that gives the stage's sample budget on this scene, held for the run (UpdateRayMarch follows the step:
-    # 16 -> 1 over the first 10,000 steps, PersSampler.cpp:958-967); tree maintenance (ProcOctree every 1000 steps) outside the window
-    rb = pipe.datamanager.next_train(first)[0]
-    lo, hi = 0.5, 64.0
-    for _ in range(14):
-        f = (lo * hi) ** 0.5
-        nat.ray_march_fineness_ = f
-        mean = nat.sample_packed(rb.origins, rb.directions, table_space=True, want_world=False)["pts_offsets"][-1].item() / n_rays
-        if abs(mean - target) / target < 0.005:
-            break
-        lo, hi = (f, hi) if mean > target else (lo, f)
-    nat.UpdateRayMarch = lambda cur_step, _f=f: setattr(nat, "ray_march_fineness_", _f)
-    nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []
+    first = (100 if stage == "global" else S_INIT + 100) if trained is None else 0
+
+    def pin_fineness(step, target):
+        """The ray-march fineness that gives `target` samples per ray on the tree as it is now, held from here on (UpdateRayMarch follows the
+        step: 16 -> 1 over the first 10,000 steps, PersSampler.cpp:958-967)."""
+        rb = pipe.datamanager.next_train(step)[0]
+        lo, hi = 0.5, 64.0
+        for _ in range(14):
+            f = (lo * hi) ** 0.5
+            nat.ray_march_fineness_ = f
+            mean = nat.sample_packed(rb.origins, rb.directions, table_space=True, want_world=False)["pts_offsets"][-1].item() / n_rays
+            if abs(mean - target) / target < 0.005:
+                break
+            lo, hi = (f, hi) if mean > target else (lo, f)
+        nat.UpdateRayMarch = lambda cur_step, _f=f: setattr(nat, "ray_march_fineness_", _f)
+        return mean
+
+    mean = pin_fineness(first, TARGET_SAMPLES[stage if trained is None else "global"])
+    if trained is None:
+        nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []  # tree maintenance (ProcOctree every 1000 steps) outside the window
 
     def train_iteration(step):
         for cb in callbacks:
@@ -551,8 +591,26 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
         return loss
 
     step = first
-    for _ in range(warmup):
-        train_iteration(step); step += 1
+    trained_info = None
+    if trained is not None:
+        # the whole run through the plugin surface: the global stage, the stage switch (camera clusters, block 0's table), block 0's period up to the
+        # timed window.  Fineness re-pinned to the stage's sample budget where the tree or the stage changes; ProcOctree at its own cadence
+        t_train = time.perf_counter()
+        last = S_INIT + S_SPLIT - steps - 8
+        while step < last:
+            if step in (S_INIT // 3, 2 * S_INIT // 3):
+                pin_fineness(step, TARGET_SAMPLES["global"])  # (the tree has been pruned: hold 128 samples per ray)
+            if step == S_INIT + 1 or step == last - warmup:
+                mean = pin_fineness(step, TARGET_SAMPLES["focal"])
+            if step == last - warmup:
+                nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []  # no tree maintenance inside the timed window
+            loss = train_iteration(step); step += 1
+        torch.cuda.synchronize()
+        trained_info = dict(train_steps=[S_INIT, step - S_INIT], train_seconds=time.perf_counter() - t_train, image_stack="64 renderings of the procedural terrain, 576 x 432",
+                            loss_before_window=float(loss.detach()))
+    else:
+        for _ in range(warmup):
+            train_iteration(step); step += 1
     torch.cuda.synchronize()
     prof = None
     if os.environ.get("GFN_PLUGIN_PROFILE"):  # where the host spends the iteration (tools/README.md)
@@ -575,7 +633,7 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     return dict(metric="train_rays_per_sec", value=n_rays / dt, unit="rays/s", ms_per_step=dt * 1e3, host_ms_per_step=host / steps * 1e3, steps=steps,
                 warmup=warmup, stage=stage, mean_samples_per_ray=mean, loss=float(loss.detach()),
                 optimizer="GfnAdam (HIP Adam kernels on the engine's gradient buffers)" if fused_optimizer else "torch.optim.Adam on dense f32 gradients",
-                prefetch_next_batch=prefetch, nan_check=nan_check,
+                prefetch_next_batch=prefetch, nan_check=nan_check, trained=trained_info, forward=getattr(model.hot, "last_forward", None),
                 surface="GFNerfPipeline.get_train_loss_dict -> backward -> Optimizers.optimizer_step_all -> scheduler_step_all (trainer.py:382-441)")
 
 
@@ -596,7 +654,30 @@ def psnr_study_record(steps_global, steps_focal):
         return {}
 
 
-def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_focal):
+def rays8192_records(sc, args, torch, sync, steps=100):
+    """The reference's DEFAULT batch -- train_num_rays_per_batch = 8192 (gfnerf/config.py:75) -- where the contract's headline is quoted on 4096 rays
+    (BASELINE configs[1], configs[2]): the same two steps, random-init engines, twice the rays.  The lookup's passes and the launch sequence do not
+    grow with the batch, so the plugin's default runs at a better rays/s than the contract batch (VERDICT r04 #4): a sub-record, not the headline."""
+    import copy
+
+    a2 = copy.copy(args)
+    a2.record_capacity = max(args.record_capacity, 1 << 28)  # (twice the records per stream: keep the streams from overflowing into atomics)
+    out = dict(rays_per_batch=8192, source="gfnerf/config.py:75 train_num_rays_per_batch")
+    for stage, n_blocks, warm in (("focal", 4, 5), ("global", 0, 60)):
+        run = StageRun(a2, stage, sc, 1, 0, sync, torch, n_blocks=n_blocks, n_rays=8192)
+        res = run.run(steps, warm)
+        roof, n_live, n_eval = run.roofline(res)
+        ms = res["elapsed"] / steps * 1e3
+        out[stage] = dict(ms_per_step=ms, rays_per_sec=8192 / (ms * 1e-3), mean_samples_per_ray=n_live / 8192, evaluated_sample_frac=n_eval / max(n_live, 1),
+                          launch=run.launch, kernel_ms=roof["kernel_ms"], roofline_frac=roof["frac"], steps=steps, warmup=warm)
+        del run, res
+        torch.cuda.empty_cache()
+    out.update(value=out["focal"]["rays_per_sec"], ms_per_step=out["focal"]["ms_per_step"], global_rays_per_sec=out["global"]["rays_per_sec"],
+               global_ms_per_step=out["global"]["ms_per_step"], metric="train_rays_per_sec", unit="rays/s")
+    return out
+
+
+def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_focal, render_cams=None):
     """The headline step (and the global-stage step) timed on TRAINED engines: gfnerf_amd.procedural trains the global stage on the procedural terrain
     (the PSNR study's scene and schedule), the global step is timed there (learning rate held at the schedule's end), then four focal blocks train in
     rotation and the focal step is timed -- same StageRun / StepGraph / roofline code as the random-init records, batches = rays of the capture with
@@ -641,6 +722,15 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
         hp.cfg.lr_block = hp.cfg.lr_block * procedural.STUDY_LR_FINAL  # the schedule's end
         rec["focal"] = timed(hp, "focal", sd)
         rec.update(psnr_global=r["psnr_global"], psnr=r["psnr"], leaves_pruned=r["leaves_pruned"], train_steps=[steps_global, steps_focal])
+        if render_cams and "render" not in [k for x in recs for k in x]:  # the first seed's trained engine renders the headline record's frames
+            try:
+                rr = render_bench(hp, sc, args, rec["focal"]["fineness"], torch, render_cams, 0)
+                rec["render"] = {k: rr[k] for k in ("value", "unit", "frames", "ms_per_frame", "tile_rays", "tiles_per_replay", "mean_accumulation", "fineness", "hbm_footprint_gb") if k in rr}
+                if rr.get("roofline"):
+                    rec["render"].update(evaluated_frac=rr["roofline"]["evaluated_frac"], samples_per_ray=rr["roofline"]["sampled_per_frame"] / (1080 * 1920),
+                                         evaluated_samples_per_frame=rr["roofline"]["evaluated_samples_per_frame"])
+            except Exception as e:  # noqa: BLE001
+                rec["render"] = dict(error=f"{type(e).__name__}: {e}")
         recs.append(rec)
         del hp, r
         torch.cuda.empty_cache()
@@ -648,7 +738,9 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
               f"{rec['focal']['evaluated_sample_frac']:.2f}), global {rec['global']['ms_per_step']:.3f} ms", file=sys.stderr)
     slow = max(recs, key=lambda x: x["focal"]["ms_per_step"])
     slow_g = max(recs, key=lambda x: x["global"]["ms_per_step"])
+    rend = next((x["render"] for x in recs if "render" in x and "error" not in x["render"]), {})
     return dict(metric="train_rays_per_sec", unit="rays/s", value=slow["focal"]["rays_per_sec"], ms_per_step=slow["focal"]["ms_per_step"], seed=slow["seed"],
+                render_ms_per_mpix=rend.get("value"), render_evaluated_frac=rend.get("evaluated_frac"), render_samples_per_ray=rend.get("samples_per_ray"),
                 alive_sample_frac=slow["focal"]["alive_sample_frac"], evaluated_sample_frac=slow["focal"]["evaluated_sample_frac"],
                 two_phase_K=(slow["focal"]["two_phase"] or {}).get("K"), roofline_frac=slow["focal"]["roofline"]["frac"],
                 global_ms_per_step=slow_g["global"]["ms_per_step"], global_rays_per_sec=slow_g["global"]["rays_per_sec"],
@@ -661,13 +753,14 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
 class StageRun:
     """K timed training steps of one stage on this rank (the same code for the headline and the `global_stage` sub-record)."""
 
-    def __init__(self, args, stage, sc, world, rank, sync, torch, cams=None, n_blocks=0, block_seed=0, engine=None):
+    def __init__(self, args, stage, sc, world, rank, sync, torch, cams=None, n_blocks=0, block_seed=0, engine=None, n_rays=None):
         """engine: dict(hp=HotPath, batches=[(o, d, cam, gt) device tensors] x 4) -- time the steps on an engine that exists already (the
         `trained_state` sub-records: tables, decoder, embedding and pruned octree as gfnerf_amd.procedural left them) instead of a fresh
         random-init one."""
         from gfnerf_amd import hotpath, ops, scene
 
         self.args, self.stage, self.world, self.rank, self.torch, self.scene = args, stage, world, rank, torch, scene
+        self.R = int(n_rays or N_RAYS)  # rays per batch (the contract's 4096; the `rays8192` sub-records: the reference's default, gfnerf/config.py:75)
         self.ops = ops
         self.trained = engine is not None
         if engine is not None:
@@ -707,8 +800,8 @@ class StageRun:
         # batches resident in HBM before the timed region (4 rotated batches per rank); cams = this rank's camera cluster
         self.batches_np, self.batches = [], []
         for k in range(4):
-            o, d, cam = scene.make_rays(sc["c2w"], N_RAYS, seed=1000 * rank + k + (0 if stage == "focal" else 500), cams=cams)
-            gt = np.random.default_rng(7 + k).random((N_RAYS, 3)).astype(np.float32)
+            o, d, cam = scene.make_rays(sc["c2w"], self.R, seed=1000 * rank + k + (0 if stage == "focal" else 500), cams=cams)
+            gt = np.random.default_rng(7 + k).random((self.R, 3)).astype(np.float32)
             self.batches_np.append((o, d, cam, gt))
             self.batches.append(tuple(torch.from_numpy(a).cuda() for a in (o, d, cam, gt)))
         self.target = TARGET_SAMPLES[stage]
@@ -730,8 +823,8 @@ class StageRun:
         torch, hp = self.torch, self.hp
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self.draw_stream):
-            nz = self.ops.sampler_noise(N_RAYS, self.fineness, train=True, device="cuda")
-            s3 = self.ops.s3im_index(N_RAYS, self.cfg.s3im_repeat_time, device="cuda")
+            nz = self.ops.sampler_noise(self.R, self.fineness, train=True, device="cuda")
+            s3 = self.ops.s3im_index(self.R, self.cfg.s3im_repeat_time, device="cuda")
         for t_ in (nz, s3):
             t_.record_stream(main)
             if hp._side is not None:
@@ -758,8 +851,8 @@ class StageRun:
     def run_graph_experiment(self, steps, warmup, mode):
         torch, hp = self.torch, self.hp
         o, d, cam, gt = self.batches[0]
-        noise = self.ops.sampler_noise(N_RAYS, self.fineness, train=True, device="cuda")
-        s3 = self.ops.s3im_index(N_RAYS, self.cfg.s3im_repeat_time, device="cuda")
+        noise = self.ops.sampler_noise(self.R, self.fineness, train=True, device="cuda")
+        s3 = self.ops.s3im_index(self.R, self.cfg.s3im_repeat_time, device="cuda")
         block = 0 if self.stage == "focal" else None
 
         def one():
@@ -803,7 +896,7 @@ class StageRun:
         try:
             hp._drop_stale_samples()  # the last eager step prefetched a sample nobody will collect
             blocks = list(range(self.n_blocks)) if self.stage == "focal" else None
-            sg = stepgraph.StepGraph(hp, self.stage, N_RAYS, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update,
+            sg = stepgraph.StepGraph(hp, self.stage, self.R, self.fineness, block=blocks, update_oct=self.stage == "global" and not args.no_oct_update,
                                      draws_after_lookup=not args.draws_first,
                                      segmented=True if (args.segmented and self.stage == "global") else None)
             o, d, _, _ = self.batches[self.i % 4]
@@ -1021,12 +1114,15 @@ def compact_line(out):
             cfg["render_mfma_busy_frac"] = _r(rr["mfma_busy_frac"])
     hoist("plugin_step_focal", (("ms_per_step", "plugin_ms_per_step"),))
     hoist("plugin_step_global", (("ms_per_step", "plugin_global_ms_per_step"),))
+    hoist("plugin_step_trained", (("ms_per_step", "plugin_trained_ms_per_step"),))
+    hoist("rays8192", (("value", "rays8192_rays_per_sec"), ("global_rays_per_sec", "rays8192_global_rays_per_sec")))
     hoist("batch_assembly", (("ms_per_batch", "batch_assembly_ms"),))
     hoist("psnr", (("psnr_fast", "psnr"), ("psnr_reference", "psnr_reference"), ("delta", "psnr_delta"), ("se", "psnr_se"), ("n_seeds", "psnr_n_seeds"),
                    ("decoder_delta", "psnr_decoder_delta"), ("study_delta", "psnr_study_delta"), ("study_se", "psnr_study_se"), ("study_n_seeds", "psnr_study_n_seeds")))
     hoist("trained_state", (("value", "trained_rays_per_sec"), ("ms_per_step", "trained_ms_per_step"), ("alive_sample_frac", "trained_alive_sample_frac"),
                             ("evaluated_sample_frac", "trained_evaluated_sample_frac"), ("two_phase_K", "trained_two_phase_K"),
-                            ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step")))
+                            ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step"),
+                            ("render_ms_per_mpix", "trained_render_ms_per_mpix"), ("render_evaluated_frac", "trained_render_evaluated_frac")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
     for k in ("mfma_busy_frac",):
         if out["roofline"].get(k) is not None:
@@ -1276,9 +1372,24 @@ def run_rank(args):
     trained_seeds = [int(v) for v in args.trained_seeds.split(",") if v.strip() != ""]
     if out is not None and world == 1 and trained_seeds and pg > 0 and args.stage == "focal":
         try:
-            out["trained_state"] = trained_state_records(sc, args, torch, sync, trained_seeds, pg, pf)
+            out["trained_state"] = trained_state_records(sc, args, torch, sync, trained_seeds, pg, pf,
+                                                         render_cams=[(37 * (f + 1)) % n_cams for f in range(args.render_frames)] if args.render_frames > 0 else None)
         except Exception as e:  # noqa: BLE001
             out["trained_state"] = dict(error=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
+    # ---- the plugin surface on a TRAINED scene, trained through the surface itself
+    if out is not None and world == 1 and args.plugin_steps > 0 and pg > 0 and pf >= args.plugin_steps + 100 and args.stage == "focal":
+        try:
+            out["plugin_step_trained"] = plugin_step_bench(sc, torch, "focal", steps=args.plugin_steps, warmup=30, trained=(pg, pf))
+        except Exception as e:  # noqa: BLE001
+            out["plugin_step_trained"] = dict(error=f"{type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
+    # ---- the reference's default batch of 8192 rays (a sub-record; the headline stays on the contract's 4096)
+    if out is not None and world == 1 and args.rays8192_steps > 0 and args.stage == "focal":
+        try:
+            out["rays8192"] = rays8192_records(sc, args, torch, sync, steps=args.rays8192_steps)
+        except Exception as e:  # noqa: BLE001
+            out["rays8192"] = dict(error=f"{type(e).__name__}: {e}")
         torch.cuda.empty_cache()
     # ---- PSNR: the engine trained on the procedural scene by the product's leg and by the reference-semantics leg, paired by seed
     if out is not None and world == 1 and pg + pf > 0 and args.psnr_seeds > 0:

@@ -16,8 +16,13 @@
 // reference's atomicAdd(half2) rounds after every add, :151; its result depends on the order the hardware took them).  A
 // 32-bit field holds |sum| < 128 (x128-scaled, i.e. a gradient of 1 per slot and step).  Every lane therefore also sums
 // the magnitudes of what it adds: if the whole range's sum of |component| stays below 2^31 units no field can have
-// left its 32 bits at any moment and the image is valid; otherwise (or with f16_accumulate) the range is done again the
-// reference's way, with ds_pk_add_f16 into an f16 image -- decided per range, workgroup-uniform.
+// left its 32 bits at any moment and the image is valid.  Otherwise the range is done again in COARSER units, 2^(k-24) with k
+// chosen from that sum so that it fits now (round 5; rounds 1-4 fell back to f16 adds here -- a focal step's ~16 k records per
+// range at |value| ~ 1e-2 sit right at the limit, so that which ranges were exact depended on the state): every addend is rounded
+// to the coarser grid once (2^(k-25) of a unit whose sums are >= 128: below f16's own rounding of the result by 2^10 and more),
+// the sum is again order independent, rounded to f16 once.  Only a NaN / inf among the addends (or f16_accumulate) takes the
+// reference's way, ds_pk_add_f16 into an f16 image, which carries it into the pool like atomicAdd(half2) does -- decided per
+// range, workgroup-uniform.
 #include "gfn_common.h"
 #include "hash_device.h"
 
@@ -27,10 +32,10 @@ constexpr int kSlice = 1 << GFN_GRAD_RANGE_LOG2;  // slots (f16 pairs) per range
 constexpr float kFixed = 16777216.f;               // 2^24: the f16 grid
 constexpr int kQ = 2;                              // producer streams a wave reads together
 
-__device__ __forceinline__ uint32_t fixed_to_half2(unsigned long long S) {
+__device__ __forceinline__ uint32_t fixed_to_half2(unsigned long long S, float unit = 1.f / kFixed) {  // unit: value of one count (2^(k-24))
   const int lo = (int)(unsigned int)(S & 0xffffffffull);            // the low field, signed
   const int hi = (int)(((long long)S - (long long)lo) >> 32);       // what is left once its borrow is taken back
-  const half2_t v = {(_Float16)((float)lo * (1.f / kFixed)), (_Float16)((float)hi * (1.f / kFixed))};
+  const half2_t v = {(_Float16)((float)lo * unit), (_Float16)((float)hi * unit)};
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -44,11 +49,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
   extern __shared__ __attribute__((aligned(16))) unsigned long long img64[];  // [kSlice] fixed-point pairs, or [kSlice] half2 in its first half
   half2_t* image = reinterpret_cast<half2_t*>(img64);
   __shared__ unsigned int s_cnt[256];
-  __shared__ unsigned int s_any;
+  __shared__ unsigned int s_any, s_poison;
   __shared__ unsigned long long s_mag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int b = range_begin + blockIdx.x; b < n_ranges; b += gridDim.x) {  // n_ranges: end of this launch's ranges
-    if (tid == 0) { s_any = 0; s_mag = 0ull; }
+    if (tid == 0) { s_any = 0; s_mag = 0ull; s_poison = 0; }
     __syncthreads();
     if (tid < 256) {
       const unsigned int c = rec_count[b * 256 + tid];
@@ -59,8 +64,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
     }
     __syncthreads();
     if (!s_any) continue;  // workgroup-uniform
-    bool exact = mode == 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    bool exact = mode == 0;  // fixed point (units of 2^(shift - 24)) | the reference's f16 adds
+    int shift = 0;
+    float to_fixed = kFixed, unit = 1.f / kFixed;
+    for (int attempt = 0; attempt < 3; attempt++) {
       for (int i = tid; i < (exact ? kSlice / 2 : kSlice / 4); i += 1024) reinterpret_cast<uint4*>(img64)[i] = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
       float mag = 0.f;  // this lane's sum of |c0| + |c1| in 2^-24 units: an upper bound (by up to 2x) of what any field saw, and -- unlike
@@ -72,9 +79,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
         const uint32_t local = slot & (kSlice - 1);
         const half2_t v = __builtin_bit_cast(half2_t, val);
         if (exact) {
-          const float f0 = (float)v[0] * kFixed, f1 = (float)v[1] * kFixed;  // exact: an integer below 2^40
+          const float f0 = (float)v[0] * to_fixed, f1 = (float)v[1] * to_fixed;  // shift = 0: exact, an integer below 2^40
           mag += fabsf(f0) + fabsf(f1);
-          const int c0 = (int)f0, c1 = (int)f1;  // (saturates beyond 2^31: such a range is done again below)
+          const int c0 = __float2int_rn(f0), c1 = __float2int_rn(f1);  // (shift = 0: saturates beyond 2^31, such a range is done again below;
+                                                                       // shift > 0: the addend's one rounding, to the coarser grid)
           atomicAdd(img64 + local, ((unsigned long long)(unsigned int)c1 << 32) + (unsigned long long)(long long)c0);
         } else {
           __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(image + local), v);
@@ -104,13 +112,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
           }
         }
       }
-      if (exact) {  // f32 sums of <= a few thousand terms: relative error < 1e-3, hence the margin below; NaN / inf -> 2^40
-        const unsigned long long m = (mag < 1.0995e12f) ? (unsigned long long)mag : (1ull << 40);
-        if (m) atomicAdd(&s_mag, m);
+      if (exact && shift == 0) {  // f32 sums of <= a few thousand terms: relative error < 1e-3, hence the margin below; NaN / inf -> poison
+        if (mag < 1.0995e12f) { if (mag > 0.f) atomicAdd(&s_mag, (unsigned long long)mag); }
+        else s_poison = 1;  // (benign race)
       }
       __syncthreads();
-      if (!exact || s_mag < 2140000000ull) break;  // workgroup-uniform: no field can have left its 32 bits (2^31 = 2147483648)
-      exact = false;                              // they may have: once more, the reference's way
+      if (!exact || shift > 0) break;                 // the f16 image, or coarser units chosen to fit: done
+      if (s_poison) { exact = false; continue; }      // workgroup-uniform: a NaN / inf among the addends -- the reference's way carries it
+      if (s_mag < 2140000000ull) break;               // no field can have left its 32 bits (2^31 = 2147483648)
+      shift = 64 - __clzll(s_mag) - 30;               // sum of |addend| >> shift < 2^30 (+ half a count of rounding per addend, <= 2^17 of them)
+      to_fixed = __uint_as_float((uint32_t)(127 + 24 - shift) << 23);   // 2^(24 - shift)
+      unit = __uint_as_float((uint32_t)(127 - 24 + shift) << 23);       // 2^(shift - 24)
     }
     // pool range += image, 16 bytes (4 slots) per lane, all loads of a thread in flight before the first add; this
     // workgroup owns the range: no atomics (overflow atomics were issued by the producer, an earlier kernel)
@@ -128,8 +140,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
         uint4 v;
         if (exact) {
           const uint4 a = reinterpret_cast<const uint4*>(img64)[2 * i4], c = reinterpret_cast<const uint4*>(img64)[2 * i4 + 1];
-          v.x = fixed_to_half2(((unsigned long long)a.y << 32) | a.x); v.y = fixed_to_half2(((unsigned long long)a.w << 32) | a.z);
-          v.z = fixed_to_half2(((unsigned long long)c.y << 32) | c.x); v.w = fixed_to_half2(((unsigned long long)c.w << 32) | c.z);
+          v.x = fixed_to_half2(((unsigned long long)a.y << 32) | a.x, unit); v.y = fixed_to_half2(((unsigned long long)a.w << 32) | a.z, unit);
+          v.z = fixed_to_half2(((unsigned long long)c.y << 32) | c.x, unit); v.w = fixed_to_half2(((unsigned long long)c.w << 32) | c.z, unit);
         } else {
           v = reinterpret_cast<const uint4*>(image)[i4];
         }
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5))) void 
     } else {
       for (int i = tid; i < kSlice; i += 1024) {
         const int64_t s = s0 + i;
-        const half2_t v = exact ? __builtin_bit_cast(half2_t, fixed_to_half2(img64[i])) : image[i];
+        const half2_t v = exact ? __builtin_bit_cast(half2_t, fixed_to_half2(img64[i], unit)) : image[i];
         if (s < pool_slots && (v[0] != (_Float16)0.f || v[1] != (_Float16)0.f)) pool[s] = pool[s] + v;
       }
     }

@@ -153,6 +153,30 @@ class TileRenderer:
             _lib.lib().gfn_set_decoder_cus(prev)
         return outs
 
+    def footprint_bytes(self):
+        """Device memory of this renderer's static buffers: tile inputs, the ring of sample buffers (the record form's march_rec and hit lists
+        dominate) and the tiles' outputs -- what the captured graph keeps alive.  None before the first frame (nothing is allocated yet)."""
+        if self.T is None or (self.use_graph and self.graph is None):
+            return None
+        seen, total = set(), 0
+
+        def add(x):
+            nonlocal total
+            if isinstance(x, torch.Tensor):
+                key = (x.untyped_storage().data_ptr(), x.untyped_storage().nbytes())
+                if key not in seen:
+                    seen.add(key)
+                    total += x.untyped_storage().nbytes()
+            elif isinstance(x, dict):
+                for v in x.values():
+                    add(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    add(v)
+
+        add([self.o, self.d, self.cam, self.noise, getattr(self, "_keep", None), self.out, self.hp._record_ws, self.hp._sampler_ws])
+        return total
+
     SLOTS = 2  # sample buffers of the tile pipeline: the one the inference kernel reads and the one the next tile's sampler fills
 
     def _consume(self, i, main, done, used, samples, outs):

@@ -232,7 +232,8 @@ def test_bench_line_stays_under_two_thousand_characters():
                psnr=dict(psnr_fast=33.668123, psnr_reference=33.565123, delta=0.1026612, se=0.1582212, n_seeds=3, decoder_delta=1.2716e-06, study_delta=0.012345, study_se=0.048712,
                          study_n_seeds=148),
                trained_state=dict(value=f, ms_per_step=1.583012, alive_sample_frac=0.8626212, evaluated_sample_frac=1.0, two_phase_K=1024, roofline_frac=0.2323312,
-                                  global_ms_per_step=1.782412, global_rays_per_sec=f),
+                                  global_ms_per_step=1.782412, global_rays_per_sec=f, render_ms_per_mpix=35.123456, render_evaluated_frac=0.912345),
+               plugin_step_trained=dict(value=f, ms_per_step=1.712345), rays8192=dict(value=f * 1.5, global_rays_per_sec=f * 1.4, ms_per_step=2.1),
                cpu_reference_field=dict(train_rays_per_sec=4227.212), cpu_baseline=dict(value=712.0812, unit="rays/s", cores=256, kind="port",
                                                                                         sample="2048 rays (392816 samples) of the same batch, oracle fwd+bwd (no Adam), 2.9 s; all stages OpenMP"))
     line = bench.compact_line(out)
@@ -242,7 +243,8 @@ def test_bench_line_stays_under_two_thousand_characters():
         assert key in line, key
     c = line["config"]
     for key in ("workload", "trained_rays_per_sec", "trained_ms_per_step", "psnr", "psnr_reference", "psnr_delta", "psnr_se", "psnr_n_seeds", "psnr_study_delta", "psnr_study_se",
-                "psnr_study_n_seeds", "render_ms_per_mpix", "global_ms_per_step", "plugin_ms_per_step"):
+                "psnr_study_n_seeds", "render_ms_per_mpix", "global_ms_per_step", "plugin_ms_per_step", "trained_render_ms_per_mpix", "plugin_trained_ms_per_step",
+                "rays8192_rays_per_sec", "rays8192_global_rays_per_sec"):
         assert key in c, key
     assert line["roofline"]["kernel"] == "lm_lookup_kernel<true, false>" and set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}

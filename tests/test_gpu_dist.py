@@ -22,6 +22,22 @@ from helpers import ROOT, has_gpu
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_device_memory():
+    """The tests of this module start other processes on the same card: whatever this pytest process still caches from earlier modules
+    (a full-HD tile renderer's record buffers alone are 34 GB) goes back to the device first."""
+    import gc
+
+    gc.collect()
+    if has_gpu():
+        torch.cuda.empty_cache()
+    yield
+
+
+def _tail(outs, n=3000):
+    return [o[-n:] if isinstance(o, str) else o for o in outs]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -51,7 +67,7 @@ def test_two_rank_global_stage_replicas_stay_identical(tmp_path, mode):
     worker = os.path.join(ROOT, "tests", "dp_worker.py")
     codes, outs = _run_ranks(lambda r: [sys.executable, worker, str(r), "2", port, out, mode], 2, timeout=420)
     res = json.load(open(out)) if os.path.exists(out) else {}
-    assert codes == [0, 0] and res.get("ok"), (codes, res.get("error"), outs)
+    assert codes == [0, 0] and res.get("ok"), (codes, res.get("error"), _tail(outs), torch.cuda.mem_get_info())
     assert res["ranks_seen"] == 2
     # the exchanged gradients are the mean of the ranks' local gradients (f16 pool: one rounding of the f32 mean, or f16 adds)
     assert res["table_grad_nonzero"] > 1000
@@ -80,7 +96,7 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     worker = os.path.join(ROOT, "tests", "rccl_worker.py")
     codes, outs = _run_ranks(lambda r: [sys.executable, worker, port, out], 1, timeout=420)
     res = json.load(open(out)) if os.path.exists(out) else {}
-    assert codes == [0] and res.get("ok"), (codes, res.get("error"), outs)
+    assert codes == [0] and res.get("ok"), (codes, res.get("error"), _tail(outs), torch.cuda.mem_get_info())
     assert res["backend"] == "nccl" and res["allreduce_of_ones"] == [1.0] * 4
     assert res["selfcheck"]["ok"] and res["selfcheck"]["n"] > 0 and res["selfcheck"]["max_abs_err"] == 0.0, res["selfcheck"]
     assert res["direct_71MB_identity"]
@@ -137,26 +153,27 @@ def test_bench_self_spawns_two_ranks():
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
-def test_bench_six_ranks_share_the_card():
-    """VERDICT r04 #3(b), as far as one card goes: the GPU boxes allow at most 6 processes on a card, so the widest job that can run
-    here is `bench.py --gpus 6 --share-gpu` (gloo) -- shards of n/6, six blocks on six ranks, six-way frame routing, the four-segment
-    data-parallel StepGraph with six replicas.  (World 8 -- shard = n/8 at the table gradient's real size, 8 blocks, 8-way routing --
+def test_bench_four_ranks_share_the_card():
+    """VERDICT r04 #3(b), as far as one card goes: the GPU boxes allow at most 6 processes on a card, this test process being one of
+    them (a 6-rank job was killed by the box's process guard), so the widest job run here is `bench.py --gpus 4 --share-gpu` (gloo) --
+    shards of n/4, four blocks on four ranks, four-way frame routing, the four-segment data-parallel StepGraph with four replicas.  (World 8 -- shard = n/8 at the table gradient's real size, 8 blocks, 8-way routing --
     runs on the CPU: tests/test_dist_cpu.py::test_eight_rank_rehearsal.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--share-gpu", "--n-side", "6", "--log2-T", "16", "--steps", "3",
-           "--warmup", "0", "--global-steps", "3", "--global-warmup", "0", "--render-frames", "1", "--no-cpu-baseline", "--sub-timeout", "400"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-gpu", "--n-side", "6", "--log2-T", "16", "--steps", "3",
+           "--warmup", "0", "--global-steps", "3", "--global-warmup", "0", "--render-frames", "1", "--no-cpu-baseline", "--sub-timeout", "400",
+           "--render-tile-rays", "32768", "--render-tile-width", "128"]  # (four renderers on one card: small tiles, 1 GB of sample records each)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < 2000, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 6 and d["ranks_seen"] == 6 and d["scaling"] == "weak" and d["value"] > 0 and "errors" not in d
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["scaling"] == "weak" and d["value"] > 0 and "errors" not in d
     assert d["config"]["global_ms_per_step"] > 0 and d["config"]["global_rays_per_sec"] > 0 and d["config"]["replicas_bit_identical"] is True
     det = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench-details] ")]
     d = json.loads(det[0][len("[bench-details] "):])
     g = d["global_stage"]
-    assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and "dp6" in g["parallelism"], g
-    assert d["render"]["frames"] == 6 and "routed" in d["render"]["routing"], d["render"]
+    assert g["replicas_bit_identical"] is True and g["sync"]["octree_max_reduces"] >= 3 and "dp4" in g["parallelism"], g
+    assert d["render"]["frames"] == 4 and "routed" in d["render"]["routing"], d["render"]
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a GPU")

@@ -860,8 +860,8 @@ def test_level_major_lookup_is_bit_identical(ops, dev, n, log2_T, halves_from, s
 def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
     """gfn_grad_records_reduce on hand-made record streams (the layout include/gfnerf_amd.h documents): small values take the
     exact fixed-point path -- the pool is f16(exact sum), whatever the order --; a range that could overflow the 32-bit
-    fields (sum of |component| >= 128) is done again on the f16 path instead of wrapping; f16_accumulate forces the
-    reference's f16 adds; the counters are consumed."""
+    fields (sum of |component| >= 128) is done again in coarser fixed-point units instead of wrapping (a NaN among the addends: on the
+    f16 path, which carries it); f16_accumulate forces the reference's f16 adds; the counters are consumed."""
     import torch
 
     from gfnerf_amd import _lib
@@ -905,9 +905,11 @@ def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
     exact16 = want.astype(np.float16).astype(np.float64)
     # exact path (ranges 0 and 2): bit-identical to rounding the exact sum once
     assert np.array_equal(got["auto"][:16384], exact16[:16384]) and np.array_equal(got["auto"][32768:], exact16[32768:])
-    # range 1 holds 256 * 64 * 0.5 / 8 slots = +-1024 per slot: beyond a 32-bit field of 2^-24 units -> the f16 image
+    # range 1 holds 256 * 64 * 0.5 / 8 slots = +-1024 per slot: beyond a 32-bit field of 2^-24 units -> done again in coarser units
+    # chosen to fit (round 5; the f16 image before): still the exact sum of these addends (multiples of 0.5), rounded to f16 once
     big = got["auto"][16384:16392]
-    assert (big[:, 0] > 500).all() and (big[:, 1] < -500).all() and np.abs(big - want[16384:16392]).max() <= 0.6 * 1024
+    assert (big[:, 0] > 500).all() and (big[:, 1] < -500).all() and np.array_equal(big, exact16[16384:16392])
+    assert np.abs(got["f16"][16384:16392] - want[16384:16392]).max() <= 0.6 * 1024  # (the reference's f16 adds lose most of it)
     # the reference's accumulation everywhere: small sums lose what the running f16 value swallows, but stay close
     assert np.abs(got["f16"][:64] - want[:64]).max() <= 2e-2 * np.abs(want[:64]).max()
     assert np.abs(got["f16"][:64] - exact16[:64]).max() > 0  # (and is indeed not the exact sum)
@@ -923,3 +925,11 @@ def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
     assert np.array_equal(pool.float().cpu().numpy()[:pool_slots].astype(np.float64), got["auto"])
     with pytest.raises(Exception):
         ops.grad_records_reduce((rec, cnt), pool, log2_T, ranges=(2, 1))
+    # a NaN among a range's addends reaches the pool (as atomicAdd(half2) would carry it), the other ranges are untouched by it
+    fill(2, 9, np.array([pool_slots - 5]), np.array([[np.nan, 1.0]]))
+    upload()
+    pool = torch.zeros((16 * T, 2), dtype=torch.float16, device=dev)
+    ops.grad_records_reduce((rec, cnt), pool, log2_T)
+    out = pool.float().cpu().numpy()
+    assert np.isnan(out[pool_slots - 5, 0]) and out[pool_slots - 5, 1] == 1.0 and np.isfinite(out[:32768]).all()
+    assert np.array_equal(out[:16384].astype(np.float64), exact16[:16384])
