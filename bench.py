@@ -124,6 +124,7 @@ def parse():
     ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
                     help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
                          "nearest (default); x3 = hi + lo' planes (rounds 1-4); mixed = dz one plane, activations split")
+    ap.add_argument("--wgrad-beside-accumulate", action="store_true", help="experiment (global stage): wgrad on a second stream beside grad_accumulate")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
     return ap.parse_args()
@@ -394,7 +395,8 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
         roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
     fp = tr.footprint_bytes()
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
-                hbm_footprint_gb=None if fp is None else fp / 1e9,
+                hbm_footprint_gb=None if fp is None else fp / 1e9, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
+                record_pool_regrown=tr.pool_regrown,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,
                 kernel=("fused_render_patch_kernel: a wave walks %d x %d neighbouring pixels' rays in lockstep, samples read from the counting march's records" % (args.render_patch_width, 32 // args.render_patch_width)
@@ -777,6 +779,7 @@ class StageRun:
         ga = args.lm_global_after
         self.cfg = cfg = hotpath.HotPathConfig(
             log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision, wgrad_planes=args.wgrad_planes,
+            wgrad_beside_accumulate=args.wgrad_beside_accumulate,
             two_phase=not args.one_phase,
             **({"prefetch_cus": args.prefetch_cus, "prefetch_cus_global": args.prefetch_cus} if args.prefetch_cus else {}),
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,

@@ -16,7 +16,7 @@ class WgradLayer(C.Structure):
                 ("m_valid", C.c_int32), ("k_valid", C.c_int32), ("col_map", _vp), ("dW", _vp), ("ldw", C.c_int32), ("db", _vp)]
 
 
-ABI_VERSION = 104  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
+ABI_VERSION = 105  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
 
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {
@@ -35,7 +35,7 @@ SIGNATURES = {
     "gfn_tree_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_sample_rays": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
-    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_update_nodes_mark": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -70,7 +70,7 @@ SIGNATURES = {
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
                          _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
+    "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

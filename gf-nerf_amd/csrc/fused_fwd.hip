@@ -27,6 +27,7 @@ struct FusedArgs {
   const int* pts_offsets; int n_rays;
   const float* pts; const int* anchors; const float* dt; const float* ts;
   const float* rec; const int* counts;  // gfn_fused_render_rec: the samples where the counting march recorded them (slot k of ray r at (r * 1024 + k) * 8)
+  const int* page_table;                // ... or, paged (gfn_sample_rays_record): at (page_table[r * 32 + k / 32] * 32 + k % 32) * 8
   const void* table_a; const void* table_b; const int* prim_a; const int* prim_b; const float* bias_pool;
   int64_t n_volumes; int log2_T;
   const u32x4* image; const float* sh; const float* emb; const int* cam_idx;
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     }
     const int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
     const int cnt = REC ? A.counts[ray] : A.pts_offsets[ray + 1] - A.pts_offsets[ray];
-    const int64_t s = REC ? (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY : (int64_t)A.pts_offsets[ray];
+    int64_t s = REC ? (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY : (int64_t)A.pts_offsets[ray];
+    const bool paged = REC && A.page_table != nullptr;  // wave-uniform
     int kmax = cnt;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
@@ -324,6 +326,11 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
       if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
+      if (paged && (k & (GFN_REC_PAGE - 1)) == 0 && k < cnt) {  // a new page of this ray's records: s such that slot k is still s + k
+        int ray_p = ray;
+        asm volatile("" : "+v"(ray_p));
+        s = ((int64_t)A.page_table[(int64_t)ray_p * (GFN_MAX_SAMPLE_PER_RAY / GFN_REC_PAGE) + (k >> GFN_REC_PAGE_LOG2)] << GFN_REC_PAGE_LOG2) - k;
+      }
       const int64_t q = s + k;
       // (rebuilt every sample from two 32-bit values the compiler cannot see through: as 64-bit pointers -- or their hoisted parts -- kept
       // across the loops they were what spilled)
@@ -427,8 +434,14 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     if (A.t_minmax) {  // t grows along a ray: its range is its first and its last sample, terminated or not
       float tmin = INFINITY, tmax = 0.f;
       if (cnt > 0) {
-        tmin = REC ? A.rec[s * GFN_MARCH_REC_FLOATS] : A.ts[s];
-        tmax = REC ? A.rec[(s + cnt - 1) * GFN_MARCH_REC_FLOATS] : A.ts[s + cnt - 1];
+        int64_t first = s, last = s + cnt - 1;
+        if (paged) {
+          const int* pt = A.page_table + (int64_t)ray * (GFN_MAX_SAMPLE_PER_RAY / GFN_REC_PAGE);
+          first = (int64_t)pt[0] << GFN_REC_PAGE_LOG2;
+          last = ((int64_t)pt[(cnt - 1) >> GFN_REC_PAGE_LOG2] << GFN_REC_PAGE_LOG2) + ((cnt - 1) & (GFN_REC_PAGE - 1));
+        }
+        tmin = REC ? A.rec[first * GFN_MARCH_REC_FLOATS] : A.ts[first];
+        tmax = REC ? A.rec[last * GFN_MARCH_REC_FLOATS] : A.ts[last];
       }
       if (cnt < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
 #pragma unroll
@@ -577,7 +590,7 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
                              emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
 }
 
-int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const uint16_t* table_f16, const uint16_t* table2_f16,
+int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16, const uint16_t* table2_f16,
                          const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
                          const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
                          int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
@@ -585,7 +598,7 @@ int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* mar
   if (n_rays == 0) return GFN_OK;
   GFN_CHECK_ARG(counts && march_rec && (reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_fused_render_rec: counts / march_rec null or not 16-byte aligned");
   FusedArgs A{};
-  A.counts = counts; A.rec = march_rec;
+  A.counts = counts; A.rec = march_rec; A.page_table = page_table;
   return fused_render_launch(A, "gfn_fused_render_rec", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image,
                              sh, emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
 }

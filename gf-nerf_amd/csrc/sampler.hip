@@ -495,7 +495,12 @@ __global__ __launch_bounds__(256) void trace_group_kernel(
     }
     active = in_range && sp > 0 && cnt < max_hits;
   }
-  if (in_range && k == 0) counts[ray] = cnt;
+  if (in_range && k == 0) {
+    counts[ray] = cnt;
+    // the traversal ended at max_hits with nodes still on the stack: the reference's own truncation when max_hits is its
+    // max_oct_intersect_per_ray (1024) -- a caller that passed a SMALLER cap to keep its hit lists small reads bit 8 and asks again
+    if (sp > 0 && cnt >= max_hits && overflow) atomicOr(overflow, 8);
+  }
 }
 
 // ---- the 12 projections of a step, shared by the L lanes of a ray --------------------------------------------------------------
@@ -547,6 +552,15 @@ template <> struct MarchGroup<4> {
   template <int N> static __device__ __forceinline__ float to_lane(float v) { return v; }
 };
 
+// Where the counting march keeps its records when they are what the inference kernel reads (gfn_sample_rays_record).  Dense: slot k of
+// ray r at (r * 1024 + k) -- 32 KB per ray whatever its length (17 GB for a 518 k-ray tile, of which the rays' ~180 samples fill 18 %).
+// Paged (table != NULL): pages of GFN_REC_PAGE slots from a pool, handed out as the rays need them by one atomic counter; page p of ray r
+// is table[r * 32 + p].  The pool is sized by the SAMPLES (n_pages: ~224 slots per ray), not by the cap; a pool that runs out is flagged
+// in the overflow word (bit 16) and the caller samples again into a larger one.
+struct RecPages {
+  int* table; int* counter; int n_pages;
+};
+
 // K4 with L lanes per ray.  Hits come from the dense slots of trace_group_kernel.
 template <int L, bool FILL>
 __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
@@ -557,7 +571,8 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
     const int* __restrict__ pts_offsets, float* __restrict__ world_pts, float* __restrict__ warped_pts,
     float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
     int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow,
-    float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf, warped point} for fill_from_rec_kernel, or NULL */) {
+    float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf, warped point} for fill_from_rec_kernel, or NULL */,
+    RecPages pages /* table != NULL: the records live in pages of GFN_REC_PAGE slots handed out as the rays need them (see RecPages) */) {
   using G = MarchGroup<L>;
   constexpr int P = G::P, NZ = G::NZ;
   const int g = threadIdx.x & (L - 1);
@@ -570,7 +585,8 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
   const int n_oct = in_range ? hit_counts[r] : 0;
   hit_idx += (int64_t)r * max_hits;
   hit_nf += (int64_t)r * max_hits;
-  if (rec) rec += (int64_t)r * GFN_MAX_SAMPLE_PER_RAY * GFN_MARCH_REC_FLOATS;
+  if (rec && !pages.table) rec += (int64_t)r * GFN_MAX_SAMPLE_PER_RAY * GFN_MARCH_REC_FLOATS;
+  int page_slot0 = 0;  // (paged records) first slot of the page this ray is filling
   int max_n = GFN_MAX_SAMPLE_PER_RAY;
   int64_t base = 0;
   if (FILL) {
@@ -701,7 +717,24 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
         float2 v2;
         v2.x = g == 0 ? cur_t : (g == 1 ? __int_as_float(cur_oct_idx) : (g == 2 ? wp_x2 : wp_z3));
         v2.y = g == 0 ? exp_march_step * (pnorm + 1e-6f) : (g == 1 ? __int_as_float(trans_idx) : (g == 2 ? wp_y2 : __int_as_float(block_idx)));
-        if (g < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + (int64_t)pts_ptr * GFN_MARCH_REC_FLOATS)[g] = v2;
+        int64_t slot = pts_ptr;
+        if (pages.table) {
+          if ((pts_ptr & (GFN_REC_PAGE - 1)) == 0) {  // the ray's lanes reach this together: its first lane takes the next free page
+            int pg = 0;
+            if (g == 0) {
+              pg = atomicAdd(pages.counter, 1);
+              if (pg >= pages.n_pages) {  // pool exhausted: flagged (the caller renders again with a larger pool); the slots stay inside the buffer
+                if (overflow) atomicOr(overflow, 16);
+                pg = pages.n_pages - 1;
+              }
+              pages.table[(int64_t)r * (GFN_MAX_SAMPLE_PER_RAY / GFN_REC_PAGE) + (pts_ptr >> GFN_REC_PAGE_LOG2)] = pg;
+            }
+            pg = __shfl(pg, (int)(threadIdx.x & 63u) & ~(L - 1), 64);
+            page_slot0 = pg << GFN_REC_PAGE_LOG2;
+          }
+          slot = (int64_t)page_slot0 + (pts_ptr & (GFN_REC_PAGE - 1));
+        }
+        if (g < GFN_MARCH_REC_FLOATS / 2) reinterpret_cast<float2*>(rec + slot * GFN_MARCH_REC_FLOATS)[g] = v2;
       }
       if (!first) pts_ptr += 1;
       while (cur_t + cur_march_step > cur_far) {
@@ -1066,7 +1099,7 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
                             int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                             int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                             float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                            int32_t* overflow_dev, float* march_rec, int tree_depth, int32_t* record_counts, void* stream) {
+                            int32_t* overflow_dev, float* march_rec, int tree_depth, int32_t* record_counts, RecPages pages, void* stream) {
   const bool record_only = record_counts != nullptr;
   GFN_CHECK_ARG(record_only || pts_offsets, "gfn_sample_rays: null pts_offsets");
   GFN_CHECK_ARG(tree_depth <= kMaxDepth, "gfn_sample_rays: tree_depth=%d (at most %d levels)", tree_depth, kMaxDepth);
@@ -1104,7 +1137,8 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
         (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
         reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts_out, offsets,
         FILL ? world_pts : nullptr, FILL ? warped_pts : nullptr, FILL ? dirs : nullptr, FILL ? dists : nullptr, FILL ? ts : nullptr,
-        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, (FILL || record_only) ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec);
+        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, (FILL || record_only) ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec,
+        (record_only && rec) ? pages : RecPages{nullptr, nullptr, 0});
   };
   using Row = std::integral_constant<int, 16>;
   using Quad = std::integral_constant<int, 4>;
@@ -1136,20 +1170,23 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream) {
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis,
                           table_space, hit_counts, hit_idx, hit_near_far, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
-                          first_oct_dis, pts_cap, overflow_dev, march_rec, tree_depth, nullptr, stream);
+                          first_oct_dis, pts_cap, overflow_dev, march_rec, tree_depth, nullptr, RecPages{nullptr, nullptr, 0}, stream);
 }
 
 int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
-                           float* march_rec, int tree_depth, void* stream) {
+                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int tree_depth, void* stream) {
   if (n_rays == 0) return GFN_OK;  // (an empty batch has no outputs to point at)
   GFN_CHECK_ARG(counts && first_oct_dis && march_rec, "gfn_sample_rays_record: null output pointer");
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays_record: march_rec must be 16-byte aligned");
+  GFN_CHECK_ARG(!page_table || (page_counter && overflow_dev && n_pages >= 1 && n_pages < (1ll << 31) / GFN_REC_PAGE),
+                "gfn_sample_rays_record: paged records need the page counter, the overflow word and 1 <= n_pages < 2^31 / %d", GFN_REC_PAGE);
+  if (page_table) GFN_CHECK_HIP(hipMemsetAsync(page_counter, 0, sizeof(int32_t), gfn_stream(stream)));
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis, 1,
                           hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                          first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, stream);
+                          first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, RecPages{page_table, page_counter, (int)n_pages}, stream);
 }
 
 int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float* world_pts,

@@ -83,6 +83,8 @@ class HotPathConfig:
                                      # half the plane traffic, one MFMA per fragment pair); "x3" hi + lo' planes for both (rounds 1-4:
                                      # f32-class per term); "mixed" dz one plane, activations hi + lo'.  The per-sample chains (forward,
                                      # d x = W^T dz, the table gradient) are x3 whatever this says
+    wgrad_beside_accumulate: bool = False  # global stage, one rank: the decoder's weight-gradient kernel on a second stream beside the LDS accumulation
+                                     # of the table gradient's records (both read what the backward wrote, neither the other's result)
     exact_oct_alphas: bool = True    # a training forward that UpdateOctNodes follows evaluates the density of EVERY sample, so that K5 reads true alphas
                                      # behind the rays' termination points like the reference does (forward_train's all_alphas); False: rounds 2-3
                                      # (alpha = 0 where the forward skipped a sample: a node's alpha statistic then decays whenever only occluded rays reach it)
@@ -119,6 +121,7 @@ class HotPath:
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
         self._wgrad_parts = None    # per-workgroup partial weight gradients of the decoder (ops.wgrad_x3_layers)
+        self._wg_stream = None      # cfg.wgrad_beside_accumulate: the stream of the weight-gradient kernel
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self._deferred = []
         self.last_forward_replayed = False
@@ -266,11 +269,14 @@ class HotPath:
             self._depth_key = key
         return self._depth_val
 
-    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False):
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False, pool_slots_per_ray=0, max_hits=None):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
         returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph).
         record: traversal + counting march only (ops.sample_rays_record) -- the samples stay in the march's records, for
-        render(tile_width=...), whose patch kernel reads them there (no scan, no fill, no packed copy)."""
+        render(tile_width=...), whose patch kernel reads them there (no scan, no fill, no packed copy); pool_slots_per_ray > 0: in pages
+        from a pool of that many slots per ray on average instead of 1024 slots for every ray (ops.sample_rays_record); max_hits: leaves per
+        ray of the record form's hit lists (default cfg.max_oct_per_ray = the reference's 1024: 12 KB per ray; a caller that passes less
+        checks ops.HIT_CAP_REACHED in the overflow word)."""
         c = self.cfg
         pre, self._pre = self._pre, None
         if not record and pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
@@ -290,9 +296,9 @@ class HotPath:
         sh = ops.sh4(d, out=None if out is None else out["sh"])
         if record:
             s = self._timed("sample", ops.sample_rays_record, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l, c.scale_by_dis,
-                            near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
+                            near=c.global_near, far=1e8, max_hits=min(int(max_hits), c.max_oct_per_ray) if max_hits else c.max_oct_per_ray,
                             workspace=self._record_ws if self._record_ws is not None else self._sampler_ws,  # (the hit lists of the packed form will do)
-                            out=out, tree_depth=self.tree_depth())
+                            out=out, tree_depth=self.tree_depth(), pool_slots_per_ray=pool_slots_per_ray)
             if s["workspace"] is not self._sampler_ws:
                 self._record_ws = s["workspace"]
             s["dirs_unit"], s["sh"] = d, sh
@@ -767,6 +773,12 @@ class HotPath:
                     self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                                 s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
                                 gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
+                wg_side = None
+                if c.wgrad_beside_accumulate and rec is not None and not self.sync.exchanges and self.seg is None:
+                    if self._wg_stream is None:
+                        self._wg_stream = ops.concurrent_stream(self.dev, role="wgrad")
+                    wg_side = self._wg_stream
+                    wg_side.wait_stream(torch.cuda.current_stream())  # forks behind the backward kernel: planes and records are final
                 if rec is not None:
                     self._reduce_records(rec)
                 dfeat = None
@@ -795,7 +807,12 @@ class HotPath:
             layers = [(bv(dzk), fv(ak), g[li][0], g[li][1], mv, cmap)
                       for li, dzk, ak, mv, cmap in ((4, "dz3", "c2", 3, None), (3, "dz2", "c1", 128, None), (2, "dz1", "xp", 128, self._xp_col_map),
                                                     (1, "dh", "a1", 16, None), (0, "dza1", "feat", 128, None))]
-            self._timed("wgrad", ops.wgrad_x3_layers, layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
+            if scattered and wg_side is not None:
+                with torch.cuda.stream(wg_side):
+                    ops.wgrad_x3_layers(layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
+                torch.cuda.current_stream().wait_stream(wg_side)
+            else:
+                self._timed("wgrad", ops.wgrad_x3_layers, layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
             rec = self._record_buffers()
             with self._cu_cap():

@@ -14,6 +14,9 @@ from . import _lib
 MAX_SAMPLE_PER_RAY = 1024
 MAX_OCT_PER_RAY = 1024
 MARCH_REC_FLOATS = 8  # GFN_MARCH_REC_FLOATS: t, dist, leaf, transform, warped x y z, block per recorded sample
+REC_PAGE = 32         # GFN_REC_PAGE: sample slots per page of sample_rays_record's paged form
+REC_POOL_OVERFLOW = 16  # bit of the sampler's overflow word: the page pool ran out
+HIT_CAP_REACHED = 8     # ... some ray's traversal stopped at max_hits leaves with nodes still to visit
 TREE_NODE_BYTES = 128
 TRANS_INFO_BYTES = 576
 
@@ -293,10 +296,13 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
 
 
 def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8, max_hits=MAX_OCT_PER_RAY,
-                       workspace=None, out=None, tree_depth=0):
+                       workspace=None, out=None, tree_depth=0, pool_slots_per_ray=0):
     """gfn_sample_rays_record: traversal + counting march only -> dict(counts i32 [R], first_oct_dis [R], march_rec f32 [R * 1024 * 8],
     overflow, workspace): the samples stay where the march recorded them (slot k of ray r at (r * 1024 + k) * MARCH_REC_FLOATS), for
-    fused_render's record form.  out: the dict of an earlier call with the same R, written again in place."""
+    fused_render's record form.  out: the dict of an earlier call with the same R, written again in place.
+    pool_slots_per_ray > 0: the PAGED form -- march_rec is a pool of R * pool_slots_per_ray / 32 pages of 32 slots, page_table i32
+    [R * 32] says where each ray's pages are: sized by the samples the rays have, not by the 1024 they may have (7 KB instead of 32 KB
+    per ray at 224).  When the pool runs out, overflow gets bit REC_POOL_OVERFLOW: sample again with a larger pool."""
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
     _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
     R = rays_o.shape[0]
@@ -312,6 +318,13 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
             raise _lib.GfnError("sample_rays_record: `out` was made for another batch size")
         out["overflow"].zero_()
         out["workspace"] = workspace
+    elif pool_slots_per_ray > 0:
+        n_pages = max((R * int(pool_slots_per_ray) + REC_PAGE - 1) // REC_PAGE, 1)
+        out = dict(counts=torch.empty(R, dtype=torch.int32, device=dev), first_oct_dis=torch.empty(R, dtype=torch.float32, device=dev),
+                   march_rec=torch.empty(n_pages * REC_PAGE * MARCH_REC_FLOATS, dtype=torch.float32, device=dev),
+                   page_table=torch.empty(max(R, 1) * (MAX_SAMPLE_PER_RAY // REC_PAGE), dtype=torch.int32, device=dev),
+                   page_counter=torch.zeros(1, dtype=torch.int32, device=dev), n_pages=n_pages,
+                   overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace)
     else:
         out = dict(counts=torch.empty(R, dtype=torch.int32, device=dev), first_oct_dis=torch.empty(R, dtype=torch.float32, device=dev),
                    march_rec=torch.empty(max(R, 1) * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS, dtype=torch.float32, device=dev),
@@ -319,7 +332,8 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
     rc = _lib.lib().gfn_sample_rays_record(_ptr(rays_o), _ptr(rays_d), _ptr(noise), R, _ptr(compact_nodes), _ptr(transes), near, far, max_hits,
                                            float(sample_l), int(bool(scale_by_dis)), _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]),
                                            _ptr(workspace["hit_nf"]), _ptr(out["counts"]), _ptr(out["first_oct_dis"]), _ptr(out["overflow"]),
-                                           _ptr(out["march_rec"]), int(tree_depth), _stream())
+                                           _ptr(out["march_rec"]), _ptr(out.get("page_table")), _ptr(out.get("page_counter")), int(out.get("n_pages", 0)),
+                                           int(tree_depth), _stream())
     _lib.check(rc, "gfn_sample_rays_record")
     return out
 
@@ -935,8 +949,11 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
         po = None
         R = s["counts"].numel()
         dev = s["counts"].device
-        _chk(s["counts"], torch.int32, "counts"); _chk(s["march_rec"], torch.float32, "march_rec")
-        if s["march_rec"].numel() < R * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS:
+        _chk(s["counts"], torch.int32, "counts"); _chk(s["march_rec"], torch.float32, "march_rec"); _chk(s.get("page_table"), torch.int32, "page_table")
+        if s.get("page_table") is not None:
+            if s["page_table"].numel() < R * (MAX_SAMPLE_PER_RAY // REC_PAGE) or s["march_rec"].numel() < s["n_pages"] * REC_PAGE * MARCH_REC_FLOATS:
+                raise _lib.GfnError("page_table / march_rec do not match the paged record form")
+        elif s["march_rec"].numel() < R * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS:
             raise _lib.GfnError("march_rec does not hold 1024 record slots per ray")
     else:
         po = s["pts_offsets"]
@@ -964,7 +981,7 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
             _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
             _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
     if rec:
-        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), *tail)
+        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail)
     else:
         rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), *tail)
     _lib.check(rc, "gfn_fused_render")

@@ -52,17 +52,24 @@ def frame_shard(n_frames, world_size, rank):
 
 class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
-    BYTES_PER_RAY = 1024 * 32 + 6144  # record form: 1024 sample slots of 32 bytes + the traversal's hit lists
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
-                 pipeline=None, decoder_cus=224):
+                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
         tile_rays / tile_width: a tile is a tile_width x (tile_rays / tile_width) BLOCK of pixels (tile_width 0: a raster run);
         None = chosen per image size by choose_tile (~512 Ki rays, dividing the frame).  pipeline: tiles per graph replay
         (their samplers run on a second graph branch, through a ring of two sample buffers); None = the largest divisor of the tile
-        count <= 16 (a full-HD frame: its 4 tiles in one replay)."""
+        count <= 16 (a full-HD frame: its 4 tiles in one replay).  rec_slots: record slots per ray, on average, of a ring buffer of the tile
+        pipeline (the paged record form, ops.sample_rays_record: 7 KB per ray at 224 instead of the 32 KB of 1024 slots for every ray); a
+        frame whose tiles need more is rendered again with a pool half as large again (checked once per frame); 0 or >= 1024: the dense form.
+        hit_cap: leaves per ray of the pipeline's hit lists (12 bytes each; the reference's cap, cfg.max_oct_per_ray = 1024, is 12 KB per ray,
+        6.4 GB for a 518 k-ray tile, where a ray crosses a few dozen leaves): a frame in which a ray reaches the cap is rendered again with four
+        times the cap, up to the reference's -- whose truncation is then the semantics."""
+        self.hit_cap = max(int(hit_cap), 1)
+        self.rec_slots = int(rec_slots) if 0 < int(rec_slots) < 1024 else 0
+        self.pool_regrown = 0  # how often a frame had to be rendered again with a larger record pool
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
         self.block, self.early_T, self.fineness = block, early_T, float(fineness)
@@ -81,7 +88,8 @@ class TileRenderer:
             # the record form costs 32 KB per ray and ring buffer + 6 KB of hit lists: a tile may take a quarter of what is free now
             # (two ring buffers, and the eager warm-ups' cached blocks beside the graph's private pool)
             free = torch.cuda.mem_get_info(self.hp.dev)[0] if self.hp.dev.type == "cuda" else 1 << 40
-            cap = max(int(free // 4 // self.BYTES_PER_RAY) // 32 * 32, 8192)
+            per_ray = (self.rec_slots or 1024) * 32 + 128 + 12 * self.hit_cap  # record slots + page table + the traversal's hit lists
+            cap = max(int(free // 4 // per_ray) // 32 * 32, 8192)
             tw, th = choose_tile(height, width, max_rays=min(cap, MAX_TILE_RAYS))
             T = tw * th
         else:
@@ -115,6 +123,7 @@ class TileRenderer:
         self.graph, self.out = None, None
         self._side = torch.cuda.Stream(device=dev) if self.P > 1 else None
         self._size = (height, width)
+        self._ovf = torch.zeros(1, dtype=torch.int32, device=dev)  # the samplers' overflow words of a frame, or-ed (a ring buffer's own word is zeroed by the next tile)
 
     def _tile(self):
         """-> [(rgb, accumulation, depth)] of the P tiles in the input buffers."""
@@ -139,7 +148,9 @@ class TileRenderer:
                         side.wait_event(used[i - self.SLOTS])
                     # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
                     samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
-                                             record=self.record))
+                                             record=self.record, pool_slots_per_ray=self.rec_slots if self.record else 0,
+                                             max_hits=self.hit_cap if self.record else None))
+                    torch.bitwise_or(self._ovf, samples[-1]["overflow"], out=self._ovf)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     done.append(ev)
@@ -213,12 +224,36 @@ class TileRenderer:
     def render_rays(self, O, D, embed_idx, height, width):
         """The rays of one image, row major: O, D f32 [H*W,3] on the device; embed_idx: the appearance-embedding row of the
         whole image -> dict(rgb [H,W,3], accumulation / depth / oct_depth [H,W,1])."""
+        for _ in range(8):
+            out = self._render_rays(O, D, embed_idx, height, width)
+            if not (self.P > 1 and self.record):
+                return out
+            ovf = int(self._ovf.item())  # (one synchronisation per frame: ~0.1 % of a full-HD frame)
+            hits_short = bool(ovf & ops.HIT_CAP_REACHED) and self.hit_cap < self.hp.cfg.max_oct_per_ray
+            if not (ovf & ops.REC_POOL_OVERFLOW) and not hits_short:
+                return out
+            # a tile's rays needed more record pages than the pool holds: a pool half as large again (the dense form from 1024 slots per ray on);
+            # or a ray crossed more leaves than the hit lists hold: four times the cap.  Captured again, and this frame once more
+            if ovf & ops.REC_POOL_OVERFLOW:
+                self.rec_slots = (int(self.rec_slots * 1.5) + 31) // 32 * 32
+                if self.rec_slots >= 1024:
+                    self.rec_slots = 0
+            if hits_short:
+                self.hit_cap = min(self.hit_cap * 4, self.hp.cfg.max_oct_per_ray)
+                self.hp._record_ws = None  # (hit lists of the old stride)
+            self.pool_regrown += 1
+            self.graph, self.out, self._keep = None, None, None
+            torch.cuda.empty_cache()
+        raise RuntimeError("TileRenderer: the record pool kept overflowing")
+
+    def _render_rays(self, O, D, embed_idx, height, width):
         if self.T is None or (self._want[0] is None and self._size != (height, width)):
             self._setup(height, width)
         hp, T = self.hp, self.T
         n = height * width
         O, D = O.reshape(n, 3), D.reshape(n, 3)
         self.cam.fill_(int(embed_idx))
+        self._ovf.zero_()
         rgb = torch.empty((n, 3), dtype=torch.float32, device=hp.dev)
         acc = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         depth = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)

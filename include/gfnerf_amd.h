@@ -50,8 +50,9 @@ typedef enum {
  *   100: rounds 1-2.   101: round 3 (gfn_adam_step_ex / gfn_fused_forward / gfn_fused_render lost an int, gfn_hash_fwd_lm /
  *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
  *   102: round 4.   103: round 4 (gfn_sample_rays_record, gfn_fused_render_rec added; GFN_MARCH_REC_FLOATS 6 -> 8: a caller's march_rec
- *   buffer grows by a third). */
-#define GFN_ABI_VERSION 104
+ *   buffer grows by a third).   104, 105: round 5 (gfn_set_plane_dither, gfn_set_march_lanes added; one-plane forms of the x3 plane
+ *   arguments; gfn_sample_rays_record / gfn_fused_render_rec gained the paged record form's arguments). */
+#define GFN_ABI_VERSION 105
 
 const char* gfn_last_error(void);
 int gfn_version(void);
@@ -191,12 +192,21 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
 /* The first half of the same only: traversal + counting march.  The samples stay where the march recorded them -- slot k of ray r at
  * march_rec[(r * 1024 + k) * GFN_MARCH_REC_FLOATS], counts[r] of them (table_space does not apply: the record holds the warped point) --
  * for a consumer that walks rays, not packed samples: gfn_fused_render_rec.  No scan, no fill, no second copy of the samples (a
- * 138 k-ray render tile: 1.4 GB of the 2.8 GB its samples cost the memory system).  first_oct_dis f32 [R] as gfn_sample_rays. */
+ * 138 k-ray render tile: 1.4 GB of the 2.8 GB its samples cost the memory system).  first_oct_dis f32 [R] as gfn_sample_rays.
+ * page_table != NULL (round 5): the PAGED form -- march_rec is a pool of n_pages pages of GFN_REC_PAGE slots, handed to the rays as they
+ * march (one atomic counter, page_counter i32 [1], zeroed here); page p of ray r is page_table[r * (1024 / GFN_REC_PAGE) + p] (i32
+ * [R * 32]; entries beyond a ray's count are not written), slot k of ray r at march_rec[(page_table[r * 32 + k / 32] * 32 + k % 32) *
+ * GFN_MARCH_REC_FLOATS].  The pool is sized by the samples (~7 KB per ray at 180 samples per ray) instead of the cap (32 KB per ray); when it
+ * runs out, bit 16 of *overflow_dev is set (the slots written from then on alias the pool's last page): the caller samples again
+ * into a larger pool.  Bit 8 (gfn_sample_rays too): some ray's traversal stopped at max_hits leaves with nodes still to visit -- the
+ * reference's truncation at its max_oct_intersect_per_ray = 1024; a caller that passes a smaller max_hits (hit lists of n_rays *
+ * max_hits entries) finds out here that it must ask again with a larger one. */
 int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
-                           float* march_rec, int tree_depth, void* stream);
+                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int tree_depth,
+                           void* stream);
 
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
@@ -351,6 +361,8 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
  * the pool) while later ranges still accumulate. */
 #define GFN_GRAD_RANGE_LOG2 14
 #define GFN_MARCH_REC_FLOATS 8 /* per sample slot of gfn_sample_rays' march_rec: t, dist, leaf (i32), transform (i32), warped x y z, block (i32) */
+#define GFN_REC_PAGE_LOG2 5    /* gfn_sample_rays_record's paged form: pages of 32 sample slots (1 KB) */
+#define GFN_REC_PAGE (1 << GFN_REC_PAGE_LOG2)
 #define GFN_GRAD_MAX_RANGES 1088
 int gfn_grad_record_ranges(int log2_T);
 int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_t record_capacity, int log2_T,
@@ -443,8 +455,9 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
                      float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
 /* The same on the samples of gfn_sample_rays_record: counts i32 [R] and march_rec (16-byte aligned) instead of the packed arrays.  Slot k
  * of ray r is read where the counting march left it; the table-space point is made from the recorded warped point as the fill pass
- * makes it ((w + 1.5) * (1/3)), so the images are the bits of gfn_sample_rays(table_space = 1) + gfn_fused_render. */
-int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const uint16_t* table_f16,
+ * makes it ((w + 1.5) * (1/3)), so the images are the bits of gfn_sample_rays(table_space = 1) + gfn_fused_render.
+ * page_table: NULL, or the page table of gfn_sample_rays_record's paged form (march_rec is then the page pool). */
+int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16,
                          const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                          int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                          const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,

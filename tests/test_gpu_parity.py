@@ -933,3 +933,48 @@ def test_grad_records_reduce_exact_and_f16_paths(ops, dev):
     out = pool.float().cpu().numpy()
     assert np.isnan(out[pool_slots - 5, 0]) and out[pool_slots - 5, 1] == 1.0 and np.isfinite(out[:32768]).all()
     assert np.array_equal(out[:16384].astype(np.float64), exact16[:16384])
+
+
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_sample_record_paged_form_holds_the_same_samples(oracle, ops, dev, set_march_lanes, lanes):
+    """gfn_sample_rays_record with a page pool (round 5): pages of 32 record slots handed to the rays as they march instead of 1024 slots
+    for every ray.  Slot k of ray r -- at (page_table[r * 32 + k / 32] * 32 + k % 32) -- holds the dense form's record bit for bit; every
+    page is handed out once; a pool that is too small sets bit 16 of the overflow word and writes nothing outside the pool."""
+    import torch
+
+    from gfnerf_amd import scene
+
+    set_march_lanes(lanes)
+    n_rays = 160
+    sc, ref, _ = _sample_both(oracle, ops, dev, n_rays=n_rays, train=True, fineness=6.0)
+    noise = _t(scene.make_noise(n_rays, True, 6.0, seed=1), dev)
+    cn, tr = ops.tree_compact(_t(sc["nodes"], dev)), _t(sc["transes"], dev)
+    o, d = _t(ref["o"], dev), _t(ref["d"], dev)
+    dense = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True)
+    cnt = dense["counts"].cpu().numpy()
+    need = int(np.ceil(cnt / 32).sum())  # pages the rays need
+    mean = float(cnt.mean())
+    paged = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True, pool_slots_per_ray=int(mean) + 40)
+    assert paged["n_pages"] >= need and int(paged["overflow"].item()) == 0 and int(paged["page_counter"].item()) == need
+    assert torch.equal(paged["counts"], dense["counts"]) and torch.equal(paged["first_oct_dis"], dense["first_oct_dis"])
+    D = dense["march_rec"].view(n_rays, ops.MAX_SAMPLE_PER_RAY, ops.MARCH_REC_FLOATS).cpu().numpy().view(np.uint32)
+    P = paged["march_rec"].view(-1, ops.REC_PAGE, ops.MARCH_REC_FLOATS).cpu().numpy().view(np.uint32)
+    pt = paged["page_table"].view(n_rays, ops.MAX_SAMPLE_PER_RAY // ops.REC_PAGE).cpu().numpy()
+    used = []
+    for r in range(n_rays):
+        for p in range((cnt[r] + 31) // 32):
+            k0, k1 = 32 * p, min(32 * p + 32, cnt[r])
+            assert 0 <= pt[r, p] < paged["n_pages"]
+            used.append(int(pt[r, p]))
+            assert np.array_equal(P[pt[r, p], : k1 - k0], D[r, k0:k1]), (r, p)
+    assert sorted(used) == list(range(need))  # every page handed out exactly once
+    # written again in place (the tile pipeline's ring): the same result, the counter starts from zero again
+    again = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True, out=paged)
+    assert again is paged and int(paged["page_counter"].item()) == need and int(paged["overflow"].item()) == 0
+    # a pool of half the pages: flagged, and nothing written outside it
+    small = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True, pool_slots_per_ray=max(int(mean) // 2, 1))
+    assert small["n_pages"] < need and int(small["overflow"].item()) & ops.REC_POOL_OVERFLOW
+    assert torch.equal(small["counts"], dense["counts"])
+    pts = small["page_table"].view(n_rays, -1).cpu().numpy()
+    for r in range(n_rays):
+        assert (pts[r, : (cnt[r] + 31) // 32] < small["n_pages"]).all() and (pts[r, : (cnt[r] + 31) // 32] >= 0).all()

@@ -813,6 +813,49 @@ def test_tile_pipeline_without_the_patch_kernel(setup, variant):
     np.testing.assert_allclose(imgs[variant].cpu().numpy(), imgs["default"].cpu().numpy(), atol=tol)
 
 
+def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_runs_out(setup):
+    """the tile pipeline's ring buffers hold the march's records in pages from a pool of `rec_slots` slots per ray
+    (224 by default: 7 KB per ray) instead of 1024 slots for every ray (32 KB).  The image is the dense form's bit for bit; a pool that is too
+    small (rec_slots = 32 here) is noticed at the end of the frame -- the samplers' overflow words, or-ed over the frame's tiles -- and
+    the frame is rendered again with a pool half as large again, until it fits.  The same for the traversal's hit lists: 128 leaves per ray
+    by default instead of the reference's cap of 1024 (a ray that reaches the cap: four times the cap, and the frame again)."""
+    import torch
+
+    from gfnerf_amd import hotpath
+    from gfnerf_amd import render as rmod
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    c2w = t(sc["c2w"])
+    K = sc["intri"]
+    intr = t(np.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1).astype(np.float32))
+    H, W = 256, 384  # three tiles of 128 x 256 = 32,768 rays through a ring of two buffers
+    intr2 = intr.clone(); intr2[:, 2] = W / 2; intr2[:, 3] = H / 2; intr2[:, 0] *= 0.25; intr2[:, 1] *= 0.25
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=S["cfg"], seed=1, n_blocks=1)
+    hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(5)); hp.refresh_shadows()
+    imgs, foot = {}, {}
+    for name, slots, hits in (("dense", 0, 1024), ("paged", 224, 128), ("starved", 32, 2)):
+        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=3, rec_slots=slots, hit_cap=hits)
+        out = tr.render_camera(3, H, W)
+        imgs[name] = (out["rgb"].clone(), out["depth"].clone())
+        again = tr.render_camera(3, H, W)  # a second frame through the same capture
+        assert torch.equal(again["rgb"], imgs[name][0])
+        foot[name] = tr.footprint_bytes()
+        assert tr.record and tr.P == 3
+        if name == "dense":
+            assert tr.rec_slots == 0 and tr.pool_regrown == 0
+        elif name == "paged":
+            assert tr.rec_slots == 224 and tr.hit_cap == 128 and tr.pool_regrown == 0
+        else:
+            assert tr.pool_regrown >= 1 and tr.rec_slots > 32 and tr.hit_cap > 2, (tr.pool_regrown, tr.rec_slots, tr.hit_cap)
+        del tr
+        torch.cuda.empty_cache()
+    assert float(imgs["dense"][0].std()) > 0.003
+    for name in ("paged", "starved"):
+        assert torch.equal(imgs[name][0], imgs["dense"][0]) and torch.equal(imgs[name][1], imgs["dense"][1]), name
+    assert foot["paged"] < 0.45 * foot["dense"], foot
+
+
 def test_step_graph_replays_without_host_sync_use_each_steps_own_adam_factors(setup):
     """StepGraph replays enqueued back to back, the host several steps ahead of the device (nothing is read back in between): Adam's
     step-dependent factors -- they travel through a ring of pinned blocks, one per replay -- must still be those of the step being
