@@ -1348,9 +1348,10 @@ def test_psnr_of_the_product_against_the_reference_semantics():
          on the rays whose error is that small;
       3. trained end to end (reduced length: 1,500 + 400 steps, four seeds), the product's leg ("fast") against the reference-semantics leg
          ("reference": early_T = 0, every sample, exact-f32 decoder, f16 atomics, torch.optim.Adam; engine/trainer.py:382-441,
-         gfnerf/nerfacto.py:522-619,628-689), paired by seed: |mean difference| <= 0.1 dB + 2 standard errors.  One training run is one draw
-         (Adam at eps = 1e-15 amplifies last-bit differences), so the standard error of four pairs is what bounds this statement; the
-         many-seed record narrows it (+0.001 +- 0.038 dB over 148 pairs)."""
+         gfnerf/nerfacto.py:522-619,628-689), paired by seed: a SANITY bound only, |mean difference| <= 0.1 dB + 3 x max(standard error, 0.3 dB)
+         ~ 1.0 dB.  One training run is one draw (Adam at eps = 1e-15 amplifies last-bit differences; pairs scatter by ~0.5 dB), so four
+         short pairs cannot resolve 0.1 dB and a tighter gate on them would fail by chance; the claim itself -- within 0.1 dB -- is the
+         many-seed record's (+0.001 +- 0.038 dB over 148 pairs), held to the protocol in the tree by tests/test_procedural.py."""
     import torch
 
     import gfnerf_amd  # noqa: F401

@@ -54,3 +54,34 @@ def test_psnr_record_of_the_round():
     g = rec["grad_cosine"]["min_cos"]
     assert min(g["exact|reference"].values()) > 0.99999 and min(g["exact|fast0"].values()) > 0.99999 and min(g["fast|f32"].values()) > 0.99999
     assert min(g["exact|fast"].values()) > 0.999                                   # the cut moves the gradient through the sign-like loss: DESIGN.md section 7
+
+
+def test_octree_study_record_of_the_round():
+    """profiles/r05_octree_study.json (tools/octree_study.py) and the sentences INTEGRATION.md section 5 / DESIGN.md section 4
+    make about it: >= 16 seeds, the summary recomputed from the rows, and every figure the documents quote is the record's."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import octree_study as st
+
+    rec = json.load(open(os.path.join(root, "profiles", "r05_octree_study.json")))
+    rows, summ = rec["rows"], rec["summary"]
+    assert len(rows) >= 16 and summ["n_seeds"] == len(rows) and sorted(r["seed"] for r in rows) == list(range(len(rows)))
+    assert st.summarise(rows) == summ  # the statistics are the rows'
+    c, n, n8, c8 = (summ["legs"][k] for k in ("cut", "no_cut", "no_cut_eps8", "cut_eps8"))
+    p = summ["pairs"]["cut|no_cut"]
+    q = summ["pairs"]["no_cut|no_cut_eps8"]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for text in (f"{c['valid_leaves_mean']} +- {c['valid_leaves_se']} valid leaves", f"{n['valid_leaves_mean']} +- {n['valid_leaves_se']}",
+                 f"{p['valid_leaves_diff_mean']} +- {p['valid_leaves_diff_se']} leaves ({100 * p['valid_leaves_diff_rel']:.1f} %)",
+                 f"in {p['seeds_with_more_only_in_b']} of {len(rows)} seeds", f"sign test p = {p['sign_test_p']:.3f}", f"Jaccard index {p['jaccard_mean']:.2f}",
+                 f"+{p['psnr_diff_mean']:.2f} +- {p['psnr_diff_se']:.2f} dB on held-out pixels", f"+{p['psnr_heldout_cams_diff_mean']:.2f} +- {p['psnr_heldout_cams_diff_se']:.2f} dB from held-out cameras",
+                 f"{n8['valid_leaves_mean']} +- {n8['valid_leaves_se']}", f"= {q['valid_leaves_diff_mean']}\n  +- {q['valid_leaves_diff_se']}", f"{c8['valid_leaves_mean']} +- {c8['valid_leaves_se']}"):
+        assert text in doc, text
+    # the statements themselves: one-sided (p < 0.05), no loss of held-out PSNR beyond two standard errors, eps is not the mechanism (no_cut keeps its leaves)
+    assert p["sign_test_p"] < 0.05 and p["seeds_with_more_only_in_b"] > p["seeds_with_more_only_in_a"] and p["valid_leaves_diff_mean"] < 0
+    assert p["psnr_heldout_cams_diff_mean"] > -2 * p["psnr_heldout_cams_diff_se"] and p["psnr_diff_mean"] > -2 * p["psnr_diff_se"]
+    assert q["valid_leaves_diff_mean"] < 2 * q["valid_leaves_diff_se"]  # eps 1e-8 does not prune the no_cut leg
