@@ -35,7 +35,8 @@ SIGNATURES = {
     "gfn_tree_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_sample_rays": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
-    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "gfn_sample_rays_continue": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_update_nodes_mark": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -71,7 +72,7 @@ SIGNATURES = {
     "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
                          _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
-                             _vp, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),

@@ -56,6 +56,8 @@ class HotPathConfig:
                                      # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
     lm_halves_from: int = 6          # levels >= this are gathered one address part at a time ...
     lm_split_log2: int = 0           # ... of 2^this parts per level (0 = 1: halves; 2: quarters, no gain inside the step)
+    render_first_k: int = 0          # inference (TileRenderer's pipeline): two-phase march -- every ray marched this many samples deep first, the rays still
+                                     # transparent there marched again and resumed (0: every ray marched to its end)
     render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
@@ -269,14 +271,16 @@ class HotPath:
             self._depth_key = key
         return self._depth_val
 
-    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False, pool_slots_per_ray=0, max_hits=None):
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False, pool_slots_per_ray=0, max_hits=None, sample_cap=0,
+               own_workspace=False):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
         returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph).
         record: traversal + counting march only (ops.sample_rays_record) -- the samples stay in the march's records, for
         render(tile_width=...), whose patch kernel reads them there (no scan, no fill, no packed copy); pool_slots_per_ray > 0: in pages
         from a pool of that many slots per ray on average instead of 1024 slots for every ray (ops.sample_rays_record); max_hits: leaves per
         ray of the record form's hit lists (default cfg.max_oct_per_ray = the reference's 1024: 12 KB per ray; a caller that passes less
-        checks ops.HIT_CAP_REACHED in the overflow word)."""
+        checks ops.HIT_CAP_REACHED in the overflow word); sample_cap: phase A of the two-phase march (ops.sample_rays_record); own_workspace: the
+        hit lists belong to the returned dict (a ring of sample buffers whose phase B reads them while the next tile is traversed)."""
         c = self.cfg
         pre, self._pre = self._pre, None
         if not record and pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
@@ -297,9 +301,10 @@ class HotPath:
         if record:
             s = self._timed("sample", ops.sample_rays_record, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l, c.scale_by_dis,
                             near=c.global_near, far=1e8, max_hits=min(int(max_hits), c.max_oct_per_ray) if max_hits else c.max_oct_per_ray,
-                            workspace=self._record_ws if self._record_ws is not None else self._sampler_ws,  # (the hit lists of the packed form will do)
-                            out=out, tree_depth=self.tree_depth(), pool_slots_per_ray=pool_slots_per_ray)
-            if s["workspace"] is not self._sampler_ws:
+                            workspace=(out["workspace"] if out is not None else None) if own_workspace else
+                            (self._record_ws if self._record_ws is not None else self._sampler_ws),  # (the hit lists of the packed form will do)
+                            out=out, tree_depth=self.tree_depth(), pool_slots_per_ray=pool_slots_per_ray, sample_cap=sample_cap)
+            if s["workspace"] is not self._sampler_ws and not own_workspace:
                 self._record_ws = s["workspace"]
             s["dirs_unit"], s["sh"] = d, sh
             return s

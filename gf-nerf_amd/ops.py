@@ -296,13 +296,19 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
 
 
 def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8, max_hits=MAX_OCT_PER_RAY,
-                       workspace=None, out=None, tree_depth=0, pool_slots_per_ray=0):
+                       workspace=None, out=None, tree_depth=0, pool_slots_per_ray=0, sample_cap=0):
     """gfn_sample_rays_record: traversal + counting march only -> dict(counts i32 [R], first_oct_dis [R], march_rec f32 [R * 1024 * 8],
     overflow, workspace): the samples stay where the march recorded them (slot k of ray r at (r * 1024 + k) * MARCH_REC_FLOATS), for
     fused_render's record form.  out: the dict of an earlier call with the same R, written again in place.
     pool_slots_per_ray > 0: the PAGED form -- march_rec is a pool of R * pool_slots_per_ray / 32 pages of 32 slots, page_table i32
     [R * 32] says where each ray's pages are: sized by the samples the rays have, not by the 1024 they may have (7 KB instead of 32 KB
-    per ray at 224).  When the pool runs out, overflow gets bit REC_POOL_OVERFLOW: sample again with a larger pool."""
+    per ray at 224).  When the pool runs out, overflow gets bit REC_POOL_OVERFLOW: sample again with a larger pool.
+    sample_cap > 0 (a multiple of 32; needs the paged form): phase A of the two-phase march -- at most sample_cap samples per ray, out["more"]
+    i32 [R] = 1 where the cap ended the march; fused_render then composites them, marches the rays still transparent there again
+    (gfn_sample_rays_continue) and resumes them.  What lies behind a ray's termination point is neither marched nor recorded."""
+    sample_cap = int(sample_cap)
+    if sample_cap and (sample_cap % REC_PAGE or not 0 < sample_cap < MAX_SAMPLE_PER_RAY or pool_slots_per_ray <= 0 and out is None):
+        raise _lib.GfnError("sample_rays_record: sample_cap must be a multiple of 32 below 1024 and needs the paged form (pool_slots_per_ray)")
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
     _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
     R = rays_o.shape[0]
@@ -314,8 +320,8 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
                          hit_nf=torch.empty((max(R * max_hits, 1), 2), dtype=torch.float32, device=dev))
     if out is not None:
-        if out["counts"].numel() != R:
-            raise _lib.GfnError("sample_rays_record: `out` was made for another batch size")
+        if out["counts"].numel() != R or bool(sample_cap) != (out.get("more") is not None):
+            raise _lib.GfnError("sample_rays_record: `out` was made for another batch size or march form")
         out["overflow"].zero_()
         out["workspace"] = workspace
     elif pool_slots_per_ray > 0:
@@ -325,6 +331,9 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                    page_table=torch.empty(max(R, 1) * (MAX_SAMPLE_PER_RAY // REC_PAGE), dtype=torch.int32, device=dev),
                    page_counter=torch.zeros(1, dtype=torch.int32, device=dev), n_pages=n_pages,
                    overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace)
+        if sample_cap:
+            out.update(more=torch.empty(R, dtype=torch.int32, device=dev), state=torch.empty(max(R, 1) * 8, dtype=torch.float32, device=dev),
+                       cont_list=torch.empty(max(R, 1), dtype=torch.int32, device=dev), cont_n=torch.zeros(1, dtype=torch.int32, device=dev))
     else:
         out = dict(counts=torch.empty(R, dtype=torch.int32, device=dev), first_oct_dis=torch.empty(R, dtype=torch.float32, device=dev),
                    march_rec=torch.empty(max(R, 1) * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS, dtype=torch.float32, device=dev),
@@ -333,9 +342,26 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                                            float(sample_l), int(bool(scale_by_dis)), _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]),
                                            _ptr(workspace["hit_nf"]), _ptr(out["counts"]), _ptr(out["first_oct_dis"]), _ptr(out["overflow"]),
                                            _ptr(out["march_rec"]), _ptr(out.get("page_table")), _ptr(out.get("page_counter")), int(out.get("n_pages", 0)),
-                                           int(tree_depth), _stream())
+                                           sample_cap, _ptr(out.get("more")), int(tree_depth), _stream())
     _lib.check(rc, "gfn_sample_rays_record")
+    if sample_cap:  # what phase B of the march needs again (the same rays, noise and hit lists: the same samples)
+        out["sample_cap"] = sample_cap
+        out["_march"] = dict(rays_o=rays_o, rays_d=rays_d, noise=noise, compact_nodes=compact_nodes, transes=transes, sample_l=float(sample_l),
+                             scale_by_dis=int(bool(scale_by_dis)), max_hits=int(max_hits))
     return out
+
+
+def sample_rays_continue(s):
+    """Phase B of the two-phase march (gfn_sample_rays_continue): the rays s["cont_list"][: s["cont_n"]] (fused_render's phase A listed them:
+    still transparent where the capped march ended) marched again from the start, recording the samples from s["sample_cap"] on into pages
+    of the same pool; s["counts"] of those rays becomes their full count."""
+    m, ws = s["_march"], s["workspace"]
+    R = s["counts"].numel()
+    rc = _lib.lib().gfn_sample_rays_continue(_ptr(m["rays_o"]), _ptr(m["rays_d"]), _ptr(m["noise"]), R, _ptr(m["compact_nodes"]), _ptr(m["transes"]), m["max_hits"],
+                                             m["sample_l"], m["scale_by_dis"], _ptr(ws["hit_counts"]), _ptr(ws["hit_idx"]), _ptr(ws["hit_nf"]), _ptr(s["counts"]),
+                                             _ptr(s["overflow"]), _ptr(s["march_rec"]), _ptr(s["page_table"]), _ptr(s["page_counter"]), int(s["n_pages"]),
+                                             _ptr(s["cont_list"]), _ptr(s["cont_n"]), int(s["sample_cap"]), _stream())
+    _lib.check(rc, "gfn_sample_rays_continue")
 
 
 def tree_depth(nodes):
@@ -980,8 +1006,14 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
     tail = (_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
             _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
             _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
-    if rec:
-        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail)
+    if rec and s.get("more") is not None:  # the two-phase march: composite the capped samples, march the rays still transparent again, resume them
+        head = (_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s["page_table"]))
+        rc = _lib.lib().gfn_fused_render_rec(*head, *tail[:-1], _ptr(s["more"]), _ptr(s["state"]), _ptr(s["cont_list"]), _ptr(s["cont_n"]), None, None, 0, _stream())
+        _lib.check(rc, "gfn_fused_render_rec (phase A)")
+        sample_rays_continue(s)
+        rc = _lib.lib().gfn_fused_render_rec(*head, *tail[:-1], None, _ptr(s["state"]), None, None, _ptr(s["cont_list"]), _ptr(s["cont_n"]), int(s["sample_cap"]), _stream())
+    elif rec:
+        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail[:-1], None, None, None, None, None, None, 0, _stream())
     else:
         rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), *tail)
     _lib.check(rc, "gfn_fused_render")

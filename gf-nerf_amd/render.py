@@ -54,7 +54,7 @@ class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
-                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128):
+                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128, first_k=None):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
@@ -68,6 +68,10 @@ class TileRenderer:
         6.4 GB for a 518 k-ray tile, where a ray crosses a few dozen leaves): a frame in which a ray reaches the cap is rendered again with four
         times the cap, up to the reference's -- whose truncation is then the semantics."""
         self.hit_cap = max(int(hit_cap), 1)
+        # the two-phase march (ops.sample_rays_record's sample_cap): the tile's rays are marched first_k samples deep, composited, and only the rays
+        # still transparent there are marched again and resumed; None: hp.cfg.render_first_k; 0: off (every ray marched to its end)
+        fk = hp.cfg.render_first_k if first_k is None else first_k
+        self.first_k = int(fk) // 32 * 32 if self.rec_slots else 0
         self.rec_slots = int(rec_slots) if 0 < int(rec_slots) < 1024 else 0
         self.pool_regrown = 0  # how often a frame had to be rendered again with a larger record pool
         self.hp = hp
@@ -149,7 +153,8 @@ class TileRenderer:
                     # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
                     samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
                                              record=self.record, pool_slots_per_ray=self.rec_slots if self.record else 0,
-                                             max_hits=self.hit_cap if self.record else None))
+                                             max_hits=self.hit_cap if self.record else None,
+                                             sample_cap=self.first_k if (self.record and self.rec_slots) else 0, own_workspace=self.record and self.first_k > 0))
                     torch.bitwise_or(self._ovf, samples[-1]["overflow"], out=self._ovf)
                     ev = torch.cuda.Event()
                     ev.record(side)

@@ -200,13 +200,24 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
  * runs out, bit 16 of *overflow_dev is set (the slots written from then on alias the pool's last page): the caller samples again
  * into a larger pool.  Bit 8 (gfn_sample_rays too): some ray's traversal stopped at max_hits leaves with nodes still to visit -- the
  * reference's truncation at its max_oct_intersect_per_ray = 1024; a caller that passes a smaller max_hits (hit lists of n_rays *
- * max_hits entries) finds out here that it must ask again with a larger one. */
+ * max_hits entries) finds out here that it must ask again with a larger one.
+ * sample_cap > 0 (a multiple of GFN_REC_PAGE): phase A of a TWO-PHASE march -- at most sample_cap samples per ray; more i32 [R]
+ * receives 1 where the cap, not the ray's end, stopped the march.  gfn_fused_render_rec composites those samples and lists the rays
+ * that are still transparent there; gfn_sample_rays_continue marches the listed rays again (same hit lists, same noise: the same
+ * samples) and records the samples from record_from = sample_cap on, pages from the same pool (page_counter is NOT reset),
+ * counts[ray] = the ray's full count; gfn_fused_render_rec then resumes those rays.  What lies behind the point where a ray
+ * becomes opaque is neither marched nor recorded (41 % of a fog scene's samples). */
 int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
-                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int tree_depth,
-                           void* stream);
+                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int sample_cap,
+                           int32_t* more, int tree_depth, void* stream);
+int gfn_sample_rays_continue(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
+                             const void* compact_nodes, const void* transes, int max_hits, float sample_l, int scale_by_dis,
+                             int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far, int32_t* counts, int32_t* overflow_dev,
+                             float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages,
+                             const int32_t* ray_list, const int32_t* list_n, int record_from, void* stream);
 
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
@@ -456,12 +467,19 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
 /* The same on the samples of gfn_sample_rays_record: counts i32 [R] and march_rec (16-byte aligned) instead of the packed arrays.  Slot k
  * of ray r is read where the counting march left it; the table-space point is made from the recorded warped point as the fill pass
  * makes it ((w + 1.5) * (1/3)), so the images are the bits of gfn_sample_rays(table_space = 1) + gfn_fused_render.
- * page_table: NULL, or the page table of gfn_sample_rays_record's paged form (march_rec is then the page pool). */
+ * page_table: NULL, or the page table of gfn_sample_rays_record's paged form (march_rec is then the page pool).
+ * Two-phase march (all NULL / 0 otherwise).  Phase A: more = gfn_sample_rays_record's flags -- a ray that is still transparent after
+ * its (capped) samples and has more[ray] set leaves its compositing state in state f32 [R * 8] (16-byte aligned) and its index in
+ * cont_list i32 [R] (*cont_n of them, zeroed by this launch); its outputs are partial until phase B.  Phase B: ray_list / list_n =
+ * that list and count; patches are runs of 32 list entries (tile_width is ignored), every ray resumes from its state at sample
+ * k_first (= the cap) and its outputs are written again; t_minmax accumulates over both launches. */
 int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16,
                          const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                          int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                          const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
-                         float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
+                         float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const int32_t* more,
+                         float* state, int32_t* cont_list, int32_t* cont_n, const int32_t* ray_list, const int32_t* list_n,
+                         int k_first, void* stream);
 
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's

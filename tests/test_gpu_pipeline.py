@@ -818,7 +818,9 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
     (224 by default: 7 KB per ray) instead of 1024 slots for every ray (32 KB).  The image is the dense form's bit for bit; a pool that is too
     small (rec_slots = 32 here) is noticed at the end of the frame -- the samplers' overflow words, or-ed over the frame's tiles -- and
     the frame is rendered again with a pool half as large again, until it fits.  The same for the traversal's hit lists: 128 leaves per ray
-    by default instead of the reference's cap of 1024 (a ray that reaches the cap: four times the cap, and the frame again)."""
+    by default instead of the reference's cap of 1024 (a ray that reaches the cap: four times the cap, and the frame again).  And the
+    two-phase march (first_k = 32 / 64 here): every ray marched first_k samples deep and composited, the rays still
+    transparent there marched again and resumed from their compositing state -- the same image bit for bit."""
     import torch
 
     from gfnerf_amd import hotpath
@@ -834,8 +836,9 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=S["cfg"], seed=1, n_blocks=1)
     hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(5)); hp.refresh_shadows()
     imgs, foot = {}, {}
-    for name, slots, hits in (("dense", 0, 1024), ("paged", 224, 128), ("starved", 32, 2)):
-        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=3, rec_slots=slots, hit_cap=hits)
+    for name, slots, hits, fk in (("dense", 0, 1024, 0), ("paged", 224, 128, 0), ("starved", 32, 2, 0), ("two_phase", 224, 128, 32), ("two_phase_64", 224, 128, 64)):
+        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=3, rec_slots=slots, hit_cap=hits,
+                               first_k=fk)
         out = tr.render_camera(3, H, W)
         imgs[name] = (out["rgb"].clone(), out["depth"].clone())
         again = tr.render_camera(3, H, W)  # a second frame through the same capture
@@ -846,12 +849,18 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
             assert tr.rec_slots == 0 and tr.pool_regrown == 0
         elif name == "paged":
             assert tr.rec_slots == 224 and tr.hit_cap == 128 and tr.pool_regrown == 0
+        elif name.startswith("two_phase"):
+            # the two-phase march: first_k samples of every ray, then the rays still transparent there again -- some rays continue, most do not
+            k = tr._keep[0]
+            n_cont, cnt, more = int(k["cont_n"].item()), k["counts"], k["more"]
+            assert tr.first_k == fk and tr.pool_regrown == 0 and 0 < n_cont < int((more != 0).sum().item()) <= tr.T, (n_cont, int((more != 0).sum().item()))
+            assert int(cnt.max().item()) > fk  # (the continued rays have their full counts)
         else:
             assert tr.pool_regrown >= 1 and tr.rec_slots > 32 and tr.hit_cap > 2, (tr.pool_regrown, tr.rec_slots, tr.hit_cap)
         del tr
         torch.cuda.empty_cache()
     assert float(imgs["dense"][0].std()) > 0.003
-    for name in ("paged", "starved"):
+    for name in ("paged", "starved", "two_phase", "two_phase_64"):  # the same images bit for bit (depth: the clip range never binds)
         assert torch.equal(imgs[name][0], imgs["dense"][0]) and torch.equal(imgs[name][1], imgs["dense"][1]), name
     assert foot["paged"] < 0.45 * foot["dense"], foot
 

@@ -1,9 +1,11 @@
-"""Copy the summaries of a tools/r04_profiles.sh run (gpurun_out/r04p: both modes) into profiles/r04_* and refresh profiles/pmc_traffic.json
+"""Copy the summaries of a tools/rNN_profiles.sh run (gpurun_out/rNNp: modes traces + pmc) into profiles/rNN_* and refresh profiles/pmc_traffic.json
+    python tools/sync_profiles.py gpurun_out/r05p r05
 (what bench.py reads for roofline.traffic / request_rate / mfma_busy_frac; the hashes of the kernel sources the counters were
 collected on are recorded beside them, and bench.py reports none of it for other sources)."""
 import csv, glob, hashlib, json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04p"
-TAG = "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r05p"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
+PREV = "r%02d" % (int(TAG[1:]) - 1)
 py = sys.executable
 for t in ("focal_graph", "global_graph"):
     subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_{t}", f"profiles/{TAG}_{t}_kernel_stats.csv"])
@@ -22,11 +24,11 @@ subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}
 p = "profiles/pmc_traffic.json"
 old = json.load(open(p))
 j = {k: old[k] for k in ("gather_request_ceiling_per_s", "l2_gather_ceiling_per_s")}
-for k in ("r01", "r02", "r03"):
-    if k in old:
-        j[k] = old[k]
-if "r03" not in old:  # the previous round's figures move under their key
-    j["r03"] = {k: v for k, v in old.items() if k not in ("r01", "r02", "gather_request_ceiling_per_s", "l2_gather_ceiling_per_s")}
+rounds = [k for k in old if len(k) == 3 and k[0] == "r" and k[1:].isdigit()]
+for k in rounds:
+    j[k] = old[k]
+if PREV not in old:  # the previous round's figures move under their key
+    j[PREV] = {k: v for k, v in old.items() if k not in rounds + ["gather_request_ceiling_per_s", "l2_gather_ceiling_per_s"]}
 load = lambda pp: {r["kernel"]: r for r in csv.DictReader(open(pp))}
 f, g = load(f"profiles/{TAG}_pmc_focal_per_kernel.csv"), load(f"profiles/{TAG}_pmc_global_per_kernel.csv")
 tr = lambda r: int(round((2 * float(r["FETCH_SIZE_mean"]) + float(r["WRITE_SIZE_mean"])) * 1024))
@@ -39,8 +41,8 @@ busy = lambda r: round(float(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"]) / (float(r["GRB
 lm = sorted([r for k, r in f.items() if "lm_lookup" in k], key=lambda r: -float(r["FETCH_SIZE_mean"]))
 n_launch_rows = len(lm)
 j["n_side"] = 40
-j["_note"] = ("HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes of the r04 build on the default workload "
-              "(1,600 cameras, T = 2^21, own primes per table, early_T 1e-4, phased forward): profiles/r04_pmc_{focal,global,render}_per_kernel.csv.  2 x: a request moves a 128-byte "
+j["_note"] = ("HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes of the " + TAG + " build on the default workload "
+              "(1,600 cameras, T = 2^21, own primes per table, early_T 1e-4, phased forward): profiles/" + TAG + "_pmc_{focal,global,render}_per_kernel.csv.  2 x: a request moves a 128-byte "
               "line and is tallied as 64 bytes (profiles/r02_pmc_fetch_calibration.csv).  lm_lookup rows are means over ALL launches of a kernel instantiation, "
               f"phase-B launches that return at once included ({n_launch_rows} instantiations): bench.py uses the per-launch figures of the instantiation with the larger FETCH.")
 # per-launch means include the gated phase-B launches (no traffic): scale to the launches that work.  launches column = per pass
