@@ -396,7 +396,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
         roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
     fp = tr.footprint_bytes()
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
-                hbm_footprint_gb=None if fp is None else fp / 1e9, march_first_k=tr.first_k, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
+                hbm_footprint_gb=None if fp is None else fp / 1e9, march_first_k=tr.first_k, march_continued_frac=tr.continued_frac, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
                 record_pool_regrown=tr.pool_regrown,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,

@@ -71,8 +71,9 @@ class TileRenderer:
         # the two-phase march (ops.sample_rays_record's sample_cap): the tile's rays are marched first_k samples deep, composited, and only the rays
         # still transparent there are marched again and resumed; None: hp.cfg.render_first_k; 0: off (every ray marched to its end)
         fk = hp.cfg.render_first_k if first_k is None else first_k
-        self.first_k = int(fk) // 32 * 32 if self.rec_slots else 0
         self.rec_slots = int(rec_slots) if 0 < int(rec_slots) < 1024 else 0
+        self.first_k = int(fk) // 32 * 32 if self.rec_slots else 0
+        self.continued_frac = 0.0  # rays of the last frame the two-phase march had to continue, as a fraction of the frame
         self.pool_regrown = 0  # how often a frame had to be rendered again with a larger record pool
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
@@ -127,7 +128,9 @@ class TileRenderer:
         self.graph, self.out = None, None
         self._side = torch.cuda.Stream(device=dev) if self.P > 1 else None
         self._size = (height, width)
-        self._ovf = torch.zeros(1, dtype=torch.int32, device=dev)  # the samplers' overflow words of a frame, or-ed (a ring buffer's own word is zeroed by the next tile)
+        # per frame, read back once at its end: [0] the tiles' overflow words or-ed (a ring buffer's own word is zeroed by the next tile into it),
+        # [1] the rays the two-phase march had to continue, summed over the tiles
+        self._stat = torch.zeros(2, dtype=torch.int32, device=dev)
 
     def _tile(self):
         """-> [(rgb, accumulation, depth)] of the P tiles in the input buffers."""
@@ -155,7 +158,6 @@ class TileRenderer:
                                              record=self.record, pool_slots_per_ray=self.rec_slots if self.record else 0,
                                              max_hits=self.hit_cap if self.record else None,
                                              sample_cap=self.first_k if (self.record and self.rec_slots) else 0, own_workspace=self.record and self.first_k > 0))
-                    torch.bitwise_or(self._ovf, samples[-1]["overflow"], out=self._ovf)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     done.append(ev)
@@ -200,6 +202,10 @@ class TileRenderer:
         main.wait_event(done[i])
         out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw)
         outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
+        if self.record:  # (behind the tile's last kernel: phase B of the march can exhaust the page pool too)
+            torch.bitwise_or(self._stat[0:1], samples[i]["overflow"], out=self._stat[0:1])
+            if samples[i].get("cont_n") is not None:
+                self._stat[1:2].add_(samples[i]["cont_n"])
         ev = torch.cuda.Event()
         ev.record(main)
         used.append(ev)
@@ -233,16 +239,22 @@ class TileRenderer:
             out = self._render_rays(O, D, embed_idx, height, width)
             if not (self.P > 1 and self.record):
                 return out
-            ovf = int(self._ovf.item())  # (one synchronisation per frame: ~0.1 % of a full-HD frame)
+            ovf, n_cont = self._stat.tolist()  # (one synchronisation per frame: ~0.1 % of a full-HD frame)
+            self.continued_frac = n_cont / float(height * width)
             hits_short = bool(ovf & ops.HIT_CAP_REACHED) and self.hit_cap < self.hp.cfg.max_oct_per_ray
             if not (ovf & ops.REC_POOL_OVERFLOW) and not hits_short:
+                # the two-phase march pays while few rays need its second phase (each of them is marched twice); a scene where more than a quarter
+                # do -- thin, transparent -- gets a deeper first phase from the next frame on (captured again), and none from 384 samples on
+                if self.first_k and self.continued_frac > 0.25:
+                    self.first_k = self.first_k + 64 if self.first_k + 64 < 384 else 0
+                    self.graph, self.out, self._keep = None, None, None
                 return out
             # a tile's rays needed more record pages than the pool holds: a pool half as large again (the dense form from 1024 slots per ray on);
             # or a ray crossed more leaves than the hit lists hold: four times the cap.  Captured again, and this frame once more
             if ovf & ops.REC_POOL_OVERFLOW:
                 self.rec_slots = (int(self.rec_slots * 1.5) + 31) // 32 * 32
                 if self.rec_slots >= 1024:
-                    self.rec_slots = 0
+                    self.rec_slots, self.first_k = 0, 0  # (the dense form: no pages, no two-phase march)
             if hits_short:
                 self.hit_cap = min(self.hit_cap * 4, self.hp.cfg.max_oct_per_ray)
                 self.hp._record_ws = None  # (hit lists of the old stride)
@@ -258,7 +270,6 @@ class TileRenderer:
         n = height * width
         O, D = O.reshape(n, 3), D.reshape(n, 3)
         self.cam.fill_(int(embed_idx))
-        self._ovf.zero_()
         rgb = torch.empty((n, 3), dtype=torch.float32, device=hp.dev)
         acc = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
         depth = torch.empty((n, 1), dtype=torch.float32, device=hp.dev)
@@ -267,6 +278,7 @@ class TileRenderer:
             self.o.copy_((O[:T] if n >= T else torch.cat([O, O[-1:].expand(T - n, 3)]))[None].expand_as(self.o))
             self.d.copy_((D[:T] if n >= T else torch.cat([D, D[-1:].expand(T - n, 3)]))[None].expand_as(self.d))
             self._capture()
+        self._stat.zero_()  # (behind the capture's eager warm-up tiles: the statistics are this frame's)
         if self.tw:
             tw, th = self.tw, T // self.tw
             O2, D2 = O.view(height, width, 3), D.view(height, width, 3)

