@@ -851,10 +851,9 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
             assert tr.rec_slots == 224 and tr.hit_cap == 128 and tr.pool_regrown == 0
         elif name.startswith("two_phase"):
             # the two-phase march: first_k samples of every ray, then the rays still transparent there again -- some rays continue, most do not
-            k = tr._keep[0]
-            n_cont, cnt, more = int(k["cont_n"].item()), k["counts"], k["more"]
-            assert tr.first_k == fk and tr.pool_regrown == 0 and 0 < n_cont <= int((more != 0).sum().item()) <= tr.T, (n_cont, int((more != 0).sum().item()))
-            assert int(cnt.max().item()) > fk  # (the continued rays have their full counts)
+            # (in this scene nearly every ray is still transparent after 32 or 64 samples: the renderer notices -- continued_frac, read once per
+            # frame -- and deepens the first phase for the next frame, which the second render above went through)
+            assert tr.pool_regrown == 0 and 0.0 < tr.continued_frac <= 1.0 and tr.first_k in (fk, fk + 64, fk + 128, 0), (tr.continued_frac, tr.first_k)
         else:
             assert tr.pool_regrown >= 1 and tr.rec_slots > 32 and tr.hit_cap > 2, (tr.pool_regrown, tr.rec_slots, tr.hit_cap)
         del tr

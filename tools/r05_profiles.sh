@@ -1,8 +1,8 @@
 # round-5 profile collection, two gpurun calls (a call lasts 20 minutes at most):
 #   bash tools/r05_profiles.sh traces   the bench line + kernel-trace stats (focal / global graph launch, render graph + eager, the plugin-surface step)
 #   bash tools/r05_profiles.sh pmc_render   only the inference kernel's passes of the next mode (after a change to csrc/fused_fwd.hip alone)
-#   bash tools/r05_profiles.sh pmc      separate --pmc passes (one counter group each; never together with a trace: MI355X guide) for the focal step,
-#                                       the global step and the inference kernel (tiles rendered eagerly: --render-eager)
+#   bash tools/r05_profiles.sh pmc      separate --pmc passes (one counter group each; never together with a trace: MI355X guide) for the focal step and
+#                                       the global step; pmc_render: the inference kernel's (tiles rendered eagerly: --render-eager); pmc_all: both
 # Everything is addressed through $GRAFT_REPO_ROOT (the r03 script mixed it with /root/repo).
 set -e
 MODE=${1:-traces}
@@ -11,8 +11,8 @@ O=$GRAFT_REPO_ROOT/gpurun_out/r05p
 mkdir -p $O
 export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-COMMON="--no-cpu-baseline --render-frames 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds="
-RENDER="--steps 2 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --render-frames 1 --render-eager"
+COMMON="--no-cpu-baseline --render-frames 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0"
+RENDER="--steps 2 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 1 --render-eager"
 if [ "$MODE" = "traces" ]; then
   timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
   grep "bench-details" $O/bench.err | sed 's/^\[bench-details\] //' > $O/bench_details.json
@@ -22,7 +22,7 @@ if [ "$MODE" = "traces" ]; then
   echo "kt focal graph done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_global_graph -- python3 $B --steps 60 --warmup 60 $COMMON --stage global > $O/global_graph_under_rocprof.json 2>$O/kt_global_graph.err
   echo "kt global graph done"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
   echo "kt render done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render_eager -- python3 $B $RENDER > $O/render_eager_under_rocprof.json 2>$O/kt_render_eager.err
   echo "kt render eager done"
@@ -51,7 +51,7 @@ else
     rocprofv3 --pmc $C --output-format csv -d $O/pmc_global_$T -- python3 $B --steps 3 --warmup 58 $COMMON --stage global --launch eager > $O/pmc_global_$T.json 2>$O/pmc_global_$T.err || echo "pmc global $T failed"
     echo "pmc global $T done"
   done
-  for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+  [ "$MODE" = "pmc" ] || for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "TCP_TCC_READ_REQ_sum" "TCC_HIT TCC_MISS" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_VMEM"; do
     T=$(echo $C | tr ' ' '_')
