@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--job-timeout", type=float, default=1500.0, help="N > 1, self-spawned ranks: seconds after which the ranks are killed and the exit code is 124")
     ap.add_argument("--psnr-seeds", type=int, default=3,
                     help="`psnr` sub-record: seeds per leg (the product's training leg against the reference-semantics leg, paired by seed); the many-seed "
-                         "record is profiles/r04_psnr_study.json (tools/psnr_study.py)")
+                         "record is profiles/r05_psnr_study.json (tools/psnr_study.py)")
     ap.add_argument("--trained-seeds", type=str, default="0,1",
                     help="`trained_state` sub-records (N = 1): engine seeds whose procedurally TRAINED state (global stage, then 4 focal blocks in rotation) the same "
                          "steps are timed on; empty = none")
@@ -641,18 +641,18 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
 
 
 def psnr_study_record(steps_global, steps_focal):
-    """The many-seed PSNR record of the round (profiles/r04_psnr_study.json, written by tools/psnr_study.py on an MI355X): reported beside this run's few
+    """The many-seed PSNR record of the round (profiles/r05_psnr_study.json, written by tools/psnr_study.py on an MI355X): reported beside this run's few
     seeds ONLY when it was made with the same protocol (gfnerf_amd.procedural.PROTOCOL, steps)."""
     from gfnerf_amd import procedural
 
-    path = os.path.join(ROOT, "profiles", "r04_psnr_study.json")
+    path = os.path.join(ROOT, "profiles", "r05_psnr_study.json")
     try:
         rec = json.load(open(path))
         st = rec["psnr_study"]
         if st["steps"] != [steps_global, steps_focal] or rec.get("protocol") != procedural.PROTOCOL:
-            return dict(study_note="profiles/r04_psnr_study.json was made with another protocol: not reported")
+            return dict(study_note="profiles/r05_psnr_study.json was made with another protocol: not reported")
         return dict(study_delta=st["delta"], study_se=st["se"], study_n_seeds=st["n_seeds"], study_decoder_delta=st["decoder_delta"],
-                    study_source="profiles/r04_psnr_study.json (tools/psnr_study.py; same protocol)")
+                    study_source="profiles/r05_psnr_study.json (tools/psnr_study.py; same protocol)")
     except (OSError, KeyError, ValueError):
         return {}
 
