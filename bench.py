@@ -125,6 +125,7 @@ def parse():
     ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
                     help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
                          "nearest (default); x3 = hi + lo' planes (rounds 1-4); mixed = dz one plane, activations split")
+    ap.add_argument("--record-merge", type=int, default=-1, help="focal backward in record form: merge runs of samples in one cell first (gfn_set_record_merge; -1: the library's default)")
     ap.add_argument("--wgrad-beside-accumulate", action="store_true", help="experiment (global stage): wgrad on a second stream beside grad_accumulate")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
@@ -633,6 +634,18 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(60)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if trained_info is not None and model.hot._records is not None:  # how full the backward's record streams run on this scene (one more iteration, counted)
+        hot = model.hot
+        hot.record_counts_seen = torch.zeros_like(hot._records[1])
+        train_iteration(step); step += 1
+        torch.cuda.synchronize()
+        seen = hot.record_counts_seen.to(torch.int64)
+        n_streams = seen.numel()
+        cap = (hot._records[0].numel() // n_streams) & ~1
+        trained_info.update(records_per_step=int(seen.sum().item()), record_stream_cap=int(cap), streams_over_cap=int((seen > cap).sum().item()),
+                            records_over_cap=int((seen - cap).clamp(min=0).sum().item()), busiest_stream=int(seen.max().item()),
+                            table_grad_nonzero=int((hot.table_grad != 0).sum().item()), loss_after_window=float(loss.detach()))
+        hot.record_counts_seen = None
     return dict(metric="train_rays_per_sec", value=n_rays / dt, unit="rays/s", ms_per_step=dt * 1e3, host_ms_per_step=host / steps * 1e3, steps=steps,
                 warmup=warmup, stage=stage, mean_samples_per_ray=mean, loss=float(loss.detach()),
                 optimizer="GfnAdam (HIP Adam kernels on the engine's gradient buffers)" if fused_optimizer else "torch.optim.Adam on dense f32 gradients",
@@ -1173,6 +1186,8 @@ def run_rank(args):
     import gfnerf_amd  # noqa: F401
     from gfnerf_amd import _lib, cluster, dist as gdist, scene
 
+    if args.record_merge >= 0:
+        _lib.lib().gfn_set_record_merge(args.record_merge)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

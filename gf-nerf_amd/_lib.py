@@ -63,6 +63,7 @@ SIGNATURES = {
     "gfn_grad_scale_host": (_f32, [_f32]),
     "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_set_plane_dither": (_i32, [_i32]),
+    "gfn_set_record_merge": (_i32, [_i32]),
     "gfn_set_march_lanes": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_wgrad_x3_parts": (_i32, []),

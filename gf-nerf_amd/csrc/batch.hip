@@ -370,7 +370,7 @@ int gfn_errmap_sample(const float* error_map, int64_t n_pixels, const double* bl
   GFN_CHECK_ARG(n <= n_pixels, "gfn_errmap_sample: %lld draws without replacement from %lld pixels", (long long)n, (long long)n_pixels);
   hipStream_t st = gfn_stream(stream);
   const int64_t nb = (n_pixels + kBlk - 1) / kBlk;
-  GFN_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st));
+  GFN_CHECK_HIP(gfn_zero_async(status, 2 * sizeof(int32_t), st));
   errmap_prefix_kernel<<<1, 1024, 0, st>>>(block_sums, nb, prefix_ws);
   GFN_CHECK_LAUNCH();
   errmap_draw_kernel<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(error_map, n_pixels, prefix_ws, bits, n, n_weighted, cand_ws, status);

@@ -277,7 +277,7 @@ __device__ __forceinline__ void scatter_level(const ScatterArgs& S, const float*
 template <int PLANES, int SCATTER>
 constexpr int bwd_threads() { return 512; }
 
-template <int PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records */>
+template <int PLANES, int SCATTER /* 0 none, 1 f16 pool, 2 f32 pool, 3 f16 pool through records, 4 the same with runs of samples in one cell merged first */>
 __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx_x3_kernel(
     int64_t n_max, const int32_t* __restrict__ n_dev, const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
     const float* __restrict__ rgb, const float* __restrict__ h0, const unsigned long long* __restrict__ masks,
@@ -291,9 +291,9 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
-  __shared__ unsigned int s_rec_cursor[SCATTER == 3 ? GFN_GRAD_MAX_RANGES : 1];
+  __shared__ unsigned int s_rec_cursor[SCATTER >= 3 ? GFN_GRAD_MAX_RANGES : 1];
   if (SCATTER && threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = S.sc.s[threadIdx.x];
-  if (SCATTER == 3)
+  if (SCATTER >= 3)
     for (int e = threadIdx.x; e < GFN_GRAD_MAX_RANGES; e += blockDim.x) s_rec_cursor[e] = 0;
   __syncthreads();
   const u32x4* Ihi = L;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
           nx[0] = pn[0]; nx[1] = pn[1]; nx[2] = pn[2];
         }
         const float gx = acc_get(gf, 2 * a) * inv, gy = acc_get(gf, 2 * a + 1) * inv;
-        if (SCATTER == 3) scatter_level<true, true, PLANES != 0>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr, s_rec_cursor);
+        if (SCATTER >= 3) scatter_level<true, true, (PLANES != 0 || SCATTER == 4)>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr, s_rec_cursor);
         else if (SCATTER == 1) scatter_level<true>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
         else scatter_level<false>(S, s_scale, level, px, py, pz, vol, gx, gy, valid, h, j, T, pr);
         pr[0] = nx[0]; pr[1] = nx[1]; pr[2] = nx[2];
@@ -546,7 +546,7 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
                                       acc_get(gf, 4 * qd + 3) * inv);
     }
   }
-  if (SCATTER == 3) {
+  if (SCATTER >= 3) {
     __syncthreads();
     for (int e = threadIdx.x; e < S.n_ranges; e += blockDim.x)
       S.rec_count[e * 256 + blockIdx.x] = s_rec_cursor[e] < S.rec_cap ? s_rec_cursor[e] : S.rec_cap;
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
 
 int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
 int g_plane_dither = 1;  // gfn_set_plane_dither
+int g_record_merge = 0;  // gfn_set_record_merge
 
 }  // namespace
 int gfn_decoder_cu_cap() { return (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256; }
@@ -678,7 +679,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
                   reinterpret_cast<uintptr_t>(planes_lo)) & 15) == 0, "%s: image, dfeat and planes must be 16-byte aligned", fn);
   constexpr int kLds = GFN_FIELD_X3_BWD_BYTES + 64;  // + the 16 level scales of the scatter epilogue
   static unsigned long long attr_seen = 0;  // one bit per device: the attribute belongs to the (function, device) pair
-#define GFN_BWD_ALL(X) X(0, 0) X(0, 1) X(0, 2) X(0, 3) X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(2, 0) X(2, 1) X(2, 2) X(2, 3)
+#define GFN_BWD_ALL(X) X(0, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(1, 0) X(1, 1) X(1, 2) X(1, 3) X(2, 0) X(2, 1) X(2, 2) X(2, 3)
   if (gfn_first_call_on_device(attr_seen)) {
 #define GFN_SET(P, SC) GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(field_bwd_dx_x3_kernel<P, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     GFN_BWD_ALL(GFN_SET)
@@ -704,7 +705,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   }
   gfn_hash_level_scales_host(S.sc.s);
   const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
-  const int mode = !scatter ? 0 : (sh.rec ? 3 : (sh.grad_f16 ? 1 : 2));
+  const int mode = !scatter ? 0 : (sh.rec ? ((g_record_merge && !planes) ? 4 : 3) : (sh.grad_f16 ? 1 : 2));
   if (!planes) { gmax_dev = nullptr; plane_cap = 0; ray_id = nullptr; cam_idx = nullptr; demb = nullptr; }
 #define GFN_LAUNCH(P, SC)                                                                                                        \
   if (planes == P && mode == SC)                                                                                                 \
@@ -764,6 +765,12 @@ int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int6
 }
 
 float gfn_grad_scale_host(float gmax) { return gfn_grad_scale_of(gmax); }
+
+int gfn_set_record_merge(int on) {
+  const int old = g_record_merge;
+  g_record_merge = on != 0;
+  return old;
+}
 
 int gfn_set_plane_dither(int on) {
   const int old = g_plane_dither;

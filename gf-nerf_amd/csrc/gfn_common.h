@@ -38,6 +38,12 @@ float gfn_plane_dither_amp();
 
 static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero `bytes` bytes at p on `stream` with a KERNEL (runtime.hip), never a memset node: a hipMemsetAsync captured into a hipGraph executes in
+// full on the first launch of the instantiated graph only -- later replays of the node leave a quarter or a half of a 71 MB buffer, or all of a
+// 4-byte one, untouched (ROCm 7.0 runtime of this image; tools/README.md, tests/test_gpu_parity.py::test_fill_zero_replays).  Every zeroing the
+// library does may end up inside a caller's capture (a training step, a forward, a render tile), so none of them is a memset.
+hipError_t gfn_zero_async(void* p, size_t bytes, hipStream_t stream);
+
 // One-time set-up per (call site, device), e.g. hipFuncSetAttribute for a kernel's dynamic LDS size: true the first time it is
 // reached with the current device selected (`seen`: a function-local static, one bit per device ordinal).
 static inline bool gfn_first_call_on_device(unsigned long long& seen) {

@@ -890,7 +890,7 @@ int gfn_adam_step_ex(float* p, const void* g, int g_f16, float g_scale, float* m
 int gfn_fill_zero(void* p, int64_t bytes, void* stream) {
   GFN_CHECK_ARG(p && bytes >= 0, "gfn_fill_zero: bad arguments");
   if (bytes == 0) return GFN_OK;
-  GFN_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)bytes, gfn_stream(stream)));
+  GFN_CHECK_HIP(gfn_zero_async(p, (size_t)bytes, gfn_stream(stream)));
   return GFN_OK;
 }
 

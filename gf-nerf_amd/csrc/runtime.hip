@@ -28,6 +28,15 @@ __global__ __launch_bounds__(256) void reduce_shards_kernel(const T* __restrict_
   __builtin_memcpy(out + i, r, sizeof(r));
 }
 
+// gfn_zero_async: 16-byte stores over the aligned body, single bytes at the ragged ends
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* __restrict__ p, size_t head, size_t body16, size_t tail) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  uint4* b = reinterpret_cast<uint4*>(p + head);
+  for (size_t i = tid; i < body16; i += stride) b[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < head) p[tid] = 0;
+  if (tid < tail) p[head + body16 * 16 + tid] = 0;
+}
+
 // Several small device-to-device copies in ONE launch (the per-step batch hand-over of a captured training step: four tensors of
 // 16 - 48 KB; as four memcpy nodes they cost the stream 4 x 6 us of launch latency in front of every replay).
 constexpr int kMaxCopies = 8;
@@ -91,6 +100,19 @@ void gfn_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+hipError_t gfn_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  unsigned char* c = static_cast<unsigned char*>(p);
+  size_t head = (16 - (reinterpret_cast<uintptr_t>(c) & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const size_t body16 = (bytes - head) / 16, tail = bytes - head - body16 * 16;
+  size_t blocks = (body16 + 1023) / 1024;  // four stores per lane
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  zero_bytes_kernel<<<(unsigned)blocks, 256, 0, stream>>>(c, head, body16, tail);
+  return hipGetLastError();
 }
 
 extern "C" {

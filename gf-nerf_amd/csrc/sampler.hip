@@ -1029,7 +1029,7 @@ int gfn_trace(const float* rays_o, const float* rays_d, int64_t n_rays, const vo
               int32_t* overflow_dev, void* stream) {
   GFN_CHECK_ARG(oct_offsets, "gfn_trace: null oct_offsets");
   if (n_rays == 0) {
-    GFN_CHECK_HIP(hipMemsetAsync(oct_offsets, 0, sizeof(int32_t), gfn_stream(stream)));
+    GFN_CHECK_HIP(gfn_zero_async(oct_offsets, sizeof(int32_t), gfn_stream(stream)));
     return GFN_OK;
   }
   GFN_CHECK_ARG(rays_o && rays_d && nodes && hit_idx && hit_near_far, "gfn_trace: null pointer");
@@ -1039,7 +1039,7 @@ int gfn_trace(const float* rays_o, const float* rays_d, int64_t n_rays, const vo
   GFN_CHECK_ARG(hit_cap > 0 && hit_cap < (1ll << 31), "gfn_trace: hit_cap=%lld", (long long)hit_cap);
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
-    GFN_CHECK_HIP(hipMemsetAsync(oct_offsets, 0, sizeof(int32_t), st));
+    GFN_CHECK_HIP(gfn_zero_async(oct_offsets, sizeof(int32_t), st));
     return GFN_OK;
   }
   const unsigned grid = (unsigned)((n_rays + kRayBlock - 1) / kRayBlock);
@@ -1068,7 +1068,7 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
               int32_t* overflow_dev, void* stream) {
   GFN_CHECK_ARG(pts_offsets, "gfn_march: null pts_offsets");
   if (n_rays == 0) {
-    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), gfn_stream(stream)));
+    GFN_CHECK_HIP(gfn_zero_async(pts_offsets, sizeof(int32_t), gfn_stream(stream)));
     return GFN_OK;
   }
   GFN_CHECK_ARG(rays_o && rays_d && noise && oct_offsets && hit_idx && hit_near_far && nodes && transes,
@@ -1079,7 +1079,7 @@ int gfn_march(const float* rays_o, const float* rays_d, const float* noise, int6
                 (long long)pts_cap);
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
-    GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
+    GFN_CHECK_HIP(gfn_zero_async(pts_offsets, sizeof(int32_t), st));
     return GFN_OK;
   }
   const unsigned grid = (unsigned)((n_rays + kRayBlock - 1) / kRayBlock);
@@ -1129,7 +1129,7 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
   GFN_CHECK_ARG(tree_depth <= kMaxDepth, "gfn_sample_rays: tree_depth=%d (at most %d levels)", tree_depth, kMaxDepth);
   hipStream_t st = gfn_stream(stream);
   if (n_rays == 0) {
-    if (!record_only) GFN_CHECK_HIP(hipMemsetAsync(pts_offsets, 0, sizeof(int32_t), st));
+    if (!record_only) GFN_CHECK_HIP(gfn_zero_async(pts_offsets, sizeof(int32_t), st));
     return GFN_OK;
   }
   GFN_CHECK_ARG(rays_o && rays_d && noise && compact_nodes && transes && hit_counts && hit_idx && hit_near_far,
@@ -1213,7 +1213,7 @@ int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays_record: march_rec must be 16-byte aligned");
   GFN_CHECK_ARG(!page_table || (page_counter && overflow_dev && n_pages >= 1 && n_pages < (1ll << 31) / GFN_REC_PAGE),
                 "gfn_sample_rays_record: paged records need the page counter, the overflow word and 1 <= n_pages < 2^31 / %d", GFN_REC_PAGE);
-  if (page_table) GFN_CHECK_HIP(hipMemsetAsync(page_counter, 0, sizeof(int32_t), gfn_stream(stream)));
+  if (page_table) GFN_CHECK_HIP(gfn_zero_async(page_counter, sizeof(int32_t), gfn_stream(stream)));
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis, 1,
                           hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                           first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, RecPages{page_table, page_counter, (int)n_pages},
@@ -1264,7 +1264,7 @@ int gfn_update_nodes_mark(const int32_t* pts_offsets, int64_t n_rays, const int3
   long long* mark = a_adder + n_nodes;
   fill_i64_kernel<<<(unsigned)((2 * n_nodes + 255) / 256), 256, 0, st>>>(w_adder, -1, 2 * n_nodes);  // :617-618
   GFN_CHECK_LAUNCH();
-  GFN_CHECK_HIP(hipMemsetAsync(mark, 0, sizeof(long long) * n_nodes, st));
+  GFN_CHECK_HIP(gfn_zero_async(mark, sizeof(long long) * n_nodes, st));
   if (n_rays > 0) {
     mark_visit_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, st>>>(
         (int)n_rays, pts_offsets, anchors, weights, alphas, (int)n_nodes, w_adder, a_adder, mark,

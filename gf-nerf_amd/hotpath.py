@@ -69,7 +69,10 @@ class HotPathConfig:
                                      # frozen global table (HBM-bound beside address-path-bound)
     loss_before_fork: bool = True    # forward_backward enqueues the loss kernels before it forks the octree update / next sampler
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
-    record_capacity: int = 1 << 27   # 8-byte record slots (1 GiB; the global stage reaches 48 M records per step) shared by the (range, workgroup) streams; a full stream falls back to atomics
+    record_capacity: int = 1 << 29   # 8-byte record slots (4 GiB; 1,927 per (range, workgroup) stream at T = 2^21) -- a full stream falls back to atomics, at a
+                                     # fifth of the rate.  The global stage writes 48 M records per step, a focal step 13-17 M on a young table (most
+                                     # contributions round to zero at the pool's f16 x128 scale) and up to 79 M once every sample carries a gradient
+                                     # (measured through the plugin surface on a scene trained there: bench.py plugin_step_trained)
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
     prefetch_cus_global: int = 192   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
@@ -740,7 +743,7 @@ class HotPath:
             return None
         if self._records is None:
             n_streams = _lib.lib().gfn_grad_record_ranges(c.log2_T) * 256
-            self._records = ops.grad_records_buffers(c.log2_T, min(c.record_capacity, n_streams * 1024), self.dev)  # <= 1024 records per stream
+            self._records = ops.grad_records_buffers(c.log2_T, min(c.record_capacity, n_streams * 2048), self.dev)  # <= 2048 records per stream
         return self._records
 
     @contextlib.contextmanager

@@ -1420,6 +1420,11 @@ def concurrent_stream(device=None, role=None):
 
 
 def fill_zero(t):
+    """t[...] = 0 on the current stream (a kernel, not a memset node: safe inside a captured graph, see csrc/gfn_common.h gfn_zero_async)."""
+    if t.numel() == 0:
+        return
+    if not t.is_contiguous():
+        raise _lib.GfnError("fill_zero: contiguous tensors only")
     _lib.check(_lib.lib().gfn_fill_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "gfn_fill_zero")
 
 

@@ -391,6 +391,11 @@ int gfn_set_decoder_cus(int n_cus);
  * rne(dz * (1 - u_q)), u_q a fixed hash of q in +-2^-11, so that neighbouring samples' rounding errors are independent
  * (csrc/x3_device.h).  on = 0 switches the dither off (plain rounding).  Returns the previous value.  Process-wide; default on. */
 int gfn_set_plane_dither(int on);
+/* Focal-stage backward in record form (gfn_field_bwd_scatter_x3 with records, no planes): on != 0 merges the contributions of
+ * consecutive samples of a ray that fall into one cell before they become records (the global stage always does).  Fewer, larger
+ * records where a batch's rays crowd few cells (one camera cluster: the coarse levels' streams fill up and the overflow goes
+ * through atomics); a few shuffles more where they do not.  Returns the previous value.  Process-wide; default off. */
+int gfn_set_record_merge(int on);
 /* Lanes per ray of gfn_sample_rays' march: 16 (a row per ray: batches that leave the machine empty) or 4 (a quad: a quarter of the
  * vector work per ray), 0 = by batch size (a quad from 32 Ki rays on).  Both give the same bits (tests run both on the same rays).
  * Starts at GFN_MARCH_LANES from the environment, read once.  Returns the previous value.  Process-wide. */

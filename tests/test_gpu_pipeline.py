@@ -982,18 +982,22 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
 
 
-def test_graphed_forward_is_the_eager_forward(setup):
+@pytest.mark.parametrize("async_adam", [True, False])
+def test_graphed_forward_is_the_eager_forward(setup, async_adam):
     """HotPath.forward_train_graphed (the plugin surface's focal forward over two static sets of sample buffers): three eager runs per
     set, then one hipGraph replay per call -- the same training run as forward_train, bit for bit (focal stage, T = 2^18: exact record
-    accumulation): losses, the block table and its Adam moments after eight iterations, phased forward included; and a decoder
-    written from outside between two replays (a checkpoint) is repacked before the next one."""
+    accumulation): losses, the block table and its Adam moments after fourteen iterations (FOUR replays of each capture), phased forward
+    included; and a decoder written from outside between two replays (a checkpoint) is repacked before the next one.
+    async_adam=False is the plugin surface's arrangement (an optimiser of the caller's steps the table: gfnerf.optim.GfnAdam): the gradient pool
+    is zeroed by the forward itself, i.e. INSIDE the captured graph -- as a memset node that zeroing ran in full on a capture's first replay only
+    (round 5: the trained plugin run degraded and then died of it; csrc/gfn_common.h, gfn_zero_async), so every replay is checked."""
     import torch
 
     from gfnerf_amd import hotpath, ops, scene
 
     S = setup
     t, sc = S["t"], S["sc"]
-    R, K = 256, 8
+    R, K = 256, 14
     noise = t(scene.make_noise(R, False, 5.0))
     batches = []
     for k in range(K):
@@ -1002,7 +1006,7 @@ def test_graphed_forward_is_the_eager_forward(setup):
         batches.append(tuple(t(a) for a in (o, d, cam, gt)))
 
     def run(graphed):
-        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=graphed)
+        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=graphed, async_adam=async_adam)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.table.mul_(100.0); hp.refresh_shadows()
         bufs, losses, kinds = [None, None], [], []
@@ -1013,6 +1017,8 @@ def test_graphed_forward_is_the_eager_forward(setup):
             bufs[k % 2] = s
             comp, ctx = hp.forward_train_graphed(cam, "focal", 0, s, want_depth=False)
             kinds.append(hp.last_forward_replayed)
+            if not async_adam:  # the forward has zeroed the gradient pool (the last backward's gradient was in it): on every replay
+                assert int((hp._grad_live() != 0).sum()) == 0, k
             loss, g = ops.charbonnier(comp["rgb"], gt)
             hp.backward(ctx, g)
             hp.optimizer_step("focal", 0)
@@ -1022,7 +1028,7 @@ def test_graphed_forward_is_the_eager_forward(setup):
                     k=int(hp._phase.k.item()))
 
     a, b = run(False), run(True)
-    assert a["kinds"] == [False] * K and b["kinds"] == [False] * 6 + [True] * 2, (a["kinds"], b["kinds"])  # three eager runs per buffer set first
+    assert a["kinds"] == [False] * K and b["kinds"] == [False] * 6 + [True] * (K - 6), (a["kinds"], b["kinds"])  # three eager runs per buffer set first
     np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-6)  # (the loss scalar is summed with atomics)
     assert a["k"] == b["k"] and a["losses"][6] != a["losses"][5]
     for key in ("table", "m", "v"):

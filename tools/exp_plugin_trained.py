@@ -1,0 +1,20 @@
+"""The plugin-surface focal iteration on the plugin-TRAINED scene (bench.plugin_step_bench(trained=(3000, 1000))) under its switches: graph replay of the
+forward or the eager forward, the backward's run merge of records on or off, no prefetch (tools/README.md, round 5)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import gfnerf_amd  # noqa: E402,F401
+from gfnerf_amd import scene  # noqa: E402
+
+sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir="/tmp/gfnerf_amd_scene")
+from gfnerf_amd import _lib  # noqa: E402
+for name, kw, merge in (("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward", dict(graph_forward=False), 0), ("eager forward+merge", dict(graph_forward=False), 1),
+                        ("graph, no prefetch", dict(prefetch=False), 0)):
+    _lib.lib().gfn_set_record_merge(merge)
+    r = bench.plugin_step_bench(sc, torch, "focal", steps=200, warmup=30, trained=(3000, 1000), **kw)
+    print(name, round(r["ms_per_step"], 4), "host", round(r["host_ms_per_step"], 4), "forward", r["forward"], "samples/ray", round(r["mean_samples_per_ray"], 1),
+          {k: v for k, v in r["trained"].items() if "record" in k or "stream" in k or "loss" in k or "grad" in k}, flush=True)
+    torch.cuda.empty_cache()
+_lib.lib().gfn_set_record_merge(0)

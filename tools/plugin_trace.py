@@ -13,5 +13,6 @@ from gfnerf_amd import scene  # noqa: E402
 
 stage = sys.argv[1] if len(sys.argv) > 1 else "focal"
 sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir="/tmp/gfnerf_amd_scene")
-r = bench.plugin_step_bench(sc, torch, stage, steps=int(sys.argv[2]) if len(sys.argv) > 2 else 100, warmup=20)
+trained = (3000, 1000) if len(sys.argv) > 3 and sys.argv[3] == "trained" else None  # the focal step on a scene trained through the plugin surface itself
+r = bench.plugin_step_bench(sc, torch, stage, steps=int(sys.argv[2]) if len(sys.argv) > 2 else 100, warmup=20, trained=trained)
 print(r)
