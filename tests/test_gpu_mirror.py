@@ -703,3 +703,50 @@ def test_gfn_adam_is_the_same_training_run_as_torch_adam(dev, tmp_path, prefetch
         assert float((diff > tol).float().mean()) < share and float(diff.max()) < 0.05, (k, float((diff > tol).float().mean()), float(diff.max()))
     # the kernel that steps a table refreshes the f16 shadow the lookups read
     assert torch.equal(b["shadow"], b["table"].to(torch.float16))
+
+
+def test_replayed_focal_forward_is_the_same_training_run(dev, tmp_path):
+    """The plugin surface's focal iteration with the forward as a hipGraph replay (HotPath.forward_train_graphed: on from the fourth use of a set
+    of static sample buffers) against the same run with cfg.graph_forward off: one block's period long enough that each of the two captures is
+    replayed five times -- the gradient pool is zeroed INSIDE the captured forward here (the optimiser is the caller's), and that zeroing must
+    happen on every replay (round 5: as a memset node it ran in full on a capture's first replay only; the earlier tests of this file never
+    replayed a capture twice).  Same losses, same block table, and the pool holds one step's gradient, not a sum of steps."""
+    import torch
+
+    from gfnerf_amd.gfnerf._host import Optimizers, TrainingCallbackAttributes
+    from gfnerf_amd.gfnerf.optim import GfnAdamOptimizerConfig
+    from gfnerf_amd.gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
+
+    runs = {}
+    for name, graphed in (("eager", False), ("replayed", True)):
+        torch.manual_seed(77)
+        pipe, _, _ = _small_pipeline(dev, base_dir=str(tmp_path / name), steps_perssampler_init=4, steps_per_split_dataset=16, early_T=1e-2)
+        pipe.config.prefetch_next_batch = True
+        model = pipe.model
+        model.hot.cfg.graph_forward = graphed
+        sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=4, n_split_dataset=2, n_dataset_circles=1, steps_per_split_dataset=16,
+                                                      steps_perssampler_init=4)
+        optimizers = Optimizers({"fields": {"optimizer": GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": sched}}, pipe.get_param_groups())
+        callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
+        model.train(); model.persampler.update_mode(0)
+        replays, pool_abs = [], []
+        inner = model.hot.forward_train_graphed
+
+        def counted(*a, _inner=inner, _hot=model.hot, **k):
+            out = _inner(*a, **k)
+            replays.append(_hot.last_forward_replayed)
+            return out
+
+        model.hot.forward_train_graphed = counted
+        hist = []
+        for step in range(20):
+            hist += _trainer_loop(pipe, optimizers, callbacks, [step], fixed=False)
+            pool_abs.append(float(model.hot._grad_live().float().abs().sum()))
+        torch.cuda.synchronize()
+        runs[name] = dict(hist=hist, block0=model.hot.blocks[0].clone(), replays=replays, pool_abs=pool_abs)
+    a, b = runs["eager"], runs["replayed"]
+    assert not any(a["replays"]) and sum(b["replays"]) >= 8, (a["replays"], b["replays"])  # 16 focal iterations: 2 x 3 eager, then replays
+    np.testing.assert_allclose(b["hist"], a["hist"], rtol=1e-3)
+    np.testing.assert_allclose(b["pool_abs"], a["pool_abs"], rtol=0.05)  # (a pool that is not zeroed grows by a step's gradient per step)
+    diff = (b["block0"] - a["block0"]).abs()
+    assert float(a["block0"].abs().max()) > 0 and float((diff > 2e-5).float().mean()) < 3e-2 and float(diff.max()) < 0.05
