@@ -28,6 +28,9 @@ if [ "$MODE" = "traces" ]; then
   echo "kt render eager done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_plugin_focal -- python3 $GRAFT_REPO_ROOT/tools/plugin_trace.py focal 100 > $O/plugin_focal_under_rocprof.txt 2>$O/kt_plugin_focal.err
   echo "kt plugin done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_plugin_trained -- python3 $GRAFT_REPO_ROOT/tools/plugin_trace.py focal 200 trained > $O/plugin_trained_under_rocprof.txt 2>$O/kt_plugin_trained.err
+  python3 $GRAFT_REPO_ROOT/tools/trace_tail.py $O/kt_plugin_trained 300 auto:grad_accumulate > $O/plugin_trained_window.txt
+  echo "kt plugin trained done"
 elif [ "$MODE" = "sq_global" ]; then
   # the global step's kernels under the SQ counter groups (what bounds field_bwd_dx_x3_kernel<2, 3> and wgrad_x3_layers_kernel)
   cd /tmp

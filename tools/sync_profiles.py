@@ -14,6 +14,10 @@ subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_render", f
 shutil.copy(f"{R}/render_under_rocprof.json", f"profiles/{TAG}_render_bench_under_rocprof.json")
 subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_focal", f"profiles/{TAG}_plugin_focal_kernel_stats.csv"])
 shutil.copy(f"{R}/plugin_focal_under_rocprof.txt", f"profiles/{TAG}_plugin_focal_under_rocprof.txt")
+if os.path.exists(f"{R}/kt_plugin_trained"):  # the focal iteration on the scene trained through the plugin surface (the last 300 ms of the run: per step)
+    subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_trained", f"profiles/{TAG}_plugin_trained_kernel_stats.csv"])
+    shutil.copy(f"{R}/plugin_trained_under_rocprof.txt", f"profiles/{TAG}_plugin_trained_under_rocprof.txt")
+    shutil.copy(f"{R}/plugin_trained_window.txt", f"profiles/{TAG}_plugin_trained_window.txt")
 shutil.copy(f"{R}/bench.json", f"profiles/{TAG}_bench.json")
 shutil.copy(f"{R}/bench_details.json", f"profiles/{TAG}_bench_details.json")
 subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_*/")))
@@ -82,7 +86,7 @@ j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / 216.0 *
 # (per-launch figures belong to the tile the eager run rendered: the renderer's default for a full-HD frame, bench.py scales by its own tile)
 _src = open("gf-nerf_amd/render.py").read()
 _ns = {}
-exec("import math\n" + _src[_src.index("def choose_tile"):_src.index("def frame_shard")], _ns)
+exec("import math\n" + _src[_src.index("MAX_TILE_RAYS = "):_src.index("def frame_shard")], _ns)
 _tw, _th = _ns["choose_tile"](1080, 1920)
 j["tile_rays:render"] = _tw * _th
 j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA") / 216.0), 1)
