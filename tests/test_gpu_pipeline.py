@@ -980,6 +980,11 @@ def test_step_graph_is_the_same_training_run(setup, stage):
         assert float(far.float().mean()) < 1e-3 and float((pg - pe).abs().max()) <= 2 * K * 1e-2
         np.testing.assert_allclose(hg.mlp_flat.cpu().numpy(), he.mlp_flat.cpu().numpy(), atol=2e-2 * float(he.mlp_flat.abs().max()))
         assert torch.equal(hg.visit_cnt, he.visit_cnt)  # the octree statistics are integer maxima: exact
+        # the gradient buffers hold the LAST step's gradient, not a sum over the replays (they are zeroed inside the captured step: csrc/gfn_common.h)
+        ge, gg = he.mlp_grad.float(), hg.mlp_grad.float()
+        assert float((gg - ge).abs().max()) < 0.2 * float(ge.abs().max()), (float(gg.abs().max()), float(ge.abs().max()))
+        pe_, pg_ = he._grad_live().float().abs().sum(), hg._grad_live().float().abs().sum()
+        assert abs(float(pg_) / float(pe_) - 1.0) < 0.2, (float(pg_), float(pe_))
 
 
 @pytest.mark.parametrize("async_adam", [True, False])
