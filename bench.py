@@ -507,7 +507,8 @@ def procedural_image_stack(sc, torch, image_idx, H, W, chunk=1 << 17):
     return images, K
 
 
-def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True, graph_forward=True, trained=None):
+def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fused_optimizer=True, prefetch=True, nan_check=True, graph_forward=True, trained=None,
+                      hot_cfg=None):
     """The training iteration THROUGH the plugin surface, the way the reference's Trainer drives it (engine/trainer.py:195-231,
     382-441): callbacks before -> optimizers.zero_grad_all -> pipeline.get_train_loss_dict(step) (incl. datamanager.next_train)
     -> sum(loss_dict) -> backward -> the NaN check over model.named_parameters() -> optimizers.optimizer_step_all ->
@@ -547,6 +548,8 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfn_plugin_bench"))
     model = pipe.model
     model.hot.cfg.graph_forward = bool(graph_forward)
+    for k, v in (hot_cfg or {}).items():  # experiments (tools/exp_plugin_trained.py): any HotPathConfig field
+        setattr(model.hot.cfg, k, v)
     sched = GFNerfExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=S_INIT, n_split_dataset=N_SPLIT, n_dataset_circles=1,
                                                   steps_per_split_dataset=S_SPLIT, steps_perssampler_init=S_INIT)
     ocfg = (GfnAdamOptimizerConfig if fused_optimizer else AdamOptimizerConfig)(lr=1e-2, eps=1e-15)
@@ -712,6 +715,8 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
             o, d, cam = procedural.device_rays(c2w, N_RAYS, gen)
             batches.append((o, d, cam, procedural.gt_colors(o, d, procedural.STUDY_DETAIL)))
         hp._drop_stale_samples()
+        if args.prefetch_cus:  # (the engine came with procedural's configuration: the bench's switch applies to its timed steps too)
+            hp.cfg.prefetch_cus = hp.cfg.prefetch_cus_global = hp.cfg.prefetch_cus_dense = hp.cfg.prefetch_cus_dense_eager = args.prefetch_cus
         run = StageRun(args, stage, sc, 1, 0, sync, torch, engine=dict(hp=hp, batches=batches))
         res = run.run(args.trained_steps, 10)
         roof, n_live, n_eval = run.roofline(res)
@@ -795,7 +800,8 @@ class StageRun:
             log2_T=args.log2_T, early_T=args.early_T, mlp_precision=args.mlp_precision, wgrad_planes=args.wgrad_planes,
             wgrad_beside_accumulate=args.wgrad_beside_accumulate,
             two_phase=not args.one_phase,
-            **({"prefetch_cus": args.prefetch_cus, "prefetch_cus_global": args.prefetch_cus} if args.prefetch_cus else {}),
+            **({"prefetch_cus": args.prefetch_cus, "prefetch_cus_global": args.prefetch_cus, "prefetch_cus_dense": args.prefetch_cus,
+                "prefetch_cus_dense_eager": args.prefetch_cus} if args.prefetch_cus else {}),
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
             level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, loss_before_fork=not args.fork_first,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),

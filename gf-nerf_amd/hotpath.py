@@ -76,6 +76,14 @@ class HotPathConfig:
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
     prefetch_cus_global: int = 192   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
+    prefetch_dense_front: int = 600_000  # focal stage, a batch with at least this many samples in front of the termination points (a trained scene:
+                                     # most of 4096 x 192; the random-init fog has 450 k) has a backward two to three times as long as the sampler
+                                     # beside it, which then needs fewer CUs (round 5, tools/README.md: native replay 1.57 -> 1.52 ms at 176-192 CUs, a
+                                     # cliff from 200 on; through the plugin surface, eager launches with the sampler enqueued first, 2.30 -> 2.21 ms with
+                                     # no cap at all).  The count is last step's (a pinned word the forward's side branch copies, read late) or the
+                                     # capture's planning forward's (StepGraph)
+    prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
+    prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
     two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
                                      # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
                                      # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
@@ -122,6 +130,8 @@ class HotPath:
         self._records = None
         self._opt_stream, self._opt_pending = None, False
         self.k_host = None          # see _forward_phased
+        self._front_host = torch.zeros(1, dtype=torch.int32).pin_memory()  # samples in front of the termination points, as the last phased focal forward counted them (_cu_cap)
+        self.front_override = None  # StepGraph.capture: the count of its planning forward, for the launches it captures
         self._aux_stream, self._aux_pending = None, False  # branch of the phased forward: front list + plan beside the loss
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
@@ -483,6 +493,8 @@ class HotPath:
             self._timed("phase_plan", ops.two_phase_plan, s["pts_offsets"], st, c.two_phase_fixed_cost, save_enter=enter, save_stay=stay)
             if self.k_host is not None:  # a pinned int32 [1]: the planned K travels to the host from this branch (read late, never waited for)
                 self.k_host.copy_(st.k, non_blocking=True)
+            if planes is None:  # and how long the backward's list is (_cu_cap reads it a step or two late: a hint, not a value)
+                self._front_host.copy_(st.stats[4:5], non_blocking=True)
         self._aux_pending = True
         f["feat"] = feat
         return f, comp
@@ -749,7 +761,12 @@ class HotPath:
     @contextlib.contextmanager
     def _cu_cap(self, stage=STAGE_FOCAL):
         """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it some of the CUs."""
-        n = self.cfg.prefetch_cus_global if stage == STAGE_GLOBAL else self.cfg.prefetch_cus
+        c = self.cfg
+        n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
+        if stage != STAGE_GLOBAL and self._pre is not None:
+            front = self.front_override if self.front_override is not None else int(self._front_host[0])
+            if front >= c.prefetch_dense_front:
+                n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
         cap = self._pre is not None and 0 < n < 256
         prev = _lib.lib().gfn_set_decoder_cus(n) if cap else 0
         try:

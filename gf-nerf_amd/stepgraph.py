@@ -160,6 +160,8 @@ class StepGraph:
                 if hp.last_forward == "lm2":
                     self.phased = int(hp._phase.k.item()) < 1024
                     hp.phase_override = None if self.phased else False
+                    if self.stage != hp_mod.STAGE_GLOBAL:  # how long the backward will be: the CUs it keeps beside the sampler (HotPath._cu_cap)
+                        hp.front_override = int(hp._phase.stats[4].item())
             self._since_capture, self._idle = 0, 0
             self._lm_captured = hp.level_major_global_now(self.update_oct) if self.stage == hp_mod.STAGE_GLOBAL else None
             self._k_host.fill_(-1)
@@ -179,6 +181,7 @@ class StepGraph:
             hp.step, hp._adam_t = steps_before, ticks_before  # capturing executes nothing: the counters must not move
         finally:
             hp.phase_override = outer_override
+            hp.front_override = None
         self._tree = (hp.nodes.data_ptr(), hp.n_nodes)
 
     def _capture_segments(self, j, pool):

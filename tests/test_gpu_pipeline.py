@@ -1285,7 +1285,9 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
         scale = float(ref["tg"].abs().max())
         assert float((b["tg"] - ref["tg"]).abs().max()) <= 5e-3 * scale, label   # zero gradients behind the cut either way; f16 pool
         if stage == "global":
-            np.testing.assert_allclose(b["mlp"].cpu().numpy(), ref["mlp"].cpu().numpy(), rtol=1e-4, atol=1e-6 * float(ref["mlp"].abs().max()), err_msg=label)
+            # (wgrad_reduce_kernel adds its shares of the 512 partial vectors with f32 atomics, in an order that differs from run to run: an entry that
+            # nearly cancels -- 2.7e-6 where the largest is 1e-2 -- was seen to differ by 1.8e-8, once in four runs: the floor is 1e-5 of the largest entry)
+            np.testing.assert_allclose(b["mlp"].cpu().numpy(), ref["mlp"].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref["mlp"].abs().max()), err_msg=label)
 
     b = run(two)  # second step: planned K
     last = two._phase.stats_last.cpu().numpy()
