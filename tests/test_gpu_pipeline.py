@@ -1400,3 +1400,38 @@ def test_psnr_of_the_product_against_the_reference_semantics():
         for g, v in pairs["exact|fast"].items():    # with the cut: the <= 1e-4 colour change flips Charbonnier's sign-like gradient on the few rays at |error| < 1e-4
             assert v["cos"] >= 0.995, (stage, step, g, v)
     torch.cuda.empty_cache()
+
+
+def test_backward_cu_share_follows_the_batch(setup):
+    """HotPath._cu_cap: while a prefetched sampler runs beside it the focal backward keeps cfg.prefetch_cus CUs -- unless the batch is dense (at least
+    cfg.prefetch_dense_front samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is
+    StepGraph's planning forward's, HotPath.front_override) and cfg.prefetch_cus_dense_eager when launched eagerly (the count is the pinned word the last
+    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards."""
+    from gfnerf_amd import _lib, hotpath
+
+    S = setup
+    cfg = hotpath.HotPathConfig(log2_T=S["cfg"].log2_T, prefetch_cus=160, prefetch_cus_global=192, prefetch_dense_front=1000, prefetch_cus_dense=184, prefetch_cus_dense_eager=200)
+    hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
+    L = _lib.lib()
+
+    def seen(stage):
+        with hp._cu_cap(stage):
+            now = L.gfn_set_decoder_cus(0)
+            L.gfn_set_decoder_cus(now)
+        return now
+
+    base = L.gfn_set_decoder_cus(0)
+    try:
+        assert seen("focal") == 0  # nothing prefetched: no cap
+        hp._pre = (None, None, None, False, {})
+        hp._front_host[0] = 10
+        assert seen("focal") == 160 and seen("global") == 192
+        hp._front_host[0] = 5000
+        assert seen("focal") == 200 and seen("global") == 192  # dense, eager launch
+        hp.front_override = 10  # (a capture's planning forward says otherwise: its word counts)
+        assert seen("focal") == 160
+        hp.front_override = None
+        assert L.gfn_set_decoder_cus(0) == 0  # restored
+    finally:
+        hp._pre = None
+        L.gfn_set_decoder_cus(base)
