@@ -125,7 +125,7 @@ def parse():
     ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
                     help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
                          "nearest (default); x3 = hi + lo' planes (rounds 1-4); mixed = dz one plane, activations split")
-    ap.add_argument("--record-merge", type=int, default=-1, help="focal backward in record form: merge runs of samples in one cell first (gfn_set_record_merge; -1: the library's default)")
+    ap.add_argument("--record-merge", type=int, default=-1, help="focal backward in record form: merge runs of samples in one cell first, 0 / 1 for every launch (gfn_set_record_merge); -1: the engine's policy (dense batches only)")
     ap.add_argument("--wgrad-beside-accumulate", action="store_true", help="experiment (global stage): wgrad on a second stream beside grad_accumulate")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
@@ -1193,7 +1193,10 @@ def run_rank(args):
     from gfnerf_amd import _lib, cluster, dist as gdist, scene
 
     if args.record_merge >= 0:
+        from gfnerf_amd import hotpath as _hp
+
         _lib.lib().gfn_set_record_merge(args.record_merge)
+        _hp.RECORD_MERGE_FIXED = True  # (the engines' own policy -- merge on dense batches -- is off: the switch is the experiment's)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

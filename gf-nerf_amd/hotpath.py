@@ -21,6 +21,7 @@ from . import _lib, dist as gdist, ops, scene
 
 STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
 STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
+RECORD_MERGE_FIXED = False  # True: the caller has fixed gfn_set_record_merge for the process (bench.py --record-merge): no per-launch policy (_cu_cap)
 
 
 @dataclass
@@ -84,6 +85,9 @@ class HotPathConfig:
                                      # capture's planning forward's (StepGraph)
     prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
     prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
+    record_merge_dense: bool = True  # ... and such a batch merges runs of samples in one cell before it writes its gradient records (gfn_set_record_merge
+                                     # for the launch): on the plugin-trained scene 90 -> 56 M records per step and 2.22 -> 2.10 ms per iteration; neutral on
+                                     # the natively trained scenes; on a sparse batch the shuffles cost more than the records they save (+2 %: not there)
     two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
                                      # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
                                      # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
@@ -760,20 +764,28 @@ class HotPath:
 
     @contextlib.contextmanager
     def _cu_cap(self, stage=STAGE_FOCAL):
-        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it some of the CUs."""
+        """Launch policy of the persistent backward kernel.  While a prefetched sampler runs on the second stream the kernel leaves it some of the
+        CUs; a DENSE focal batch (cfg.prefetch_dense_front) keeps more of them and merges runs of samples in one cell before it writes its records."""
         c = self.cfg
         n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
-        if stage != STAGE_GLOBAL and self._pre is not None:
+        dense = False
+        if stage != STAGE_GLOBAL:
             front = self.front_override if self.front_override is not None else int(self._front_host[0])
-            if front >= c.prefetch_dense_front:
+            dense = front >= c.prefetch_dense_front
+            if dense and self._pre is not None:
                 n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
         cap = self._pre is not None and 0 < n < 256
-        prev = _lib.lib().gfn_set_decoder_cus(n) if cap else 0
+        merge = dense and c.record_merge_dense and not RECORD_MERGE_FIXED
+        L = _lib.lib()
+        prev = L.gfn_set_decoder_cus(n) if cap else 0
+        prev_merge = L.gfn_set_record_merge(1) if merge else 0
         try:
             yield
         finally:
             if cap:
-                _lib.lib().gfn_set_decoder_cus(prev)
+                L.gfn_set_decoder_cus(prev)
+            if merge:
+                L.gfn_set_record_merge(prev_merge)
 
     def backward(self, ctx, g_rgb, g_acc=None):
         """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]): final on the

@@ -1406,7 +1406,8 @@ def test_backward_cu_share_follows_the_batch(setup):
     """HotPath._cu_cap: while a prefetched sampler runs beside it the focal backward keeps cfg.prefetch_cus CUs -- unless the batch is dense (at least
     cfg.prefetch_dense_front samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is
     StepGraph's planning forward's, HotPath.front_override) and cfg.prefetch_cus_dense_eager when launched eagerly (the count is the pinned word the last
-    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards."""
+    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards.  A dense focal batch
+    also has its record runs merged for the launch (cfg.record_merge_dense) unless the process fixed the switch (hotpath.RECORD_MERGE_FIXED)."""
     from gfnerf_amd import _lib, hotpath
 
     S = setup
@@ -1414,11 +1415,13 @@ def test_backward_cu_share_follows_the_batch(setup):
     hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
     L = _lib.lib()
 
-    def seen(stage):
+    def seen(stage, what="cus"):
         with hp._cu_cap(stage):
             now = L.gfn_set_decoder_cus(0)
             L.gfn_set_decoder_cus(now)
-        return now
+            merged = L.gfn_set_record_merge(0)
+            L.gfn_set_record_merge(merged)
+        return now if what == "cus" else merged
 
     base = L.gfn_set_decoder_cus(0)
     try:
@@ -1432,6 +1435,58 @@ def test_backward_cu_share_follows_the_batch(setup):
         assert seen("focal") == 160
         hp.front_override = None
         assert L.gfn_set_decoder_cus(0) == 0  # restored
+        # a dense focal batch also merges runs of samples in one cell before it writes its records (cfg.record_merge_dense), prefetch or not
+        assert seen("focal", "merge") == 1 and seen("global", "merge") == 0
+        hp._pre = None
+        assert seen("focal", "merge") == 1 and seen("focal") == 0
+        hp._front_host[0] = 10
+        assert seen("focal", "merge") == 0
+        hp._front_host[0] = 5000
+        hotpath.RECORD_MERGE_FIXED = True  # (bench.py --record-merge: the process-wide setting rules)
+        try:
+            assert seen("focal", "merge") == 0
+        finally:
+            hotpath.RECORD_MERGE_FIXED = False
+        assert L.gfn_set_record_merge(0) == 0  # restored
     finally:
         hp._pre = None
         L.gfn_set_decoder_cus(base)
+
+
+def test_merged_record_runs_give_the_same_table_gradient(setup):
+    """gfn_set_record_merge(1) (the focal backward's launch policy on dense batches, HotPath._cu_cap): runs of consecutive samples in one cell are summed
+    in f32 and written as ONE record per corner (field_bwd_dx_x3_kernel<0, 4>) -- fewer records, the same gradient up to the f16 rounding of a run's
+    sum (every addend is still quantised like the reference's, x128 -> f16), gradient mass conserved per channel."""
+    import torch
+
+    from gfnerf_amd import _lib, hotpath, ops
+
+    S = setup
+    t = S["t"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")
+    L = _lib.lib()
+    out = {}
+    base = L.gfn_set_record_merge(0)
+    try:
+        for merge in (0, 1):
+            cfg = hotpath.HotPathConfig(log2_T=18, early_T=1e-2)  # (T = 2^18: no record stream overflows into unordered atomics)
+            hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
+            hp.table.mul_(300.0)
+            hp.blocks[0].uniform_(-1e-1, 1e-1, generator=torch.Generator(device="cuda").manual_seed(5))
+            hp.refresh_shadows()
+            L.gfn_set_record_merge(merge)
+            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # (buffers exist now)
+            hp.record_counts_seen = torch.zeros_like(hp._records[1])
+            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
+            torch.cuda.synchronize()
+            out[merge] = dict(g=hp.table_grad.float().clone(), records=int(hp.record_counts_seen.to(torch.int64).sum()))
+    finally:
+        L.gfn_set_record_merge(base)
+    g0, g1 = out[0]["g"], out[1]["g"]
+    assert 0 < out[1]["records"] < 0.9 * out[0]["records"], (out[0]["records"], out[1]["records"])  # the merged form did run, and merged
+    scale = float(g0.abs().max())
+    assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-3 * scale
+    for ch in (0, 1):
+        a, b = g0.view(-1, 2)[:, ch].double().sum(), g1.view(-1, 2)[:, ch].double().sum()
+        assert abs(float(a - b)) <= 1e-3 * float(g0.view(-1, 2)[:, ch].double().abs().sum())

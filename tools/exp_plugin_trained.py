@@ -10,10 +10,14 @@ from gfnerf_amd import scene  # noqa: E402
 
 sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir="/tmp/gfnerf_amd_scene")
 from gfnerf_amd import _lib  # noqa: E402
+from gfnerf_amd import hotpath  # noqa: E402
 VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward", dict(graph_forward=False), 0), ("eager forward+merge", dict(graph_forward=False), 1),
                       ("graph, no prefetch", dict(prefetch=False), 0)],
-                cus=[(f"graph, backward on {n or 256} CUs beside the sampler", dict(hot_cfg=dict(prefetch_cus=n)), 0) for n in (0, 128, 160, 192, 224)])
+                cus=[(f"graph, backward on {n or 256} CUs beside the sampler", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n or 256)), 0) for n in (0, 128, 160, 192, 224)],
+                policy=[("the engine's policy (dense batch: every CU, records merged)", {}, None), ("merge fixed off", {}, 0), ("merge fixed on", {}, 1)])
 for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
+    hotpath.RECORD_MERGE_FIXED = merge is not None  # (None: the engine decides per launch, HotPath._cu_cap)
+    merge = merge or 0
     _lib.lib().gfn_set_record_merge(merge)
     r = bench.plugin_step_bench(sc, torch, "focal", steps=200, warmup=30, trained=(3000, 1000), **kw)
     print(name, round(r["ms_per_step"], 4), "host", round(r["host_ms_per_step"], 4), "forward", r["forward"], "samples/ray", round(r["mean_samples_per_ray"], 1),
