@@ -15,7 +15,7 @@ def short(name):
 
 
 def stats(d, out):
-    f = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # (a merged gpurun_out/ keeps earlier runs' files: the newest)
     rows = list(csv.DictReader(open(f)))
     with open(out, "w", newline="") as fo:
         w = csv.writer(fo)
@@ -25,7 +25,7 @@ def stats(d, out):
 
 
 def pmc_table(d, counter):
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
