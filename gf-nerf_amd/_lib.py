@@ -16,7 +16,7 @@ class WgradLayer(C.Structure):
                 ("m_valid", C.c_int32), ("k_valid", C.c_int32), ("col_map", _vp), ("dW", _vp), ("ldw", C.c_int32), ("db", _vp)]
 
 
-ABI_VERSION = 105  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
+ABI_VERSION = 106  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
 
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {
@@ -64,6 +64,7 @@ SIGNATURES = {
     "gfn_set_decoder_cus": (_i32, [_i32]),
     "gfn_set_plane_dither": (_i32, [_i32]),
     "gfn_set_record_merge": (_i32, [_i32]),
+    "gfn_set_record_merge_auto": (_i32, [_vp, _vp, _f32]),
     "gfn_set_march_lanes": (_i32, [_i32]),
     "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_wgrad_x3_parts": (_i32, []),

@@ -180,6 +180,10 @@ struct ScatterArgs {
   // (16 Ki-slot range, this workgroup): rec[(range * 256 + workgroup) * rec_cap + position], positions from LDS cursors;
   // csrc/grad_part.hip then accumulates every range in LDS (gfn_grad_records_reduce)
   uint2* rec; unsigned int* rec_count; unsigned int rec_cap; int n_ranges;
+  // gate (gfn_set_record_merge_auto): the launch is one of a PAIR -- the plain record form and the run-merging one -- and only the kernel whose
+  // `gate_want` equals [*gate_front >= gate_frac * *gate_n] does anything: which form a batch gets is decided on the device, from this step's own
+  // counts (samples in front of the termination points, samples), so a replayed step and an eagerly launched one decide alike
+  const int* gate_front; const int* gate_n; float gate_frac; int gate_want;
 };
 
 // sum v over the lanes [j, run_end] of this 32-lane half (runs = consecutive samples in one cell of one volume)
@@ -288,6 +292,11 @@ __global__ __launch_bounds__((bwd_threads<PLANES, SCATTER>())) void field_bwd_dx
     const int32_t* __restrict__ list_n /* termination points -- every other sample's incoming gradient is zero */,
     float dither /* PL_RNE: amplitude of the per-sample dither (plane_dither, x3_device.h) */) {
 #define BPL(half, C) (planes_##half + cap * (C))
+  if (SCATTER >= 3 && S.gate_front) {  // kernel-uniform: the other kernel of the pair has this batch
+    const int gn = *S.gate_n;
+    const bool dense = gn > 0 && (float)*S.gate_front >= S.gate_frac * (float)gn;
+    if ((int)dense != S.gate_want) return;
+  }
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_BWD_BYTES / 16; e += blockDim.x) L[e] = image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_BWD_BYTES / 16);
@@ -585,6 +594,9 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
 int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
 int g_plane_dither = 1;  // gfn_set_plane_dither
 int g_record_merge = 0;  // gfn_set_record_merge
+const int* g_merge_gate_front = nullptr;  // gfn_set_record_merge_auto
+const int* g_merge_gate_n = nullptr;
+float g_merge_gate_frac = 0.f;
 
 }  // namespace
 int gfn_decoder_cu_cap() { return (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256; }
@@ -692,6 +704,7 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   S.pts = sh.pts; S.anchors = sh.anchors; S.prim_pool = sh.prim_pool; S.bias_pool = sh.bias_pool; S.n_volumes = sh.n_volumes; S.log2_T = sh.log2_T;
   S.grad_pool = sh.grad_pool; S.grad_f16 = sh.grad_f16;
   S.rec = reinterpret_cast<uint2*>(sh.rec); S.rec_count = sh.rec_count; S.rec_cap = 0; S.n_ranges = 0;
+  S.gate_front = nullptr; S.gate_n = nullptr; S.gate_frac = 0.f; S.gate_want = 0;
   if (sh.rec) {
     const int64_t T = 1ll << sh.log2_T;
     const int64_t n_ranges = (8 * T + T / 2 + (1ll << GFN_GRAD_RANGE_LOG2) - 1) >> GFN_GRAD_RANGE_LOG2;
@@ -711,6 +724,20 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   if (planes == P && mode == SC)                                                                                                 \
     field_bwd_dx_x3_kernel<P, SC><<<grid, bwd_threads<P, SC>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi, \
                                                                           planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
+  if (mode == 3 && !planes && g_merge_gate_front) {  // the gated pair: the device picks the form (see ScatterArgs)
+    S.gate_front = g_merge_gate_front; S.gate_n = g_merge_gate_n; S.gate_frac = g_merge_gate_frac;
+    for (int want = 0; want < 2; want++) {
+      S.gate_want = want;
+      if (want == 0)
+        field_bwd_dx_x3_kernel<0, 3><<<grid, bwd_threads<0, 3>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi,
+                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
+      else
+        field_bwd_dx_x3_kernel<0, 4><<<grid, bwd_threads<0, 4>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi,
+                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
+      GFN_CHECK_LAUNCH();
+    }
+    return GFN_OK;
+  }
   GFN_BWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_BWD_ALL
@@ -770,6 +797,12 @@ int gfn_set_record_merge(int on) {
   const int old = g_record_merge;
   g_record_merge = on != 0;
   return old;
+}
+
+int gfn_set_record_merge_auto(const int32_t* front_dev, const int32_t* n_dev, float frac) {
+  GFN_CHECK_ARG((front_dev == nullptr) == (n_dev == nullptr) && frac >= 0.f, "gfn_set_record_merge_auto: both counts (or neither), frac >= 0");
+  g_merge_gate_front = front_dev; g_merge_gate_n = n_dev; g_merge_gate_frac = frac;
+  return GFN_OK;
 }
 
 int gfn_set_plane_dither(int on) {

@@ -257,7 +257,8 @@ class GFNeRFModel(Model):
         assert c.hidden_dim == c.hidden_dim_color, "the fused decoder uses one hidden width (gfnerf/config.py:124-125: 128 / 128)"
         cfg = hp_mod.HotPathConfig(log2_T=c.log2_hashmap_size, hidden=c.hidden_dim, scale_factor=c.scale_factor, early_T=c.early_T,
                                    use_appearance_embedding=c.use_appearance_embedding, s3im_loss_mult=c.s3im_loss_mult,
-                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time)
+                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time,
+                                   record_merge_dense=True)  # (dense focal batches merge their record runs, decided on the device: HotPath._record_merge)
         self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg, device=dev,
                                   seed=c.engine_seed, n_blocks=0, sync=self.kwargs.get("sync", None))
         if self.hot.sync.world > 1 and c.n_split_dataset % self.hot.sync.world != 0:

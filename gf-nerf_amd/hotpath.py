@@ -77,17 +77,19 @@ class HotPathConfig:
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
     prefetch_cus_global: int = 192   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)
-    prefetch_dense_front: int = 600_000  # focal stage, a batch with at least this many samples in front of the termination points (a trained scene:
-                                     # most of 4096 x 192; the random-init fog has 450 k) has a backward two to three times as long as the sampler
-                                     # beside it, which then needs fewer CUs (round 5, tools/README.md: native replay 1.57 -> 1.52 ms at 176-192 CUs, a
-                                     # cliff from 200 on; through the plugin surface, eager launches with the sampler enqueued first, 2.30 -> 2.21 ms with
-                                     # no cap at all).  The count is last step's (a pinned word the forward's side branch copies, read late) or the
-                                     # capture's planning forward's (StepGraph)
+    prefetch_dense_frac: float = 0.75  # focal stage, a DENSE batch -- at least this share of its samples in front of the termination points (a trained
+                                     # scene: 0.87-0.95 of 4096 x 192; the random-init fog has 0.57, a half-pruned scene 0.61-0.65) -- has a backward two
+                                     # to three times as long as the sampler beside it, which then needs fewer CUs (round 5, tools/README.md: native replay
+                                     # 1.57 -> 1.52 ms at 176-192 CUs, a cliff from 200 on; through the plugin surface, eager launches with the sampler
+                                     # enqueued first, 2.30 -> 2.21 ms with no cap at all).  The two counts are last step's (a pinned pair the forward's side
+                                     # branch copies, read late) or the capture's planning forward's (StepGraph)
     prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
     prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
-    record_merge_dense: bool = True  # ... and such a batch merges runs of samples in one cell before it writes its gradient records (gfn_set_record_merge
-                                     # for the launch): on the plugin-trained scene 90 -> 56 M records per step and 2.22 -> 2.10 ms per iteration; neutral on
-                                     # the natively trained scenes; on a sparse batch the shuffles cost more than the records they save (+2 %: not there)
+    record_merge_dense: bool = False  # ... and such a batch merges runs of samples in one cell before it writes its gradient records -- decided on the DEVICE
+                                     # from the step's own counts (gfn_set_record_merge_auto; needs the phased forward's front list).  On through the plugin
+                                     # surface (gfnerf/nerfacto.py: 90 -> 56 M records per step and 2.22 -> 2.10 ms per iteration on a scene trained there);
+                                     # off here because it is neutral on the natively trained scenes and a merged run's sum is rounded to f16 once more: the
+                                     # list-walking and the every-sample form of the backward would no longer give the same bits (StepGraph against eager steps)
     two_phase: bool = True           # level-major training forward with early_T > 0: look up / decode only the first K samples of every ray,
                                      # then the rest of the rays that are still transparent (none, as a rule); K is planned on the device
                                      # from where the previous batch's rays ended (ops.two_phase_plan).  False: every sample
@@ -134,8 +136,8 @@ class HotPath:
         self._records = None
         self._opt_stream, self._opt_pending = None, False
         self.k_host = None          # see _forward_phased
-        self._front_host = torch.zeros(1, dtype=torch.int32).pin_memory()  # samples in front of the termination points, as the last phased focal forward counted them (_cu_cap)
-        self.front_override = None  # StepGraph.capture: the count of its planning forward, for the launches it captures
+        self._front_host = torch.zeros(2, dtype=torch.int32).pin_memory()  # [samples in front of the termination points, samples] of the last phased focal forward (_cu_cap)
+        self.front_override = None  # StepGraph.capture: (in front, samples) of its planning forward, for the launches it captures
         self._aux_stream, self._aux_pending = None, False  # branch of the phased forward: front list + plan beside the loss
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
                                     # matrix-bound: side work started here does not slow the gathers down; gfnerf_amd.stepgraph)
@@ -498,7 +500,8 @@ class HotPath:
             if self.k_host is not None:  # a pinned int32 [1]: the planned K travels to the host from this branch (read late, never waited for)
                 self.k_host.copy_(st.k, non_blocking=True)
             if planes is None:  # and how long the backward's list is (_cu_cap reads it a step or two late: a hint, not a value)
-                self._front_host.copy_(st.stats[4:5], non_blocking=True)
+                self._front_host[0:1].copy_(st.stats[4:5], non_blocking=True)
+                self._front_host[1:2].copy_(n_dev, non_blocking=True)
         self._aux_pending = True
         f["feat"] = feat
         return f, comp
@@ -762,30 +765,42 @@ class HotPath:
             self._records = ops.grad_records_buffers(c.log2_T, min(c.record_capacity, n_streams * 2048), self.dev)  # <= 2048 records per stream
         return self._records
 
+    def _dense_hint(self):
+        """Is the focal batch at hand DENSE (cfg.prefetch_dense_frac of its samples in front of the termination points)?  The host's view: the counts of
+        StepGraph's planning forward while it captures, else those of the last phased forward (a pinned pair, read late: a hint)."""
+        front, n_all = self.front_override if self.front_override is not None else (int(self._front_host[0]), int(self._front_host[1]))
+        return n_all > 0 and front >= self.cfg.prefetch_dense_frac * n_all
+
     @contextlib.contextmanager
     def _cu_cap(self, stage=STAGE_FOCAL):
-        """Launch policy of the persistent backward kernel.  While a prefetched sampler runs on the second stream the kernel leaves it some of the
-        CUs; a DENSE focal batch (cfg.prefetch_dense_front) keeps more of them and merges runs of samples in one cell before it writes its records."""
+        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it some of the CUs -- fewer of them when the focal
+        batch is dense (its backward is long: _dense_hint).  Only the grid depends on this: the gradient's bits do not."""
         c = self.cfg
         n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
-        dense = False
-        if stage != STAGE_GLOBAL:
-            front = self.front_override if self.front_override is not None else int(self._front_host[0])
-            dense = front >= c.prefetch_dense_front
-            if dense and self._pre is not None:
-                n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
+        if stage != STAGE_GLOBAL and self._pre is not None and self._dense_hint():
+            n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
         cap = self._pre is not None and 0 < n < 256
-        merge = dense and c.record_merge_dense and not RECORD_MERGE_FIXED
-        L = _lib.lib()
-        prev = L.gfn_set_decoder_cus(n) if cap else 0
-        prev_merge = L.gfn_set_record_merge(1) if merge else 0
+        prev = _lib.lib().gfn_set_decoder_cus(n) if cap else 0
         try:
             yield
         finally:
             if cap:
-                L.gfn_set_decoder_cus(prev)
-            if merge:
-                L.gfn_set_record_merge(prev_merge)
+                _lib.lib().gfn_set_decoder_cus(prev)
+
+    @contextlib.contextmanager
+    def _record_merge(self, front, n_dev):
+        """cfg.record_merge_dense: the focal backward merges the record runs of a DENSE batch (cfg.prefetch_dense_frac).  front = (list, count) of the phased
+        forward: the DEVICE decides from this step's own counts (gfn_set_record_merge_auto: both forms are launched, one does the work), so a replayed
+        forward and an eager one lead to the same bits.  Without a front list: no merging."""
+        L = _lib.lib()
+        if not self.cfg.record_merge_dense or RECORD_MERGE_FIXED or front is None:
+            yield
+            return
+        _lib.check(L.gfn_set_record_merge_auto(ops._ptr(front[1]), ops._ptr(n_dev), float(self.cfg.prefetch_dense_frac)), "gfn_set_record_merge_auto")
+        try:
+            yield
+        finally:
+            L.gfn_set_record_merge_auto(None, None, 0.0)
 
     def backward(self, ctx, g_rgb, g_acc=None):
         """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]): final on the
@@ -852,7 +867,7 @@ class HotPath:
                 self._timed("wgrad", ops.wgrad_x3_layers, layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
             rec = self._record_buffers()
-            with self._cu_cap():
+            with self._cu_cap(), self._record_merge(f.get("front") if rec is not None else None, n_dev):
                 self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
                             s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
                             self.table_grad, n_dev=n_dev, records=rec, sample_list=f.get("front"))

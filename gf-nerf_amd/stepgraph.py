@@ -161,7 +161,7 @@ class StepGraph:
                     self.phased = int(hp._phase.k.item()) < 1024
                     hp.phase_override = None if self.phased else False
                     if self.stage != hp_mod.STAGE_GLOBAL:  # how long the backward will be: the CUs it keeps beside the sampler (HotPath._cu_cap)
-                        hp.front_override = int(hp._phase.stats[4].item())
+                        hp.front_override = (int(hp._phase.stats[4].item()), int(self.S[j0 % 2]["pts_offsets"][-1].item()))
             self._since_capture, self._idle = 0, 0
             self._lm_captured = hp.level_major_global_now(self.update_oct) if self.stage == hp_mod.STAGE_GLOBAL else None
             self._k_host.fill_(-1)

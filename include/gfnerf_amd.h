@@ -52,7 +52,7 @@ typedef enum {
  *   102: round 4.   103: round 4 (gfn_sample_rays_record, gfn_fused_render_rec added; GFN_MARCH_REC_FLOATS 6 -> 8: a caller's march_rec
  *   buffer grows by a third).   104, 105: round 5 (gfn_set_plane_dither, gfn_set_march_lanes added; one-plane forms of the x3 plane
  *   arguments; gfn_sample_rays_record / gfn_fused_render_rec gained the paged record form's arguments). */
-#define GFN_ABI_VERSION 105
+#define GFN_ABI_VERSION 106
 
 const char* gfn_last_error(void);
 int gfn_version(void);
@@ -396,6 +396,13 @@ int gfn_set_plane_dither(int on);
  * records where a batch's rays crowd few cells (one camera cluster: the coarse levels' streams fill up and the overflow goes
  * through atomics); a few shuffles more where they do not.  Returns the previous value.  Process-wide; default off. */
 int gfn_set_record_merge(int on);
+/* ... or decided ON THE DEVICE for every launch: with front_dev / n_dev set (device i32 words: the batch's samples in front of the
+ * termination points, e.g. the count of gfn_phase_list's front list, and its samples), gfn_field_bwd_scatter_x3 in record form without
+ * planes launches BOTH forms and only the one that fits does anything -- the merging form when *front_dev >= frac * *n_dev (a dense
+ * batch), the plain one otherwise.  The choice then depends on the step's own data and not on when the host looked: a replayed step
+ * and an eagerly launched one produce the same bits.  NULL, NULL switches it off (gfn_set_record_merge rules again).  Process-wide;
+ * the pointers must stay valid for every launch made while they are set. */
+int gfn_set_record_merge_auto(const int32_t* front_dev, const int32_t* n_dev, float frac);
 /* Lanes per ray of gfn_sample_rays' march: 16 (a row per ray: batches that leave the machine empty) or 4 (a quad: a quarter of the
  * vector work per ray), 0 = by batch size (a quad from 32 Ki rays on).  Both give the same bits (tests run both on the same rays).
  * Starts at GFN_MARCH_LANES from the environment, read once.  Returns the previous value.  Process-wide. */

@@ -1404,53 +1404,81 @@ def test_psnr_of_the_product_against_the_reference_semantics():
 
 def test_backward_cu_share_follows_the_batch(setup):
     """HotPath._cu_cap: while a prefetched sampler runs beside it the focal backward keeps cfg.prefetch_cus CUs -- unless the batch is dense (at least
-    cfg.prefetch_dense_front samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is
+    cfg.prefetch_dense_frac of its samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is
     StepGraph's planning forward's, HotPath.front_override) and cfg.prefetch_cus_dense_eager when launched eagerly (the count is the pinned word the last
-    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards.  A dense focal batch
-    also has its record runs merged for the launch (cfg.record_merge_dense) unless the process fixed the switch (hotpath.RECORD_MERGE_FIXED)."""
+    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards.  (Only the grid depends
+    on the hint; what does change values -- merging the record runs of a dense batch -- is decided on the device: next test.)"""
     from gfnerf_amd import _lib, hotpath
 
     S = setup
-    cfg = hotpath.HotPathConfig(log2_T=S["cfg"].log2_T, prefetch_cus=160, prefetch_cus_global=192, prefetch_dense_front=1000, prefetch_cus_dense=184, prefetch_cus_dense_eager=200)
+    cfg = hotpath.HotPathConfig(log2_T=S["cfg"].log2_T, prefetch_cus=160, prefetch_cus_global=192, prefetch_dense_frac=0.75, prefetch_cus_dense=184, prefetch_cus_dense_eager=200)
     hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
     L = _lib.lib()
 
-    def seen(stage, what="cus"):
+    def seen(stage):
         with hp._cu_cap(stage):
             now = L.gfn_set_decoder_cus(0)
             L.gfn_set_decoder_cus(now)
-            merged = L.gfn_set_record_merge(0)
-            L.gfn_set_record_merge(merged)
-        return now if what == "cus" else merged
+        return now
 
     base = L.gfn_set_decoder_cus(0)
     try:
         assert seen("focal") == 0  # nothing prefetched: no cap
         hp._pre = (None, None, None, False, {})
-        hp._front_host[0] = 10
+        hp._front_host[0], hp._front_host[1] = 10, 1000
         assert seen("focal") == 160 and seen("global") == 192
-        hp._front_host[0] = 5000
+        hp._front_host[0] = 800
         assert seen("focal") == 200 and seen("global") == 192  # dense, eager launch
-        hp.front_override = 10  # (a capture's planning forward says otherwise: its word counts)
+        hp.front_override = (10, 1000)  # (a capture's planning forward says otherwise: its word counts)
         assert seen("focal") == 160
         hp.front_override = None
         assert L.gfn_set_decoder_cus(0) == 0  # restored
-        # a dense focal batch also merges runs of samples in one cell before it writes its records (cfg.record_merge_dense), prefetch or not
-        assert seen("focal", "merge") == 1 and seen("global", "merge") == 0
-        hp._pre = None
-        assert seen("focal", "merge") == 1 and seen("focal") == 0
-        hp._front_host[0] = 10
-        assert seen("focal", "merge") == 0
-        hp._front_host[0] = 5000
-        hotpath.RECORD_MERGE_FIXED = True  # (bench.py --record-merge: the process-wide setting rules)
-        try:
-            assert seen("focal", "merge") == 0
-        finally:
-            hotpath.RECORD_MERGE_FIXED = False
-        assert L.gfn_set_record_merge(0) == 0  # restored
     finally:
         hp._pre = None
         L.gfn_set_decoder_cus(base)
+
+
+def test_record_merge_is_decided_on_the_device_from_the_steps_own_counts(setup):
+    """cfg.record_merge_dense: with the phased forward's front list at hand the focal backward launches the plain and the run-merging record form as a
+    gated pair (gfn_set_record_merge_auto) and the DEVICE picks one from this step's counts -- front >= cfg.prefetch_dense_frac x samples: the merging
+    form.  Seen from outside: the number of records written.  A threshold no batch reaches gives the plain form's count, one every batch reaches the
+    merged form's (fewer), from the very first step (no host-side hint is involved); the process-wide switch (hotpath.RECORD_MERGE_FIXED, bench.py
+    --record-merge) takes the gate out; the gradient is the same up to the f16 rounding of a run's sum either way."""
+    import torch
+
+    from gfnerf_amd import _lib, hotpath, ops
+
+    S = setup
+    t = S["t"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")
+
+    def run(frac, fixed=None):
+        cfg = hotpath.HotPathConfig(log2_T=18, early_T=1e-2, prefetch_dense_frac=frac, record_merge_dense=True)  # (what the plugin surface switches on)
+        hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
+        hp.table.mul_(300.0)
+        hp.blocks[0].uniform_(-1e-1, 1e-1, generator=torch.Generator(device="cuda").manual_seed(5))
+        hp.refresh_shadows()
+        hp._record_buffers()
+        hp.record_counts_seen = torch.zeros_like(hp._records[1])
+        prev = _lib.lib().gfn_set_record_merge(0)
+        try:
+            if fixed is not None:
+                hotpath.RECORD_MERGE_FIXED = True
+                _lib.lib().gfn_set_record_merge(fixed)
+            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # the FIRST step of the engine
+            torch.cuda.synchronize()
+        finally:
+            hotpath.RECORD_MERGE_FIXED = False
+            _lib.lib().gfn_set_record_merge(prev)
+        assert hp.last_forward == "lm2"
+        return int(hp.record_counts_seen.to(torch.int64).sum()), hp.table_grad.float().clone()
+
+    plain, g_plain = run(2.0)
+    merged, g_merged = run(0.0)
+    assert 0 < merged < 0.9 * plain, (plain, merged)
+    assert run(2.0, fixed=1)[0] == merged and run(0.0, fixed=0)[0] == plain  # the process-wide switch rules when it is fixed
+    assert float((g_merged - g_plain).abs().max()) <= 2e-3 * float(g_plain.abs().max())
 
 
 def test_merged_record_runs_give_the_same_table_gradient(setup):
