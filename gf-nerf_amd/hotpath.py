@@ -21,7 +21,7 @@ from . import _lib, dist as gdist, ops, scene
 
 STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
 STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
-RECORD_MERGE_FIXED = False  # True: the caller has fixed gfn_set_record_merge for the process (bench.py --record-merge): no per-launch policy (_cu_cap)
+RECORD_MERGE_FIXED = False  # True: the caller has fixed gfn_set_record_merge for the process (bench.py --record-merge): no per-launch choice (HotPath._record_merge)
 
 
 @dataclass
@@ -72,7 +72,7 @@ class HotPathConfig:
     lds_accumulate: bool = True      # backward: write the table adds as records, sort + accumulate them in LDS (grad_part.hip)
     record_capacity: int = 1 << 29   # 8-byte record slots (4 GiB; 1,927 per (range, workgroup) stream at T = 2^21) -- a full stream falls back to atomics, at a
                                      # fifth of the rate.  The global stage writes 48 M records per step, a focal step 13-17 M on a young table (most
-                                     # contributions round to zero at the pool's f16 x128 scale) and up to 79 M once every sample carries a gradient
+                                     # contributions round to zero at the pool's f16 x128 scale) and up to 90 M once every sample carries a gradient
                                      # (measured through the plugin surface on a scene trained there: bench.py plugin_step_trained)
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
@@ -98,8 +98,9 @@ class HotPathConfig:
     two_phase_min_saving_planes: tuple = (0.30, 0.20)  # ... in the global stage: compacted samples write unaligned activation-plane rows
     mlp_precision: str = "x3"        # fused decoder arithmetic: "x3" split-f16 MFMA (f32 accuracy), "f32" exact f32 MFMA
     wgrad_planes: str = "rne"        # operands of the decoder's WEIGHT gradient (global stage; dW = sum over the batch's 5e5 samples of dz a):
-                                     # "rne" one f16 plane per operand, rounded to nearest (zero-mean per term, averages out in the sum;
-                                     # half the plane traffic, one MFMA per fragment pair); "x3" hi + lo' planes for both (rounds 1-4:
+                                     # "rne" one f16 plane per operand, rounded to nearest under a per-sample dither that makes neighbouring samples'
+                                     # rounding errors independent (zero-mean per term, averages out in the sum; half the plane traffic, one MFMA
+                                     # per fragment pair; dza1 alone keeps its lo' half: csrc/x3_device.h); "x3" hi + lo' planes for both (rounds 1-4:
                                      # f32-class per term); "mixed" dz one plane, activations hi + lo'.  The per-sample chains (forward,
                                      # d x = W^T dz, the table gradient) are x3 whatever this says
     wgrad_beside_accumulate: bool = False  # global stage, one rank: the decoder's weight-gradient kernel on a second stream beside the LDS accumulation
@@ -136,7 +137,7 @@ class HotPath:
         self._records = None
         self._opt_stream, self._opt_pending = None, False
         self.k_host = None          # see _forward_phased
-        self._front_host = torch.zeros(2, dtype=torch.int32).pin_memory()  # [samples in front of the termination points, samples] of the last phased focal forward (_cu_cap)
+        self._front_host = torch.zeros(2, dtype=torch.int32).pin_memory()  # [samples in front of the termination points, samples] of the last phased focal forward (_dense_hint)
         self.front_override = None  # StepGraph.capture: (in front, samples) of its planning forward, for the launches it captures
         self._aux_stream, self._aux_pending = None, False  # branch of the phased forward: front list + plan beside the loss
         self.after_lookup = None    # called once the training forward's table lookups are enqueued (the kernels that follow are
