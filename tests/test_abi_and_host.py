@@ -248,3 +248,54 @@ def test_bench_line_stays_under_two_thousand_characters():
         assert key in c, key
     assert line["roofline"]["kernel"] == "lm_lookup_kernel<true, false>" and set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_profile_summaries_take_the_newest_run_of_a_merged_directory(tmp_path):
+    """tools/prof_summary.py (what turns rocprofv3 output into profiles/*.csv): gpurun merges every call's files into the same local directory, named by
+    process id, so a directory may hold several runs' files -- the summary must be the NEWEST run's (round 5: the first file found was an older run's)
+    -- and tools/trace_tail.py's per-step window divides by the dispatches of the kernel it is told marks a step."""
+    import csv
+    import subprocess
+    import time
+
+    d = tmp_path / "kt" / "runc"
+    d.mkdir(parents=True)
+    head = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]
+    for pid, avg in ((111, "100.0"), (222, "200.0")):
+        with open(d / f"{pid}_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(head)
+            w.writerow(["void (anonymous namespace)::k(int)", "4", "800", avg, "100", "1", "9"])
+        time.sleep(0.05)
+    os.utime(d / "111_kernel_stats.csv", (1, 1))  # the older run
+    out = tmp_path / "stats.csv"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), "stats", str(tmp_path / "kt"), str(out)])
+    rows = list(csv.DictReader(open(out)))
+    assert rows == [dict(kernel="k(int)", calls="4", total_ns="800", avg_ns="200.0", percent="100", min_ns="1", max_ns="9")]
+    p = tmp_path / "pmc" / "runc"
+    p.mkdir(parents=True)
+    for pid, val in ((5, "1000"), (6, "3000")):
+        with open(p / f"{pid}_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writerow(["void (anonymous namespace)::k(int)", "FETCH_SIZE", val])
+    os.utime(p / "5_counter_collection.csv", (1, 1))
+    out2 = tmp_path / "pmc.csv"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), "pmc_many", str(out2), str(tmp_path / "pmc")])
+    r2 = list(csv.DictReader(open(out2)))
+    assert len(r2) == 1 and r2[0]["kernel"] == "k(int)" and float(r2[0]["FETCH_SIZE_mean"]) == 3000.0
+    # trace_tail: the last 1 ms of a trace, per step = per dispatch of the marker kernel
+    t = tmp_path / "trace"
+    t.mkdir()
+    with open(t / "7_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Start_Timestamp", "End_Timestamp", "Kernel_Name", "Queue_Id"])
+        w.writerow([0, 100, "old", "1"])  # outside the window
+        for i in range(4):
+            w.writerow([10_000_000 + i * 100_000, 10_000_000 + i * 100_000 + 50_000, "step_marker", "1"])
+            w.writerow([10_000_000 + i * 100_000 + 50_000, 10_000_000 + i * 100_000 + 80_000, "other", "1"])
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_tail.py"), str(t), "1", "auto:step_marker"], capture_output=True, text=True, check=True).stdout
+    assert "/ 4:" in res and "old" not in res, res
+    lines = [ln.split() for ln in res.splitlines()[1:]]
+    got = {ln[-1]: float(ln[0]) for ln in lines}
+    assert abs(got["step_marker"] - 0.05) < 1e-9 and abs(got["other"] - 0.03) < 1e-9, res

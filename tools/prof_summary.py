@@ -48,7 +48,8 @@ def pmc_many(dirs, out):
     """pmc_many <out.csv> <dir>...: mean per launch of every counter found in several --pmc passes (one row per kernel)."""
     acc = defaultdict(lambda: defaultdict(list))
     for d in dirs:
-        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        found = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+        for f in ([max(found, key=os.path.getmtime)] if found else []):  # (one pass per directory: the newest, as in stats())
             for r in csv.DictReader(open(f)):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for k in acc for c in acc[k]})
