@@ -394,21 +394,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_layers_kernel(int64_t n_max, 
   }
 }
 
-// out[i] += sum over the workgroups' partial vectors (split over blockIdx.y; out zeroed by the caller)
+// out[i] += sum over the workgroups' partial vectors, in ONE fixed order whatever the launch's timing (the same bits every run, like the
+// cuBLAS GEMMs of gfnerf/mlp.py:35-57): a workgroup owns 64 consecutive outputs; wave w adds the parts w, w + 4, w + 8, ... of its quarter
+// into four running sums, the four waves' results meet in LDS and are added as ((w0 + w1) + (w2 + w3)); one plain store per output.
+constexpr int kReduceCols = 64;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t stride, int64_t n,
                                                            float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int per = (n_parts + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = (b0 + per < n_parts) ? b0 + per : n_parts;
+  __shared__ float part_sum[4][kReduceCols];
+  const int col = threadIdx.x & (kReduceCols - 1), w = threadIdx.x / kReduceCols;
+  const int64_t i = (int64_t)blockIdx.x * kReduceCols + col;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  int b = b0;
-  for (; b + 4 <= b1; b += 4)
+  if (i < n) {
+    int b = w;
+    for (; b + 12 < n_parts; b += 16)
 #pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] += parts[(int64_t)(b + u) * stride + i];
-  for (; b < b1; b++) acc[0] += parts[(int64_t)b * stride + i];
-  const float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  if (v != 0.f) atomicAdd(out + i, v);
+      for (int u = 0; u < 4; u++) acc[u] += parts[(int64_t)(b + 4 * u) * stride + i];
+    for (; b < n_parts; b += 4) acc[0] += parts[(int64_t)b * stride + i];
+  }
+  part_sum[w][col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (w == 0 && i < n) {
+    const float v = (part_sum[0][col] + part_sum[1][col]) + (part_sum[2][col] + part_sum[3][col]);
+    if (v != 0.f) out[i] += v;
+  }
 }
 
 constexpr int kWgradBlocks = 512;  // two workgroups per CU; also the number of partial vectors
@@ -538,8 +546,7 @@ int gfn_wgrad_x3_layers(const gfn_wgrad_layer* layers, int n_layers, int64_t n_m
 int gfn_wgrad_reduce(const float* parts, int n_parts, int64_t part_stride, int64_t n, float* out, void* stream) {
   if (n <= 0 || n_parts <= 0) return GFN_OK;
   GFN_CHECK_ARG(parts && out && part_stride >= n, "gfn_wgrad_reduce: bad arguments");
-  const dim3 grid((unsigned)((n + 255) / 256), 4);
-  wgrad_reduce_kernel<<<grid, 256, 0, gfn_stream(stream)>>>(parts, n_parts, part_stride, n, out);
+  wgrad_reduce_kernel<<<(unsigned)((n + kReduceCols - 1) / kReduceCols), 256, 0, gfn_stream(stream)>>>(parts, n_parts, part_stride, n, out);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

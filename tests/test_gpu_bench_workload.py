@@ -282,7 +282,44 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
         hp._plane_bufs = None
 
 
+def _wgrad_exact(world, S, hp, torch, ops):
+    """The float64 contraction dz^T a of the x3 planes (22-bit operands) over all samples, per layer: what the one-plane modes are held to.  Made by
+    the "x3" case when it runs first, and HERE when a one-plane case runs without it (-k rne, another order, another worker): the accuracy gate never
+    passes for want of its reference (VERDICT r05 #10)."""
+    exact = world["cache"].setdefault("wgrad_exact", {})
+    if len(exact) == 5:
+        return exact
+    prev = (hp.cfg.wgrad_planes, hp.cfg.level_major_global)
+    hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp._plane_bufs = "x3", False, None
+    try:
+        o, d, cam, noise = _t(S["o"]), _t(S["d"]), _t(S["cam"]), _t(S["noise"])
+        comp, ctx = hp.forward_train(o, d, cam, noise, stage="global")
+        s = ctx["samples"]
+        n = int(s["pts_offsets"][-1].item())
+        _, g_rgb = _g_rgb(S, comp["rgb"])
+        hp.backward(ctx, g_rgb)
+        scale = ops.grad_scale(float(hp._gmax.item()))
+        fp, bp = hp._planes(s["ts"].shape[0])
+        pl = lambda pair, ld, name, table: (ops.plane_view(pair[0], ld, name, table)[:n].double() +  # noqa: E731
+                                            ops.plane_view(pair[1], ld, name, table)[:n].double() / 2048.0)
+        cm = torch.from_numpy(hp._xp_col_map.cpu().numpy()).cuda()
+        for li, dzk, ak, mv in ((4, "dz3", "c2", 3), (3, "dz2", "c1", 128), (2, "dz1", "xp", 128), (1, "dh", "a1", 16), (0, "dza1", "feat", 128)):
+            dz = pl(bp, ops.FIELD_X3_BWD_PLANE_LD, dzk, ops.BWD_PLANE)[:, :mv] / scale
+            want = dz.T @ pl(fp, ops.FIELD_X3_FWD_PLANE_LD, ak, ops.FWD_PLANE)
+            if ak == "xp":
+                w2 = torch.zeros((mv, 63), dtype=torch.float64, device="cuda")
+                w2[:, cm[cm >= 0].long()] = want[:, cm >= 0]
+                want = w2
+            exact[li] = (want, dz.sum(0))
+    finally:
+        hp.cfg.wgrad_planes, hp.cfg.level_major_global = prev
+        hp._plane_bufs = None
+    return exact
+
+
 def _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=1e-4):
+    if mode != "x3":
+        _wgrad_exact(world, S, hp, torch, ops)
     o, d, cam, noise = _t(S["o"]), _t(S["d"]), _t(S["cam"]), _t(S["noise"])
     comp, ctx = hp.forward_train(o, d, cam, noise, stage="global")
     s, f = ctx["samples"], ctx["field"]
@@ -356,10 +393,10 @@ def _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=1e
             eB = float((gB.double() - wB).abs().max()) / float(wB.abs().max())
             cos = float((gW.double() * wW).sum() / (gW.double().norm() * wW.norm()))
             report.append((li, eW, eB, cos))
-    if report:
+    if mode != "x3":
         print(f"\n[wgrad {mode}/{forward}] max |dW - exact| / max |dW| per layer (layer, dW, db, cosine): " +
               ", ".join(f"({li}, {eW:.2e}, {eB:.2e}, {cos:.8f})" for li, eW, eB, cos in report))
-        assert len(report) == 5  # (the x3 case runs first: pytest keeps the parametrisation's order)
+        assert len(report) == 5, "the one-plane accuracy gate has no x3 reference to compare with"  # (made by _wgrad_exact when the x3 case did not run first)
         for li, eW, eB, cos in report:
             assert eW <= bar and eB <= bar and cos >= 0.99999, (mode, li, eW, eB, cos)
 

@@ -1252,8 +1252,8 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
     assert two.last_forward == "lm2"
     for k in ("rgb", "acc", "w", "sigma", "srgb"):
         assert torch.equal(a[k], ref[k]), k
-    # (the gradients are sums in an order that differs from run to run at this table size: the record streams of a 2^14 table
-    # overflow into f16 atomics, and the decoder's partial sums meet in f32 atomics)
+    # (the table gradient is a sum in an order that differs from run to run at this table size: the record streams of a 2^14 table
+    # overflow into f16 atomics)
     assert float((a["tg"] - ref["tg"]).abs().max()) <= 5e-3 * float(ref["tg"].abs().max())
     st = two._phase
     last = st.stats_last.cpu().numpy()
@@ -1285,9 +1285,9 @@ def test_phased_forward_is_the_one_phase_forward(setup, stage):
         scale = float(ref["tg"].abs().max())
         assert float((b["tg"] - ref["tg"]).abs().max()) <= 5e-3 * scale, label   # zero gradients behind the cut either way; f16 pool
         if stage == "global":
-            # (wgrad_reduce_kernel adds its shares of the 512 partial vectors with f32 atomics, in an order that differs from run to run: an entry that
-            # nearly cancels -- 2.7e-6 where the largest is 1e-2 -- was seen to differ by 1.8e-8, once in four runs: the floor is 1e-5 of the largest entry)
-            np.testing.assert_allclose(b["mlp"].cpu().numpy(), ref["mlp"].cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref["mlp"].abs().max()), err_msg=label)
+            # (round 6: wgrad_reduce_kernel adds the 512 partial vectors in one fixed order -- no atomics -- so a run repeats its bits; the phased step's
+            # compacted plane rows still meet in another order than the one-phase step's, hence a floor of 1e-6 of the largest entry, not equality)
+            np.testing.assert_allclose(b["mlp"].cpu().numpy(), ref["mlp"].cpu().numpy(), rtol=1e-4, atol=1e-6 * float(ref["mlp"].abs().max()), err_msg=label)
 
     b = run(two)  # second step: planned K
     last = two._phase.stats_last.cpu().numpy()
