@@ -119,13 +119,12 @@ def parse():
     ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
     ap.add_argument("--render-patch-width", type=int, default=8,
                     help="render: a wave walks a patch of this x 32/this neighbouring pixels' rays in lockstep (0: a wave per ray, like the training forward)")
-    ap.add_argument("--render-first-k", type=int, default=-1, help="render: two-phase march, samples per ray of its first phase (0: off; -1: HotPathConfig.render_first_k)")
     ap.add_argument("--render-tile-rays", type=int, default=0, help="rays per render tile (0: render.choose_tile picks a block of ~512 Ki rays that divides the frame, capped by the free device memory)")
     ap.add_argument("--render-tile-width", type=int, default=128, help="with --render-tile-rays: render tiles are blocks of this width (0 = raster runs)")
     ap.add_argument("--wgrad-planes", choices=["rne", "x3", "mixed"], default="rne",
                     help="global stage: operands of the decoder's weight gradient (HotPathConfig.wgrad_planes): rne = one f16 plane per operand, rounded to "
                          "nearest (default); x3 = hi + lo' planes (rounds 1-4); mixed = dz one plane, activations split")
-    ap.add_argument("--record-merge", type=int, default=-1, help="focal backward in record form: merge runs of samples in one cell first, 0 / 1 for every launch (gfn_set_record_merge); -1: the engine's policy (dense batches only)")
+    ap.add_argument("--record-merge", type=int, default=-1, help="focal backward in record form: merge runs of samples in one cell first, 0 / 1 for every launch (HotPathConfig.record_merge); -1: the engine's policy (dense batches only)")
     ap.add_argument("--wgrad-beside-accumulate", action="store_true", help="experiment (global stage): wgrad on a second stream beside grad_accumulate")
     ap.add_argument("--mlp-precision", choices=["x3", "f32"], default="x3",
                     help="fused decoder arithmetic: x3 = split-f16 MFMA at f32 accuracy (default), f32 = exact f32 MFMA")
@@ -370,7 +369,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     hp.cfg.render_patch_width = int(args.render_patch_width)
     tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=not args.render_eager,
                            tile_width=args.render_tile_width if args.render_tile_rays else None, pipeline=args.render_pipeline or None,
-                           decoder_cus=args.render_decoder_cus, first_k=None if args.render_first_k < 0 else args.render_first_k)
+                           decoder_cus=args.render_decoder_cus)
     mine = [f for f in range(len(cams)) if owners is None or owners[f] == rank]
     tr.render_camera(int(cams[mine[0]]) if mine else 0, H, W)  # capture + warm-up
     torch.cuda.synchronize()
@@ -397,7 +396,7 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
         roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
     fp = tr.footprint_bytes()
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
-                hbm_footprint_gb=None if fp is None else fp / 1e9, march_first_k=tr.first_k, march_continued_frac=tr.continued_frac, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
+                hbm_footprint_gb=None if fp is None else fp / 1e9, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
                 record_pool_regrown=tr.pool_regrown,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
                 tiles_per_replay=tr.P,
@@ -805,6 +804,7 @@ class StageRun:
             fused_backward=not args.unfused_backward, lds_accumulate=not args.atomic_backward, async_adam=args.async_adam,
             level_major_global=args.lm_global_forward, lm_halves_from=args.lm_halves_from, lm_split_log2=args.lm_split_log2, loss_before_fork=not args.fork_first,
             **({"record_capacity": args.record_capacity} if args.record_capacity else {}),
+            **({"record_merge": args.record_merge} if args.record_merge >= 0 else {}),
             **({"level_major_global_after": ga} if ga is not None else {}))
         self.n_blocks = n_blocks
         # every rank builds the SAME replica (seed 0): the data-parallel global stage keeps them bit-identical from there on
@@ -1192,11 +1192,6 @@ def run_rank(args):
     import gfnerf_amd  # noqa: F401
     from gfnerf_amd import _lib, cluster, dist as gdist, scene
 
-    if args.record_merge >= 0:
-        from gfnerf_amd import hotpath as _hp
-
-        _lib.lib().gfn_set_record_merge(args.record_merge)
-        _hp.RECORD_MERGE_FIXED = True  # (the engines' own policy -- merge on dense batches -- is off: the switch is the experiment's)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -16,7 +16,16 @@ class WgradLayer(C.Structure):
                 ("m_valid", C.c_int32), ("k_valid", C.c_int32), ("col_map", _vp), ("dW", _vp), ("ldw", C.c_int32), ("db", _vp)]
 
 
-ABI_VERSION = 106  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
+class LaunchOpts(C.Structure):
+    """gfn_launch_opts (include/gfnerf_amd.h): the launch policy of ONE call (ops.launch_opts builds it)."""
+    _fields_ = [("decoder_cus", C.c_int32), ("plain_rounding", C.c_int32), ("record_merge", C.c_int32), ("march_lanes", C.c_int32),
+                ("merge_front", _vp), ("merge_n", _vp), ("merge_frac", C.c_float), ("reserved", C.c_int32)]
+
+
+MERGE_OFF, MERGE_ON, MERGE_DEVICE = 0, 1, 2  # GFN_MERGE_*
+_opts = C.POINTER(LaunchOpts)
+
+ABI_VERSION = 107  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
 
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {
@@ -34,9 +43,8 @@ SIGNATURES = {
                          _vp, _vp, _i64, _vp, _vp]),
     "gfn_tree_compact": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_sample_rays": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
-    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
-    "gfn_sample_rays_continue": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _opts, _vp]),
+    "gfn_sample_rays_record": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _opts, _vp]),
     "gfn_samples_to_dense": (_i32, [_vp, _i64] + [_vp] * 14),
     "gfn_update_nodes": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_update_nodes_mark": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -53,35 +61,30 @@ SIGNATURES = {
     "gfn_field_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_field_bwd_dx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_field_pack_x3": (_i32, [_vp, _vp, _vp, _vp]),
-    "gfn_field_fwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "gfn_field_bwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "gfn_field_fwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _opts, _vp]),
+    "gfn_field_bwd_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _opts, _vp]),
     "gfn_field_bwd_scatter_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i64,
-                                        _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+                                        _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _opts, _vp]),
     "gfn_grad_record_ranges": (_i32, [_i32]),
     "gfn_grad_records_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "gfn_grad_max": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gfn_grad_scale_host": (_f32, [_f32]),
-    "gfn_set_decoder_cus": (_i32, [_i32]),
-    "gfn_set_plane_dither": (_i32, [_i32]),
-    "gfn_set_record_merge": (_i32, [_i32]),
-    "gfn_set_record_merge_auto": (_i32, [_vp, _vp, _f32]),
-    "gfn_set_march_lanes": (_i32, [_i32]),
-    "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "gfn_field_bwd_dx_x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _opts, _vp]),
     "gfn_wgrad_x3_parts": (_i32, []),
     "gfn_wgrad_x3_layers": (_i32, [C.POINTER(WgradLayer), _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "gfn_wgrad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
-                         _vp, _vp, _vp, _vp, _vp, _vp]),
+                         _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
     "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
-                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+                             _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
     "gfn_sh4": (_i32, [_vp, _i64, _vp, _vp]),
     "gfn_head_pack": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "gfn_head_unpack_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gfn_generate_rays": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gfn_hash_fwd_lm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "gfn_hash_fwd_lm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _opts, _vp]),
     "gfn_pixel_uniform": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "gfn_pixel_collate": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gfn_errmap_block_sums": (_i32, [_vp, _i64, _vp, _vp]),
@@ -96,6 +99,8 @@ SIGNATURES = {
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "gfn_s3im": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "gfn_train_losses": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gfn_loss_grad_combine": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_adam_hyper_host": (None, [_i32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "gfn_adam_step_ex": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),

@@ -180,7 +180,7 @@ struct ScatterArgs {
   // (16 Ki-slot range, this workgroup): rec[(range * 256 + workgroup) * rec_cap + position], positions from LDS cursors;
   // csrc/grad_part.hip then accumulates every range in LDS (gfn_grad_records_reduce)
   uint2* rec; unsigned int* rec_count; unsigned int rec_cap; int n_ranges;
-  // gate (gfn_set_record_merge_auto): the launch is one of a PAIR -- the plain record form and the run-merging one -- and only the kernel whose
+  // gate (gfn_launch_opts.record_merge = GFN_MERGE_DEVICE): the launch is one of a PAIR -- the plain record form and the run-merging one -- and only the kernel whose
   // `gate_want` equals [*gate_front >= gate_frac * *gate_n] does anything: which form a batch gets is decided on the device, from this step's own
   // counts (samples in front of the termination points, samples), so a replayed step and an eagerly launched one decide alike
   const int* gate_front; const int* gate_n; float gate_frac; int gate_want;
@@ -591,22 +591,10 @@ __global__ __launch_bounds__(256) void grad_max_kernel(int64_t n_max, const int3
   }
 }
 
-int g_decoder_cus = 0;  // gfn_set_decoder_cus: cap on the workgroups (= CUs) of the fused decoder kernels, 0 = every CU
-int g_plane_dither = 1;  // gfn_set_plane_dither
-int g_record_merge = 0;  // gfn_set_record_merge
-const int* g_merge_gate_front = nullptr;  // gfn_set_record_merge_auto
-const int* g_merge_gate_n = nullptr;
-float g_merge_gate_frac = 0.f;
-
-}  // namespace
-int gfn_decoder_cu_cap() { return (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256; }
-float gfn_plane_dither_amp() { return g_plane_dither ? 0x1p-22f : 0.f; }
-namespace {
-
-unsigned persistent_grid8(int64_t n_max) {
+unsigned persistent_grid8(int64_t n_max, const gfn_launch_opts* opts) {
   int64_t tiles = (n_max + 31) / 32;
   int64_t blocks = (tiles + 7) / 8;
-  const int cap = (g_decoder_cus > 0 && g_decoder_cus < 256) ? g_decoder_cus : 256;
+  const int cap = gfn_decoder_cu_cap(opts);
   if (blocks > cap) blocks = cap;  // one 512-thread workgroup per CU: the LDS image is copied once per workgroup
   return (unsigned)(blocks > 0 ? blocks : 1);
 }
@@ -629,7 +617,7 @@ int gfn_field_pack_x3(const float* const* weights, void* fwd_image, void* bwd_im
 int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, const float* emb, const int32_t* cam_idx,
                      const void* fwd_image, int64_t n_max, const int32_t* n_dev, float* sigma, float* rgb, float* h0,
                      uint64_t* masks, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride,
-                     const int32_t* list, const int32_t* list_n, void* stream) {
+                     const int32_t* list, const int32_t* list_n, const gfn_launch_opts* opts, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr), "gfn_field_fwd_x3: a sample list needs its count");
   GFN_CHECK_ARG(feat && ray_id && sh && fwd_image && sigma && rgb, "gfn_field_fwd_x3: null pointer");
@@ -649,7 +637,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
     GFN_FWD_ALL(GFN_SET)
 #undef GFN_SET
   }
-  const unsigned grid = persistent_grid8(n_max);
+  const unsigned grid = persistent_grid8(n_max, opts);
   const u32x4* img = reinterpret_cast<const u32x4*>(fwd_image);
   hipStream_t st = gfn_stream(stream);
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(masks);
@@ -659,7 +647,7 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
 #define GFN_LAUNCH(S, P, L)                                                                                                         \
   if (save == S && planes == P && planar == L)                                                                                       \
     field_fwd_x3_kernel<S, P, L><<<grid, 512, GFN_FIELD_X3_FWD_BYTES, st>>>(n_max, n_dev, feat, ray_id, sh, emb, cam_idx, img, sigma, rgb, h0, mk, \
-                                                                           planes_hi, planes_lo, plane_cap, feat_stride, list, list_n, gfn_plane_dither_amp());
+                                                                           planes_hi, planes_lo, plane_cap, feat_stride, list, list_n, gfn_plane_dither_amp(opts));
   GFN_FWD_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_FWD_ALL
@@ -676,9 +664,13 @@ struct ScatterHost {  // optional: scatter d feat into a table gradient pool ins
 static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                              const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
-                             const int32_t* cam_idx, float* demb, const ScatterHost& sh, void* stream, const int32_t* list = nullptr,
-                             const int32_t* list_n = nullptr) {
+                             const int32_t* cam_idx, float* demb, const ScatterHost& sh, const gfn_launch_opts* opts, void* stream,
+                             const int32_t* list = nullptr, const int32_t* list_n = nullptr) {
   if (n_max == 0) return GFN_OK;
+  const int merge = opts ? opts->record_merge : GFN_MERGE_OFF;
+  GFN_CHECK_ARG(merge == GFN_MERGE_OFF || merge == GFN_MERGE_ON || merge == GFN_MERGE_DEVICE, "%s: record_merge=%d", fn, merge);
+  GFN_CHECK_ARG(merge != GFN_MERGE_DEVICE || (opts->merge_front && opts->merge_n && opts->merge_frac >= 0.f),
+                "%s: GFN_MERGE_DEVICE needs both device counts and merge_frac >= 0", fn);
   GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr) && !(list && planes_hi), "%s: a sample list needs its count and excludes the planes", fn);
   GFN_CHECK_ARG(!list || sh.grad_pool, "%s: the sample list belongs to the scattering form", fn);
   const bool scatter = sh.grad_pool != nullptr;
@@ -697,7 +689,8 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
     GFN_BWD_ALL(GFN_SET)
 #undef GFN_SET
   }
-  const unsigned grid = persistent_grid8(n_max);
+  const unsigned grid = persistent_grid8(n_max, opts);
+  const float dither = gfn_plane_dither_amp(opts);
   const u32x4* img = reinterpret_cast<const u32x4*>(bwd_image);
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(masks);
   ScatterArgs S;
@@ -718,22 +711,22 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
   }
   gfn_hash_level_scales_host(S.sc.s);
   const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
-  const int mode = !scatter ? 0 : (sh.rec ? ((g_record_merge && !planes) ? 4 : 3) : (sh.grad_f16 ? 1 : 2));
+  const int mode = !scatter ? 0 : (sh.rec ? ((merge == GFN_MERGE_ON && !planes) ? 4 : 3) : (sh.grad_f16 ? 1 : 2));
   if (!planes) { gmax_dev = nullptr; plane_cap = 0; ray_id = nullptr; cam_idx = nullptr; demb = nullptr; }
 #define GFN_LAUNCH(P, SC)                                                                                                        \
   if (planes == P && mode == SC)                                                                                                 \
     field_bwd_dx_x3_kernel<P, SC><<<grid, bwd_threads<P, SC>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi, \
-                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
-  if (mode == 3 && !planes && g_merge_gate_front) {  // the gated pair: the device picks the form (see ScatterArgs)
-    S.gate_front = g_merge_gate_front; S.gate_n = g_merge_gate_n; S.gate_frac = g_merge_gate_frac;
+                                                                          planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, dither);
+  if (mode == 3 && !planes && merge == GFN_MERGE_DEVICE) {  // the gated pair: the device picks the form (see ScatterArgs)
+    S.gate_front = opts->merge_front; S.gate_n = opts->merge_n; S.gate_frac = opts->merge_frac;
     for (int want = 0; want < 2; want++) {
       S.gate_want = want;
       if (want == 0)
         field_bwd_dx_x3_kernel<0, 3><<<grid, bwd_threads<0, 3>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi,
-                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
+                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, dither);
       else
         field_bwd_dx_x3_kernel<0, 4><<<grid, bwd_threads<0, 4>(), kLds, gfn_stream(stream)>>>(n_max, n_dev, d_sigma, d_rgb, rgb, h0, mk, img, dfeat, gmax_dev, planes_hi,
-                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, gfn_plane_dither_amp());
+                                                                                       planes_lo, plane_cap, ray_id, cam_idx, demb, S, list, list_n, dither);
       GFN_CHECK_LAUNCH();
     }
     return GFN_OK;
@@ -746,9 +739,9 @@ static int field_bwd_x3_impl(const char* fn, const float* d_sigma, const float* 
 }
 
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
-                        const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, void* stream) {
+                        const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, const gfn_launch_opts* opts, void* stream) {
   return field_bwd_x3_impl("gfn_field_bwd_dx_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, nullptr, nullptr, nullptr, 0,
-                           nullptr, nullptr, nullptr, ScatterHost{}, stream);
+                           nullptr, nullptr, nullptr, ScatterHost{}, opts, stream);
 }
 
 int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
@@ -756,7 +749,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const int32_t* prim_pool, const float* bias_pool, int64_t n_volumes, int log2_T, void* grad_pool, int grad_f16,
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id,
                              const int32_t* cam_idx, float* demb, void* records, uint32_t* record_counts, int64_t record_capacity,
-                             const int32_t* list, const int32_t* list_n, void* stream) {
+                             const int32_t* list, const int32_t* list_n, const gfn_launch_opts* opts, void* stream) {
   GFN_CHECK_ARG(n_max == 0 || grad_pool, "gfn_field_bwd_scatter_x3: null gradient pool");
   GFN_CHECK_ARG(n_max == 0 || planes_hi || !planes_lo, "gfn_field_bwd_scatter_x3: a lo' plane needs its hi plane");
   GFN_CHECK_ARG(n_max == 0 || !planes_hi || gmax_dev, "gfn_field_bwd_scatter_x3: planes need gmax");
@@ -766,17 +759,17 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
   sh.grad_pool = grad_pool; sh.grad_f16 = grad_f16;
   sh.rec = records; sh.rec_count = record_counts; sh.rec_cap_total = record_capacity;
   return field_bwd_x3_impl("gfn_field_bwd_scatter_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, nullptr, gmax_dev, planes_hi, planes_lo,
-                           plane_cap, ray_id, cam_idx, demb, sh, stream, list, list_n);
+                           plane_cap, ray_id, cam_idx, demb, sh, opts, stream, list, list_n);
 }
 
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0, const uint64_t* masks,
                      const void* bwd_image, int64_t n_max, const int32_t* n_dev, float* dfeat, const float* gmax_dev,
                      uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx,
-                     float* demb, void* stream) {
+                     float* demb, const gfn_launch_opts* opts, void* stream) {
   GFN_CHECK_ARG(n_max == 0 || (gmax_dev && planes_hi), "gfn_field_bwd_x3: gmax and the planes (hi, or hi and lo') are required");
   GFN_CHECK_ARG(n_max == 0 || !demb || (ray_id && cam_idx), "gfn_field_bwd_x3: demb needs ray_id and cam_idx");
   return field_bwd_x3_impl("gfn_field_bwd_x3", d_sigma, d_rgb, rgb, h0, masks, bwd_image, n_max, n_dev, dfeat, gmax_dev, planes_hi, planes_lo,
-                           plane_cap, ray_id, cam_idx, demb, ScatterHost{}, stream);
+                           plane_cap, ray_id, cam_idx, demb, ScatterHost{}, opts, stream);
 }
 
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max, const int32_t* n_dev, float* gmax_dev,
@@ -792,29 +785,5 @@ int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int6
 }
 
 float gfn_grad_scale_host(float gmax) { return gfn_grad_scale_of(gmax); }
-
-int gfn_set_record_merge(int on) {
-  const int old = g_record_merge;
-  g_record_merge = on != 0;
-  return old;
-}
-
-int gfn_set_record_merge_auto(const int32_t* front_dev, const int32_t* n_dev, float frac) {
-  GFN_CHECK_ARG((front_dev == nullptr) == (n_dev == nullptr) && frac >= 0.f, "gfn_set_record_merge_auto: both counts (or neither), frac >= 0");
-  g_merge_gate_front = front_dev; g_merge_gate_n = n_dev; g_merge_gate_frac = frac;
-  return GFN_OK;
-}
-
-int gfn_set_plane_dither(int on) {
-  const int old = g_plane_dither;
-  g_plane_dither = on != 0;
-  return old;
-}
-
-int gfn_set_decoder_cus(int n_cus) {
-  const int old = g_decoder_cus;
-  g_decoder_cus = n_cus < 0 ? 0 : n_cus;
-  return old;
-}
 
 }  // extern "C"

@@ -36,12 +36,6 @@ struct FusedArgs {
   uint16_t* planes_hi; uint16_t* planes_lo; int64_t cap; float dither;
   float* out_rgb; float* out_acc; float* out_depth; float* t_minmax;
   int* counter;
-  // the two-phase inference march (gfn_fused_render_rec; csrc/sampler.hip MarchPlan).  Phase A (more != NULL): a ray that is still transparent
-  // after the samples it has, and whose march the cap ended (more[ray]), leaves its compositing state in state[ray * 8 ..] and its index in
-  // cont_list (count: *cont_n, zeroed by the launch).  Phase B (ray_list != NULL): the patches are runs of 32 entries of ray_list (count on the
-  // device), each ray resumes from its state at sample k_first.
-  const int* more; float* state; int* cont_list; int* cont_n;
-  const int* ray_list; const int* list_n; int k_first;
 };
 
 __device__ __forceinline__ float incl_scan64(float v, int lane) {
@@ -290,9 +284,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
   const uint32_t T = 1u << A.log2_T;
   const float early_T = A.early_T;
   const int n_vol = (int)A.n_volumes;    // 16 * n_volumes * 3 < 2^31 (checked by the host)
-  const bool phase_b = REC && A.ray_list != nullptr;  // wave-uniform
-  const int n_list = phase_b ? min(*A.list_n, A.n_rays) : 0;
-  const int n_patches = phase_b ? (n_list + 31) / 32 : A.n_rays / 32;  // the host guarantees whole patches (phase B: the list's tail patch is ragged)
+  const int n_patches = A.n_rays / 32;  // the host guarantees whole patches
   const int patches_per_row = tile_w > 0 ? tile_w / patch_w : 1, patch_h = tile_w > 0 ? 32 / patch_w : 1;
   const int pw_shift = 31 - __builtin_clz((unsigned)(patch_w > 0 ? patch_w : 1));  // patch_w divides 32: a power of two (checked by the host)
   // patches are handed out like fused_fwd_kernel's rays: 8 counters, a workgroup starts on the eighth of its XCD group
@@ -321,10 +313,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       const int strip = patch / per_strip, rem = patch - strip * per_strip;
       prow = rem / kRenderStrip; pcol = strip * kRenderStrip + rem % kRenderStrip;
     }
-    int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
-    bool live = true;  // (phase B: the lanes beyond the list's end have no ray)
-    if (phase_b) { live = patch * 32 + j < n_list; ray = live ? A.ray_list[patch * 32 + j] : 0; }
-    const int cnt = !live ? 0 : (REC ? A.counts[ray] : A.pts_offsets[ray + 1] - A.pts_offsets[ray]);
+    const int ray = tile_w > 0 ? (prow * patch_h + (j >> pw_shift)) * tile_w + pcol * patch_w + (j & (patch_w - 1)) : patch * 32 + j;
+    const int cnt = REC ? A.counts[ray] : A.pts_offsets[ray + 1] - A.pts_offsets[ray];
     int64_t s = REC ? (int64_t)ray * GFN_MAX_SAMPLE_PER_RAY : (int64_t)A.pts_offsets[ray];
     const bool paged = REC && A.page_table != nullptr;  // wave-uniform
     int kmax = cnt;
@@ -333,11 +323,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     const int cam = A.emb ? A.cam_idx[ray] : 0;
     float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
     bool done = false;
-    if (phase_b && live) {  // resume where phase A left this ray (both lane halves read it: the upper half only follows `done`)
-      const float4 s0 = *reinterpret_cast<const float4*>(A.state + (int64_t)ray * 8), s1 = *reinterpret_cast<const float4*>(A.state + (int64_t)ray * 8 + 4);
-      carry = s0.x; cr = s0.y; cg = s0.z; cb = s0.w; ca = s1.x; cd = s1.y;
-    }
-    for (int k = phase_b ? A.k_first : 0; k < kmax; k++) {
+    for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
       if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
       if (paged && (k & (GFN_REC_PAGE - 1)) == 0 && k < cnt) {  // a new page of this ray's records: s such that slot k is still s + k
@@ -440,15 +426,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       }
       done = __shfl((int)done, j, 64) != 0;  // the upper half (the ray's other 8 levels) follows its ray
     }
-    if (h == 0 && live) {
+    if (h == 0) {
       A.out_rgb[3 * ray] = cr; A.out_rgb[3 * ray + 1] = cg; A.out_rgb[3 * ray + 2] = cb;
       if (A.out_acc) A.out_acc[ray] = ca;
       if (A.out_depth) A.out_depth[ray] = cd / (ca + 1e-10f);  // renderers.py:279
-      if (REC && A.more && !done && A.more[ray]) {  // phase A: still transparent where the capped march ended -> phase B
-        *reinterpret_cast<float4*>(A.state + (int64_t)ray * 8) = make_float4(carry, cr, cg, cb);
-        *reinterpret_cast<float4*>(A.state + (int64_t)ray * 8 + 4) = make_float4(ca, cd, 0.f, 0.f);
-        A.cont_list[atomicAdd(A.cont_n, 1)] = ray;
-      }
     }
     if (A.t_minmax) {  // t grows along a ray: its range is its first and its last sample, terminated or not
       float tmin = INFINITY, tmax = 0.f;
@@ -462,7 +443,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
         tmin = REC ? A.rec[first * GFN_MARCH_REC_FLOATS] : A.ts[first];
         tmax = REC ? A.rec[last * GFN_MARCH_REC_FLOATS] : A.ts[last];
       }
-      if (cnt < GFN_MAX_SAMPLE_PER_RAY && live) tmin = 0.f;  // the reference's dense zero padding joins the min
+      if (cnt < GFN_MAX_SAMPLE_PER_RAY) tmin = 0.f;  // the reference's dense zero padding joins the min
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         tmin = fminf(tmin, __shfl_xor(tmin, off, 64));
@@ -477,11 +458,9 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
   }
 }
 
-// keep_range: phase B of a two-phase render adds to the t range phase A found
-__global__ void fused_init_kernel(int* counter, float* t_minmax, int* cont_n = nullptr, bool keep_range = false) {
+__global__ void fused_init_kernel(int* counter, float* t_minmax) {
   for (int i = 0; i < 8; i++) counter[i] = 0;
-  if (t_minmax && !keep_range) { t_minmax[0] = INFINITY; t_minmax[1] = 0.f; }
-  if (cont_n) *cont_n = 0;
+  if (t_minmax) { t_minmax[0] = INFINITY; t_minmax[1] = 0.f; }
 }
 
 }  // namespace
@@ -494,7 +473,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
                       const float* sh, const float* emb, const int32_t* cam_idx, float early_T, float* sigma, float* rgb,
                       float* h0, uint64_t* masks, float* weights, float* alphas, float* feat, uint16_t* planes_hi,
                       uint16_t* planes_lo, int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth,
-                      float* t_minmax, int32_t* work_counter, void* stream) {
+                      float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts, void* stream) {
   if (n_rays == 0) return GFN_OK;
   GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts && table_f16 && prim_pool && fwd_image && sh && sigma && rgb && out_rgb &&
                     work_counter, "gfn_fused_forward: null pointer");
@@ -513,7 +492,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.sigma = sigma; A.rgb = rgb; A.h0 = h0; A.masks = reinterpret_cast<unsigned long long*>(masks); A.weights = weights; A.alphas = alphas;
-  A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap; A.dither = gfn_plane_dither_amp();
+  A.feat = feat; A.planes_hi = planes_hi; A.planes_lo = planes_lo; A.cap = plane_cap; A.dither = gfn_plane_dither_amp(opts);
   A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
   LevelScales sc;
   gfn_hash_level_scales_host(sc.s);
@@ -534,7 +513,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
   const int planes = !planes_hi ? PL_NONE : (planes_lo ? PL_SPLIT : PL_RNE);
   const int threads = save ? FUSED_THREADS : FUSED_THREADS_LEAN;
   int64_t blocks = (waves + threads / 64 - 1) / (threads / 64);
-  const int cu_cap = gfn_decoder_cu_cap();  // gfn_set_decoder_cus: leave CUs to kernels of another stream
+  const int cu_cap = gfn_decoder_cu_cap(opts);  // leave CUs to kernels of another stream
   if (blocks > cu_cap) blocks = cu_cap;
 #define GFN_LAUNCH(D, S, P) \
   if (tab == D && save == S && planes == P) fused_fwd_kernel<D, S, P><<<(unsigned)blocks, fused_threads<S>(), FUSED_LDS_BYTES, st>>>(A, sc);
@@ -552,7 +531,7 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
                                const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
                                const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
                                int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
-                               void* stream) {
+                               const gfn_launch_opts* opts, void* stream) {
   GFN_CHECK_ARG(table_f16 && prim_pool && fwd_image && sh && out_rgb && work_counter, "%s: null pointer", who);
   GFN_CHECK_ARG(n_rays > 0 && n_rays < (1ll << 30) && n_rays % 32 == 0, "%s: n_rays=%lld must be a positive multiple of 32", who, (long long)n_rays);
   GFN_CHECK_ARG(n_volumes > 0 && n_volumes < (1ll << 25) && log2_T >= 4 && log2_T <= 26, "%s: n_volumes / log2_T out of range", who);
@@ -580,11 +559,10 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
 #undef GFN_SET
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
-  fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax, A.more ? A.cont_n : nullptr, A.ray_list != nullptr);
+  fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
-  if (A.ray_list) { tile_width = 0; }  // phase B: the list's rays are no pixel block
   int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave
-  const int cu_cap = gfn_decoder_cu_cap();
+  const int cu_cap = gfn_decoder_cu_cap(opts);
   if (blocks > cu_cap) blocks = cu_cap;
   const int tab = table2_f16 ? 1 : 0;
   const bool rec = A.rec != nullptr;
@@ -603,31 +581,27 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
                      const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
                      const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
                      const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
-                     float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream) {
+                     float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
+                     void* stream) {
   if (n_rays == 0) return GFN_OK;
   GFN_CHECK_ARG(pts_offsets && pts && anchors && dt && ts, "gfn_fused_render: null sample pointer");
   FusedArgs A{};
   A.pts_offsets = pts_offsets; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
   return fused_render_launch(A, "gfn_fused_render", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image, sh,
-                             emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
+                             emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
 }
 
 int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16, const uint16_t* table2_f16,
                          const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
                          const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
                          int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
-                         const int32_t* more, float* state, int32_t* cont_list, int32_t* cont_n, const int32_t* ray_list, const int32_t* list_n,
-                         int k_first, void* stream) {
+                         const gfn_launch_opts* opts, void* stream) {
   if (n_rays == 0) return GFN_OK;
   GFN_CHECK_ARG(counts && march_rec && (reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_fused_render_rec: counts / march_rec null or not 16-byte aligned");
-  GFN_CHECK_ARG(!more || (state && cont_list && cont_n && !ray_list), "gfn_fused_render_rec: phase A (more) needs state, cont_list and cont_n, and no ray list");
-  GFN_CHECK_ARG(!ray_list || (list_n && state && k_first >= 0 && k_first % GFN_REC_PAGE == 0), "gfn_fused_render_rec: phase B (ray_list) needs list_n, state and k_first, a multiple of %d", GFN_REC_PAGE);
-  GFN_CHECK_ARG(!state || (reinterpret_cast<uintptr_t>(state) & 15) == 0, "gfn_fused_render_rec: state must be 16-byte aligned");
   FusedArgs A{};
   A.counts = counts; A.rec = march_rec; A.page_table = page_table;
-  A.more = more; A.state = state; A.cont_list = cont_list; A.cont_n = cont_n; A.ray_list = ray_list; A.list_n = list_n; A.k_first = k_first;
   return fused_render_launch(A, "gfn_fused_render_rec", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image,
-                             sh, emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, stream);
+                             sh, emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
 }
 
 }  // extern "C"

@@ -31,10 +31,10 @@ void gfn_set_error(const char* fmt, ...);
   } while (0)
 #define GFN_CHECK_LAUNCH() GFN_CHECK_HIP(hipGetLastError())
 
-// cap on the workgroups (= CUs) of the persistent decoder kernels (gfn_set_decoder_cus), 256 = every CU; field_x3.hip
-int gfn_decoder_cu_cap();
-// amplitude of the one-plane (PL_RNE) producers' per-sample dither (gfn_set_plane_dither; x3_device.h), 0 = off; field_x3.hip
-float gfn_plane_dither_amp();
+// cap on the workgroups (= CUs) of the persistent kernels from the call's launch policy (gfn_launch_opts.decoder_cus), 256 = every CU
+inline int gfn_decoder_cu_cap(const gfn_launch_opts* opts) { return (opts && opts->decoder_cus > 0 && opts->decoder_cus < 256) ? opts->decoder_cus : 256; }
+// amplitude of the one-plane (PL_RNE) producers' per-sample dither (x3_device.h), 0 = off (gfn_launch_opts.plain_rounding)
+inline float gfn_plane_dither_amp(const gfn_launch_opts* opts) { return (opts && opts->plain_rounding) ? 0.f : 0x1p-22f; }
 
 static inline hipStream_t gfn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -194,7 +194,7 @@ extern "C" {
 int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2,
                     const float* bias_pool, const float* pts, const int32_t* anchors, int anchor_stride, int64_t n_max, const int32_t* n_dev,
                     int64_t n_volumes, int log2_T, int halves_from, int split_log2, int planar, int accumulate, float* out,
-                    const int32_t* list, const int32_t* list_n, void* stream) {
+                    const int32_t* list, const int32_t* list_n, const gfn_launch_opts* opts, void* stream) {
   if (n_max == 0) return GFN_OK;
   GFN_CHECK_ARG((list == nullptr) == (list_n == nullptr), "gfn_hash_fwd_lm: a sample list needs its count");
   GFN_CHECK_ARG(table_f16 && prim_pool && pts && anchors && out, "gfn_hash_fwd_lm: null pointer");
@@ -209,7 +209,7 @@ int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const
   A.split_log2 = split_log2 > 0 ? split_log2 : 1;
   A.out = out;
   gfn_hash_level_scales_host(A.sc.s);
-  const int grid = gfn_decoder_cu_cap();  // one workgroup per CU
+  const int grid = gfn_decoder_cu_cap(opts);  // one workgroup per CU
   int64_t cap = (n_max + grid - 1) / grid;
   cap = (cap + 63) & ~63ll;
   if (cap > kLmK * kLmThreads) cap = kLmK * kLmThreads;  // 32 B of LDS and a register slot per sample

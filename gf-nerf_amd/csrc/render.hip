@@ -547,6 +547,60 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_rows);
 }
 
+// Everything a training iteration of the plugin surface runs between the compositing and the backward, in ONE workgroup (a batch is a few
+// thousand rays: 12 k elements): the Charbonnier loss + gradient (the arithmetic of charbonnier_kernel), the PSNR of get_metrics_dict
+// (nerfacto.py:300,624), a zeroed buffer for gfn_s3im's scatter, and the block stage's error-map write-back (gf_pipeline.py:180-185 =
+// errmap_update_kernel).  Sums in a fixed order (thread-strided partial sums, wave shuffles, 16 wave totals added by one thread): the same bits
+// every run, and the outputs are WRITTEN, not accumulated -- nothing to zero beforehand.
+__global__ __launch_bounds__(1024) void train_losses_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int64_t rows, float eps,
+                                                            float* __restrict__ out3, float* __restrict__ g_char, float* __restrict__ g_zero,
+                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ slot, int n_images, int H, int W,
+                                                            float* __restrict__ error_map, double* __restrict__ sums, int err_block) {
+  const int64_t n = rows * 3;
+  const float inv_rows = 1.0f / (float)rows;
+  float acc = 0.f, sq = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = pred[i] - gt[i];
+    const float q = sqrtf(d * d + eps * eps);
+    acc += q;
+    sq += d * d;
+    if (g_char) g_char[i] = d / q * inv_rows;
+    if (g_zero) g_zero[i] = 0.f;
+  }
+  acc = wave_sum(acc); sq = wave_sum(sq);
+  __shared__ float s_acc[16], s_sq[16];
+  if ((threadIdx.x & 63) == 0) { s_acc[threadIdx.x >> 6] = acc; s_sq[threadIdx.x >> 6] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 16; w++) { a += s_acc[w]; b += s_sq[w]; }
+    out3[0] = a * inv_rows;
+    out3[1] = 0.f;
+    out3[2] = -10.0f * log10f(b / (float)n);
+  }
+  if (error_map && idx) {
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) {
+      const int c = slot ? slot[i] : idx[3 * i], y = idx[3 * i + 1], x = idx[3 * i + 2];
+      if (c < 0 || c >= n_images || y < 0 || y >= H || x < 0 || x >= W) continue;
+      const float e = (fabsf(gt[3 * i] - pred[3 * i]) + fabsf(gt[3 * i + 1] - pred[3 * i + 1])) + fabsf(gt[3 * i + 2] - pred[3 * i + 2]);
+      const int64_t p = ((int64_t)c * H + y) * W + x;
+      const float old = atomicExch(error_map + p, e);
+      if (sums) atomicAdd(sums + p / err_block, (double)e - (double)old);
+    }
+  }
+}
+
+// out = g_a * w_a[0] + g_b * w_b[0]: the gradients of two losses of one prediction under the (device-resident) gradients of the two loss values --
+// what autograd hands the backward of `loss = rgb_loss + s3im_loss` (trainer.py:391) -- in one launch instead of two scalings and an add
+__global__ __launch_bounds__(256) void loss_grad_combine_kernel(const float* __restrict__ g_a, const float* __restrict__ w_a, const float* __restrict__ g_b,
+                                                                const float* __restrict__ w_b, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = w_a ? g_a[i] * w_a[0] : 0.f;
+  if (g_b && w_b) v += g_b[i] * w_b[0];
+  out[i] = v;
+}
+
 // ---- Adam ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -842,6 +896,26 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
   int64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   charbonnier_kernel<<<(unsigned)blocks, 256, 0, gfn_stream(stream)>>>(pred, gt, n, 1.0f / (float)rows, eps, loss_dev, g_pred);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_train_losses(const float* pred, const float* gt, int64_t rows, float eps, float* out3, float* g_char, float* g_zero,
+                     const int32_t* indices, const int32_t* slot, int32_t n_images, int32_t height, int32_t width, float* error_map,
+                     double* block_sums, void* stream) {
+  if (rows == 0) return GFN_OK;
+  GFN_CHECK_ARG(pred && gt && out3 && rows > 0 && rows <= (1ll << 20), "gfn_train_losses: pred, gt, out3 and 1 <= rows <= 2^20 (one workgroup: a training batch)");
+  GFN_CHECK_ARG(!error_map || (indices && n_images > 0 && height > 0 && width > 0), "gfn_train_losses: the error map needs the rays' (c, y, x) rows and its extents");
+  train_losses_kernel<<<1, 1024, 0, gfn_stream(stream)>>>(pred, gt, rows, eps, out3, g_char, g_zero, indices, slot, n_images, height, width, error_map,
+                                                         block_sums, GFN_ERRMAP_BLOCK);
+  GFN_CHECK_LAUNCH();
+  return GFN_OK;
+}
+
+int gfn_loss_grad_combine(const float* g_a, const float* w_a, const float* g_b, const float* w_b, int64_t n, float* out, void* stream) {
+  if (n == 0) return GFN_OK;
+  GFN_CHECK_ARG(out && n > 0 && (g_a || !w_a) && (g_b || !w_b), "gfn_loss_grad_combine: a weight without its gradient, or no output");
+  loss_grad_combine_kernel<<<(unsigned)((n + 255) / 256), 256, 0, gfn_stream(stream)>>>(g_a, w_a, g_b, w_b, n, out);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -561,19 +561,6 @@ struct RecPages {
   int* table; int* counter; int n_pages;
 };
 
-// The counting march in two phases (inference tiles, round 5): rays end where they become opaque, and what the march records behind that
-// point nobody reads (41 % of a fog scene's samples).  Phase A marches at most `sample_cap` samples per ray and notes in more[ray] whether the
-// ray had leaves left; the inference kernel composites those, and the rays still transparent there are marched again by phase B -- over
-// `ray_list` (count on the device), from the start (the march has no state worth saving: a few per cent of the rays), recording only the
-// samples from `record_from` on, into pages taken from the same pool.
-struct MarchPlan {
-  int sample_cap;       // phase A: samples per ray at most (0: GFN_MAX_SAMPLE_PER_RAY)
-  int* more;            // phase A: i32 [R], 1 where the cap ended the march
-  const int* ray_list;  // phase B: the rays to march (NULL: all, in order)
-  const int* list_n;    // phase B: their number, on the device
-  int record_from;      // phase B: first sample to record (a multiple of GFN_REC_PAGE)
-};
-
 // K4 with L lanes per ray.  Hits come from the dense slots of trace_group_kernel.
 template <int L, bool FILL>
 __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
@@ -585,17 +572,12 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
     float* __restrict__ dirs, float* __restrict__ dists, float* __restrict__ ts, int* __restrict__ anchors,
     int* __restrict__ ray_id, float* __restrict__ first_oct_dis, int64_t pts_cap, int* __restrict__ overflow,
     float* __restrict__ rec /* count pass only: per ray 1024 x {t, dist, leaf, warped point} for fill_from_rec_kernel, or NULL */,
-    RecPages pages /* table != NULL: the records live in pages of GFN_REC_PAGE slots handed out as the rays need them (see RecPages) */,
-    MarchPlan plan /* count pass only: see MarchPlan (all zero: every ray, up to 1024 samples, everything recorded) */) {
+    RecPages pages /* table != NULL: the records live in pages of GFN_REC_PAGE slots handed out as the rays need them (see RecPages) */) {
   using G = MarchGroup<L>;
   constexpr int P = G::P, NZ = G::NZ;
   const int g = threadIdx.x & (L - 1);
-  int ray = blockIdx.x * (G::THREADS / L) + (threadIdx.x / L);
-  bool in_range = ray < n_rays;
-  if (!FILL && plan.ray_list) {  // phase B: entry `ray` of the list
-    in_range = in_range && ray < *plan.list_n;
-    ray = in_range ? plan.ray_list[ray] : 0;
-  }
+  const int ray = blockIdx.x * (G::THREADS / L) + (threadIdx.x / L);
+  const bool in_range = ray < n_rays;
   const int r = in_range ? ray : 0;
   const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
   const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
@@ -605,8 +587,7 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
   hit_nf += (int64_t)r * max_hits;
   if (rec && !pages.table) rec += (int64_t)r * GFN_MAX_SAMPLE_PER_RAY * GFN_MARCH_REC_FLOATS;
   int page_slot0 = 0;  // (paged records) first slot of the page this ray is filling
-  int max_n = (!FILL && plan.sample_cap > 0 && plan.sample_cap < GFN_MAX_SAMPLE_PER_RAY) ? plan.sample_cap : GFN_MAX_SAMPLE_PER_RAY;
-  const int record_from = FILL ? 0 : plan.record_from;
+  int max_n = GFN_MAX_SAMPLE_PER_RAY;
   int64_t base = 0;
   if (FILL) {
     base = pts_offsets[r];
@@ -615,7 +596,7 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
     max_n = (int)(end > base ? end - base : 0);
     if (max_n > GFN_MAX_SAMPLE_PER_RAY) max_n = GFN_MAX_SAMPLE_PER_RAY;
   }
-  if ((FILL || rec) && in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;  // (:229-234; the count pass of gfn_sample_rays_record; not phase B)
+  if ((FILL || rec) && in_range && g == 0 && first_oct_dis) first_oct_dis[r] = n_oct > 0 ? hit_nf[0].x : 1e9f;  // (:229-234; the count pass of gfn_sample_rays_record)
   bool active = in_range && max_n > 0 && n_oct > 0;
   int pts_ptr = 0, oct_ptr = 0;
   int nz_base = -1;
@@ -729,7 +710,7 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
         anchors[3 * p + 2] = block_idx;
         if (ray_id) ray_id[p] = ray;
       }
-      if (!FILL && rec && !first && pts_ptr >= record_from) {  // the sample as a 32-byte record {t, dist, leaf, transform, warped x y z, block}: all the sample-parallel fill (or the
+      if (!FILL && rec && !first) {  // the sample as a 32-byte record {t, dist, leaf, transform, warped x y z, block}: all the sample-parallel fill (or the
         // inference kernel, gfn_fused_render_rec) needs -- ONE 8-byte store from lanes 0 .. 3 of the ray (one store per value from one lane were
         // six memory instructions per step, and on this architecture a wave's next load waits for every store before it: beside a kernel that
         // keeps the L2 busy the march ran at the pace of the L2's write acknowledgements)
@@ -772,10 +753,7 @@ __global__ __launch_bounds__(MarchGroup<L>::THREADS) void march_group_kernel(
       active = pts_ptr < max_n && oct_ptr < n_oct;
     }
   }
-  if (!FILL && in_range && g == 0) {
-    counts[ray] = pts_ptr;
-    if (plan.more) plan.more[ray] = (pts_ptr >= max_n && oct_ptr < n_oct) ? 1 : 0;  // the cap, not the ray's end, stopped the march
-  }
+  if (!FILL && in_range && g == 0) counts[ray] = pts_ptr;
 }
 
 __device__ __forceinline__ float sum12_tree(const float* q) {  // the association of row_sum12 / Eigen's redux
@@ -1003,16 +981,11 @@ __global__ void query_centers_kernel(int64_t n_pts, int64_t n_nodes, const uint8
 }  // namespace
 
 namespace {
-int g_march_lanes = [] { const char* e = getenv("GFN_MARCH_LANES"); return e ? atoi(e) : 0; }();
+// GFN_MARCH_LANES = 4 | 16 in the environment: the march's lanes per ray for calls that leave gfn_launch_opts.march_lanes at 0 (read once, never written)
+const int kEnvMarchLanes = [] { const char* e = getenv("GFN_MARCH_LANES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 16) ? v : 0; }();
 }  // namespace
 
 extern "C" {
-
-int gfn_set_march_lanes(int lanes) {
-  const int old = g_march_lanes;
-  g_march_lanes = (lanes == 4 || lanes == 16) ? lanes : 0;
-  return old;
-}
 
 
 int gfn_normalize_dirs(const float* rays_d_raw, float* rays_d, int64_t n_rays, void* stream) {
@@ -1121,10 +1094,9 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
                             int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                             int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                             float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                            int32_t* overflow_dev, float* march_rec, int tree_depth, int32_t* record_counts, RecPages pages, MarchPlan plan,
-                            void* stream) {
+                            int32_t* overflow_dev, float* march_rec, int tree_depth, int32_t* record_counts, RecPages pages,
+                            const gfn_launch_opts* opts, void* stream) {
   const bool record_only = record_counts != nullptr;
-  const bool phase_b = record_only && plan.ray_list != nullptr;  // the traversal's hit lists are those of phase A
   GFN_CHECK_ARG(record_only || pts_offsets, "gfn_sample_rays: null pts_offsets");
   GFN_CHECK_ARG(tree_depth <= kMaxDepth, "gfn_sample_rays: tree_depth=%d (at most %d levels)", tree_depth, kMaxDepth);
   hipStream_t st = gfn_stream(stream);
@@ -1143,16 +1115,15 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
                 (long long)pts_cap);
   const CompactNode* cn = reinterpret_cast<const CompactNode*>(compact_nodes);
   const int stack = 7 * (tree_depth > 0 ? tree_depth : kMaxDepth) + 2;  // every expansion nets at most +7 entries per level
-  if (!phase_b) {
-    trace_group_kernel<<<(unsigned)((n_rays + kTraceRays - 1) / kTraceRays), 256, (size_t)kTraceRays * stack * 12, st>>>(
-        (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
-        reinterpret_cast<float2*>(hit_near_far), overflow_dev, stack);
-    GFN_CHECK_LAUNCH();
-  }
+  trace_group_kernel<<<(unsigned)((n_rays + kTraceRays - 1) / kTraceRays), 256, (size_t)kTraceRays * stack * 12, st>>>(
+      (int)n_rays, cn, rays_o, rays_d, near_bound, far_bound, max_hits, hit_counts, hit_idx,
+      reinterpret_cast<float2*>(hit_near_far), overflow_dev, stack);
+  GFN_CHECK_LAUNCH();
   int* counts = record_only ? record_counts : anchors;  // (anchors: scratch until the fill pass)
   // lanes per ray (MarchGroup): a row of 16 while the batch leaves the machine empty (the shortest chain per step), a quad from 32 Ki rays on
-  // (a quarter of the vector work per ray); GFN_MARCH_LANES = 4 | 16 in the environment overrides (tests run both on the same rays)
-  const int forced_lanes = g_march_lanes;  // gfn_set_march_lanes (GFN_MARCH_LANES in the environment is its start value, read once)
+  // (a quarter of the vector work per ray); opts->march_lanes = 4 | 16 (or GFN_MARCH_LANES in the environment) overrides: tests run both on the same rays
+  GFN_CHECK_ARG(!opts || opts->march_lanes == 0 || opts->march_lanes == 4 || opts->march_lanes == 16, "gfn_sample_rays: march_lanes=%d (0, 4 or 16)", opts->march_lanes);
+  const int forced_lanes = (opts && opts->march_lanes) ? opts->march_lanes : kEnvMarchLanes;
   const bool quad = forced_lanes == 4 || (forced_lanes != 16 && n_rays >= 32768);
   auto march = [&](auto lanes, auto fill, int* counts_out, const int* offsets, float* rec) {
     constexpr int L = decltype(lanes)::value;
@@ -1163,8 +1134,8 @@ static int sample_rays_core(const float* rays_o, const float* rays_d, const floa
         (int)n_rays, sample_l, scale_by_dis, table_space, max_hits, rays_o, rays_d, noise, hit_counts, hit_idx,
         reinterpret_cast<const float2*>(hit_near_far), cn, reinterpret_cast<const float*>(transes), counts_out, offsets,
         FILL ? world_pts : nullptr, FILL ? warped_pts : nullptr, FILL ? dirs : nullptr, FILL ? dists : nullptr, FILL ? ts : nullptr,
-        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, (FILL || (record_only && !phase_b)) ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec,
-        (record_only && rec) ? pages : RecPages{nullptr, nullptr, 0}, (record_only && !FILL) ? plan : MarchPlan{0, nullptr, nullptr, nullptr, 0});
+        FILL ? anchors : nullptr, FILL ? ray_id : nullptr, (FILL || record_only) ? first_oct_dis : nullptr, pts_cap, overflow_dev, rec,
+        (record_only && rec) ? pages : RecPages{nullptr, nullptr, 0});
   };
   using Row = std::integral_constant<int, 16>;
   using Quad = std::integral_constant<int, 4>;
@@ -1193,22 +1164,19 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream) {
+                    int32_t* overflow_dev, float* march_rec, int tree_depth, const gfn_launch_opts* opts, void* stream) {
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis,
                           table_space, hit_counts, hit_idx, hit_near_far, pts_offsets, world_pts, warped_pts, dirs, dists, ts, anchors, ray_id,
-                          first_oct_dis, pts_cap, overflow_dev, march_rec, tree_depth, nullptr, RecPages{nullptr, nullptr, 0},
-                          MarchPlan{0, nullptr, nullptr, nullptr, 0}, stream);
+                          first_oct_dis, pts_cap, overflow_dev, march_rec, tree_depth, nullptr, RecPages{nullptr, nullptr, 0}, opts, stream);
 }
 
 int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
-                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int sample_cap, int32_t* more,
-                           int tree_depth, void* stream) {
+                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int tree_depth,
+                           const gfn_launch_opts* opts, void* stream) {
   if (n_rays == 0) return GFN_OK;  // (an empty batch has no outputs to point at)
-  GFN_CHECK_ARG(sample_cap >= 0 && sample_cap <= GFN_MAX_SAMPLE_PER_RAY && sample_cap % GFN_REC_PAGE == 0 && (sample_cap == 0 || more),
-                "gfn_sample_rays_record: sample_cap=%d must be 0 or a multiple of %d up to 1024, with the `more` flags", sample_cap, GFN_REC_PAGE);
   GFN_CHECK_ARG(counts && first_oct_dis && march_rec, "gfn_sample_rays_record: null output pointer");
   GFN_CHECK_ARG((reinterpret_cast<uintptr_t>(march_rec) & 15) == 0, "gfn_sample_rays_record: march_rec must be 16-byte aligned");
   GFN_CHECK_ARG(!page_table || (page_counter && overflow_dev && n_pages >= 1 && n_pages < (1ll << 31) / GFN_REC_PAGE),
@@ -1216,25 +1184,7 @@ int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float
   if (page_table) GFN_CHECK_HIP(gfn_zero_async(page_counter, sizeof(int32_t), gfn_stream(stream)));
   return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, near_bound, far_bound, max_hits, sample_l, scale_by_dis, 1,
                           hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                          first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, RecPages{page_table, page_counter, (int)n_pages},
-                          MarchPlan{sample_cap, sample_cap > 0 ? more : nullptr, nullptr, nullptr, 0}, stream);
-}
-
-int gfn_sample_rays_continue(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays, const void* compact_nodes,
-                             const void* transes, int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
-                             float* hit_near_far, int32_t* counts, int32_t* overflow_dev, float* march_rec, int32_t* page_table,
-                             int32_t* page_counter, int64_t n_pages, const int32_t* ray_list, const int32_t* list_n, int record_from,
-                             void* stream) {
-  if (n_rays == 0) return GFN_OK;
-  GFN_CHECK_ARG(counts && march_rec && ray_list && list_n, "gfn_sample_rays_continue: null pointer");
-  GFN_CHECK_ARG((page_table == nullptr) == (page_counter == nullptr) && (!page_table || (overflow_dev && n_pages >= 1 && n_pages < (1ll << 31) / GFN_REC_PAGE)),
-                "gfn_sample_rays_continue: the page table needs its counter, the overflow word and 1 <= n_pages < 2^31 / %d", GFN_REC_PAGE);
-  GFN_CHECK_ARG(record_from >= 0 && record_from < GFN_MAX_SAMPLE_PER_RAY && record_from % GFN_REC_PAGE == 0,
-                "gfn_sample_rays_continue: record_from=%d must be a multiple of %d below 1024", record_from, GFN_REC_PAGE);
-  return sample_rays_core(rays_o, rays_d, noise, n_rays, compact_nodes, transes, 0.f, 0.f, max_hits, sample_l, scale_by_dis, 1,
-                          hit_counts, hit_idx, hit_near_far, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                          nullptr, 0, overflow_dev, march_rec, 0, counts, RecPages{page_table, page_counter, (int)n_pages},
-                          MarchPlan{0, nullptr, ray_list, list_n, record_from}, stream);
+                          first_oct_dis, 0, overflow_dev, march_rec, tree_depth, counts, RecPages{page_table, page_counter, (int)n_pages}, opts, stream);
 }
 
 int gfn_samples_to_dense(const int32_t* pts_offsets, int64_t n_rays, const float* world_pts,

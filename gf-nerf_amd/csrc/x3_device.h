@@ -56,7 +56,7 @@ static_assert(FP_LD == 480 && BP_LD == 408 && BP_LD_RNE == BP_LD + 128, "plane r
 // 3x what dz's did, 2e-4 of the largest |dW| in the head's first layer).  So sample q's activations are stored as
 // rne(a * (1 + u_q)) and its dz as rne(dz * (1 - u_q)), u_q a fixed low-discrepancy hash of q in +-2^-11 (about one f16 ulp): the
 // products dz a keep their value to 2^-22, every rounding meets its own position on the f16 grid, and db = sum dz (1 - u_q) gains
-// zero-mean noise of 3e-4 per term.  amp = 0 switches it off (gfn_set_plane_dither).
+// zero-mean noise of 3e-4 per term.  amp = 0 switches it off (gfn_launch_opts.plain_rounding).
 constexpr int PL_NONE = 0, PL_SPLIT = 1, PL_RNE = 2;
 __device__ __forceinline__ float plane_dither(int64_t q, float amp) {
   const uint32_t hq = (uint32_t)q * 2654435761u;  // golden-ratio sequence: consecutive samples spread evenly

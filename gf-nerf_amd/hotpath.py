@@ -9,7 +9,6 @@ call through the C ABI into hand-written HIP kernels (ops.py); samples stay PACK
 live sample count stays on the device (no host synchronisation inside a step).
 """
 import collections
-import contextlib
 import math
 import weakref
 from dataclasses import dataclass
@@ -21,7 +20,6 @@ from . import _lib, dist as gdist, ops, scene
 
 STAGE_GLOBAL = "global"  # the reference's 'init_stage': global table + MLPs + embedding train
 STAGE_FOCAL = "focal"    # 'block_stage': only the active block's residual table trains
-RECORD_MERGE_FIXED = False  # True: the caller has fixed gfn_set_record_merge for the process (bench.py --record-merge): no per-launch choice (HotPath._record_merge)
 
 
 @dataclass
@@ -57,8 +55,6 @@ class HotPathConfig:
                                      # steps) the level-major order does (2.77 vs 3.03 ms/step over 300 steps)
     lm_halves_from: int = 6          # levels >= this are gathered one address part at a time ...
     lm_split_log2: int = 0           # ... of 2^this parts per level (0 = 1: halves; 2: quarters, no gain inside the step)
-    render_first_k: int = 0          # inference (TileRenderer's pipeline): two-phase march -- every ray marched this many samples deep first, the rays still
-                                     # transparent there marched again and resumed (0: every ray marched to its end)
     render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
@@ -85,8 +81,10 @@ class HotPathConfig:
                                      # branch copies, read late) or the capture's planning forward's (StepGraph)
     prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
     prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
+    record_merge: int = -1           # focal backward in record form: 0 / 1 = plain / run-merging records for EVERY launch (experiments: bench.py --record-merge);
+                                     # -1: the policy below
     record_merge_dense: bool = False  # ... and such a batch merges runs of samples in one cell before it writes its gradient records -- decided on the DEVICE
-                                     # from the step's own counts (gfn_set_record_merge_auto; needs the phased forward's front list).  On through the plugin
+                                     # from the step's own counts (gfn_launch_opts GFN_MERGE_DEVICE; needs the phased forward's front list).  On through the plugin
                                      # surface (gfnerf/nerfacto.py: 90 -> 56 M records per step and 2.22 -> 2.10 ms per iteration on a scene trained there);
                                      # off here because it is neutral on the natively trained scenes and a merged run's sum is rounded to f16 once more: the
                                      # list-walking and the every-sample form of the backward would no longer give the same bits (StepGraph against eager steps)
@@ -103,6 +101,7 @@ class HotPathConfig:
                                      # per fragment pair; dza1 alone keeps its lo' half: csrc/x3_device.h); "x3" hi + lo' planes for both (rounds 1-4:
                                      # f32-class per term); "mixed" dz one plane, activations hi + lo'.  The per-sample chains (forward,
                                      # d x = W^T dz, the table gradient) are x3 whatever this says
+    plane_dither: bool = True        # ... the one-plane producers' per-sample dither (False: plain rounding; tests measure what it buys)
     wgrad_beside_accumulate: bool = False  # global stage, one rank: the decoder's weight-gradient kernel on a second stream beside the LDS accumulation
                                      # of the table gradient's records (both read what the backward wrote, neither the other's result)
     exact_oct_alphas: bool = True    # a training forward that UpdateOctNodes follows evaluates the density of EVERY sample, so that K5 reads true alphas
@@ -255,6 +254,10 @@ class HotPath:
             self._gmax = torch.zeros(1, dtype=torch.float32, device=self.dev)
         return self._plane_bufs
 
+    def _plane_opts(self, planes):
+        """Launch policy of a plane-producing forward: None (the default: dithered) unless cfg.plane_dither is off."""
+        return ops.launch_opts(plain_rounding=True) if (planes is not None and not self.cfg.plane_dither) else None
+
     def _x3(self):
         """Current split-f16 weight images of the fused decoder (rebuilt after every weight update)."""
         if self._x3_stale or self._x3_images[0] is None:
@@ -291,16 +294,16 @@ class HotPath:
             self._depth_key = key
         return self._depth_val
 
-    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False, pool_slots_per_ray=0, max_hits=None, sample_cap=0,
-               own_workspace=False):
+    def sample(self, rays_o, rays_d_raw, noise, need_world=False, out=None, record=False, pool_slots_per_ray=0, max_hits=None, own_workspace=False,
+               opts=None):
         """PersSampler.GetSamples (PersSampler_cuda.cu:321-477), packed, table-space points.  out: the dict an earlier call
         returned, to be written again in place (the static sample buffers of a captured step, gfnerf_amd.stepgraph).
         record: traversal + counting march only (ops.sample_rays_record) -- the samples stay in the march's records, for
         render(tile_width=...), whose patch kernel reads them there (no scan, no fill, no packed copy); pool_slots_per_ray > 0: in pages
         from a pool of that many slots per ray on average instead of 1024 slots for every ray (ops.sample_rays_record); max_hits: leaves per
         ray of the record form's hit lists (default cfg.max_oct_per_ray = the reference's 1024: 12 KB per ray; a caller that passes less
-        checks ops.HIT_CAP_REACHED in the overflow word); sample_cap: phase A of the two-phase march (ops.sample_rays_record); own_workspace: the
-        hit lists belong to the returned dict (a ring of sample buffers whose phase B reads them while the next tile is traversed)."""
+        checks ops.HIT_CAP_REACHED in the overflow word); own_workspace: the hit lists belong to the returned dict (a ring of sample buffers);
+        opts: ops.launch_opts(march_lanes=...) for the samplers' march (default: by batch size)."""
         c = self.cfg
         pre, self._pre = self._pre, None
         if not record and pre is not None and pre[0] is rays_o and pre[1] is rays_d_raw and pre[2] is noise and pre[3] == need_world:
@@ -323,7 +326,7 @@ class HotPath:
                             near=c.global_near, far=1e8, max_hits=min(int(max_hits), c.max_oct_per_ray) if max_hits else c.max_oct_per_ray,
                             workspace=(out["workspace"] if out is not None else None) if own_workspace else
                             (self._record_ws if self._record_ws is not None else self._sampler_ws),  # (the hit lists of the packed form will do)
-                            out=out, tree_depth=self.tree_depth(), pool_slots_per_ray=pool_slots_per_ray, sample_cap=sample_cap)
+                            out=out, tree_depth=self.tree_depth(), pool_slots_per_ray=pool_slots_per_ray, opts=opts)
             if s["workspace"] is not self._sampler_ws and not own_workspace:
                 self._record_ws = s["workspace"]
             s["dirs_unit"], s["sh"] = d, sh
@@ -332,7 +335,7 @@ class HotPath:
         s = self._timed("sample", ops.sample_rays, rays_o, d, noise, self.nodes_compact, self.transes, c.sample_l,
                         c.scale_by_dis, near=c.global_near, far=1e8, max_hits=c.max_oct_per_ray,
                         pts_cap=max(R * c.max_samples_per_ray, 1), want_world=need_world, want_dirs=need_world,
-                        table_space=True, workspace=self._sampler_ws, out=out, tree_depth=self.tree_depth())
+                        table_space=True, workspace=self._sampler_ws, out=out, tree_depth=self.tree_depth(), opts=opts)
         self._sampler_ws = s["workspace"]
         s["dirs_unit"] = d
         s["n_dev"] = s["pts_offsets"][R:R + 1]
@@ -423,7 +426,7 @@ class HotPath:
             sh = s["sh"] if s.get("sh") is not None else ops.sh4(s["dirs_unit"])
             prec = self.cfg.mlp_precision
             out = self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save,
-                              precision=prec, image=self._x3()[0] if prec == "x3" else None, planes=planes)
+                              precision=prec, image=self._x3()[0] if prec == "x3" else None, planes=planes, opts=self._plane_opts(planes))
             out["feat"] = feat
             return out
         (bW0, bb0), (bW1, bb1), (hW0, hb0), (hW1, hb1), (hW2, hb2) = self.layers
@@ -478,13 +481,13 @@ class HotPath:
         if self.after_lookup is not None:
             self.after_lookup()
         self._timed("field_fwd", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save, precision="x3",
-                    image=self._x3()[0], planes=planes, sample_list=sa, out=f)
+                    image=self._x3()[0], planes=planes, sample_list=sa, out=f, opts=self._plane_opts(planes))
         comp = self._timed("composite_fwd", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
                            want_t_range=want_depth)
         sb = self._timed("phase_list_b", ops.phase_list, s["pts_offsets"], st, phase_b=True)
         lookups("hash_fwd_b", sb, feat, False)
         self._timed("field_fwd_b", ops.field_fwd, feat, s["ray_id"], sh, emb, cam_idx, self.layers, n_dev=n_dev, save=save, precision="x3",
-                    image=self._x3()[0], planes=planes, sample_list=sb, out=f)
+                    image=self._x3()[0], planes=planes, sample_list=sb, out=f, opts=self._plane_opts(planes))
         self._timed("composite_fwd_b", ops.composite_fwd_phased, s["pts_offsets"], f["sigma"], s["dists"], s["ts"], f["rgb"], st, c.early_T,
                     second=True, out=comp)
         # the backward's list and the next step's K are not the loss's business: a branch of their own, beside the loss kernels
@@ -528,7 +531,8 @@ class HotPath:
                           self.cfg.log2_T, self._x3()[0], sh, emb, cam_idx,
                           table2_f16=self.blocks16[block] if block is not None else None,
                           prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg,
-                          early_T=early_T, save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes)
+                          early_T=early_T, save=save, want_weights=want_weights, want_feat=self.cfg.keep_features, planes=planes,
+                          opts=self._plane_opts(planes))
         f = dict(sigma=out["sigma"], rgb=out["rgb_samples"], h0=out["h0"], masks=out["masks"], feat=out["feat"])
         comp = dict(weights=out["weights"], alphas=out["alphas"], rgb=out["rgb"], acc=out["acc"], depth_raw=out["depth_raw"],
                     t_minmax=out["t_minmax"])
@@ -542,12 +546,13 @@ class HotPath:
         return bool(tile_width is not None and pw > 0 and self._fused_ok(block) and n_rays % 32 == 0 and
                     (tile_width == 0 or (tile_width % pw == 0 and n_rays % tile_width == 0 and (n_rays // tile_width) % (32 // pw) == 0)))
 
-    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None):
+    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None, opts=None):
         """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566).
         samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles).
         tile_width (not None): the rays are neighbours -- a block of pixels this wide, row major, or (0) a run of a row -- and only
         the four images are wanted: the lookup + decoder + compositing go through gfn_fused_render, which walks patches of 32
-        neighbouring rays in lockstep (field / weights are then not returned)."""
+        neighbouring rays in lockstep (field / weights are then not returned).  opts: ops.launch_opts(decoder_cus=...) of the patch kernel's
+        launch (TileRenderer leaves CUs to the next tile's sampler)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         R = rays_o.shape[0]
@@ -564,7 +569,7 @@ class HotPath:
                                self._x3()[0], sh, self.emb if c.use_appearance_embedding else None, cam_idx,
                                table2_f16=self.blocks16[block] if block is not None else None,
                                prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg,
-                               early_T=early, tile_width=tile_width, patch_width=pw)
+                               early_T=early, tile_width=tile_width, patch_width=pw, opts=opts)
             depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
             rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)
             return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],
@@ -772,36 +777,24 @@ class HotPath:
         front, n_all = self.front_override if self.front_override is not None else (int(self._front_host[0]), int(self._front_host[1]))
         return n_all > 0 and front >= self.cfg.prefetch_dense_frac * n_all
 
-    @contextlib.contextmanager
     def _cu_cap(self, stage=STAGE_FOCAL):
-        """While a prefetched sampler runs on the second stream the persistent backward kernel leaves it some of the CUs -- fewer of them when the focal
-        batch is dense (its backward is long: _dense_hint).  Only the grid depends on this: the gradient's bits do not."""
+        """CUs of the persistent backward kernel (0: all): while a prefetched sampler runs on the second stream it leaves that one some of the CUs --
+        fewer of them when the focal batch is dense (its backward is long: _dense_hint).  Only the grid depends on this: the gradient's bits do not."""
         c = self.cfg
+        if self._pre is None:
+            return 0
         n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
-        if stage != STAGE_GLOBAL and self._pre is not None and self._dense_hint():
+        if stage != STAGE_GLOBAL and self._dense_hint():
             n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
-        cap = self._pre is not None and 0 < n < 256
-        prev = _lib.lib().gfn_set_decoder_cus(n) if cap else 0
-        try:
-            yield
-        finally:
-            if cap:
-                _lib.lib().gfn_set_decoder_cus(prev)
+        return n if 0 < n < 256 else 0
 
-    @contextlib.contextmanager
-    def _record_merge(self, front, n_dev):
+    def _merge_gate(self, front, n_dev):
         """cfg.record_merge_dense: the focal backward merges the record runs of a DENSE batch (cfg.prefetch_dense_frac).  front = (list, count) of the phased
-        forward: the DEVICE decides from this step's own counts (gfn_set_record_merge_auto: both forms are launched, one does the work), so a replayed
-        forward and an eager one lead to the same bits.  Without a front list: no merging."""
-        L = _lib.lib()
-        if not self.cfg.record_merge_dense or RECORD_MERGE_FIXED or front is None:
-            yield
-            return
-        _lib.check(L.gfn_set_record_merge_auto(ops._ptr(front[1]), ops._ptr(n_dev), float(self.cfg.prefetch_dense_frac)), "gfn_set_record_merge_auto")
-        try:
-            yield
-        finally:
-            L.gfn_set_record_merge_auto(None, None, 0.0)
+        forward, or None (a one-phase forward: every sample is in front): the DEVICE decides from this step's own counts (ops.launch_opts merge_gate: both
+        forms are launched, one does the work), so a replayed forward and an eager one lead to the same bits.  -> the gate, or None: no merging."""
+        if not self.cfg.record_merge_dense:
+            return None
+        return (front[1] if front is not None else n_dev, n_dev, float(self.cfg.prefetch_dense_frac))
 
     def backward(self, ctx, g_rgb, g_acc=None):
         """Gradients of every trainable parameter of the stage from d loss / d rgb [R,3] (and optionally d acc [R]): final on the
@@ -822,10 +815,11 @@ class HotPath:
             scattered = c.fused_backward
             if scattered:
                 rec = self._record_buffers()
-                with self._cu_cap(STAGE_GLOBAL):  # leave CUs to the octree update + sampler on the second stream
-                    self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
-                                s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
-                                gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec)
+                # (the CU cap leaves CUs to the octree update + sampler on the second stream)
+                self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                            s["warped_pts"], s["anchors"], self.prim, self.bias_arg, self.n_volumes, c.log2_T, self.table_grad,
+                            gmax=self._gmax, planes=bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, records=rec,
+                            opts=ops.launch_opts(decoder_cus=self._cu_cap(STAGE_GLOBAL), plain_rounding=not c.plane_dither))
                 wg_side = None
                 if c.wgrad_beside_accumulate and rec is not None and not self.sync.exchanges and self.seg is None:
                     if self._wg_stream is None:
@@ -841,7 +835,7 @@ class HotPath:
                 ctx["table_exchange_started"] = True
             else:
                 dfeat = self._timed("field_bwd", ops.field_bwd_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1], self._gmax,
-                                    bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev)
+                                    bp, ray_id=s["ray_id"], cam_idx=cam_idx, demb=demb, n_dev=n_dev, opts=self._plane_opts(bp))
             g = self.layer_grads
             def pv(bufs, ld, k, table):  # (hi_flat, lo_flat | None, width) of plane k
                 hi, w = ops.plane_flat(bufs[0], ld, k, table)
@@ -868,10 +862,13 @@ class HotPath:
                 self._timed("wgrad", ops.wgrad_x3_layers, layers, self.mlp_grad, n_cap, n_dev=n_dev, gmax=self._gmax, parts=self._wgrad_parts)
         elif ctx["fused"] and c.fused_backward and c.mlp_precision == "x3":
             rec = self._record_buffers()
-            with self._cu_cap(), self._record_merge(f.get("front") if rec is not None else None, n_dev):
-                self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
-                            s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
-                            self.table_grad, n_dev=n_dev, records=rec, sample_list=f.get("front"))
+            if rec is None or c.record_merge >= 0:
+                lo = ops.launch_opts(decoder_cus=self._cu_cap(), record_merge=max(c.record_merge, 0) if rec is not None else 0)
+            else:
+                lo = ops.launch_opts(decoder_cus=self._cu_cap(), merge_gate=self._merge_gate(f.get("front"), n_dev))
+            self._timed("bwd_scatter", ops.field_bwd_scatter_x3, d_sigma, d_rgb, f["rgb"], f["h0"], f["masks"], self._x3()[1],
+                        s["warped_pts"], s["anchors"], self.block_prims[ctx["block"]], self.bias_arg, self.n_volumes, c.log2_T,
+                        self.table_grad, n_dev=n_dev, records=rec, sample_list=f.get("front"), opts=lo)
             if rec is not None:
                 self._reduce_records(rec)
             dfeat = None

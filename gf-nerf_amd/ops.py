@@ -49,6 +49,29 @@ def _chk(t, dtype, name, shape_last=None):
         raise _lib.GfnError(f"{name}: last dimension must be {shape_last}, got {tuple(t.shape)}")
 
 
+def launch_opts(decoder_cus=0, plain_rounding=False, record_merge=_lib.MERGE_OFF, march_lanes=0, merge_gate=None):
+    """gfn_launch_opts for ONE call (include/gfnerf_amd.h): the library keeps no launch policy of its own -- whoever launches says how.
+    decoder_cus: cap on the persistent kernels' workgroups (0: every CU); plain_rounding: one-plane producers without their dither;
+    record_merge: _lib.MERGE_OFF / MERGE_ON, or merge_gate = (front count i32 [1], sample count i32 [1], frac): MERGE_DEVICE, the device picks
+    the form from the step's own counts; march_lanes: 0 (by batch size), 4 or 16.  The returned struct keeps the gate's tensors alive."""
+    o = _lib.LaunchOpts()
+    o.decoder_cus = int(decoder_cus) if 0 < int(decoder_cus) < 256 else 0
+    o.plain_rounding = int(bool(plain_rounding))
+    o.march_lanes = int(march_lanes)
+    if merge_gate is not None:
+        front, n_dev, frac = merge_gate
+        _chk(front, torch.int32, "merge gate front count"); _chk(n_dev, torch.int32, "merge gate sample count")
+        o.record_merge, o.merge_front, o.merge_n, o.merge_frac = _lib.MERGE_DEVICE, front.data_ptr(), n_dev.data_ptr(), float(frac)
+        o._keep = (front, n_dev)
+    else:
+        o.record_merge = int(record_merge)
+    return o
+
+
+def _opt(opts):
+    return None if opts is None else C.byref(opts)
+
+
 def level_scales():
     out = np.zeros(16, np.float32)
     _lib.lib().gfn_hash_level_scales_host(out.ctypes.data_as(C.c_void_p))
@@ -93,7 +116,7 @@ _part_ws = {}
 
 
 def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T, table2_f16=None, prim_pool2=None, out=None, n_dev=None,
-                halves_from=6, planar=False, accumulate=False, split_log2=0, sample_list=None):
+                halves_from=6, planar=False, accumulate=False, split_log2=0, sample_list=None, opts=None):
     """Level-major lookup (csrc/lm_lookup.hip): same features as hash_fwd_f16, gathered one L2-sized address range at a time
     (levels >= halves_from in 2^split_log2 parts; 0 = halves).
     planar: out is float2 [16, n] (level-major) instead of f32 [n, 32].
@@ -112,7 +135,7 @@ def hash_fwd_lm(table_f16, prim_pool, bias_pool, pts, anchors, n_volumes, log2_T
         raise _lib.GfnError("hash_fwd_lm: out must hold 32 features per sample")
     rc = _lib.lib().gfn_hash_fwd_lm(_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), _ptr(pts), _ptr(anchors),
                                     _anchor_stride(anchors, n), n, _ptr(n_dev), int(n_volumes), int(log2_T), int(halves_from), int(split_log2), int(bool(planar)), int(bool(accumulate)), _ptr(out),
-                                    _ptr(lst), _ptr(lst_n), _stream())
+                                    _ptr(lst), _ptr(lst_n), _opt(opts), _stream())
     _lib.check(rc, "gfn_hash_fwd_lm")
     return out
 
@@ -253,7 +276,7 @@ def tree_compact(nodes, out=None):
 
 def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8,
                 max_hits=MAX_OCT_PER_RAY, pts_cap=None, want_world=False, want_dirs=False, table_space=True, workspace=None, out=None,
-                tree_depth=0):
+                tree_depth=0, opts=None):
     """Fast GetSamples: single-pass dense trace + march with a group of lanes per ray (a 16-lane row below 32 Ki rays, a quad from there on).  Same dict as march().  out: a dict an earlier call
     returned (same R / pts_cap / options): its tensors are written again instead of allocating new ones (static buffers of a
     captured step).  tree_depth: depth of the deepest node (see tree_depth()) or 0 for the reference's bound of 24."""
@@ -290,25 +313,19 @@ def sample_rays(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_b
                                     _ptr(out["pts_offsets"]), _ptr(out["world_pts"]), _ptr(out["warped_pts"]), _ptr(out["dirs"]),
                                     _ptr(out["dists"]), _ptr(out["ts"]), _ptr(out["anchors"]), _ptr(out["ray_id"]),
                                     _ptr(out["first_oct_dis"]), pts_cap, _ptr(out["overflow"]), _ptr(workspace.get("march_rec")), int(tree_depth),
-                                    _stream())
+                                    _opt(opts), _stream())
     _lib.check(rc, "gfn_sample_rays")
     return out
 
 
 def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, scale_by_dis, near=0.01, far=1e8, max_hits=MAX_OCT_PER_RAY,
-                       workspace=None, out=None, tree_depth=0, pool_slots_per_ray=0, sample_cap=0):
+                       workspace=None, out=None, tree_depth=0, pool_slots_per_ray=0, opts=None):
     """gfn_sample_rays_record: traversal + counting march only -> dict(counts i32 [R], first_oct_dis [R], march_rec f32 [R * 1024 * 8],
     overflow, workspace): the samples stay where the march recorded them (slot k of ray r at (r * 1024 + k) * MARCH_REC_FLOATS), for
     fused_render's record form.  out: the dict of an earlier call with the same R, written again in place.
     pool_slots_per_ray > 0: the PAGED form -- march_rec is a pool of R * pool_slots_per_ray / 32 pages of 32 slots, page_table i32
     [R * 32] says where each ray's pages are: sized by the samples the rays have, not by the 1024 they may have (7 KB instead of 32 KB
-    per ray at 224).  When the pool runs out, overflow gets bit REC_POOL_OVERFLOW: sample again with a larger pool.
-    sample_cap > 0 (a multiple of 32; needs the paged form): phase A of the two-phase march -- at most sample_cap samples per ray, out["more"]
-    i32 [R] = 1 where the cap ended the march; fused_render then composites them, marches the rays still transparent there again
-    (gfn_sample_rays_continue) and resumes them.  What lies behind a ray's termination point is neither marched nor recorded."""
-    sample_cap = int(sample_cap)
-    if sample_cap and (sample_cap % REC_PAGE or not 0 < sample_cap < MAX_SAMPLE_PER_RAY or pool_slots_per_ray <= 0 and out is None):
-        raise _lib.GfnError("sample_rays_record: sample_cap must be a multiple of 32 below 1024 and needs the paged form (pool_slots_per_ray)")
+    per ray at 224).  When the pool runs out, overflow gets bit REC_POOL_OVERFLOW: sample again with a larger pool."""
     _chk(rays_o, torch.float32, "rays_o", 3); _chk(rays_d, torch.float32, "rays_d", 3); _chk(noise, torch.float32, "noise")
     _chk(compact_nodes, torch.uint8, "compact_nodes"); _chk(transes, torch.uint8, "transes")
     R = rays_o.shape[0]
@@ -320,8 +337,8 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                          hit_idx=torch.empty(max(R * max_hits, 1), dtype=torch.int32, device=dev),
                          hit_nf=torch.empty((max(R * max_hits, 1), 2), dtype=torch.float32, device=dev))
     if out is not None:
-        if out["counts"].numel() != R or bool(sample_cap) != (out.get("more") is not None):
-            raise _lib.GfnError("sample_rays_record: `out` was made for another batch size or march form")
+        if out["counts"].numel() != R:
+            raise _lib.GfnError("sample_rays_record: `out` was made for another batch size")
         out["overflow"].zero_()
         out["workspace"] = workspace
     elif pool_slots_per_ray > 0:
@@ -331,9 +348,6 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                    page_table=torch.empty(max(R, 1) * (MAX_SAMPLE_PER_RAY // REC_PAGE), dtype=torch.int32, device=dev),
                    page_counter=torch.zeros(1, dtype=torch.int32, device=dev), n_pages=n_pages,
                    overflow=torch.zeros(1, dtype=torch.int32, device=dev), workspace=workspace)
-        if sample_cap:
-            out.update(more=torch.empty(R, dtype=torch.int32, device=dev), state=torch.empty(max(R, 1) * 8, dtype=torch.float32, device=dev),
-                       cont_list=torch.empty(max(R, 1), dtype=torch.int32, device=dev), cont_n=torch.zeros(1, dtype=torch.int32, device=dev))
     else:
         out = dict(counts=torch.empty(R, dtype=torch.int32, device=dev), first_oct_dis=torch.empty(R, dtype=torch.float32, device=dev),
                    march_rec=torch.empty(max(R, 1) * MAX_SAMPLE_PER_RAY * MARCH_REC_FLOATS, dtype=torch.float32, device=dev),
@@ -342,26 +356,9 @@ def sample_rays_record(rays_o, rays_d, noise, compact_nodes, transes, sample_l, 
                                            float(sample_l), int(bool(scale_by_dis)), _ptr(workspace["hit_counts"]), _ptr(workspace["hit_idx"]),
                                            _ptr(workspace["hit_nf"]), _ptr(out["counts"]), _ptr(out["first_oct_dis"]), _ptr(out["overflow"]),
                                            _ptr(out["march_rec"]), _ptr(out.get("page_table")), _ptr(out.get("page_counter")), int(out.get("n_pages", 0)),
-                                           sample_cap, _ptr(out.get("more")), int(tree_depth), _stream())
+                                           int(tree_depth), _opt(opts), _stream())
     _lib.check(rc, "gfn_sample_rays_record")
-    if sample_cap:  # what phase B of the march needs again (the same rays, noise and hit lists: the same samples)
-        out["sample_cap"] = sample_cap
-        out["_march"] = dict(rays_o=rays_o, rays_d=rays_d, noise=noise, compact_nodes=compact_nodes, transes=transes, sample_l=float(sample_l),
-                             scale_by_dis=int(bool(scale_by_dis)), max_hits=int(max_hits))
     return out
-
-
-def sample_rays_continue(s):
-    """Phase B of the two-phase march (gfn_sample_rays_continue): the rays s["cont_list"][: s["cont_n"]] (fused_render's phase A listed them:
-    still transparent where the capped march ended) marched again from the start, recording the samples from s["sample_cap"] on into pages
-    of the same pool; s["counts"] of those rays becomes their full count."""
-    m, ws = s["_march"], s["workspace"]
-    R = s["counts"].numel()
-    rc = _lib.lib().gfn_sample_rays_continue(_ptr(m["rays_o"]), _ptr(m["rays_d"]), _ptr(m["noise"]), R, _ptr(m["compact_nodes"]), _ptr(m["transes"]), m["max_hits"],
-                                             m["sample_l"], m["scale_by_dis"], _ptr(ws["hit_counts"]), _ptr(ws["hit_idx"]), _ptr(ws["hit_nf"]), _ptr(s["counts"]),
-                                             _ptr(s["overflow"]), _ptr(s["march_rec"]), _ptr(s["page_table"]), _ptr(s["page_counter"]), int(s["n_pages"]),
-                                             _ptr(s["cont_list"]), _ptr(s["cont_n"]), int(s["sample_cap"]), _stream())
-    _lib.check(rc, "gfn_sample_rays_continue")
 
 
 def tree_depth(nodes):
@@ -745,7 +742,7 @@ def field_outputs(n, device, save=True):
 
 
 def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, precision="x3", image=None, planes=None, sample_list=None,
-              out=None):
+              out=None, opts=None):
     """Fused decoder forward -> dict(sigma [n], rgb [n,3], h0 [n]|None, masks [n,6] int64|None).
     precision "x3": split-f16 MFMA (f32 accuracy, ~5x the f32 matrix rate; `image` = a current forward image from
     field_pack_x3, built here when absent); "f32": exact f32 MFMA.
@@ -779,7 +776,7 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
         cap = _plane_cap(ph, pl, FIELD_X3_FWD_PLANE_LD, n)  # split-f16 activation planes for the weight gradients (global stage)
         rc = _lib.lib().gfn_field_fwd_x3(_ptr(feat), _ptr(ray_id), _ptr(sh), _ptr(emb), _ptr(cam_idx), _ptr(image), n, _ptr(n_dev),
                                          _ptr(sigma), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(ph), _ptr(pl), cap, n if planar else 0,
-                                         _ptr(lst), _ptr(lst_n), _stream())
+                                         _ptr(lst), _ptr(lst_n), _opt(opts), _stream())
         _lib.check(rc, "gfn_field_fwd_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)
@@ -791,7 +788,7 @@ def field_fwd(feat, ray_id, sh, emb, cam_idx, layers, n_dev=None, save=False, pr
     return dict(sigma=sigma, rgb=rgb, h0=h0, masks=masks)
 
 
-def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None, precision="x3", image=None):
+def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None, precision="x3", image=None, opts=None):
     """Fused decoder backward w.r.t. the hash features (decoder frozen) -> dfeat [n,32]."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
     _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6)
@@ -801,7 +798,7 @@ def field_bwd_dx(d_sigma, d_rgb, rgb, h0, masks, layers, n_dev=None, precision="
         if image is None:
             _, image = field_pack_x3(layers, want_fwd=False)
         rc = _lib.lib().gfn_field_bwd_dx_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
-                                            _ptr(dfeat), _stream())
+                                            _ptr(dfeat), _opt(opts), _stream())
         _lib.check(rc, "gfn_field_bwd_dx_x3")
     elif precision == "f32":
         wp = _weight_ptrs(layers)
@@ -908,7 +905,7 @@ def grad_max(d_sigma, d_rgb, h0, gmax, n_dev=None):
     return gmax
 
 
-def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=None, cam_idx=None, demb=None, n_dev=None):
+def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=None, cam_idx=None, demb=None, n_dev=None, opts=None):
     """Fused decoder backward of the global stage: dfeat [n,32] + dz planes (for wgrad_x3) + appearance-embedding gradient."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
     _chk(h0, torch.float32, "h0"); _chk(masks, torch.int64, "masks", 6); _chk(gmax, torch.float32, "gmax")
@@ -918,13 +915,13 @@ def field_bwd_x3(d_sigma, d_rgb, rgb, h0, masks, image, gmax, planes, ray_id=Non
     cap = _plane_cap(ph, pl, FIELD_X3_BWD_PLANE_LD if (pl is not None or ph is None) else FIELD_X3_BWD_PLANE_LD_RNE, n)
     dfeat = torch.empty((n, 32), dtype=torch.float32, device=d_sigma.device)
     rc = _lib.lib().gfn_field_bwd_x3(_ptr(d_sigma), _ptr(d_rgb), _ptr(rgb), _ptr(h0), _ptr(masks), _ptr(image), n, _ptr(n_dev),
-                                     _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _stream())
+                                     _ptr(dfeat), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id), _ptr(cam_idx), _ptr(demb), _opt(opts), _stream())
     _lib.check(rc, "gfn_field_bwd_x3")
     return dfeat
 
 
 def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None):
+                  early_T=0.0, save=False, want_weights=True, want_feat=False, planes=None, opts=None):
     """gfn_fused_forward on the packed sampler outputs `s` (dict of ops.sample_rays with table_space=True).
     -> dict(sigma, rgb_samples, h0, masks, weights, alphas, feat, rgb [R,3], acc [R], depth_raw [R], t_minmax [2])."""
     po = s["pts_offsets"]
@@ -959,13 +956,13 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
                                       _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), _ptr(out["sigma"]), _ptr(out["rgb_samples"]),
                                       _ptr(out["h0"]), _ptr(out["masks"]), _ptr(out["weights"]), _ptr(out["alphas"]), _ptr(out["feat"]),
                                       _ptr(ph), _ptr(pl), cap, _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]),
-                                      _ptr(counter), _stream())
+                                      _ptr(counter), _opt(opts), _stream())
     _lib.check(rc, "gfn_fused_forward")
     return out
 
 
 def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                 early_T=0.0, tile_width=0, patch_width=8):
+                 early_T=0.0, tile_width=0, patch_width=8, opts=None):
     """gfn_fused_render: inference through patches of 32 neighbouring rays walked in lockstep (no per-sample outputs).
     -> dict(rgb [R,3], acc [R], depth_raw [R], t_minmax [2]).  R must be a multiple of 32; tile_width: the rays are a block of
     pixels this wide, row major (0: a run of rays).  s: the packed samples of sample_rays, or the records of sample_rays_record
@@ -1005,15 +1002,9 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
     counter = torch.empty(8, dtype=torch.int32, device=dev)
     tail = (_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
             _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
-            _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _stream())
-    if rec and s.get("more") is not None:  # the two-phase march: composite the capped samples, march the rays still transparent again, resume them
-        head = (_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s["page_table"]))
-        rc = _lib.lib().gfn_fused_render_rec(*head, *tail[:-1], _ptr(s["more"]), _ptr(s["state"]), _ptr(s["cont_list"]), _ptr(s["cont_n"]), None, None, 0, _stream())
-        _lib.check(rc, "gfn_fused_render_rec (phase A)")
-        sample_rays_continue(s)
-        rc = _lib.lib().gfn_fused_render_rec(*head, *tail[:-1], None, _ptr(s["state"]), None, None, _ptr(s["cont_list"]), _ptr(s["cont_n"]), int(s["sample_cap"]), _stream())
-    elif rec:
-        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail[:-1], None, None, None, None, None, None, 0, _stream())
+            _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _opt(opts), _stream())
+    if rec:
+        rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail)
     else:
         rc = _lib.lib().gfn_fused_render(_ptr(po), R, _ptr(s["warped_pts"]), _ptr(s["anchors"]), _ptr(s["dists"]), _ptr(s["ts"]), *tail)
     _lib.check(rc, "gfn_fused_render")
@@ -1021,7 +1012,7 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
 
 
 def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, prim_pool, bias_pool, n_volumes, log2_T, grad_pool,
-                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None, sample_list=None):
+                         gmax=None, planes=None, ray_id=None, cam_idx=None, demb=None, n_dev=None, records=None, sample_list=None, opts=None):
     """Decoder backward + hash scatter in one kernel: accumulates into grad_pool (f16 x128-scaled or f32, like hash_bwd); with
     planes / gmax (global stage) it also writes the dz planes for wgrad_x3 and the appearance-embedding gradient."""
     _chk(d_sigma, torch.float32, "d_sigma"); _chk(d_rgb, torch.float32, "d_rgb", 3); _chk(rgb, torch.float32, "rgb", 3)
@@ -1049,7 +1040,7 @@ def field_bwd_scatter_x3(d_sigma, d_rgb, rgb, h0, masks, image, pts, anchors, pr
                                              _ptr(anchors), _ptr(prim_pool), _ptr(bias_pool), n_volumes, log2_T, _ptr(grad_pool),
                                              int(grad_pool.dtype == torch.float16), _ptr(gmax), _ptr(ph), _ptr(pl), cap, _ptr(ray_id),
                                              _ptr(cam_idx), _ptr(demb), _ptr(rec), _ptr(cnt), rec.numel() if rec is not None else 0,
-                                             _ptr(lst), _ptr(lst_n), _stream())
+                                             _ptr(lst), _ptr(lst_n), _opt(opts), _stream())
     _lib.check(rc, "gfn_field_bwd_scatter_x3")
     return grad_pool
 
@@ -1239,6 +1230,46 @@ def charbonnier(pred, gt, eps=1e-6, loss=None):
     _lib.check(_lib.lib().gfn_charbonnier(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(loss), _ptr(g), _stream()),
                "gfn_charbonnier")
     return loss, g
+
+
+def train_losses(pred, gt, eps=1e-6, want_s3im_grad=True, errmap=None):
+    """gfn_train_losses: what a training iteration of the plugin surface runs between the compositing and the backward, in ONE launch ->
+    (out3 f32 [3] = [Charbonnier loss, 0 (for s3im to add into), PSNR], g_char [R,3], g_zero [R,3] zeroed | None).
+    errmap = (error_map f32 [n_images,H,W(,1)], block_sums f64 | None, indices i32 [R,3] = (c, y, x), slot i32 [R] | None): the block stage's
+    error-map write-back (errmap_update) rides along."""
+    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3)
+    if pred.shape != gt.shape:
+        raise _lib.GfnError("train_losses: pred and gt differ in shape")
+    out3 = torch.empty(3, dtype=torch.float32, device=pred.device)
+    g = torch.empty_like(pred)
+    gz = torch.empty_like(pred) if want_s3im_grad else None
+    em, bs, idx, slot, n_img, H, W = None, None, None, None, 0, 0, 0
+    if errmap is not None:
+        em, bs, idx, slot = errmap
+        _chk(em, torch.float32, "error_map"); _chk(bs, torch.float64, "block_sums"); _chk(idx, torch.int32, "indices", 3); _chk(slot, torch.int32, "slot")
+        if idx.shape[0] != pred.shape[0] or em.dim() < 3 or (slot is not None and slot.numel() != pred.shape[0]):
+            raise _lib.GfnError("train_losses: one (c, y, x) row (and slot) per ray and an error map [n_images,H,W]")
+        if bs is not None and bs.numel() != (em.numel() + ERRMAP_BLOCK - 1) // ERRMAP_BLOCK:
+            raise _lib.GfnError("train_losses: block_sums does not belong to this error map")
+        n_img, H, W = em.shape[:3]
+    rc = _lib.lib().gfn_train_losses(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(out3), _ptr(g), _ptr(gz), _ptr(idx), _ptr(slot),
+                                     int(n_img), int(H), int(W), _ptr(em), _ptr(bs), _stream())
+    _lib.check(rc, "gfn_train_losses")
+    return out3, g, gz
+
+
+def loss_grad_combine(g_a, w_a, g_b=None, w_b=None, out=None):
+    """out = g_a * w_a[0] + g_b * w_b[0] (w_*: device f32 scalars, e.g. the gradients autograd hands the backward of two losses)."""
+    _chk(g_a, torch.float32, "g_a"); _chk(g_b, torch.float32, "g_b")
+    for w in (w_a, w_b):
+        if w is not None and not (w.is_cuda and w.dtype == torch.float32 and w.numel() == 1):
+            raise _lib.GfnError("loss_grad_combine: weights are device float32 scalars")
+    if g_b is not None and g_b.numel() != g_a.numel():
+        raise _lib.GfnError("loss_grad_combine: gradients differ in size")
+    out = torch.empty_like(g_a) if out is None else out
+    _chk(out, torch.float32, "out")
+    _lib.check(_lib.lib().gfn_loss_grad_combine(_ptr(g_a), _ptr(w_a), _ptr(g_b), _ptr(w_b), g_a.numel(), _ptr(out), _stream()), "gfn_loss_grad_combine")
+    return out
 
 
 def s3im_index(n_rays, repeat_time=10, generator=None, device=None, out=None):

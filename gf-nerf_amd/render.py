@@ -54,7 +54,7 @@ class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
-                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128, first_k=None):
+                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
@@ -68,12 +68,7 @@ class TileRenderer:
         6.4 GB for a 518 k-ray tile, where a ray crosses a few dozen leaves): a frame in which a ray reaches the cap is rendered again with four
         times the cap, up to the reference's -- whose truncation is then the semantics."""
         self.hit_cap = max(int(hit_cap), 1)
-        # the two-phase march (ops.sample_rays_record's sample_cap): the tile's rays are marched first_k samples deep, composited, and only the rays
-        # still transparent there are marched again and resumed; None: hp.cfg.render_first_k; 0: off (every ray marched to its end)
-        fk = hp.cfg.render_first_k if first_k is None else first_k
         self.rec_slots = int(rec_slots) if 0 < int(rec_slots) < 1024 else 0
-        self.first_k = int(fk) // 32 * 32 if self.rec_slots else 0
-        self.continued_frac = 0.0  # rays of the last frame the two-phase march had to continue, as a fraction of the frame
         self.pool_regrown = 0  # how often a frame had to be rendered again with a larger record pool
         self.hp = hp
         self.c2w, self.intr = (None, None) if c2w is None else (c2w.contiguous(), intr.contiguous())  # None: render_rays only
@@ -90,10 +85,11 @@ class TileRenderer:
         """Tile shape, tiles per replay and the static input buffers for images of this size."""
         tile_rays, tile_width, pipeline = self._want
         if tile_rays is None:
-            # the record form costs 32 KB per ray and ring buffer + 6 KB of hit lists: a tile may take a quarter of what is free now
-            # (two ring buffers, and the eager warm-ups' cached blocks beside the graph's private pool)
+            # what a ray costs per ring buffer in the form that WILL be used (paged: rec_slots record slots of 32 bytes + a page table; dense from
+            # rec_slots = 0 on: 1024 slots) + the traversal's hit lists of hit_cap leaves: a tile may take a quarter of what is free now (two ring
+            # buffers, and the eager warm-ups' cached blocks beside the graph's private pool).  Derived again after every regrow (render_rays)
             free = torch.cuda.mem_get_info(self.hp.dev)[0] if self.hp.dev.type == "cuda" else 1 << 40
-            per_ray = (self.rec_slots or 1024) * 32 + 128 + 12 * self.hit_cap  # record slots + page table + the traversal's hit lists
+            per_ray = (self.rec_slots or 1024) * 32 + 128 + 12 * self.hit_cap
             cap = max(int(free // 4 // per_ray) // 32 * 32, 8192)
             tw, th = choose_tile(height, width, max_rays=min(cap, MAX_TILE_RAYS))
             T = tw * th
@@ -128,47 +124,45 @@ class TileRenderer:
         self.graph, self.out = None, None
         self._side = torch.cuda.Stream(device=dev) if self.P > 1 else None
         self._size = (height, width)
-        # per frame, read back once at its end: [0] the tiles' overflow words or-ed (a ring buffer's own word is zeroed by the next tile into it),
-        # [1] the rays the two-phase march had to continue, summed over the tiles
-        self._stat = torch.zeros(2, dtype=torch.int32, device=dev)
+        # per frame, read back once at its end: the tiles' overflow words or-ed (a ring buffer's own word is zeroed by the next tile into it)
+        self._stat = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def _tile(self):
         """-> [(rgb, accumulation, depth)] of the P tiles in the input buffers."""
         hp = self.hp
         if self.P == 1:
-            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, tile_width=self.patch_tw)
+            s = None
+            if self.record:  # the same paged records and hit-list cap as the pipeline's tiles (the memory budget of _setup counts on it)
+                s = hp.sample(self.o[0], self.d[0], self.noise, record=True, pool_slots_per_ray=self.rec_slots, max_hits=self.hit_cap)
+            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=s, tile_width=self.patch_tw)
+            if s is not None:
+                torch.bitwise_or(self._stat, s["overflow"], out=self._stat)
+                self._keep = [s]
             return [(out["rgb"], out["accumulation"], out["depth"], out["oct_depth"])]
-        from . import _lib
-
         main, side = torch.cuda.current_stream(), self._side
-        prev = _lib.lib().gfn_set_decoder_cus(self.decoder_cus)  # the grid is baked into the captured launches
-        try:
-            side.wait_stream(main)
-            # producer branch: the P samplers back to back (they share one workspace), into a ring of SLOTS sample buffers -- tile i
-            # is sampled into the buffer of tile i - SLOTS once that tile's fused forward has read it, so a whole frame can be one
-            # replay without one 4.5 GB record buffer per tile; consumer branch: the fused forward of tile i beside the samplers
-            # of the tiles after it
-            done, used, samples, outs = [], [], [], []
-            for i in range(self.P):
-                with torch.cuda.stream(side):
-                    if i >= self.SLOTS:
-                        side.wait_event(used[i - self.SLOTS])
-                    # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
-                    samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
-                                             record=self.record, pool_slots_per_ray=self.rec_slots if self.record else 0,
-                                             max_hits=self.hit_cap if self.record else None,
-                                             sample_cap=self.first_k if (self.record and self.rec_slots) else 0, own_workspace=self.record and self.first_k > 0))
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    done.append(ev)
-                if i >= self.SLOTS - 1:  # (the consumer trails the producer by SLOTS - 1 tiles in enqueue order: a wait needs its event recorded)
-                    self._consume(i - (self.SLOTS - 1), main, done, used, samples, outs)
-            for i in range(max(self.P - (self.SLOTS - 1), 0), self.P):
-                self._consume(i, main, done, used, samples, outs)
-            main.wait_stream(side)
-            self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
-        finally:
-            _lib.lib().gfn_set_decoder_cus(prev)
+        side.wait_stream(main)
+        # producer branch: the P samplers back to back (they share one workspace), into a ring of SLOTS sample buffers -- tile i
+        # is sampled into the buffer of tile i - SLOTS once that tile's fused forward has read it, so a whole frame can be one
+        # replay without one 4.5 GB record buffer per tile; consumer branch: the fused forward of tile i beside the samplers
+        # of the tiles after it
+        done, used, samples, outs = [], [], [], []
+        for i in range(self.P):
+            with torch.cuda.stream(side):
+                if i >= self.SLOTS:
+                    side.wait_event(used[i - self.SLOTS])
+                # (tiles for the patch kernel: traversal + counting march only -- the kernel reads the march's records, one copy of the samples)
+                samples.append(hp.sample(self.o[i], self.d[i], self.noise, out=samples[i - self.SLOTS] if i >= self.SLOTS else None,
+                                         record=self.record, pool_slots_per_ray=self.rec_slots if self.record else 0,
+                                         max_hits=self.hit_cap if self.record else None))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                done.append(ev)
+            if i >= self.SLOTS - 1:  # (the consumer trails the producer by SLOTS - 1 tiles in enqueue order: a wait needs its event recorded)
+                self._consume(i - (self.SLOTS - 1), main, done, used, samples, outs)
+        for i in range(max(self.P - (self.SLOTS - 1), 0), self.P):
+            self._consume(i, main, done, used, samples, outs)
+        main.wait_stream(side)
+        self._keep = samples  # sampler outputs were allocated on the side branch: hold them as long as the graph
         return outs
 
     def footprint_bytes(self):
@@ -200,12 +194,12 @@ class TileRenderer:
     def _consume(self, i, main, done, used, samples, outs):
         hp = self.hp
         main.wait_event(done[i])
-        out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw)
+        # (the inference kernel's grid is capped -- baked into the captured launch -- so that the next tile's sampler finds free CUs)
+        out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw,
+                        opts=ops.launch_opts(decoder_cus=self.decoder_cus))
         outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
-        if self.record:  # (behind the tile's last kernel: phase B of the march can exhaust the page pool too)
-            torch.bitwise_or(self._stat[0:1], samples[i]["overflow"], out=self._stat[0:1])
-            if samples[i].get("cont_n") is not None:
-                self._stat[1:2].add_(samples[i]["cont_n"])
+        if self.record:
+            torch.bitwise_or(self._stat, samples[i]["overflow"], out=self._stat)
         ev = torch.cuda.Event()
         ev.record(main)
         used.append(ev)
@@ -237,30 +231,26 @@ class TileRenderer:
         whole image -> dict(rgb [H,W,3], accumulation / depth / oct_depth [H,W,1])."""
         for _ in range(8):
             out = self._render_rays(O, D, embed_idx, height, width)
-            if not (self.P > 1 and self.record):
+            if not self.record:
                 return out
-            ovf, n_cont = self._stat.tolist()  # (one synchronisation per frame: ~0.1 % of a full-HD frame)
-            self.continued_frac = n_cont / float(height * width)
+            ovf = int(self._stat.item())  # (one synchronisation per frame: ~0.1 % of a full-HD frame)
             hits_short = bool(ovf & ops.HIT_CAP_REACHED) and self.hit_cap < self.hp.cfg.max_oct_per_ray
             if not (ovf & ops.REC_POOL_OVERFLOW) and not hits_short:
-                # the two-phase march pays while few rays need its second phase (each of them is marched twice); a scene where more than a quarter
-                # do -- thin, transparent -- gets a deeper first phase from the next frame on (captured again), and none from 384 samples on
-                if self.first_k and self.continued_frac > 0.25:
-                    self.first_k = self.first_k + 64 if self.first_k + 64 < 384 else 0
-                    self.graph, self.out, self._keep = None, None, None
                 return out
             # a tile's rays needed more record pages than the pool holds: a pool half as large again (the dense form from 1024 slots per ray on);
             # or a ray crossed more leaves than the hit lists hold: four times the cap.  Captured again, and this frame once more
             if ovf & ops.REC_POOL_OVERFLOW:
                 self.rec_slots = (int(self.rec_slots * 1.5) + 31) // 32 * 32
                 if self.rec_slots >= 1024:
-                    self.rec_slots, self.first_k = 0, 0  # (the dense form: no pages, no two-phase march)
+                    self.rec_slots = 0  # (the dense form: no pages)
             if hits_short:
                 self.hit_cap = min(self.hit_cap * 4, self.hp.cfg.max_oct_per_ray)
                 self.hp._record_ws = None  # (hit lists of the old stride)
             self.pool_regrown += 1
             self.graph, self.out, self._keep = None, None, None
             torch.cuda.empty_cache()
+            if self._want[0] is None:
+                self.T = None  # the tile size follows the new per-ray cost and what is free NOW (_setup): smaller tiles instead of running out of memory
         raise RuntimeError("TileRenderer: the record pool kept overflowing")
 
     def _render_rays(self, O, D, embed_idx, height, width):

@@ -51,11 +51,53 @@ typedef enum {
  *   gfn_field_fwd_x3 / gfn_field_bwd_scatter_x3 gained pointers, gfn_hash_fwd_pair / gfn_table_pair_f16 removed).
  *   102: round 4.   103: round 4 (gfn_sample_rays_record, gfn_fused_render_rec added; GFN_MARCH_REC_FLOATS 6 -> 8: a caller's march_rec
  *   buffer grows by a third).   104, 105: round 5 (gfn_set_plane_dither, gfn_set_march_lanes added; one-plane forms of the x3 plane
- *   arguments; gfn_sample_rays_record / gfn_fused_render_rec gained the paged record form's arguments). */
-#define GFN_ABI_VERSION 106
+ *   arguments; gfn_sample_rays_record / gfn_fused_render_rec gained the paged record form's arguments).   106: round 5
+ *   (gfn_sample_rays_continue and the two-phase arguments of gfn_sample_rays_record / gfn_fused_render_rec; gfn_set_record_merge_auto).
+ *   107: round 6 -- the five process-wide setters (gfn_set_decoder_cus, gfn_set_plane_dither, gfn_set_record_merge,
+ *   gfn_set_record_merge_auto, gfn_set_march_lanes) are GONE: launch policy is a `const gfn_launch_opts*` argument of the entry
+ *   points that read it (gfn_hash_fwd_lm, gfn_sample_rays, gfn_sample_rays_record, gfn_field_fwd_x3, gfn_field_bwd_dx_x3,
+ *   gfn_field_bwd_x3, gfn_field_bwd_scatter_x3, gfn_fused_forward, gfn_fused_render, gfn_fused_render_rec); the two-phase inference
+ *   march is gone too (gfn_sample_rays_continue and those arguments: a 6 % gain on a random-init scene, a 3x loss on a trained one);
+ *   gfn_train_losses, gfn_loss_grad_combine added. */
+#define GFN_ABI_VERSION 107
 
 const char* gfn_last_error(void);
 int gfn_version(void);
+
+/* Launch policy of ONE call.  The library keeps no copy and no state of its own: two engines, or a render thread beside the training
+ * thread, each pass their own (until ABI 106 these were process-wide setters that callers set, launched under and restored -- the
+ * stash-on-`this` hazard of Hash3DAnchored.cpp:104-106 rebuilt; ctypes releases the GIL around every call).  NULL, or a zeroed
+ * struct, is the default policy.
+ *   decoder_cus   cap on the workgroups (= CUs) of the persistent kernels -- the fused x3 decoder kernels (one 512-thread workgroup
+ *                 per CU with the whole LDS), gfn_fused_forward / gfn_fused_render(_rec), gfn_hash_fwd_lm's sweep -- so that they
+ *                 leave the other CUs to a kernel of another stream (the next batch's sampler); 0 or >= 256: every CU.  Only the
+ *                 grid depends on it, never a value.
+ *   plain_rounding  != 0: the one-plane (planes_lo == NULL) producers round WITHOUT their per-sample dither (csrc/x3_device.h:
+ *                 sample q's activations are stored as rne(a (1 + u_q)), its dz as rne(dz (1 - u_q)), u_q a fixed hash of q in
+ *                 +-2^-11, so that neighbouring samples' rounding errors are independent); default: dithered.
+ *   record_merge  gfn_field_bwd_scatter_x3 / gfn_field_bwd_dx_x3 in record form without planes (the focal stage): GFN_MERGE_OFF one
+ *                 record per sample and cell; GFN_MERGE_ON contributions of consecutive samples of a ray that fall into one cell are
+ *                 summed first (the global stage always does; a merged run is rounded to f16 once more: the choice changes bits);
+ *                 GFN_MERGE_DEVICE both forms are launched and the DEVICE runs the one that fits this step's own counts -- the
+ *                 merging form when *merge_front >= merge_frac * *merge_n (device i32 words: the samples in front of the
+ *                 termination points, e.g. gfn_phase_list's front count, and the batch's samples) -- so that a replayed step and an
+ *                 eagerly launched one decide alike.
+ *   march_lanes   lanes per ray of the samplers' march: 16 (a row per ray: batches that leave the machine empty), 4 (a quad: a
+ *                 quarter of the vector work per ray), 0 = by batch size (a quad from 32 Ki rays on; GFN_MARCH_LANES in the
+ *                 environment, read once, overrides that).  Both give the same bits. */
+#define GFN_MERGE_OFF 0
+#define GFN_MERGE_ON 1
+#define GFN_MERGE_DEVICE 2
+typedef struct gfn_launch_opts {
+  int32_t decoder_cus;
+  int32_t plain_rounding;
+  int32_t record_merge;
+  int32_t march_lanes;
+  const int32_t* merge_front;
+  const int32_t* merge_n;
+  float merge_frac;
+  int32_t reserved;
+} gfn_launch_opts; /* 40 B */
 /* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only host). */
 int gfn_device_count(void);
 
@@ -126,7 +168,7 @@ int gfn_hash_fwd_lm(const uint16_t* table_f16, const uint16_t* table2_f16, const
                     const int32_t* prim_pool2, const float* bias_pool, const float* pts, const int32_t* anchors,
                     int anchor_stride, int64_t n_max, const int32_t* n_dev, int64_t n_volumes, int log2_T,
                     int halves_from, int split_log2, int planar, int accumulate, float* out,
-                    const int32_t* list, const int32_t* list_n, void* stream);
+                    const int32_t* list, const int32_t* list_n, const gfn_launch_opts* opts, void* stream);
 /* f32 master -> f16 shadow (the reference's per-call pool.to(f16), Hash3DAnchored_cuda.cu:185). */
 int gfn_table_to_f16(const float* feat_pool, uint16_t* table_f16, int64_t n_elems, void* stream);
 
@@ -188,7 +230,7 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
                     int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far,
                     int32_t* pts_offsets, float* world_pts, float* warped_pts, float* dirs, float* dists,
                     float* ts, int32_t* anchors, int32_t* ray_id, float* first_oct_dis, int64_t pts_cap,
-                    int32_t* overflow_dev, float* march_rec, int tree_depth, void* stream);
+                    int32_t* overflow_dev, float* march_rec, int tree_depth, const gfn_launch_opts* opts, void* stream);
 /* The first half of the same only: traversal + counting march.  The samples stay where the march recorded them -- slot k of ray r at
  * march_rec[(r * 1024 + k) * GFN_MARCH_REC_FLOATS], counts[r] of them (table_space does not apply: the record holds the warped point) --
  * for a consumer that walks rays, not packed samples: gfn_fused_render_rec.  No scan, no fill, no second copy of the samples (a
@@ -200,24 +242,13 @@ int gfn_sample_rays(const float* rays_o, const float* rays_d, const float* noise
  * runs out, bit 16 of *overflow_dev is set (the slots written from then on alias the pool's last page): the caller samples again
  * into a larger pool.  Bit 8 (gfn_sample_rays too): some ray's traversal stopped at max_hits leaves with nodes still to visit -- the
  * reference's truncation at its max_oct_intersect_per_ray = 1024; a caller that passes a smaller max_hits (hit lists of n_rays *
- * max_hits entries) finds out here that it must ask again with a larger one.
- * sample_cap > 0 (a multiple of GFN_REC_PAGE): phase A of a TWO-PHASE march -- at most sample_cap samples per ray; more i32 [R]
- * receives 1 where the cap, not the ray's end, stopped the march.  gfn_fused_render_rec composites those samples and lists the rays
- * that are still transparent there; gfn_sample_rays_continue marches the listed rays again (same hit lists, same noise: the same
- * samples) and records the samples from record_from = sample_cap on, pages from the same pool (page_counter is NOT reset),
- * counts[ray] = the ray's full count; gfn_fused_render_rec then resumes those rays.  What lies behind the point where a ray
- * becomes opaque is neither marched nor recorded (41 % of a fog scene's samples). */
+ * max_hits entries) finds out here that it must ask again with a larger one. */
 int gfn_sample_rays_record(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
                            const void* compact_nodes, const void* transes, float near_bound, float far_bound,
                            int max_hits, float sample_l, int scale_by_dis, int32_t* hit_counts, int32_t* hit_idx,
                            float* hit_near_far, int32_t* counts, float* first_oct_dis, int32_t* overflow_dev,
-                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int sample_cap,
-                           int32_t* more, int tree_depth, void* stream);
-int gfn_sample_rays_continue(const float* rays_o, const float* rays_d, const float* noise, int64_t n_rays,
-                             const void* compact_nodes, const void* transes, int max_hits, float sample_l, int scale_by_dis,
-                             int32_t* hit_counts, int32_t* hit_idx, float* hit_near_far, int32_t* counts, int32_t* overflow_dev,
-                             float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages,
-                             const int32_t* ray_list, const int32_t* list_n, int record_from, void* stream);
+                           float* march_rec, int32_t* page_table, int32_t* page_counter, int64_t n_pages, int tree_depth,
+                           const gfn_launch_opts* opts, void* stream);
 
 /* Packed -> the reference's dense, zero-padded GetSamples() tensors
  * (PersSampler_cuda.cu:437-476): [R,1024,3] f32 x3, [R,1024] f32 x2,
@@ -307,7 +338,7 @@ int gfn_field_bwd_dx(const float* d_sigma, const float* d_rgb, const float* rgb,
  * Global stage (decoder trains): gfn_field_fwd_x3 with planes_{hi,lo} != NULL also keeps every layer
  * input as split-f16 planes.  planes_hi != NULL with planes_lo == NULL (the same in gfn_field_bwd_x3, gfn_field_bwd_scatter_x3,
  * gfn_fused_forward; dz_lo / a_lo of gfn_wgrad_x3_layers): ONE plane per operand, its values rounded to f16 once, to nearest
- * even, under a per-sample dither (gfn_set_plane_dither) -- for the weight gradient only, a sum over every sample of the batch
+ * even, under a per-sample dither (gfn_launch_opts.plain_rounding switches it off) -- for the weight gradient only, a sum over every sample of the batch
  * in which zero-mean, sample-to-sample independent rounding averages out; half the plane traffic (csrc/x3_device.h, PL_RNE).
  * The backward's one-plane buffer has GFN_FIELD_X3_BWD_PLANE_LD_RNE columns: dza1 -- whose layer contracts against the hash
  * features, exact in f16 -- keeps its lo' plane there (C=408 W=128) and is not dithered, nor is feat.  A plane buffer holds plane_cap * LD u16 (plane_cap >= n_max, multiple of
@@ -332,15 +363,15 @@ int gfn_field_fwd_x3(const float* feat, const int32_t* ray_id, const float* sh, 
                      const int32_t* cam_idx, const void* fwd_image, int64_t n_max, const int32_t* n_dev,
                      float* sigma, float* rgb, float* h0, uint64_t* masks, uint16_t* planes_hi,
                      uint16_t* planes_lo, int64_t plane_cap, int64_t feat_stride, const int32_t* list,
-                     const int32_t* list_n, void* stream);
+                     const int32_t* list_n, const gfn_launch_opts* opts, void* stream);
 int gfn_field_bwd_dx_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                         const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
-                        float* dfeat, void* stream);
+                        float* dfeat, const gfn_launch_opts* opts, void* stream);
 int gfn_field_bwd_x3(const float* d_sigma, const float* d_rgb, const float* rgb, const float* h0,
                      const uint64_t* masks, const void* bwd_image, int64_t n_max, const int32_t* n_dev,
                      float* dfeat, const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo,
                      int64_t plane_cap, const int32_t* ray_id, const int32_t* cam_idx, float* demb,
-                     void* stream);
+                     const gfn_launch_opts* opts, void* stream);
 /* Decoder backward + hash scatter in one kernel: d feat never leaves the chip -- each lane of the d-feat
  * tile hashes 8 levels of its sample and adds into grad_pool (same quantisation / accumulation rules as
  * gfn_hash_bwd; grad_f16 as there; pts / anchors [n,3] i32 / prim_pool of the table being trained).
@@ -352,7 +383,7 @@ int gfn_field_bwd_scatter_x3(const float* d_sigma, const float* d_rgb, const flo
                              const float* gmax_dev, uint16_t* planes_hi, uint16_t* planes_lo, int64_t plane_cap,
                              const int32_t* ray_id, const int32_t* cam_idx, float* demb, void* records,
                              uint32_t* record_counts, int64_t record_capacity, const int32_t* list,
-                             const int32_t* list_n, void* stream);
+                             const int32_t* list_n, const gfn_launch_opts* opts, void* stream);
 /* records != NULL (f16 pool only) DEFERS the atomics of gfn_field_bwd_scatter_x3: the pool's live slots (f16
  * pairs [0, 17T/2)) are cut into ranges of 2^GFN_GRAD_RANGE_LOG2 slots, and every add becomes a record (slot u32,
  * packed f16x2 value) in the stream of (range, workgroup): records[(range * 256 + workgroup) * cap + i] with
@@ -382,31 +413,6 @@ int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_
 int gfn_grad_max(const float* d_sigma, const float* d_rgb, const float* h0, int64_t n_max,
                  const int32_t* n_dev, float* gmax_dev, void* stream);
 float gfn_grad_scale_host(float gmax);
-/* The fused x3 decoder kernels are persistent, one 512-thread workgroup per CU with the whole LDS and
- * register file.  n_cus > 0 caps their grid so that they leave the other CUs to the fabric-bound
- * gather / scatter kernels of another chunk running on a second stream (0 = every CU).  Returns the
- * previous value.  Process-wide. */
-int gfn_set_decoder_cus(int n_cus);
-/* One-plane (planes_lo == NULL) producers: sample q's activations are stored as rne(a * (1 + u_q)) and its dz as
- * rne(dz * (1 - u_q)), u_q a fixed hash of q in +-2^-11, so that neighbouring samples' rounding errors are independent
- * (csrc/x3_device.h).  on = 0 switches the dither off (plain rounding).  Returns the previous value.  Process-wide; default on. */
-int gfn_set_plane_dither(int on);
-/* Focal-stage backward in record form (gfn_field_bwd_scatter_x3 with records, no planes): on != 0 merges the contributions of
- * consecutive samples of a ray that fall into one cell before they become records (the global stage always does).  Fewer, larger
- * records where a batch's rays crowd few cells (one camera cluster: the coarse levels' streams fill up and the overflow goes
- * through atomics); a few shuffles more where they do not.  Returns the previous value.  Process-wide; default off. */
-int gfn_set_record_merge(int on);
-/* ... or decided ON THE DEVICE for every launch: with front_dev / n_dev set (device i32 words: the batch's samples in front of the
- * termination points, e.g. the count of gfn_phase_list's front list, and its samples), gfn_field_bwd_scatter_x3 in record form without
- * planes launches BOTH forms and only the one that fits does anything -- the merging form when *front_dev >= frac * *n_dev (a dense
- * batch), the plain one otherwise.  The choice then depends on the step's own data and not on when the host looked: a replayed step
- * and an eagerly launched one produce the same bits.  NULL, NULL switches it off (gfn_set_record_merge rules again).  Process-wide;
- * the pointers must stay valid for every launch made while they are set. */
-int gfn_set_record_merge_auto(const int32_t* front_dev, const int32_t* n_dev, float frac);
-/* Lanes per ray of gfn_sample_rays' march: 16 (a row per ray: batches that leave the machine empty) or 4 (a quad: a quarter of the
- * vector work per ray), 0 = by batch size (a quad from 32 Ki rays on).  Both give the same bits (tests run both on the same rays).
- * Starts at GFN_MARCH_LANES from the environment, read once.  Returns the previous value.  Process-wide. */
-int gfn_set_march_lanes(int lanes);
 
 /* Weight gradient of one decoder layer from split-f16 planes (global stage):
  *   dW[m*ldw + col(k)] += (1/scale) sum_s dz[s][m] a[s][k],   db[m] += (1/scale) sum_s dz[s][m]
@@ -461,7 +467,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
                       const int32_t* cam_idx, float early_T, float* sigma, float* rgb, float* h0, uint64_t* masks,
                       float* weights, float* alphas, float* feat, uint16_t* planes_hi, uint16_t* planes_lo,
                       int64_t plane_cap, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax,
-                      int32_t* work_counter, void* stream);
+                      int32_t* work_counter, const gfn_launch_opts* opts, void* stream);
 
 /* Inference form of gfn_fused_forward (csrc/fused_fwd.hip, fused_render_patch_kernel): the same lookup + decoder +
  * compositing with early termination, but a wave owns a PATCH of 32 neighbouring rays (tile_width > 0: the rays are a
@@ -475,23 +481,18 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
                      const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                      int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                      const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
-                     float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, void* stream);
+                     float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
+                     void* stream);
 /* The same on the samples of gfn_sample_rays_record: counts i32 [R] and march_rec (16-byte aligned) instead of the packed arrays.  Slot k
  * of ray r is read where the counting march left it; the table-space point is made from the recorded warped point as the fill pass
  * makes it ((w + 1.5) * (1/3)), so the images are the bits of gfn_sample_rays(table_space = 1) + gfn_fused_render.
- * page_table: NULL, or the page table of gfn_sample_rays_record's paged form (march_rec is then the page pool).
- * Two-phase march (all NULL / 0 otherwise).  Phase A: more = gfn_sample_rays_record's flags -- a ray that is still transparent after
- * its (capped) samples and has more[ray] set leaves its compositing state in state f32 [R * 8] (16-byte aligned) and its index in
- * cont_list i32 [R] (*cont_n of them, zeroed by this launch); its outputs are partial until phase B.  Phase B: ray_list / list_n =
- * that list and count; patches are runs of 32 list entries (tile_width is ignored), every ray resumes from its state at sample
- * k_first (= the cap) and its outputs are written again; t_minmax accumulates over both launches. */
+ * page_table: NULL, or the page table of gfn_sample_rays_record's paged form (march_rec is then the page pool). */
 int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16,
                          const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                          int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
                          const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
-                         float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const int32_t* more,
-                         float* state, int32_t* cont_list, int32_t* cont_n, const int32_t* ray_list, const int32_t* list_n,
-                         int k_first, void* stream);
+                         float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
+                         void* stream);
 
 /* SH degree 4 of per-ray unit directions, tiny-cuda-nn convention on
  * (d+1)/2 (nerfacto_field.py:64-70,152-158,519-521), rounded to f16 like tcnn's
@@ -633,6 +634,19 @@ int gfn_errmap_sample(const float* error_map, int64_t n_pixels, const double* bl
 /* loss_dev[0] += sum(sqrt((pred-gt)^2+eps^2))/rows; g_pred = d loss / d pred. */
 int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps, float* loss_dev,
                     float* g_pred, void* stream);
+/* The launches between the compositing and the backward of a training iteration through the plugin surface, in one (csrc/render.hip): out3[0] =
+ * the Charbonnier loss of gfn_charbonnier (WRITTEN, nothing to zero first; sums in a fixed order: the same bits every run), out3[1] = 0 (for gfn_s3im
+ * to add its loss into), out3[2] = PSNR = -10 log10(mean((pred - gt)^2)) (get_metrics_dict, gfnerf/nerfacto.py:300,624); g_char f32 [rows,3] = d out3[0] /
+ * d pred (may be NULL); g_zero f32 [rows,3] zeroed (may be NULL: the buffer gfn_s3im scatters its gradient into); and, with error_map != NULL, the block
+ * stage's error-map write-back (gf_pipeline.py:180-185) exactly as gfn_errmap_update does it, the image of row i being slot[i] when slot != NULL (the
+ * position in the cached stack) and indices[3 i] otherwise.  One workgroup: rows <= 2^20. */
+int gfn_train_losses(const float* pred, const float* gt, int64_t rows, float eps, float* out3, float* g_char, float* g_zero,
+                     const int32_t* indices, const int32_t* slot, int32_t n_images, int32_t height, int32_t width, float* error_map,
+                     double* block_sums, void* stream);
+/* out[i] = g_a[i] * w_a[0] + g_b[i] * w_b[0] (w_* device f32 words; a NULL weight or gradient drops its term): the gradient of
+ * `loss = rgb_loss + s3im_loss` (engine/trainer.py:391) with respect to the prediction from the two losses' own gradients and the gradients autograd
+ * hands their backward, in one launch. */
+int gfn_loss_grad_combine(const float* g_a, const float* w_a, const float* g_b, const float* w_b, int64_t n, float* out, void* stream);
 /* S3IM (losses.py:713-794 as configured by gfnerf/config.py:96-100: 4x4 gaussian window, stride 4, zero
  * padding 1): loss_dev[0] += mult * (1 - mean SSIM) over the virtual image [3, patch_h, n_idx/patch_h]
  * whose pixel k is ray index[k] (arange + randperms, :780-789); g_pred [R,3] += mult * d/d pred (may be

@@ -261,24 +261,23 @@ def test_bench_global_step_planes_scale_and_weight_gradients_at_full_size(world,
     equal a float64 contraction dz^T a / scale over ALL samples of the very planes it read (2e-6 of sum |dz||a|: the kernel's own
     arithmetic), and -- the one-plane modes' accuracy -- the float64 contraction of the x3 planes (22-bit
     operands, taken as exact) to 1e-4 of each layer's largest |dW|: the achieved figure is printed.  "rne-plain": the one-plane
-    mode WITHOUT its per-sample dither (gfn_set_plane_dither(0)), reported for comparison and held to 3e-4 only."""
+    mode WITHOUT its per-sample dither (HotPathConfig.plane_dither = False: gfn_launch_opts.plain_rounding), reported for comparison and held to 3e-4 only."""
     import torch
 
-    from gfnerf_amd import _lib, ops
+    from gfnerf_amd import ops
 
     S = _stage(world, "global")
     hp = S["hp"]
-    prev = (hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override)
+    prev = (hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override, hp.cfg.plane_dither)
     plain = mode == "rne-plain"
     mode = "rne" if plain else mode
     hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override = mode, forward == "lm", False  # (one phase: every plane row written)
+    hp.cfg.plane_dither = not plain
     hp._plane_bufs = None  # the planes are allocated for one mode
-    was = _lib.lib().gfn_set_plane_dither(0 if plain else 1)
     try:
         _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=3e-4 if plain else 1e-4)
     finally:
-        _lib.lib().gfn_set_plane_dither(was)
-        hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override = prev
+        hp.cfg.wgrad_planes, hp.cfg.level_major_global, hp.phase_override, hp.cfg.plane_dither = prev
         hp._plane_bufs = None
 
 

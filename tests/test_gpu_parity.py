@@ -34,19 +34,23 @@ def ops():
 
 
 @pytest.fixture
-def set_march_lanes():
-    """gfn_set_march_lanes for one test (the library's process-wide setting is put back afterwards)."""
+def set_march_lanes(monkeypatch):
+    """The samplers' lanes per ray for one test: every ops.sample_rays / ops.sample_rays_record call the test makes without launch options of its own
+    carries ops.launch_opts(march_lanes=lanes) (the policy is an argument of the call since ABI 107: nothing process-wide is set or put back)."""
     import gfnerf_amd  # noqa: F401
-    from gfnerf_amd import _lib
-
-    before = []
+    from gfnerf_amd import ops as _ops
 
     def _set(lanes):
-        before.append(_lib.lib().gfn_set_march_lanes(int(lanes)))
+        for name in ("sample_rays", "sample_rays_record"):
+            fn = getattr(_ops, name)
 
-    yield _set
-    if before:
-        _lib.lib().gfn_set_march_lanes(before[0])
+            def call(*a, _fn=fn, **k):
+                k.setdefault("opts", _ops.launch_opts(march_lanes=int(lanes)))
+                return _fn(*a, **k)
+
+            monkeypatch.setattr(_ops, name, call)
+
+    return _set
 
 
 def _t(a, dev):
@@ -290,7 +294,7 @@ def test_march_bit_exact(oracle, ops, dev, train, fineness):
 def test_fast_sampler_bit_exact(oracle, ops, dev, set_march_lanes, train, fineness, n_rays, lanes, with_rec):
     """gfn_sample_rays (compact nodes, one-pass dense trace, a group of lanes per ray with DPP reductions) produces the same bits as
     the oracle -- and therefore as the gfn_trace + gfn_march boundary functions -- in each of its forms: a 16-lane row per ray (what
-    batches below 32 Ki rays get) or a quad of lanes (render tiles), gfn_set_march_lanes forcing either on these rays; the counting march
+    batches below 32 Ki rays get) or a quad of lanes (render tiles), gfn_launch_opts.march_lanes forcing either on these rays; the counting march
     recording (t, dist, leaf, warped point) for the sample-parallel fill, or, without the record buffer, a second march writing the samples."""
     import torch
 
@@ -1017,46 +1021,3 @@ def test_sample_record_paged_form_holds_the_same_samples(oracle, ops, dev, set_m
     pts = small["page_table"].view(n_rays, -1).cpu().numpy()
     for r in range(n_rays):
         assert (pts[r, : (cnt[r] + 31) // 32] < small["n_pages"]).all() and (pts[r, : (cnt[r] + 31) // 32] >= 0).all()
-
-
-@pytest.mark.parametrize("lanes", [16, 4])
-def test_two_phase_march_records_the_same_samples(oracle, ops, dev, set_march_lanes, lanes):
-    """The two-phase counting march (round 5): phase A (sample_cap = 64) marches every ray at most 64 samples deep -- counts = min(count, 64),
-    more = 1 exactly where the ray had samples left --; phase B (gfn_sample_rays_continue) marches a LIST of rays again and records their samples
-    from 64 on into pages of the same pool.  Afterwards the listed rays' counts and records are the one-phase march's bit for bit, the rays
-    not listed keep their first 64."""
-    import torch
-
-    from gfnerf_amd import scene
-
-    set_march_lanes(lanes)
-    n_rays, cap = 160, 64
-    sc, ref, _ = _sample_both(oracle, ops, dev, n_rays=n_rays, train=True, fineness=6.0)
-    noise = _t(scene.make_noise(n_rays, True, 6.0, seed=1), dev)
-    cn, tr = ops.tree_compact(_t(sc["nodes"], dev)), _t(sc["transes"], dev)
-    o, d = _t(ref["o"], dev), _t(ref["d"], dev)
-    dense = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True)
-    full = dense["counts"].cpu().numpy()
-    D = dense["march_rec"].view(n_rays, ops.MAX_SAMPLE_PER_RAY, ops.MARCH_REC_FLOATS).cpu().numpy().view(np.uint32)
-    s = ops.sample_rays_record(o, d, noise, cn, tr, 1.0 / 256, True, pool_slots_per_ray=int(full.mean()) + 64, sample_cap=cap)
-    assert np.array_equal(s["counts"].cpu().numpy(), np.minimum(full, cap))
-    assert np.array_equal(s["more"].cpu().numpy(), (full > cap).astype(np.int32)) and (full > cap).sum() > 20 and (full <= cap).sum() > 5
-    assert torch.equal(s["first_oct_dis"], dense["first_oct_dis"])
-    pages_a = int(s["page_counter"].item())
-    assert pages_a == int(np.ceil(np.minimum(full, cap) / 32).sum())
-    # phase B over every second ray that has more (an unordered list, as the inference kernel's atomic append makes it)
-    todo = np.nonzero(full > cap)[0][::2][::-1].astype(np.int32).copy()
-    s["cont_list"][: todo.size] = _t(todo, dev)
-    s["cont_n"].fill_(int(todo.size))
-    ops.sample_rays_continue(s)
-    cnt = s["counts"].cpu().numpy()
-    want = np.minimum(full, cap)
-    want[todo] = full[todo]
-    assert np.array_equal(cnt, want) and int(s["overflow"].item()) == 0
-    assert int(s["page_counter"].item()) == pages_a + int((np.ceil(full[todo] / 32) - cap // 32).sum())
-    P = s["march_rec"].view(-1, ops.REC_PAGE, ops.MARCH_REC_FLOATS).cpu().numpy().view(np.uint32)
-    pt = s["page_table"].view(n_rays, -1).cpu().numpy()
-    for r in range(n_rays):
-        for p in range((cnt[r] + 31) // 32):
-            k0, k1 = 32 * p, min(32 * p + 32, cnt[r])
-            assert np.array_equal(P[pt[r, p], : k1 - k0], D[r, k0:k1]), (r, p)

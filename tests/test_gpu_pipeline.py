@@ -818,9 +818,8 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
     (224 by default: 7 KB per ray) instead of 1024 slots for every ray (32 KB).  The image is the dense form's bit for bit; a pool that is too
     small (rec_slots = 32 here) is noticed at the end of the frame -- the samplers' overflow words, or-ed over the frame's tiles -- and
     the frame is rendered again with a pool half as large again, until it fits.  The same for the traversal's hit lists: 128 leaves per ray
-    by default instead of the reference's cap of 1024 (a ray that reaches the cap: four times the cap, and the frame again).  And the
-    two-phase march (first_k = 32 / 64 here): every ray marched first_k samples deep and composited, the rays still
-    transparent there marched again and resumed from their compositing state -- the same image bit for bit."""
+    by default instead of the reference's cap of 1024 (a ray that reaches the cap: four times the cap, and the frame again).  A frame rendered as ONE
+    tile per replay (pipeline = 1) uses the same paged records and caps, and notices their overflow the same way (round 6: the memory budget counts on it)."""
     import torch
 
     from gfnerf_amd import hotpath
@@ -836,30 +835,24 @@ def test_tile_pipeline_record_pool_is_sized_by_the_samples_and_grows_when_it_run
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=S["cfg"], seed=1, n_blocks=1)
     hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(5)); hp.refresh_shadows()
     imgs, foot = {}, {}
-    for name, slots, hits, fk in (("dense", 0, 1024, 0), ("paged", 224, 128, 0), ("starved", 32, 2, 0), ("two_phase", 224, 128, 32), ("two_phase_64", 224, 128, 64)):
-        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=3, rec_slots=slots, hit_cap=hits,
-                               first_k=fk)
+    for name, slots, hits, pipe in (("dense", 0, 1024, 3), ("paged", 224, 128, 3), ("starved", 32, 2, 3), ("one_tile", 224, 128, 1), ("one_tile_starved", 32, 2, 1)):
+        tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=pipe, rec_slots=slots, hit_cap=hits)
         out = tr.render_camera(3, H, W)
         imgs[name] = (out["rgb"].clone(), out["depth"].clone())
         again = tr.render_camera(3, H, W)  # a second frame through the same capture
         assert torch.equal(again["rgb"], imgs[name][0])
         foot[name] = tr.footprint_bytes()
-        assert tr.record and tr.P == 3
+        assert tr.record and tr.P == pipe
         if name == "dense":
             assert tr.rec_slots == 0 and tr.pool_regrown == 0
-        elif name == "paged":
+        elif name in ("paged", "one_tile"):
             assert tr.rec_slots == 224 and tr.hit_cap == 128 and tr.pool_regrown == 0
-        elif name.startswith("two_phase"):
-            # the two-phase march: first_k samples of every ray, then the rays still transparent there again -- some rays continue, most do not
-            # (in this scene nearly every ray is still transparent after 32 or 64 samples: the renderer notices -- continued_frac, read once per
-            # frame -- and deepens the first phase for the next frame, which the second render above went through)
-            assert tr.pool_regrown == 0 and 0.0 < tr.continued_frac <= 1.0 and tr.first_k in (fk, fk + 64, fk + 128, 0), (tr.continued_frac, tr.first_k)
         else:
             assert tr.pool_regrown >= 1 and tr.rec_slots > 32 and tr.hit_cap > 2, (tr.pool_regrown, tr.rec_slots, tr.hit_cap)
         del tr
         torch.cuda.empty_cache()
     assert float(imgs["dense"][0].std()) > 0.003
-    for name in ("paged", "starved", "two_phase", "two_phase_64"):  # the same images bit for bit (depth: the clip range never binds)
+    for name in ("paged", "starved", "one_tile", "one_tile_starved"):  # the same images bit for bit (depth: the clip range never binds)
         assert torch.equal(imgs[name][0], imgs["dense"][0]) and torch.equal(imgs[name][1], imgs["dense"][1]), name
     assert foot["paged"] < 0.45 * foot["dense"], foot
 
@@ -1406,111 +1399,91 @@ def test_backward_cu_share_follows_the_batch(setup):
     """HotPath._cu_cap: while a prefetched sampler runs beside it the focal backward keeps cfg.prefetch_cus CUs -- unless the batch is dense (at least
     cfg.prefetch_dense_frac of its samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is
     StepGraph's planning forward's, HotPath.front_override) and cfg.prefetch_cus_dense_eager when launched eagerly (the count is the pinned word the last
-    phased forward copied); the global stage keeps its own share; no prefetch, no cap; the previous value comes back afterwards.  (Only the grid depends
-    on the hint; what does change values -- merging the record runs of a dense batch -- is decided on the device: next test.)"""
-    from gfnerf_amd import _lib, hotpath
+    phased forward copied); the global stage keeps its own share; no prefetch, no cap.  The cap is a value handed to the ONE launch it is for
+    (ops.launch_opts(decoder_cus=...), ABI 107): nothing process-wide is set, so there is nothing to put back.  (Only the grid depends on the hint; what
+    does change values -- merging the record runs of a dense batch -- is decided on the device: next test.)"""
+    from gfnerf_amd import hotpath, ops
 
     S = setup
     cfg = hotpath.HotPathConfig(log2_T=S["cfg"].log2_T, prefetch_cus=160, prefetch_cus_global=192, prefetch_dense_frac=0.75, prefetch_cus_dense=184, prefetch_cus_dense_eager=200)
     hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
-    L = _lib.lib()
-
-    def seen(stage):
-        with hp._cu_cap(stage):
-            now = L.gfn_set_decoder_cus(0)
-            L.gfn_set_decoder_cus(now)
-        return now
-
-    base = L.gfn_set_decoder_cus(0)
     try:
-        assert seen("focal") == 0  # nothing prefetched: no cap
+        assert hp._cu_cap("focal") == 0  # nothing prefetched: no cap
         hp._pre = (None, None, None, False, {})
         hp._front_host[0], hp._front_host[1] = 10, 1000
-        assert seen("focal") == 160 and seen("global") == 192
+        assert hp._cu_cap("focal") == 160 and hp._cu_cap("global") == 192
         hp._front_host[0] = 800
-        assert seen("focal") == 200 and seen("global") == 192  # dense, eager launch
+        assert hp._cu_cap("focal") == 200 and hp._cu_cap("global") == 192  # dense, eager launch
         hp.front_override = (10, 1000)  # (a capture's planning forward says otherwise: its word counts)
-        assert seen("focal") == 160
+        assert hp._cu_cap("focal") == 160
         hp.front_override = None
-        assert L.gfn_set_decoder_cus(0) == 0  # restored
+        hp.cfg.prefetch_cus_dense_eager = 256
+        assert hp._cu_cap("focal") == 0  # 256 = every CU = no cap
     finally:
         hp._pre = None
-        L.gfn_set_decoder_cus(base)
+    o = ops.launch_opts(decoder_cus=300)
+    assert o.decoder_cus == 0 and ops.launch_opts(decoder_cus=184).decoder_cus == 184 and ops.launch_opts().record_merge == 0
+
+
+def _merge_engine(S, torch, hotpath, **cfg_kw):
+    hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=hotpath.HotPathConfig(log2_T=18, early_T=1e-2, **cfg_kw), seed=0, n_blocks=1)
+    hp.table.mul_(300.0)  # (T = 2^18: no record stream overflows into unordered atomics)
+    hp.blocks[0].uniform_(-1e-1, 1e-1, generator=torch.Generator(device="cuda").manual_seed(5))
+    hp.refresh_shadows()
+    hp._record_buffers()
+    hp.record_counts_seen = torch.zeros_like(hp._records[1])
+    return hp
 
 
 def test_record_merge_is_decided_on_the_device_from_the_steps_own_counts(setup):
     """cfg.record_merge_dense: with the phased forward's front list at hand the focal backward launches the plain and the run-merging record form as a
-    gated pair (gfn_set_record_merge_auto) and the DEVICE picks one from this step's counts -- front >= cfg.prefetch_dense_frac x samples: the merging
-    form.  Seen from outside: the number of records written.  A threshold no batch reaches gives the plain form's count, one every batch reaches the
-    merged form's (fewer), from the very first step (no host-side hint is involved); the process-wide switch (hotpath.RECORD_MERGE_FIXED, bench.py
-    --record-merge) takes the gate out; the gradient is the same up to the f16 rounding of a run's sum either way."""
+    gated pair (gfn_launch_opts.record_merge = GFN_MERGE_DEVICE) and the DEVICE picks one from this step's counts -- front >= cfg.prefetch_dense_frac x
+    samples: the merging form.  Seen from outside: the number of records written.  A threshold no batch reaches gives the plain form's count, one every
+    batch reaches the merged form's (fewer), from the very first step (no host-side hint is involved); cfg.record_merge = 0 / 1 (bench.py --record-merge)
+    takes the gate out; the gradient is the same up to the f16 rounding of a run's sum either way."""
     import torch
 
-    from gfnerf_amd import _lib, hotpath, ops
+    from gfnerf_amd import hotpath, ops
 
     S = setup
     t = S["t"]
     o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
     s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")
 
-    def run(frac, fixed=None):
-        cfg = hotpath.HotPathConfig(log2_T=18, early_T=1e-2, prefetch_dense_frac=frac, record_merge_dense=True)  # (what the plugin surface switches on)
-        hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
-        hp.table.mul_(300.0)
-        hp.blocks[0].uniform_(-1e-1, 1e-1, generator=torch.Generator(device="cuda").manual_seed(5))
-        hp.refresh_shadows()
-        hp._record_buffers()
-        hp.record_counts_seen = torch.zeros_like(hp._records[1])
-        prev = _lib.lib().gfn_set_record_merge(0)
-        try:
-            if fixed is not None:
-                hotpath.RECORD_MERGE_FIXED = True
-                _lib.lib().gfn_set_record_merge(fixed)
-            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # the FIRST step of the engine
-            torch.cuda.synchronize()
-        finally:
-            hotpath.RECORD_MERGE_FIXED = False
-            _lib.lib().gfn_set_record_merge(prev)
+    def run(frac, fixed=-1):
+        hp = _merge_engine(S, torch, hotpath, prefetch_dense_frac=frac, record_merge_dense=True, record_merge=fixed)  # (record_merge_dense: what the plugin surface switches on)
+        hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # the FIRST step of the engine
+        torch.cuda.synchronize()
         assert hp.last_forward == "lm2"
         return int(hp.record_counts_seen.to(torch.int64).sum()), hp.table_grad.float().clone()
 
     plain, g_plain = run(2.0)
     merged, g_merged = run(0.0)
     assert 0 < merged < 0.9 * plain, (plain, merged)
-    assert run(2.0, fixed=1)[0] == merged and run(0.0, fixed=0)[0] == plain  # the process-wide switch rules when it is fixed
+    assert run(2.0, fixed=1)[0] == merged and run(0.0, fixed=0)[0] == plain  # the fixed form rules when it is set
     assert float((g_merged - g_plain).abs().max()) <= 2e-3 * float(g_plain.abs().max())
 
 
 def test_merged_record_runs_give_the_same_table_gradient(setup):
-    """gfn_set_record_merge(1) (the focal backward's launch policy on dense batches, HotPath._cu_cap): runs of consecutive samples in one cell are summed
-    in f32 and written as ONE record per corner (field_bwd_dx_x3_kernel<0, 4>) -- fewer records, the same gradient up to the f16 rounding of a run's
-    sum (every addend is still quantised like the reference's, x128 -> f16), gradient mass conserved per channel."""
+    """cfg.record_merge = 1 (GFN_MERGE_ON: the focal backward's form on dense batches): runs of consecutive samples in one cell are summed in f32 and
+    written as ONE record per corner (field_bwd_dx_x3_kernel<0, 4>) -- fewer records, the same gradient up to the f16 rounding of a run's sum (every
+    addend is still quantised like the reference's, x128 -> f16), gradient mass conserved per channel."""
     import torch
 
-    from gfnerf_amd import _lib, hotpath, ops
+    from gfnerf_amd import hotpath, ops
 
     S = setup
     t = S["t"]
     o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
     s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")
-    L = _lib.lib()
     out = {}
-    base = L.gfn_set_record_merge(0)
-    try:
-        for merge in (0, 1):
-            cfg = hotpath.HotPathConfig(log2_T=18, early_T=1e-2)  # (T = 2^18: no record stream overflows into unordered atomics)
-            hp = hotpath.HotPath(S["sc"]["nodes"], S["sc"]["transes"], n_cams=S["sc"]["c2w"].shape[0], cfg=cfg, seed=0, n_blocks=1)
-            hp.table.mul_(300.0)
-            hp.blocks[0].uniform_(-1e-1, 1e-1, generator=torch.Generator(device="cuda").manual_seed(5))
-            hp.refresh_shadows()
-            L.gfn_set_record_merge(merge)
-            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # (buffers exist now)
-            hp.record_counts_seen = torch.zeros_like(hp._records[1])
-            hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
-            torch.cuda.synchronize()
-            out[merge] = dict(g=hp.table_grad.float().clone(), records=int(hp.record_counts_seen.to(torch.int64).sum()))
-    finally:
-        L.gfn_set_record_merge(base)
+    for merge in (0, 1):
+        hp = _merge_engine(S, torch, hotpath, record_merge=merge)
+        hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)  # (buffers exist now)
+        hp.record_counts_seen.zero_()
+        hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3)
+        torch.cuda.synchronize()
+        out[merge] = dict(g=hp.table_grad.float().clone(), records=int(hp.record_counts_seen.to(torch.int64).sum()))
     g0, g1 = out[0]["g"], out[1]["g"]
     assert 0 < out[1]["records"] < 0.9 * out[0]["records"], (out[0]["records"], out[1]["records"])  # the merged form did run, and merged
     scale = float(g0.abs().max())
@@ -1518,3 +1491,62 @@ def test_merged_record_runs_give_the_same_table_gradient(setup):
     for ch in (0, 1):
         a, b = g0.view(-1, 2)[:, ch].double().sum(), g1.view(-1, 2)[:, ch].double().sum()
         assert abs(float(a - b)) <= 1e-3 * float(g0.view(-1, 2)[:, ch].double().abs().sum())
+
+
+def test_two_engines_on_two_threads_keep_their_own_launch_policy(setup):
+    """VERDICT r05 #3 / ADVICE r05: launch policy is an argument of each call (gfn_launch_opts, ABI 107), not a process-wide setting that callers set,
+    launch under and restore -- ctypes releases the GIL around every call, so a render or evaluation thread beside the training thread, or two engines,
+    used to race on it.  Two engines with DIFFERENT policies -- A: plain records, every CU, 16 lanes per ray; B: merged records, a backward capped to 96
+    CUs behind a pending prefetch, a quad of lanes per ray -- run 24 focal steps each on two Python threads at once (separate streams), and each ends
+    with the bits it produces alone on one thread: same record counts per step (the merge form is a policy), same table gradient, same samples."""
+    import threading
+
+    import torch
+
+    from gfnerf_amd import hotpath, ops
+
+    S = setup
+    t = S["t"]
+    o, d, cam, gt, noise = t(S["o"]), t(S["d"]), t(S["cam"]), t(S["gt"]), t(S["noise"])
+    s3 = ops.s3im_index(S["o"].shape[0], 10, device="cuda")
+    policies = dict(A=dict(record_merge=0, lanes=16, cus=0), B=dict(record_merge=1, lanes=4, cus=96))
+
+    def work(name, n_steps, out, stream):
+        pol = policies[name]
+        with torch.cuda.stream(stream):
+            hp = _merge_engine(S, torch, hotpath, record_merge=pol["record_merge"], prefetch_cus=pol["cus"] or 256, prefetch_cus_dense_eager=pol["cus"] or 256)
+            counts, lanes = [], ops.launch_opts(march_lanes=pol["lanes"])
+            for _ in range(n_steps):
+                smp = hp.sample(o, d, noise, opts=lanes)
+                if pol["cus"]:
+                    hp._pre = (None, None, None, False, {})  # (a prefetch pending: the backward's launch carries the CU cap)
+                hp.record_counts_seen.zero_()
+                hp.forward_backward(o, d, cam, gt, noise, stage="focal", block=0, s3im_index=s3, samples=smp)
+                hp._pre = None
+                counts.append(hp.record_counts_seen.to(torch.int64).sum())
+            stream.synchronize()
+            out[name] = dict(counts=[int(c) for c in counts], g=hp.table_grad.float().clone(), po=smp["pts_offsets"].clone(), ts=smp["ts"].clone())
+
+    alone, both = {}, {}
+    main = torch.cuda.current_stream()
+    for name in policies:
+        work(name, 24, alone, main)
+    streams = {name: torch.cuda.Stream() for name in policies}
+    errs = []
+
+    def guarded(name):
+        try:
+            work(name, 24, both, streams[name])
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, e))
+
+    threads = [threading.Thread(target=guarded, args=(name,)) for name in policies]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    assert 0 < alone["B"]["counts"][0] < 0.9 * alone["A"]["counts"][0]  # the two policies do differ in what they write
+    for name in policies:
+        assert both[name]["counts"] == alone[name]["counts"], name
+        assert torch.equal(both[name]["g"], alone[name]["g"]) and torch.equal(both[name]["po"], alone[name]["po"]) and torch.equal(both[name]["ts"], alone[name]["ts"]), name

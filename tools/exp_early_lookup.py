@@ -71,11 +71,12 @@ def timed(fn_main, fn_side=None, reps=12, cus=0):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fn_side()
-        prev = _lib.lib().gfn_set_decoder_cus(cus) if cus else 0
+        # (the cap is the engine's policy for a backward with a prefetch pending -- HotPath._cu_cap -- not a process-wide setting since ABI 107)
+        hp.cfg.prefetch_cus = hp.cfg.prefetch_cus_dense_eager = cus or 256
+        hp._pre = (None, None, None, False, {}) if cus else None
         if fn_main is not None:
             fn_main()
-        if cus:
-            _lib.lib().gfn_set_decoder_cus(prev)
+        hp._pre = None
         if fn_side is not None:
             main.wait_stream(side)
         e1.record()

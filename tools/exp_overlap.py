@@ -25,8 +25,9 @@ def hashf(s):
 featA = hashf(sA)
 shA = ops.sh4(sA["dirs_unit"])
 img = hp._x3()[0]
+CUS = [0]
 def field(s, feat, cam, sh):
-    return ops.field_fwd(feat, s["ray_id"], sh, hp.emb, cam, hp.layers, n_dev=s["n_dev"], save=True, image=img)
+    return ops.field_fwd(feat, s["ray_id"], sh, hp.emb, cam, hp.layers, n_dev=s["n_dev"], save=True, image=img, opts=ops.launch_opts(decoder_cus=CUS[0]))
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def timed(fn, reps=5):
     ts = []
@@ -37,7 +38,7 @@ def timed(fn, reps=5):
     return float(np.median(ts))
 print("hash(B) alone", timed(lambda: hashf(sB)))
 for cus in (0, 128, 64, 48, 32):
-    _lib.lib().gfn_set_decoder_cus(cus)
+    CUS[0] = cus
     ta = timed(lambda: field(sA, featA, camA, shA))
     def both():
         cur = torch.cuda.current_stream()

@@ -16,11 +16,9 @@ VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward"
                 cus=[(f"graph, backward on {n or 256} CUs beside the sampler", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n or 256)), 0) for n in (0, 128, 160, 192, 224)],
                 policy=[("the engine's policy (dense batch: every CU, records merged)", {}, None), ("merge fixed off", {}, 0), ("merge fixed on", {}, 1)])
 for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
-    hotpath.RECORD_MERGE_FIXED = merge is not None  # (None: the engine decides per launch, HotPath._cu_cap)
-    merge = merge or 0
-    _lib.lib().gfn_set_record_merge(merge)
+    if merge is not None:  # (None: the engine decides per launch on the device, HotPath._merge_gate)
+        kw = dict(kw, hot_cfg=dict(kw.get("hot_cfg", {}), record_merge=int(merge)))
     r = bench.plugin_step_bench(sc, torch, "focal", steps=200, warmup=30, trained=(3000, 1000), **kw)
     print(name, round(r["ms_per_step"], 4), "host", round(r["host_ms_per_step"], 4), "forward", r["forward"], "samples/ray", round(r["mean_samples_per_ray"], 1),
           {k: v for k, v in r["trained"].items() if "record" in k or "stream" in k or "loss" in k or "grad" in k}, flush=True)
     torch.cuda.empty_cache()
-_lib.lib().gfn_set_record_merge(0)
