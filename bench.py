@@ -22,6 +22,7 @@ processes, before anything touches a GPU); under torchrun it is one of the ranks
 Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
 """
 import argparse
+import functools
 import json
 import os
 import socket
@@ -36,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RAYS = 4096
+PSNR_RECORD = "r06_psnr_study.json"  # the round's many-seed PSNR record under profiles/ (tools/psnr_study.py; legs plugin | reference)
 TARGET_SAMPLES = {"focal": 192, "global": 128}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PRIMING = 2            # set-up steps before the W warm-up steps (code objects, workspaces, allocator blocks)
@@ -78,7 +80,7 @@ def parse():
     ap.add_argument("--job-timeout", type=float, default=1500.0, help="N > 1, self-spawned ranks: seconds after which the ranks are killed and the exit code is 124")
     ap.add_argument("--psnr-seeds", type=int, default=3,
                     help="`psnr` sub-record: seeds per leg (the product's training leg against the reference-semantics leg, paired by seed); the many-seed "
-                         "record is profiles/r05_psnr_study.json (tools/psnr_study.py)")
+                         "record is profiles/r06_psnr_study.json (tools/psnr_study.py)")
     ap.add_argument("--trained-seeds", type=str, default="0,1",
                     help="`trained_state` sub-records (N = 1): engine seeds whose procedurally TRAINED state (global stage, then 4 focal blocks in rotation) the same "
                          "steps are timed on; empty = none")
@@ -582,7 +584,7 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
             cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
         optimizers.zero_grad_all()
         _, loss_dict, metrics_dict = pipe.get_train_loss_dict(step=step)
-        loss = sum(loss_dict.values())
+        loss = functools.reduce(torch.add, loss_dict.values())  # trainer.py:391
         loss.backward()
         is_nan = False
         if nan_check:  # trainer.py:415-423 (one host synchronisation per parameter that carries a .grad)
@@ -656,18 +658,18 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
 
 
 def psnr_study_record(steps_global, steps_focal):
-    """The many-seed PSNR record of the round (profiles/r05_psnr_study.json, written by tools/psnr_study.py on an MI355X): reported beside this run's few
+    """The many-seed PSNR record of the round (profiles/r06_psnr_study.json, written by tools/psnr_study.py on an MI355X): reported beside this run's few
     seeds ONLY when it was made with the same protocol (gfnerf_amd.procedural.PROTOCOL, steps)."""
     from gfnerf_amd import procedural
 
-    path = os.path.join(ROOT, "profiles", "r05_psnr_study.json")
+    path = os.path.join(ROOT, "profiles", PSNR_RECORD)
     try:
         rec = json.load(open(path))
         st = rec["psnr_study"]
         if st["steps"] != [steps_global, steps_focal] or rec.get("protocol") != procedural.PROTOCOL:
-            return dict(study_note="profiles/r05_psnr_study.json was made with another protocol: not reported")
-        return dict(study_delta=st["delta"], study_se=st["se"], study_n_seeds=st["n_seeds"], study_decoder_delta=st["decoder_delta"],
-                    study_source="profiles/r05_psnr_study.json (tools/psnr_study.py; same protocol)")
+            return dict(study_note=f"profiles/{PSNR_RECORD} was made with another protocol: not reported")
+        return dict(study_delta=st["delta"], study_se=st["se"], study_n_seeds=st["n_seeds"], study_decoder_delta=st["decoder_delta"], study_legs=st["legs"],
+                    study_source=f"profiles/{PSNR_RECORD} (tools/psnr_study.py; same protocol)")
     except (OSError, KeyError, ValueError):
         return {}
 

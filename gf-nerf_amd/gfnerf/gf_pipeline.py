@@ -193,6 +193,14 @@ class ImageStackDataManager(_DataManagerBase):
     def fixed_indices_eval_dataloader(self):
         return [(bundle, {"image": gt}) for gt, bundle in self.train_images_for_error_maps(down_scale_factor=1)]
 
+    def error_map_sink(self, ray_indices, slot=None):
+        """What the fused loss launch needs to do update_error_map's work itself (GFNeRFModel.set_error_map_sink): (error map, its block sums, the rays'
+        (c, y, x) rows, their positions in the cached stack), or None without an error map."""
+        if self.error_map is None:
+            return None
+        idx = ray_indices if ray_indices.dtype == torch.int32 and ray_indices.is_contiguous() else ray_indices.to(torch.int32).contiguous()
+        return (self.error_map.map, self.error_map.block_sums, idx, slot)
+
     def update_error_map(self, ray_indices, pred_rgb, gt_rgb):
         """_update_error_map(ray_indices, |gt - pred|.sum(-1)) (dataloaders.py:140-142; the error of gf_pipeline.py:181-184)
         fused into one launch."""
@@ -279,6 +287,7 @@ class GFNerfPipeline(Pipeline):
         self.model.to(device)
         self.world_size, self.local_rank = world_size, local_rank
         self._next_batch = None   # (step, datamanager split version, next_train(step) result) drawn one call early
+        self._rays_per_batch = None  # rays of the last training batch (the next S3IM index vector is drawn for as many)
         if world_size > 1:
             # no DDP wrapper (see the module docstring): the engine exchanges octree statistics and gradients itself
             assert self.model.hot.sync.world == world_size, "torch.distributed must be initialised before the pipeline is built (scripts/train.py:124)"
@@ -299,12 +308,22 @@ class GFNerfPipeline(Pipeline):
         else:  # nothing drawn ahead, or the callbacks changed the camera split since (update_datamanager, nerfacto.py:491-519)
             nxt = self.datamanager.next_train(step)
         ray_bundle, batch, ray_indices = nxt if len(nxt) == 3 else (nxt[0], nxt[1], None)
+        self._rays_per_batch = int(ray_bundle.origins.shape[0]) if ray_bundle.origins.dim() == 2 else int(ray_bundle.origins.numel() // 3)
         model_outputs = self.model(ray_bundle)
+        # update error map in block stage (:180-185).  A datamanager that keeps its error map in HBM (error_map_sink) has the write-back done by the
+        # model's fused loss launch -- the same |gt - pred|.sum(-1) into the same pixels, in the launch that computes the losses from them
+        update_map = (self.model.field.cur_stage == "block_stage" and hasattr(self.datamanager, "train_image_dataloader") and ray_indices is not None)
+        loader = self.datamanager.train_image_dataloader if update_map else None
+        sink = None
+        if update_map and hasattr(loader, "error_map_sink") and hasattr(self.model, "set_error_map_sink") and self.model.training:
+            sink = loader.error_map_sink(ray_indices, batch.get("slot"))
+            self.model.set_error_map_sink(sink)
         metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
         loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
-        # update error map in block stage (:180-185)
-        if self.model.field.cur_stage == "block_stage" and hasattr(self.datamanager, "train_image_dataloader") and ray_indices is not None:
-            loader = self.datamanager.train_image_dataloader
+        if sink is not None and getattr(self.model, "_errmap_sink", None) is not None:
+            self.model.set_error_map_sink(None)  # (the fused node did not run -- another loss configuration: the write-back is done here after all)
+            sink = None
+        if update_map and sink is None:
             pred_color, gt_color = model_outputs["rgb"].detach().contiguous(), batch["image"]
             if hasattr(loader, "update_error_map"):   # |gt - pred|.sum(-1) and the write-back in one launch
                 slots = torch.cat([batch["slot"][:, None], ray_indices[:, 1:3]], 1) if "slot" in batch else ray_indices
@@ -328,6 +347,8 @@ class GFNerfPipeline(Pipeline):
             main, side = torch.cuda.current_stream(), hot.side_stream()
             side.wait_event(here)
             with torch.cuda.stream(side):
+                if self._rays_per_batch and hasattr(self.model, "draw_s3im_index"):
+                    self.model.draw_s3im_index(self._rays_per_batch)  # the next iteration's S3IM index vector: a sort and four launches off the main stream
                 nxt = self.datamanager.next_train(step)
                 self._next_batch = (step, getattr(self.datamanager, "split_version", 0), nxt)
                 self.model.prefetch_samples(nxt[0])

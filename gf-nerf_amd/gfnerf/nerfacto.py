@@ -88,6 +88,10 @@ class GFNeRFModelConfig(ModelConfig):
     early_T: float = 1e-4               # early-termination transmittance of the compositing (0 = the reference: none)
     keep_blocks_resident: bool = True   # inactive block tables stay in HBM instead of being swapped through disk
     engine_seed: int = 0                # parameter initialisation of the engine (every rank uses the same)
+    octree_seed: int = -1               # random streams of the host octree build (probe points of ConstructTrans); -1: 1234 + engine_seed
+    wgrad_planes: str = "rne"           # HotPathConfig.wgrad_planes: operands of the decoder's weight gradient (global stage): "rne" one f16 plane each under
+                                        # a per-sample dither (f64 bar 1e-4 of max |dW|), "x3" hi + lo' planes (f32-class per term), "mixed"
+    record_capacity: int = 0            # HotPathConfig.record_capacity (8-byte gradient-record slots; 0: the engine's default, capped at 2048 per stream)
     render_tile_rays: int = 0           # rays per hipGraph-captured inference tile (get_outputs_for_camera_ray_bundle); 0 = a block of
                                         # ~128 Ki rays that divides the image (gfnerf_amd.render.choose_tile)
 
@@ -114,14 +118,16 @@ class _RenderFn(torch.autograd.Function):
         # static buffers (prefetch_samples): the focal stage's forward as a graph replay (global stage, measured: 2.07 against 2.02 ms per
         # iteration -- its iteration is not bound by the host)
         if stage == hp_mod.STAGE_FOCAL and any(s is st for st in model._static_samples):
-            comp, hctx = hot.forward_train_graphed(cam, stage, block, s)
+            cam_s = s.get("cam_static")  # (prefetch_samples wrote the batch's camera column beside the samples: read in place by the replay)
+            comp, hctx = hot.forward_train_graphed(cam_s if cam_s is not None else cam, stage, block, s, cam_static=cam_s is not None)
         else:
             # (init stage: update_oct_nodes follows every training forward, nerfacto.py:605-613, and reads every sample's alpha)
             comp, hctx = hot.forward_train(o, d, cam, noise, stage=stage, block=block, samples=s, all_alphas=stage == hp_mod.STAGE_GLOBAL)
         ctx.model, ctx.hctx, ctx.stage, ctx.block = model, hctx, stage, block
         ctx.params = (table, block_table, emb) + tuple(decoder)
         ctx.set_materialize_grads(False)  # an output the loss does not use arrives as None, not as zeros to be tested on the host
-        depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], hot.cfg.scale_factor)
+        depth = comp.get("depth")  # (a replayed forward made it inside its graph)
+        depth = depth[:, 0] if depth is not None else ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], hot.cfg.scale_factor)
         ctx.mark_non_differentiable(depth)
         # fresh tensor objects on the same storage: the outputs get this node as grad_fn, and the node reaches hctx -- handing out
         # hctx's own tensors would close a reference cycle through the autograd graph that no collector can see (a step's samples
@@ -133,7 +139,7 @@ class _RenderFn(torch.autograd.Function):
         hot = ctx.model.hot
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.hctx["comp"]["rgb"])
-        hot.backward(ctx.hctx, g_rgb.contiguous(), None if g_acc is None else g_acc.contiguous())
+        hot.backward_graphed(ctx.hctx, g_rgb.contiguous(), None if g_acc is None else g_acc.contiguous())  # (a replay when the forward was one)
         hot.sync_grads(ctx.stage, ctx.hctx)  # ray data parallelism: averaged over the ranks before any optimiser sees them
         table, block_table, emb = ctx.params[:3]
         decoder = ctx.params[3:]
@@ -203,6 +209,36 @@ class _S3IMFn(torch.autograd.Function):
         return g * g_out, None, None, None, None
 
 
+class _TrainLossesFn(torch.autograd.Function):
+    """What the pipeline runs between get_outputs and backward (get_metrics_dict's PSNR, nerfacto.py:300,624; get_loss_dict's Charbonnier rgb_loss +
+    s3im_loss_mult * S3IM, :628-689; the block stage's error-map write-back, gf_pipeline.py:180-185) as TWO launches (gfn_train_losses, gfn_s3im) instead of
+    ~twenty, and its backward -- d(rgb_loss) / d rgb * g_1 + d(s3im_loss) / d rgb * g_2 for whatever gradients g_1, g_2 autograd hands the two losses --
+    as one (gfn_loss_grad_combine), written straight into the buffer the engine's replayed backward reads (`grad_out`, or a fresh tensor).
+    -> (rgb_loss, s3im_loss | None, psnr): 0-dim views of one device vector."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, s3im_index, patch_h, mult, errmap, grad_out):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        out3, g_char, g_s3 = ops.train_losses(pred, gt, want_s3im_grad=s3im_index is not None, errmap=errmap)
+        if s3im_index is not None:
+            ops.s3im(gt, pred, s3im_index, patch_h=patch_h, mult=mult, loss=out3[1:2], g_pred=g_s3)
+        ctx.g, ctx.grad_out = (g_char, g_s3), grad_out
+        ctx.set_materialize_grads(False)
+        rgb_loss, s3_loss, psnr = out3[0], out3[1], out3[2]
+        ctx.mark_non_differentiable(psnr)
+        return rgb_loss, s3_loss, psnr
+
+    @staticmethod
+    def backward(ctx, go_rgb, go_s3, _go_psnr):
+        g_char, g_s3 = ctx.g
+        fix = lambda w: None if w is None else w.reshape(1).float().contiguous()  # noqa: E731
+        if g_s3 is None:
+            go_s3 = None
+        g = ops.loss_grad_combine(g_char, fix(go_rgb), g_s3, fix(go_s3), out=ctx.grad_out)
+        ctx.g = ctx.grad_out = None
+        return g, None, None, None, None, None, None
+
+
 def _ssim(img0, img1, data_range=1.0):
     """structural_similarity_index_measure (torchmetrics defaults: 11x11 gaussian window, sigma 1.5, k1 0.01, k2 0.03) of two
     [1,C,H,W] images; an evaluation-time metric on whole images (nerfacto.py:736), plain tensor arithmetic."""
@@ -245,7 +281,8 @@ class GFNeRFModel(Model):
         self.density_fns = []
         self.persampler = PersSampler(cameras=self.cameras, bounds=bounds, bbox_levels=10, max_level=16,
                                       steps_per_split_dataset=c.steps_per_split_dataset, steps_perssampler_init=c.steps_perssampler_init,
-                                      n_split_dataset=c.n_split_dataset, device=dev, seed=1234 + c.engine_seed)   # :223-227
+                                      n_split_dataset=c.n_split_dataset, device=dev,
+                                      seed=(1234 + c.engine_seed) if c.octree_seed < 0 else c.octree_seed)   # :223-227
         self.scale_factor = c.scale_factor
         self.sample_tmp_dir = None
         n_blocks = c.n_blocks
@@ -257,8 +294,9 @@ class GFNeRFModel(Model):
         assert c.hidden_dim == c.hidden_dim_color, "the fused decoder uses one hidden width (gfnerf/config.py:124-125: 128 / 128)"
         cfg = hp_mod.HotPathConfig(log2_T=c.log2_hashmap_size, hidden=c.hidden_dim, scale_factor=c.scale_factor, early_T=c.early_T,
                                    use_appearance_embedding=c.use_appearance_embedding, s3im_loss_mult=c.s3im_loss_mult,
-                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time,
-                                   record_merge_dense=True)  # (dense focal batches merge their record runs, decided on the device: HotPath._record_merge)
+                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time, wgrad_planes=c.wgrad_planes,
+                                   **({"record_capacity": c.record_capacity} if c.record_capacity > 0 else {}),
+                                   record_merge_dense=True)  # (dense focal batches merge their record runs, decided on the device: HotPath._merge_gate)
         self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg, device=dev,
                                   seed=c.engine_seed, n_blocks=0, sync=self.kwargs.get("sync", None))
         if self.hot.sync.world > 1 and c.n_split_dataset % self.hot.sync.world != 0:
@@ -432,6 +470,13 @@ class GFNeRFModel(Model):
             self.hot.forget_graphs()
         self.hot.prefetch_sample(o, d, noise, out=st[k])
         st[k] = self.hot._pre[4]
+        cam = ray_bundle.rel_camera_indices
+        if cam is not None:  # the batch's camera column beside its samples, at a fixed address: a replayed forward reads it in place (no copy on the main stream)
+            with torch.cuda.stream(self.hot.side_stream()):
+                cam = cam.reshape(-1)
+                if st[k].get("cam_static") is None or st[k]["cam_static"].numel() != cam.numel():
+                    st[k]["cam_static"] = torch.empty(cam.numel(), dtype=torch.int32, device=o.device)
+                st[k]["cam_static"].copy_(cam)
         self._static_turn = 1 - k
         self._prefetched = (ray_bundle, o, d, noise)
 
@@ -468,7 +513,9 @@ class GFNeRFModel(Model):
             rgb, acc, depth = _RenderFn.apply(self, stage, blk, o, d, cam, noise, self.field.base_encoding_init.hash_3d.feat_pool_, bt,
                                               self.field.embedding_appearance.weight, *self.field.decoder_parameters())
             ctx = self.hot._last_train_ctx
-            oct_depth = ctx["samples"]["first_oct_dis"][:, None] / self.scale_factor      # :555
+            oct_depth = ctx["comp"].get("oct_depth") if self.hot.last_forward_replayed else None  # (a replayed forward made it inside its graph)
+            if oct_depth is None:
+                oct_depth = ctx["samples"]["first_oct_dis"][:, None] / self.scale_factor  # :555
             outputs = {"rgb": rgb, "accumulation": acc[:, None], "depth": depth[:, None], "oct_depth": oct_depth}
             self.persampler.update_ray_march(step)                      # :603-604
             self.persampler.update_mode(0)
@@ -540,7 +587,62 @@ class GFNeRFModel(Model):
         out = self._tile_renderer[1].render_rays(o, d, embed_idx, H, W)
         return {k: v.view(H, W, -1) for k, v in out.items()}
 
+    # ---- the iteration's losses and metric as one fused node (<= 15 launches outside the two graphs)
+    def draw_s3im_index(self, n_rays):
+        """S3IM's index vector (arange + repeat_time - 1 random permutations, losses.py:780-789) of the NEXT get_loss_dict, drawn now on the current
+        stream (the pipeline calls this from its draw-ahead on the engine's second stream: a radix sort and four small launches less between the forward
+        and the backward).  One draw per iteration from the model's own generator either way: the same sequence of indices."""
+        c = self.config
+        if c.s3im_loss_mult <= 0:
+            return
+        idx = ops.s3im_index(n_rays, c.s3im_repeat_time, generator=self._s3im_gen, device=self._s3im_gen.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._s3im_next = (int(n_rays), idx, ev)
+
+    def _s3im_index(self, n_rays, device):
+        nxt, self._s3im_next = getattr(self, "_s3im_next", None), None
+        if nxt is not None and nxt[0] == n_rays:
+            torch.cuda.current_stream().wait_event(nxt[2])
+            nxt[1].record_stream(torch.cuda.current_stream())
+            return nxt[1]
+        return ops.s3im_index(n_rays, self.config.s3im_repeat_time, generator=self._s3im_gen, device=device)
+
+    def set_error_map_sink(self, sink):
+        """(error_map f32 [n,H,W(,1)], block_sums f64 | None, indices i32 [R,3], slot i32 [R] | None) of THIS iteration's error-map write-back
+        (gf_pipeline.py:180-185), or None: the pipeline hands it over so that the write-back rides in the fused loss launch (get_metrics_dict / get_loss_dict)."""
+        self._errmap_sink = sink
+
+    def _fused_losses(self, outputs, batch):
+        """The fused node's results for this (outputs, batch) pair -- computed by whichever of get_metrics_dict / get_loss_dict the pipeline calls first
+        (:172-173), read by the other -- or None when the fast form does not apply (not training, MSE loss, odd shapes: the plain tensor code below)."""
+        c = self.config
+        y, image = outputs.get("rgb"), batch.get("image")
+        if not (self.training and c.use_ch_loss and isinstance(y, torch.Tensor) and isinstance(image, torch.Tensor) and y.is_cuda and image.device == y.device
+                and y.dtype == torch.float32 and image.dtype == torch.float32 and y.dim() == 2 and y.shape[1] == 3 and image.shape == y.shape and y.shape[0] > 0):
+            return None
+        cache = getattr(self, "_loss_cache", None)
+        if cache is not None and cache[0] is y and cache[1] is image:
+            return cache[2]
+        R = y.shape[0]
+        idx = None
+        if c.s3im_loss_mult > 0:
+            if c.s3im_kernel_size != 4 or c.s3im_stride != 4:
+                raise NotImplementedError("the S3IM kernel is the method config's 4x4 window at stride 4 (gfnerf/config.py:97-98)")
+            assert (R * c.s3im_repeat_time) % c.s3im_patch_height == 0, "S3IM folds repeat_time * rays into rows of s3im_patch_height"
+            idx = self._s3im_index(R, y.device)
+        sink, self._errmap_sink = getattr(self, "_errmap_sink", None), None
+        grad_out = self.hot.grad_in_buffer(self.hot._last_train_ctx) if (y.requires_grad and self.hot.last_forward_replayed) else None
+        if grad_out is not None and grad_out.shape != y.shape:
+            grad_out = None
+        res = _TrainLossesFn.apply(y, image, idx, c.s3im_patch_height, c.s3im_loss_mult, sink, grad_out)
+        self._loss_cache = (y, image, res)
+        return res
+
     def get_metrics_dict(self, outputs, batch):
+        fused = self._fused_losses(outputs, batch)
+        if fused is not None:
+            return {"psnr": fused[2]}
         image = batch["image"].to(outputs["rgb"].device)
         mse = torch.mean((outputs["rgb"].detach() - image) ** 2)
         return {"psnr": -10.0 * torch.log10(mse)}   # torchmetrics PeakSignalNoiseRatio(data_range=1.0), nerfacto.py:300,624
@@ -548,6 +650,13 @@ class GFNeRFModel(Model):
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         """nerfacto.py:628-689: rgb_loss (Charbonnier when use_ch_loss, losses.py:73-84, else MSE) + s3im_loss_mult * S3IM."""
         c = self.config
+        fused = self._fused_losses(outputs, batch)
+        if fused is not None:
+            self._loss_cache = None  # (both readers served: the step's tensors are not held past the iteration)
+            loss_dict = {"rgb_loss": fused[0]}
+            if c.s3im_loss_mult > 0:
+                loss_dict["s3im_loss"] = fused[1]
+            return loss_dict
         image = batch["image"].to(outputs["rgb"].device)
         x, y = image, outputs["rgb"]
         loss_dict = {}

@@ -60,6 +60,8 @@ class HotPathConfig:
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
                                      # hipGraph replay per (stage, block, buffer) after three eager runs: ~25 launches less for the host
     graph_forward_shared_pool: bool = True  # the captured forwards share one memory pool (their transient buffers overlap; replays are sequential)
+    graph_backward: bool = True      # ... and the backward of such a replayed forward (compositing backward, decoder backward + record scatter, LDS accumulation)
+                                     # as a second replayed graph on the same static buffers (HotPath.backward_graphed; focal stage)
     graph_forward_keep: int = 4      # captured forwards kept (least recently used go first): each holds a full set of forward activations
                                      # (150-200 MB at 4096 x 192); 4 = two sample buffers x (the active block + the one before it)
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
@@ -146,6 +148,8 @@ class HotPath:
         self._side, self._pre = None, None  # sampler of the NEXT batch on a second stream (prefetch_sample)
         self._deferred = []
         self.last_forward_replayed = False
+        self.last_backward_replayed = False
+        self._backward_eager_like = False
         self._fwd_graphs = collections.OrderedDict()  # forward_train_graphed: key -> dict(n, graph, cam, comp, ctx, last_forward), least recently used first
         self._fwd_pool = None       # one memory pool for every captured forward (their transient buffers share it; replays are sequential)
         self.seg = None             # set by a segmented StepGraph capture: seg(fn) ends the graph segment being captured, notes fn as the
@@ -706,14 +710,16 @@ class HotPath:
         """Whatever a captured forward has baked in (tree blob, table addresses) is about to change."""
         self._fwd_graphs.clear()
 
-    def forward_train_graphed(self, cam_idx, stage, block, samples, want_depth=True):
+    def forward_train_graphed(self, cam_idx, stage, block, samples, want_depth=True, cam_static=False):
         """forward_train(samples=...) for a caller whose sample buffers are static (HotPath.sample(out=...): the same dict every other
         step) -- after three eager runs per (stage, block, buffer, forward kind) the launches are captured once and replayed: the
         training iteration of the plugin surface is bound by the host, and the forward is a third of its launches.  Outputs (comp,
         ctx) of a replay are the capture's tensors, written again: valid until the NEXT replay of any captured forward (the captures share one
         memory pool, so a later forward's transient buffers may reuse an earlier one's; a training iteration consumes them in its own backward,
         before the next forward).  At most cfg.graph_forward_keep captures are kept, the least recently used go first (each holds a full set
-        of forward activations)."""
+        of forward activations).  A capture with want_depth also holds the two per-ray leftovers of get_outputs -- comp["depth"] (DepthRenderer's clip + the
+        scale, nerfacto.py:545-546) and comp["oct_depth"] (:555) -- so that a replayed iteration launches nothing for them.  cam_static: cam_idx is a
+        buffer of the caller's that keeps its address (written before every call: the static sample set's own camera column): read in place, not copied."""
         c = self.cfg
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
         blk = block if stage == STAGE_FOCAL else None
@@ -728,7 +734,7 @@ class HotPath:
             ent["n"] += 1
             return self.forward_train(None, None, cam_idx, None, stage, block, want_depth=want_depth, samples=samples)
         if "graph" not in ent:
-            cam = cam_idx.clone()
+            cam = cam_idx if cam_static else cam_idx.clone()
             self._join_aux()
             self._sync_opt()
             if stage == STAGE_GLOBAL:
@@ -749,8 +755,13 @@ class HotPath:
             with torch.cuda.graph(g, pool=self._fwd_pool if c.graph_forward_shared_pool else None, capture_error_mode="thread_local"):
                 comp, ctx = self.forward_train(None, None, cam, None, stage, block, want_depth=want_depth, samples=samples)
                 self._join_aux()  # (the branch that builds the backward's list: inside the graph)
+                if want_depth:
+                    comp["depth"] = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)[:, None]
+                    comp["oct_depth"] = samples["first_oct_dis"][:, None] / c.scale_factor
             ent.update(graph=g, cam=cam, comp=comp, ctx=ctx, last_forward=self.last_forward)
-        ent["cam"].copy_(cam_idx)
+            ctx["graph_key"] = key  # (backward_graphed finds the capture its context belongs to)
+        if ent["cam"].data_ptr() != cam_idx.data_ptr():
+            ent["cam"].copy_(cam_idx)
         self._join_aux()
         self._sync_opt()
         if stage != STAGE_GLOBAL and self._x3_stale:
@@ -761,6 +772,56 @@ class HotPath:
         if stage == STAGE_GLOBAL:
             self._x3_stale = False
         return ent["comp"], ent["ctx"]
+
+    def grad_in_buffer(self, ctx):
+        """Where the backward of the captured forward `ctx` belongs to wants d loss / d rgb [R,3] written (a static buffer its replayed backward reads in
+        place), or None: a caller that produces the gradient there (gfnerf/nerfacto.py's fused loss node) saves backward_graphed a copy."""
+        ent = self._entry_of(ctx)
+        if ent is None or not self.cfg.graph_backward:
+            return None
+        if "g_rgb" not in ent:
+            ent["g_rgb"] = torch.zeros_like(ent["comp"]["rgb"])
+        return ent["g_rgb"]
+
+    def _entry_of(self, ctx):
+        ent = self._fwd_graphs.get(ctx.get("graph_key")) if ctx is not None else None
+        return ent if (ent is not None and ent.get("ctx") is ctx) else None
+
+    def backward_graphed(self, ctx, g_rgb, g_acc=None):
+        """backward(ctx, g_rgb) for the context of a REPLAYED forward (forward_train_graphed): the same launches -- compositing backward, decoder backward +
+        record scatter (the gated pair), LDS accumulation -- captured once per forward capture on its static buffers and replayed from then on; d loss /
+        d rgb is read from the capture's own buffer (grad_in_buffer: written there by the caller, or copied).  Everything else (another stage, d acc, a
+        context that is not a capture's, timed ops, a segmented or enclosing capture): the eager backward."""
+        c = self.cfg
+        self.last_backward_replayed = False
+        ent = self._entry_of(ctx)
+        usable = (ent is not None and c.graph_backward and c.graph_forward and g_acc is None and ctx["stage"] == STAGE_FOCAL and self.seg is None
+                  and not self.timed_ops and not torch.cuda.is_current_stream_capturing())
+        if not usable:
+            return self.backward(ctx, g_rgb, g_acc)
+        buf = self.grad_in_buffer(ctx)
+        if g_rgb.data_ptr() != buf.data_ptr():
+            buf.copy_(g_rgb)
+        if "bgraph" not in ent:
+            ent["bn"] = ent.get("bn", 0) + 1
+            if ent["bn"] < 2:  # (one eager run on these very buffers first: lazily made state -- record buffers, kernel attributes, the merge gate's words)
+                return self.backward(ctx, buf)
+            self._sync_opt()
+            self._join_aux()
+            self._x3()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            self._backward_eager_like = True  # (the sampler beside this graph is launched eagerly on the second stream: the eager CU share, not a captured step's)
+            try:
+                with torch.cuda.graph(g, pool=self._fwd_pool if c.graph_forward_shared_pool else None, capture_error_mode="thread_local"):
+                    self.backward(ctx, buf)
+            finally:
+                self._backward_eager_like = False
+            ent["bgraph"], ent["b_cus"] = g, self._cu_cap()
+        self._sync_opt()
+        self._join_aux()
+        ent["bgraph"].replay()
+        self.last_backward_replayed = True
 
     def _record_buffers(self):
         c = self.cfg
@@ -785,7 +846,7 @@ class HotPath:
             return 0
         n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
         if stage != STAGE_GLOBAL and self._dense_hint():
-            n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
+            n = c.prefetch_cus_dense if (torch.cuda.is_current_stream_capturing() and not self._backward_eager_like) else c.prefetch_cus_dense_eager
         return n if 0 < n < 256 else 0
 
     def _merge_gate(self, front, n_dev):

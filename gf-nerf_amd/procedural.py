@@ -14,6 +14,7 @@ eps = 1e-15 (gfnerf/config.py:130) turns the first last-bit difference of a near
 gradient is sign-like, and from there two runs (or two arithmetics of one) follow different trajectories whose PSNR scatters by ~0.5 dB; single steps
 from a common state agree (grad_cosine; tools/exp_x3_vs_f32_step.py).  The legs are compared through their means over many seeds
 (profiles/r04_psnr_study.json) and, without any training chaos, through the same trained states rendered with either decoder."""
+import gc
 import math
 
 import numpy as np
@@ -23,6 +24,7 @@ from . import hotpath, ops, scene
 
 Z_TOP, Z_BOTTOM, N_QUAD = 4.0, -4.0, 384
 PROTOCOL = "r04b: fresh rays every step, one fixed held-out set, texture 0.5, 3000 + 1000 steps, lr x0.1 per stage, legs fast | reference"  # bumped when the study's meaning changes
+# (round 6 adds the leg "plugin" under the same protocol: the same rays, schedule and held-out set, trained through the plugin surface)
 STUDY_STEPS = (3000, 1000)  # global, focal steps of a study run
 STUDY_LR_FINAL = 0.1        # learning-rate decay over each stage (1e-2 -> 1e-3, 5e-3 -> 5e-4).  With the rounds 2-3 schedule (2,000 steps, x0.01) the rate
                             # collapsed before the initial fog had cleared in some runs: a bimodal outcome (crisp ~32 dB | foggy 27-29 dB, chosen by
@@ -105,6 +107,10 @@ LEGS = {
     # (no transmittance cut), exact-f32 nn.Linear decoder (gfnerf/mlp.py:35-57), table gradient through f16 x128 atomic adds
     # (Hash3DAnchored_cuda.cu:151,209,222), torch.optim.Adam per parameter group (engine/optimizers.py:100-133)
     "reference": dict(precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, torch_adam=True),
+    # the product AS THE PLUGIN SURFACE BUILDS AND DRIVES IT: GFNerfPipeline.get_train_loss_dict -> backward -> Optimizers.optimizer_step_all ->
+    # scheduler_step_all with the callbacks of GFNeRFModel (engine/trainer.py:382-441) -- the engine gfnerf/nerfacto.py configures (record_merge_dense,
+    # replayed forward + backward, the fused loss node, GfnAdam through Optimizers), on the same rays, schedule and held-out set as the other legs
+    "plugin": dict(plugin=True),
 }
 
 
@@ -213,10 +219,104 @@ def grad_cosine(hp, batch, noise, s3, stage, block, legs=("reference", "fast")):
     return out
 
 
+class _ProceduralDataManager:
+    """The part of the host's datamanager GFNerfPipeline touches (gf_pipeline.py:94-192), fed by a batch function: next_train(step) -> fresh rays of the
+    procedural capture with their ground-truth colours (no image stack, hence no error map: uniform rays, like the other legs)."""
+
+    def __init__(self, c2w, intri, batch_fn, device):
+        from types import SimpleNamespace
+
+        from .gfnerf.gf_pipeline import _TrainDataset
+        from .gfnerf.perssampler import _Cameras
+
+        self.device = torch.device(device)
+        self.batch_fn = batch_fn
+        self.train_dataparser_outputs = SimpleNamespace(cameras=_Cameras(torch.as_tensor(np.ascontiguousarray(c2w)).float(), torch.as_tensor(np.ascontiguousarray(intri)).float()))
+        self.train_dataset = _TrainDataset(c2w.shape[0], scene_box=SimpleNamespace(aabb=torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])))
+        self.eval_dataset = self.train_dataset
+        self.split_version = 0
+
+    def to(self, device):
+        return self
+
+    def get_training_callbacks(self, attrs):
+        return []
+
+    def get_param_groups(self):
+        return {}
+
+    def next_train(self, step):
+        from .gfnerf.rays import RayBundle
+
+        o, d, cam, gt = self.batch_fn(step)
+        steps = torch.full((o.shape[0], 1), int(step), dtype=torch.int64, device=o.device)
+        bundle = RayBundle(origins=o, directions=d, camera_indices=cam[:, None], rel_camera_indices=cam[:, None], steps=steps)
+        bundle._step_host = (steps, int(step))
+        return bundle, {"image": gt}, None
+
+
+class _DataManagerConfig:
+    def __init__(self, make):
+        self.make = make
+
+    def setup(self, **kwargs):
+        return self.make(kwargs.get("device", "cuda:0"))
+
+
+def _plugin_trainer(sc, seed, steps_global, steps_focal, n_rays, log2_T, early_T, lr_final, batch_fn, cfg_kw):
+    """The pipeline, optimizers, schedulers and callbacks of the `gf-nerf` method (gfnerf/config.py) on the procedural capture, and one Trainer iteration
+    (engine/trainer.py:195-231,382-441) as a function of the step.  The study's schedule needs one scheduler per stage -- 1e-2 -> 1e-2 lr_final over the
+    global stage for "fields" / "base_encoding_init", 5e-3 -> 5e-3 lr_final over block 0's period for "base_encoding_0" -- which Optimizers takes as
+    per-group configs (a group WITHOUT its own takes config["fields"], engine/optimizers.py:86-87)."""
+    import functools
+
+    from .gfnerf._host import Optimizers, TrainingCallbackAttributes, TrainingCallbackLocation
+    from .gfnerf.gf_pipeline import GFNerfPipelineConfig
+    from .gfnerf.nerfacto import GFNeRFModelConfig
+    from .gfnerf.optim import GfnAdamOptimizerConfig
+    from .gfnerf.schedulers import GFNerfExponentialDecaySchedulerConfig
+
+    mk = dict(log2_hashmap_size=log2_T, hidden_dim=128, hidden_dim_color=128, steps_perssampler_init=steps_global, steps_per_split_dataset=max(steps_focal, 1),
+              n_split_dataset=1, n_blocks=1, scale_factor=10.0, use_appearance_embedding=True, use_ch_loss=True, s3im_loss_mult=1.0, early_T=early_T,
+              engine_seed=seed, octree_seed=1234)  # (the scene's own tree for every seed: the legs differ in the training path, not in the octree's probe points)
+    pcfg = GFNerfPipelineConfig(datamanager=_DataManagerConfig(lambda dev: _ProceduralDataManager(sc["c2w"], sc["intri"], batch_fn, dev)), model=GFNeRFModelConfig(**mk))
+    pipe = pcfg.setup(device="cuda:%d" % torch.cuda.current_device(), test_mode="val", world_size=1, local_rank=0, base_dir="/tmp/gfn_psnr_plugin")
+    model = pipe.model
+    hp = model.hot
+    assert hp.n_nodes * 128 == np.asarray(sc["nodes"]).size, "the plugin's sampler built another tree than the scene's"
+    for k, v in cfg_kw.items():
+        setattr(hp.cfg, k, v)
+    sched = lambda lr0, n: GFNerfExponentialDecaySchedulerConfig(lr_final=lr0 * lr_final, max_steps=max(n, 1), n_split_dataset=1, n_dataset_circles=1,  # noqa: E731
+                                                                 steps_per_split_dataset=max(steps_focal, 1), steps_perssampler_init=max(n, 1))
+    group = lambda lr0, n: {"optimizer": GfnAdamOptimizerConfig(lr=lr0, eps=hp.cfg.adam_eps), "scheduler": sched(lr0, n)}  # noqa: E731
+    optimizers = Optimizers({"fields": group(hp.cfg.lr, steps_global), "base_encoding_init": group(hp.cfg.lr, steps_global), "base_encoding_0": group(hp.cfg.lr_block, steps_focal)},
+                            pipe.get_param_groups())
+    callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
+    pipe.train()
+    nat = model.persampler.sampler
+    nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []  # UpdateOctNodes (K5 / K6) every global step, no ProcOctree: what every leg of the study does
+    nat.generator.manual_seed(seed + 11)
+
+    def iteration(step):
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        optimizers.zero_grad_all()
+        _, loss_dict, _ = pipe.get_train_loss_dict(step=step)
+        loss = functools.reduce(torch.add, loss_dict.values())
+        loss.backward()
+        optimizers.optimizer_step_all()
+        optimizers.scheduler_step_all(step)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+        return loss
+
+    return pipe, hp, nat, iteration
+
+
 def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_rays=4096, log2_T=21, seed=0, n_pool=64, eval_rays=16384, target_samples=128,
                    early_T=1e-4, progress=None, update_oct=True, torch_adam=False, fresh_rays=True, data_seed=None, eval_seed=0, lr_final=1e-2,
                    holdout_every=0, cosine_every=0, cosine_legs=("reference", "fast"), keep_engine=False, detail=0.0, n_blocks=1, after_global=None, lr_hold=0,
-                   **cfg_kw):
+                   plugin=False, **cfg_kw):
     """Train on the procedural scene with the product's native step (HotPath.train_step: sampler -> lookup -> decoder -> compositing ->
     Charbonnier + S3IM -> backward -> Adam; UpdateOctNodes every global step like GFNeRFModel.get_outputs), lr 1e-2 -> 1e-2 * lr_final over the
     global stage and 5e-3 -> 5e-3 * lr_final over the focal stage (GFNerfExponentialDecayScheduler's shape, schedulers.py:113-184), then render
@@ -237,9 +337,17 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
     After training the SAME state is also rendered with the other decoder arithmetic (psnr_eval_x3 / psnr_eval_f32): the inference-only
     difference, free of training chaos."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    cfg = hotpath.HotPathConfig(log2_T=log2_T, mlp_precision=precision, early_T=early_T, **cfg_kw)
-    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=seed, n_blocks=n_blocks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    plug = None
+    if plugin:  # the engine is the one the plugin surface builds (gfnerf/nerfacto.py); `batch` below feeds its datamanager
+        if not fresh_rays or n_blocks != 1 or torch_adam or cosine_every:
+            raise ValueError("train_and_eval(plugin=True): fresh rays, one block, the surface's own optimiser, no gradient-cosine probes")
+        plug = _plugin_trainer(sc, seed, steps_global, steps_focal, n_rays, log2_T, early_T, lr_final, lambda step: batch(step), cfg_kw)
+        hp = plug[1]
+        cfg = hp.cfg
+    else:
+        cfg = hotpath.HotPathConfig(log2_T=log2_T, mlp_precision=precision, early_T=early_T, **cfg_kw)
+        hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=seed, n_blocks=n_blocks)
     data_seed = seed if data_seed is None else data_seed
     c2w = t(sc["c2w"])
     n_cams = c2w.shape[0]
@@ -308,7 +416,28 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
     adam = TorchAdam(hp) if torch_adam else None
     cosines = []
     loss = None
-    for stage, steps, lr0, block in (("global", steps_global, cfg.lr, None), ("focal", steps_focal, cfg.lr_block, 0)):
+    if plug is not None:
+        # the Trainer's loop through the plugin surface; the march's fineness held at the study's sample budget (UpdateRayMarch anneals 16 -> 1 over
+        # 10,000 steps, PersSampler.cpp:958-967: every leg of the study holds it)
+        pipe, _, nat, iteration = plug
+        nat.ray_march_fineness_ = fin
+        nat.UpdateRayMarch = lambda cur_step, _f=fin: setattr(nat, "ray_march_fineness_", _f)
+        for step in range(steps_global + steps_focal):
+            if step == steps_global:
+                pipe.eval()
+                res["psnr_global"] = evaluate(None)
+                res["leaves_pruned"] = int((hp.nodes.view(-1, 128)[:, 96:104].contiguous().view(torch.int64) < 0).sum().item())
+                pipe.train()
+            loss = iteration(step)
+            if progress is not None and (step + 1) % 500 == 0:
+                progress(f"plugin step {step + 1}/{steps_global + steps_focal} loss {float(loss):.4f}")
+        pipe.eval()
+        if steps_focal <= 0:
+            res["psnr_global"] = evaluate(None)
+        res["plugin"] = dict(forward_replayed=bool(hp.last_forward_replayed), backward_replayed=bool(hp.last_backward_replayed), forward=hp.last_forward,
+                             record_merge_dense=bool(cfg.record_merge_dense))
+        loss = loss.detach()
+    for stage, steps, lr0, block in (() if plug is not None else (("global", steps_global, cfg.lr, None), ("focal", steps_focal, cfg.lr_block, 0))):
         for i in range(steps):
             b = batch(i)
             if stage == "focal":
@@ -383,6 +512,8 @@ def psnr_study(sc, seeds=(0, 1), legs=("fast", "reference"), progress=None, prec
         for sd in seeds:
             r = train_and_eval(sc, seed=sd, **{**kw, **LEGS[leg]})
             runs[leg].append(r)
+            gc.collect()  # (a run through the plugin surface leaves its pipeline in reference cycles: autograd nodes, callbacks' closures)
+            torch.cuda.empty_cache()
             if progress is not None:
                 progress(f"psnr {leg} seed {sd}: global {r['psnr_global']:.3f} final {r['psnr']:.3f} (same state: x3 {r['psnr_eval_x3']:.3f} f32 {r['psnr_eval_f32']:.3f})")
         vals = np.array([r["psnr"] for r in runs[leg]])
@@ -392,6 +523,9 @@ def psnr_study(sc, seeds=(0, 1), legs=("fast", "reference"), progress=None, prec
         out[f"psnr_global_{leg}"] = float(np.mean([r["psnr_global"] for r in runs[leg]]))
         if "psnr_heldout" in runs[leg][0]:
             out[f"psnr_heldout_{leg}"] = float(np.mean([r["psnr_heldout"] for r in runs[leg]]))
+    for leg in legs:
+        if "plugin" in runs[leg][0]:  # how the surface ran the last iterations of every seed (replayed forward / backward, the merge policy)
+            out[f"{leg}_surface"] = [r["plugin"] for r in runs[leg]]
     r0 = runs[legs[0]][0]
     out.update(steps=[r0["steps_global"], r0["steps_focal"]], mean_samples_per_ray=r0["mean_samples_per_ray"], n_seeds=len(seeds),
                alive_sample_frac_trained=r0.get("alive_sample_frac_trained"), planned_K_trained=r0.get("planned_K_trained"))

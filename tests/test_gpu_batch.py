@@ -96,6 +96,64 @@ def test_error_map_update_and_block_sums(ops, ob, dev, golden):
     np.testing.assert_allclose(s2.cpu().numpy(), ops.errmap_block_sums(big).cpu().numpy(), rtol=1e-9, atol=1e-9)
 
 
+def test_train_losses_is_charbonnier_psnr_and_the_error_map_write_back_in_one_launch(ops, ob, oracle, dev, golden):
+    """gfn_train_losses (round 6: the plugin surface's launches between compositing and backward, fused): out3[0] / g_char = the Charbonnier loss and
+    gradient of the golden vector (losses.py:73-84) and of the oracle, out3[1] = 0, out3[2] = torchmetrics' PSNR (data_range 1: -10 log10 mse), g_zero
+    zeroed; the error map and its partial sums after the launch are those gfn_errmap_update leaves (unique pixels: bit for bit; the sums follow the map),
+    with the image of a row taken from `slot` when given; the values are WRITTEN (garbage in the outputs beforehand) and the same bits every run.
+    gfn_loss_grad_combine: g_a w_a + g_b w_b with the weights read from the device."""
+    import torch
+
+    g = golden
+    pred, gt = _t(g["charb_pred"], dev), _t(g["charb_gt"], dev)
+    out3, gc, gz = ops.train_losses(pred, gt)
+    np.testing.assert_allclose(out3[0].item(), g["charb_loss"], rtol=1e-5)
+    np.testing.assert_allclose(gc.cpu().numpy(), g["charb_gpred"], rtol=1e-4, atol=1e-7)
+    lo, go = oracle.charbonnier(g["charb_pred"], g["charb_gt"])
+    np.testing.assert_allclose(out3[0].item(), lo, rtol=2e-6)
+    np.testing.assert_allclose(gc.cpu().numpy(), go, rtol=1e-5, atol=1e-9)
+    assert out3[1].item() == 0.0 and float(gz.abs().max()) == 0.0 and gz.shape == pred.shape
+    mse = float(np.mean((g["charb_pred"].astype(np.float64) - g["charb_gt"]) ** 2))
+    np.testing.assert_allclose(out3[2].item(), -10.0 * np.log10(mse), rtol=1e-5)
+    again = ops.train_losses(pred, gt)
+    assert torch.equal(again[0], out3) and torch.equal(again[1], gc)  # fixed-order sums: the same bits
+    # the error-map write-back riding along: against gfn_errmap_update on a copy of the map
+    R = g["errupd_indices"].shape[0]
+    p2, g2, idx = _t(g["errupd_pred"], dev), _t(g["errupd_gt"], dev), _t(g["errupd_indices"], dev)
+    em_a, em_b = _t(g["errpix_map"], dev), _t(g["errpix_map"], dev)
+    s_a, s_b = ops.errmap_block_sums(em_a), ops.errmap_block_sums(em_b)
+    ops.errmap_update(em_a, s_a, idx, p2, g2)
+    o3, _, _ = ops.train_losses(p2, g2, want_s3im_grad=False, errmap=(em_b, s_b, idx, None))
+    lin = (g["errupd_indices"][:, 0] * em_a.shape[1] + g["errupd_indices"][:, 1]) * em_a.shape[2] + g["errupd_indices"][:, 2]
+    uniq, counts = np.unique(lin, return_counts=True)
+    dup = np.isin(np.arange(em_a.numel()), uniq[counts > 1])
+    assert np.array_equal(em_b.cpu().numpy().reshape(-1)[~dup], em_a.cpu().numpy().reshape(-1)[~dup]) and R >= 32
+    np.testing.assert_allclose(s_b.cpu().numpy(), ops.errmap_block_sums(em_b).cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(o3[0].item(), ops.charbonnier(p2, g2)[0].item(), rtol=2e-6)
+    # a training batch's size (the strided loops of the one workgroup): against the multi-workgroup kernel and torch
+    big_p, big_g = torch.rand(8192, 3, device=dev), torch.rand(8192, 3, device=dev)
+    ob3, ogc, _ = ops.train_losses(big_p, big_g, want_s3im_grad=False)
+    ref_l, ref_g = ops.charbonnier(big_p, big_g)
+    np.testing.assert_allclose(ob3[0].item(), ref_l.item(), rtol=3e-6)
+    assert torch.equal(ogc, ref_g)
+    np.testing.assert_allclose(ob3[2].item(), float(-10.0 * torch.log10(torch.mean((big_p.double() - big_g.double()) ** 2))), rtol=1e-5)
+    # `slot` names the image of a row (its position in the cached stack) where the indices carry the camera
+    em_c = _t(g["errpix_map"], dev)
+    cams = idx.clone(); cams[:, 0] += 1000
+    ops.train_losses(p2, g2, want_s3im_grad=False, errmap=(em_c, None, cams, idx[:, 0].contiguous()))
+    assert np.array_equal(em_c.cpu().numpy().reshape(-1)[~dup], em_a.cpu().numpy().reshape(-1)[~dup])
+    em_d = _t(g["errpix_map"], dev)
+    ops.train_losses(p2, g2, want_s3im_grad=False, errmap=(em_d, None, cams, None))  # cameras out of range: rows skipped, like gfn_errmap_update
+    assert torch.equal(em_d, _t(g["errpix_map"], dev))
+    # the backward's combination
+    wa, wb = torch.tensor([0.75], device=dev), torch.tensor([-2.0], device=dev)
+    a, b = torch.randn(300, 3, device=dev), torch.randn(300, 3, device=dev)
+    assert torch.equal(ops.loss_grad_combine(a, wa, b, wb), a * 0.75 + b * -2.0)
+    assert torch.equal(ops.loss_grad_combine(a, wa), a * 0.75) and torch.equal(ops.loss_grad_combine(a, None, b, wb), b * -2.0)
+    buf = torch.empty_like(a)
+    assert ops.loss_grad_combine(a, wa, b, None, out=buf) is buf and torch.equal(buf, a * 0.75)
+
+
 def _dyadic(rng, n, zero_frac=0.2):
     """weights whose f64 sums are exact in any order (multiples of 2^-10 below 4): bit-exact parity is then well defined"""
     w = rng.integers(0, 4096, n).astype(np.float32) / 1024.0

@@ -706,11 +706,13 @@ def test_gfn_adam_is_the_same_training_run_as_torch_adam(dev, tmp_path, prefetch
 
 
 def test_replayed_focal_forward_is_the_same_training_run(dev, tmp_path):
-    """The plugin surface's focal iteration with the forward as a hipGraph replay (HotPath.forward_train_graphed: on from the fourth use of a set
-    of static sample buffers) against the same run with cfg.graph_forward off: one block's period long enough that each of the two captures is
-    replayed five times -- the gradient pool is zeroed INSIDE the captured forward here (the optimiser is the caller's), and that zeroing must
-    happen on every replay (round 5: as a memset node it ran in full on a capture's first replay only; the earlier tests of this file never
-    replayed a capture twice).  Same losses, same block table, and the pool holds one step's gradient, not a sum of steps."""
+    """The plugin surface's focal iteration with the forward AND the backward as hipGraph replays (HotPath.forward_train_graphed: on from the fourth use
+    of a set of static sample buffers; HotPath.backward_graphed: captured at the second backward of a replayed forward, on that capture's buffers, with
+    d loss / d rgb written into it by the fused loss node) against the same run with cfg.graph_forward off: one block's period long enough that each of
+    the two forward captures is replayed five times and each backward capture four -- the gradient pool is zeroed INSIDE the captured forward here (the
+    optimiser is the caller's), and that zeroing must happen on every replay (round 5: as a memset node it ran in full on a capture's first replay
+    only; the earlier tests of this file never replayed a capture twice).  Same losses, same block table, and the pool holds one step's gradient, not a
+    sum of steps; the replayed run's per-ray extras (depth, oct_depth: made inside the forward's graph) are the eager run's."""
     import torch
 
     from gfnerf_amd.gfnerf._host import Optimizers, TrainingCallbackAttributes
@@ -729,24 +731,37 @@ def test_replayed_focal_forward_is_the_same_training_run(dev, tmp_path):
         optimizers = Optimizers({"fields": {"optimizer": GfnAdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": sched}}, pipe.get_param_groups())
         callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=optimizers, grad_scaler=None, pipeline=pipe))
         model.train(); model.persampler.update_mode(0)
-        replays, pool_abs = [], []
-        inner = model.hot.forward_train_graphed
+        replays, b_replays, pool_abs, extras = [], [], [], []
+        inner, inner_b, inner_out = model.hot.forward_train_graphed, model.hot.backward_graphed, model.get_outputs
 
         def counted(*a, _inner=inner, _hot=model.hot, **k):
             out = _inner(*a, **k)
             replays.append(_hot.last_forward_replayed)
             return out
 
-        model.hot.forward_train_graphed = counted
+        def counted_b(*a, _inner=inner_b, _hot=model.hot, **k):
+            out = _inner(*a, **k)
+            b_replays.append(_hot.last_backward_replayed)
+            return out
+
+        def outputs(rb, _inner=inner_out):
+            out = _inner(rb)
+            extras.append((float(out["depth"].sum()), float(out["oct_depth"].sum()), tuple(out["depth"].shape), tuple(out["oct_depth"].shape)))
+            return out
+
+        model.hot.forward_train_graphed, model.hot.backward_graphed, model.get_outputs = counted, counted_b, outputs
         hist = []
         for step in range(20):
             hist += _trainer_loop(pipe, optimizers, callbacks, [step], fixed=False)
             pool_abs.append(float(model.hot._grad_live().float().abs().sum()))
         torch.cuda.synchronize()
-        runs[name] = dict(hist=hist, block0=model.hot.blocks[0].clone(), replays=replays, pool_abs=pool_abs)
+        runs[name] = dict(hist=hist, block0=model.hot.blocks[0].clone(), replays=replays, b_replays=b_replays, pool_abs=pool_abs, extras=extras)
     a, b = runs["eager"], runs["replayed"]
     assert not any(a["replays"]) and sum(b["replays"]) >= 8, (a["replays"], b["replays"])  # 16 focal iterations: 2 x 3 eager, then replays
+    assert not any(a["b_replays"]) and sum(b["b_replays"]) >= 8, (a["b_replays"], b["b_replays"])  # each backward capture replayed >= 4 times
     np.testing.assert_allclose(b["hist"], a["hist"], rtol=1e-3)
     np.testing.assert_allclose(b["pool_abs"], a["pool_abs"], rtol=0.05)  # (a pool that is not zeroed grows by a step's gradient per step)
+    assert [e[2:] for e in b["extras"]] == [e[2:] for e in a["extras"]]
+    np.testing.assert_allclose([e[:2] for e in b["extras"]], [e[:2] for e in a["extras"]], rtol=2e-3)
     diff = (b["block0"] - a["block0"]).abs()
     assert float(a["block0"].abs().max()) > 0 and float((diff > 2e-5).float().mean()) < 3e-2 and float(diff.max()) < 0.05

@@ -14,7 +14,11 @@ from gfnerf_amd import hotpath  # noqa: E402
 VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward", dict(graph_forward=False), 0), ("eager forward+merge", dict(graph_forward=False), 1),
                       ("graph, no prefetch", dict(prefetch=False), 0)],
                 cus=[(f"graph, backward on {n or 256} CUs beside the sampler", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n or 256)), 0) for n in (0, 128, 160, 192, 224)],
-                policy=[("the engine's policy (dense batch: every CU, records merged)", {}, None), ("merge fixed off", {}, 0), ("merge fixed on", {}, 1)])
+                policy=[("the engine's policy (dense batch: every CU, records merged)", {}, None), ("merge fixed off", {}, 0), ("merge fixed on", {}, 1)],
+                # round 6: the backward as a second replayed graph, the fused loss node, the S3IM index drawn ahead
+                r06=[("forward + backward replayed", {}, None), ("backward eager", dict(hot_cfg=dict(graph_backward=False)), None),
+                     ("forward + backward eager", dict(graph_forward=False), None)],
+                r06cus=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n)), None) for n in (256, 224, 192, 160)])
 for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
     if merge is not None:  # (None: the engine decides per launch on the device, HotPath._merge_gate)
         kw = dict(kw, hot_cfg=dict(kw.get("hot_cfg", {}), record_merge=int(merge)))

@@ -6,6 +6,7 @@ import numpy as np
 
 every = [json.load(open(p)) for p in sys.argv[2:]]
 assert len({p["protocol"] for p in every}) == 1, "parts were made with different protocols"
+assert len({tuple(p["psnr_study"]["legs"]) for p in every if "psnr_study" in p}) == 1, "parts pair different legs"
 parts = [p for p in every if "psnr_study" in p]
 out = dict(protocol=every[0]["protocol"])
 for p in every:  # gradient-cosine trajectory / octree study: the LAST file that carries them (an aux-only call, or part 0)

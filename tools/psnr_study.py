@@ -5,7 +5,9 @@ evaluated, exact-f32 decoder, f16 atomics, torch.optim.Adam), paired by seed -- 
 octree study (early_T 1e-4 vs 0: leaf sets after the global stage).
     python tools/psnr_study.py OUT.json [n_seeds [steps_global steps_focal [detail]]]
 GFN_STUDY_SEED0=k: seeds k .. k + n_seeds - 1 and only the paired study (a call on the GPU box lasts 20 minutes at most: the record of a round is
-several calls' outputs merged by tools/psnr_merge.py)."""
+several calls' outputs merged by tools/psnr_merge.py).  GFN_STUDY_LEGS=a,b: the two legs of procedural.LEGS to pair (default, round 6: plugin,reference --
+the engine AS THE PLUGIN SURFACE BUILDS AND DRIVES IT against the reference's training semantics; rounds 4-5: fast,reference).  GFN_STUDY_NO_AUX=1: no
+gradient-cosine / octree sections even from seed 0."""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,15 +85,19 @@ def aux_sections():
 
 
 
-if seed0 == 0 or os.environ.get("GFN_STUDY_AUX_ONLY") == "1":
+legs = tuple(os.environ.get("GFN_STUDY_LEGS", "plugin,reference").split(","))
+assert len(legs) == 2 and all(leg in procedural.LEGS for leg in legs), legs
+res["legs"] = list(legs)
+if (seed0 == 0 and os.environ.get("GFN_STUDY_NO_AUX") != "1") or os.environ.get("GFN_STUDY_AUX_ONLY") == "1":
     aux_sections()
 if os.environ.get("GFN_STUDY_AUX_ONLY") == "1":  # the gradient-cosine trajectory and the octree study alone (merged with the seed ranges' parts)
     sys.exit(0)
 
 # ---- 3. the paired study
 t0 = time.perf_counter()
-st = procedural.psnr_study(sc, seeds=tuple(range(seed0, seed0 + n)), legs=("fast", "reference"), steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, holdout_every=8, progress=say)
+st = procedural.psnr_study(sc, seeds=tuple(range(seed0, seed0 + n)), legs=legs, steps_global=sg, steps_focal=sf, detail=detail, lr_final=LRF, holdout_every=8, progress=say)
 st["seconds"] = time.perf_counter() - t0
 res["psnr_study"] = st
+save()
 say(f"delta {st['delta']:+.3f} +- {st['se']:.3f} dB over {n} seeds; same-state decoder delta {st['decoder_delta']:+.4f} +- {st['decoder_se']}")
 save()
