@@ -796,7 +796,7 @@ class HotPath:
         self.last_backward_replayed = False
         ent = self._entry_of(ctx)
         usable = (ent is not None and c.graph_backward and c.graph_forward and g_acc is None and ctx["stage"] == STAGE_FOCAL and self.seg is None
-                  and not self.timed_ops and not torch.cuda.is_current_stream_capturing())
+                  and not self.timed_ops and self.record_counts_seen is None and not torch.cuda.is_current_stream_capturing())
         if not usable:
             return self.backward(ctx, g_rgb, g_acc)
         buf = self.grad_in_buffer(ctx)

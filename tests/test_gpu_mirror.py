@@ -340,6 +340,7 @@ def test_model_get_outputs_and_training_loop(oracle, dev, tmp_path):
     from gfnerf_amd import ops
     g = torch.Generator(device=dev); g.manual_seed(5)
     model._s3im_gen.manual_seed(5)
+    model._s3im_next = None  # (the index the pipeline drew AHEAD for the next iteration came from the stream before the reseed: dropped)
     idx = ops.s3im_index(256, 10, generator=g, device=dev)
     pred = outputs["rgb"].detach()
     want, _ = ops.s3im(batch["image"], pred.contiguous(), idx, patch_h=32, mult=1.0)

@@ -3,7 +3,7 @@ run): start offset, duration, queue, kernel -- to see what overlaps what.   pyth
 import csv, glob, os, sys
 d = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)  # the newest: gpurun merges earlier runs into the same directory
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in csv.DictReader(open(f))]
 rows.sort()
 anchor = sys.argv[3] if len(sys.argv) > 3 else "lm_lookup_kernel<true, false>"

@@ -3,7 +3,7 @@
 auto:<part>: divide by the number of dispatches in the window whose kernel name contains <part> (one per training step, e.g. grad_accumulate)."""
 import csv, glob, os, sys
 from collections import defaultdict
-f = glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_trace.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)  # the newest: gpurun merges earlier runs into the same directory
 win = float(sys.argv[2]) * 1e6
 div = sys.argv[3] if len(sys.argv) > 3 else "1"
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in csv.DictReader(open(f))]
