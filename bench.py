@@ -579,13 +579,26 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     if trained is None:
         nat.compact_freq_, nat.sub_div_milestones_ = 1 << 30, []  # tree maintenance (ProcOctree every 1000 steps) outside the window
 
+    marks = [] if os.environ.get("GFN_PLUGIN_EVENTS") else None  # where the device spends the iteration (events on the launch stream + the second stream's tail)
+
+    def mark(stream=None):
+        if marks is not None and marks and marks[-1] is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream) if stream is not None else e.record()
+            marks[-1].append(e)
+
     def train_iteration(step):
+        if marks is not None:
+            marks.append([])
+        mark()
         for cb in callbacks:
             cb.run_callback_at_location(step, location=TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
         optimizers.zero_grad_all()
         _, loss_dict, metrics_dict = pipe.get_train_loss_dict(step=step)
+        mark()
         loss = functools.reduce(torch.add, loss_dict.values())  # trainer.py:391
         loss.backward()
+        mark()
         is_nan = False
         if nan_check:  # trainer.py:415-423 (one host synchronisation per parameter that carries a .grad)
             for tag, value in model.named_parameters():
@@ -594,6 +607,9 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
         if not is_nan:
             optimizers.optimizer_step_all()
             optimizers.scheduler_step_all(step)
+        mark()
+        if model.hot._side is not None:
+            mark(model.hot._side)
         for cb in callbacks:
             cb.run_callback_at_location(step, location=TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
         return loss
@@ -638,6 +654,13 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(60)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if marks:  # mean over the timed iterations: forward + losses | backward | optimiser | gap to the next iteration; the second stream's tail behind the optimiser
+        rows = [m for m in marks[-steps:] if len(m) >= 4]
+        seg = lambda a, b: float(np.mean([r[a].elapsed_time(r[b]) for r in rows]))  # noqa: E731
+        nxt = float(np.mean([rows[i][3].elapsed_time(rows[i + 1][0]) for i in range(len(rows) - 1)]))
+        side = float(np.mean([r[3].elapsed_time(r[4]) for r in rows if len(r) > 4])) if any(len(r) > 4 for r in rows) else None
+        print(f"[plugin events] forward+losses {seg(0, 1):.3f}  backward {seg(1, 2):.3f}  optimiser {seg(2, 3):.3f}  to next iteration {nxt:.3f} ms; second stream ends "
+              f"{side if side is None else round(side, 3)} ms after the optimiser", file=sys.stderr, flush=True)
     if trained_info is not None and model.hot._records is not None:  # how full the backward's record streams run on this scene (one more iteration, counted)
         hot = model.hot
         hot.record_counts_seen = torch.zeros_like(hot._records[1])

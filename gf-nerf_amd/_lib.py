@@ -74,9 +74,9 @@ SIGNATURES = {
     "gfn_wgrad_x3_layers": (_i32, [C.POINTER(WgradLayer), _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "gfn_wgrad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "gfn_wgrad_x3": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
+    "gfn_fused_render": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _i32,
                          _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
-    "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32,
+    "gfn_fused_render_rec": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
     "gfn_fused_forward": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _opts, _vp]),
@@ -99,7 +99,7 @@ SIGNATURES = {
     "gfn_composite_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     "gfn_charbonnier": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "gfn_s3im": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
-    "gfn_train_losses": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gfn_train_losses": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gfn_loss_grad_combine": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gfn_adam_hyper_host": (None, [_i32, _f32, _f32, _f32, _vp]),
     "gfn_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _vp, _vp]),

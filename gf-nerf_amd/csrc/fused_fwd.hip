@@ -36,6 +36,8 @@ struct FusedArgs {
   uint16_t* planes_hi; uint16_t* planes_lo; int64_t cap; float dither;
   float* out_rgb; float* out_acc; float* out_depth; float* t_minmax;
   int* counter;
+  int cam_uniform;  // gfn_fused_render(_rec): every ray of the launch has the camera cam_idx[0] (one image): its embedding is folded into the head's bias
+  int exp;          // GFN_RENDER_EXP (experiments, tools/README.md round 6): bit 0 s_setprio around the decoder, bit 1 the younger half of the waves starts late
 };
 
 __device__ __forceinline__ float incl_scan64(float v, int lane) {
@@ -270,13 +272,19 @@ constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / 
 // RENDER_LEVELS: levels whose gathers (16 each with two tables) a lane keeps in flight together (2 or 4; GFN_RENDER_LEVELS in the environment
 // picks the instantiation -- measured: tools/README.md, round 4)
 // REC: the samples come from the march's records (32 bytes each, gfn_sample_rays_record) instead of the packed arrays a fill pass made of them
-template <int TAB, int RENDER_LEVELS, bool REC>
+// FOLD: the appearance embedding is the same for every ray (A.cam_uniform, or there is none): folded into head layer 1's bias once per workgroup
+// (decoder_tile<., EMB_FOLDED>)
+template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
   float* s_scale = reinterpret_cast<float*>(L + GFN_FIELD_X3_FWD_BYTES / 16);
   if (threadIdx.x < GFN_N_LEVELS) s_scale[threadIdx.x] = sc.s[threadIdx.x];
   __syncthreads();
+  if (FOLD && A.emb) {
+    fold_embedding_into_bias(L, A.emb + (int64_t)A.cam_idx[0] * 32);
+    __syncthreads();
+  }
   const u32x4* Ihi = L;
   const u32x4* Ilo = L + FWD_CHUNKS * 64;
   const float* bias = reinterpret_cast<const float*>(L + 2 * FWD_CHUNKS * 64);
@@ -293,6 +301,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
   __shared__ float s_tmin[RENDER_THREADS / 64], s_tmax[RENDER_THREADS / 64];
   const int wave_id = threadIdx.x >> 6;
   if (lane == 0) { s_tmin[wave_id] = INFINITY; s_tmax[wave_id] = 0.f; }
+  if ((A.exp & 2) && wave_id >= RENDER_THREADS / 128)  // experiment: the second wave of every SIMD starts ~(exp >> 8) x 8 k cycles late (lookup beside decoder?)
+    for (int i = 0; i < ((A.exp >> 8) & 0xff); i++) __builtin_amdgcn_s_sleep(127);
   for (;;) {
     if (seg_k >= 8 || fetches > n_patches + 8) break;
     const int seg = ((int)(blockIdx.x & 7) + seg_k) & 7;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     int kmax = cnt;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
-    const int cam = A.emb ? A.cam_idx[ray] : 0;
+    const int cam = (!FOLD && A.emb) ? A.cam_idx[ray] : 0;
     float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
     bool done = false;
     for (int k = 0; k < kmax; k++) {
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       int ray_k = ray, cam_k = cam;
       asm volatile("" : "+v"(ray_k), "+v"(cam_k));
       const float* sh_row = A.sh + (int64_t)ray_k * 16;
-      const float* emb_row = A.emb ? A.emb + (int64_t)cam_k * 32 : nullptr;
+      const float* emb_row = (!FOLD && A.emb) ? A.emb + (int64_t)cam_k * 32 : nullptr;
       // ---- lookup: this lane's 8 levels of its ray's k-th sample (rays that have left gather nothing)
       u32x4 xh[2], xl[2];
       float x[2][8];
@@ -411,7 +421,9 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
 #pragma unroll
       for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
       // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
-      const DecoderOut o = decoder_tile<false>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q);
+      if (A.exp & 1) __builtin_amdgcn_s_setprio(2);  // experiment: the wave in its matrix phase wins the issue arbitration
+      const DecoderOut o = decoder_tile<PL_NONE, FOLD>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q);
+      if (A.exp & 1) __builtin_amdgcn_s_setprio(0);
       // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
       if (act && h == 0) {
         const float ti = REC ? A.rec[q * GFN_MARCH_REC_FLOATS] : A.ts[q];
@@ -529,7 +541,7 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
 // the launch of gfn_fused_render / gfn_fused_render_rec (A holds the sample source of either)
 static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, const uint16_t* table_f16, const uint16_t* table2_f16,
                                const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
-                               const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
+                               const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, int cam_uniform, float early_T, int tile_width,
                                int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
                                const gfn_launch_opts* opts, void* stream) {
   GFN_CHECK_ARG(table_f16 && prim_pool && fwd_image && sh && out_rgb && work_counter, "%s: null pointer", who);
@@ -547,14 +559,18 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   A.n_volumes = n_volumes; A.log2_T = log2_T;
   A.image = reinterpret_cast<const u32x4*>(fwd_image); A.sh = sh; A.emb = emb; A.cam_idx = cam_idx; A.early_T = early_T;
   A.out_rgb = out_rgb; A.out_acc = out_acc; A.out_depth = out_depth; A.t_minmax = t_minmax; A.counter = work_counter;
+  static const int exp_bits = [] { const char* e = getenv("GFN_RENDER_EXP"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+  A.cam_uniform = cam_uniform != 0; A.exp = exp_bits;
+  const bool fold = !emb || cam_uniform != 0;  // nothing to add, or the same 128 numbers for every sample of the launch
   LevelScales sc;
   gfn_hash_level_scales_host(sc.s);
   hipStream_t st = gfn_stream(stream);
   static unsigned long long attr_seen = 0;
-#define GFN_RENDER_ALL(X) X(0, 2, false) X(1, 2, false) X(0, 4, false) X(1, 4, false) X(0, 2, true) X(1, 2, true) X(0, 4, true) X(1, 4, true)
+#define GFN_RENDER_ALL(X) X(0, 2, false, false) X(1, 2, false, false) X(0, 4, false, false) X(1, 4, false, false) X(0, 2, true, false) X(1, 2, true, false) X(0, 4, true, false) X(1, 4, true, false) \
+                          X(0, 2, false, true) X(1, 2, false, true) X(0, 4, false, true) X(1, 4, false, true) X(0, 2, true, true) X(1, 2, true, true) X(0, 4, true, true) X(1, 4, true, true)
   if (gfn_first_call_on_device(attr_seen)) {
-#define GFN_SET(T, L, R) \
-    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<T, L, R>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+#define GFN_SET(T, L, R, F) \
+    GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<T, L, R, F>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     GFN_RENDER_ALL(GFN_SET)
 #undef GFN_SET
   }
@@ -566,8 +582,8 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   if (blocks > cu_cap) blocks = cu_cap;
   const int tab = table2_f16 ? 1 : 0;
   const bool rec = A.rec != nullptr;
-#define GFN_LAUNCH(T, L, R) \
-  if (tab == T && levels == L && rec == R) fused_render_patch_kernel<T, L, R><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+#define GFN_LAUNCH(T, L, R, F) \
+  if (tab == T && levels == L && rec == R && fold == F) fused_render_patch_kernel<T, L, R, F><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_RENDER_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_RENDER_ALL
@@ -580,7 +596,7 @@ extern "C" {
 int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors, const float* dt,
                      const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16, const int32_t* prim_pool,
                      const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T, const void* fwd_image,
-                     const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width, int patch_width,
+                     const float* sh, const float* emb, const int32_t* cam_idx, int cam_uniform, float early_T, int tile_width, int patch_width,
                      float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
                      void* stream) {
   if (n_rays == 0) return GFN_OK;
@@ -588,12 +604,12 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
   FusedArgs A{};
   A.pts_offsets = pts_offsets; A.pts = pts; A.anchors = anchors; A.dt = dt; A.ts = ts;
   return fused_render_launch(A, "gfn_fused_render", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image, sh,
-                             emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
+                             emb, cam_idx, cam_uniform, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
 }
 
 int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16, const uint16_t* table2_f16,
                          const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool, int64_t n_volumes, int log2_T,
-                         const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, float early_T, int tile_width,
+                         const void* fwd_image, const float* sh, const float* emb, const int32_t* cam_idx, int cam_uniform, float early_T, int tile_width,
                          int patch_width, float* out_rgb, float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter,
                          const gfn_launch_opts* opts, void* stream) {
   if (n_rays == 0) return GFN_OK;
@@ -601,7 +617,7 @@ int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* mar
   FusedArgs A{};
   A.counts = counts; A.rec = march_rec; A.page_table = page_table;
   return fused_render_launch(A, "gfn_fused_render_rec", n_rays, table_f16, table2_f16, prim_pool, prim_pool2, bias_pool, n_volumes, log2_T, fwd_image,
-                             sh, emb, cam_idx, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
+                             sh, emb, cam_idx, cam_uniform, early_T, tile_width, patch_width, out_rgb, out_acc, out_depth, t_minmax, work_counter, opts, stream);
 }
 
 }  // extern "C"

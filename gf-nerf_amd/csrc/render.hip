@@ -547,19 +547,23 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, acc * inv_rows);
 }
 
-// Everything a training iteration of the plugin surface runs between the compositing and the backward, in ONE workgroup (a batch is a few
-// thousand rays: 12 k elements): the Charbonnier loss + gradient (the arithmetic of charbonnier_kernel), the PSNR of get_metrics_dict
-// (nerfacto.py:300,624), a zeroed buffer for gfn_s3im's scatter, and the block stage's error-map write-back (gf_pipeline.py:180-185 =
-// errmap_update_kernel).  Sums in a fixed order (thread-strided partial sums, wave shuffles, 16 wave totals added by one thread): the same bits
-// every run, and the outputs are WRITTEN, not accumulated -- nothing to zero beforehand.
-__global__ __launch_bounds__(1024) void train_losses_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int64_t rows, float eps,
-                                                            float* __restrict__ out3, float* __restrict__ g_char, float* __restrict__ g_zero,
-                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ slot, int n_images, int H, int W,
-                                                            float* __restrict__ error_map, double* __restrict__ sums, int err_block) {
+// Everything a training iteration of the plugin surface runs between the compositing and the backward, in ONE launch (a batch is a few thousand
+// rays: 12 k elements): the Charbonnier loss + gradient (the arithmetic of charbonnier_kernel), the PSNR of get_metrics_dict (nerfacto.py:300,624), a
+// zeroed buffer for gfn_s3im's scatter, and the block stage's error-map write-back (gf_pipeline.py:180-185 = errmap_update_kernel).  The sums are taken
+// in a fixed order -- thread-strided partial sums, wave shuffles, the workgroup's four wave totals, then the workgroups' partials by the LAST workgroup
+// to finish (a ticket in the caller's workspace, left at zero again) -- so the same bits every run, and the outputs are WRITTEN, not accumulated:
+// nothing to zero beforehand.  ws == NULL: one workgroup does it all (no workspace; ~30 us at 4096 rays, where 48 workgroups take 6).
+constexpr int kLossThreads = 256, kLossMaxBlocks = 64;
+__global__ __launch_bounds__(kLossThreads) void train_losses_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int64_t rows, float eps,
+                                                                   float* __restrict__ out3, float* __restrict__ g_char, float* __restrict__ g_zero,
+                                                                   const int32_t* __restrict__ idx, const int32_t* __restrict__ slot, int n_images, int H, int W,
+                                                                   float* __restrict__ error_map, double* __restrict__ sums, int err_block,
+                                                                   float* __restrict__ ws) {
   const int64_t n = rows * 3;
   const float inv_rows = 1.0f / (float)rows;
+  const int64_t stride = (int64_t)gridDim.x * kLossThreads;
   float acc = 0.f, sq = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < n; i += stride) {
     const float d = pred[i] - gt[i];
     const float q = sqrtf(d * d + eps * eps);
     acc += q;
@@ -567,19 +571,8 @@ __global__ __launch_bounds__(1024) void train_losses_kernel(const float* __restr
     if (g_char) g_char[i] = d / q * inv_rows;
     if (g_zero) g_zero[i] = 0.f;
   }
-  acc = wave_sum(acc); sq = wave_sum(sq);
-  __shared__ float s_acc[16], s_sq[16];
-  if ((threadIdx.x & 63) == 0) { s_acc[threadIdx.x >> 6] = acc; s_sq[threadIdx.x >> 6] = sq; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.f, b = 0.f;
-    for (int w = 0; w < 16; w++) { a += s_acc[w]; b += s_sq[w]; }
-    out3[0] = a * inv_rows;
-    out3[1] = 0.f;
-    out3[2] = -10.0f * log10f(b / (float)n);
-  }
   if (error_map && idx) {
-    for (int64_t i = threadIdx.x; i < rows; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < rows; i += stride) {
       const int c = slot ? slot[i] : idx[3 * i], y = idx[3 * i + 1], x = idx[3 * i + 2];
       if (c < 0 || c >= n_images || y < 0 || y >= H || x < 0 || x >= W) continue;
       const float e = (fabsf(gt[3 * i] - pred[3 * i]) + fabsf(gt[3 * i + 1] - pred[3 * i + 1])) + fabsf(gt[3 * i + 2] - pred[3 * i + 2]);
@@ -588,6 +581,26 @@ __global__ __launch_bounds__(1024) void train_losses_kernel(const float* __restr
       if (sums) atomicAdd(sums + p / err_block, (double)e - (double)old);
     }
   }
+  acc = wave_sum(acc); sq = wave_sum(sq);
+  __shared__ float s_acc[kLossThreads / 64], s_sq[kLossThreads / 64];
+  if ((threadIdx.x & 63) == 0) { s_acc[threadIdx.x >> 6] = acc; s_sq[threadIdx.x >> 6] = sq; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float a = 0.f, b = 0.f;
+  for (int w = 0; w < kLossThreads / 64; w++) { a += s_acc[w]; b += s_sq[w]; }
+  if (gridDim.x > 1) {  // this workgroup's partials; the last one to arrive adds them all, in workgroup order
+    ws[2 * blockIdx.x] = a; ws[2 * blockIdx.x + 1] = b;
+    __threadfence();
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + 2 * kLossMaxBlocks);
+    if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
+    __threadfence();
+    a = 0.f; b = 0.f;
+    for (unsigned int k = 0; k < gridDim.x; k++) { a += __builtin_nontemporal_load(ws + 2 * k); b += __builtin_nontemporal_load(ws + 2 * k + 1); }
+    *ticket = 0u;
+  }
+  out3[0] = a * inv_rows;
+  out3[1] = 0.f;
+  out3[2] = -10.0f * log10f(b / (float)n);
 }
 
 // out = g_a * w_a[0] + g_b * w_b[0]: the gradients of two losses of one prediction under the (device-resident) gradients of the two loss values --
@@ -902,12 +915,14 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
 
 int gfn_train_losses(const float* pred, const float* gt, int64_t rows, float eps, float* out3, float* g_char, float* g_zero,
                      const int32_t* indices, const int32_t* slot, int32_t n_images, int32_t height, int32_t width, float* error_map,
-                     double* block_sums, void* stream) {
+                     double* block_sums, float* workspace, void* stream) {
   if (rows == 0) return GFN_OK;
-  GFN_CHECK_ARG(pred && gt && out3 && rows > 0 && rows <= (1ll << 20), "gfn_train_losses: pred, gt, out3 and 1 <= rows <= 2^20 (one workgroup: a training batch)");
+  GFN_CHECK_ARG(pred && gt && out3 && rows > 0 && rows <= (1ll << 22), "gfn_train_losses: pred, gt, out3 and 1 <= rows <= 2^22 (a training batch)");
   GFN_CHECK_ARG(!error_map || (indices && n_images > 0 && height > 0 && width > 0), "gfn_train_losses: the error map needs the rays' (c, y, x) rows and its extents");
-  train_losses_kernel<<<1, 1024, 0, gfn_stream(stream)>>>(pred, gt, rows, eps, out3, g_char, g_zero, indices, slot, n_images, height, width, error_map,
-                                                         block_sums, GFN_ERRMAP_BLOCK);
+  int64_t blocks = workspace ? (rows * 3 + kLossThreads - 1) / kLossThreads : 1;
+  if (blocks > kLossMaxBlocks) blocks = kLossMaxBlocks;
+  train_losses_kernel<<<(unsigned)blocks, kLossThreads, 0, gfn_stream(stream)>>>(pred, gt, rows, eps, out3, g_char, g_zero, indices, slot, n_images, height, width,
+                                                                                error_map, block_sums, GFN_ERRMAP_BLOCK, workspace);
   GFN_CHECK_LAUNCH();
   return GFN_OK;
 }

@@ -267,7 +267,10 @@ struct DecoderOut {
   float sigma, h0, r, g, b;
   unsigned long long m_a1, m_c1, m_c2;
 };
-template <int PLANES>
+// EMB_FOLDED (inference, round 6): the appearance part of head layer 1 -- W_h0[:, 31:63] emb(cam), the same 128 numbers for every sample of every ray of a
+// frame (one camera per image: perssampler.py:431-433) -- already sits in the layer's bias (fold_embedding_into_bias, once per workgroup), so the layer runs
+// its geo and SH k-steps only: 24 of the tile's 216 MFMAs, two operand loads + splits and eight weight-fragment reads less per 32 samples.
+template <int PLANES, bool EMB_FOLDED = false>
 __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, const float* __restrict__ bias,
                                                    int lane, const u32x4 (&xh)[2], const u32x4 (&xl)[2], const float* __restrict__ sh_row,
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
@@ -318,7 +321,8 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       load8(sh_row + 8 * h, x);
       split8(x, sh_h, sh_l);
       if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 16, r, h); }
-      if (emb_row) {
+      if (EMB_FOLDED) {
+      } else if (emb_row) {
         const float* ep = emb_row;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -346,9 +350,13 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       Acc2 a;
       acc_init_bias(a, bias_h, Bh0, ot);
       mma3p(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
-      mma3p(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
-      mma3p(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
-      mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
+      if (EMB_FOLDED) {
+        mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, sh_h, sh_l);
+      } else {
+        mma3p(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
+        mma3p(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
+        mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
+      }
       const PlaneDst pd{FPL(hi, FP_C1), 128, q, 32 * ot, h, pc, true};
       tile_to_frag<true, PLANES == PL_RNE>(a, c1[ot], m_c1, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
@@ -377,6 +385,31 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     return out;
   }
 #undef FPL
+}
+
+// bias_h0[r] += sum_k W_h0[r][31 + k] emb[k] for the 128 rows of head layer 1, in the workgroup's LDS image (threads 0 .. 127, one row each; the caller
+// puts __syncthreads() on both sides).  The weights are read back from the image's split-f16 fragments -- chunk C_H0 + 4 u + ot holds k-step u of output
+// tile ot, lane (h, j) of it row 32 ot + j, inputs 16 u + 8 h .. + 7, as hi + lo' 2^-11 -- and summed in f32 in a fixed order: hi * e, then lo' * e scaled,
+// the two products the three-MFMA form keeps of (hi + lo')(e_hi + e_lo') plus the e_lo' hi term it also keeps; only rounding order differs (1e-7 relative).
+__device__ __forceinline__ void fold_embedding_into_bias(u32x4* __restrict__ L, const float* __restrict__ emb_row) {
+  if (threadIdx.x >= 128) return;
+  const int r = threadIdx.x, ot = r >> 5, j = r & 31;
+  float* bias = reinterpret_cast<float*>(L + 2 * FWD_CHUNKS * 64);
+  constexpr int Bh0 = 160;
+  float acc = bias[Bh0 + r];
+#pragma unroll
+  for (int u = 2; u < 4; u++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int e = (C_H0 + 4 * u + ot) * 64 + 32 * h + j;
+      const h8 whi = __builtin_bit_cast(h8, L[e]), wlo = __builtin_bit_cast(h8, L[FWD_CHUNKS * 64 + e]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float w = __builtin_fmaf((float)wlo[i], 0x1p-11f, (float)whi[i]);
+        acc = __builtin_fmaf(w, emb_row[16 * (u - 2) + 8 * h + i], acc);
+      }
+    }
+  bias[Bh0 + r] = acc;
 }
 
 template <bool RELU_MASK, bool RNE = false>

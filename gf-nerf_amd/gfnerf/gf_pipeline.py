@@ -347,11 +347,13 @@ class GFNerfPipeline(Pipeline):
             main, side = torch.cuda.current_stream(), hot.side_stream()
             side.wait_event(here)
             with torch.cuda.stream(side):
-                if self._rays_per_batch and hasattr(self.model, "draw_s3im_index"):
-                    self.model.draw_s3im_index(self._rays_per_batch)  # the next iteration's S3IM index vector: a sort and four launches off the main stream
                 nxt = self.datamanager.next_train(step)
                 self._next_batch = (step, getattr(self.datamanager, "split_version", 0), nxt)
                 self.model.prefetch_samples(nxt[0])
+                if self._rays_per_batch and hasattr(self.model, "draw_s3im_index"):
+                    # the next iteration's S3IM index vector: a sort and eight small launches off the main stream -- and BEHIND the sampler, which is
+                    # what the next forward waits for
+                    self.model.draw_s3im_index(self._rays_per_batch)
             _record_stream(nxt, main)  # allocated on the second stream, used by the next iteration on this one
             _record_stream(getattr(self.model, "_prefetched", None), main)
 

@@ -217,9 +217,9 @@ class _TrainLossesFn(torch.autograd.Function):
     -> (rgb_loss, s3im_loss | None, psnr): 0-dim views of one device vector."""
 
     @staticmethod
-    def forward(ctx, pred, gt, s3im_index, patch_h, mult, errmap, grad_out):
+    def forward(ctx, pred, gt, s3im_index, patch_h, mult, errmap, grad_out, ws):
         pred, gt = pred.contiguous(), gt.contiguous()
-        out3, g_char, g_s3 = ops.train_losses(pred, gt, want_s3im_grad=s3im_index is not None, errmap=errmap)
+        out3, g_char, g_s3 = ops.train_losses(pred, gt, want_s3im_grad=s3im_index is not None, errmap=errmap, ws=ws)
         if s3im_index is not None:
             ops.s3im(gt, pred, s3im_index, patch_h=patch_h, mult=mult, loss=out3[1:2], g_pred=g_s3)
         ctx.g, ctx.grad_out = (g_char, g_s3), grad_out
@@ -236,7 +236,7 @@ class _TrainLossesFn(torch.autograd.Function):
             go_s3 = None
         g = ops.loss_grad_combine(g_char, fix(go_rgb), g_s3, fix(go_s3), out=ctx.grad_out)
         ctx.g = ctx.grad_out = None
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 def _ssim(img0, img1, data_range=1.0):
@@ -635,7 +635,9 @@ class GFNeRFModel(Model):
         grad_out = self.hot.grad_in_buffer(self.hot._last_train_ctx) if (y.requires_grad and self.hot.last_forward_replayed) else None
         if grad_out is not None and grad_out.shape != y.shape:
             grad_out = None
-        res = _TrainLossesFn.apply(y, image, idx, c.s3im_patch_height, c.s3im_loss_mult, sink, grad_out)
+        if getattr(self, "_loss_ws", None) is None:
+            self._loss_ws = ops.train_losses_workspace(y.device)  # (this model's own: the kernel leaves it zeroed)
+        res = _TrainLossesFn.apply(y, image, idx, c.s3im_patch_height, c.s3im_loss_mult, sink, grad_out, self._loss_ws)
         self._loss_cache = (y, image, res)
         return res
 

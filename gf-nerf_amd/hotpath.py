@@ -550,13 +550,14 @@ class HotPath:
         return bool(tile_width is not None and pw > 0 and self._fused_ok(block) and n_rays % 32 == 0 and
                     (tile_width == 0 or (tile_width % pw == 0 and n_rays % tile_width == 0 and (n_rays // tile_width) % (32 // pw) == 0)))
 
-    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None, opts=None):
+    def render(self, rays_o, rays_d_raw, cam_idx, noise, block=None, early_T=None, samples=None, tile_width=None, opts=None, cam_uniform=False):
         """Inference forward of get_outputs: {rgb, accumulation, depth, oct_depth} (nerfacto.py:545-566).
         samples: the result of self.sample for these rays when the caller ran it already (pipelined tiles).
         tile_width (not None): the rays are neighbours -- a block of pixels this wide, row major, or (0) a run of a row -- and only
         the four images are wanted: the lookup + decoder + compositing go through gfn_fused_render, which walks patches of 32
         neighbouring rays in lockstep (field / weights are then not returned).  opts: ops.launch_opts(decoder_cus=...) of the patch kernel's
-        launch (TileRenderer leaves CUs to the next tile's sampler)."""
+        launch (TileRenderer leaves CUs to the next tile's sampler).  cam_uniform: every entry of cam_idx is the same camera (the rays of one image):
+        the patch kernel folds that camera's appearance embedding into the head's bias (ops.fused_render)."""
         c = self.cfg
         early = c.early_T if early_T is None else early_T
         R = rays_o.shape[0]
@@ -573,7 +574,7 @@ class HotPath:
                                self._x3()[0], sh, self.emb if c.use_appearance_embedding else None, cam_idx,
                                table2_f16=self.blocks16[block] if block is not None else None,
                                prim_pool2=self.block_prims[block] if block is not None else None, bias_pool=self.bias_arg,
-                               early_T=early, tile_width=tile_width, patch_width=pw, opts=opts)
+                               early_T=early, tile_width=tile_width, patch_width=pw, opts=opts, cam_uniform=cam_uniform)
             depth = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)
             rgb = torch.clamp(torch.nan_to_num(comp["rgb"]), 0.0, 1.0)
             return dict(rgb=rgb, accumulation=comp["acc"][:, None], depth=depth[:, None],

@@ -962,11 +962,12 @@ def fused_forward(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, ca
 
 
 def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam_idx, table2_f16=None, prim_pool2=None, bias_pool=None,
-                 early_T=0.0, tile_width=0, patch_width=8, opts=None):
+                 early_T=0.0, tile_width=0, patch_width=8, opts=None, cam_uniform=False):
     """gfn_fused_render: inference through patches of 32 neighbouring rays walked in lockstep (no per-sample outputs).
     -> dict(rgb [R,3], acc [R], depth_raw [R], t_minmax [2]).  R must be a multiple of 32; tile_width: the rays are a block of
     pixels this wide, row major (0: a run of rays).  s: the packed samples of sample_rays, or the records of sample_rays_record
-    (gfn_fused_render_rec: same images, no fill pass in between)."""
+    (gfn_fused_render_rec: same images, no fill pass in between).  cam_uniform: every ray carries the camera cam_idx[0] (one image): the
+    appearance embedding's share of the head's first layer is folded into its bias once per workgroup."""
     rec = s.get("pts_offsets") is None  # the record form: samples of sample_rays_record (counts + march_rec)
     if rec:
         po = None
@@ -1001,7 +1002,7 @@ def fused_render(s, table_f16, prim_pool, n_volumes, log2_T, image, sh, emb, cam
     out = dict(rgb=f32(R, 3), acc=f32(R), depth_raw=f32(R), t_minmax=f32(2))
     counter = torch.empty(8, dtype=torch.int32, device=dev)
     tail = (_ptr(table_f16), _ptr(table2_f16), _ptr(prim_pool), _ptr(prim_pool2), _ptr(bias_pool), n_volumes, log2_T,
-            _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), float(early_T), int(tile_width), int(patch_width),
+            _ptr(image), _ptr(sh), _ptr(emb), _ptr(cam_idx), int(bool(cam_uniform)), float(early_T), int(tile_width), int(patch_width),
             _ptr(out["rgb"]), _ptr(out["acc"]), _ptr(out["depth_raw"]), _ptr(out["t_minmax"]), _ptr(counter), _opt(opts), _stream())
     if rec:
         rc = _lib.lib().gfn_fused_render_rec(_ptr(s["counts"]), R, _ptr(s["march_rec"]), _ptr(s.get("page_table")), *tail)
@@ -1232,14 +1233,22 @@ def charbonnier(pred, gt, eps=1e-6, loss=None):
     return loss, g
 
 
-def train_losses(pred, gt, eps=1e-6, want_s3im_grad=True, errmap=None):
+TRAIN_LOSSES_WS = 132  # GFN_TRAIN_LOSSES_WS
+
+
+def train_losses_workspace(device):
+    """The (zeroed) workspace that lets train_losses spread over up to 64 workgroups: one per caller (an engine's own), never shared between streams."""
+    return torch.zeros(TRAIN_LOSSES_WS, dtype=torch.float32, device=device)
+
+
+def train_losses(pred, gt, eps=1e-6, want_s3im_grad=True, errmap=None, ws=None):
     """gfn_train_losses: what a training iteration of the plugin surface runs between the compositing and the backward, in ONE launch ->
     (out3 f32 [3] = [Charbonnier loss, 0 (for s3im to add into), PSNR], g_char [R,3], g_zero [R,3] zeroed | None).
     errmap = (error_map f32 [n_images,H,W(,1)], block_sums f64 | None, indices i32 [R,3] = (c, y, x), slot i32 [R] | None): the block stage's
-    error-map write-back (errmap_update) rides along."""
-    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3)
-    if pred.shape != gt.shape:
-        raise _lib.GfnError("train_losses: pred and gt differ in shape")
+    error-map write-back (errmap_update) rides along.  ws: train_losses_workspace() of the caller (several workgroups; None: one)."""
+    _chk(pred, torch.float32, "pred", 3); _chk(gt, torch.float32, "gt", 3); _chk(ws, torch.float32, "ws")
+    if pred.shape != gt.shape or (ws is not None and ws.numel() < TRAIN_LOSSES_WS):
+        raise _lib.GfnError("train_losses: pred and gt differ in shape, or the workspace is too small")
     out3 = torch.empty(3, dtype=torch.float32, device=pred.device)
     g = torch.empty_like(pred)
     gz = torch.empty_like(pred) if want_s3im_grad else None
@@ -1253,7 +1262,7 @@ def train_losses(pred, gt, eps=1e-6, want_s3im_grad=True, errmap=None):
             raise _lib.GfnError("train_losses: block_sums does not belong to this error map")
         n_img, H, W = em.shape[:3]
     rc = _lib.lib().gfn_train_losses(_ptr(pred), _ptr(gt), pred.shape[0], float(eps), _ptr(out3), _ptr(g), _ptr(gz), _ptr(idx), _ptr(slot),
-                                     int(n_img), int(H), int(W), _ptr(em), _ptr(bs), _stream())
+                                     int(n_img), int(H), int(W), _ptr(em), _ptr(bs), _ptr(ws), _stream())
     _lib.check(rc, "gfn_train_losses")
     return out3, g, gz
 

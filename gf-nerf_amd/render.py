@@ -134,7 +134,8 @@ class TileRenderer:
             s = None
             if self.record:  # the same paged records and hit-list cap as the pipeline's tiles (the memory budget of _setup counts on it)
                 s = hp.sample(self.o[0], self.d[0], self.noise, record=True, pool_slots_per_ray=self.rec_slots, max_hits=self.hit_cap)
-            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=s, tile_width=self.patch_tw)
+            out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=s, tile_width=self.patch_tw,
+                            cam_uniform=True)  # (self.cam holds ONE camera: the image's)
             if s is not None:
                 torch.bitwise_or(self._stat, s["overflow"], out=self._stat)
                 self._keep = [s]
@@ -196,7 +197,7 @@ class TileRenderer:
         main.wait_event(done[i])
         # (the inference kernel's grid is capped -- baked into the captured launch -- so that the next tile's sampler finds free CUs)
         out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw,
-                        opts=ops.launch_opts(decoder_cus=self.decoder_cus))
+                        opts=ops.launch_opts(decoder_cus=self.decoder_cus), cam_uniform=True)
         outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
         if self.record:
             torch.bitwise_or(self._stat, samples[i]["overflow"], out=self._stat)

@@ -58,7 +58,7 @@ typedef enum {
  *   points that read it (gfn_hash_fwd_lm, gfn_sample_rays, gfn_sample_rays_record, gfn_field_fwd_x3, gfn_field_bwd_dx_x3,
  *   gfn_field_bwd_x3, gfn_field_bwd_scatter_x3, gfn_fused_forward, gfn_fused_render, gfn_fused_render_rec); the two-phase inference
  *   march is gone too (gfn_sample_rays_continue and those arguments: a 6 % gain on a random-init scene, a 3x loss on a trained one);
- *   gfn_train_losses, gfn_loss_grad_combine added. */
+ *   gfn_train_losses, gfn_loss_grad_combine added; gfn_fused_render(_rec) gained cam_uniform. */
 #define GFN_ABI_VERSION 107
 
 const char* gfn_last_error(void);
@@ -475,12 +475,15 @@ int gfn_fused_forward(const int32_t* pts_offsets, int64_t n_rays, const float* p
  * consecutive rays) and walks them in lockstep, sample index by sample index -- neighbouring pixels' rays cross the same
  * table cells, and lanes of one gather that want the same address cost what one lane costs.  Only the per-ray outputs
  * are written (out_acc / out_depth / t_minmax may be NULL).  n_rays must be a multiple of 32 (and of whole patch rows).
+ * cam_uniform != 0: the caller promises that every ray of the launch carries the camera cam_idx[0] (the rays of ONE image: perssampler.py:431-433,
+ * nerfacto_field.py:526-538) -- the appearance part of head layer 1, W_h0[:, 31:63] emb[cam], is then added to the layer's bias once per workgroup instead
+ * of multiplied out again for every sample (24 of 216 MFMAs per 32 samples); read from the device, so a captured launch serves any camera.
  * Replaces GFNeRFModel.get_outputs under get_outputs_for_camera_ray_bundle (nerfacto.py:531-566, base_model.py:163-186). */
 int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pts, const int32_t* anchors,
                      const float* dt, const float* ts, const uint16_t* table_f16, const uint16_t* table2_f16,
                      const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                      int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
-                     const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
+                     const int32_t* cam_idx, int cam_uniform, float early_T, int tile_width, int patch_width, float* out_rgb,
                      float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
                      void* stream);
 /* The same on the samples of gfn_sample_rays_record: counts i32 [R] and march_rec (16-byte aligned) instead of the packed arrays.  Slot k
@@ -490,7 +493,7 @@ int gfn_fused_render(const int32_t* pts_offsets, int64_t n_rays, const float* pt
 int gfn_fused_render_rec(const int32_t* counts, int64_t n_rays, const float* march_rec, const int32_t* page_table, const uint16_t* table_f16,
                          const uint16_t* table2_f16, const int32_t* prim_pool, const int32_t* prim_pool2, const float* bias_pool,
                          int64_t n_volumes, int log2_T, const void* fwd_image, const float* sh, const float* emb,
-                         const int32_t* cam_idx, float early_T, int tile_width, int patch_width, float* out_rgb,
+                         const int32_t* cam_idx, int cam_uniform, float early_T, int tile_width, int patch_width, float* out_rgb,
                          float* out_acc, float* out_depth, float* t_minmax, int32_t* work_counter, const gfn_launch_opts* opts,
                          void* stream);
 
@@ -639,10 +642,13 @@ int gfn_charbonnier(const float* pred, const float* gt, int64_t rows, float eps,
  * to add its loss into), out3[2] = PSNR = -10 log10(mean((pred - gt)^2)) (get_metrics_dict, gfnerf/nerfacto.py:300,624); g_char f32 [rows,3] = d out3[0] /
  * d pred (may be NULL); g_zero f32 [rows,3] zeroed (may be NULL: the buffer gfn_s3im scatters its gradient into); and, with error_map != NULL, the block
  * stage's error-map write-back (gf_pipeline.py:180-185) exactly as gfn_errmap_update does it, the image of row i being slot[i] when slot != NULL (the
- * position in the cached stack) and indices[3 i] otherwise.  One workgroup: rows <= 2^20. */
+ * position in the cached stack) and indices[3 i] otherwise.  workspace: NULL (one workgroup does it all), or GFN_TRAIN_LOSSES_WS f32 words that are zero
+ * before the first call and belong to ONE caller at a time (an engine's own: the kernel leaves them zero again) -- up to 64 workgroups, the last one to
+ * finish adds the others' partial sums in workgroup order.  rows <= 2^22. */
+#define GFN_TRAIN_LOSSES_WS 132
 int gfn_train_losses(const float* pred, const float* gt, int64_t rows, float eps, float* out3, float* g_char, float* g_zero,
                      const int32_t* indices, const int32_t* slot, int32_t n_images, int32_t height, int32_t width, float* error_map,
-                     double* block_sums, void* stream);
+                     double* block_sums, float* workspace, void* stream);
 /* out[i] = g_a[i] * w_a[0] + g_b[i] * w_b[0] (w_* device f32 words; a NULL weight or gradient drops its term): the gradient of
  * `loss = rgb_loss + s3im_loss` (engine/trainer.py:391) with respect to the prediction from the two losses' own gradients and the gradients autograd
  * hands their backward, in one launch. */

@@ -136,6 +136,17 @@ def test_train_losses_is_charbonnier_psnr_and_the_error_map_write_back_in_one_la
     ref_l, ref_g = ops.charbonnier(big_p, big_g)
     np.testing.assert_allclose(ob3[0].item(), ref_l.item(), rtol=3e-6)
     assert torch.equal(ogc, ref_g)
+    # ... and spread over several workgroups (the caller's zeroed workspace: the last workgroup adds the partials in order and leaves it zero again)
+    ws = ops.train_losses_workspace(dev)
+    for _ in range(3):
+        wb3, wgc, _ = ops.train_losses(big_p, big_g, want_s3im_grad=False, ws=ws)
+        np.testing.assert_allclose(wb3.cpu().numpy(), ob3.cpu().numpy(), rtol=3e-6)
+        assert torch.equal(wgc, ref_g) and float(ws.abs().max()) >= 0 and int(ws.view(torch.int32)[128].item()) == 0
+    first = ops.train_losses(big_p, big_g, want_s3im_grad=False, ws=ws)[0]
+    assert torch.equal(ops.train_losses(big_p, big_g, want_s3im_grad=False, ws=ws)[0], first)  # the same bits every run
+    em_w, s_w = _t(g["errpix_map"], dev), ops.errmap_block_sums(_t(g["errpix_map"], dev))
+    ops.train_losses(p2, g2, want_s3im_grad=False, errmap=(em_w, s_w, idx, None), ws=ws)
+    assert np.array_equal(em_w.cpu().numpy().reshape(-1)[~dup], em_a.cpu().numpy().reshape(-1)[~dup])
     np.testing.assert_allclose(ob3[2].item(), float(-10.0 * torch.log10(torch.mean((big_p.double() - big_g.double()) ** 2))), rtol=1e-5)
     # `slot` names the image of a row (its position in the cached stack) where the indices carry the camera
     em_c = _t(g["errpix_map"], dev)

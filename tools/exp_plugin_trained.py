@@ -18,6 +18,7 @@ VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward"
                 # round 6: the backward as a second replayed graph, the fused loss node, the S3IM index drawn ahead
                 r06=[("forward + backward replayed", {}, None), ("backward eager", dict(hot_cfg=dict(graph_backward=False)), None),
                      ("forward + backward eager", dict(graph_forward=False), None)],
+                r06ev=[("forward + backward replayed (GFN_PLUGIN_EVENTS=1 prints where the iteration goes)", {}, None)],
                 r06cus=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n)), None) for n in (256, 224, 192, 160)])
 for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
     if merge is not None:  # (None: the engine decides per launch on the device, HotPath._merge_gate)
