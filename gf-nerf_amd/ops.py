@@ -1406,7 +1406,7 @@ def copy_list(pairs):
 _SIDE_STREAMS = {}  # (device index, role) -> the probed stream of that role
 
 
-def concurrent_stream(device=None, role=None):
+def concurrent_stream(device=None, role=None, priority=0):
     """A stream that demonstrably runs BESIDE the current one.  role (a name: "sampler", "aux", "adam", "comm", "draws" ...): ONE stream per
     device and role for the whole process, probed once and handed out again afterwards -- torch takes its streams from a round-robin pool of 32 per
     device, so engines that each made their own would soon be handed streams already in use by another role (safe, but the overlap the probe is for
@@ -1415,7 +1415,9 @@ def concurrent_stream(device=None, role=None):
     process made before (round 4: the plugin surface's focal iteration took 1.81 or 1.55 ms depending on whether bench.py had rendered first; with
     this probe 1.55 either way).  Up to 8 candidates, each probed once: a ~2.5 ms spin on the current stream, a tiny kernel on the candidate -- does
     the candidate's event complete while the spin still runs?  ~20 ms once per stream made; a plain stream under capture (graph branches are not
-    queues) or with GFN_SIDE_STREAM_PROBE=0."""
+    queues) or with GFN_SIDE_STREAM_PROBE=0.  priority: 0, or -1 for a HIGH-priority stream -- its workgroups are dispatched first whenever the chip has
+    room for one (the next batch's sampler beside a backward that fills every CU: its scan and fill otherwise wait until the accumulation AND Adam
+    behind the backward have drained, and the next forward waits for them: round 6, 0.22 ms of a 2.13 ms plugin iteration)."""
     import os
     import time
 
@@ -1423,14 +1425,15 @@ def concurrent_stream(device=None, role=None):
     key = (device.index if device.index is not None else torch.cuda.current_device(), role)
     if role is not None and key in _SIDE_STREAMS:
         return _SIDE_STREAMS[key]
+    priority = int(os.environ.get("GFN_SIDE_STREAM_PRIORITY", priority))
     if os.environ.get("GFN_SIDE_STREAM_PROBE", "1") != "1" or torch.cuda.is_current_stream_capturing():
-        return torch.cuda.Stream(device=device)  # (not remembered: made without a probe)
+        return torch.cuda.Stream(device=device, priority=priority)  # (not remembered: made without a probe)
     main = torch.cuda.current_stream(device)
     taken = {s.cuda_stream for (d, _), s in _SIDE_STREAMS.items() if d == key[0]} | {main.cuda_stream}
     probe = torch.zeros(64, dtype=torch.float32, device=device)
     kept = []  # (candidates that share the queue stay allocated until one is found: a fresh one would land on the same queue again)
     for _ in range(8):
-        cand = torch.cuda.Stream(device=device)
+        cand = torch.cuda.Stream(device=device, priority=priority)
         kept.append(cand)
         if cand.cuda_stream in taken:  # the pool has wrapped onto a stream in use
             continue
