@@ -333,6 +333,13 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     const int cam = (!FOLD && A.emb) ? A.cam_idx[ray] : 0;
     float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
     bool done = false;
+    // a lane's ray is fixed for the whole walk: its 8 SH values are split once (with the embedding folded away the registers are there)
+    u32x4 sh_split[2];
+    if (FOLD) {
+      float x[8];
+      load8(A.sh + (int64_t)ray * 16 + 8 * h, x);
+      split8(x, sh_split[0], sh_split[1]);
+    }
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
       if (__ballot(act) == 0ull) break;  // every ray of the patch has ended or become opaque
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
       // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
       if (A.exp & 1) __builtin_amdgcn_s_setprio(2);  // experiment: the wave in its matrix phase wins the issue arbitration
-      const DecoderOut o = decoder_tile<PL_NONE, FOLD>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q);
+      const DecoderOut o = decoder_tile<PL_NONE, FOLD>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, FOLD ? sh_split : nullptr);
       if (A.exp & 1) __builtin_amdgcn_s_setprio(0);
       // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
       if (act && h == 0) {

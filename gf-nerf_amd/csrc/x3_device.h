@@ -274,7 +274,8 @@ template <int PLANES, bool EMB_FOLDED = false>
 __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, const float* __restrict__ bias,
                                                    int lane, const u32x4 (&xh)[2], const u32x4 (&xl)[2], const float* __restrict__ sh_row,
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
-                                                   uint16_t* __restrict__ planes_lo, int64_t cap, int64_t q, float pc = 1.f) {
+                                                   uint16_t* __restrict__ planes_lo, int64_t cap, int64_t q, float pc = 1.f,
+                                                   const u32x4* __restrict__ sh_split = nullptr /* {hi, lo'} of this lane's 8 SH values, made by the caller once per ray */) {
   const int h = lane >> 5;
   const float* bias_h = bias + 4 * h;
   constexpr int Bb0 = 0, Bb1 = 128, Bh0 = 160, Bh1 = 288, Bh2 = 416;  // offsets of the five layers' biases (floats)
@@ -318,8 +319,8 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     u32x4 sh_h, sh_l, e_h[2], e_l[2];
     {
       float x[8];
-      load8(sh_row + 8 * h, x);
-      split8(x, sh_h, sh_l);
+      if (PLANES == PL_NONE && sh_split) { sh_h = sh_split[0]; sh_l = sh_split[1]; }
+      else { load8(sh_row + 8 * h, x); split8(x, sh_h, sh_l); }
       if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 16, r, h); }
       if (EMB_FOLDED) {
       } else if (emb_row) {
