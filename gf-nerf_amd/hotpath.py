@@ -62,6 +62,11 @@ class HotPathConfig:
     graph_forward_shared_pool: bool = True  # the captured forwards share one memory pool (their transient buffers overlap; replays are sequential)
     graph_backward: bool = True      # ... and the backward of such a replayed forward (compositing backward, decoder backward + record scatter, LDS accumulation)
                                      # as a second replayed graph on the same static buffers (HotPath.backward_graphed; focal stage)
+    graph_one_phase: bool = True     # ... captured in its ONE-PHASE form (every sample, no lists: eight graph nodes instead of twenty-one, each of which costs a
+                                     # replay ~6 us) while the planner's K says that a split does not pay -- a trained scene, where nearly every sample lies in
+                                     # front of its ray's termination point.  The plan is looked at again every graph_one_phase_probe forwards (one eager phased
+                                     # forward: its K travels to the host through a pinned word) and the phased capture comes back when K drops
+    graph_one_phase_probe: int = 512
     graph_forward_keep: int = 4      # captured forwards kept (least recently used go first): each holds a full set of forward activations
                                      # (150-200 MB at 4096 x 192); 4 = two sample buffers x (the active block + the one before it)
     async_adam: bool = False         # focal stage: Adam (+ zeroing the pool) on a third stream beside the next step's lookup of the
@@ -85,6 +90,10 @@ class HotPathConfig:
                                      # branch copies, read late) or the capture's planning forward's (StepGraph)
     prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
     prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
+    prefetch_cus_dense_replay: int = 200  # ... and as the plugin surface's replayed backward (HotPath.backward_graphed), beside a sampler launched eagerly on the
+                                     # second stream: with every CU (and register file) taken by the persistent backward the sampler's traversal and march only
+                                     # START when it ends, and the next forward waits 0.22 ms for them (round 6, a scene trained through the surface: 2.11 ms per
+                                     # iteration at 256 and 224 CUs, 1.99 at 192, 2.13 at 160; tools/README.md)
     record_merge: int = -1           # focal backward in record form: 0 / 1 = plain / run-merging records for EVERY launch (experiments: bench.py --record-merge);
                                      # -1: the policy below
     record_merge_dense: bool = False  # ... and such a batch merges runs of samples in one cell before it writes its gradient records -- decided on the DEVICE
@@ -152,6 +161,7 @@ class HotPath:
         self.last_forward_replayed = False
         self.last_backward_replayed = False
         self._backward_eager_like = False
+        self._one_phase, self._one_phase_uses, self._one_phase_probing = False, 0, 0  # forward_train_graphed: the captured forward's form (cfg.graph_one_phase)
         self._fwd_graphs = collections.OrderedDict()  # forward_train_graphed: key -> dict(n, graph, cam, comp, ctx, last_forward), least recently used first
         self._fwd_pool = None       # one memory pool for every captured forward (their transient buffers share it; replays are sequential)
         self.seg = None             # set by a segmented StepGraph capture: seg(fn) ends the graph segment being captured, notes fn as the
@@ -726,16 +736,48 @@ class HotPath:
         c = self.cfg
         lm_global = c.level_major_global or (c.level_major_global_after >= 0 and self.step >= c.level_major_global_after)
         blk = block if stage == STAGE_FOCAL else None
-        key = (id(samples), stage, block, bool(want_depth), self.nodes.data_ptr(), self.n_nodes, lm_global, self.phase_override, c.early_T, c.two_phase,
+        usable = (c.graph_forward and self.seg is None and self.after_lookup is None and not self.timed_ops
+                  and not torch.cuda.is_current_stream_capturing())
+        # the forward's form: phased (the planner splits, or has not spoken yet) or one phase (its K says a split does not pay: cfg.graph_one_phase)
+        can_one = usable and c.graph_one_phase and stage == STAGE_FOCAL and c.two_phase and c.early_T > 0 and self.phase_override is None
+        if can_one and self.k_host is None:
+            self.k_host = torch.zeros(1, dtype=torch.int32).pin_memory()  # the planned K, copied by every phased forward's side branch (read late)
+        if can_one and self._one_phase:
+            self._one_phase_uses += 1
+            if self._one_phase_uses % max(c.graph_one_phase_probe, 1) == 0:  # look at the plan again: this forward eager and phased (same results)
+                self._one_phase_probing = 2
+                return self.forward_train(None, None, cam_idx, None, stage, block, want_depth=want_depth, samples=samples)
+            if self._one_phase_probing:  # (the probe's K has had an iteration or two to reach the pinned word)
+                self._one_phase_probing -= 1
+                if self._one_phase_probing == 0 and int(self.k_host[0]) < 1024:
+                    self._one_phase = False
+        one = bool(can_one and self._one_phase)
+        key = (id(samples), stage, block, bool(want_depth), self.nodes.data_ptr(), self.n_nodes, lm_global, False if one else self.phase_override, c.early_T, c.two_phase,
                self.table16.data_ptr() if self.table16 is not None else 0,
                0 if blk is None else (self.blocks16[blk].data_ptr() if c.table_f16_shadow else self.blocks[blk].data_ptr(), self.block_prims[blk].data_ptr()))
         ent = self._fwd_graphs.setdefault(key, dict(n=0, samples=samples))  # (holds the buffers: their id stays theirs)
         self._fwd_graphs.move_to_end(key)
-        usable = (c.graph_forward and self.seg is None and self.after_lookup is None and not self.timed_ops
-                  and not torch.cuda.is_current_stream_capturing())
-        if not usable or ("graph" not in ent and (ent["n"] < 3 or self.table_grad is None)):
+
+        def forward(cam):
+            prev = self.phase_override
+            if one:
+                self.phase_override = False
+            try:
+                return self.forward_train(None, None, cam, None, stage, block, want_depth=want_depth, samples=samples)
+            finally:
+                self.phase_override = prev
+
+        if not usable or ("graph" not in ent and (ent["n"] < (1 if one else 3) or self.table_grad is None)):
             ent["n"] += 1
-            return self.forward_train(None, None, cam_idx, None, stage, block, want_depth=want_depth, samples=samples)
+            return forward(cam_idx)
+        if "graph" not in ent and can_one and not one and self._phase_state is not None:
+            # the eager phased runs have planned K: a plan of one phase (K = 1024; read exactly, the capture synchronises anyway) is captured as such --
+            # from the next call on (the one-phase form runs eagerly once on these buffers first)
+            self._join_aux()
+            if int(self._phase_state.k.item()) >= 1024:
+                self._one_phase, self._one_phase_uses, self._one_phase_probing = True, 0, 0
+                ent["n"] += 1
+                return forward(cam_idx)
         if "graph" not in ent:
             cam = cam_idx if cam_static else cam_idx.clone()
             self._join_aux()
@@ -756,7 +798,7 @@ class HotPath:
                 self._fwd_pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._fwd_pool if c.graph_forward_shared_pool else None, capture_error_mode="thread_local"):
-                comp, ctx = self.forward_train(None, None, cam, None, stage, block, want_depth=want_depth, samples=samples)
+                comp, ctx = forward(cam)
                 self._join_aux()  # (the branch that builds the backward's list: inside the graph)
                 if want_depth:
                     comp["depth"] = ops.depth_finalize(comp["depth_raw"], comp["t_minmax"], c.scale_factor)[:, None]
@@ -849,7 +891,9 @@ class HotPath:
             return 0
         n = c.prefetch_cus_global if stage == STAGE_GLOBAL else c.prefetch_cus
         if stage != STAGE_GLOBAL and self._dense_hint():
-            n = c.prefetch_cus_dense if (torch.cuda.is_current_stream_capturing() and not self._backward_eager_like) else c.prefetch_cus_dense_eager
+            n = c.prefetch_cus_dense if torch.cuda.is_current_stream_capturing() else c.prefetch_cus_dense_eager
+            if self._backward_eager_like:
+                n = c.prefetch_cus_dense_replay
         return n if 0 < n < 256 else 0
 
     def _merge_gate(self, front, n_dev):

@@ -1004,7 +1004,7 @@ def test_graphed_forward_is_the_eager_forward(setup, async_adam):
         batches.append(tuple(t(a) for a in (o, d, cam, gt)))
 
     def run(graphed):
-        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=graphed, async_adam=async_adam)
+        cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=graphed, async_adam=async_adam, graph_one_phase=False)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.table.mul_(100.0); hp.refresh_shadows()
         bufs, losses, kinds = [None, None], [], []
@@ -1034,6 +1034,51 @@ def test_graphed_forward_is_the_eager_forward(setup, async_adam):
     assert float(b["table"].abs().max()) > 0
 
 
+def test_captured_forward_takes_the_form_the_planner_asks_for(setup):
+    """cfg.graph_one_phase (round 6): forward_train_graphed captures the ONE-PHASE forward (every sample, no lists: eight graph nodes instead of
+    twenty-one) while the planner's K says that a split does not pay, looks at the plan again every cfg.graph_one_phase_probe forwards (one eager phased
+    forward) and goes back to the phased capture when K drops.  An empty scene first (nothing terminates: K = 1024 -> one phase), then the global table
+    made dense (rays terminate early: the probe plans a split -> phased captures); every forward's colours are those of an eager forward_train on the
+    same samples (phased and one-phase agree to 1e-6: the same cut), and the backward of either capture leaves the eager backward's table gradient."""
+    import torch
+
+    from gfnerf_amd import hotpath, ops, scene
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    R = 256
+    noise = t(scene.make_noise(R, False, 5.0))
+    plan = dict(two_phase_fixed_cost=0.0, two_phase_min_saving=(0.01, 0.005))  # (a test scene's rays are short: any saving counts as worth a split)
+    cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_one_phase_probe=6, **plan)
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
+    ref = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0],
+                          cfg=hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=False, **plan), seed=1, n_blocks=1)
+    for e in (hp, ref):
+        e.blocks[0].uniform_(-1e-2, 1e-2, generator=torch.Generator(device="cuda").manual_seed(5)); e.refresh_shadows()
+    bufs, forms, replayed = [None, None], [], []
+    for k in range(40):
+        if k == 20:  # the scene fills up: rays terminate after a few samples
+            for e in (hp, ref):
+                e.table.mul_(300.0); e.refresh_shadows()
+        o, d, cam = (t(a) for a in scene.make_rays(sc["c2w"], R, seed=500 + k))
+        gt = t(np.random.default_rng(600 + k).random((R, 3)).astype(np.float32))
+        s = hp.sample(o, d, noise, out=bufs[k % 2])
+        bufs[k % 2] = s
+        comp, ctx = hp.forward_train_graphed(cam, "focal", 0, s, want_depth=False)
+        forms.append(hp.last_forward); replayed.append(hp.last_forward_replayed)
+        comp_r, ctx_r = ref.forward_train(o, d, cam, noise, "focal", 0, want_depth=False)
+        np.testing.assert_allclose(comp["rgb"].cpu().numpy(), comp_r["rgb"].cpu().numpy(), atol=1e-6, err_msg=str(k))
+        _, g = ops.charbonnier(comp["rgb"], gt)
+        hp.backward_graphed(ctx, g)
+        ref.backward(ctx_r, ops.charbonnier(comp_r["rgb"], gt)[1])
+        a, b = hp.table_grad.float(), ref.table_grad.float()
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-12), k
+    print(list(zip(forms, replayed)))
+    assert forms[:6] == ["lm2"] * 6 and "lm" in forms[6:20] and replayed[19] and forms[19] == "lm"        # the empty scene: planned one phase, captured as such
+    assert forms[-1] == "lm2" and replayed[-1] and not hp._one_phase and int(hp._phase.k.item()) < 1024     # the dense scene: back to the phased capture
+    assert {e["last_forward"] for e in hp._fwd_graphs.values() if "graph" in e} == {"lm", "lm2"}
+
+
 def test_captured_forwards_are_bounded_and_evicted_least_recently_used(setup):
     """forward_train_graphed kept every capture (a full set of forward activations each) until drop_block / proc_octree.  Now the
     captures share one memory pool and at most cfg.graph_forward_keep stay (least recently used first out): three blocks x two sample-buffer
@@ -1047,7 +1092,7 @@ def test_captured_forwards_are_bounded_and_evicted_least_recently_used(setup):
     t, sc = S["t"], S["sc"]
     R = 256
     noise = t(scene.make_noise(R, False, 5.0))
-    cfg = hotpath.HotPathConfig(log2_T=14, s3im_loss_mult=0.0, early_T=1e-2, graph_forward_keep=4)
+    cfg = hotpath.HotPathConfig(log2_T=14, s3im_loss_mult=0.0, early_T=1e-2, graph_forward_keep=4, graph_one_phase=False)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=3)
     hp.table.mul_(100.0); hp.refresh_shadows()
     for b in hp.blocks:

@@ -19,7 +19,9 @@ VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward"
                 r06=[("forward + backward replayed", {}, None), ("backward eager", dict(hot_cfg=dict(graph_backward=False)), None),
                      ("forward + backward eager", dict(graph_forward=False), None)],
                 r06ev=[("forward + backward replayed (GFN_PLUGIN_EVENTS=1 prints where the iteration goes)", {}, None)],
-                r06cus=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_eager=n)), None) for n in (256, 224, 192, 160)])
+                r06cus=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_replay=n)), None) for n in (256, 224, 192, 160)],
+                r06cus2=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus_dense_replay=n)), None) for n in (184, 200, 208, 216)],
+                r06one=[("one-phase capture off", dict(hot_cfg=dict(graph_one_phase=False)), None), ("one-phase capture on (default)", {}, None)])
 for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
     if merge is not None:  # (None: the engine decides per launch on the device, HotPath._merge_gate)
         kw = dict(kw, hot_cfg=dict(kw.get("hot_cfg", {}), record_merge=int(merge)))
