@@ -90,10 +90,10 @@ class HotPathConfig:
                                      # branch copies, read late) or the capture's planning forward's (StepGraph)
     prefetch_cus_dense: int = 184    # ... CUs of the backward then, in a captured step
     prefetch_cus_dense_eager: int = 256  # ... and launched eagerly (256: no cap)
-    prefetch_cus_dense_replay: int = 200  # ... and as the plugin surface's replayed backward (HotPath.backward_graphed), beside a sampler launched eagerly on the
+    prefetch_cus_dense_replay: int = 184  # ... and as the plugin surface's replayed backward (HotPath.backward_graphed), beside a sampler launched eagerly on the
                                      # second stream: with every CU (and register file) taken by the persistent backward the sampler's traversal and march only
-                                     # START when it ends, and the next forward waits 0.22 ms for them (round 6, a scene trained through the surface: 2.11 ms per
-                                     # iteration at 256 and 224 CUs, 1.99 at 192, 2.13 at 160; tools/README.md)
+                                     # START when it ends, and the next forward waits 0.22 ms for them (round 6, a scene trained through the surface, ms per
+                                     # iteration at 256 / 224 / 216 / 208 / 200 / 192 / 184 / 160 CUs: 2.11 / 2.12 / 2.08 / 2.07 / 2.05 / 1.99 / 1.96 / 2.13; tools/README.md)
     record_merge: int = -1           # focal backward in record form: 0 / 1 = plain / run-merging records for EVERY launch (experiments: bench.py --record-merge);
                                      # -1: the policy below
     record_merge_dense: bool = False  # ... and such a batch merges runs of samples in one cell before it writes its gradient records -- decided on the DEVICE
