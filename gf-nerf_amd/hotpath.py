@@ -77,8 +77,9 @@ class HotPathConfig:
                                      # fifth of the rate.  The global stage writes 48 M records per step, a focal step 13-17 M on a young table (most
                                      # contributions round to zero at the pool's f16 x128 scale) and up to 90 M once every sample carries a gradient
                                      # (measured through the plugin surface on a scene trained there: bench.py plugin_step_trained)
-    sampler_stream_priority: int = -1  # the second stream (next batch's draw + sampler) is a HIGH-priority stream: its workgroups go first whenever the chip has
-                                     # room (beside a backward on every CU the sampler's scan + fill otherwise wait behind the accumulation and Adam too); 0: normal
+    sampler_stream_priority: int = 0  # -1: the second stream (next batch's draw + sampler) as a HIGH-priority stream.  Measured in round 6 and left off: no gain
+                                     # where it was meant to help (the plugin iteration: what the sampler lacks beside a backward on every CU is room, not
+                                     # rank -- prefetch_cus_dense_replay), and the eager steps' lookups and Adam 20-25 % slower beside a sampler that outranks them
     prefetch_cus: int = 160          # CUs left to the fused backward while a prefetched sampler runs beside it (focal stage; 192 until the backward
                                      # walked the front list: since then the sampler, not the backward, ends last -- tools/sweep_cus.sh)
     prefetch_cus_global: int = 192   # the same in the global stage (its backward is longer: the sampler needs fewer CUs)

@@ -400,6 +400,36 @@ def _planes_and_weight_gradients(world, S, hp, mode, forward, torch, ops, bar=1e
             assert eW <= bar and eB <= bar and cos >= 0.99999, (mode, li, eW, eB, cos)
 
 
+@pytest.mark.parametrize("mode", ["rne", "x3"])
+def test_bench_global_step_decoder_gradient_repeats_its_bits(world, mode):
+    """the decoder's weight gradient at the bench's size (524 k samples, 512 per-workgroup partial vectors) is a fixed-order sum --
+    wgrad_x3_layers_kernel's slabs are dealt statically, wgrad_reduce_kernel adds the partial vectors in one order, no atomics (round 5 ended with f32
+    atomics from four workgroups per element: one run in three differed in an entry's last bits, gfnerf/mlp.py's cuBLAS GEMMs do not) -- so two
+    backwards from the same forward and the same d loss / d rgb give the same bits in every layer's dW and db, ten times over."""
+    import torch
+
+    S = _stage(world, "global")
+    hp = S["hp"]
+    prev = (hp.cfg.wgrad_planes, hp.phase_override)
+    hp.cfg.wgrad_planes, hp.phase_override, hp._plane_bufs = mode, False, None
+    try:
+        o, d, cam, noise = _t(S["o"]), _t(S["d"]), _t(S["cam"]), _t(S["noise"])
+        comp, ctx = hp.forward_train(o, d, cam, noise, stage="global")
+        _, g_rgb = _g_rgb(S, comp["rgb"])
+        first = None
+        for rep in range(10):
+            hp.mlp_grad.zero_()
+            hp.backward(ctx, g_rgb)
+            got = hp.mlp_grad.clone()
+            if first is None:
+                first = got
+                assert float(first.abs().max()) > 0
+            assert torch.equal(got, first), (mode, rep, float((got - first).abs().max()))
+    finally:
+        hp.cfg.wgrad_planes, hp.phase_override = prev
+        hp._plane_bufs = None
+
+
 def test_bench_scene_octree_statistics_bit_exact_on_a_run_of_rays(world, oracle):
     """K5 / K6 (UpdateOctNodes, PersSampler_cuda.cu:518-665) on the bench's tree from the global stage's real weights and alphas:
     256 consecutive rays of the batch as their own update, node statistics / visit counts / invalidated leaves bit for bit."""

@@ -1037,8 +1037,8 @@ def test_graphed_forward_is_the_eager_forward(setup, async_adam):
 def test_captured_forward_takes_the_form_the_planner_asks_for(setup):
     """cfg.graph_one_phase (round 6): forward_train_graphed captures the ONE-PHASE forward (every sample, no lists: eight graph nodes instead of
     twenty-one) while the planner's K says that a split does not pay, looks at the plan again every cfg.graph_one_phase_probe forwards (one eager phased
-    forward) and goes back to the phased capture when K drops.  First a scene whose rays are too short for a split to pay (the planner's default
-    thresholds: K = 1024 -> one phase), then the global table made dense and the planner told that any saving counts (rays terminate early: the probe
+    forward) and goes back to the phased capture when K drops.  First a planner that finds no split worth its launches (thresholds no saving can
+    reach: K = 1024 -> one phase), then the global table made dense and the planner told that any saving counts (rays terminate early: the probe
     plans a split -> phased captures); every forward's colours are those of an eager forward_train on the same samples (phased and one-phase agree to
     1e-6: the same cut), and the backward of either capture leaves the eager backward's table gradient."""
     import torch
@@ -1049,10 +1049,11 @@ def test_captured_forward_takes_the_form_the_planner_asks_for(setup):
     t, sc = S["t"], S["sc"]
     R = 256
     noise = t(scene.make_noise(R, False, 5.0))
-    cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_one_phase_probe=6)
+    never = dict(two_phase_min_saving=(2.0, 2.0))  # (a saving is at most 1: no split is ever worth it)
+    cfg = hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_one_phase_probe=6, **never)
     hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
     ref = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0],
-                          cfg=hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=False), seed=1, n_blocks=1)
+                          cfg=hotpath.HotPathConfig(log2_T=18, s3im_loss_mult=0.0, early_T=1e-2, graph_forward=False, **never), seed=1, n_blocks=1)
     for e in (hp, ref):
         e.blocks[0].uniform_(-1e-2, 1e-2, generator=torch.Generator(device="cuda").manual_seed(5)); e.refresh_shadows()
     bufs, forms, replayed = [None, None], [], []
@@ -1075,7 +1076,7 @@ def test_captured_forward_takes_the_form_the_planner_asks_for(setup):
         a, b = hp.table_grad.float(), ref.table_grad.float()
         assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-12), k
     print(list(zip(forms, replayed)))
-    assert forms[:6] == ["lm2"] * 6 and "lm" in forms[6:20] and replayed[19] and forms[19] == "lm"        # short rays: planned one phase, captured as such
+    assert forms[:6] == ["lm2"] * 6 and "lm" in forms[6:20] and replayed[19] and forms[19] == "lm"        # no split planned: captured as one phase
     assert forms[-1] == "lm2" and replayed[-1] and not hp._one_phase and int(hp._phase.k.item()) < 1024     # the dense scene: back to the phased capture
     assert {e["last_forward"] for e in hp._fwd_graphs.values() if "graph" in e} == {"lm", "lm2"}
 
