@@ -444,12 +444,13 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
                 gather_note="16 levels x 8 corners per table and evaluated sample; the lanes of a patch want 0.09 distinct cells per sample and level "
                             "(tools/exp_patch_sharing.py) and a gather instruction costs its DISTINCT addresses (tools/gather_share.hip), so the nominal rate "
                             "exceeds the ceiling measured for distinct addresses: the kernel is bound by instruction issue, not by the gather path",
-                mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_tflops_issued=3.0 * n_eval * 61952.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
+                mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_per_tile=192,  # (216 until round 6: the image's embedding is folded into the head's bias)
+                mfma_tflops_issued=n_eval * 192 * 32768.0 / 32.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
                 mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
                 lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * H * W / pmc["tile_rays:render"])
                                      if fresh and pmc.get("decoded_samples_per_launch:render") and pmc.get("tile_rays:render") else None),  # useful samples /
                 # samples the lockstep patches decode (the counter run's launches are tiles of pmc["tile_rays:render"] rays)
-                kernel="fused_render_patch_kernel<1, 2, true>" if block is not None else "fused_render_patch_kernel<0, 2, true>",
+                kernel="fused_render_patch_kernel<1, 2, true, true>" if block is not None else "fused_render_patch_kernel<0, 2, true, true>",
                 kernel_ms_per_tile=(pmc["kernel_ms:render"] * tr.T / pmc["tile_rays:render"] if fresh and pmc.get("kernel_ms:render") and pmc.get("tile_rays:render") else None),
                 note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 

@@ -274,7 +274,8 @@ constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / 
 // REC: the samples come from the march's records (32 bytes each, gfn_sample_rays_record) instead of the packed arrays a fill pass made of them
 // FOLD: the appearance embedding is the same for every ray (A.cam_uniform, or there is none): folded into head layer 1's bias once per workgroup
 // (decoder_tile<., EMB_FOLDED>)
-template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD>
+// X2: a measurement (GFN_RENDER_X2=1; VERDICT r05 #2's report): the decoder's activation operands as one f16 number each, two MFMAs per product sum
+template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD, bool X2 = false>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     if (FOLD) {
       float x[8];
       load8(A.sh + (int64_t)ray * 16 + 8 * h, x);
-      split8(x, sh_split[0], sh_split[1]);
+      if (X2) { rne8(x, sh_split[0]); sh_split[1] = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_split[0], sh_split[1]);
     }
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
       // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
       if (A.exp & 1) __builtin_amdgcn_s_setprio(2);  // experiment: the wave in its matrix phase wins the issue arbitration
-      const DecoderOut o = decoder_tile<PL_NONE, FOLD>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, FOLD ? sh_split : nullptr);
+      const DecoderOut o = decoder_tile<PL_NONE, FOLD, X2>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, FOLD ? sh_split : nullptr);
       if (A.exp & 1) __builtin_amdgcn_s_setprio(0);
       // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
       if (act && h == 0) {
@@ -582,6 +583,22 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
 #undef GFN_SET
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
+  static const bool x2 = [] { const char* e = getenv("GFN_RENDER_X2"); return e && atoi(e) == 1; }();
+  if (x2 && fold && A.rec && levels == 2) {  // the measurement's form exists for the tile renderer's instantiation only
+    static unsigned long long x2_seen = 0;
+    if (gfn_first_call_on_device(x2_seen)) {
+      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    }
+    fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
+    GFN_CHECK_LAUNCH();
+    int64_t xb = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);
+    if (xb > gfn_decoder_cu_cap(opts)) xb = gfn_decoder_cu_cap(opts);
+    if (table2_f16) fused_render_patch_kernel<1, 2, true, true, true><<<(unsigned)xb, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+    else fused_render_patch_kernel<0, 2, true, true, true><<<(unsigned)xb, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+    GFN_CHECK_LAUNCH();
+    return GFN_OK;
+  }
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave

@@ -120,11 +120,13 @@ __device__ __forceinline__ WFrag wfrag_load(const u32x4* __restrict__ Ihi, const
   w.lo = __builtin_bit_cast(h8, Ilo[chunk * 64 + lane]);
   return w;
 }
+// X2 (a measurement, GFN_RENDER_X2: the activation operand as ONE f16 number, rounded to nearest -- weights stay split): two MFMAs per product sum
+template <bool X2 = false>
 __device__ __forceinline__ void mma3p(Acc2& a, WFrag& w, const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, int chunk_next, int lane,
                                       const u32x4& bhi, const u32x4& blo) {
   const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
   a.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, bh, a.m, 0, 0, 0);
-  a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, bl, a.c, 0, 0, 0);
+  if (!X2) a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, bl, a.c, 0, 0, 0);
   h8 nh = w.hi, nl = w.lo;
   if (chunk_next >= 0) { nh = __builtin_bit_cast(h8, Ihi[chunk_next * 64 + lane]); }
   a.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, bh, a.c, 0, 0, 0);
@@ -181,7 +183,7 @@ __device__ __forceinline__ void store_tile_rne(const PlaneDst& d, const float (&
     }
 }
 // RNE: the tile's 16 values also go, rounded to nearest, to the one-plane buffer row `dst` names
-template <bool RELU, bool RNE = false>
+template <bool RELU, bool RNE = false, bool X2 = false>
 __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned long long& mask, int t, const PlaneDst* dst = nullptr) {
   float v[16];
   acc_get16(a, v);
@@ -203,7 +205,8 @@ __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned lo
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       uint32_t a_, b_;
-      split2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1], a_, b_);
+      if (X2) { a_ = rne2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1]); b_ = 0u; }
+      else split2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1], a_, b_);
       f.hi[s][p] = a_; f.lo[s][p] = b_;
     }
 }
@@ -270,7 +273,7 @@ struct DecoderOut {
 // EMB_FOLDED (inference, round 6): the appearance part of head layer 1 -- W_h0[:, 31:63] emb(cam), the same 128 numbers for every sample of every ray of a
 // frame (one camera per image: perssampler.py:431-433) -- already sits in the layer's bias (fold_embedding_into_bias, once per workgroup), so the layer runs
 // its geo and SH k-steps only: 24 of the tile's 216 MFMAs, two operand loads + splits and eight weight-fragment reads less per 32 samples.
-template <int PLANES, bool EMB_FOLDED = false>
+template <int PLANES, bool EMB_FOLDED = false, bool X2 = false>
 __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, const float* __restrict__ bias,
                                                    int lane, const u32x4 (&xh)[2], const u32x4 (&xl)[2], const float* __restrict__ sh_row,
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
@@ -295,14 +298,14 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
       acc_init_bias(a, bias_h, Bb0, ot);
-      mma3p(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
-      mma3p(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
+      mma3p<X2>(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
+      mma3p<X2>(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
       Frag a1;
       const PlaneDst pd{FPL(hi, FP_A1), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE>(a, a1, m_a1, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, X2>(a, a1, m_a1, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1, h);
-      mma3p(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
-      mma3p(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
+      mma3p<X2>(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
+      mma3p<X2>(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
     }
     out.h0 = acc_get(hh, 0);            // row 0 = density channel: register 0 of the h=0 lanes
     out.sigma = expf(out.h0 + 1.0f);    // trunc_exp(h0 + 1), nerfacto_field.py:499
@@ -311,7 +314,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       float v[8];
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
-      split8(v, gh, gl);
+      if (X2) { rne8(v, gh); gl = u32x4{0u, 0u, 0u, 0u}; } else split8(v, gh, gl);
       if (PLANES == PL_SPLIT) store_half_tile(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 0, gh, gl, h);
       if (PLANES == PL_RNE) { u32x4 r; rne8(v, r, pc); store_half_tile_rne(FPL(hi, FP_XP), 64, q, 0, r, h); }
     }
@@ -320,7 +323,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     {
       float x[8];
       if (PLANES == PL_NONE && sh_split) { sh_h = sh_split[0]; sh_l = sh_split[1]; }
-      else { load8(sh_row + 8 * h, x); split8(x, sh_h, sh_l); }
+      else { load8(sh_row + 8 * h, x); if (X2) { rne8(x, sh_h); sh_l = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_h, sh_l); }
       if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 16, r, h); }
       if (EMB_FOLDED) {
       } else if (emb_row) {
@@ -350,16 +353,16 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
       acc_init_bias(a, bias_h, Bh0, ot);
-      mma3p(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
+      mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
       if (EMB_FOLDED) {
-        mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, sh_h, sh_l);
+        mma3p<X2>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, sh_h, sh_l);
       } else {
-        mma3p(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
-        mma3p(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
-        mma3p(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
+        mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
+        mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
+        mma3p<X2>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
       }
       const PlaneDst pd{FPL(hi, FP_C1), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE>(a, c1[ot], m_c1, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, X2>(a, c1[ot], m_c1, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU, feeding head layer 3: 128 -> 3 (padded), sigmoid
@@ -371,13 +374,13 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       Acc2 a;
       acc_init_bias(a, bias_h, Bh1, ot);
 #pragma unroll
-      for (int u = 0; u < 8; u++) mma3p(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
+      for (int u = 0; u < 8; u++) mma3p<X2>(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       Frag c2;
       const PlaneDst pd{FPL(hi, FP_C2), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE>(a, c2, m_c2, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, X2>(a, c2, m_c2, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2, h);
-      mma3p(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
-      mma3p(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
+      mma3p<X2>(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
+      mma3p<X2>(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
     }
     out.r = 1.f / (1.f + expf(-acc_get(o3, 0)));  // rows 0..2 = registers 0..2 of the h=0 lanes
     out.g = 1.f / (1.f + expf(-acc_get(o3, 1)));

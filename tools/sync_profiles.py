@@ -18,6 +18,8 @@ if os.path.exists(f"{R}/kt_plugin_trained"):  # the focal iteration on the scene
     subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_trained", f"profiles/{TAG}_plugin_trained_kernel_stats.csv"])
     shutil.copy(f"{R}/plugin_trained_under_rocprof.txt", f"profiles/{TAG}_plugin_trained_under_rocprof.txt")
     shutil.copy(f"{R}/plugin_trained_window.txt", f"profiles/{TAG}_plugin_trained_window.txt")
+    if os.path.exists(f"{R}/plugin_trained_timeline.txt"):
+        shutil.copy(f"{R}/plugin_trained_timeline.txt", f"profiles/{TAG}_plugin_trained_timeline.txt")
 shutil.copy(f"{R}/bench.json", f"profiles/{TAG}_bench.json")
 shutil.copy(f"{R}/bench_details.json", f"profiles/{TAG}_bench_details.json")
 subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_*/")))
@@ -82,14 +84,16 @@ j["mfma_busy:render"] = round(fv("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles, 4)
 j["valu_busy:render"] = round(4.0 * fv("SQ_ACTIVE_INST_VALU") / simd_cycles, 4)  # SQ_ACTIVE_INST_* count quad-cycles
 j["wait_frac:render"] = round(fv("SQ_WAIT_INST_ANY") / fv("SQ_WAVE_CYCLES"), 4)
 j["mfma_valu_coexec_frac:render"] = round(fv("SQ_VALU_MFMA_COEXEC_CYCLES") / fv("SQ_VALU_MFMA_BUSY_CYCLES"), 4)
-j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / 216.0 * 32.0))  # 216 MFMAs per 32-sample tile of the decoder
+MFMA_PER_TILE = 192.0 if int(TAG[1:]) >= 6 else 216.0  # MFMAs per 32-sample tile of the inference decoder (round 6: the image's embedding folded into the bias, 24 less)
+j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / MFMA_PER_TILE * 32.0))
+j["mfma_per_tile:render"] = MFMA_PER_TILE
 # (per-launch figures belong to the tile the eager run rendered: the renderer's default for a full-HD frame, bench.py scales by its own tile)
 _src = open("gf-nerf_amd/render.py").read()
 _ns = {}
 exec("import math\n" + _src[_src.index("MAX_TILE_RAYS = "):_src.index("def frame_shard")], _ns)
 _tw, _th = _ns["choose_tile"](1080, 1920)
 j["tile_rays:render"] = _tw * _th
-j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA") / 216.0), 1)
+j["valu_insts_per_tile:render"] = round(fv("SQ_INSTS_VALU") / (fv("SQ_INSTS_MFMA") / MFMA_PER_TILE), 1)
 j["l1_miss_requests:render"] = int(round(fv("TCP_TCC_READ_REQ_sum")))
 j["l2_hit_rate:render"] = round(fv("TCC_HIT") / (fv("TCC_HIT") + fv("TCC_MISS")), 3)
 j["traffic:render"] = tr(rk)
