@@ -335,8 +335,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     float carry = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f, cd = 0.f;
     bool done = false;
     // a lane's ray is fixed for the whole walk: its 8 SH values are split once (with the embedding folded away the registers are there)
+    // (the four-levels-in-flight instantiation has no registers to spare: it splits per sample like before)
+    constexpr bool KEEP_SH = FOLD && RENDER_LEVELS == 2;
     u32x4 sh_split[2];
-    if (FOLD) {
+    if (KEEP_SH) {
       float x[8];
       load8(A.sh + (int64_t)ray * 16 + 8 * h, x);
       if (X2) { rne8(x, sh_split[0]); sh_split[1] = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_split[0], sh_split[1]);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
       for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
       // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
       if (A.exp & 1) __builtin_amdgcn_s_setprio(2);  // experiment: the wave in its matrix phase wins the issue arbitration
-      const DecoderOut o = decoder_tile<PL_NONE, FOLD, X2>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, FOLD ? sh_split : nullptr);
+      const DecoderOut o = decoder_tile<PL_NONE, FOLD, X2>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, KEEP_SH ? sh_split : nullptr);
       if (A.exp & 1) __builtin_amdgcn_s_setprio(0);
       // ---- compositing (get_weights_f2nerf + renderers): each ray in its own lane, front to back
       if (act && h == 0) {
