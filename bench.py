@@ -23,6 +23,7 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
 """
 import argparse
 import functools
+import tempfile
 import json
 import os
 import socket
@@ -549,7 +550,7 @@ def plugin_step_bench(sc, torch, stage, steps=200, warmup=30, n_rays=N_RAYS, fus
     pcfg = GFNerfPipelineConfig(datamanager=HbmDataManagerConfig(c2w=sc["c2w"], intrinsics=intri, images=images, image_idx=image_idx,
                                                                  train_num_rays_per_batch=n_rays),
                                 model=GFNeRFModelConfig(**mk), prefetch_next_batch=prefetch)
-    pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfn_plugin_bench"))
+    pipe = pcfg.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, base_dir=tempfile.mkdtemp(prefix="gfn_plugin_bench_"))  # (its own: a block table checkpoint left by another run would be resumed)
     model = pipe.model
     model.hot.cfg.graph_forward = bool(graph_forward)
     for k, v in (hot_cfg or {}).items():  # experiments (tools/exp_plugin_trained.py): any HotPathConfig field

@@ -280,7 +280,13 @@ def _plugin_trainer(sc, seed, steps_global, steps_focal, n_rays, log2_T, early_T
               n_split_dataset=1, n_blocks=1, scale_factor=10.0, use_appearance_embedding=True, use_ch_loss=True, s3im_loss_mult=1.0, early_T=early_T,
               engine_seed=seed, octree_seed=1234)  # (the scene's own tree for every seed: the legs differ in the training path, not in the octree's probe points)
     pcfg = GFNerfPipelineConfig(datamanager=_DataManagerConfig(lambda dev: _ProceduralDataManager(sc["c2w"], sc["intri"], batch_fn, dev)), model=GFNeRFModelConfig(**mk))
-    pipe = pcfg.setup(device="cuda:%d" % torch.cuda.current_device(), test_mode="val", world_size=1, local_rank=0, base_dir="/tmp/gfn_psnr_plugin")
+    # base_dir of its OWN: the field resumes a block's table (and primes) from base_dir/encodings_ckpt when the block becomes active (nerfacto_field.py
+    # load_table, the reference's block swap) and saves it there at the end of the block's period -- with one directory shared by the runs of a study every
+    # run but the first started its focal stage from the PREVIOUS seed's residual table (round 6: focal gains of 0.2 ... 1.2 dB by run order)
+    import tempfile
+    base_dir = tempfile.mkdtemp(prefix="gfn_plugin_run_")
+    pipe = pcfg.setup(device="cuda:%d" % torch.cuda.current_device(), test_mode="val", world_size=1, local_rank=0, base_dir=base_dir)
+    pipe._gfn_run_dir = base_dir
     model = pipe.model
     hp = model.hot
     assert hp.n_nodes * 128 == np.asarray(sc["nodes"]).size, "the plugin's sampler built another tree than the scene's"
@@ -432,6 +438,8 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
             if progress is not None and (step + 1) % 500 == 0:
                 progress(f"plugin step {step + 1}/{steps_global + steps_focal} loss {float(loss):.4f}")
         pipe.eval()
+        import shutil
+        shutil.rmtree(pipe._gfn_run_dir, ignore_errors=True)  # (the block table checkpoint the last iteration's callback wrote: this run's own, not the next one's start)
         if steps_focal <= 0:
             res["psnr_global"] = evaluate(None)
         res["plugin"] = dict(forward_replayed=bool(hp.last_forward_replayed), backward_replayed=bool(hp.last_backward_replayed), forward=hp.last_forward,

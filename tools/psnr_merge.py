@@ -27,6 +27,11 @@ for leg in legs:
     for key in (f"psnr_global_{leg}", f"psnr_heldout_{leg}"):
         if key in st0:
             st[key] = float(np.average([p["psnr_study"][key] for p in parts], weights=[len(p["psnr_study"]["seeds"]) for p in parts]))
+    if f"{leg}_surface" in st0:  # what each run of the leg ended with (forward / backward replayed, the forward's form, the merge): one entry per seed
+        st[f"{leg}_surface"] = sum((p["psnr_study"][f"{leg}_surface"] for p in parts), [])
+for key in ("alive_sample_frac_trained", "planned_K_trained"):
+    if key in st0:
+        st[key] = st0[key]
 runs = sum((p["psnr_study"]["delta_runs"] for p in parts), [])
 st["delta_runs"] = runs
 st["delta"] = float(np.mean(runs))
