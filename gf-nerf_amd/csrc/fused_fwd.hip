@@ -585,7 +585,8 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
 #undef GFN_SET
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
-  static const bool x2 = [] { const char* e = getenv("GFN_RENDER_X2"); return e && atoi(e) == 1; }();
+  const char* x2_env = getenv("GFN_RENDER_X2");  // (read per call: tools/exp_render_x2.py renders ONE engine both ways in one process)
+  const bool x2 = x2_env && atoi(x2_env) == 1;
   if (x2 && fold && A.rec && levels == 2) {  // the measurement's form exists for the tile renderer's instantiation only
     static unsigned long long x2_seen = 0;
     if (gfn_first_call_on_device(x2_seen)) {
@@ -608,8 +609,9 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   if (blocks > cu_cap) blocks = cu_cap;
   const int tab = table2_f16 ? 1 : 0;
   const bool rec = A.rec != nullptr;
+  const int threads = (exp_bits & 4) ? RENDER_THREADS / 2 : RENDER_THREADS;  // experiment (GFN_RENDER_EXP bit 2): ONE wave per SIMD -- a wave's tile time without a partner
 #define GFN_LAUNCH(T, L, R, F) \
-  if (tab == T && levels == L && rec == R && fold == F) fused_render_patch_kernel<T, L, R, F><<<(unsigned)blocks, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+  if (tab == T && levels == L && rec == R && fold == F) fused_render_patch_kernel<T, L, R, F><<<(unsigned)blocks, threads, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_RENDER_ALL(GFN_LAUNCH)
 #undef GFN_LAUNCH
 #undef GFN_RENDER_ALL

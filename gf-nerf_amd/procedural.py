@@ -111,6 +111,9 @@ LEGS = {
     # scheduler_step_all with the callbacks of GFNeRFModel (engine/trainer.py:382-441) -- the engine gfnerf/nerfacto.py configures (record_merge_dense,
     # replayed forward + backward, the fused loss node, GfnAdam through Optimizers), on the same rays, schedule and held-out set as the other legs
     "plugin": dict(plugin=True),
+    # the native product step with the plugin engine's record policy (dense focal batches merge their record runs): paired with "fast" it isolates what
+    # the merge does to training (round 6: the plugin leg's focal stage gains MORE than the reference leg's)
+    "fast_merge": dict(precision="x3", record_merge_dense=True),
 }
 
 
@@ -529,6 +532,7 @@ def psnr_study(sc, seeds=(0, 1), legs=("fast", "reference"), progress=None, prec
         out[f"psnr_{leg}_runs"] = [round(float(v), 3) for v in vals]
         out[f"psnr_{leg}_std"] = float(vals.std(ddof=1)) if len(vals) > 1 else None
         out[f"psnr_global_{leg}"] = float(np.mean([r["psnr_global"] for r in runs[leg]]))
+        out[f"psnr_global_{leg}_runs"] = [round(float(r["psnr_global"]), 3) for r in runs[leg]]  # (per seed: the focal stage's gain is final - global)
         if "psnr_heldout" in runs[leg][0]:
             out[f"psnr_heldout_{leg}"] = float(np.mean([r["psnr_heldout"] for r in runs[leg]]))
     for leg in legs:
