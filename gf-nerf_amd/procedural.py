@@ -114,6 +114,10 @@ LEGS = {
     # the native product step with the plugin engine's record policy (dense focal batches merge their record runs): paired with "fast" it isolates what
     # the merge does to training (round 6: the plugin leg's focal stage gains MORE than the reference leg's)
     "fast_merge": dict(precision="x3", record_merge_dense=True),
+    # "reference" with the reference's block-stage sampler mode (train_and_eval focal_jitter=False): the leg the plugin surface is to be held against -- the
+    # surface mirrors that mode, and it alone is worth +0.17 dB of focal-stage gain on this scene (training and evaluation then sample alike)
+    "reference_m1": dict(precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, torch_adam=True, focal_jitter=False),
+    "fast_m1": dict(precision="x3", focal_jitter=False),
 }
 
 
@@ -325,12 +329,15 @@ def _plugin_trainer(sc, seed, steps_global, steps_focal, n_rays, log2_T, early_T
 def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_rays=4096, log2_T=21, seed=0, n_pool=64, eval_rays=16384, target_samples=128,
                    early_T=1e-4, progress=None, update_oct=True, torch_adam=False, fresh_rays=True, data_seed=None, eval_seed=0, lr_final=1e-2,
                    holdout_every=0, cosine_every=0, cosine_legs=("reference", "fast"), keep_engine=False, detail=0.0, n_blocks=1, after_global=None, lr_hold=0,
-                   plugin=False, **cfg_kw):
+                   plugin=False, focal_jitter=True, **cfg_kw):
     """Train on the procedural scene with the product's native step (HotPath.train_step: sampler -> lookup -> decoder -> compositing ->
     Charbonnier + S3IM -> backward -> Adam; UpdateOctNodes every global step like GFNeRFModel.get_outputs), lr 1e-2 -> 1e-2 * lr_final over the
     global stage and 5e-3 -> 5e-3 * lr_final over the focal stage (GFNerfExponentialDecayScheduler's shape, schedulers.py:113-184), then render
     held-out rays.  -> dict(psnr_global, psnr, loss, ...).
 
+    focal_jitter=False: the focal stage marches WITHOUT jitter from its second step on -- what the reference's block stage does: get_outputs ends every
+    block-stage iteration with persampler.update_mode(1) (gfnerf/nerfacto.py:614-616), and in that mode GetSamples' rays_noise is ones * fineness
+    (PersSampler.cpp mode_, PersSampler_cuda.cu:380-389); the plugin surface follows it (gfnerf/perssampler.py make_noise), the native legs jitter by default.
     lr_hold: global-stage steps at the initial learning rate before the decay starts.
     n_blocks: focal blocks resident; the focal stage trains them in rotation (step k: block k mod n_blocks), PSNR is block 0's.
     after_global(hp, lr_end): called between the stages (bench.py times the global step on the trained state there).
@@ -455,7 +462,7 @@ def train_and_eval(sc, precision="x3", steps_global=2000, steps_focal=1000, n_ra
                 block = i % n_blocks
             hold = lr_hold if stage == "global" else 0  # (the global stage may keep lr_init for its first lr_hold steps)
             mult = math.exp(math.log(lr_final) * max(i - hold, 0) / max(steps - hold, 1))  # lr_init -> lr_init * lr_final over the stage
-            noise = ops.sampler_noise(n_rays, fin, train=True, generator=gen, device=dev)
+            noise = ops.sampler_noise(n_rays, fin, train=bool(stage == "global" or focal_jitter or i == 0), generator=gen, device=dev)
             s3 = ops.s3im_index(n_rays, cfg.s3im_repeat_time, generator=gen, device=dev)
             if cosine_every > 0 and (i + 1) % cosine_every == 0:
                 cosines.append((stage, i + 1, grad_cosine(hp, b, noise, s3, stage, block, legs=cosine_legs)))

@@ -1443,6 +1443,43 @@ def test_psnr_of_the_product_against_the_reference_semantics():
     torch.cuda.empty_cache()
 
 
+def test_plugin_leg_runs_do_not_resume_each_others_block_tables():
+    """The field resumes a block's table and primes from base_dir/encodings_ckpt when the block becomes active and saves it there at the end of the block's
+    period (nerfacto_field.py load_table / save_table: the reference's block swap).  A study runs many seeds through the surface in one process: with one
+    base_dir for all of them every run but the first started its focal stage from the PREVIOUS run's residual table (round 6: the first 58 pairs of the
+    record were made that way and discarded).  procedural.train_and_eval(plugin=True) gives every run a directory of its own and removes it: two short
+    runs in a row find no checkpoint when their block becomes active, each writes its own, and none is left behind."""
+    import os
+
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import procedural, scene
+    from gfnerf_amd.gfnerf import nerfacto_field
+
+    sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene"))
+    seen = []
+    load, save = nerfacto_field.GFNeRFField.load_table, nerfacto_field.GFNeRFField.save_table
+
+    def load_probe(self, idx, strict=False):
+        seen.append(("load", str(self.encodings_ckpt_dir), os.path.exists(self.encodings_ckpt_dir / f"base_encoding_{idx}.ckpt")))
+        return load(self, idx, strict)
+
+    def save_probe(self, idx):
+        seen.append(("save", str(self.encodings_ckpt_dir), None))
+        return save(self, idx)
+
+    nerfacto_field.GFNeRFField.load_table, nerfacto_field.GFNeRFField.save_table = load_probe, save_probe
+    try:
+        for sd in (0, 1):
+            procedural.train_and_eval(sc, seed=sd, steps_global=12, steps_focal=8, eval_rays=4096, **procedural.LEGS["plugin"])
+    finally:
+        nerfacto_field.GFNeRFField.load_table, nerfacto_field.GFNeRFField.save_table = load, save
+    dirs = sorted({d for _, d, _ in seen})
+    assert len(dirs) == 2, seen                                     # a directory per run
+    assert all(not found for kind, _, found in seen if kind == "load"), seen   # nobody resumed anything
+    assert {d for kind, d, _ in seen if kind == "save"} == set(dirs) and {d for kind, d, _ in seen if kind == "load"} == set(dirs), seen  # each run looked, and wrote its own ...
+    assert not any(os.path.exists(os.path.dirname(d)) for d in dirs), dirs   # ... and its directory is gone with it
+
+
 def test_backward_cu_share_follows_the_batch(setup):
     """HotPath._cu_cap: while a prefetched sampler runs beside it the focal backward keeps cfg.prefetch_cus CUs -- unless the batch is dense (at least
     cfg.prefetch_dense_frac of its samples in front of the termination points, a trained scene): then cfg.prefetch_cus_dense in a captured step (the count is

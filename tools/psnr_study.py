@@ -86,7 +86,7 @@ def aux_sections():
 
 
 legs = tuple(os.environ.get("GFN_STUDY_LEGS", "plugin,reference").split(","))
-assert len(legs) == 2 and all(leg in procedural.LEGS for leg in legs), legs
+assert len(legs) in (1, 2) and all(leg in procedural.LEGS for leg in legs), legs  # (one leg: more runs for seeds another call has paired already; tools/psnr_merge.py pairs them by seed)
 res["legs"] = list(legs)
 if (seed0 == 0 and os.environ.get("GFN_STUDY_NO_AUX") != "1") or os.environ.get("GFN_STUDY_AUX_ONLY") == "1":
     aux_sections()
@@ -99,5 +99,8 @@ st = procedural.psnr_study(sc, seeds=tuple(range(seed0, seed0 + n)), legs=legs, 
 st["seconds"] = time.perf_counter() - t0
 res["psnr_study"] = st
 save()
-say(f"delta {st['delta']:+.3f} +- {st['se']:.3f} dB over {n} seeds; same-state decoder delta {st['decoder_delta']:+.4f} +- {st['decoder_se']}")
+if "delta" in st:
+    say(f"delta {st['delta']:+.3f} +- {st['se']:.3f} dB over {n} seeds; same-state decoder delta {st['decoder_delta']:+.4f} +- {st['decoder_se']}")
+else:
+    say(f"{legs[0]}: {st['psnr_' + legs[0]]:.3f} +- {st['psnr_' + legs[0] + '_std']:.3f} dB over {n} seeds")
 save()
