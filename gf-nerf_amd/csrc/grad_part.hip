@@ -23,7 +23,6 @@
 // the sum is again order independent, rounded to f16 once.  Only a NaN / inf among the addends (or f16_accumulate) takes the
 // reference's way, ds_pk_add_f16 into an f16 image, which carries it into the pool like atomicAdd(half2) does -- decided per
 // range, workgroup-uniform.
-#include <cstdlib>
 #include "gfn_common.h"
 #include "hash_device.h"
 
@@ -194,12 +193,7 @@ int gfn_grad_records_reduce(const void* records, uint32_t* record_counts, int64_
   if (range_end <= 0 || range_end > n_ranges) range_end = n_ranges;  // 0, 0: every range
   GFN_CHECK_ARG(range_begin >= 0 && range_begin <= range_end, "gfn_grad_records_reduce: ranges [%d, %d)", range_begin, range_end);
   if (range_begin == range_end) return GFN_OK;
-  int grid = range_end - range_begin;
-  if (const char* e = getenv("GFN_ACCUM_WGS")) {  // experiment (tools/README.md, round 6): the accumulation on fewer workgroups (one per CU: 128 KiB of LDS), the rest of the chip left to the stream beside it
-    const int cap_wgs = atoi(e);
-    if (cap_wgs > 0 && cap_wgs < grid) grid = cap_wgs;
-  }
-  grad_accumulate_kernel<<<grid, 1024, kSlice * 8, gfn_stream(stream)>>>(
+  grad_accumulate_kernel<<<range_end - range_begin, 1024, kSlice * 8, gfn_stream(stream)>>>(
       reinterpret_cast<const uint2*>(records), record_counts, (unsigned int)cap, range_begin, range_end, pool_slots,
       reinterpret_cast<half2_t*>(grad_pool_f16), counts_seen, f16_accumulate ? 1 : 0);
   GFN_CHECK_LAUNCH();

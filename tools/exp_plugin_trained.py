@@ -21,13 +21,8 @@ VARIANTS = dict(base=[("graph", {}, 0), ("graph+merge", {}, 1), ("eager forward"
                 r06ev=[("forward + backward replayed (GFN_PLUGIN_EVENTS=1 prints where the iteration goes)", {}, None)],
                 r06cus=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus=n, prefetch_cus_dense_replay=n)), None) for n in (256, 224, 192, 160)],
                 r06cus2=[(f"replayed, backward on {n} CUs", dict(hot_cfg=dict(prefetch_cus_dense_replay=n)), None) for n in (184, 200, 208, 216)],
-                # the backward kernel on every CU and the LDS accumulation behind it on fewer workgroups instead (GFN_ACCUM_WGS, read per launch): does the sampler fit THERE?
-                r06acc=[("backward 184 CUs, accumulation everywhere (default)", {}, None, 0), ("backward 256, accumulation on 184", dict(hot_cfg=dict(prefetch_cus_dense_replay=256)), None, 184),
-                        ("backward 224, accumulation on 184", dict(hot_cfg=dict(prefetch_cus_dense_replay=224)), None, 184),
-                        ("backward 256, accumulation on 160", dict(hot_cfg=dict(prefetch_cus_dense_replay=256)), None, 160)],
                 r06one=[("one-phase capture off", dict(hot_cfg=dict(graph_one_phase=False)), None), ("one-phase capture on (default)", {}, None)])
-for name, kw, merge, *rest in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
-    os.environ["GFN_ACCUM_WGS"] = str(rest[0] if rest else 0)
+for name, kw, merge in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "base"]:
     if merge is not None:  # (None: the engine decides per launch on the device, HotPath._merge_gate)
         kw = dict(kw, hot_cfg=dict(kw.get("hot_cfg", {}), record_merge=int(merge)))
     r = bench.plugin_step_bench(sc, torch, "focal", steps=200, warmup=30, trained=(3000, 1000), **kw)
