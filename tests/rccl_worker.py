@@ -97,6 +97,9 @@ def main():
         res["eager_control_identical"] = same(plain, control)
         res["eager_forced_identical"] = same(plain, forced)
         res["eager_forced_rel"] = close(plain, forced)
+        # decoder / embedding entries further apart than 2e-4 of the largest: a flipped Adam step moves ONE weight, an exchange that lost or mis-scaled a gradient most
+        far_of = lambda a, b: [float(((x.float() - y.float()).abs() > 2e-4 * float(y.float().abs().max())).float().mean()) for x, y in ((a.mlp_flat, b.mlp_flat), (a.emb, b.emb))]  # noqa: E731
+        res["eager_forced_far"], res["eager_control_far"] = far_of(plain, forced), far_of(plain, control)
         res["eager_control_rel"] = close(plain, control)
         res["eager_forced_table_far_frac"], res["eager_control_table_far_frac"] = far(plain, forced), far(plain, control)
         # without the appearance embedding (its gradient is the step's only float-atomic sum): is the step then repeatable bit for bit?

@@ -115,9 +115,13 @@ def test_rccl_world_one_runs_every_exchange_of_the_step(tmp_path):
     # decoder, embedding: as close to the plain run as the control run is, or within a few flipped Adam steps -- the table's last-bit differences reach the
     # decoder's gradients, and a weight whose gradient is near zero then steps the other way: 3e-4 - 6e-4 of the largest weight per flip, seen in the
     # control as often as in the forced run.  (An exchange that lost, doubled or mis-scaled a gradient moves every weight: 1e-2 and more.)  The table: far_frac above
-    FLIPS = 2e-3
+    # Three steps: a weight whose sign flipped in the first keeps drifting in the other two, so the LARGEST difference is bounded by a few flips' worth (seen:
+    # 2.3e-3 in the forced run beside 7e-6 in the control, and the other way round), while the FRACTION of weights that moved at all stays tiny -- the
+    # signature that tells a flip from a broken exchange
+    FLIPS = 5e-3
     for i in (2, 3):
         assert res["eager_forced_rel"][i] <= max(2.0 * res["eager_control_rel"][i], FLIPS), (i, res["eager_forced_rel"], res["eager_control_rel"])
+        assert res["eager_forced_far"][i - 2] <= max(2.0 * res["eager_control_far"][i - 2], 5e-3), (i, res["eager_forced_far"], res["eager_control_far"])
     # segmented replay: four graphs, three eager RCCL exchanges, four replays
     assert res["segments"] == ["graph", "eager", "graph", "eager", "graph", "eager", "graph"], res["segments"]
     assert res["graph_sync_stats"]["octree_max_reduces"] == 5 and res["graph_sync_stats"]["direct_reduces"] == 5, res["graph_sync_stats"]
