@@ -1637,4 +1637,6 @@ def test_two_engines_on_two_threads_keep_their_own_launch_policy(setup):
     assert 0 < alone["B"]["counts"][0] < 0.9 * alone["A"]["counts"][0]  # the two policies do differ in what they write
     for name in policies:
         assert both[name]["counts"] == alone[name]["counts"], name
-        assert torch.equal(both[name]["g"], alone[name]["g"]) and torch.equal(both[name]["po"], alone[name]["po"]) and torch.equal(both[name]["ts"], alone[name]["ts"]), name
+        n_live = int(alone[name]["po"][-1])  # (the sample buffers are sized for 1024 per ray: what lies behind the live count is whatever the allocator handed out)
+        assert torch.equal(both[name]["g"], alone[name]["g"]) and torch.equal(both[name]["po"], alone[name]["po"]), name
+        assert torch.equal(both[name]["ts"][:n_live], alone[name]["ts"][:n_live]), name
