@@ -777,6 +777,43 @@ def test_patch_render_matches_ray_per_wave_render(setup, block, early_T, tile_wi
     assert odd["field"] is not None
 
 
+def test_patch_render_with_the_embedding_folded_into_the_bias(setup):
+    """gfn_fused_render(cam_uniform): an image has ONE appearance embedding (test mode: the nearest training image's, perssampler.py:431-433), so head layer
+    1's appearance part -- W_h0[:, 31:63] emb, the same 128 numbers for every sample -- is added to the layer's bias once per workgroup
+    (fold_embedding_into_bias) and the decoder runs 192 instead of 216 MFMAs per 32 samples.  Same products, another summation order: the image with the
+    fold equals the image without it to f32 rounding, for a camera with a LARGE embedding (so that a dropped or doubled appearance term would show), on
+    packed samples and on the march's records; and the camera is read from the device (cam_idx[0]) by every launch: another camera, another image, no
+    recompilation or host value involved."""
+    import torch
+
+    from gfnerf_amd import hotpath
+
+    S = setup
+    t, sc = S["t"], S["sc"]
+    hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=S["cfg"], seed=1, n_blocks=1)
+    hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3)
+    hp.emb.normal_(0, 1.0, generator=torch.Generator(device="cuda").manual_seed(3))  # (an appearance term of the size of the other inputs)
+    hp.refresh_shadows(); hp._x3_stale = True
+    R = (S["o"].shape[0] // 64) * 64
+    o, d, noise = t(S["o"][:R]), t(S["d"][:R]), t(S["noise"])
+    cam5 = torch.full((R,), 5, dtype=torch.int32, device="cuda")
+    smp = hp.sample(o, d, noise)
+    plain = hp.render(o, d, cam5, noise, block=0, samples=smp, tile_width=0)
+    fold = hp.render(o, d, cam5, noise, block=0, samples=smp, tile_width=0, cam_uniform=True)
+    for k, tol in (("rgb", 2e-6), ("accumulation", 2e-6)):
+        np.testing.assert_allclose(fold[k].cpu().numpy(), plain[k].cpu().numpy(), rtol=0, atol=tol, err_msg=k)
+    assert float(plain["accumulation"].max()) > 0.5
+    # the appearance term matters in this setup: without it the colours move by far more than the tolerance above
+    cam9 = torch.full((R,), 9, dtype=torch.int32, device="cuda")
+    other = hp.render(o, d, cam9, noise, block=0, samples=smp, tile_width=0, cam_uniform=True)
+    assert float((other["rgb"] - fold["rgb"]).abs().max()) > 1e-2
+    np.testing.assert_allclose(other["rgb"].cpu().numpy(), hp.render(o, d, cam9, noise, block=0, samples=smp, tile_width=0)["rgb"].cpu().numpy(), rtol=0, atol=2e-6)
+    # the record form (what the tile renderer launches)
+    recd = hp.sample(o, d, noise, record=True)
+    rec_fold = hp.render(o, d, cam5, noise, block=0, samples=recd, tile_width=0, cam_uniform=True)
+    assert torch.equal(rec_fold["rgb"], fold["rgb"])
+
+
 @pytest.mark.parametrize("variant", ["patch_width_0", "f32_decoder", "unfused_forward"])
 def test_tile_pipeline_without_the_patch_kernel(setup, variant):
     """the pipelined TileRenderer (several tiles per replay, tiles of >= 32 Ki rays) sampled in the record form whenever the
