@@ -111,13 +111,9 @@ LEGS = {
     # scheduler_step_all with the callbacks of GFNeRFModel (engine/trainer.py:382-441) -- the engine gfnerf/nerfacto.py configures (record_merge_dense,
     # replayed forward + backward, the fused loss node, GfnAdam through Optimizers), on the same rays, schedule and held-out set as the other legs
     "plugin": dict(plugin=True),
-    # the native product step with the plugin engine's record policy (dense focal batches merge their record runs): paired with "fast" it isolates what
-    # the merge does to training (round 6: the plugin leg's focal stage gains MORE than the reference leg's)
-    "fast_merge": dict(precision="x3", record_merge_dense=True),
     # "reference" with the reference's block-stage sampler mode (train_and_eval focal_jitter=False): the leg the plugin surface is to be held against -- the
     # surface mirrors that mode, and it alone is worth +0.17 dB of focal-stage gain on this scene (training and evaluation then sample alike)
     "reference_m1": dict(precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, torch_adam=True, focal_jitter=False),
-    "fast_m1": dict(precision="x3", focal_jitter=False),
 }
 
 
