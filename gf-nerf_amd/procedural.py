@@ -112,7 +112,7 @@ LEGS = {
     # replayed forward + backward, the fused loss node, GfnAdam through Optimizers), on the same rays, schedule and held-out set as the other legs
     "plugin": dict(plugin=True),
     # "reference" with the reference's block-stage sampler mode (train_and_eval focal_jitter=False): the leg the plugin surface is to be held against -- the
-    # surface mirrors that mode, and it alone is worth +0.17 dB of focal-stage gain on this scene (training and evaluation then sample alike)
+    # surface mirrors that mode, and it alone is worth +0.198 +- 0.006 dB of focal-stage gain on this scene (training and evaluation then sample alike: profiles/r06_psnr_study.json)
     "reference_m1": dict(precision="f32", early_T=0.0, two_phase=False, lds_accumulate=False, torch_adam=True, focal_jitter=False),
 }
 
