@@ -17,6 +17,7 @@
 // termination point get sigma = rgb = weight = alpha = 0 so that the unchanged backward kernels see no gradient there.
 #include <stdlib.h>
 
+
 #include "gfn_common.h"
 #include "hash_device.h"
 #include "x3_device.h"
@@ -110,6 +111,42 @@ __device__ __forceinline__ float2 blend_pairs(const uint32_t (&v)[8], const floa
     a = (d == 0) ? f2{t0, t1} : a + f2{t0, t1};
   }
   return make_float2(gfn_round_f16(a[0]), gfn_round_f16(a[1]));
+}
+
+// hash_corners / rehash_corners (hash_device.h) with xor and mask kept APART: an optimisation barrier between them keeps the compiler from fusing the two
+// into ONE v_bitop3_b32.  Round 6: the inference kernel's instantiation with the launch's pointer tests compiled away (fused_render_patch_kernel<..., PLAIN>:
+// one long basic block per gather group) rendered a handful of pixels of a frame differently from run to run -- same build, same inputs -- until these
+// sixteen fused operations per level were split again; with them split two renders of a frame are the same bits (tools/README.md, round 6).  Whether the
+// instruction, its distance to the quarter-rate multiplies feeding it, or the compiler's hazard table for gfx950 is at fault was not established: the
+// forms that have been bit-exact against the oracle for five rounds keep hash_device.h's code, this instantiation uses the split one.  Same values.
+__device__ __forceinline__ uint32_t xor_then_mask(uint32_t t, uint32_t mask) {
+  asm("" : "+v"(t));
+  return t & mask;
+}
+__device__ __forceinline__ void corner_slots_split(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, uint32_t mask, uint32_t (&pos)[8]) {
+  pos[0] = xor_then_mask(x0 ^ y0 ^ z0, mask); pos[1] = xor_then_mask(x0 ^ y0 ^ z1, mask);
+  pos[2] = xor_then_mask(x0 ^ y1 ^ z0, mask); pos[3] = xor_then_mask(x0 ^ y1 ^ z1, mask);
+  pos[4] = xor_then_mask(x1 ^ y0 ^ z0, mask); pos[5] = xor_then_mask(x1 ^ y0 ^ z1, mask);
+  pos[6] = xor_then_mask(x1 ^ y1 ^ z0, mask); pos[7] = xor_then_mask(x1 ^ y1 ^ z1, mask);
+}
+// (no bias pool: PLAIN's launches have none)
+__device__ __forceinline__ void hash_corners_split(float px, float py, float pz, float scale, const int* __restrict__ prim, uint32_t mask, Corners& c, uint32_t cell[3]) {
+  px = px * scale; py = py * scale; pz = pz * scale;
+  const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  const uint32_t ux = sat_u32(fx), uy = sat_u32(fy), uz = sat_u32(fz);
+  cell[0] = ux; cell[1] = uy; cell[2] = uz;
+  const uint32_t pa = (uint32_t)prim[0], pb = (uint32_t)prim[1], pc = (uint32_t)prim[2];
+  const uint32_t x0 = ux * pa, y0 = uy * pb, z0 = uz * pc;
+  corner_slots_split(x0, x0 + pa, y0, y0 + pb, z0, z0 + pc, mask, c.pos);
+  const float a = px - fx, b = py - fy, cc = pz - fz;
+  const float na = 1.f - a, nb = 1.f - b, nc = 1.f - cc;
+  c.w[0] = (na * nb) * nc; c.w[1] = (na * nb) * cc; c.w[2] = (na * b) * nc; c.w[3] = (na * b) * cc;
+  c.w[4] = (a * nb) * nc; c.w[5] = (a * nb) * cc; c.w[6] = (a * b) * nc; c.w[7] = (a * b) * cc;
+}
+__device__ __forceinline__ void rehash_corners_split(const uint32_t cell[3], const int* __restrict__ prim, uint32_t mask, Corners& c) {
+  const uint32_t pa = (uint32_t)prim[0], pb = (uint32_t)prim[1], pc = (uint32_t)prim[2];
+  const uint32_t x0 = cell[0] * pa, y0 = cell[1] * pb, z0 = cell[2] * pc;
+  corner_slots_split(x0, x0 + pa, y0, y0 + pb, z0, z0 + pc, mask, c.pos);
 }
 
 // TAB: 0 one table, 1 two tables with their own primes (the focal stage: global + residual block table).
@@ -275,7 +312,11 @@ constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / 
 // FOLD: the appearance embedding is the same for every ray (A.cam_uniform, or there is none): folded into head layer 1's bias once per workgroup
 // (decoder_tile<., EMB_FOLDED>)
 // X2: a measurement (GFN_RENDER_X2=1; VERDICT r05 #2's report): the decoder's activation operands as one f16 number each, two MFMAs per product sum
-template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD, bool X2 = false>
+// PLAIN: what the launch's pointers say is known at compile time -- no bias pool (rand_bias off) and, with two tables, the block table's own primes: the
+// per-level `pointer ? ... : ...` branches (wave-uniform, but each one ends a scheduling region and the slot copies for the shared-primes case are made
+// whether they are used or not) fold away: 4,423 -> 4,248 instructions in the kernel, 62 -> 38 basic blocks; its hashes keep xor and mask apart
+// (hash_corners_split above: with the two fused into v_bitop3_b32 this instantiation was not deterministic)
+template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD, bool X2 = false, bool PLAIN = false>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -390,7 +431,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
           const int level = 8 * uu + 4 * h + m;
           const int tr3 = 3 * (level * n_vol + vol);
           pra[m][0] = A.prim_a[tr3]; pra[m][1] = A.prim_a[tr3 + 1]; pra[m][2] = A.prim_a[tr3 + 2];
-          if (TAB == 1 && A.prim_b) { prb[m][0] = A.prim_b[tr3]; prb[m][1] = A.prim_b[tr3 + 1]; prb[m][2] = A.prim_b[tr3 + 2]; }
+          if (TAB == 1 && (PLAIN || A.prim_b)) { prb[m][0] = A.prim_b[tr3]; prb[m][1] = A.prim_b[tr3 + 1]; prb[m][2] = A.prim_b[tr3 + 2]; }
         }
 #pragma unroll
         for (int g0 = 4 * uu; g0 < 4 * uu + 4; g0 += RENDER_LEVELS) {
@@ -400,12 +441,14 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
           for (int l = 0; l < RENDER_LEVELS; l++) {
             const int g = g0 + l, level = 8 * (g >> 2) + 4 * h + (g & 3);
             uint32_t cell[3];
-            hash_corners(px, py, pz, s_scale[level], pra[g & 3], A.bias_pool ? A.bias_pool + 3 * (level * n_vol + vol) : nullptr, T - 1u, c[l], cell);
+            if (PLAIN) hash_corners_split(px, py, pz, s_scale[level], pra[g & 3], T - 1u, c[l], cell);
+            else hash_corners(px, py, pz, s_scale[level], pra[g & 3], A.bias_pool ? A.bias_pool + 3 * (level * n_vol + vol) : nullptr, T - 1u, c[l], cell);
             if (TAB == 1) {
               Corners cb;
-              if (A.prim_b) rehash_corners(cell, prb[g & 3], T - 1u, cb);  // same cell, same weights: only the slots change
+              if (PLAIN) rehash_corners_split(cell, prb[g & 3], T - 1u, cb);
+              else if (A.prim_b) rehash_corners(cell, prb[g & 3], T - 1u, cb);  // same cell, same weights: only the slots change
 #pragma unroll
-              for (int d = 0; d < 8; d++) posb[l][d] = A.prim_b ? cb.pos[d] : c[l].pos[d];
+              for (int d = 0; d < 8; d++) posb[l][d] = (PLAIN || A.prim_b) ? cb.pos[d] : c[l].pos[d];
             }
           }
 #pragma unroll
@@ -610,6 +653,18 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   const int tab = table2_f16 ? 1 : 0;
   const bool rec = A.rec != nullptr;
   const int threads = (exp_bits & 4) ? RENDER_THREADS / 2 : RENDER_THREADS;  // experiment (GFN_RENDER_EXP bit 2): ONE wave per SIMD -- a wave's tile time without a partner
+  // no bias pool and (two tables) the second table's own primes, the record form, the fold, two levels in flight: the instantiation with those facts compiled in
+  // (two tables only: the one-table form gains nothing to speak of and spills a register that way; GFN_RENDER_EXP bit 3: the generic form, for A/B)
+  const bool plain = !bias_pool && table2_f16 && prim_pool2 && rec && fold && levels == 2 && !(exp_bits & 8);
+  if (plain) {
+    static unsigned long long plain_seen = 0;
+    if (gfn_first_call_on_device(plain_seen)) {
+      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+    }
+    fused_render_patch_kernel<1, 2, true, true, false, true><<<(unsigned)blocks, threads, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+    GFN_CHECK_LAUNCH();
+    return GFN_OK;
+  }
 #define GFN_LAUNCH(T, L, R, F) \
   if (tab == T && levels == L && rec == R && fold == F) fused_render_patch_kernel<T, L, R, F><<<(unsigned)blocks, threads, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
   GFN_RENDER_ALL(GFN_LAUNCH)
