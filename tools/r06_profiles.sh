@@ -1,6 +1,6 @@
 # round-6 profile collection, two gpurun calls (a call lasts 20 minutes at most):
 #   bash tools/r06_profiles.sh traces   the bench line + kernel-trace stats (focal / global graph launch, render graph + eager, the plugin-surface step)
-#   bash tools/r06_profiles.sh pmc_render   only the inference kernel's passes of the next mode (after a change to csrc/fused_fwd.hip alone)
+#   bash tools/r06_profiles.sh render_traces | pmc_render   after a change to csrc/fused_fwd.hip alone: the bench line + the two render traces | the inference kernel's counter passes
 #   bash tools/r06_profiles.sh pmc      separate --pmc passes (one counter group each; never together with a trace: MI355X guide) for the focal step and
 #                                       the global step; pmc_render: the inference kernel's (tiles rendered eagerly: --render-eager); pmc_all: both
 # Everything is addressed through $GRAFT_REPO_ROOT (the r03 script mixed it with /root/repo).
@@ -32,6 +32,16 @@ if [ "$MODE" = "traces" ]; then
   python3 $GRAFT_REPO_ROOT/tools/trace_tail.py $O/kt_plugin_trained 300 auto:grad_accumulate > $O/plugin_trained_window.txt
   python3 $GRAFT_REPO_ROOT/tools/timeline.py $O/kt_plugin_trained --anchor adam_ex --steps 100 --dump-step > $O/plugin_trained_timeline.txt
   echo "kt plugin trained done"
+elif [ "$MODE" = "render_traces" ]; then
+  # after a change to csrc/fused_fwd.hip alone: the bench line again and the two render traces (then: pmc_render)
+  timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
+  grep "bench-details" $O/bench.err | sed 's/^\[bench-details\] //' > $O/bench_details.json
+  echo "bench done"
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
+  echo "kt render done"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render_eager -- python3 $B $RENDER > $O/render_eager_under_rocprof.json 2>$O/kt_render_eager.err
+  echo "kt render eager done"
 elif [ "$MODE" = "sq_global" ]; then
   # the global step's kernels under the SQ counter groups (what bounds field_bwd_dx_x3_kernel<2, 3> and wgrad_x3_layers_kernel)
   cd /tmp
