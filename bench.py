@@ -451,7 +451,7 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
                 lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * H * W / pmc["tile_rays:render"])
                                      if fresh and pmc.get("decoded_samples_per_launch:render") and pmc.get("tile_rays:render") else None),  # useful samples /
                 # samples the lockstep patches decode (the counter run's launches are tiles of pmc["tile_rays:render"] rays)
-                kernel="fused_render_patch_kernel<1, 2, true, true>" if block is not None else "fused_render_patch_kernel<0, 2, true, true>",
+                kernel="fused_render_patch_kernel<1, 2, true, true, false, true>" if block is not None else "fused_render_patch_kernel<0, 2, true, true>",
                 kernel_ms_per_tile=(pmc["kernel_ms:render"] * tr.T / pmc["tile_rays:render"] if fresh and pmc.get("kernel_ms:render") and pmc.get("tile_rays:render") else None),
                 note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 
