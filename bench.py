@@ -119,6 +119,8 @@ def parse():
     ap.add_argument("--prefetch-cus", type=int, default=0, help="CUs left to the fused backward while the prefetched sampler runs beside it")
     ap.add_argument("--render-pipeline", type=int, default=0,
                     help="tiles per hipGraph replay: their samplers run beside the fused forwards on a second graph branch (1 = one tile per replay)")
+    ap.add_argument("--no-render-x3", action="store_true", help="skip the render sub-record's second pass with the x3 decoder form throughout (profile runs: ONE inference "
+                    "kernel instantiation in the trace / counter tables)")
     ap.add_argument("--render-eager", action="store_true", help="render tiles as eager launches, one tile at a time (counter collection: rocprofv3 --pmc serialises "
                     "dispatches anyway and sees eager launches reliably); the kernels are the graph's")
     ap.add_argument("--render-decoder-cus", type=int, default=224, help="CUs the fused forward may occupy while a sampler runs beside it")
@@ -400,7 +402,29 @@ def render_bench(hp, sc, args, fineness, torch, cams, block, world=1, rank=0, ow
     if world == 1 and mine:
         roof = render_roofline(hp, tr, c2w, intr, int(cams[mine[-1]]), H, W, block, fineness, dt / len(mine), torch)
     fp = tr.footprint_bytes()
+    # the renderer's default decoder form (HotPathConfig.render_colour_x2: the colour head's layer 2 on one f16 activation operand; density, accumulation and
+    # depth are the x3 form's bits) -- and, beside it, the same frames with the split-f16 x3 form throughout and how far the two frames' rgb are apart
+    x3_ms, x2_dist = None, None
+    if world == 1 and mine and tr.colour_x2 and getattr(tr, "record", False) and not args.no_render_x3:
+        last = {k: local[mine[-1]][k].clone() for k in ("rgb", "accumulation", "depth")}
+        tile_rays, rec_slots = tr.T, tr.rec_slots
+        del tr, local
+        torch.cuda.empty_cache()
+        tr = rmod.TileRenderer(hp, c2w, intr, tile_rays=args.render_tile_rays or None, block=block, fineness=fineness, use_graph=not args.render_eager,
+                               tile_width=args.render_tile_width if args.render_tile_rays else None, pipeline=args.render_pipeline or None,
+                               decoder_cus=args.render_decoder_cus, colour_x2=False)
+        tr.render_camera(int(cams[mine[0]]), H, W)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in mine:
+            f3 = tr.render_camera(int(cams[f]), H, W)
+        torch.cuda.synchronize()
+        x3_ms = (time.perf_counter() - t1) * 1e3 / mpix
+        x2_dist = dict(max_abs_rgb=float((f3["rgb"] - last["rgb"]).abs().max().item()),
+                       accumulation_and_depth_same_bits=bool(torch.equal(f3["accumulation"], last["accumulation"]) and torch.equal(f3["depth"], last["depth"])))
     return dict(metric="render_ms_per_mpix", value=dt * 1e3 / mpix, unit="ms/Mpix", frames=n_frames, frame=f"{W}x{H}", roofline=roof,
+                decoder=("split-f16 x3; colour head layer 2 on one f16 activation operand (colour_x2: density / accumulation / depth are the x3 form's bits)"
+                         if tr.colour_x2 or x3_ms is not None else "split-f16 x3"), x3_ms_per_mpix=x3_ms, colour_x2_vs_x3=x2_dist,
                 hbm_footprint_gb=None if fp is None else fp / 1e9, record_slots_per_ray=tr.rec_slots if getattr(tr, "record", False) else None,
                 record_pool_regrown=tr.pool_regrown,
                 ms_per_frame=dt * 1e3 / max(len(mine), 1), rays_per_sec=n_frames * H * W / dt, tile_rays=tr.T, hipgraph=tr.use_graph,
@@ -445,13 +469,13 @@ def render_roofline(hp, tr, c2w, intr, cam, H, W, block, fineness, s_per_frame, 
                 gather_note="16 levels x 8 corners per table and evaluated sample; the lanes of a patch want 0.09 distinct cells per sample and level "
                             "(tools/exp_patch_sharing.py) and a gather instruction costs its DISTINCT addresses (tools/gather_share.hip), so the nominal rate "
                             "exceeds the ceiling measured for distinct addresses: the kernel is bound by instruction issue, not by the gather path",
-                mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_per_tile=192,  # (216 until round 6: the image's embedding is folded into the head's bias)
-                mfma_tflops_issued=n_eval * 192 * 32768.0 / 32.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
+                mfma_tflops_useful=n_eval * 61952.0 / s_per_frame / 1e12, mfma_per_tile=160 if (tr.colour_x2 and block is not None) else 192,  # (216 until round 6: the image's embedding is folded into the head's bias; colour_x2: head layer 2 issues 64 instead of 96)
+                mfma_tflops_issued=n_eval * (160 if (tr.colour_x2 and block is not None) else 192) * 32768.0 / 32.0 / s_per_frame / 1e12, mfma_peak_tflops=2500.0,
                 mfma_busy_frac=pmc.get("mfma_busy:render") if fresh else None, valu_busy_frac=pmc.get("valu_busy:render") if fresh else None,
                 lockstep_efficiency=(n_eval / (pmc["decoded_samples_per_launch:render"] * H * W / pmc["tile_rays:render"])
                                      if fresh and pmc.get("decoded_samples_per_launch:render") and pmc.get("tile_rays:render") else None),  # useful samples /
                 # samples the lockstep patches decode (the counter run's launches are tiles of pmc["tile_rays:render"] rays)
-                kernel="fused_render_patch_kernel<1, 2, true, true, false, true>" if block is not None else "fused_render_patch_kernel<0, 2, true, true>",
+                kernel=("fused_render_patch_kernel<1, 2, true, true, %d, true>" % (8 if tr.colour_x2 else 0)) if block is not None else "fused_render_patch_kernel<0, 2, true, true>",
                 kernel_ms_per_tile=(pmc["kernel_ms:render"] * tr.T / pmc["tile_rays:render"] if fresh and pmc.get("kernel_ms:render") and pmc.get("tile_rays:render") else None),
                 note="rates over the whole frame time; counters from profiles/pmc_traffic.json only while csrc/fused_fwd.hip, x3_device.h, hash_device.h are the profiled ones")
 
@@ -777,7 +801,8 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
         if render_cams and "render" not in [k for x in recs for k in x]:  # the first seed's trained engine renders the headline record's frames
             try:
                 rr = render_bench(hp, sc, args, rec["focal"]["fineness"], torch, render_cams, 0)
-                rec["render"] = {k: rr[k] for k in ("value", "unit", "frames", "ms_per_frame", "tile_rays", "tiles_per_replay", "mean_accumulation", "fineness", "hbm_footprint_gb") if k in rr}
+                rec["render"] = {k: rr[k] for k in ("value", "unit", "frames", "ms_per_frame", "tile_rays", "tiles_per_replay", "mean_accumulation", "fineness", "hbm_footprint_gb",
+                                                    "decoder", "x3_ms_per_mpix", "colour_x2_vs_x3") if k in rr}
                 if rr.get("roofline"):
                     rec["render"].update(evaluated_frac=rr["roofline"]["evaluated_frac"], samples_per_ray=rr["roofline"]["sampled_per_frame"] / (1080 * 1920),
                                          evaluated_samples_per_frame=rr["roofline"]["evaluated_samples_per_frame"])
@@ -793,6 +818,7 @@ def trained_state_records(sc, args, torch, sync, seeds, steps_global, steps_foca
     rend = next((x["render"] for x in recs if "render" in x and "error" not in x["render"]), {})
     return dict(metric="train_rays_per_sec", unit="rays/s", value=slow["focal"]["rays_per_sec"], ms_per_step=slow["focal"]["ms_per_step"], seed=slow["seed"],
                 render_ms_per_mpix=rend.get("value"), render_evaluated_frac=rend.get("evaluated_frac"), render_samples_per_ray=rend.get("samples_per_ray"),
+                render_x3_ms_per_mpix=rend.get("x3_ms_per_mpix"), render_colour_x2_max_abs_rgb=(rend.get("colour_x2_vs_x3") or {}).get("max_abs_rgb"),
                 alive_sample_frac=slow["focal"]["alive_sample_frac"], evaluated_sample_frac=slow["focal"]["evaluated_sample_frac"],
                 two_phase_K=(slow["focal"]["two_phase"] or {}).get("K"), roofline_frac=slow["focal"]["roofline"]["frac"],
                 global_ms_per_step=slow_g["global"]["ms_per_step"], global_rays_per_sec=slow_g["global"]["rays_per_sec"],
@@ -1162,7 +1188,10 @@ def compact_line(out):
                            ("replicas_bit_identical", "replicas_bit_identical"), ("wgrad_operands", "global_wgrad_operands"), ("x3_ms_per_step", "global_x3_ms_per_step")))
     if out.get("n_gpus", 1) == 1:
         cfg.pop("global_launch", None)  # (the N > 1 line says whether the data-parallel step replays graph segments; at N = 1 it is "graph" like the headline)
-    hoist("render", (("value", "render_ms_per_mpix"),))
+    hoist("render", (("value", "render_ms_per_mpix"), ("x3_ms_per_mpix", "render_x3_ms_per_mpix")))
+    if isinstance(out.get("render"), dict) and isinstance(out["render"].get("colour_x2_vs_x3"), dict):
+        cfg["render_decoder"] = "x3 + colour_x2 (head layer 2: one f16 activation operand)"
+        cfg["render_colour_x2_max_abs_rgb"] = _r(out["render"]["colour_x2_vs_x3"]["max_abs_rgb"])
     if isinstance(out.get("render"), dict) and isinstance(out["render"].get("roofline"), dict):
         rr = out["render"]["roofline"]
         if rr.get("mfma_busy_frac") is not None:
@@ -1177,7 +1206,8 @@ def compact_line(out):
     hoist("trained_state", (("value", "trained_rays_per_sec"), ("ms_per_step", "trained_ms_per_step"), ("alive_sample_frac", "trained_alive_sample_frac"),
                             ("evaluated_sample_frac", "trained_evaluated_sample_frac"), ("two_phase_K", "trained_two_phase_K"),
                             ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step"),
-                            ("render_ms_per_mpix", "trained_render_ms_per_mpix"), ("render_evaluated_frac", "trained_render_evaluated_frac")))
+                            ("render_ms_per_mpix", "trained_render_ms_per_mpix"), ("render_evaluated_frac", "trained_render_evaluated_frac"),
+                            ("render_x3_ms_per_mpix", "trained_render_x3_ms_per_mpix"), ("render_colour_x2_max_abs_rgb", "trained_render_colour_x2_max_abs_rgb")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
     for k in ("mfma_busy_frac",):
         if out["roofline"].get(k) is not None:

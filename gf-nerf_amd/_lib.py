@@ -19,13 +19,13 @@ class WgradLayer(C.Structure):
 class LaunchOpts(C.Structure):
     """gfn_launch_opts (include/gfnerf_amd.h): the launch policy of ONE call (ops.launch_opts builds it)."""
     _fields_ = [("decoder_cus", C.c_int32), ("plain_rounding", C.c_int32), ("record_merge", C.c_int32), ("march_lanes", C.c_int32),
-                ("merge_front", _vp), ("merge_n", _vp), ("merge_frac", C.c_float), ("reserved", C.c_int32)]
+                ("merge_front", _vp), ("merge_n", _vp), ("merge_frac", C.c_float), ("colour_x2", C.c_int32)]
 
 
 MERGE_OFF, MERGE_ON, MERGE_DEVICE = 0, 1, 2  # GFN_MERGE_*
 _opts = C.POINTER(LaunchOpts)
 
-ABI_VERSION = 107  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
+ABI_VERSION = 108  # = GFN_ABI_VERSION of the include/gfnerf_amd.h the SIGNATURES below were written for; lib() refuses any other library
 
 # name -> (restype, argtypes); must list every function include/gfnerf_amd.h declares
 SIGNATURES = {

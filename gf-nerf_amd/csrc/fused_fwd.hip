@@ -311,12 +311,12 @@ constexpr int RENDER_THREADS = 512;  // two waves per SIMD: with 32-bit table / 
 // REC: the samples come from the march's records (32 bytes each, gfn_sample_rays_record) instead of the packed arrays a fill pass made of them
 // FOLD: the appearance embedding is the same for every ray (A.cam_uniform, or there is none): folded into head layer 1's bias once per workgroup
 // (decoder_tile<., EMB_FOLDED>)
-// X2: a measurement (GFN_RENDER_X2=1; VERDICT r05 #2's report): the decoder's activation operands as one f16 number each, two MFMAs per product sum
+// X2: a measurement (GFN_RENDER_X2=<layer mask>, x3_device.h X2_*; VERDICT r05 #2's report): those layers' activation operands as one f16 number each, two MFMAs per product sum
 // PLAIN: what the launch's pointers say is known at compile time -- no bias pool (rand_bias off) and, with two tables, the block table's own primes: the
 // per-level `pointer ? ... : ...` branches (wave-uniform, but each one ends a scheduling region and the slot copies for the shared-primes case are made
 // whether they are used or not) fold away: 4,423 -> 4,248 instructions in the kernel, 62 -> 38 basic blocks; its hashes keep xor and mask apart
 // (hash_corners_split above: with the two fused into v_bitop3_b32 this instantiation was not deterministic)
-template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD, bool X2 = false, bool PLAIN = false>
+template <int TAB, int RENDER_LEVELS, bool REC, bool FOLD, int X2 = 0, bool PLAIN = false>
 __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(FusedArgs A, LevelScales sc, int tile_w, int patch_w) {
   extern __shared__ __attribute__((aligned(16))) u32x4 L[];
   for (int e = threadIdx.x; e < GFN_FIELD_X3_FWD_BYTES / 16; e += blockDim.x) L[e] = A.image[e];
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
     if (KEEP_SH) {
       float x[8];
       load8(A.sh + (int64_t)ray * 16 + 8 * h, x);
-      if (X2) { rne8(x, sh_split[0]); sh_split[1] = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_split[0], sh_split[1]);
+      if (X2 & X2_H0) { rne8(x, sh_split[0]); sh_split[1] = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_split[0], sh_split[1]);
     }
     for (int k = 0; k < kmax; k++) {
       const bool act = k < cnt && !done;
@@ -472,7 +472,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void fused_render_patch_kernel(Fuse
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++) split8(x[u], xh[u], xl[u]);
+      for (int u = 0; u < 2; u++) {
+        if (X2 & X2_B0) { rne8(x[u], xh[u]); xl[u] = u32x4{0u, 0u, 0u, 0u}; }  // (to NEAREST: split8's hi half is rounded toward zero, its lo' makes up for it)
+        else split8(x[u], xh[u], xl[u]);
+      }
       // ---- decoder: the 32 rays' k-th samples are the tile's 32 rows
       if (A.exp & 1) __builtin_amdgcn_s_setprio(2);  // experiment: the wave in its matrix phase wins the issue arbitration
       const DecoderOut o = decoder_tile<PL_NONE, FOLD, X2>(Ihi, Ilo, bias, lane, xh, xl, sh_row, emb_row, nullptr, nullptr, 0, q, 1.f, KEEP_SH ? sh_split : nullptr);
@@ -628,23 +631,38 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
 #undef GFN_SET
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
-  const char* x2_env = getenv("GFN_RENDER_X2");  // (read per call: tools/exp_render_x2.py renders ONE engine both ways in one process)
-  const bool x2 = x2_env && atoi(x2_env) == 1;
-  if (x2 && fold && A.rec && levels == 2) {  // the measurement's form exists for the tile renderer's instantiation only
+  // The layers of the decoder whose activation operand is one f16 number (x3_device.h X2_*): gfn_launch_opts.colour_x2 asks for the colour head's layer 2
+  // (128 -> 128: half of the decoder's MFMAs; measured, tools/README.md round 6: 8 % of the frame time for <= 9e-5 on trained frames, where layers 2 AND 3 cost
+  // twice the distance for 2 % more); GFN_RENDER_X2=<mask> overrides it (a measurement, read per call: tools/exp_render_x2.py renders ONE engine every way in one process).  The
+  // forms exist for the tile renderer's instantiation (PLAIN) only: other launches run the x3 form whatever is asked
+  const char* x2_env = getenv("GFN_RENDER_X2");
+  const int x2 = x2_env ? atoi(x2_env) : ((opts && opts->colour_x2) ? X2_H1 : 0);
+#define GFN_X2_MASKS(X) X(1) X(2) X(4) X(8) X(16) X(24) X(28) X(31)
+  if (x2 != 0 && !bias_pool && table2_f16 && prim_pool2 && A.rec && fold && levels == 2) {
+    bool known = false;
+#define GFN_X2_KNOWN(M) known = known || x2 == M;
+    GFN_X2_MASKS(GFN_X2_KNOWN)
+#undef GFN_X2_KNOWN
+    GFN_CHECK_ARG(known, "%s: GFN_RENDER_X2=%d is not one of the instantiated layer masks (1 2 4 8 16 24 28 31)", who, x2);
     static unsigned long long x2_seen = 0;
     if (gfn_first_call_on_device(x2_seen)) {
-      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<0, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+#define GFN_X2_SET(M) \
+      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, M, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      GFN_X2_MASKS(GFN_X2_SET)
+#undef GFN_X2_SET
     }
     fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
     GFN_CHECK_LAUNCH();
     int64_t xb = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);
     if (xb > gfn_decoder_cu_cap(opts)) xb = gfn_decoder_cu_cap(opts);
-    if (table2_f16) fused_render_patch_kernel<1, 2, true, true, true><<<(unsigned)xb, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
-    else fused_render_patch_kernel<0, 2, true, true, true><<<(unsigned)xb, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+#define GFN_X2_LAUNCH(M) \
+    if (x2 == M) fused_render_patch_kernel<1, 2, true, true, M, true><<<(unsigned)xb, RENDER_THREADS, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+    GFN_X2_MASKS(GFN_X2_LAUNCH)
+#undef GFN_X2_LAUNCH
     GFN_CHECK_LAUNCH();
     return GFN_OK;
   }
+#undef GFN_X2_MASKS
   fused_init_kernel<<<1, 1, 0, st>>>(work_counter, t_minmax);
   GFN_CHECK_LAUNCH();
   int64_t blocks = (n_rays / 32 + RENDER_THREADS / 64 - 1) / (RENDER_THREADS / 64);  // one patch at a time per wave
@@ -659,9 +677,9 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   if (plain) {
     static unsigned long long plain_seen = 0;
     if (gfn_first_call_on_device(plain_seen)) {
-      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+      GFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_render_patch_kernel<1, 2, true, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
     }
-    fused_render_patch_kernel<1, 2, true, true, false, true><<<(unsigned)blocks, threads, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
+    fused_render_patch_kernel<1, 2, true, true, 0, true><<<(unsigned)blocks, threads, FUSED_LDS_BYTES, st>>>(A, sc, tile_width, patch_width);
     GFN_CHECK_LAUNCH();
     return GFN_OK;
   }

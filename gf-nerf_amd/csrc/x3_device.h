@@ -273,7 +273,12 @@ struct DecoderOut {
 // EMB_FOLDED (inference, round 6): the appearance part of head layer 1 -- W_h0[:, 31:63] emb(cam), the same 128 numbers for every sample of every ray of a
 // frame (one camera per image: perssampler.py:431-433) -- already sits in the layer's bias (fold_embedding_into_bias, once per workgroup), so the layer runs
 // its geo and SH k-steps only: 24 of the tile's 216 MFMAs, two operand loads + splits and eight weight-fragment reads less per 32 samples.
-template <int PLANES, bool EMB_FOLDED = false, bool X2 = false>
+// X2 (inference only; 0 = the split-f16 x3 form everywhere): a mask of the layers whose ACTIVATION operand is one f16 number (rounded to nearest; the
+// weights stay split), i.e. two MFMAs per product sum instead of three and no lo' half to make -- X2_B0 base layer 1 (the hash features), X2_B1 base layer 2,
+// X2_H0 head layer 1 (geo | SH), X2_H1 head layer 2, X2_H2 head layer 3.  The two base layers and head layer 1's geo input feed the DENSITY (h0 -> exp);
+// head layers 2 and 3 only the colour behind its sigmoid.
+constexpr int X2_B0 = 1, X2_B1 = 2, X2_H0 = 4, X2_H1 = 8, X2_H2 = 16, X2_ALL = 31;
+template <int PLANES, bool EMB_FOLDED = false, int X2 = 0>
 __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi, const u32x4* __restrict__ Ilo, const float* __restrict__ bias,
                                                    int lane, const u32x4 (&xh)[2], const u32x4 (&xl)[2], const float* __restrict__ sh_row,
                                                    const float* __restrict__ emb_row, uint16_t* __restrict__ planes_hi,
@@ -298,14 +303,14 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
       acc_init_bias(a, bias_h, Bb0, ot);
-      mma3p<X2>(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
-      mma3p<X2>(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
+      mma3p<(X2 & X2_B0) != 0>(a, w, Ihi, Ilo, C_B0 + 4 + ot, lane, xh[0], xl[0]);
+      mma3p<(X2 & X2_B0) != 0>(a, w, Ihi, Ilo, C_B1 + 2 * ot, lane, xh[1], xl[1]);
       Frag a1;
       const PlaneDst pd{FPL(hi, FP_A1), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE, X2>(a, a1, m_a1, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, (X2 & X2_B1) != 0>(a, a1, m_a1, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_A1), FPL(lo, FP_A1), 128, q, 32 * ot, a1, h);
-      mma3p<X2>(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
-      mma3p<X2>(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
+      mma3p<(X2 & X2_B1) != 0>(hh, w, Ihi, Ilo, C_B1 + 2 * ot + 1, lane, a1.hi[0], a1.lo[0]);
+      mma3p<(X2 & X2_B1) != 0>(hh, w, Ihi, Ilo, ot < 3 ? C_B0 + ot + 1 : C_H0, lane, a1.hi[1], a1.lo[1]);
     }
     out.h0 = acc_get(hh, 0);            // row 0 = density channel: register 0 of the h=0 lanes
     out.sigma = expf(out.h0 + 1.0f);    // trunc_exp(h0 + 1), nerfacto_field.py:499
@@ -314,7 +319,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       float v[8];
 #pragma unroll
       for (int r = 0; r < 8; r++) v[r] = acc_get(hh, r);
-      if (X2) { rne8(v, gh); gl = u32x4{0u, 0u, 0u, 0u}; } else split8(v, gh, gl);
+      if (X2 & X2_H0) { rne8(v, gh); gl = u32x4{0u, 0u, 0u, 0u}; } else split8(v, gh, gl);
       if (PLANES == PL_SPLIT) store_half_tile(FPL(hi, FP_XP), FPL(lo, FP_XP), 64, q, 0, gh, gl, h);
       if (PLANES == PL_RNE) { u32x4 r; rne8(v, r, pc); store_half_tile_rne(FPL(hi, FP_XP), 64, q, 0, r, h); }
     }
@@ -323,7 +328,7 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     {
       float x[8];
       if (PLANES == PL_NONE && sh_split) { sh_h = sh_split[0]; sh_l = sh_split[1]; }
-      else { load8(sh_row + 8 * h, x); if (X2) { rne8(x, sh_h); sh_l = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_h, sh_l); }
+      else { load8(sh_row + 8 * h, x); if (X2 & X2_H0) { rne8(x, sh_h); sh_l = u32x4{0u, 0u, 0u, 0u}; } else split8(x, sh_h, sh_l); }
       if (PLANES == PL_RNE) { u32x4 r; rne8(x, r, pc); store_nat_rne(FPL(hi, FP_XP), 64, q, 16, r, h); }
       if (EMB_FOLDED) {
       } else if (emb_row) {
@@ -353,16 +358,17 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
     for (int ot = 0; ot < 4; ot++) {
       Acc2 a;
       acc_init_bias(a, bias_h, Bh0, ot);
-      mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
+      constexpr bool x2h0 = (X2 & X2_H0) != 0;
+      mma3p<x2h0>(a, w, Ihi, Ilo, C_H0 + 1 * 4 + ot, lane, gh, gl);
       if (EMB_FOLDED) {
-        mma3p<X2>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, sh_h, sh_l);
+        mma3p<x2h0>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, sh_h, sh_l);
       } else {
-        mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
-        mma3p<X2>(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
-        mma3p<X2>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
+        mma3p<x2h0>(a, w, Ihi, Ilo, C_H0 + 2 * 4 + ot, lane, sh_h, sh_l);
+        mma3p<x2h0>(a, w, Ihi, Ilo, C_H0 + 3 * 4 + ot, lane, e_h[0], e_l[0]);
+        mma3p<x2h0>(a, w, Ihi, Ilo, ot < 3 ? C_H0 + ot + 1 : C_H1, lane, e_h[1], e_l[1]);
       }
       const PlaneDst pd{FPL(hi, FP_C1), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE, X2>(a, c1[ot], m_c1, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, (X2 & X2_H1) != 0>(a, c1[ot], m_c1, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C1), FPL(lo, FP_C1), 128, q, 32 * ot, c1[ot], h);
     }
     // ---- head layer 2: 128 -> 128, ReLU, feeding head layer 3: 128 -> 3 (padded), sigmoid
@@ -374,13 +380,13 @@ __device__ __forceinline__ DecoderOut decoder_tile(const u32x4* __restrict__ Ihi
       Acc2 a;
       acc_init_bias(a, bias_h, Bh1, ot);
 #pragma unroll
-      for (int u = 0; u < 8; u++) mma3p<X2>(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
+      for (int u = 0; u < 8; u++) mma3p<(X2 & X2_H1) != 0>(a, w, Ihi, Ilo, u < 7 ? C_H1 + (u + 1) * 4 + ot : C_H2 + 2 * ot, lane, c1[u >> 1].hi[u & 1], c1[u >> 1].lo[u & 1]);
       Frag c2;
       const PlaneDst pd{FPL(hi, FP_C2), 128, q, 32 * ot, h, pc, true};
-      tile_to_frag<true, PLANES == PL_RNE, X2>(a, c2, m_c2, ot, &pd);
+      tile_to_frag<true, PLANES == PL_RNE, (X2 & X2_H2) != 0>(a, c2, m_c2, ot, &pd);
       if (PLANES == PL_SPLIT) store_tile(FPL(hi, FP_C2), FPL(lo, FP_C2), 128, q, 32 * ot, c2, h);
-      mma3p<X2>(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
-      mma3p<X2>(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
+      mma3p<(X2 & X2_H2) != 0>(o3, w, Ihi, Ilo, C_H2 + 2 * ot + 1, lane, c2.hi[0], c2.lo[0]);
+      mma3p<(X2 & X2_H2) != 0>(o3, w, Ihi, Ilo, ot < 3 ? C_H1 + ot + 1 : -1, lane, c2.hi[1], c2.lo[1]);
     }
     out.r = 1.f / (1.f + expf(-acc_get(o3, 0)));  // rows 0..2 = registers 0..2 of the h=0 lanes
     out.g = 1.f / (1.f + expf(-acc_get(o3, 1)));

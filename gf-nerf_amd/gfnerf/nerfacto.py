@@ -92,6 +92,8 @@ class GFNeRFModelConfig(ModelConfig):
     wgrad_planes: str = "rne"           # HotPathConfig.wgrad_planes: operands of the decoder's weight gradient (global stage): "rne" one f16 plane each under
                                         # a per-sample dither (f64 bar 1e-4 of max |dW|), "x3" hi + lo' planes (f32-class per term), "mixed"
     record_capacity: int = 0            # HotPathConfig.record_capacity (8-byte gradient-record slots; 0: the engine's default, capped at 2048 per stream)
+    render_colour_x2: bool = True       # HotPathConfig.render_colour_x2: full-image inference with the colour head's layer 2 on a one-f16 activation operand
+                                        # (faster; density / accumulation / depth unchanged bit for bit, rgb within that layer's f16 rounding)
     render_tile_rays: int = 0           # rays per hipGraph-captured inference tile (get_outputs_for_camera_ray_bundle); 0 = a block of
                                         # ~128 Ki rays that divides the image (gfnerf_amd.render.choose_tile)
 
@@ -294,7 +296,7 @@ class GFNeRFModel(Model):
         assert c.hidden_dim == c.hidden_dim_color, "the fused decoder uses one hidden width (gfnerf/config.py:124-125: 128 / 128)"
         cfg = hp_mod.HotPathConfig(log2_T=c.log2_hashmap_size, hidden=c.hidden_dim, scale_factor=c.scale_factor, early_T=c.early_T,
                                    use_appearance_embedding=c.use_appearance_embedding, s3im_loss_mult=c.s3im_loss_mult,
-                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time, wgrad_planes=c.wgrad_planes,
+                                   s3im_patch_height=c.s3im_patch_height, s3im_repeat_time=c.s3im_repeat_time, wgrad_planes=c.wgrad_planes, render_colour_x2=c.render_colour_x2,
                                    **({"record_capacity": c.record_capacity} if c.record_capacity > 0 else {}),
                                    record_merge_dense=True)  # (dense focal batches merge their record runs, decided on the device: HotPath._merge_gate)
         self.hot = hp_mod.HotPath(nat.tree_nodes_gpu_, nat.pers_trans_gpu_, n_cams=self.num_train_data, cfg=cfg, device=dev,

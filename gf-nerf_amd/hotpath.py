@@ -57,6 +57,10 @@ class HotPathConfig:
     lm_split_log2: int = 0           # ... of 2^this parts per level (0 = 1: halves; 2: quarters, no gain inside the step)
     render_patch_width: int = 8      # inference (TileRenderer): patches of this x 32/this neighbouring pixels walked in lockstep by one wave
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
+    render_colour_x2: bool = True    # inference (TileRenderer): the colour head's layer 2 (128 -> 128) with a one-f16 activation operand (ops.launch_opts(colour_x2=True):
+                                     # two MFMAs per product instead of three; density, accumulation and depth unchanged bit for bit, rgb by that layer's f16
+                                     # rounding -- DESIGN.md section 4 has the measured distance (<= 1e-4 on full-HD frames of trained scenes, 2.3e-4 the
+                                     # worst case met: north_star's bar is 1e-3) and time (-8 %); False: the x3 form throughout
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
                                      # hipGraph replay per (stage, block, buffer) after three eager runs: ~25 launches less for the host
     graph_forward_shared_pool: bool = True  # the captured forwards share one memory pool (their transient buffers overlap; replays are sequential)

@@ -49,12 +49,14 @@ def _chk(t, dtype, name, shape_last=None):
         raise _lib.GfnError(f"{name}: last dimension must be {shape_last}, got {tuple(t.shape)}")
 
 
-def launch_opts(decoder_cus=0, plain_rounding=False, record_merge=_lib.MERGE_OFF, march_lanes=0, merge_gate=None):
+def launch_opts(decoder_cus=0, plain_rounding=False, record_merge=_lib.MERGE_OFF, march_lanes=0, merge_gate=None, colour_x2=False):
     """gfn_launch_opts for ONE call (include/gfnerf_amd.h): the library keeps no launch policy of its own -- whoever launches says how.
     decoder_cus: cap on the persistent kernels' workgroups (0: every CU); plain_rounding: one-plane producers without their dither;
     record_merge: _lib.MERGE_OFF / MERGE_ON, or merge_gate = (front count i32 [1], sample count i32 [1], frac): MERGE_DEVICE, the device picks
-    the form from the step's own counts; march_lanes: 0 (by batch size), 4 or 16.  The returned struct keeps the gate's tensors alive."""
+    the form from the step's own counts; march_lanes: 0 (by batch size), 4 or 16; colour_x2: the inference kernel's colour head layer 2 with a one-f16
+    activation operand (fused_render on march records, tile renderer's form; density path unchanged).  The returned struct keeps the gate's tensors alive."""
     o = _lib.LaunchOpts()
+    o.colour_x2 = int(bool(colour_x2))
     o.decoder_cus = int(decoder_cus) if 0 < int(decoder_cus) < 256 else 0
     o.plain_rounding = int(bool(plain_rounding))
     o.march_lanes = int(march_lanes)

@@ -54,7 +54,7 @@ class TileRenderer:
     PATCH_MIN_RAYS = 32768  # below ~1 patch of 32 rays per SIMD the patch kernel starves: small tiles keep the wave-per-ray kernel
 
     def __init__(self, hp, c2w, intr, tile_rays=None, block=None, fineness=1.0, early_T=None, use_graph=True, tile_width=None,
-                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128):
+                 pipeline=None, decoder_cus=224, rec_slots=224, hit_cap=128, colour_x2=None):
         """hp: HotPath; c2w f32 [n_cams,3,4] and intr f32 [n_cams,4] = (fx, fy, cx, cy) device tensors of the path's
         cameras; block: focal block table to add (None = global table only); fineness: ray-march fineness of the
         validation mode (rays_noise = ones * fineness, PersSampler_cuda.cu:381-388).
@@ -66,7 +66,10 @@ class TileRenderer:
         frame whose tiles need more is rendered again with a pool half as large again (checked once per frame); 0 or >= 1024: the dense form.
         hit_cap: leaves per ray of the pipeline's hit lists (12 bytes each; the reference's cap, cfg.max_oct_per_ray = 1024, is 12 KB per ray,
         6.4 GB for a 518 k-ray tile, where a ray crosses a few dozen leaves): a frame in which a ray reaches the cap is rendered again with four
-        times the cap, up to the reference's -- whose truncation is then the semantics."""
+        times the cap, up to the reference's -- whose truncation is then the semantics.
+        colour_x2: the inference kernel's colour head layer 2 with a one-f16 activation operand (gfn_launch_opts.colour_x2: faster, rgb moves by that layer's
+        f16 rounding, density / accumulation / depth do not move at all); None = the engine's HotPathConfig.render_colour_x2."""
+        self.colour_x2 = bool(hp.cfg.render_colour_x2 if colour_x2 is None else colour_x2)
         self.hit_cap = max(int(hit_cap), 1)
         self.rec_slots = int(rec_slots) if 0 < int(rec_slots) < 1024 else 0
         self.pool_regrown = 0  # how often a frame had to be rendered again with a larger record pool
@@ -135,7 +138,7 @@ class TileRenderer:
             if self.record:  # the same paged records and hit-list cap as the pipeline's tiles (the memory budget of _setup counts on it)
                 s = hp.sample(self.o[0], self.d[0], self.noise, record=True, pool_slots_per_ray=self.rec_slots, max_hits=self.hit_cap)
             out = hp.render(self.o[0], self.d[0], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=s, tile_width=self.patch_tw,
-                            cam_uniform=True)  # (self.cam holds ONE camera: the image's)
+                            opts=ops.launch_opts(colour_x2=self.colour_x2), cam_uniform=True)  # (self.cam holds ONE camera: the image's)
             if s is not None:
                 torch.bitwise_or(self._stat, s["overflow"], out=self._stat)
                 self._keep = [s]
@@ -197,7 +200,7 @@ class TileRenderer:
         main.wait_event(done[i])
         # (the inference kernel's grid is capped -- baked into the captured launch -- so that the next tile's sampler finds free CUs)
         out = hp.render(self.o[i], self.d[i], self.cam, self.noise, block=self.block, early_T=self.early_T, samples=samples[i], tile_width=self.patch_tw,
-                        opts=ops.launch_opts(decoder_cus=self.decoder_cus), cam_uniform=True)
+                        opts=ops.launch_opts(decoder_cus=self.decoder_cus, colour_x2=self.colour_x2), cam_uniform=True)
         outs.append((out["rgb"], out["accumulation"], out["depth"], out["oct_depth"]))
         if self.record:
             torch.bitwise_or(self._stat, samples[i]["overflow"], out=self._stat)

@@ -58,8 +58,9 @@ typedef enum {
  *   points that read it (gfn_hash_fwd_lm, gfn_sample_rays, gfn_sample_rays_record, gfn_field_fwd_x3, gfn_field_bwd_dx_x3,
  *   gfn_field_bwd_x3, gfn_field_bwd_scatter_x3, gfn_fused_forward, gfn_fused_render, gfn_fused_render_rec); the two-phase inference
  *   march is gone too (gfn_sample_rays_continue and those arguments: a 6 % gain on a random-init scene, a 3x loss on a trained one);
- *   gfn_train_losses, gfn_loss_grad_combine added; gfn_fused_render(_rec) gained cam_uniform. */
-#define GFN_ABI_VERSION 107
+ *   gfn_train_losses, gfn_loss_grad_combine added; gfn_fused_render(_rec) gained cam_uniform.
+ *   108: round 6 -- gfn_launch_opts.reserved became colour_x2 (same size and offsets: a 107 caller's zeroed word is the default). */
+#define GFN_ABI_VERSION 108
 
 const char* gfn_last_error(void);
 int gfn_version(void);
@@ -84,7 +85,16 @@ int gfn_version(void);
  *                 eagerly launched one decide alike.
  *   march_lanes   lanes per ray of the samplers' march: 16 (a row per ray: batches that leave the machine empty), 4 (a quad: a
  *                 quarter of the vector work per ray), 0 = by batch size (a quad from 32 Ki rays on; GFN_MARCH_LANES in the
- *                 environment, read once, overrides that).  Both give the same bits. */
+ *                 environment, read once, overrides that).  Both give the same bits.
+ *   colour_x2     gfn_fused_render_rec in the tile renderer's form (two tables with their own primes, no bias pool, the embedding folded:
+ *                 cam_uniform or none): != 0: the colour head's layer 2 (128 -> 128, half of the decoder's MFMAs; behind head layer 1, two
+ *                 layers in front of the sigmoid) takes its ACTIVATION operand as one f16 number, rounded to nearest, instead of the
+ *                 split pair hi + lo' -- two MFMAs per product sum instead of three and no lo' half to make (csrc/x3_device.h X2_H1).
+ *                 Everything the DENSITY depends on (hash features, base network, head layer 1's geo input) keeps the split-f16 x3
+ *                 form: sigma, accumulation, depth and every ray's termination point are the same bits either way; rgb moves by
+ *                 that layer's f16 rounding (measured: DESIGN.md section 4; <= 1e-4 on full-HD frames of trained scenes).  Other
+ *                 forms of the launch ignore it.  GFN_RENDER_X2=<layer mask> in the environment (read per call; a measurement,
+ *                 tools/exp_render_x2.py) overrides it; 0 there forces the x3 form. */
 #define GFN_MERGE_OFF 0
 #define GFN_MERGE_ON 1
 #define GFN_MERGE_DEVICE 2
@@ -96,7 +106,7 @@ typedef struct gfn_launch_opts {
   const int32_t* merge_front;
   const int32_t* merge_n;
   float merge_frac;
-  int32_t reserved;
+  int32_t colour_x2;
 } gfn_launch_opts; /* 40 B */
 /* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only host). */
 int gfn_device_count(void);

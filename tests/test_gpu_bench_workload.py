@@ -521,7 +521,9 @@ def test_bench_scene_full_frame_tile_render(world, oracle):
       * a run of 32 pixels across the corner (row 540, columns 944..975: two tiles, the first row of the second tile row) against the CPU
         oracle pipeline: rgb within 1e-3 abs (north_star's bar), accumulation 1e-4;
       * a second camera through the same captured graph: the same run against a direct render;
-      * the frame rendered three more times: the same bits (round 6).
+      * the frame rendered three more times: the same bits (round 6);
+      * the renderer's default form (colour_x2: head layer 2 on one f16 activation operand): accumulation and depth the same bits, rgb within 2e-5 of the x3
+        frame on this random-init scene and within 1e-3 of the oracle on the same run (a trained scene: tests/test_gpu_pipeline.py::test_colour_x2_...).
     Reference: Model.get_outputs_for_camera_ray_bundle, nerfstudio/models/base_model.py:163-186."""
     import torch
 
@@ -536,7 +538,7 @@ def test_bench_scene_full_frame_tile_render(world, oracle):
     zoom = W / 1152.0
     intr = _t(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1).astype(np.float32))
     fin = S["fineness"]
-    tr = rmod.TileRenderer(hp, c2w, intr, block=0, fineness=fin, use_graph=True)
+    tr = rmod.TileRenderer(hp, c2w, intr, block=0, fineness=fin, use_graph=True, colour_x2=False)  # (the x3 form: compared with other kernels to 2e-6 below)
     cam0 = 37
     img = tr.render_camera(cam0, H, W)
     tw, th = tr.tw, tr.T // tr.tw
@@ -587,4 +589,20 @@ def test_bench_scene_full_frame_tile_render(world, oracle):
     assert float((img1["rgb"][y, x0:x0 + 32] - ref1["rgb"]).abs().max()) <= 2e-6
     assert float((img1["rgb"] - rgb).abs().mean()) > 1e-3  # and it is another picture
     del tr
+    torch.cuda.empty_cache()
+
+    # the renderer's DEFAULT form (HotPathConfig.render_colour_x2, ABI 108): the colour head's layer 2 on one f16 activation operand.  Nothing the density
+    # depends on moves -- accumulation and depth are the x3 frame's bits --, rgb stays within a third of north_star's bar of the x3 frame (here, on the
+    # random-init scene: within 2e-5) and within the bar of the oracle on the same 32 pixels; the same bits when rendered again
+    assert hp.cfg.render_colour_x2
+    tr2 = rmod.TileRenderer(hp, c2w, intr, block=0, fineness=fin, use_graph=True)
+    assert tr2.colour_x2
+    img2 = tr2.render_camera(cam0, H, W)
+    assert torch.equal(img2["accumulation"], first["accumulation"]) and torch.equal(img2["depth"], first["depth"])
+    d2 = (img2["rgb"] - first["rgb"]).abs()
+    assert 0.0 < float(d2.max()) <= 2e-5, float(d2.max())
+    np.testing.assert_allclose(img2["rgb"][y, x0:x0 + 32].cpu().numpy(), ref["rgb"], atol=1e-3)
+    keep = img2["rgb"].clone()
+    assert torch.equal(tr2.render_camera(cam0, H, W)["rgb"], keep)
+    del tr2
     torch.cuda.empty_cache()

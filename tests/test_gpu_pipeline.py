@@ -837,7 +837,7 @@ def test_tile_pipeline_without_the_patch_kernel(setup, variant):
     over = dict(patch_width_0=dict(render_patch_width=0), f32_decoder=dict(mlp_precision="f32"), unfused_forward=dict(fused_forward=False))[variant]
     imgs = {}
     for name, kw in (("default", {}), (variant, over)):
-        cfg = dataclasses.replace(S["cfg"], **kw)
+        cfg = dataclasses.replace(S["cfg"], render_colour_x2=False, **kw)  # (x3 throughout: the two kernels are compared to 2e-5; colour_x2 has its own test)
         hp = hotpath.HotPath(sc["nodes"], sc["transes"], n_cams=sc["c2w"].shape[0], cfg=cfg, seed=1, n_blocks=1)
         hp.table.mul_(30.0); hp.blocks[0].normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(5)); hp.refresh_shadows()
         tr = rmod.TileRenderer(hp, c2w, intr2, tile_rays=32768, tile_width=128, block=0, fineness=5.0, early_T=1e-4, pipeline=2)
@@ -1477,6 +1477,59 @@ def test_psnr_of_the_product_against_the_reference_semantics():
             assert v["cos"] >= 0.99999 and v["rel_diff"] <= 3e-3, (stage, step, g, v)
         for g, v in pairs["exact|fast"].items():    # with the cut: the <= 1e-4 colour change flips Charbonnier's sign-like gradient on the few rays at |error| < 1e-4
             assert v["cos"] >= 0.995, (stage, step, g, v)
+    torch.cuda.empty_cache()
+
+
+def test_colour_x2_render_moves_the_colour_only():
+    """gfn_launch_opts.colour_x2 (ABI 108; HotPathConfig.render_colour_x2 / TileRenderer(colour_x2=True)): the inference kernel with the colour head's
+    layer 2 -- 128 -> 128, half of the decoder's MFMAs, behind head layer 1 and two layers in front of the sigmoid -- on ONE f16 activation operand (round to
+    nearest) instead of the split pair: two MFMAs per product sum, no lo' half to make.  On an engine TRAINED on the procedural terrain (short: 1,500 + 400
+    steps) and a COARSE march (fineness 8: few samples per ray, so a sample's colour error reaches the pixel almost undiluted -- the worst case met; full-HD
+    frames at 192 samples per ray of fully trained engines are at 9e-5, tools/exp_render_x2.py), two cameras, 960 x 540 frames through the tile renderer (the
+    patch kernel on the march's records, the form bench.py times):
+      * nothing the density depends on is touched: accumulation and depth are the SAME BITS as the x3 form's;
+      * rgb moves, and by no more than a third of north_star's 1e-3 bar ("do not switch the default unless the margin to 1e-3 is >= 3 x");
+      * either form renders the same bits twice.
+    Reference: the decoder of gfnerf/nerfacto_field.py:509-555 behind Model.get_outputs_for_camera_ray_bundle, nerfstudio/models/base_model.py:163-186."""
+    import os
+
+    import torch
+
+    import gfnerf_amd  # noqa: F401
+    from gfnerf_amd import procedural, scene
+    from gfnerf_amd import render as rmod
+
+    sc = scene.build_scene(n_side=40, max_depth=16, seed=1234, cache_dir=os.path.join(os.environ.get("TMPDIR", "/tmp"), "gfnerf_amd_scene"))
+    r = procedural.train_and_eval(sc, seed=0, steps_global=1500, steps_focal=400, eval_rays=4096, detail=procedural.STUDY_DETAIL, lr_final=procedural.STUDY_LR_FINAL,
+                                  keep_engine=True, **procedural.LEGS["fast"])
+    assert r["psnr"] > 24.0, r["psnr"]  # a trained scene: surfaces and free space, weights far from their initialisation
+    hp = r["engine"]
+    H, W = 540, 960
+    c2w = torch.from_numpy(sc["c2w"]).cuda()
+    K = sc["intri"]
+    zoom = W / 1152.0
+    intr = torch.from_numpy(np.stack([K[:, 0, 0] * zoom, K[:, 1, 1] * zoom, np.full(K.shape[0], W / 2), np.full(K.shape[0], H / 2)], -1).astype(np.float32)).cuda()
+    assert os.environ.get("GFN_RENDER_X2") is None  # (the measurement switch would override the argument)
+    worst = 0.0
+    for cam in (37, 74):
+        frames = {}
+        for x2 in (False, True):
+            tr = rmod.TileRenderer(hp, c2w, intr, block=0, fineness=8.0, colour_x2=x2)
+            out = tr.render_camera(cam, H, W)
+            assert tr.record and tr.patch_tw  # the patch kernel on the march's records
+            frames[x2] = {k: out[k].clone() for k in ("rgb", "accumulation", "depth")}
+            again = tr.render_camera(cam, H, W)
+            for k, v in frames[x2].items():
+                assert torch.equal(again[k], v), (cam, x2, k)
+            del tr
+            torch.cuda.empty_cache()
+        assert float(frames[False]["accumulation"].mean()) > 0.3
+        assert torch.equal(frames[True]["accumulation"], frames[False]["accumulation"]) and torch.equal(frames[True]["depth"], frames[False]["depth"]), cam
+        d = (frames[True]["rgb"] - frames[False]["rgb"]).abs()
+        print(f"camera {cam}: |rgb_x2 - rgb_x3| max {float(d.max()):.2e} mean {float(d.mean()):.2e}")
+        assert 0.0 < float(d.max()) <= 1e-3 / 3, (cam, float(d.max()))
+        worst = max(worst, float(d.max()))
+    del hp, r
     torch.cuda.empty_cache()
 
 

@@ -12,7 +12,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
 COMMON="--no-cpu-baseline --render-frames 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --global-x3-steps 0"
-RENDER="--steps 2 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --global-x3-steps 0 --render-frames 1 --render-eager"
+RENDER="--steps 2 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --global-x3-steps 0 --render-frames 1 --render-eager --no-render-x3"
 if [ "$MODE" = "traces" ]; then
   timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err
   grep "bench-details" $O/bench.err | sed 's/^\[bench-details\] //' > $O/bench_details.json
@@ -22,7 +22,7 @@ if [ "$MODE" = "traces" ]; then
   echo "kt focal graph done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_global_graph -- python3 $B --steps 60 --warmup 60 $COMMON --stage global > $O/global_graph_under_rocprof.json 2>$O/kt_global_graph.err
   echo "kt global graph done"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 --no-render-x3 > $O/render_under_rocprof.json 2>$O/kt_render.err
   echo "kt render done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render_eager -- python3 $B $RENDER > $O/render_eager_under_rocprof.json 2>$O/kt_render_eager.err
   echo "kt render eager done"
@@ -38,7 +38,7 @@ elif [ "$MODE" = "render_traces" ]; then
   grep "bench-details" $O/bench.err | sed 's/^\[bench-details\] //' > $O/bench_details.json
   echo "bench done"
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 > $O/render_under_rocprof.json 2>$O/kt_render.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --global-steps 0 --plugin-steps 0 --psnr-steps 0,0 --trained-seeds= --rays8192-steps 0 --render-frames 2 --no-render-x3 > $O/render_under_rocprof.json 2>$O/kt_render.err
   echo "kt render done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render_eager -- python3 $B $RENDER > $O/render_eager_under_rocprof.json 2>$O/kt_render_eager.err
   echo "kt render eager done"

@@ -84,7 +84,8 @@ j["mfma_busy:render"] = round(fv("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles, 4)
 j["valu_busy:render"] = round(4.0 * fv("SQ_ACTIVE_INST_VALU") / simd_cycles, 4)  # SQ_ACTIVE_INST_* count quad-cycles
 j["wait_frac:render"] = round(fv("SQ_WAIT_INST_ANY") / fv("SQ_WAVE_CYCLES"), 4)
 j["mfma_valu_coexec_frac:render"] = round(fv("SQ_VALU_MFMA_COEXEC_CYCLES") / fv("SQ_VALU_MFMA_BUSY_CYCLES"), 4)
-MFMA_PER_TILE = 192.0 if int(TAG[1:]) >= 6 else 216.0  # MFMAs per 32-sample tile of the inference decoder (round 6: the image's embedding folded into the bias, 24 less)
+MFMA_PER_TILE = 160.0 if int(TAG[1:]) >= 6 else 216.0  # MFMAs per 32-sample tile of the inference decoder (round 6: the image's embedding folded into the bias, 24 less;
+                                                       # colour_x2, the renderer's default: head layer 2 issues 64 instead of 96)
 j["decoded_samples_per_launch:render"] = int(round(fv("SQ_INSTS_MFMA") / MFMA_PER_TILE * 32.0))
 j["mfma_per_tile:render"] = MFMA_PER_TILE
 # (per-launch figures belong to the tile the eager run rendered: the renderer's default for a full-HD frame, bench.py scales by its own tile)
