@@ -1,6 +1,7 @@
 # round-6 profile collection, two gpurun calls (a call lasts 20 minutes at most):
 #   bash tools/r06_profiles.sh traces   the bench line + kernel-trace stats (focal / global graph launch, render graph + eager, the plugin-surface step)
-#   bash tools/r06_profiles.sh render_traces | pmc_render   after a change to csrc/fused_fwd.hip alone: the bench line + the two render traces | the inference kernel's counter passes
+#   bash tools/r06_profiles.sh render_traces | pmc_render | busy   after a change to csrc/fused_fwd.hip / x3_device.h's inference parts alone: the bench line + the two render
+#                                       traces | the inference kernel's counter passes | the decoder kernels' occupancy passes (then: sync_profiles.py gpurun_out/r06p r06 render)
 #   bash tools/r06_profiles.sh pmc      separate --pmc passes (one counter group each; never together with a trace: MI355X guide) for the focal step and
 #                                       the global step; pmc_render: the inference kernel's (tiles rendered eagerly: --render-eager); pmc_all: both
 # Everything is addressed through $GRAFT_REPO_ROOT (the r03 script mixed it with /root/repo).
@@ -42,6 +43,14 @@ elif [ "$MODE" = "render_traces" ]; then
   echo "kt render done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_render_eager -- python3 $B $RENDER > $O/render_eager_under_rocprof.json 2>$O/kt_render_eager.err
   echo "kt render eager done"
+elif [ "$MODE" = "busy" ]; then
+  # the decoder kernels' matrix-pipe occupancy in the focal and the global step alone (after a change to csrc/x3_device.h that leaves their code as it was)
+  cd /tmp
+  C="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; T=$(echo $C | tr ' ' '_')
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc_focal_$T -- python3 $B --steps 3 --warmup 2 $COMMON --global-steps 0 --launch eager > $O/pmc_focal_$T.json 2>$O/pmc_focal_$T.err || echo "pmc $T failed"
+  echo "pmc focal $T done"
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc_global_$T -- python3 $B --steps 3 --warmup 58 $COMMON --stage global --launch eager > $O/pmc_global_$T.json 2>$O/pmc_global_$T.err || echo "pmc global $T failed"
+  echo "pmc global $T done"
 elif [ "$MODE" = "sq_global" ]; then
   # the global step's kernels under the SQ counter groups (what bounds field_bwd_dx_x3_kernel<2, 3> and wgrad_x3_layers_kernel)
   cd /tmp

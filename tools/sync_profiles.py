@@ -1,20 +1,26 @@
 """Copy the summaries of a tools/rNN_profiles.sh run (gpurun_out/rNNp: modes traces + pmc) into profiles/rNN_* and refresh profiles/pmc_traffic.json
     python tools/sync_profiles.py gpurun_out/r05p r05
+    python tools/sync_profiles.py gpurun_out/r06p r06 render     after a change to the inference kernel / x3_device.h that leaves the training kernels' code as it
+                                                                was (modes render_traces + pmc_render + busy): the bench record, the render traces and counters, and
+                                                                the decoder kernels' matrix-pipe occupancy passes (their own table, profiles/rNN_pmc_{focal,global}_busy_per_kernel.csv;
+                                                                the focal / global traces and traffic tables of the full run stay)
 (what bench.py reads for roofline.traffic / request_rate / mfma_busy_frac; the hashes of the kernel sources the counters were
 collected on are recorded beside them, and bench.py reports none of it for other sources)."""
 import csv, glob, hashlib, json, os, shutil, subprocess, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r05p"
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
 PREV = "r%02d" % (int(TAG[1:]) - 1)
+PARTIAL = len(sys.argv) > 3 and sys.argv[3] == "render"
 py = sys.executable
-for t in ("focal_graph", "global_graph"):
+for t in (() if PARTIAL else ("focal_graph", "global_graph")):
     subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_{t}", f"profiles/{TAG}_{t}_kernel_stats.csv"])
     shutil.copy(f"{R}/{t}_under_rocprof.json", f"profiles/{TAG}_{t}_bench_under_rocprof.json")
 subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_render", f"profiles/{TAG}_render_kernel_stats.csv"])
 shutil.copy(f"{R}/render_under_rocprof.json", f"profiles/{TAG}_render_bench_under_rocprof.json")
-subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_focal", f"profiles/{TAG}_plugin_focal_kernel_stats.csv"])
-shutil.copy(f"{R}/plugin_focal_under_rocprof.txt", f"profiles/{TAG}_plugin_focal_under_rocprof.txt")
-if os.path.exists(f"{R}/kt_plugin_trained"):  # the focal iteration on the scene trained through the plugin surface (the last 300 ms of the run: per step)
+if not PARTIAL:
+    subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_focal", f"profiles/{TAG}_plugin_focal_kernel_stats.csv"])
+    shutil.copy(f"{R}/plugin_focal_under_rocprof.txt", f"profiles/{TAG}_plugin_focal_under_rocprof.txt")
+if not PARTIAL and os.path.exists(f"{R}/kt_plugin_trained"):  # the focal iteration on the scene trained through the plugin surface (the last 300 ms of the run: per step)
     subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_plugin_trained", f"profiles/{TAG}_plugin_trained_kernel_stats.csv"])
     shutil.copy(f"{R}/plugin_trained_under_rocprof.txt", f"profiles/{TAG}_plugin_trained_under_rocprof.txt")
     shutil.copy(f"{R}/plugin_trained_window.txt", f"profiles/{TAG}_plugin_trained_window.txt")
@@ -22,8 +28,12 @@ if os.path.exists(f"{R}/kt_plugin_trained"):  # the focal iteration on the scene
         shutil.copy(f"{R}/plugin_trained_timeline.txt", f"profiles/{TAG}_plugin_trained_timeline.txt")
 shutil.copy(f"{R}/bench.json", f"profiles/{TAG}_bench.json")
 shutil.copy(f"{R}/bench_details.json", f"profiles/{TAG}_bench_details.json")
-subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_*/")))
-subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_global_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_global_*/")))
+if PARTIAL:  # (the occupancy passes alone, into their own tables)
+    subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_busy_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_SQ_VALU_MFMA_BUSY*/")))
+    subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_global_busy_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_global_SQ_VALU_MFMA_BUSY*/")))
+else:
+    subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_focal_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_focal_*/")))
+    subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_global_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_global_*/")))
 subprocess.check_call([py, "tools/prof_summary.py", "stats", f"{R}/kt_render_eager", f"profiles/{TAG}_render_eager_kernel_stats.csv"])
 shutil.copy(f"{R}/render_eager_under_rocprof.json", f"profiles/{TAG}_render_eager_bench_under_rocprof.json")
 subprocess.check_call([py, "tools/prof_summary.py", "pmc_many", f"profiles/{TAG}_pmc_render_per_kernel.csv"] + sorted(glob.glob(f"{R}/pmc_render_*/")))
@@ -37,6 +47,7 @@ if PREV not in old:  # the previous round's figures move under their key
     j[PREV] = {k: v for k, v in old.items() if k not in rounds + ["gather_request_ceiling_per_s", "l2_gather_ceiling_per_s"]}
 load = lambda pp: {r["kernel"]: r for r in csv.DictReader(open(pp))}
 f, g = load(f"profiles/{TAG}_pmc_focal_per_kernel.csv"), load(f"profiles/{TAG}_pmc_global_per_kernel.csv")
+fb, gb = (load(f"profiles/{TAG}_pmc_focal_busy_per_kernel.csv"), load(f"profiles/{TAG}_pmc_global_busy_per_kernel.csv")) if PARTIAL else (f, g)
 tr = lambda r: int(round((2 * float(r["FETCH_SIZE_mean"]) + float(r["WRITE_SIZE_mean"])) * 1024))
 def one(d, sub):
     ks = [k for k in d if sub in k]
@@ -70,11 +81,16 @@ for key, d, sub in (("bwd_scatter:focal", f, "field_bwd_dx"), ("grad_reduce:foca
 glm = [r for k, r in g.items() if "lm_lookup" in k]
 if glm:
     j["lm_lookup:global"] = j["hash_fwd:global"] = sum(tr(r) for r in glm) // len(glm)
-j["mfma_busy:field_fwd:focal"] = busy(one(f, "field_fwd_x3"))
-j["mfma_busy:bwd_scatter:focal"] = busy(one(f, "field_bwd_dx"))
-j["mfma_busy:field_fwd:global"] = busy(one(g, "field_fwd_x3"))
-j["mfma_busy:bwd_scatter:global"] = busy(one(g, "field_bwd_dx"))
-j["mfma_busy:wgrad:global"] = busy(one(g, "wgrad_x3_layers"))
+j["mfma_busy:field_fwd:focal"] = busy(one(fb, "field_fwd_x3"))
+j["mfma_busy:bwd_scatter:focal"] = busy(one(fb, "field_bwd_dx"))
+j["mfma_busy:field_fwd:global"] = busy(one(gb, "field_fwd_x3"))
+j["mfma_busy:bwd_scatter:global"] = busy(one(gb, "field_bwd_dx"))
+j["mfma_busy:wgrad:global"] = busy(one(gb, "wgrad_x3_layers"))
+if PARTIAL:
+    j["_note_partial"] = ("the traffic figures of the focal / global steps' kernels are the full run's (" + TAG + "_pmc_{focal,global}_per_kernel.csv: lm_lookup.hip, hash_device.h, grad_part.hip, "
+                          "render.hip unchanged since); after csrc/x3_device.h changed (inference-only template parameters: the training kernels' code objects are the same "
+                          "instructions, checked by disassembly) the decoder kernels' matrix-pipe occupancy was measured again (" + TAG + "_pmc_{focal,global}_busy_per_kernel.csv) "
+                          "and the inference kernel's traces and counters collected anew (" + TAG + "_render_*, " + TAG + "_pmc_render_per_kernel.csv)")
 # the inference kernel (one eager launch per 138,240-ray tile): matrix / vector pipe occupancy, what it decodes, its duration
 rd = load(f"profiles/{TAG}_pmc_render_per_kernel.csv")
 rk = one(rd, "fused_render_patch_kernel")
