@@ -632,7 +632,7 @@ static int fused_render_launch(FusedArgs& A, const char* who, int64_t n_rays, co
   }
   static const int levels = [] { const char* e = getenv("GFN_RENDER_LEVELS"); return (e && atoi(e) == 4) ? 4 : 2; }();
   // The layers of the decoder whose activation operand is one f16 number (x3_device.h X2_*): gfn_launch_opts.colour_x2 asks for the colour head's layer 2
-  // (128 -> 128: half of the decoder's MFMAs; measured, tools/README.md round 6: 8 % of the frame time for <= 9e-5 on trained frames, where layers 2 AND 3 cost
+  // (128 -> 128: half of the decoder's MFMAs; measured, tools/README.md round 6: 7-8 % of the frame time for 5.5e-5 ... 1.3e-4 on trained frames, where layers 2 AND 3 cost
   // twice the distance for 2 % more); GFN_RENDER_X2=<mask> overrides it (a measurement, read per call: tools/exp_render_x2.py renders ONE engine every way in one process).  The
   // forms exist for the tile renderer's instantiation (PLAIN) only: other launches run the x3 form whatever is asked
   const char* x2_env = getenv("GFN_RENDER_X2");

@@ -191,11 +191,14 @@ __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned lo
                       // tile alive at once the compiler spilled SGPRs through v_writelane / v_readlane (724 of the forward kernel's
                       // ~2,700 vector instructions per tile).  Here every compare lands in VCC and is shifted into `bits` by the
                       // next instruction (bits = 2 * bits + carry), registers 15 .. 0 so that bit r ends up as register r's.
+  // X2 without planes (inference): the ReLU is taken on the rounded pair instead -- max(rne(v), 0) = rne(max(v, 0)), rounding is monotone and keeps the sign --
+  // one v_pk_max_f16 per pair in place of two v_max_f32 (NaN -> 0 either way)
+  constexpr bool RELU_PACKED = RELU && X2 && !RNE;
 #pragma unroll
   for (int r = 15; r >= 0; r--) {
     if (RELU) {
       asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v[r]) : "vcc");  // not volatile: dropped where nobody reads the masks (inference)
-      v[r] = fmaxf(v[r], 0.f);  // = v > 0 ? v : 0 (NaN -> 0 either way)
+      if (!RELU_PACKED) v[r] = fmaxf(v[r], 0.f);  // = v > 0 ? v : 0 (NaN -> 0 either way)
     }
   }
   if (RELU) mask |= (unsigned long long)bits << (t * 16);
@@ -205,7 +208,13 @@ __device__ __forceinline__ void tile_to_frag(const Acc2& a, Frag& f, unsigned lo
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       uint32_t a_, b_;
-      if (X2) { a_ = rne2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1]); b_ = 0u; }
+      if (X2) {
+        a_ = rne2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1]); b_ = 0u;
+        if (RELU_PACKED) {
+          using h2 = __attribute__((ext_vector_type(2))) _Float16;
+          a_ = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, a_), h2{(_Float16)0, (_Float16)0}));
+        }
+      }
       else split2(v[8 * s + 2 * p], v[8 * s + 2 * p + 1], a_, b_);
       f.hi[s][p] = a_; f.lo[s][p] = b_;
     }

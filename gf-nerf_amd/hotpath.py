@@ -59,7 +59,7 @@ class HotPathConfig:
                                      # (gfn_fused_render); 0 = a wave per ray like the training forward
     render_colour_x2: bool = True    # inference (TileRenderer): the colour head's layer 2 (128 -> 128) with a one-f16 activation operand (ops.launch_opts(colour_x2=True):
                                      # two MFMAs per product instead of three; density, accumulation and depth unchanged bit for bit, rgb by that layer's f16
-                                     # rounding -- DESIGN.md section 4 has the measured distance (<= 1e-4 on full-HD frames of trained scenes, 2.3e-4 the
+                                     # rounding -- DESIGN.md section 4 has the measured distance (5.5e-5 ... 1.3e-4 at the worst pixel of full-HD frames of trained scenes, 2.1e-4 the
                                      # worst case met: north_star's bar is 1e-3) and time (-8 %); False: the x3 form throughout
     graph_forward: bool = True       # callers that hand forward_train_graphed static sample buffers (the plugin surface) get the forward as one
                                      # hipGraph replay per (stage, block, buffer) after three eager runs: ~25 launches less for the host

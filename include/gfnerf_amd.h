@@ -92,7 +92,7 @@ int gfn_version(void);
  *                 split pair hi + lo' -- two MFMAs per product sum instead of three and no lo' half to make (csrc/x3_device.h X2_H1).
  *                 Everything the DENSITY depends on (hash features, base network, head layer 1's geo input) keeps the split-f16 x3
  *                 form: sigma, accumulation, depth and every ray's termination point are the same bits either way; rgb moves by
- *                 that layer's f16 rounding (measured: DESIGN.md section 4; <= 1e-4 on full-HD frames of trained scenes).  Other
+ *                 that layer's f16 rounding (measured: DESIGN.md section 4; 5.5e-5 ... 1.3e-4 at the worst pixel of full-HD frames of trained scenes).  Other
  *                 forms of the launch ignore it.  GFN_RENDER_X2=<layer mask> in the environment (read per call; a measurement,
  *                 tools/exp_render_x2.py) overrides it; 0 there forces the x3 form. */
 #define GFN_MERGE_OFF 0
