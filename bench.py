@@ -1186,12 +1186,14 @@ def compact_line(out):
 
     hoist("global_stage", (("ms_per_step", "global_ms_per_step"), ("value", "global_rays_per_sec"), ("launch_short", "global_launch"),
                            ("replicas_bit_identical", "replicas_bit_identical"), ("wgrad_operands", "global_wgrad_operands"), ("x3_ms_per_step", "global_x3_ms_per_step")))
+    if "global_wgrad_operands" in cfg:
+        cfg["global_wgrad_operands"] = str(cfg["global_wgrad_operands"]).split(" (")[0]  # ("f16 rne+dither": which plane keeps its lo' half is in [bench-details])
     if out.get("n_gpus", 1) == 1:
         cfg.pop("global_launch", None)  # (the N > 1 line says whether the data-parallel step replays graph segments; at N = 1 it is "graph" like the headline)
     hoist("render", (("value", "render_ms_per_mpix"), ("x3_ms_per_mpix", "render_x3_ms_per_mpix")))
     if isinstance(out.get("render"), dict) and isinstance(out["render"].get("colour_x2_vs_x3"), dict):
-        cfg["render_decoder"] = "x3 + colour_x2 (head layer 2: one f16 activation operand)"
-        cfg["render_colour_x2_max_abs_rgb"] = _r(out["render"]["colour_x2_vs_x3"]["max_abs_rgb"])
+        cfg["render_decoder"] = "x3+colour_x2"  # (the colour head's layer 2 on one f16 activation operand: gfn_launch_opts.colour_x2, the tile renderer's default)
+        cfg["render_x2_max_drgb"] = _r(out["render"]["colour_x2_vs_x3"]["max_abs_rgb"])  # max |rgb - rgb of the x3 form| over the last frame
     if isinstance(out.get("render"), dict) and isinstance(out["render"].get("roofline"), dict):
         rr = out["render"]["roofline"]
         if rr.get("mfma_busy_frac") is not None:
@@ -1207,7 +1209,7 @@ def compact_line(out):
                             ("evaluated_sample_frac", "trained_evaluated_sample_frac"), ("two_phase_K", "trained_two_phase_K"),
                             ("roofline_frac", "trained_roofline_frac"), ("global_ms_per_step", "trained_global_ms_per_step"),
                             ("render_ms_per_mpix", "trained_render_ms_per_mpix"), ("render_evaluated_frac", "trained_render_evaluated_frac"),
-                            ("render_x3_ms_per_mpix", "trained_render_x3_ms_per_mpix"), ("render_colour_x2_max_abs_rgb", "trained_render_colour_x2_max_abs_rgb")))
+                            ("render_x3_ms_per_mpix", "trained_render_x3_ms_per_mpix"), ("render_colour_x2_max_abs_rgb", "trained_render_x2_max_drgb")))
     hoist("cpu_reference_field", (("train_rays_per_sec", "cpu_torch_field_rays_per_sec"),))
     for k in ("mfma_busy_frac",):
         if out["roofline"].get(k) is not None:
@@ -1224,8 +1226,9 @@ def compact_line(out):
     ro["kernel"] = str(ro.get("kernel", "")).split(" (")[0]
     # the driver keeps the tail of the log: the line must stay under 2,000 characters whatever sub-records ran (everything is in [bench-details])
     for k in ("cpu_torch_field_rays_per_sec", "batch_assembly_ms", "rays_per_batch", "loss", "global_rays_per_sec", "n_tree_nodes", "log2_table_size",
-              "trained_roofline_frac", "psnr_decoder_delta", "plugin_global_ms_per_step", "trained_two_phase_K"):
-        if len(json.dumps(line)) <= 1950:
+              "trained_roofline_frac", "psnr_decoder_delta", "render_x2_max_drgb", "trained_two_phase_K", "trained_alive_sample_frac",
+              "render_x3_ms_per_mpix", "trained_render_evaluated_frac", "trained_evaluated_sample_frac", "plugin_global_ms_per_step"):
+        if len(json.dumps(line)) <= 1985:
             break
         cfg.pop(k, None)
     return line

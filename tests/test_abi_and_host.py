@@ -226,13 +226,15 @@ def test_bench_line_stays_under_two_thousand_characters():
                            parallelism="single GPU", two_phase=dict(K=130), allreduce_selfcheck=None),
                roofline=dict(bound="hbm", kernel="lm_lookup_kernel<true, false> (+ <true, true>: the second table accumulates)", achieved=1242.01234, peak=8000.0, unit="GB/s",
                              frac=0.1552512, traffic=1033260646, avg_kernel_ms=0.2828112, alg_bytes_per_launch=351253980, launches_per_step=2, mfma_busy_frac=0.3612),
-               global_stage=dict(ms_per_step=1.926412, value=f, launch_short="graph", replicas_bit_identical=None),
-               render=dict(value=51.655123, roofline=dict(samples_per_sec=f * 1000, mfma_busy_frac=0.3039)),
+               global_stage=dict(ms_per_step=1.926412, value=f, launch_short="graph", replicas_bit_identical=None, wgrad_operands="f16 rne+dither (dza1 hi + lo')", x3_ms_per_step=2.002512),
+               render=dict(value=51.655123, roofline=dict(samples_per_sec=f * 1000, mfma_busy_frac=0.3039), x3_ms_per_mpix=55.123456,
+                           colour_x2_vs_x3=dict(max_abs_rgb=4.1127e-06, accumulation_and_depth_same_bits=True)),
                plugin_step_focal=dict(value=f, ms_per_step=1.817712), plugin_step_global=dict(value=f, ms_per_step=2.028512), batch_assembly=dict(ms_per_batch=0.1041123),
                psnr=dict(psnr_fast=33.668123, psnr_reference=33.565123, delta=0.1026612, se=0.1582212, n_seeds=3, decoder_delta=1.2716e-06, study_delta=0.012345, study_se=0.048712,
                          study_n_seeds=148),
                trained_state=dict(value=f, ms_per_step=1.583012, alive_sample_frac=0.8626212, evaluated_sample_frac=1.0, two_phase_K=1024, roofline_frac=0.2323312,
-                                  global_ms_per_step=1.782412, global_rays_per_sec=f, render_ms_per_mpix=35.123456, render_evaluated_frac=0.912345),
+                                  global_ms_per_step=1.782412, global_rays_per_sec=f, render_ms_per_mpix=35.123456, render_evaluated_frac=0.912345,
+                                  render_x3_ms_per_mpix=38.123456, render_colour_x2_max_abs_rgb=0.00016761),
                plugin_step_trained=dict(value=f, ms_per_step=1.712345), rays8192=dict(value=f * 1.5, global_rays_per_sec=f * 1.4, ms_per_step=2.1),
                cpu_reference_field=dict(train_rays_per_sec=4227.212), cpu_baseline=dict(value=712.0812, unit="rays/s", cores=256, kind="port",
                                                                                         sample="2048 rays (392816 samples) of the same batch, oracle fwd+bwd (no Adam), 2.9 s; all stages OpenMP"))
@@ -244,7 +246,8 @@ def test_bench_line_stays_under_two_thousand_characters():
     c = line["config"]
     for key in ("workload", "trained_rays_per_sec", "trained_ms_per_step", "psnr", "psnr_reference", "psnr_delta", "psnr_se", "psnr_n_seeds", "psnr_study_delta", "psnr_study_se",
                 "psnr_study_n_seeds", "render_ms_per_mpix", "global_ms_per_step", "plugin_ms_per_step", "trained_render_ms_per_mpix", "plugin_trained_ms_per_step",
-                "rays8192_rays_per_sec", "rays8192_global_rays_per_sec"):
+                "rays8192_rays_per_sec", "rays8192_global_rays_per_sec", "render_decoder", "trained_render_x3_ms_per_mpix", "trained_render_x2_max_drgb",
+                "global_x3_ms_per_step", "global_wgrad_operands", "plugin_global_ms_per_step"):
         assert key in c, key
     assert line["roofline"]["kernel"] == "lm_lookup_kernel<true, false>" and set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
