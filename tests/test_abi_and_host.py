@@ -302,3 +302,25 @@ def test_profile_summaries_take_the_newest_run_of_a_merged_directory(tmp_path):
     lines = [ln.split() for ln in res.splitlines()[1:]]
     got = {ln[-1]: float(ln[0]) for ln in lines}
     assert abs(got["step_marker"] - 0.05) < 1e-9 and abs(got["other"] - 0.03) < 1e-9, res
+
+
+def test_committed_counters_belong_to_the_kernel_sources_in_the_tree():
+    """bench.py reports roofline.traffic, request_rate, mfma_busy_frac and the inference kernel's occupancy from profiles/pmc_traffic.json ONLY while the
+    sha256 of the kernel sources recorded with the counters equals the tree's (a number measured on another kernel is not reported at all).  The committed
+    file must therefore be the committed sources': an edit to csrc/lm_lookup.hip, field_x3.hip, fused_fwd.hip, x3_device.h or hash_device.h after the last
+    counter run would silently drop those fields from the driver's bench line -- this fails instead, and says which passes to run again
+    (tools/r06_profiles.sh pmc | pmc_render | busy, then tools/sync_profiles.py)."""
+    import hashlib
+    import json
+
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    groups = pmc["source_sha256"]
+    assert set(groups) == {"lm_lookup", "decoder", "render"}
+    for group, files in groups.items():
+        for rel, want in files.items():
+            got = hashlib.sha256(open(os.path.join(ROOT, "gf-nerf_amd", rel), "rb").read()).hexdigest()
+            assert got == want, f"profiles/pmc_traffic.json [{group}] was collected on another {rel}: run the counter passes again"
+    # and the figures the line takes from it are there
+    for key in ("lm_lookup:focal", "mfma_busy:field_fwd:focal", "mfma_busy:render", "valu_busy:render", "kernel_ms:render", "tile_rays:render", "mfma_per_tile:render"):
+        assert pmc.get(key) is not None, key
+    assert pmc["mfma_per_tile:render"] == 160.0  # the renderer's default decoder form (colour_x2): head layer 2 issues 64 MFMAs instead of 96
