@@ -19,7 +19,16 @@
  *
  * Floating point: built with -ffp-contract=off; every multi-term sum spells out
  * its association (Eigen 3.4 redux_novec_unroller halving tree for the fixed
- * size products the reference evaluates through Eigen).
+ * size products the reference evaluates through Eigen).  One thing this cannot
+ * settle: the reference's device code is built with nvcc's default -fmad=true
+ * (gfnerf/bindings/setup.py:103-121 passes no -fmad), which lets the compiler
+ * fuse a * b + c of the .cu files into FMAs -- which ones it fuses is a property
+ * of the reference's binary that nothing here can observe.  The restatement (and
+ * the HIP product, bit for bit with it) rounds every product.  For K1's 8-term
+ * blend (Hash3DAnchored_cuda.cu:73-77) a fused chain differs only where the f32
+ * sum lies within an ulp of a rounding boundary of the f16 the result is cast to;
+ * K4's warp arithmetic is pinned by the reference's PyTorch statement
+ * (gfnerf/persoctree.py), which fuses nothing.  Part of "parity unpinned" above.
  */
 #ifndef GFN_ORACLE_H
 #define GFN_ORACLE_H
